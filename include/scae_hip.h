@@ -1,0 +1,254 @@
+/*
+ * scae_hip.h -- C ABI of libscae_hip.so: the MI355X (gfx950) kernels of the
+ * SCAE forward/backward hot path.
+ *
+ * Drop-in boundary.  The reference (bdsaglam/torch-scae) has no FFI of its
+ * own -- every op on the path is a stock ATen call made from Python
+ * (SURVEY.md section 8b).  The entry points below are therefore what a
+ * maintainer of the reference would bind (ctypes / cffi stub in
+ * INTEGRATION.md) to replace each ATen op cluster, one launcher per cluster,
+ * each citing the reference lines it replaces (paths relative to the
+ * reference checkout).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch types, no exceptions, no
+ *     allocation, no global state, no implicit synchronisation;
+ *   - every pointer is a DEVICE pointer to densely packed (contiguous,
+ *     row-major, last index fastest) float32 unless stated otherwise; the
+ *     caller owns every buffer, including the "saved"/"partial" workspaces;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it
+ *     and the call returns immediately (safe under hipGraph capture);
+ *   - launchers are re-entrant (autograd calls the *_bwd ones from its own
+ *     worker thread);
+ *   - return value: 0 on success, SCAE_ERR_* (negative) for rejected
+ *     arguments, otherwise the positive hipError_t of the failed launch;
+ *   - pointers documented "nullable" select a mode of the reference op.
+ */
+#ifndef SCAE_HIP_H
+#define SCAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCAE_ABI_VERSION 1
+
+#define SCAE_OK 0
+#define SCAE_ERR_BAD_ARG (-1)      /* null pointer / non-positive size     */
+#define SCAE_ERR_UNSUPPORTED (-2)  /* shape outside the kernels' limits    */
+
+/* limits of this build (checked by the launchers) */
+#define SCAE_MAX_CHANNELS 4        /* image channels C                     */
+#define SCAE_ATTN_MAX_SET 64       /* queries N and keys M per attention   */
+#define SCAE_RENDER_MAX_TEMPLATE_ELEMS 4096 /* C*th*tw + th*tw per template */
+
+int scae_abi_version(void);
+const char *scae_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * K5  geometric_transform            replaces cv_ops.py:20-76
+ *   pose (n,6) -> out (n,6), or (n,9) when as_matrix (third row 0,0,1).
+ *   similarity / nonlinear / as_matrix: the reference's three flags.
+ * ---------------------------------------------------------------------- */
+int scae_geometric_transform_fwd_f32(const float *pose, float *out, int64_t n,
+                                     int similarity, int nonlinear,
+                                     int as_matrix, void *stream);
+/* gout has the forward's output layout; gpose (n,6). */
+int scae_geometric_transform_bwd_f32(const float *pose, const float *gout,
+                                     float *gpose, int64_t n, int similarity,
+                                     int nonlinear, int as_matrix,
+                                     void *stream);
+
+/* ------------------------------------------------------------------------
+ * K2  qkv_attention                  replaces set_transformer.py:24-47
+ *   q (HB,N,dk)  k (HB,M,dk)  v (HB,M,dv)  presence (HB,M) nullable
+ *   out (HB,N,dv);  probs (HB,N,M) = softmax((q k^T - (1-presence) 1e32) /
+ *   sqrt_dk) is written for the backward pass.  QK^T and PV run on the fp32
+ *   MFMA (v_mfma_f32_16x16x4_f32).  N, M <= SCAE_ATTN_MAX_SET.
+ *   sqrt_dk: the divisor, float(np.sqrt(dk)) in the reference (:43).
+ * ---------------------------------------------------------------------- */
+int scae_qkv_attention_fwd_f32(const float *q, const float *k, const float *v,
+                               const float *presence, float *out, float *probs,
+                               int HB, int N, int M, int dk, int dv,
+                               float sqrt_dk, void *stream);
+/* gq (HB,N,dk) gk (HB,M,dk) gv (HB,M,dv); gpresence (HB,M) nullable. */
+int scae_qkv_attention_bwd_f32(const float *q, const float *k, const float *v,
+                               const float *probs, const float *gout,
+                               float *gq, float *gk, float *gv,
+                               float *gpresence, int HB, int N, int M, int dk,
+                               int dv, float sqrt_dk, void *stream);
+
+/* ------------------------------------------------------------------------
+ * K3  capsule votes                  replaces object_decoder.py:160-225
+ *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
+ *   all_param (B,O,A), A = 6V+6+1+2V, the output of the per-capsule MLPs,
+ *     split as [cpr_dynamic 6V | cvr 6 | caps logit 1 | vote logit V |
+ *     scale V] (:160-162).
+ *   cpr_static (O,V,6); bias_cvr (O,6); bias_caps (O); bias_vote (O,V);
+ *   bias_scale (O,V)  (caps_bias_list, :108-111).
+ *   noise_caps (B,O) / noise_vote (B,O,V): U[0,1) draws, nullable (no noise);
+ *     the kernel adds (u-0.5)*noise_scale (:201).
+ *   outputs: vote (B,O,V,6) = top two rows of OVR x OPR (:189-191, :413),
+ *     scale (B,O,V) (:225), vote_presence (B,O,V) (:217-219),
+ *     logit_caps (B,O), logit_vote (B,O,V) (noised logits, :211-212),
+ *     reg_partial (B,O): per-(b,o) sum of cpr_dynamic^2 (caller: sum/2/B,
+ *     :170).
+ * ---------------------------------------------------------------------- */
+int scae_capsule_votes_fwd_f32(const float *all_param, const float *cpr_static,
+                               const float *bias_cvr, const float *bias_caps,
+                               const float *bias_vote, const float *bias_scale,
+                               const float *noise_caps, const float *noise_vote,
+                               float noise_scale, float *vote, float *scale,
+                               float *vote_presence, float *logit_caps,
+                               float *logit_vote, float *reg_partial, int B,
+                               int O, int V, int similarity,
+                               int learn_vote_scale, int allow_deformations,
+                               void *stream);
+/* incoming grads (all nullable = zero): gvote (B,O,V,6) gscale (B,O,V)
+ * gvote_presence (B,O,V) glogit_caps (B,O) glogit_vote (B,O,V);
+ * greg: d loss / d cpr_dynamic_reg_loss, a DEVICE scalar, nullable.
+ * outputs: gall_param (B,O,A); gcpr_in (B,O,V,6) = grad wrt
+ * (cpr_dynamic + cpr_static) (caller sums over B for cpr_static; the bias
+ * grads are the batch sums of the matching gall_param slices). */
+int scae_capsule_votes_bwd_f32(const float *all_param, const float *cpr_static,
+                               const float *bias_cvr, const float *bias_caps,
+                               const float *bias_vote, const float *bias_scale,
+                               const float *noise_caps, const float *noise_vote,
+                               float noise_scale, const float *gvote,
+                               const float *gscale, const float *gvote_presence,
+                               const float *glogit_caps,
+                               const float *glogit_vote, const float *greg,
+                               float *gall_param, float *gcpr_in, int B, int O,
+                               int V, int similarity, int learn_vote_scale,
+                               int allow_deformations, void *stream);
+
+/* ------------------------------------------------------------------------
+ * K4  capsule likelihood             replaces object_decoder.py:257-372
+ *   vote (B,O,M,6) scale (B,O,M) vote_presence (B,O,M) dummy_vote (M,6)
+ *   x (B,M,6) presence (B,M) nullable
+ *   outputs: log_prob_per_point (B,M) (:296-300; caller: sum/B -> log_prob),
+ *     vote_presence_binary (B,O,M), winner (B,M,6), winner_presence (B,M),
+ *     winner_idx (B,M) int64 (:310), is_from_capsule (B,M) int64 (:334),
+ *     soft_winner (B,M,6), soft_winner_presence (B,M),
+ *     posterior (B,O+1,M) (softmax of :338 incl. the dummy row),
+ *     mixing_log_prob (B,O+1,M), mixing_logit (B,O+1,M).
+ * ---------------------------------------------------------------------- */
+int scae_capsule_likelihood_fwd_f32(
+    const float *vote, const float *scale, const float *vote_presence,
+    const float *dummy_vote, const float *x, const float *presence,
+    float *log_prob_per_point, float *vote_presence_binary, float *winner,
+    float *winner_presence, int64_t *winner_idx, int64_t *is_from_capsule,
+    float *soft_winner, float *soft_winner_presence, float *posterior,
+    float *mixing_log_prob, float *mixing_logit, int B, int O, int M,
+    void *stream);
+/* incoming grads, each nullable: g_lpp (B,M), g_winner (B,M,6),
+ * g_winner_presence (B,M), g_soft_winner (B,M,6), g_soft_winner_presence
+ * (B,M), g_posterior (B,O+1,M), g_mixing_log_prob (B,O+1,M), g_mixing_logit
+ * (B,O+1,M).  outputs: gvote, gscale, gvote_presence, gx (B,M,6),
+ * gpresence (B,M) (nullable), gdummy_partial (B,M,6) (caller sums over B). */
+int scae_capsule_likelihood_bwd_f32(
+    const float *vote, const float *scale, const float *vote_presence,
+    const float *dummy_vote, const float *x, const float *presence,
+    const float *posterior, const int64_t *winner_idx, const float *g_lpp,
+    const float *g_winner, const float *g_winner_presence,
+    const float *g_soft_winner, const float *g_soft_winner_presence,
+    const float *g_posterior, const float *g_mixing_log_prob,
+    const float *g_mixing_logit, float *gvote, float *gscale,
+    float *gvote_presence, float *gx, float *gpresence, float *gdummy_partial,
+    int B, int O, int M, void *stream);
+
+/* ------------------------------------------------------------------------
+ * K1  template render + Gaussian-mixture image likelihood
+ *     replaces part_decoder.py:174-237 (affine_grid + 2x grid_sample +
+ *     background + presence), distributions.py:34-47 (mixture log_prob) and
+ *     the rec term of stacked_capsule_auto_encoder.py:220.
+ *
+ * Decoder description shared by the K1 entry points:
+ *   templates (B,M,C,th,tw); pose (B,M,6) = row-major 2x3 affine;
+ *   presence (B,M) nullable;
+ *   templates_alpha (M,th,tw) -- non-null selects the alpha-channel mode
+ *     (mixing logits have ONE channel, Cm = 1), null selects the temperature
+ *     mode (logits = transformed/temperature, Cm = C) and then
+ *     temperature_logit (1) must be given;
+ *   bg_image (B,C,H,W) nullable; when null bg_value (1) must be given;
+ *   bg_mixing_logit (1) (alpha mode only);
+ *   out_scale (1) nullable: sigma = softplus(out_scale)+1e-4, else sigma = 1.
+ *   K = M+1 mixture components, the last one is the background.
+ * ---------------------------------------------------------------------- */
+typedef struct scae_decoder_desc {
+  const float *templates;
+  const float *templates_alpha;
+  const float *pose;
+  const float *presence;
+  const float *bg_image;
+  const float *bg_value;
+  const float *bg_mixing_logit;
+  const float *temperature_logit;
+  const float *out_scale;
+  int B, M, C, th, tw, H, W;
+} scae_decoder_desc;
+
+/* materialise transformed_templates (B,K,C,H,W) and mixing_logits
+ * (B,K,Cm,H,W): part_decoder.py:174-231. */
+int scae_template_render_fwd_f32(const scae_decoder_desc *d,
+                                 float *transformed_templates,
+                                 float *mixing_logits, void *stream);
+
+/* fused path: log_prob (B,C,H,W) of image x (B,C,H,W) under the mixture,
+ * straight from the compact decoder inputs (nothing (B,K,..)-sized touches
+ * HBM).  lse_post (B,C,H,W) and lse_prior (B,Cm,H,W) are saved for the
+ * backward pass; log_prob = lse_post - lse_prior. */
+int scae_render_gmm_logprob_fwd_f32(const scae_decoder_desc *d, const float *x,
+                                    float *log_prob, float *lse_post,
+                                    float *lse_prior, void *stream);
+
+/* backward of either path.
+ *   fused (g_tt == NULL): g_logprob (B,C,H,W) with x / lse_post / lse_prior of
+ *     the forward;
+ *   materialised (g_tt != NULL): g_tt (B,K,C,H,W), g_ml (B,K,Cm,H,W) (either
+ *     may be NULL = zero, not both) -- x, lse_*, g_logprob ignored.
+ * outputs: g_templates (B,M,C,th,tw), g_alpha_partial (B,M,th,tw) (alpha mode;
+ *   caller sums over B), g_pose (B,M,6), g_presence (B,M) (nullable),
+ *   g_bg_image (B,C,H,W) (nullable),
+ *   g_scalar_partial (B,K,4): per-(b,k) partial grads of [bg_value,
+ *   bg_mixing_logit, temperature_logit, out_scale] with the sigmoid/softplus
+ *   chain already applied (caller sums over (B,K)). */
+int scae_render_gmm_bwd_f32(const scae_decoder_desc *d, const float *x,
+                            const float *lse_post, const float *lse_prior,
+                            const float *g_logprob, const float *g_tt,
+                            const float *g_ml, float *g_templates,
+                            float *g_alpha_partial, float *g_pose,
+                            float *g_presence, float *g_bg_image,
+                            float *g_scalar_partial, void *stream);
+
+/* generic mixture over materialised tensors: distributions.py:34-47.
+ *   loc (B,K,C,P), mixing_logits (B,K,Cm,P) with Cm in {1,C}, sigma (1) device
+ *   scalar (the Normal's scale), x (B,C,P) -> log_prob (B,C,P). */
+int scae_gmm_log_prob_fwd_f32(const float *loc, const float *mixing_logits,
+                              const float *sigma, const float *x,
+                              float *log_prob, int B, int K, int C, int Cm,
+                              int64_t P, void *stream);
+/* g_loc (B,K,C,P), g_ml (B,K,Cm,P), g_sigma_partial (B) (caller sums),
+ * g_x (B,C,P) nullable. */
+int scae_gmm_log_prob_bwd_f32(const float *loc, const float *mixing_logits,
+                              const float *sigma, const float *x,
+                              const float *g_logprob, float *g_loc,
+                              float *g_ml, float *g_sigma_partial, float *g_x,
+                              int B, int K, int C, int Cm, int64_t P,
+                              void *stream);
+/* mean (distributions.py:37-39) and mode (:50-77, one-hot argmax over K of
+ * log_softmax(logits) [+ component log-prob at its own mean when `maximum`])
+ * -> out (B,C,P).  mode: Cm == 1 with C > 1 and maximum is rejected like the
+ * reference (its in-place add cannot broadcast). */
+int scae_gmm_mean_f32(const float *loc, const float *mixing_logits, float *out,
+                      int B, int K, int C, int Cm, int64_t P, void *stream);
+int scae_gmm_mode_f32(const float *loc, const float *mixing_logits,
+                      const float *sigma, float *out, int maximum, int B,
+                      int K, int C, int Cm, int64_t P, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCAE_HIP_H */

@@ -1,0 +1,163 @@
+"""GPU parity of the whole drop-in: SCAE built by torch_scae_amd.factory,
+loaded with the golden parameters, against (a) the vectors captured from the
+reference and (b) the CPU oracle at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scae_oracle as O
+from tests.golden_util import assert_close, load, model_names, sub
+
+pytestmark = pytest.mark.gpu
+
+
+def run_model(cfg, params, image, label, noise, train):
+    from torch_scae_amd import factory, nn_utils
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(cfg)
+    model.load_state_dict(params)
+    model = model.cuda().train(train)
+    with nn_utils.fixed_noise(noise):
+        res = model(image.cuda())
+    loss, log = model.loss(res, image.cuda(), label.cuda())
+    return model, res, loss, log
+
+
+@pytest.mark.parametrize("name", model_names())
+def test_scae_vs_golden(name):
+    from torch_scae_amd import nn_ext
+    blob, meta = load(name)
+    noise = sub(blob, "noise/")
+    noise = [noise[k] for k in sorted(noise)]
+    image, label = blob["in/image"], blob["in/label"]
+    model, res, loss, log = run_model(meta["config"], sub(blob, "param/"),
+                                      image, label, noise, meta["train"])
+    loss.backward()
+    assert_close(loss, blob["out/loss"], 1e-4, 1e-5, "loss")
+    for k, ref in sub(blob, "log/").items():
+        assert_close(log[k], ref, 1e-4, 1e-4, "log " + k)
+    assert_close(model.calculate_accuracy(res, label.cuda()),
+                 blob["out/accuracy"], 0, 0, "accuracy")
+    n = 0
+    for k, ref in sub(blob, "res/").items():
+        if "." in k:
+            head, tail = k.split(".", 1)
+            rec = res[head]
+            if tail in rec:
+                got = rec[tail]
+            elif tail == "log_prob":
+                got = rec.pdf.log_prob(image.cuda())
+            elif tail == "mode":
+                got = rec.pdf.mode()
+            elif tail == "mode_max":
+                got = rec.pdf.mode(maximum=True)
+            elif tail == "mean":
+                got = rec.pdf.mean()
+            elif tail == "mixing_log_prob":
+                got = rec.pdf.mixing_log_prob()
+            else:
+                raise KeyError(k)
+        else:
+            got = res[k]
+        assert_close(got, ref, 5e-5, 1e-4, "res " + k)
+        n += 1
+    assert n >= 27
+    grads = nn_ext.named_reference_grads(model)
+    m = 0
+    for k, g in sub(blob, "grad/").items():
+        assert grads[k] is not None, k
+        assert_close(grads[k], g, 1e-4, 5e-4, "grad " + k)
+        m += 1
+    assert m > 20
+    for k in meta["no_grad_params"]:
+        assert grads[k] is None or float(grads[k].abs().sum()) == 0.0, k
+
+
+FULL = {
+    # BASELINE.json configs[1]: MNIST 40x40, 24/24, bs=128, fp32
+    "cfg2": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24,
+                  n_obj_caps=24,
+                  scae_params=dict(reconstruct_alternatives=False)), 128),
+    # configs[4]: CIFAR shape, 32/32, 3-channel templates (batch cut to keep
+    # the CPU oracle quick)
+    "cfg5": (dict(image_shape=(3, 32, 32), n_classes=10, n_part_caps=32,
+                  n_obj_caps=32,
+                  scae_params=dict(reconstruct_alternatives=False)), 32),
+    # hydra default of the reference: 40 part / 32 object capsules
+    "mnist_40_32": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=40,
+                         n_obj_caps=32,
+                         scae_params=dict(reconstruct_alternatives=False)),
+                    16),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_scae_vs_oracle_full_size(name):
+    from torch_scae_amd import factory, nn_ext
+    cfg, B = FULL[name]
+    np.random.seed(1)
+    torch.manual_seed(1)
+    proto = factory.make_scae(cfg)
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for p in proto.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    sd = {k: v.clone() for k, v in proto.state_dict().items()}
+    M, Oc = cfg["n_part_caps"], cfg["n_obj_caps"]
+    image = torch.rand(B, *cfg["image_shape"], generator=g)
+    label = torch.randint(0, 10, (B,), generator=g)
+    noise = [torch.rand(B, M, generator=g), torch.rand(B, Oc, 1, generator=g),
+             torch.rand(B, Oc, M, generator=g)]
+
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = O.prepare_model_params(**cfg)
+    ores = O.scae_forward(P, ocfg, image, noise, training=True)
+    oloss, olog = O.scae_loss(ocfg, ores, image, label)
+    oloss.backward()
+
+    model, res, loss, log = run_model(cfg, sd, image, label, noise, True)
+    loss.backward()
+    # north-star bar: <= 1e-4 fp32, relative on the O(1e3) sums
+    assert_close(loss, oloss, 1e-4, 1e-4, "loss")
+    for k in olog:
+        assert_close(log[k], olog[k], 1e-4, 1e-4, "log " + k)
+    for k in ("vote", "scale", "vote_presence", "caps_presence",
+              "posterior_mixing_prob", "soft_winner", "winner",
+              "transformed_templates", "prior_cls_prob", "posterior_cls_prob"):
+        assert_close(res[k], ores[k], 1e-4, 1e-4, "res " + k)
+    lp = res.rec.pdf.log_prob(image.cuda())
+    olp = O.gmm_log_prob(ores.rec.transformed_templates, ores.rec.scale,
+                         ores.rec.mixing_logits, image)
+    assert_close(lp, olp, 1e-4, 1e-4, "rec log_prob")
+    grads = nn_ext.named_reference_grads(model)
+    for k, p in P.items():
+        if p.grad is None:
+            continue
+        ref = p.grad
+        assert_close(grads[k], ref, 1e-4 * max(1.0, float(ref.abs().max())),
+                     1e-3, "grad " + k)
+
+
+def test_scae_forward_is_stochastic_like_the_reference():
+    """No replayed noise: two forwards differ (uniform presence noise is
+    always on in CapsuleLayer, object_decoder.py:198-212)."""
+    from torch_scae_amd import factory
+    cfg, _ = FULL["cfg2"]
+    torch.manual_seed(0)
+    model = factory.make_scae(cfg).cuda().eval()
+    img = torch.rand(4, 1, 40, 40, device="cuda")
+    with torch.no_grad():
+        a, b = model(img), model(img)
+    assert not torch.equal(a.vote_presence, b.vote_presence)
+    assert torch.equal(a.templates, b.templates)
+
+
+def test_invalid_vote_type():
+    from torch_scae_amd import factory
+    cfg = dict(FULL["cfg2"][0])
+    cfg["scae_params"] = dict(vote_type="bogus", reconstruct_alternatives=False)
+    model = factory.make_scae(cfg).cuda()
+    with pytest.raises(ValueError):
+        model(torch.rand(2, 1, 40, 40, device="cuda"))

@@ -1,0 +1,496 @@
+"""GPU parity: every HIP op (through the C ABI) against the golden vectors
+captured from the reference and against the CPU oracle on random inputs.
+Tolerances are the north-star's 1e-4 (fp32), written per assertion."""
+import pytest
+import torch
+
+from oracle import scae_oracle as O
+from tests.golden_util import assert_close, load, sub
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-5, 1e-4      # outputs
+GATOL, GRTOL = 2e-5, 1e-4    # gradients
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def leaf(t):
+    return t.detach().clone().cuda().requires_grad_(True)
+
+
+# ------------------------------------------------------------------ K5 -----
+def test_geometric_transform_flags_vs_golden():
+    from torch_scae_amd.cv_ops import geometric_transform
+    blob, _ = load("op_geometric_transform")
+    x = blob["in/pose"].cuda()
+    for sim in (0, 1):
+        for nl in (0, 1):
+            for mat in (0, 1):
+                y = geometric_transform(x, bool(sim), bool(nl), bool(mat))
+                assert_close(y, blob[f"out/sim{sim}_nl{nl}_mat{mat}"], ATOL,
+                             RTOL, f"sim{sim} nl{nl} mat{mat}")
+
+
+def test_geometric_transform_grad_vs_golden():
+    from torch_scae_amd.cv_ops import geometric_transform
+    blob, _ = load("op_geometric_transform_grad")
+    for sim in (0, 1):
+        x = leaf(blob[f"in/pose_sim{sim}"])
+        y = geometric_transform(x, bool(sim))
+        (y * blob[f"in/w_sim{sim}"].cuda()).sum().backward()
+        assert_close(y, blob[f"out/y_sim{sim}"], ATOL, RTOL, "y")
+        assert_close(x.grad, blob[f"grad/pose_sim{sim}"], GATOL, GRTOL, "g")
+
+
+@pytest.mark.parametrize("sim,nl,mat", [(0, 1, 1), (1, 1, 0), (0, 0, 0),
+                                        (1, 0, 1)])
+def test_geometric_transform_vs_oracle_large(sim, nl, mat):
+    from torch_scae_amd.cv_ops import geometric_transform
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(128, 24, 24, 6, generator=g)
+    w = torch.randn(128, 24, 24, 3, 3, generator=g) if mat else \
+        torch.randn(128, 24, 24, 6, generator=g)
+    xc = x.clone().requires_grad_(True)
+    yo = O.geometric_transform(xc, bool(sim), bool(nl), bool(mat))
+    (yo * w).sum().backward()
+    xg = leaf(x)
+    yg = geometric_transform(xg, bool(sim), bool(nl), bool(mat))
+    (yg * w.cuda()).sum().backward()
+    assert_close(yg, yo, ATOL, RTOL, "y")
+    assert_close(xg.grad, xc.grad, 1e-4, 1e-4, "grad")
+
+
+# ------------------------------------------------------------------ K2 -----
+@pytest.mark.parametrize("case", ["plain", "nopresence", "saturated", "ties",
+                                  "wide"])
+def test_qkv_attention_vs_golden(case):
+    from torch_scae_amd.set_transformer import qkv_attention
+    blob, _ = load("op_qkv_attention")
+    c = sub(blob, case + "/")
+    q, k, v = leaf(c["q"]), leaf(c["k"]), leaf(c["v"])
+    out = qkv_attention(q, k, v, dev(c.get("presence")))
+    (out * c["w"].cuda()).sum().backward()
+    assert_close(out, c["out"], 2e-5, 1e-4, "out")
+    assert_close(q.grad, c["gq"], 5e-5, 1e-4, "gq")
+    assert_close(k.grad, c["gk"], 5e-5, 1e-4, "gk")
+    assert_close(v.grad, c["gv"], 5e-5, 1e-4, "gv")
+
+
+@pytest.mark.parametrize("HB,N,M,dk,dv,pres", [
+    (128, 24, 24, 16, 16, "mixed"),      # SAB of cfg-2
+    (128, 24, 24, 256, 256, "mixed"),    # output attention of cfg-2
+    (16, 64, 48, 256, 256, "ones"),      # cfg-3 shape
+    (7, 1, 1, 3, 5, None),               # degenerate
+    (5, 33, 17, 70, 130, "mixed"),       # ragged, multi-chunk
+    (6, 10, 20, 6, 6, "rand"),           # heads-of-3 shape, one-hot regime
+])
+def test_qkv_attention_vs_oracle(HB, N, M, dk, dv, pres):
+    from torch_scae_amd.set_transformer import qkv_attention
+    g = torch.Generator().manual_seed(HB * 1000 + N)
+    q = torch.randn(HB, N, dk, generator=g)
+    k = torch.randn(HB, M, dk, generator=g)
+    v = torch.randn(HB, M, dv, generator=g)
+    w = torch.randn(HB, N, dv, generator=g)
+    p = None
+    if pres == "rand":
+        p = torch.rand(HB, M, generator=g)
+    elif pres == "ones":
+        p = torch.ones(HB, M)
+    elif pres == "mixed":
+        p = torch.ones(HB, M)
+        p[:, ::3] = torch.rand(HB, len(range(0, M, 3)), generator=g)
+        p[0] = 1.0
+    qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
+    oo = O.qkv_attention(qc, kc, vc, p)
+    (oo * w).sum().backward()
+    qg, kg, vg = leaf(q), leaf(k), leaf(v)
+    og = qkv_attention(qg, kg, vg, dev(p))
+    (og * w.cuda()).sum().backward()
+    scale = max(1.0, float(oo.abs().max()))
+    assert_close(og, oo, 1e-4 * scale, 1e-4, "out")
+    for name, a, b in (("gq", qg.grad, qc.grad), ("gk", kg.grad, kc.grad),
+                       ("gv", vg.grad, vc.grad)):
+        assert_close(a, b, 1e-4 * max(1.0, float(b.abs().max())), 1e-4, name)
+
+
+def test_qkv_attention_presence_gradient():
+    """d/d presence = +1e32 * sum_n dS (set_transformer.py:42): compare in
+    units of 1e32 against autograd on the oracle."""
+    from torch_scae_amd.set_transformer import qkv_attention
+    g = torch.Generator().manual_seed(9)
+    q, k, v = (torch.randn(3, 5, 8, generator=g) for _ in range(3))
+    p = torch.ones(3, 5)
+    pc = p.clone().requires_grad_(True)
+    O.qkv_attention(q, k, v, pc).square().sum().backward()
+    pg = leaf(p)
+    qkv_attention(q.cuda(), k.cuda(), v.cuda(), pg).square().sum().backward()
+    assert_close(pg.grad / 1e32, pc.grad / 1e32, 1e-4, 1e-3, "gpresence")
+
+
+def test_qkv_attention_rejects_oversize_sets():
+    from torch_scae_amd.ops import ScaeHipError
+    from torch_scae_amd.set_transformer import qkv_attention
+    x = torch.zeros(1, 65, 4, device="cuda")
+    with pytest.raises(ScaeHipError):
+        qkv_attention(x, x, x)
+
+
+BLOCKS = {
+    "mha_h3": ("MultiHeadQKVAttention", dict(d_k=16, d_v=32, n_heads=3),
+               ("q", "k", "v", "presence")),
+    "mab_h3": ("MAB", dict(d=16, n_heads=3, layer_norm=False),
+               ("q", "k", "presence")),
+    "mab_ln": ("MAB", dict(d=16, n_heads=2, layer_norm=True),
+               ("q", "k", "presence")),
+    "sab": ("SAB", dict(d=16, n_heads=1, layer_norm=True), ("x", "presence")),
+    "isab": ("ISAB", dict(d=16, n_heads=2, n_inducing_points=5,
+                          layer_norm=True), ("x", "presence")),
+    "isab_nopres": ("ISAB", dict(d=16, n_heads=1, n_inducing_points=3,
+                                 layer_norm=False), ("x",)),
+    "pma": ("PMA", dict(d=16, n_heads=1, n_seeds=5, layer_norm=True),
+            ("x", "presence")),
+    "st_sab": ("SetTransformer", dict(dim_in=11, dim_hidden=16, dim_out=24,
+                                      n_outputs=4, n_layers=2, n_heads=1,
+                                      layer_norm=True), ("x", "presence")),
+    "st_isab": ("SetTransformer", dict(dim_in=11, dim_hidden=16, dim_out=24,
+                                       n_outputs=4, n_layers=2, n_heads=3,
+                                       layer_norm=True, n_inducing_points=5),
+                ("x", "presence")),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BLOCKS))
+def test_set_transformer_modules_vs_golden(name):
+    from torch_scae_amd import set_transformer as st
+    blob, _ = load("op_set_transformer_blocks")
+    c = sub(blob, name + "/")
+    cls, kw, argn = BLOCKS[name]
+    mod = getattr(st, cls)(**kw)
+    mod.load_state_dict(sub(c, "param/"))
+    mod = mod.cuda()
+    ins = {}
+    for a in argn:
+        t = c["in/" + a]
+        ins[a] = t.cuda() if a == "presence" else leaf(t)
+    out = mod(*[ins[a] for a in argn])
+    (out * c["w"].cuda()).sum().backward()
+    assert_close(out, c["out"], 2e-5, 1e-4, "out")
+    grads = dict(mod.named_parameters())
+    for k, g in sub(c, "grad/").items():
+        assert_close(grads[k].grad, g, 5e-5, 2e-4, "grad " + k)
+    for k, g in sub(c, "gin/").items():
+        assert_close(ins[k].grad, g, 5e-5, 2e-4, "gin " + k)
+
+
+# --------------------------------------------------------------- K3 / K4 ---
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_capsule_likelihood_vs_golden(case):
+    from torch_scae_amd.object_decoder import CapsuleLikelihood
+    blob, _ = load("op_capsule_likelihood")
+    c = sub(blob, case + "/")
+    i = {k: leaf(v) for k, v in sub(c, "in/").items()}
+    res = CapsuleLikelihood(i["vote"], i["scale"], i["vote_presence"],
+                            i["dummy_vote"])(i["x"], i["presence"])
+    tot = res.log_prob * 1.7
+    for k, w in sub(c, "w/").items():
+        tot = tot + (res[k] * w.cuda()).sum()
+    tot.backward()
+    for k, ref in sub(c, "out/").items():
+        assert_close(res[k], ref, ATOL, RTOL, "out " + k)
+    for k, g in sub(c, "grad/").items():
+        assert_close(i[k].grad, g, 5e-5, 2e-4, "grad " + k)
+
+
+def test_capsule_likelihood_no_presence_vs_golden():
+    from torch_scae_amd.object_decoder import CapsuleLikelihood
+    blob, _ = load("op_capsule_likelihood")
+    c = sub(blob, "nopres/")
+    i = {k: v.cuda() for k, v in sub(c, "in/").items()}
+    res = CapsuleLikelihood(i["vote"], i["scale"], i["vote_presence"],
+                            i["dummy_vote"])(i["x"], None)
+    for k, ref in sub(c, "out/").items():
+        assert_close(res[k], ref, ATOL, RTOL, "out " + k)
+
+
+def test_capsule_likelihood_vs_oracle_cfg2():
+    from torch_scae_amd.object_decoder import CapsuleLikelihood
+    g = torch.Generator().manual_seed(77)
+    B, Oc, M = 128, 24, 24
+    ins = dict(vote=torch.randn(B, Oc, M, 6, generator=g),
+               scale=torch.rand(B, Oc, M, generator=g) + 0.1,
+               vote_presence=torch.rand(B, Oc, M, generator=g),
+               dummy_vote=torch.randn(1, 1, M, 6, generator=g) * 0.1,
+               x=torch.randn(B, M, 6, generator=g),
+               presence=torch.rand(B, M, generator=g))
+    ws = dict(posterior_mixing_prob=torch.randn(B, Oc, M, generator=g),
+              soft_winner=torch.randn(B, M, 6, generator=g))
+    ic = {k: v.clone().requires_grad_(True) for k, v in ins.items()}
+    ro = O.capsule_likelihood(ic["vote"], ic["scale"], ic["vote_presence"],
+                              ic["dummy_vote"], ic["x"], ic["presence"])
+    (ro.log_prob + sum((ro[k] * w).sum() for k, w in ws.items())).backward()
+    ig = {k: leaf(v) for k, v in ins.items()}
+    rg = CapsuleLikelihood(ig["vote"], ig["scale"], ig["vote_presence"],
+                           ig["dummy_vote"])(ig["x"], ig["presence"])
+    (rg.log_prob + sum((rg[k] * w.cuda()).sum()
+                       for k, w in ws.items())).backward()
+    for k in ro:
+        assert_close(rg[k], ro[k], 1e-4, 1e-4, "out " + k)
+    for k in ins:
+        ref = ic[k].grad
+        assert_close(ig[k].grad, ref, 1e-4 * max(1, float(ref.abs().max())),
+                     2e-4, "grad " + k)
+
+
+CAPS_VARIANTS = {
+    "default": dict(learn_vote_scale=True, allow_deformations=True,
+                    noise_type="uniform", noise_scale=4.,
+                    similarity_transform=False),
+    "sim_nonoise": dict(learn_vote_scale=False, allow_deformations=False,
+                        noise_type=None, noise_scale=0.,
+                        similarity_transform=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CAPS_VARIANTS))
+def test_capsule_layer_and_decoder_vs_golden(name):
+    from torch_scae_amd import nn_ext, nn_utils
+    from torch_scae_amd.object_decoder import CapsuleLayer, CapsuleObjectDecoder
+    blob, _ = load("op_capsule_layer")
+    c = sub(blob, name + "/")
+    layer = CapsuleLayer(n_caps=4, dim_feature=10, n_votes=5, dim_caps=6,
+                         hidden_sizes=(7,), **CAPS_VARIANTS[name])
+    layer.load_state_dict(sub(c, "layer_param/"))
+    layer = layer.cuda()
+    feat = leaf(c["in/feature"])
+    noise = sub(c, "noise/")
+    with nn_utils.fixed_noise([noise[k] for k in sorted(noise)]):
+        res = layer(feat)
+    tot = res.cpr_dynamic_reg_loss * 0.9
+    for k, w in sub(c, "w/").items():
+        tot = tot + (res[k] * w.cuda()).sum()
+    tot.backward()
+    for k, ref in sub(c, "out/").items():
+        assert_close(res[k], ref, ATOL, RTOL, "out " + k)
+    assert_close(feat.grad, c["grad/feature"], GATOL, 2e-4, "grad feature")
+    grads = nn_ext.named_reference_grads(layer)
+    for k, g in sub(c, "grad/").items():
+        if k != "feature":
+            assert_close(grads[k], g, GATOL, 2e-4, "grad " + k)
+
+    dec = CapsuleObjectDecoder(CapsuleLayer(
+        n_caps=4, dim_feature=10, n_votes=5, dim_caps=6, hidden_sizes=(7,),
+        **CAPS_VARIANTS[name]))
+    dec.load_state_dict(sub(c, "dec_param/"))
+    dec = dec.cuda()
+    dn = sub(c, "dec_noise/")
+    with torch.no_grad(), nn_utils.fixed_noise([dn[k] for k in sorted(dn)]):
+        r2 = dec(feat.detach(), c["dec_in/x"].cuda(),
+                 c["dec_in/presence"].cuda())
+    for k, ref in sub(c, "dec_out/").items():
+        assert_close(r2[k], ref, ATOL, RTOL, "dec_out " + k)
+
+
+def test_capsule_layer_error_behaviour():
+    from torch_scae_amd.object_decoder import CapsuleLayer, sparsity_loss
+    x = torch.zeros(2, 3, 4, device="cuda")
+    with pytest.raises(ValueError):
+        CapsuleLayer(3, 4, 5, 6, noise_type="bogus").cuda()(x)
+    with pytest.raises(NameError):      # reference crashes the same way
+        CapsuleLayer(3, 4, 5, 6, caps_dropout_rate=0.5).cuda()(x)
+    with pytest.raises(ValueError):
+        sparsity_loss("nope", x[0])
+
+
+# ------------------------------------------------------------------ K1 -----
+def decoder_cases():
+    _, meta = load("op_image_decoder")
+    return sorted(k for k in meta if not k.startswith("tg_"))
+
+
+def make_decoder(m, params):
+    from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
+    dec = TemplateBasedImageDecoder(
+        n_templates=m["M"], template_size=tuple(m["template_size"]),
+        output_size=tuple(m["HW"]), learn_output_scale=m["learn_output_scale"],
+        use_alpha_channel=m["use_alpha_channel"],
+        background_value=m["background_value"])
+    dec.load_state_dict(params)
+    return dec.cuda()
+
+
+@pytest.mark.parametrize("name", decoder_cases())
+def test_image_decoder_vs_golden(name):
+    blob, meta = load("op_image_decoder")
+    c = sub(blob, name + "/")
+    dec = make_decoder(meta[name], sub(c, "param/"))
+    i = {k: leaf(v) for k, v in sub(c, "in/").items() if k not in ("x", "w")}
+    x, w = c["in/x"].cuda(), c["in/w"].cuda()
+    r = dec(i["templates"], i["pose"], i.get("presence"), i.get("bg_image"))
+    assert_close(r.transformed_templates, c["out/transformed_templates"],
+                 ATOL, RTOL, "tt")
+    assert_close(r.mixing_logits, c["out/mixing_logits"], 2e-5, RTOL, "ml")
+
+    # fused likelihood path
+    lp = r.pdf.log_prob(x)
+    (lp * w).sum().backward()
+    assert_close(lp, c["out/log_prob"], 5e-5, 1e-4, "log_prob")
+    for k, g in sub(c, "grad/").items():
+        assert_close(i[k].grad, g, 5e-5, 2e-4, "grad " + k)
+    pg = dict(dec.named_parameters())
+    for k, g in sub(c, "pgrad/").items():
+        assert_close(pg[k].grad, g, 1e-4, 2e-4, "pgrad " + k)
+
+    # the generic (materialised) mixture gives the same numbers
+    from torch_scae_amd.distributions import GaussianMixture
+    generic = GaussianMixture.make_from_stats(
+        r.transformed_templates.detach(), r.pdf.dist.scale.detach(),
+        r.mixing_logits.detach())
+    assert_close(generic.log_prob(x), c["out/log_prob"], 5e-5, 1e-4,
+                 "generic log_prob")
+    assert_close(r.pdf.mean(), c["out/mean"], 2e-5, 1e-4, "mean")
+    assert_close(r.pdf.mode(), c["out/mode"], 2e-5, 1e-4, "mode")
+    assert_close(r.pdf.mixing_log_prob(), c["out/mixing_log_prob"], 2e-5,
+                 1e-4, "mixing_log_prob")
+    if "out/mode_max" in c:
+        assert_close(r.pdf.mode(maximum=True), c["out/mode_max"], 2e-5, 1e-4,
+                     "mode_max")
+    else:
+        with pytest.raises(RuntimeError):
+            r.pdf.mode(maximum=True)
+
+    # gradients THROUGH the materialised tensors (autograd of the renderer)
+    for p in dec.parameters():
+        p.grad = None
+    i2 = {k: leaf(v) for k, v in sub(c, "in/").items() if k not in ("x", "w")}
+    bg = i2.get("bg_image")
+    r2 = dec(i2["templates"], i2["pose"], i2.get("presence"),
+             None if bg is None else bg.detach())
+    ((r2.transformed_templates * c["mat/wt"].cuda()).sum()
+     + (r2.mixing_logits * c["mat/wm"].cuda()).sum()).backward()
+    for k, g in sub(c, "mat/grad/").items():
+        assert_close(i2[k].grad, g, 1e-4, 2e-4, "mat grad " + k)
+    for k, g in sub(c, "mat/pgrad/").items():
+        assert_close(pg[k].grad, g, 2e-4, 2e-4, "mat pgrad " + k)
+
+    # generic mixture backward == fused backward
+    loc = r.transformed_templates.detach().clone().requires_grad_(True)
+    ml = r.mixing_logits.detach().clone().requires_grad_(True)
+    sig = r.pdf.dist.scale.detach().clone().requires_grad_(True)
+    (GaussianMixture.make_from_stats(loc, sig, ml).log_prob(x) * w) \
+        .sum().backward()
+    cfg = dict(output_size=tuple(meta[name]["HW"]),
+               learn_output_scale=meta[name]["learn_output_scale"],
+               use_alpha_channel=meta[name]["use_alpha_channel"])
+    locc = r.transformed_templates.detach().cpu().requires_grad_(True)
+    mlc = r.mixing_logits.detach().cpu().requires_grad_(True)
+    sigc = r.pdf.dist.scale.detach().cpu().requires_grad_(True)
+    (O.gmm_log_prob(locc, sigc, mlc, x.cpu()) * w.cpu()).sum().backward()
+    assert_close(loc.grad, locc.grad, 5e-5, 2e-4, "generic g_loc")
+    assert_close(ml.grad, mlc.grad, 5e-5, 2e-4, "generic g_ml")
+    assert_close(sig.grad, sigc.grad, 2e-4, 2e-4, "generic g_sigma")
+
+
+@pytest.mark.parametrize("B,M,C,HW,ts,alpha,scale", [
+    (128, 24, 1, (40, 40), (11, 11), True, False),    # cfg-2
+    (16, 32, 3, (32, 32), (11, 11), True, False),     # cfg-5 shape
+    (8, 48, 1, (40, 40), (11, 11), True, False),      # cfg-3 shape
+    (4, 5, 3, (17, 23), (7, 9), False, True),         # ragged, temperature
+])
+def test_image_decoder_vs_oracle_full_size(B, M, C, HW, ts, alpha, scale):
+    from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
+    torch.manual_seed(0)
+    dec = TemplateBasedImageDecoder(M, ts, HW, learn_output_scale=scale,
+                                    use_alpha_channel=alpha)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in dec.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    P = {"d." + k: v.clone().requires_grad_(True)
+         for k, v in dec.state_dict().items()}
+    templates = torch.rand(B, M, C, *ts, generator=g)
+    pose = torch.randn(B, M, 6, generator=g) * 0.5
+    pose[:, :, 0] += 1.0
+    pose[:, :, 4] += 1.0
+    presence = torch.rand(B, M, generator=g)
+    x = torch.rand(B, C, *HW, generator=g)
+    cfg = dict(output_size=HW, learn_output_scale=scale,
+               use_alpha_channel=alpha)
+    tc, pc, prc = (t.clone().requires_grad_(True)
+                   for t in (templates, pose, presence))
+    ro = O.image_decoder(P, "d", tc, pc, prc, None, cfg)
+    lpo = O.gmm_log_prob(ro.transformed_templates, ro.scale, ro.mixing_logits,
+                         x)
+    rec_ll = lpo.flatten(1).sum(-1).mean()
+    rec_ll.backward()
+
+    dec = dec.cuda()
+    tg, pg_, prg = leaf(templates), leaf(pose), leaf(presence)
+    rg = dec(tg, pg_, prg)
+    lpg = rg.pdf.log_prob(x.cuda())
+    lpg.flatten(1).sum(-1).mean().backward()
+    assert_close(rg.transformed_templates, ro.transformed_templates, 1e-5,
+                 1e-4, "tt")
+    assert_close(rg.mixing_logits, ro.mixing_logits, 2e-5, 1e-4, "ml")
+    assert_close(lpg, lpo, 1e-4, 1e-4, "log_prob")
+    for name, a, b in (("templates", tg.grad, tc.grad),
+                       ("pose", pg_.grad, pc.grad),
+                       ("presence", prg.grad, prc.grad)):
+        assert_close(a, b, 1e-4 * max(1.0, float(b.abs().max())), 2e-4,
+                     "grad " + name)
+    for k, p in dec.named_parameters():
+        ref = P["d." + k].grad
+        assert_close(p.grad, ref, 1e-4 * max(1.0, float(ref.abs().max())),
+                     5e-4, "pgrad " + k)
+
+
+def test_image_decoder_error_behaviour():
+    from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
+    dec = TemplateBasedImageDecoder(2, (5, 5), (8, 8), use_alpha_channel=True,
+                                    background_value=False).cuda()
+    t = torch.rand(1, 2, 1, 5, 5, device="cuda")
+    p = torch.rand(1, 2, 6, device="cuda")
+    with pytest.raises(AttributeError):      # like the reference, :192
+        dec(t, p)
+
+
+@pytest.mark.parametrize("name", ["tg_default", "tg_relu1_rgb", "tg_nocolor"])
+def test_template_generator_vs_golden(name):
+    from torch_scae_amd.part_decoder import TemplateGenerator
+    blob, meta = load("op_image_decoder")
+    c = sub(blob, name + "/")
+    kw = dict(meta[name])
+    kw["template_size"] = tuple(kw["template_size"])
+    tg = TemplateGenerator(**kw)
+    tg.load_state_dict(sub(c, "param/"))
+    tg = tg.cuda()
+    feat = c.get("in/feature")
+    if feat is not None:
+        feat = leaf(feat)
+    r = tg(feature=feat, batch_size=2)
+    assert_close(r.templates, c["out/templates"], ATOL, RTOL, "templates")
+    assert_close(r.raw_templates, c["out/raw_templates"], ATOL, RTOL, "raw")
+
+
+@pytest.mark.parametrize("name,shape,sim,train", [
+    ("affine_train", (1, 16, 16), False, True),
+    ("similarity_eval", (3, 14, 14), True, False)])
+def test_part_encoder_vs_golden(name, shape, sim, train):
+    from torch_scae_amd import nn_utils
+    from torch_scae_amd.part_encoder import CNNEncoder, PCAE
+    blob, _ = load("op_part_encoder")
+    c = sub(blob, name + "/")
+    cnn = CNNEncoder(input_shape=shape, out_channels=[6, 6],
+                     kernel_sizes=[3, 3], strides=[2, 1])
+    enc = PCAE(input_shape=shape, encoder=cnn, n_caps=3, n_poses=6,
+               n_special_features=4, similarity_transform=sim)
+    enc.load_state_dict(sub(c, "param/"))
+    enc = enc.cuda().train(train)
+    noise = sub(c, "noise/")
+    with torch.no_grad(), nn_utils.fixed_noise([noise[k]
+                                                for k in sorted(noise)]):
+        r = enc(c["in/image"].cuda())
+    for k in ("pose", "presence", "feature"):
+        assert_close(r[k], c["out/" + k], 2e-5, 1e-4, k)

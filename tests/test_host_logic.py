@@ -1,0 +1,151 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every
+symbol the header declares, the nn.Module surface / checkpoint schema match
+the reference, and the product refuses to run without a HIP device."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load, model_names, sub
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from torch_scae_amd import _lib
+    header = open(os.path.join(ROOT, "include", "scae_hip.h")).read()
+    declared = set(re.findall(r"\b(scae_[a-z0-9_]+)\s*\(", header))
+    declared -= {"scae_decoder_desc"}
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), \
+        declared.symmetric_difference(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.scae_abi_version() == 1
+    assert b"limits" in lib.scae_error_string(-2)
+
+
+def test_launchers_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call."""
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    assert lib.scae_geometric_transform_fwd_f32(None, None, 4, 0, 1, 0,
+                                                None) == -1
+    assert lib.scae_qkv_attention_fwd_f32(None, None, None, None, None, None,
+                                          1, 65, 4, 4, 4, 2.0, None) == -2
+    d = _lib.DecoderDesc()
+    assert lib.scae_template_render_fwd_f32(d, None, None, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    from torch_scae_amd import cv_ops, ops
+    with pytest.raises(ops.ScaeHipError):
+        cv_ops.geometric_transform(torch.zeros(3, 6))
+    from torch_scae_amd.set_transformer import qkv_attention
+    with pytest.raises(ops.ScaeHipError):
+        qkv_attention(torch.zeros(1, 2, 4), torch.zeros(1, 2, 4),
+                      torch.zeros(1, 2, 4))
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "torch_scae_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("oracle-", ""), fn
+
+
+@pytest.mark.parametrize("name", model_names())
+def test_state_dict_schema_matches_reference(name):
+    """Checkpoint keys / shapes / order equal the reference's (captured in the
+    golden files), including the per-capsule MLP keys."""
+    from torch_scae_amd import factory
+    blob, meta = load(name)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(meta["config"])
+    ref = sub(blob, "param/")
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    model.load_state_dict(ref)
+    sd = model.state_dict()
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
+
+
+def test_default_config_counts():
+    from torch_scae_amd import factory
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(dict(image_shape=(1, 40, 40), n_classes=10,
+                                   n_part_caps=24, n_obj_caps=24))
+    sd = model.state_dict()
+    assert len(sd) == 228
+    assert sum(v.numel() for v in sd.values()) == 2414879
+    assert model.reconstruct_alternatives is True      # SCAE ctor default
+    assert tuple(sd["part_encoder.img_embedding_bias"].shape) == (128, 5, 5)
+    assert tuple(sd["obj_decoder.capsule_layer.caps_mlps.0.2.weight"].shape) \
+        == (199, 128)
+
+
+def test_prepare_model_params_matches_oracle_defaults():
+    from oracle import scae_oracle as O
+    from torch_scae_amd import factory
+    kw = dict(image_shape=(3, 32, 32), n_classes=10, n_part_caps=32,
+              n_obj_caps=32)
+    a, b = factory.prepare_model_params(**kw), O.prepare_model_params(**kw)
+    for sec in a:
+        if isinstance(a[sec], dict):
+            for k, v in a[sec].items():
+                bv = b[sec][k]
+                assert (tuple(v) == tuple(bv)) if isinstance(v, (list, tuple)) \
+                    else v == bv, (sec, k)
+    assert a["ocae_encoder_set_transformer"]["dim_in"] == 386
+    with pytest.raises(AssertionError):       # derived keys are protected
+        factory.prepare_model_params(pcae_decoder_params=dict(n_templates=3),
+                                     **kw)
+
+
+def test_attr_dict_behaviour():
+    from torch_scae_amd.general_utils import AttrDict
+    d = AttrDict(a=1)
+    d.b = 2
+    assert d["b"] == 2 and d.a == 1
+    del d.a
+    assert "a" not in d
+    d.update(c=3)
+    assert d.get("c") == 3 and d.get("zz") is None
+
+
+def test_grouped_mlp_equals_per_capsule_loop():
+    """Stacked-weight batched evaluation == the reference's loop of MLPs."""
+    from torch_scae_amd.nn_ext import MLP, GroupedMLP
+    torch.manual_seed(0)
+    G, B = 5, 7
+    for bias, ones in ((True, False), (False, True)):
+        d_in = 6 + (1 if ones else 0)
+        gm = GroupedMLP(G, [d_in, 9, 4], bias=bias, ones_input=ones)
+        loop = torch.nn.ModuleList([MLP([d_in, 9, 4], bias=bias)
+                                    for _ in range(G)])
+        loop.load_state_dict(gm.state_dict())
+        x = torch.randn(B, G, 6)
+        xin = torch.cat([x, torch.ones(B, G, 1)], -1) if ones else x
+        want = torch.stack([loop[g](xin[:, g]) for g in range(G)], 1)
+        assert torch.allclose(gm(x), want, atol=1e-6)
+
+
+def test_fixed_noise_replay_and_shape_check():
+    from torch_scae_amd import nn_utils
+    a = torch.rand(2, 3)
+    with nn_utils.fixed_noise([a]):
+        assert torch.equal(nn_utils.rand_like(torch.empty(2, 3)), a)
+        # queue exhausted -> fresh noise
+        assert nn_utils.rand_like(torch.empty(2, 3)).shape == (2, 3)
+    with nn_utils.fixed_noise([a]):
+        with pytest.raises(ValueError):
+            nn_utils.rand_like(torch.empty(4, 4))

@@ -1,0 +1,88 @@
+"""ctypes binding of libscae_hip.so (C ABI: include/scae_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C torch_scae_amd/csrc``.  There is NO fallback: if it is missing, or a
+tensor is not on a HIP device, the ops raise.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscae_hip.so")
+
+P = c_void_p  # device pointer
+
+
+class DecoderDesc(Structure):
+    """struct scae_decoder_desc"""
+    _fields_ = [("templates", P), ("templates_alpha", P), ("pose", P),
+                ("presence", P), ("bg_image", P), ("bg_value", P),
+                ("bg_mixing_logit", P), ("temperature_logit", P),
+                ("out_scale", P),
+                ("B", c_int), ("M", c_int), ("C", c_int), ("th", c_int),
+                ("tw", c_int), ("H", c_int), ("W", c_int)]
+
+
+# name -> argtypes; mirrors include/scae_hip.h one to one
+SIGNATURES = {
+    "scae_abi_version": [],
+    "scae_error_string": [c_int],
+    "scae_geometric_transform_fwd_f32": [P, P, c_int64, c_int, c_int, c_int, P],
+    "scae_geometric_transform_bwd_f32": [P, P, P, c_int64, c_int, c_int, c_int,
+                                         P],
+    "scae_qkv_attention_fwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int,
+                                   c_int, c_int, c_float, P],
+    "scae_qkv_attention_bwd_f32": [P, P, P, P, P, P, P, P, P, c_int, c_int,
+                                   c_int, c_int, c_int, c_float, P],
+    "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
+                                  + [c_int] * 6 + [P],
+    "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8
+                                  + [c_int] * 6 + [P],
+    "scae_capsule_likelihood_fwd_f32": [P] * 17 + [c_int] * 3 + [P],
+    "scae_capsule_likelihood_bwd_f32": [P] * 22 + [c_int] * 3 + [P],
+    "scae_template_render_fwd_f32": [POINTER(DecoderDesc), P, P, P],
+    "scae_render_gmm_logprob_fwd_f32": [POINTER(DecoderDesc), P, P, P, P, P],
+    "scae_render_gmm_bwd_f32": [POINTER(DecoderDesc)] + [P] * 12 + [P],
+    "scae_gmm_log_prob_fwd_f32": [P] * 5 + [c_int] * 4 + [c_int64, P],
+    "scae_gmm_log_prob_bwd_f32": [P] * 9 + [c_int] * 4 + [c_int64, P],
+    "scae_gmm_mean_f32": [P] * 3 + [c_int] * 4 + [c_int64, P],
+    "scae_gmm_mode_f32": [P] * 4 + [c_int] * 5 + [c_int64, P],
+}
+
+_lib = None
+
+
+class ScaeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScaeHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` or `make -C torch_scae_amd/csrc`."
+            " torch_scae_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_char_p if name == "scae_error_string" else c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().scae_error_string(rc)
+        raise ScaeHipError(f"{what} failed with code {rc}: "
+                           f"{msg.decode() if msg else '?'}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

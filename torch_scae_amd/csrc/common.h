@@ -1,0 +1,105 @@
+// Shared device helpers for the SCAE gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scae_hip.h"
+
+#define SCAE_WAVE 64
+
+#define SCAE_REQUIRE(cond)            \
+  do {                                \
+    if (!(cond)) return SCAE_ERR_BAD_ARG; \
+  } while (0)
+
+// Returns the hipError_t of the launch that was just enqueued (0 = success).
+static inline int scae_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SCAE_OK : (int)e;
+}
+
+namespace scae {
+
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr float kLogSafeEps = 1e-16f;   // math_ops.py:18
+constexpr float kLogSafeFloor = -1e8f;  // math_ops.py:21
+
+__device__ __forceinline__ float log_safe(float x) {
+  return x < kLogSafeEps ? kLogSafeFloor : logf(x);
+}
+// d log_safe / dx: the reference's torch.where routes zero grad to the masked
+// branch (log(1)=0 path), so the derivative is 0 below eps.
+__device__ __forceinline__ float log_safe_grad(float x) {
+  return x < kLogSafeEps ? 0.f : 1.f / x;
+}
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return 1.f / (1.f + expf(-x));
+}
+// F.softplus with the default threshold 20 (torch semantics).
+__device__ __forceinline__ float softplusf_(float x) {
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float softplus_grad(float x) {
+  return x > 20.f ? 1.f : sigmoidf_(x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Sum `N` per-thread values over a block of NT threads (NT multiple of 64).
+// `red` is LDS scratch of at least N * (NT/64) floats.  Result valid in
+// thread 0 (returned in vals[]).  Contains __syncthreads().
+template <int N, int NT>
+__device__ __forceinline__ void block_sum(float (&vals)[N], float *red) {
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) vals[i] = wave_sum(vals[i]);
+  if (NW > 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) red[i * NW + wid] = vals[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        float s = 0.f;
+        for (int w = 0; w < NW; ++w) s += red[i * NW + w];
+        vals[i] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Online log-sum-exp accumulator.  m starts at a large finite negative so
+// that (m - m_new) never evaluates inf - inf.
+struct Lse {
+  float m, s;
+  __device__ __forceinline__ void init() {
+    m = -3.0e38f;
+    s = 0.f;
+  }
+  __device__ __forceinline__ void add(float v) {
+    float mn = fmaxf(m, v);
+    s = s * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+  }
+  __device__ __forceinline__ void merge(float m2, float s2) {
+    float mn = fmaxf(m, m2);
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+  }
+  __device__ __forceinline__ float value() const { return m + __logf(s); }
+};
+
+}  // namespace scae

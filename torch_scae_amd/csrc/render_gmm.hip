@@ -1,0 +1,849 @@
+// K1 -- template render + per-pixel Gaussian-mixture image likelihood for
+// gfx950 (MI355X).  Replaces the ATen op cluster of the reference's
+//   part_decoder.py:174-237   (affine_grid, 2x grid_sample, background,
+//                              presence logits)
+//   distributions.py:34-47    (mixture log_prob = logsumexp over components)
+//   stacked_capsule_auto_encoder.py:220 (reconstruction log-likelihood)
+//
+// Design (HBM/VALU bound, no MFMA -- there is no contraction here):
+//   * the compact decoder inputs of one image -- M templates (+alpha) of
+//     th x tw texels, M poses, M presences -- are staged in LDS once per
+//     workgroup; the (B,K,C,H,W) tensors of the reference never exist on the
+//     fused path;
+//   * forward: one lane owns (pixel, component-subset); the mixture
+//     log-sum-exp is an online (max,sum) pair per lane, merged across the
+//     KSPLIT lanes of a pixel with wavefront xor-shuffles;
+//   * backward: one workgroup per (image, component); template / alpha
+//     gradients are scattered with LDS float atomics into a th x tw patch,
+//     the 6 pose gradients and the presence gradient are wave-shuffle +
+//     LDS block reductions; no global atomics, every output has one writer.
+#include "common.h"
+
+namespace {
+
+using scae::log_safe;
+using scae::sigmoidf_;
+using scae::softplusf_;
+
+constexpr int NT = 256;
+
+struct Taps {
+  int i00, i01, i10, i11;      // texel offsets inside one th*tw plane (clamped)
+  float m00, m01, m10, m11;    // 1 if that texel is inside the template
+  float fx, fy;                // fractional position
+  float xn, yn;                // normalised output-pixel coordinates
+};
+
+// affine_grid (align_corners=False) + grid_sample's un-normalisation, as
+// derived in SURVEY.md 8c: x_j = (2j+1)/W - 1; g = theta [x,y,1];
+// ix = ((gx+1) w - 1)/2; bilinear taps, zero padding.
+__device__ __forceinline__ void make_taps(const float *a, int p, int W, int H,
+                                          int tw, int th, Taps &t) {
+  const int i = p / W, j = p - i * W;
+  t.xn = (2 * j + 1) / (float)W - 1.f;
+  t.yn = (2 * i + 1) / (float)H - 1.f;
+  const float gx = a[0] * t.xn + a[1] * t.yn + a[2];
+  const float gy = a[3] * t.xn + a[4] * t.yn + a[5];
+  const float ix = ((gx + 1.f) * tw - 1.f) * 0.5f;
+  const float iy = ((gy + 1.f) * th - 1.f) * 0.5f;
+  float x0f = floorf(ix), y0f = floorf(iy);
+  t.fx = ix - x0f;
+  t.fy = iy - y0f;
+  // keep the int conversion defined for wild poses; such taps are all outside
+  x0f = fminf(fmaxf(x0f, -2.f), (float)(tw + 1));
+  y0f = fminf(fmaxf(y0f, -2.f), (float)(th + 1));
+  if (!(ix == ix)) x0f = -2.f;  // NaN pose -> everything outside
+  if (!(iy == iy)) y0f = -2.f;
+  const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  const bool bx0 = x0 >= 0 && x0 < tw, bx1 = x1 >= 0 && x1 < tw;
+  const bool by0 = y0 >= 0 && y0 < th, by1 = y1 >= 0 && y1 < th;
+  const int cx0 = min(max(x0, 0), tw - 1), cx1 = min(max(x1, 0), tw - 1);
+  const int cy0 = min(max(y0, 0), th - 1), cy1 = min(max(y1, 0), th - 1);
+  t.i00 = cy0 * tw + cx0;
+  t.i01 = cy0 * tw + cx1;
+  t.i10 = cy1 * tw + cx0;
+  t.i11 = cy1 * tw + cx1;
+  t.m00 = (bx0 && by0) ? 1.f : 0.f;
+  t.m01 = (bx1 && by0) ? 1.f : 0.f;
+  t.m10 = (bx0 && by1) ? 1.f : 0.f;
+  t.m11 = (bx1 && by1) ? 1.f : 0.f;
+}
+
+__device__ __forceinline__ float tap_value(const float *plane, const Taps &t) {
+  const float wx1 = t.fx, wx0 = 1.f - t.fx, wy1 = t.fy, wy0 = 1.f - t.fy;
+  return plane[t.i00] * (wx0 * wy0 * t.m00) + plane[t.i01] * (wx1 * wy0 * t.m01) +
+         plane[t.i10] * (wx0 * wy1 * t.m10) + plane[t.i11] * (wx1 * wy1 * t.m11);
+}
+
+// value and d/dix, d/diy (grid_sampler_2d_backward's formulas).
+__device__ __forceinline__ void tap_value_grad(const float *plane, const Taps &t,
+                                               float &v, float &dx, float &dy) {
+  const float v00 = plane[t.i00] * t.m00, v01 = plane[t.i01] * t.m01;
+  const float v10 = plane[t.i10] * t.m10, v11 = plane[t.i11] * t.m11;
+  const float wx1 = t.fx, wx0 = 1.f - t.fx, wy1 = t.fy, wy0 = 1.f - t.fy;
+  v = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+  dx = (v01 - v00) * wy0 + (v11 - v10) * wy1;
+  dy = (v10 - v00) * wx0 + (v11 - v01) * wx1;
+}
+
+__device__ __forceinline__ void tap_scatter(float *plane, const Taps &t, float g) {
+  const float wx1 = t.fx, wx0 = 1.f - t.fx, wy1 = t.fy, wy0 = 1.f - t.fy;
+  if (t.m00 != 0.f) atomicAdd(&plane[t.i00], g * (wx0 * wy0));
+  if (t.m01 != 0.f) atomicAdd(&plane[t.i01], g * (wx1 * wy0));
+  if (t.m10 != 0.f) atomicAdd(&plane[t.i10], g * (wx0 * wy1));
+  if (t.m11 != 0.f) atomicAdd(&plane[t.i11], g * (wx1 * wy1));
+}
+
+struct Scalars {
+  float sigma, inv_var, log_sigma;  // Normal scale of every component
+  float temperature;                // temperature mode only
+  float bg_ml;                      // alpha mode: softplus(bg_mixing_logit)
+  float bg_val;                     // sigmoid(bg_value) when no bg_image
+};
+
+__device__ __forceinline__ Scalars load_scalars(const scae_decoder_desc &d) {
+  Scalars s;
+  s.sigma = d.out_scale ? softplusf_(d.out_scale[0]) + 1e-4f : 1.f;  // :220-223
+  s.inv_var = 1.f / (s.sigma * s.sigma);
+  s.log_sigma = logf(s.sigma);
+  s.temperature = d.templates_alpha ? 1.f
+                                    : softplusf_(d.temperature_logit[0] + .5f) + 1e-4f;
+  s.bg_ml = d.templates_alpha ? softplusf_(d.bg_mixing_logit[0]) : 0.f;
+  s.bg_val = d.bg_image ? 0.f : sigmoidf_(d.bg_value[0]);
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// materialising forward: one workgroup per (component k, image b)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void render_fwd_kernel(scae_decoder_desc d,
+                                                        float *__restrict__ tt,
+                                                        float *__restrict__ ml) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int M = d.M, C = d.C, K = M + 1, HW = d.H * d.W, tsz = d.th * d.tw;
+  const bool alpha_mode = d.templates_alpha != nullptr;
+  const int Cm = alpha_mode ? 1 : C;
+  const Scalars sc = load_scalars(d);
+  float *tt_out = tt + (size_t)(b * K + k) * C * HW;
+  float *ml_out = ml + (size_t)(b * K + k) * Cm * HW;
+
+  if (k == M) {  // background component, part_decoder.py:189-195, :210-213
+    for (int p = tid; p < HW; p += NT) {
+      for (int c = 0; c < C; ++c) {
+        const float v = d.bg_image ? d.bg_image[(size_t)(b * C + c) * HW + p] : sc.bg_val;
+        tt_out[c * HW + p] = v;
+        if (!alpha_mode) ml_out[c * HW + p] = v / sc.temperature;
+      }
+      if (alpha_mode) ml_out[p] = sc.bg_ml;
+    }
+    return;
+  }
+
+  float *s_tmpl = smem;             // C * tsz
+  float *s_alpha = smem + C * tsz;  // tsz (alpha mode)
+  const float *g_tmpl = d.templates + (size_t)(b * M + k) * C * tsz;
+  for (int i = tid; i < C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
+  if (alpha_mode)
+    for (int i = tid; i < tsz; i += NT) s_alpha[i] = d.templates_alpha[(size_t)k * tsz + i];
+  float a[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) a[i] = d.pose[(size_t)(b * M + k) * 6 + i];
+  const float lsp = d.presence ? log_safe(d.presence[b * M + k]) : 0.f;  // :225-231
+  __syncthreads();
+
+  for (int p = tid; p < HW; p += NT) {
+    Taps t;
+    make_taps(a, p, d.W, d.H, d.tw, d.th, t);
+    for (int c = 0; c < C; ++c) {
+      const float v = tap_value(s_tmpl + c * tsz, t);
+      tt_out[c * HW + p] = v;
+      if (!alpha_mode) ml_out[c * HW + p] = v / sc.temperature + lsp;
+    }
+    if (alpha_mode) ml_out[p] = tap_value(s_alpha, t) + lsp;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fused forward: log_prob(x) straight from the compact inputs.
+// grid (pixel tiles, B).  Lane layout: tid = pixel_local * KSPLIT + kgroup.
+// ---------------------------------------------------------------------------
+template <int C, int KSPLIT>
+__global__ __launch_bounds__(NT) void logprob_fwd_kernel(
+    scae_decoder_desc d, const float *__restrict__ x, float *__restrict__ log_prob,
+    float *__restrict__ lse_post, float *__restrict__ lse_prior, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int M = d.M, HW = d.H * d.W, tsz = d.th * d.tw;
+  const bool alpha_mode = d.templates_alpha != nullptr;
+  constexpr int CM = C;  // register arrays sized for the per-channel mode
+  const Scalars sc = load_scalars(d);
+
+  float *s_tmpl = smem;                                // M*C*tsz
+  float *s_alpha = s_tmpl + M * C * tsz;               // M*tsz (alpha mode)
+  float *s_pose = s_alpha + (alpha_mode ? M * tsz : 0);  // M*6
+  float *s_lsp = s_pose + M * 6;                       // M
+  {
+    const float *g_tmpl = d.templates + (size_t)b * M * C * tsz;
+    for (int i = tid; i < M * C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
+    if (alpha_mode)
+      for (int i = tid; i < M * tsz; i += NT) s_alpha[i] = d.templates_alpha[i];
+    for (int i = tid; i < M * 6; i += NT) s_pose[i] = d.pose[(size_t)b * M * 6 + i];
+    for (int i = tid; i < M; i += NT)
+      s_lsp[i] = d.presence ? log_safe(d.presence[b * M + i]) : 0.f;
+  }
+  __syncthreads();
+
+  const int kg = tid % KSPLIT;
+  const int p_begin = blockIdx.x * pix_per_block;
+  const int p_end = min(p_begin + pix_per_block, HW);
+  // every lane of a wave runs the same number of iterations (shuffles below)
+  const int n_iter = (pix_per_block + (NT / KSPLIT) - 1) / (NT / KSPLIT);
+  for (int it = 0; it < n_iter; ++it) {
+    const int p = p_begin + it * (NT / KSPLIT) + tid / KSPLIT;
+    const bool live = p < p_end;
+    const int pc = live ? p : p_begin;
+    float xv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xv[c] = x[(size_t)(b * C + c) * HW + pc];
+
+    scae::Lse post[C], prior[CM];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      post[c].init();
+      prior[c].init();
+    }
+    for (int k = kg; k < M; k += KSPLIT) {
+      Taps t;
+      make_taps(s_pose + k * 6, pc, d.W, d.H, d.tw, d.th, t);
+      float mlv = 0.f;
+      if (alpha_mode) {
+        mlv = tap_value(s_alpha + k * tsz, t) + s_lsp[k];
+        prior[0].add(mlv);
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float v = tap_value(s_tmpl + (k * C + c) * tsz, t);
+        if (!alpha_mode) {
+          mlv = v / sc.temperature + s_lsp[k];
+          prior[c].add(mlv);
+        }
+        const float diff = xv[c] - v;
+        const float lp = -(diff * diff) * (0.5f * sc.inv_var) - sc.log_sigma - scae::kHalfLog2Pi;
+        post[c].add(lp + mlv);
+      }
+    }
+    if (kg == 0) {  // background component (k = M)
+      float mlv = sc.bg_ml;
+      if (alpha_mode) prior[0].add(mlv);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float v = d.bg_image ? d.bg_image[(size_t)(b * C + c) * HW + pc] : sc.bg_val;
+        if (!alpha_mode) {
+          mlv = v / sc.temperature;
+          prior[c].add(mlv);
+        }
+        const float diff = xv[c] - v;
+        const float lp = -(diff * diff) * (0.5f * sc.inv_var) - sc.log_sigma - scae::kHalfLog2Pi;
+        post[c].add(lp + mlv);
+      }
+    }
+    // merge the KSPLIT partial (max,sum) pairs of this pixel: wave shuffles
+#pragma unroll
+    for (int off = 1; off < KSPLIT; off <<= 1) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        post[c].merge(__shfl_xor(post[c].m, off, 64), __shfl_xor(post[c].s, off, 64));
+        if (c == 0 || !alpha_mode)
+          prior[c].merge(__shfl_xor(prior[c].m, off, 64), __shfl_xor(prior[c].s, off, 64));
+      }
+    }
+    if (live && kg == 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float lpost = post[c].value();
+        const float lprior = prior[alpha_mode ? 0 : c].value();
+        const size_t o = (size_t)(b * C + c) * HW + p;
+        log_prob[o] = lpost - lprior;
+        lse_post[o] = lpost;
+        if (!alpha_mode) lse_prior[o] = lprior;
+      }
+      if (alpha_mode) lse_prior[(size_t)b * HW + p] = prior[0].value();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward: one workgroup per (component k, image b).
+//   FUSED: incoming g_logprob, mixture responsibilities recomputed from the
+//          saved per-pixel log-sum-exps;
+//   else : incoming g_tt / g_ml of the materialised tensors.
+// ---------------------------------------------------------------------------
+template <int C, bool FUSED>
+__global__ __launch_bounds__(NT) void render_bwd_kernel(
+    scae_decoder_desc d, const float *__restrict__ x, const float *__restrict__ lse_post,
+    const float *__restrict__ lse_prior, const float *__restrict__ g_logprob,
+    const float *__restrict__ G_tt, const float *__restrict__ G_ml,
+    float *__restrict__ g_templates, float *__restrict__ g_alpha_partial,
+    float *__restrict__ g_pose, float *__restrict__ g_presence,
+    float *__restrict__ g_bg_image, float *__restrict__ g_scalar_partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int M = d.M, K = M + 1, HW = d.H * d.W, tsz = d.th * d.tw;
+  const bool alpha_mode = d.templates_alpha != nullptr;
+  const int Cm = alpha_mode ? 1 : C;
+  const Scalars sc = load_scalars(d);
+  const float inv_T = 1.f / sc.temperature;
+
+  float *s_tmpl = smem;                 // C*tsz
+  float *s_alpha = s_tmpl + C * tsz;    // tsz
+  float *s_gtmpl = s_alpha + tsz;       // C*tsz
+  float *s_galpha = s_gtmpl + C * tsz;  // tsz
+  float *s_red = s_galpha + tsz;        // 10 * (NT/64)
+
+  const bool is_bg = (k == M);
+  float a[6] = {0, 0, 0, 0, 0, 0};
+  float lsp = 0.f;
+  if (!is_bg) {
+    const float *g_tmpl = d.templates + (size_t)(b * M + k) * C * tsz;
+    for (int i = tid; i < C * tsz; i += NT) {
+      s_tmpl[i] = g_tmpl[i];
+      s_gtmpl[i] = 0.f;
+    }
+    for (int i = tid; i < tsz; i += NT) {
+      s_alpha[i] = alpha_mode ? d.templates_alpha[(size_t)k * tsz + i] : 0.f;
+      s_galpha[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = d.pose[(size_t)(b * M + k) * 6 + i];
+    lsp = d.presence ? log_safe(d.presence[b * M + k]) : 0.f;
+  }
+  __syncthreads();
+
+  // accumulators: 6 pose grads, d/d log_safe(presence), bg_value, bg_ml,
+  // temperature, sigma
+  float acc[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) acc[i] = 0.f;
+
+  for (int p = tid; p < HW; p += NT) {
+    Taps t;
+    float tv[C], tdx[C], tdy[C];
+    float av = 0.f, adx = 0.f, ady = 0.f;
+    if (!is_bg) {
+      make_taps(a, p, d.W, d.H, d.tw, d.th, t);
+#pragma unroll
+      for (int c = 0; c < C; ++c) tap_value_grad(s_tmpl + c * tsz, t, tv[c], tdx[c], tdy[c]);
+      if (alpha_mode) tap_value_grad(s_alpha, t, av, adx, ady);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        tv[c] = d.bg_image ? d.bg_image[(size_t)(b * C + c) * HW + p] : sc.bg_val;
+    }
+
+    float gtt[C];
+    float gml_alpha = 0.f;  // alpha mode: grad wrt the (single-channel) logit
+    if (FUSED) {
+      float mlv = 0.f, sp = 0.f;
+      if (alpha_mode) {
+        mlv = (is_bg ? sc.bg_ml : av + lsp);
+        sp = expf(mlv - lse_prior[(size_t)b * HW + p]);
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const size_t o = (size_t)(b * C + c) * HW + p;
+        const float gc = g_logprob[o];
+        if (!alpha_mode) {
+          mlv = tv[c] / sc.temperature + lsp;
+          sp = expf(mlv - lse_prior[o]);
+        }
+        const float diff = x[o] - tv[c];
+        const float lp =
+            -(diff * diff) * (0.5f * sc.inv_var) - sc.log_sigma - scae::kHalfLog2Pi;
+        const float w = expf(lp + mlv - lse_post[o]);
+        gtt[c] = gc * w * diff * sc.inv_var;
+        const float gml = gc * (w - sp);
+        acc[10] += gc * w * (diff * diff * sc.inv_var - 1.f) / sc.sigma;
+        if (alpha_mode) {
+          gml_alpha += gml;
+        } else {
+          gtt[c] += gml * inv_T;
+          acc[9] += -gml * tv[c] * inv_T * inv_T;
+          acc[6] += gml;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        gtt[c] = G_tt ? G_tt[((size_t)(b * K + k) * C + c) * HW + p] : 0.f;
+        if (!alpha_mode && G_ml) {
+          const float gml = G_ml[((size_t)(b * K + k) * C + c) * HW + p];
+          gtt[c] += gml * inv_T;
+          acc[9] += -gml * tv[c] * inv_T * inv_T;
+          acc[6] += gml;
+        }
+      }
+      if (alpha_mode && G_ml) gml_alpha = G_ml[(size_t)(b * K + k) * HW + p];
+    }
+    if (alpha_mode) acc[6] += gml_alpha;
+
+    if (is_bg) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (d.bg_image) {
+          if (g_bg_image) g_bg_image[(size_t)(b * C + c) * HW + p] = gtt[c];
+        } else {
+          acc[7] += gtt[c];
+        }
+      }
+      acc[8] += gml_alpha;
+    } else {
+      float gix = gml_alpha * adx, giy = gml_alpha * ady;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        gix += gtt[c] * tdx[c];
+        giy += gtt[c] * tdy[c];
+        if (gtt[c] != 0.f) tap_scatter(s_gtmpl + c * tsz, t, gtt[c]);
+      }
+      if (alpha_mode && gml_alpha != 0.f) tap_scatter(s_galpha, t, gml_alpha);
+      gix *= 0.5f * d.tw;
+      giy *= 0.5f * d.th;
+      acc[0] += gix * t.xn;
+      acc[1] += gix * t.yn;
+      acc[2] += gix;
+      acc[3] += giy * t.xn;
+      acc[4] += giy * t.yn;
+      acc[5] += giy;
+    }
+  }
+
+  scae::block_sum<11, NT>(acc, s_red);  // ends with __syncthreads()
+
+  if (!is_bg) {
+    float *o_t = g_templates + (size_t)(b * M + k) * C * tsz;
+    for (int i = tid; i < C * tsz; i += NT) o_t[i] = s_gtmpl[i];
+    if (alpha_mode) {
+      float *o_a = g_alpha_partial + (size_t)(b * M + k) * tsz;
+      for (int i = tid; i < tsz; i += NT) o_a[i] = s_galpha[i];
+    }
+  }
+  if (tid == 0) {
+    float *sp = g_scalar_partial + (size_t)(b * K + k) * 4;
+    sp[0] = sp[1] = sp[2] = sp[3] = 0.f;
+    if (!is_bg) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g_pose[(size_t)(b * M + k) * 6 + i] = acc[i];
+      if (g_presence && d.presence)
+        g_presence[b * M + k] = acc[6] * scae::log_safe_grad(d.presence[b * M + k]);
+    } else {
+      if (!d.bg_image) {
+        const float s = sc.bg_val;
+        sp[0] = acc[7] * s * (1.f - s);
+      }
+      if (alpha_mode) sp[1] = acc[8] * scae::softplus_grad(d.bg_mixing_logit[0]);
+    }
+    if (!alpha_mode) sp[2] = acc[9] * scae::softplus_grad(d.temperature_logit[0] + .5f);
+    if (FUSED && d.out_scale) sp[3] = acc[10] * scae::softplus_grad(d.out_scale[0]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// generic mixture over materialised (B,K,C,P) tensors: one lane per (b, p)
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(NT) void gmm_logprob_fwd_kernel(
+    const float *__restrict__ loc, const float *__restrict__ ml,
+    const float *__restrict__ sigma_p, const float *__restrict__ x,
+    float *__restrict__ out, int K, int Cm, int64_t P) {
+  const int b = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (p >= P) return;
+  const float sigma = sigma_p[0], inv_var = 1.f / (sigma * sigma), ls = logf(sigma);
+  float xv[C];
+  scae::Lse post[C], prior[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    xv[c] = x[((size_t)b * C + c) * P + p];
+    post[c].init();
+    prior[c].init();
+  }
+  for (int k = 0; k < K; ++k) {
+    float mlv = 0.f;
+    if (Cm == 1) {
+      mlv = ml[((size_t)b * K + k) * P + p];
+      prior[0].add(mlv);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (Cm != 1) {
+        mlv = ml[(((size_t)b * K + k) * C + c) * P + p];
+        prior[c].add(mlv);
+      }
+      const float diff = xv[c] - loc[(((size_t)b * K + k) * C + c) * P + p];
+      post[c].add(-(diff * diff) * (0.5f * inv_var) - ls - scae::kHalfLog2Pi + mlv);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+    out[((size_t)b * C + c) * P + p] = post[c].value() - prior[Cm == 1 ? 0 : c].value();
+}
+
+template <int C>
+__global__ __launch_bounds__(NT) void gmm_logprob_bwd_kernel(
+    const float *__restrict__ loc, const float *__restrict__ ml,
+    const float *__restrict__ sigma_p, const float *__restrict__ x,
+    const float *__restrict__ g, float *__restrict__ g_loc, float *__restrict__ g_ml,
+    float *__restrict__ g_sigma_partial, float *__restrict__ g_x, int K, int Cm,
+    int64_t P) {
+  __shared__ float s_red[NT / 64];
+  const int b = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
+  const bool live = p < P;
+  const float sigma = sigma_p[0], inv_var = 1.f / (sigma * sigma), ls = logf(sigma);
+  float gsig[1] = {0.f};
+  if (live) {
+    float xv[C], gv[C], gx[C];
+    scae::Lse post[C], prior[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      xv[c] = x[((size_t)b * C + c) * P + p];
+      gv[c] = g[((size_t)b * C + c) * P + p];
+      gx[c] = 0.f;
+      post[c].init();
+      prior[c].init();
+    }
+    for (int k = 0; k < K; ++k) {
+      float mlv = 0.f;
+      if (Cm == 1) {
+        mlv = ml[((size_t)b * K + k) * P + p];
+        prior[0].add(mlv);
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (Cm != 1) {
+          mlv = ml[(((size_t)b * K + k) * C + c) * P + p];
+          prior[c].add(mlv);
+        }
+        const float diff = xv[c] - loc[(((size_t)b * K + k) * C + c) * P + p];
+        post[c].add(-(diff * diff) * (0.5f * inv_var) - ls - scae::kHalfLog2Pi + mlv);
+      }
+    }
+    float lpost[C], lprior[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      lpost[c] = post[c].value();
+      lprior[c] = prior[Cm == 1 ? 0 : c].value();
+    }
+    for (int k = 0; k < K; ++k) {
+      float mlv = 0.f, gml1 = 0.f;
+      if (Cm == 1) mlv = ml[((size_t)b * K + k) * P + p];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const size_t o = (((size_t)b * K + k) * C + c) * P + p;
+        if (Cm != 1) mlv = ml[o];
+        const float diff = xv[c] - loc[o];
+        const float w = expf(-(diff * diff) * (0.5f * inv_var) - ls - scae::kHalfLog2Pi +
+                             mlv - lpost[c]);
+        const float sp = expf(mlv - lprior[c]);
+        const float gl = gv[c] * w * diff * inv_var;
+        g_loc[o] = gl;
+        gx[c] -= gl;
+        gsig[0] += gv[c] * w * (diff * diff * inv_var - 1.f) / sigma;
+        if (Cm != 1)
+          g_ml[o] = gv[c] * (w - sp);
+        else
+          gml1 += gv[c] * (w - sp);
+      }
+      if (Cm == 1) g_ml[((size_t)b * K + k) * P + p] = gml1;
+    }
+    if (g_x) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) g_x[((size_t)b * C + c) * P + p] = gx[c];
+    }
+  }
+  scae::block_sum<1, NT>(gsig, s_red);
+  if (threadIdx.x == 0) atomicAdd(&g_sigma_partial[b], gsig[0]);
+}
+
+template <int C, bool MODE>
+__global__ __launch_bounds__(NT) void gmm_mean_mode_kernel(
+    const float *__restrict__ loc, const float *__restrict__ ml,
+    const float *__restrict__ sigma_p, float *__restrict__ out, int maximum, int K,
+    int Cm, int64_t P) {
+  const int b = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (p >= P) return;
+  if (MODE) {
+    // argmax over K of log_softmax(ml) (+ log N(loc; loc, sigma), a constant
+    // per component here) -- first maximum wins, like torch.argmax on CPU.
+    (void)sigma_p;
+    (void)maximum;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int cm = (Cm == 1) ? 0 : c;
+      float best = -INFINITY;
+      int bk = 0;
+      for (int k = 0; k < K; ++k) {
+        const float v = ml[(((size_t)b * K + k) * Cm + cm) * P + p];
+        if (v > best) {
+          best = v;
+          bk = k;
+        }
+      }
+      out[((size_t)b * C + c) * P + p] = loc[(((size_t)b * K + bk) * C + c) * P + p];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int cm = (Cm == 1) ? 0 : c;
+      float m = -INFINITY;
+      for (int k = 0; k < K; ++k)
+        m = fmaxf(m, ml[(((size_t)b * K + k) * Cm + cm) * P + p]);
+      float s = 0.f, acc = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float e = expf(ml[(((size_t)b * K + k) * Cm + cm) * P + p] - m);
+        s += e;
+        acc += e * loc[(((size_t)b * K + k) * C + c) * P + p];
+      }
+      out[((size_t)b * C + c) * P + p] = acc / s;
+    }
+  }
+}
+
+int check_desc(const scae_decoder_desc *d) {
+  if (!d || !d->templates || !d->pose) return SCAE_ERR_BAD_ARG;
+  if (d->B <= 0 || d->M <= 0 || d->C <= 0 || d->th <= 0 || d->tw <= 0 || d->H <= 0 ||
+      d->W <= 0)
+    return SCAE_ERR_BAD_ARG;
+  if (!d->bg_image && !d->bg_value) return SCAE_ERR_BAD_ARG;
+  if (d->templates_alpha && !d->bg_mixing_logit) return SCAE_ERR_BAD_ARG;
+  if (!d->templates_alpha && !d->temperature_logit) return SCAE_ERR_BAD_ARG;
+  if (d->C > SCAE_MAX_CHANNELS) return SCAE_ERR_UNSUPPORTED;
+  if ((d->C + 1) * d->th * d->tw > SCAE_RENDER_MAX_TEMPLATE_ELEMS) return SCAE_ERR_UNSUPPORTED;
+  return SCAE_OK;
+}
+
+template <typename KernelT>
+int set_lds(KernelT kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return SCAE_ERR_UNSUPPORTED;
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return SCAE_OK;
+}
+
+}  // namespace
+
+extern "C" int scae_template_render_fwd_f32(const scae_decoder_desc *d,
+                                            float *transformed_templates,
+                                            float *mixing_logits, void *stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  SCAE_REQUIRE(transformed_templates && mixing_logits);
+  const size_t lds = sizeof(float) * (size_t)(d->C + 1) * d->th * d->tw;
+  hipLaunchKernelGGL(render_fwd_kernel, dim3(d->M + 1, d->B), dim3(NT), lds,
+                     (hipStream_t)stream, *d, transformed_templates, mixing_logits);
+  return scae_launch_status();
+}
+
+namespace {
+template <int C>
+int launch_logprob_fwd(const scae_decoder_desc *d, const float *x, float *log_prob,
+                       float *lse_post, float *lse_prior, hipStream_t st) {
+  const int HW = d->H * d->W, tsz = d->th * d->tw;
+  const size_t lds = sizeof(float) * ((size_t)d->M * d->C * tsz +
+                                      (d->templates_alpha ? (size_t)d->M * tsz : 0) +
+                                      (size_t)d->M * 7);
+  // component split across lanes: more lanes per pixel when the batch alone
+  // cannot fill 256 CUs
+  const long pixels = (long)d->B * HW;
+  const int ksplit = pixels >= 256L * 1024 * 4 ? 1 : (pixels >= 256L * 1024 ? 2 : 4);
+  int ppb = 4 * NT / ksplit;  // four pixel rounds per workgroup amortise the LDS fill
+  if (ppb > HW) ppb = ((HW + (NT / ksplit) - 1) / (NT / ksplit)) * (NT / ksplit);
+  const dim3 grid((HW + ppb - 1) / ppb, d->B);
+  int rc;
+#define SCAE_LAUNCH_LP(KS)                                                            \
+  rc = set_lds(logprob_fwd_kernel<C, KS>, lds);                                       \
+  if (rc) return rc;                                                                  \
+  hipLaunchKernelGGL((logprob_fwd_kernel<C, KS>), grid, dim3(NT), lds, st, *d, x,     \
+                     log_prob, lse_post, lse_prior, ppb)
+  if (ksplit == 1) {
+    SCAE_LAUNCH_LP(1);
+  } else if (ksplit == 2) {
+    SCAE_LAUNCH_LP(2);
+  } else {
+    SCAE_LAUNCH_LP(4);
+  }
+#undef SCAE_LAUNCH_LP
+  return scae_launch_status();
+}
+
+template <int C>
+int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post,
+               const float *lse_prior, const float *g_logprob, const float *g_tt,
+               const float *g_ml, float *g_templates, float *g_alpha_partial,
+               float *g_pose, float *g_presence, float *g_bg_image,
+               float *g_scalar_partial, hipStream_t st) {
+  const int tsz = d->th * d->tw;
+  const size_t lds = sizeof(float) * (2 * (size_t)(d->C + 1) * tsz + 11 * (NT / 64));
+  const dim3 grid(d->M + 1, d->B);
+  const bool fused = (g_tt == nullptr && g_ml == nullptr);
+  int rc;
+  if (fused) {
+    rc = set_lds(render_bwd_kernel<C, true>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((render_bwd_kernel<C, true>), grid, dim3(NT), lds, st, *d, x,
+                       lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,
+                       g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial);
+  } else {
+    rc = set_lds(render_bwd_kernel<C, false>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((render_bwd_kernel<C, false>), grid, dim3(NT), lds, st, *d, x,
+                       lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,
+                       g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial);
+  }
+  return scae_launch_status();
+}
+}  // namespace
+
+#define SCAE_DISPATCH_C(Cval, CALL)  \
+  switch (Cval) {                    \
+    case 1: return CALL(1);          \
+    case 2: return CALL(2);          \
+    case 3: return CALL(3);          \
+    case 4: return CALL(4);          \
+    default: return SCAE_ERR_UNSUPPORTED; \
+  }
+
+extern "C" int scae_render_gmm_logprob_fwd_f32(const scae_decoder_desc *d, const float *x,
+                                               float *log_prob, float *lse_post,
+                                               float *lse_prior, void *stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  SCAE_REQUIRE(x && log_prob && lse_post && lse_prior);
+#define CALL(CC) \
+  launch_logprob_fwd<CC>(d, x, log_prob, lse_post, lse_prior, (hipStream_t)stream)
+  SCAE_DISPATCH_C(d->C, CALL)
+#undef CALL
+}
+
+extern "C" int scae_render_gmm_bwd_f32(const scae_decoder_desc *d, const float *x,
+                                       const float *lse_post, const float *lse_prior,
+                                       const float *g_logprob, const float *g_tt,
+                                       const float *g_ml, float *g_templates,
+                                       float *g_alpha_partial, float *g_pose,
+                                       float *g_presence, float *g_bg_image,
+                                       float *g_scalar_partial, void *stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  SCAE_REQUIRE(g_templates && g_pose && g_scalar_partial);
+  if (d->templates_alpha) SCAE_REQUIRE(g_alpha_partial);
+  if (!g_tt && !g_ml) SCAE_REQUIRE(x && lse_post && lse_prior && g_logprob);
+#define CALL(CC)                                                                       \
+  launch_bwd<CC>(d, x, lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,        \
+                 g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,    \
+                 (hipStream_t)stream)
+  SCAE_DISPATCH_C(d->C, CALL)
+#undef CALL
+}
+
+namespace {
+template <int C>
+int launch_gmm_fwd(const float *loc, const float *ml, const float *sigma, const float *x,
+                   float *out, int B, int K, int Cm, int64_t P, hipStream_t st) {
+  const dim3 grid((unsigned)((P + NT - 1) / NT), B);
+  hipLaunchKernelGGL((gmm_logprob_fwd_kernel<C>), grid, dim3(NT), 0, st, loc, ml, sigma, x,
+                     out, K, Cm, P);
+  return scae_launch_status();
+}
+template <int C>
+int launch_gmm_bwd(const float *loc, const float *ml, const float *sigma, const float *x,
+                   const float *g, float *g_loc, float *g_ml, float *g_sigma_partial,
+                   float *g_x, int B, int K, int Cm, int64_t P, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(g_sigma_partial, 0, sizeof(float) * B, st);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((unsigned)((P + NT - 1) / NT), B);
+  hipLaunchKernelGGL((gmm_logprob_bwd_kernel<C>), grid, dim3(NT), 0, st, loc, ml, sigma, x,
+                     g, g_loc, g_ml, g_sigma_partial, g_x, K, Cm, P);
+  return scae_launch_status();
+}
+template <int C>
+int launch_gmm_mm(bool mode, const float *loc, const float *ml, const float *sigma,
+                  float *out, int maximum, int B, int K, int Cm, int64_t P,
+                  hipStream_t st) {
+  const dim3 grid((unsigned)((P + NT - 1) / NT), B);
+  if (mode)
+    hipLaunchKernelGGL((gmm_mean_mode_kernel<C, true>), grid, dim3(NT), 0, st, loc, ml,
+                       sigma, out, maximum, K, Cm, P);
+  else
+    hipLaunchKernelGGL((gmm_mean_mode_kernel<C, false>), grid, dim3(NT), 0, st, loc, ml,
+                       sigma, out, maximum, K, Cm, P);
+  return scae_launch_status();
+}
+int check_gmm(int B, int K, int C, int Cm, int64_t P) {
+  if (B <= 0 || K <= 0 || C <= 0 || P <= 0) return SCAE_ERR_BAD_ARG;
+  if (Cm != 1 && Cm != C) return SCAE_ERR_BAD_ARG;
+  if (C > SCAE_MAX_CHANNELS) return SCAE_ERR_UNSUPPORTED;
+  return SCAE_OK;
+}
+}  // namespace
+
+extern "C" int scae_gmm_log_prob_fwd_f32(const float *loc, const float *mixing_logits,
+                                         const float *sigma, const float *x,
+                                         float *log_prob, int B, int K, int C, int Cm,
+                                         int64_t P, void *stream) {
+  int rc = check_gmm(B, K, C, Cm, P);
+  if (rc) return rc;
+  SCAE_REQUIRE(loc && mixing_logits && sigma && x && log_prob);
+#define CALL(CC) \
+  launch_gmm_fwd<CC>(loc, mixing_logits, sigma, x, log_prob, B, K, Cm, P, (hipStream_t)stream)
+  SCAE_DISPATCH_C(C, CALL)
+#undef CALL
+}
+
+extern "C" int scae_gmm_log_prob_bwd_f32(const float *loc, const float *mixing_logits,
+                                         const float *sigma, const float *x,
+                                         const float *g_logprob, float *g_loc,
+                                         float *g_ml, float *g_sigma_partial, float *g_x,
+                                         int B, int K, int C, int Cm, int64_t P,
+                                         void *stream) {
+  int rc = check_gmm(B, K, C, Cm, P);
+  if (rc) return rc;
+  SCAE_REQUIRE(loc && mixing_logits && sigma && x && g_logprob && g_loc && g_ml &&
+               g_sigma_partial);
+#define CALL(CC)                                                                       \
+  launch_gmm_bwd<CC>(loc, mixing_logits, sigma, x, g_logprob, g_loc, g_ml,             \
+                     g_sigma_partial, g_x, B, K, Cm, P, (hipStream_t)stream)
+  SCAE_DISPATCH_C(C, CALL)
+#undef CALL
+}
+
+extern "C" int scae_gmm_mean_f32(const float *loc, const float *mixing_logits, float *out,
+                                 int B, int K, int C, int Cm, int64_t P, void *stream) {
+  int rc = check_gmm(B, K, C, Cm, P);
+  if (rc) return rc;
+  SCAE_REQUIRE(loc && mixing_logits && out);
+#define CALL(CC)                                                                    \
+  launch_gmm_mm<CC>(false, loc, mixing_logits, nullptr, out, 0, B, K, Cm, P,        \
+                    (hipStream_t)stream)
+  SCAE_DISPATCH_C(C, CALL)
+#undef CALL
+}
+
+extern "C" int scae_gmm_mode_f32(const float *loc, const float *mixing_logits,
+                                 const float *sigma, float *out, int maximum, int B,
+                                 int K, int C, int Cm, int64_t P, void *stream) {
+  int rc = check_gmm(B, K, C, Cm, P);
+  if (rc) return rc;
+  SCAE_REQUIRE(loc && mixing_logits && out);
+  // distributions.py:64-65 adds (B,K,C,..) into (B,K,1,..) in place: the
+  // reference raises for C > 1 there; so do we.
+  if (maximum && Cm == 1 && C > 1) return SCAE_ERR_UNSUPPORTED;
+#define CALL(CC)                                                                    \
+  launch_gmm_mm<CC>(true, loc, mixing_logits, sigma, out, maximum, B, K, Cm, P,     \
+                    (hipStream_t)stream)
+  SCAE_DISPATCH_C(C, CALL)
+#undef CALL
+}

@@ -1,0 +1,95 @@
+"""Hyper-parameter defaults and model assembly (reference:
+torch_scae/factory.py)."""
+from argparse import Namespace
+
+from .object_decoder import CapsuleLayer, CapsuleObjectDecoder
+from .part_decoder import TemplateBasedImageDecoder, TemplateGenerator
+from .part_encoder import CNNEncoder, CapsuleImageEncoder
+from .set_transformer import SetTransformer
+from .stacked_capsule_auto_encoder import SCAE
+
+
+def _section(defaults, overrides, derived=()):
+    overrides = overrides or {}
+    for key in derived:      # the reference asserts these are not overridden
+        assert key not in overrides
+    out = dict(defaults)
+    out.update(overrides)
+    return out
+
+
+def prepare_model_params(image_shape, n_classes, n_part_caps, n_obj_caps,
+                         pcae_cnn_encoder_params=None,
+                         pcae_encoder_params=None,
+                         pcae_template_generator_params=None,
+                         pcae_decoder_params=None,
+                         ocae_encoder_set_transformer_params=None,
+                         ocae_decoder_capsule_params=None, scae_params=None):
+    """Merge user overrides into the defaults of factory.py:33-135 and derive
+    the cross-module sizes."""
+    cnn = _section(dict(input_shape=image_shape, out_channels=[128] * 4,
+                        kernel_sizes=[3, 3, 3, 3], strides=[2, 2, 1, 1],
+                        activate_final=True),
+                   pcae_cnn_encoder_params, ('input_shape',))
+    enc = _section(dict(input_shape=image_shape, n_caps=n_part_caps, n_poses=6,
+                        n_special_features=16, similarity_transform=False),
+                   pcae_encoder_params, ('input_shape',))
+    tgen = _section(dict(n_templates=enc['n_caps'], n_channels=image_shape[0],
+                         template_size=(11, 11), template_nonlin='sigmoid',
+                         dim_feature=enc['n_special_features'],
+                         colorize_templates=True, color_nonlin='sigmoid'),
+                    pcae_template_generator_params,
+                    ('n_templates', 'n_channels', 'dim_feature'))
+    dec = _section(dict(n_templates=tgen['n_templates'],
+                        template_size=tgen['template_size'],
+                        output_size=image_shape[1:], learn_output_scale=False,
+                        use_alpha_channel=True, background_value=True),
+                   pcae_decoder_params,
+                   ('n_templates', 'template_size', 'output_size'))
+    # factory.py:79-86 squares template_size[0] (not h*w); kept as is
+    st_dim_in = (enc['n_poses'] + tgen['dim_feature'] + 1
+                 + tgen['n_channels'] * tgen['template_size'][0]
+                 * tgen['template_size'][0])
+    st = _section(dict(n_layers=3, n_heads=1, dim_in=st_dim_in, dim_hidden=16,
+                       dim_out=256, n_outputs=n_obj_caps, layer_norm=True),
+                  ocae_encoder_set_transformer_params,
+                  ('_ocae_st_dim_in', 'n_obj_caps'))
+    caps = _section(dict(n_caps=st['n_outputs'], dim_feature=st['dim_out'],
+                         n_votes=dec['n_templates'], dim_caps=32,
+                         hidden_sizes=(128,), caps_dropout_rate=0.0,
+                         learn_vote_scale=True, allow_deformations=True,
+                         noise_type='uniform', noise_scale=4.,
+                         similarity_transform=False),
+                    ocae_decoder_capsule_params,
+                    ('n_caps', 'dim_feature', 'n_votes'))
+    scae = _section(dict(n_classes=n_classes, vote_type='enc',
+                         presence_type='enc', stop_grad_caps_input=True,
+                         stop_grad_caps_target=True, caps_ll_weight=1.,
+                         cpr_dynamic_reg_weight=10,
+                         prior_sparsity_loss_type='l2',
+                         prior_within_example_sparsity_weight=2.0,
+                         prior_between_example_sparsity_weight=0.35,
+                         posterior_sparsity_loss_type='entropy',
+                         posterior_within_example_sparsity_weight=0.7,
+                         posterior_between_example_sparsity_weight=0.2),
+                    scae_params, ('n_classes',))
+    return dict(image_shape=image_shape, n_classes=n_classes,
+                n_part_caps=n_part_caps, n_obj_caps=n_obj_caps,
+                pcae_cnn_encoder=cnn, pcae_encoder=enc,
+                pcae_template_generator=tgen, pcae_decoder=dec,
+                ocae_encoder_set_transformer=st, ocae_decoder_capsule=caps,
+                scae=scae)
+
+
+def make_scae(model_params: dict):
+    """config dict -> wired SCAE (factory.py:152-178)."""
+    cfg = Namespace(**prepare_model_params(**model_params))
+    part_encoder = CapsuleImageEncoder(
+        encoder=CNNEncoder(**cfg.pcae_cnn_encoder), **cfg.pcae_encoder)
+    obj_decoder = CapsuleObjectDecoder(CapsuleLayer(**cfg.ocae_decoder_capsule))
+    return SCAE(part_encoder=part_encoder,
+                template_generator=TemplateGenerator(
+                    **cfg.pcae_template_generator),
+                part_decoder=TemplateBasedImageDecoder(**cfg.pcae_decoder),
+                obj_encoder=SetTransformer(**cfg.ocae_encoder_set_transformer),
+                obj_decoder=obj_decoder, **cfg.scae)

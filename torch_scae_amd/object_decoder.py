@@ -1,0 +1,208 @@
+"""Object-capsule decoder on the HIP kernels K3 (votes) and K4 (likelihood)
+(reference: torch_scae/object_decoder.py)."""
+import torch
+import torch.nn as nn
+
+from . import math_ops, ops
+from .general_utils import AttrDict, prod
+from .nn_ext import GroupedMLP
+from .nn_utils import rand_like
+
+
+class CapsuleLayer(nn.Module):
+    """Object capsules -> per-part votes (object_decoder.py:28-240).
+
+    The reference's two Python loops over n_caps tiny MLPs are batched GEMMs
+    here (``GroupedMLP``; checkpoints keep the per-capsule keys), and the
+    split / geometric_transform / 3x3 product / presence / scale chain is one
+    kernel.
+    """
+
+    n_transform_params = 6
+
+    def __init__(self, n_caps, dim_feature, n_votes, dim_caps,
+                 hidden_sizes=(128,), caps_dropout_rate=0.0,
+                 learn_vote_scale=False, allow_deformations=True,
+                 noise_type=None, noise_scale=0., similarity_transform=True):
+        super().__init__()
+        self.n_caps = n_caps
+        self.dim_feature = dim_feature
+        self.hidden_sizes = list(hidden_sizes)
+        self.dim_caps = dim_caps
+        self.caps_dropout_rate = caps_dropout_rate
+        self.n_votes = n_votes
+        self.learn_vote_scale = learn_vote_scale
+        self.allow_deformations = allow_deformations
+        self.noise_type = noise_type
+        self.noise_scale = noise_scale
+        self.similarity_transform = similarity_transform
+
+        self.mlps = GroupedMLP(
+            n_caps, [dim_feature] + self.hidden_sizes + [dim_caps])
+        self.output_shapes = (
+            [n_votes, self.n_transform_params],   # OPR-dynamic
+            [1, self.n_transform_params],         # OVR
+            [1],                                  # per-object presence
+            [n_votes],                            # per-vote presence
+            [n_votes],                            # per-vote scale
+        )
+        self.splits = [prod(s) for s in self.output_shapes]
+        self.n_outputs = sum(self.splits)
+        # bias-free output MLPs: the static part of the OPR is cpr_static
+        self.caps_mlps = GroupedMLP(
+            n_caps, [dim_caps + 1] + self.hidden_sizes + [self.n_outputs],
+            bias=False, ones_input=True)
+        self.caps_bias_list = nn.ParameterList([
+            nn.Parameter(torch.zeros(1, n_caps, *shape))
+            for shape in self.output_shapes[1:]])
+        self.cpr_static = nn.Parameter(
+            torch.zeros(1, n_caps, n_votes, self.n_transform_params))
+
+    def _votes(self, feature, parent_transform=None, parent_presence=None):
+        if parent_transform is not None or parent_presence is not None:
+            raise NotImplementedError(
+                "hierarchical parent_transform / parent_presence are not used "
+                "by SCAE and not built")
+        if self.caps_dropout_rate != 0.0:
+            # the reference deletes `caps_exist` (:152) before reading it (:196)
+            raise NameError("free variable 'caps_exist' referenced before "
+                            "assignment in enclosing scope")
+        if self.noise_type not in (None, False, '', 'uniform', 'logistic'):
+            raise ValueError(f'Invalid noise type: {self.noise_type}')
+        if self.noise_type == 'logistic':
+            raise NotImplementedError("LogisticNormal presence noise "
+                                      "(object_decoder.py:203) is not built")
+        B = feature.shape[0]
+        raw_caps_param = self.mlps(feature)                      # (B, O, D)
+        all_param = self.caps_mlps(raw_caps_param)               # (B, O, A)
+        noise_caps = noise_vote = None
+        if self.noise_type == 'uniform':
+            proto = all_param.new_empty(B, self.n_caps, 1)
+            noise_caps = rand_like(proto)
+            noise_vote = rand_like(all_param.new_empty(B, self.n_caps,
+                                                       self.n_votes))
+        return ops.capsule_votes(
+            all_param, self.cpr_static, *self.caps_bias_list,
+            noise_caps=noise_caps, noise_vote=noise_vote,
+            noise_scale=self.noise_scale,
+            similarity=self.similarity_transform,
+            learn_vote_scale=self.learn_vote_scale,
+            allow_deformations=self.allow_deformations)
+
+    def forward(self, feature, parent_transform=None, parent_presence=None):
+        """feature [B, O, F] -> AttrDict(vote (B,O,V,3,3), scale,
+        vote_presence, presence_logit_per_caps, presence_logit_per_vote,
+        cpr_dynamic_reg_loss)."""
+        vote6, scale, vote_presence, logit_caps, logit_vote, reg = \
+            self._votes(feature, parent_transform, parent_presence)
+        last_row = vote6.new_tensor([0., 0., 1.]).expand(*vote6.shape[:-1], 3)
+        vote = torch.cat([vote6, last_row], -1).view(*vote6.shape[:-1], 3, 3)
+        return AttrDict(vote=vote, scale=scale, vote_presence=vote_presence,
+                        presence_logit_per_caps=logit_caps,
+                        presence_logit_per_vote=logit_vote,
+                        cpr_dynamic_reg_loss=reg)
+
+
+class CapsuleLikelihood:
+    """Capsule voting mechanism (object_decoder.py:243-372)."""
+
+    def __init__(self, vote, scale, vote_presence, dummy_vote):
+        self.n_caps = vote.shape[1]
+        self.vote = vote                      # (B, O, M, P)
+        self.scale = scale                    # (B, O, M)
+        self.vote_presence = vote_presence    # (B, O, M)
+        self.dummy_vote = dummy_vote          # (1, 1, M, P)
+
+    def __call__(self, x, presence=None):     # (B, M, P), (B, M)
+        batch_size, n_input_points, dim_in = x.shape
+        if dim_in != 6 or self.vote.shape[-1] != 6:
+            raise ValueError("the capsule likelihood kernel is built for "
+                             "6-dim poses")
+        (lpp, binary, winner, winner_presence, _widx, is_from_capsule,
+         soft_winner, soft_winner_presence, posterior, mixing_log_prob,
+         mixing_logit) = ops.capsule_likelihood(
+            self.vote, self.scale, self.vote_presence, self.dummy_vote, x,
+            presence.float() if presence is not None else None)
+        return AttrDict(
+            log_prob=lpp.sum() / batch_size,
+            vote_presence_binary=binary,
+            winner=winner,
+            winner_presence=winner_presence,
+            soft_winner=soft_winner,
+            soft_winner_presence=soft_winner_presence,
+            posterior_mixing_prob=posterior[:, :-1],
+            mixing_log_prob=mixing_log_prob,
+            mixing_logit=mixing_logit,
+            is_from_capsule=is_from_capsule,
+        )
+
+
+class CapsuleObjectDecoder(nn.Module):
+    def __init__(self, capsule_layer: CapsuleLayer):
+        super().__init__()
+        self.capsule_layer = capsule_layer
+        self.dummy_vote = nn.Parameter(torch.zeros(
+            1, 1, capsule_layer.n_votes, capsule_layer.n_transform_params))
+
+    @property
+    def n_obj_capsules(self):
+        return self.capsule_layer.n_caps
+
+    def forward(self, obj_encoding: torch.Tensor, part_pose: torch.Tensor,
+                part_presence: torch.Tensor = None):
+        """obj_encoding [B, O, D], part_pose [B, M, P], part_presence [B, M]
+        or None -> AttrDict (object_decoder.py:393-428)."""
+        vote, scale, vote_presence, logit_caps, logit_vote, reg = \
+            self.capsule_layer._votes(obj_encoding)
+        res = AttrDict(vote=vote,             # (B, O, V, 6): rows 0..1 only
+                       scale=scale, vote_presence=vote_presence,
+                       presence_logit_per_caps=logit_caps,
+                       presence_logit_per_vote=logit_vote,
+                       cpr_dynamic_reg_loss=reg)
+        res.caps_presence = res.vote_presence.max(-1)[0]
+        likelihood = CapsuleLikelihood(vote=res.vote, scale=res.scale,
+                                       vote_presence=res.vote_presence,
+                                       dummy_vote=self.dummy_vote)
+        res.update(likelihood(part_pose, presence=part_presence))
+        return res
+
+
+def capsule_l2_loss(caps_presence, n_classes: int,
+                    within_example_constant=None, **unused_kwargs):
+    """l2 penalty on capsule activations (object_decoder.py:433-452)."""
+    del unused_kwargs
+    batch_size, num_caps = caps_presence.shape
+    if within_example_constant is None:
+        within_example_constant = float(num_caps) / n_classes
+    within_example = torch.mean(
+        (caps_presence.sum(1) - within_example_constant) ** 2)
+    between_example_constant = float(batch_size) / n_classes
+    between_example = torch.mean(
+        (caps_presence.sum(0) - between_example_constant) ** 2)
+    return within_example, between_example
+
+
+def capsule_entropy_loss(caps_presence, k=1, **unused_kwargs):
+    """entropy of capsule activations (object_decoder.py:456-471)."""
+    del unused_kwargs
+    within_prob = math_ops.normalize(caps_presence, 1)
+    within_example = math_ops.cross_entropy_safe(within_prob, within_prob * k)
+    between_prob = math_ops.normalize(torch.sum(caps_presence, 0), 0)
+    between_example = math_ops.cross_entropy_safe(between_prob,
+                                                  between_prob * k)
+    return within_example, -between_example
+
+
+def neg_capsule_kl(caps_presence, **unused_kwargs):
+    """object_decoder.py:475-479."""
+    del unused_kwargs
+    return capsule_entropy_loss(caps_presence, k=int(caps_presence.shape[-1]))
+
+
+def sparsity_loss(loss_type, *args, **kwargs):
+    """object_decoder.py:482-493."""
+    table = dict(l2=capsule_l2_loss, entropy=capsule_entropy_loss,
+                 kl=neg_capsule_kl)
+    if loss_type not in table:
+        raise ValueError(f"Invalid sparsity loss: {loss_type}")
+    return table[loss_type](*args, **kwargs)

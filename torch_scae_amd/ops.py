@@ -1,0 +1,496 @@
+"""torch.autograd bridges to the HIP kernels of libscae_hip.so.
+
+Each Function here is the host side of one C-ABI launcher pair in
+``include/scae_hip.h``.  PyTorch only owns device memory and streams: buffers
+are ``torch.empty`` allocations, kernels are enqueued on the calling thread's
+current HIP stream (so everything composes with ``torch.cuda.graph`` capture
+and with autograd's backward thread).  No op has a CPU or eager fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DecoderDesc, ScaeHipError
+
+__all__ = ["geometric_transform", "qkv_attention", "capsule_votes",
+           "capsule_likelihood", "render_templates", "render_gmm_log_prob",
+           "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
+
+
+def _need_hip(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ScaeHipError(
+                "torch_scae_amd ops run only on a HIP device (got a "
+                f"{t.device} tensor); there is no CPU path.")
+        if t.dtype != torch.float32:
+            raise ScaeHipError(f"float32 expected, got {t.dtype}")
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(ref):
+    return ctypes.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+
+def _detached(t):
+    return None if t is None else t.detach()
+
+
+# ----------------------------------------------------------------------------
+# K5 geometric_transform (cv_ops.py:20-76)
+# ----------------------------------------------------------------------------
+class _GeometricTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose, similarity, nonlinear, as_matrix):
+        _need_hip(pose)
+        pose = pose.contiguous()
+        n = pose.numel() // 6
+        out = torch.empty(*pose.shape[:-1], 9 if as_matrix else 6,
+                          device=pose.device, dtype=pose.dtype)
+        if n:
+            _lib.call("scae_geometric_transform_fwd_f32", _p(pose), _p(out), n,
+                      int(similarity), int(nonlinear), int(as_matrix),
+                      _stream(pose))
+        ctx.save_for_backward(pose)
+        ctx.flags = (int(similarity), int(nonlinear), int(as_matrix))
+        if as_matrix:
+            out = out.view(*pose.shape[:-1], 3, 3)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (pose,) = ctx.saved_tensors
+        n = pose.numel() // 6
+        gpose = torch.empty_like(pose)
+        if n:
+            gout = gout.contiguous()
+            _lib.call("scae_geometric_transform_bwd_f32", _p(pose), _p(gout),
+                      _p(gpose), n, *ctx.flags, _stream(pose))
+        return gpose, None, None, None
+
+
+def geometric_transform(pose, similarity=False, nonlinear=True,
+                        as_matrix=False):
+    if pose.shape[-1] != 6:
+        raise ValueError("pose tensor must have 6 entries in its last dim")
+    return _GeometricTransform.apply(pose, similarity, nonlinear, as_matrix)
+
+
+# ----------------------------------------------------------------------------
+# K2 qkv_attention (set_transformer.py:24-47)
+# ----------------------------------------------------------------------------
+class _QKVAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, presence):
+        _need_hip(q, k, v, presence)
+        q, k, v, presence = _c(q), _c(k), _c(v), _c(presence)
+        HB, N, dk = q.shape
+        M, dv = v.shape[1], v.shape[2]
+        out = torch.empty(HB, N, dv, device=q.device, dtype=q.dtype)
+        probs = torch.empty(HB, N, M, device=q.device, dtype=q.dtype)
+        sqrt_dk = float(np.float32(np.sqrt(dk)))
+        _lib.call("scae_qkv_attention_fwd_f32", _p(q), _p(k), _p(v),
+                  _p(presence), _p(out), _p(probs), HB, N, M, dk, dv, sqrt_dk,
+                  _stream(q))
+        ctx.save_for_backward(q, k, v, probs)
+        ctx.has_presence = presence is not None
+        ctx.sqrt_dk = sqrt_dk
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, k, v, probs = ctx.saved_tensors
+        HB, N, dk = q.shape
+        M, dv = v.shape[1], v.shape[2]
+        gout = gout.contiguous()
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        gp = None
+        if ctx.has_presence and ctx.needs_input_grad[3]:
+            gp = torch.empty(HB, M, device=q.device, dtype=q.dtype)
+        _lib.call("scae_qkv_attention_bwd_f32", _p(q), _p(k), _p(v), _p(probs),
+                  _p(gout), _p(gq), _p(gk), _p(gv), _p(gp), HB, N, M, dk, dv,
+                  ctx.sqrt_dk, _stream(q))
+        return gq, gk, gv, gp
+
+
+def qkv_attention(queries, keys, values, presence=None):
+    return _QKVAttention.apply(queries, keys, values, presence)
+
+
+# ----------------------------------------------------------------------------
+# K3 capsule votes (object_decoder.py:160-225)
+# ----------------------------------------------------------------------------
+class _CapsuleVotes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, all_param, cpr_static, b_cvr, b_caps, b_vote, b_scale,
+                noise_caps, noise_vote, noise_scale, similarity,
+                learn_vote_scale, allow_deformations):
+        _need_hip(all_param, cpr_static, b_cvr, b_caps, b_vote, b_scale,
+                  noise_caps, noise_vote)
+        B, O, A = all_param.shape
+        V = (A - 7) // 8
+        args = [_c(t) for t in (all_param, cpr_static, b_cvr, b_caps, b_vote,
+                                b_scale, noise_caps, noise_vote)]
+        dev, dt = all_param.device, all_param.dtype
+        vote = torch.empty(B, O, V, 6, device=dev, dtype=dt)
+        scale = torch.empty(B, O, V, device=dev, dtype=dt)
+        vp = torch.empty(B, O, V, device=dev, dtype=dt)
+        lc = torch.empty(B, O, 1, device=dev, dtype=dt)
+        lv = torch.empty(B, O, V, device=dev, dtype=dt)
+        reg = torch.empty(B, O, device=dev, dtype=dt)
+        flags = (B, O, V, int(similarity), int(learn_vote_scale),
+                 int(allow_deformations))
+        _lib.call("scae_capsule_votes_fwd_f32", *[_p(t) for t in args],
+                  float(noise_scale), _p(vote), _p(scale), _p(vp), _p(lc),
+                  _p(lv), _p(reg), *flags, _stream(all_param))
+        ctx.save_for_backward(*[t for t in args if t is not None])
+        ctx.has_noise = (args[6] is not None, args[7] is not None)
+        ctx.noise_scale = float(noise_scale)
+        ctx.flags = flags
+        reg_loss = reg.sum() / 2 / B          # l2_loss(.)/B, :170
+        ctx.set_materialize_grads(False)
+        return vote, scale, vp, lc, lv, reg_loss
+
+    @staticmethod
+    def backward(ctx, gvote, gscale, gvp, glc, glv, greg):
+        saved = list(ctx.saved_tensors)
+        args = saved[:6]
+        args.append(saved.pop(6) if ctx.has_noise[0] else None)
+        args.append(saved[6] if ctx.has_noise[1] else None)
+        all_param = args[0]
+        B, O, V = ctx.flags[:3]
+        gall = torch.empty_like(all_param)
+        gin = torch.empty(B, O, V, 6, device=all_param.device,
+                          dtype=all_param.dtype)
+        grads = [_c(g) for g in (gvote, gscale, gvp, glc, glv, greg)]
+        _lib.call("scae_capsule_votes_bwd_f32", *[_p(t) for t in args],
+                  ctx.noise_scale, *[_p(g) for g in grads], _p(gall), _p(gin),
+                  *ctx.flags, _stream(all_param))
+        gsum = gall.sum(0)                     # (O, A): bias gradients
+        g_static = gin.sum(0).view_as(args[1])
+        g_cvr = gsum[:, 6 * V:6 * V + 6].reshape(args[2].shape)
+        g_caps = gsum[:, 6 * V + 6].reshape(args[3].shape)
+        g_vote = gsum[:, 6 * V + 7:7 * V + 7].reshape(args[4].shape)
+        g_scale = gsum[:, 7 * V + 7:].reshape(args[5].shape)
+        return (gall, g_static, g_cvr, g_caps, g_vote, g_scale, None, None,
+                None, None, None, None)
+
+
+def capsule_votes(all_param, cpr_static, bias_cvr, bias_caps, bias_vote,
+                  bias_scale, noise_caps=None, noise_vote=None, noise_scale=0.,
+                  similarity=False, learn_vote_scale=True,
+                  allow_deformations=True):
+    """-> vote (B,O,V,6), scale, vote_presence, presence_logit_per_caps
+    (B,O,1), presence_logit_per_vote (B,O,V), cpr_dynamic_reg_loss ()."""
+    return _CapsuleVotes.apply(all_param, cpr_static, bias_cvr, bias_caps,
+                               bias_vote, bias_scale, noise_caps, noise_vote,
+                               noise_scale, similarity, learn_vote_scale,
+                               allow_deformations)
+
+
+# ----------------------------------------------------------------------------
+# K4 capsule likelihood (object_decoder.py:257-372)
+# ----------------------------------------------------------------------------
+class _CapsuleLikelihood(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vote, scale, vp, dummy_vote, x, presence):
+        _need_hip(vote, scale, vp, dummy_vote, x, presence)
+        vote, scale, vp, dummy_vote, x, presence = (
+            _c(t) for t in (vote, scale, vp, dummy_vote, x, presence))
+        B, O, M, _ = vote.shape
+        dev, dt = vote.device, vote.dtype
+        f = lambda *s: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        lpp, binary = f(B, M), f(B, O, M)
+        winner, winner_p = f(B, M, 6), f(B, M)
+        widx = torch.empty(B, M, device=dev, dtype=torch.int64)
+        from_caps = torch.empty(B, M, device=dev, dtype=torch.int64)
+        soft, soft_p = f(B, M, 6), f(B, M)
+        post, mlp, mlogit = f(B, O + 1, M), f(B, O + 1, M), f(B, O + 1, M)
+        _lib.call("scae_capsule_likelihood_fwd_f32", _p(vote), _p(scale),
+                  _p(vp), _p(dummy_vote), _p(x), _p(presence), _p(lpp),
+                  _p(binary), _p(winner), _p(winner_p), _p(widx),
+                  _p(from_caps), _p(soft), _p(soft_p), _p(post), _p(mlp),
+                  _p(mlogit), B, O, M, _stream(vote))
+        saved = [vote, scale, vp, dummy_vote, x, post, widx]
+        if presence is not None:
+            saved.append(presence)
+        ctx.save_for_backward(*saved)
+        ctx.has_presence = presence is not None
+        ctx.dims = (B, O, M)
+        ctx.dummy_shape = dummy_vote.shape
+        ctx.mark_non_differentiable(binary, widx, from_caps)
+        ctx.set_materialize_grads(False)
+        return (lpp, binary, winner, winner_p, widx, from_caps, soft, soft_p,
+                post, mlp, mlogit)
+
+    @staticmethod
+    def backward(ctx, g_lpp, _gb, g_w, g_wp, _gi, _gf, g_s, g_sp, g_post,
+                 g_mlp, g_mlogit):
+        saved = ctx.saved_tensors
+        vote, scale, vp, dummy_vote, x, post, widx = saved[:7]
+        presence = saved[7] if ctx.has_presence else None
+        B, O, M = ctx.dims
+        gvote, gscale, gvp = (torch.empty_like(t) for t in (vote, scale, vp))
+        gx = torch.empty_like(x)
+        gpres = torch.empty(B, M, device=x.device, dtype=x.dtype) \
+            if presence is not None else None
+        gdummy = torch.empty(B, M, 6, device=x.device, dtype=x.dtype)
+        gin = [_c(g) for g in (g_lpp, g_w, g_wp, g_s, g_sp, g_post, g_mlp,
+                               g_mlogit)]
+        _lib.call("scae_capsule_likelihood_bwd_f32", _p(vote), _p(scale),
+                  _p(vp), _p(dummy_vote), _p(x), _p(presence), _p(post),
+                  _p(widx), *[_p(g) for g in gin], _p(gvote), _p(gscale),
+                  _p(gvp), _p(gx), _p(gpres), _p(gdummy), B, O, M,
+                  _stream(vote))
+        return (gvote, gscale, gvp, gdummy.sum(0).view(ctx.dummy_shape), gx,
+                gpres)
+
+
+def capsule_likelihood(vote, scale, vote_presence, dummy_vote, x,
+                       presence=None):
+    """-> (log_prob_per_point (B,M), vote_presence_binary, winner,
+    winner_presence, winner_idx, is_from_capsule, soft_winner,
+    soft_winner_presence, posterior (B,O+1,M), mixing_log_prob, mixing_logit)"""
+    return _CapsuleLikelihood.apply(vote, scale, vote_presence, dummy_vote, x,
+                                    presence)
+
+
+# ----------------------------------------------------------------------------
+# K1 template render + mixture likelihood (part_decoder.py:174-237,
+# distributions.py:34-47)
+# ----------------------------------------------------------------------------
+class DecoderInputs:
+    """The compact description of one TemplateBasedImageDecoder call."""
+
+    FIELDS = ("templates", "templates_alpha", "pose", "presence", "bg_image",
+              "bg_value", "bg_mixing_logit", "temperature_logit", "out_scale")
+
+    def __init__(self, output_size, **tensors):
+        self.output_size = tuple(output_size)
+        for f in self.FIELDS:
+            setattr(self, f, tensors.get(f))
+
+    def tensors(self):
+        return [getattr(self, f) for f in self.FIELDS]
+
+
+def _make_desc(tensors, output_size):
+    (templates, alpha, pose, presence, bg_image, bg_value, bg_ml, temp,
+     out_scale) = tensors
+    B, M, C, th, tw = templates.shape
+    H, W = output_size
+    d = DecoderDesc(_p(templates), _p(alpha), _p(pose), _p(presence),
+                    _p(bg_image), _p(bg_value), _p(bg_ml), _p(temp),
+                    _p(out_scale), B, M, C, th, tw, H, W)
+    return d, (B, M, C, th, tw, H, W)
+
+
+def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
+                      g_lp, g_tt, g_ml):
+    (templates, alpha, pose, presence, bg_image, bg_value, bg_ml, temp,
+     out_scale) = ctx_tensors
+    d, (B, M, C, th, tw, H, W) = _make_desc(ctx_tensors, output_size)
+    dev, dt = templates.device, templates.dtype
+    g_templates = torch.empty_like(templates)
+    g_alpha_p = torch.empty(B, M, th, tw, device=dev, dtype=dt) \
+        if alpha is not None else None
+    g_pose = torch.empty_like(pose)
+    g_presence = torch.empty_like(presence) if presence is not None else None
+    g_bg_image = torch.empty_like(bg_image) if bg_image is not None else None
+    g_scal = torch.empty(B, M + 1, 4, device=dev, dtype=dt)
+    _lib.call("scae_render_gmm_bwd_f32", ctypes.byref(d), _p(x), _p(lse_post),
+              _p(lse_prior), _p(g_lp), _p(g_tt), _p(g_ml), _p(g_templates),
+              _p(g_alpha_p), _p(g_pose), _p(g_presence), _p(g_bg_image),
+              _p(g_scal), _stream(templates))
+    gs = g_scal.sum((0, 1))
+    return (g_templates,
+            None if alpha is None else g_alpha_p.sum(0).view_as(alpha),
+            g_pose, g_presence, g_bg_image,
+            None if bg_value is None else gs[0:1].view_as(bg_value),
+            None if bg_ml is None else gs[1:2].view_as(bg_ml),
+            None if temp is None else gs[2:3].view_as(temp),
+            None if out_scale is None else gs[3:4].view_as(out_scale))
+
+
+def _prep_decoder(tensors):
+    _need_hip(*tensors)
+    tensors = [_c(_detached(t)) for t in tensors]
+    if tensors[1] is not None:                      # templates_alpha (1,M,1,h,w)
+        tensors[1] = tensors[1].reshape(-1, *tensors[1].shape[-2:])
+    return tensors
+
+
+class _RenderTemplates(torch.autograd.Function):
+    """materialising path: (transformed_templates, mixing_logits)."""
+
+    @staticmethod
+    def forward(ctx, output_size, *tensors):
+        t = _prep_decoder(tensors)
+        d, (B, M, C, th, tw, H, W) = _make_desc(t, output_size)
+        dev, dt = t[0].device, t[0].dtype
+        Cm = 1 if t[1] is not None else C
+        tt = torch.empty(B, M + 1, C, H, W, device=dev, dtype=dt)
+        ml = torch.empty(B, M + 1, Cm, H, W, device=dev, dtype=dt)
+        _lib.call("scae_template_render_fwd_f32", ctypes.byref(d), _p(tt),
+                  _p(ml), _stream(t[0]))
+        ctx.save_for_backward(*[x for x in t if x is not None])
+        ctx.present = [x is not None for x in t]
+        ctx.output_size = output_size
+        ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
+        ctx.set_materialize_grads(False)
+        return tt, ml
+
+    @staticmethod
+    def backward(ctx, g_tt, g_ml):
+        if g_tt is None and g_ml is None:
+            return (None,) * 10
+        it = iter(ctx.saved_tensors)
+        t = [next(it) if p else None for p in ctx.present]
+        grads = _decoder_backward(t, ctx.output_size, ctx.needs_input_grad,
+                                  None, None, None, None, _c(g_tt), _c(g_ml))
+        grads = list(grads)
+        if grads[1] is not None:
+            grads[1] = grads[1].view(ctx.alpha_shape)
+        return (None, *grads)
+
+
+class _RenderGmmLogProb(torch.autograd.Function):
+    """fused path: log_prob(x) from the compact decoder inputs."""
+
+    @staticmethod
+    def forward(ctx, output_size, x, *tensors):
+        t = _prep_decoder(tensors)
+        _need_hip(x)
+        x = x.detach().contiguous()
+        d, (B, M, C, th, tw, H, W) = _make_desc(t, output_size)
+        dev, dt = t[0].device, t[0].dtype
+        Cm = 1 if t[1] is not None else C
+        lp = torch.empty(B, C, H, W, device=dev, dtype=dt)
+        lse_post = torch.empty(B, C, H, W, device=dev, dtype=dt)
+        lse_prior = torch.empty(B, Cm, H, W, device=dev, dtype=dt)
+        _lib.call("scae_render_gmm_logprob_fwd_f32", ctypes.byref(d), _p(x),
+                  _p(lp), _p(lse_post), _p(lse_prior), _stream(x))
+        ctx.save_for_backward(x, lse_post, lse_prior,
+                              *[v for v in t if v is not None])
+        ctx.present = [v is not None for v in t]
+        ctx.output_size = output_size
+        ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
+        return lp
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        x, lse_post, lse_prior = ctx.saved_tensors[:3]
+        it = iter(ctx.saved_tensors[3:])
+        t = [next(it) if p else None for p in ctx.present]
+        grads = list(_decoder_backward(t, ctx.output_size, ctx.needs_input_grad,
+                                       x, lse_post, lse_prior,
+                                       g_lp.contiguous(), None, None))
+        if grads[1] is not None:
+            grads[1] = grads[1].view(ctx.alpha_shape)
+        # the reconstruction target gets no gradient on this path (the
+        # reference feeds it the input image, which never requires grad)
+        return (None, None, *grads)
+
+
+def render_templates(inputs: DecoderInputs):
+    return _RenderTemplates.apply(inputs.output_size, *inputs.tensors())
+
+
+def render_gmm_log_prob(inputs: DecoderInputs, x):
+    B, M, C = inputs.templates.shape[:3]
+    if tuple(x.shape) != (B, C, *inputs.output_size):
+        raise ValueError(f"log_prob target must be {(B, C, *inputs.output_size)}"
+                         f", got {tuple(x.shape)}")
+    if x.requires_grad:
+        raise ScaeHipError("fused log_prob does not differentiate w.r.t. its "
+                           "target; use the materialised mixture for that")
+    return _RenderGmmLogProb.apply(inputs.output_size, x, *inputs.tensors())
+
+
+# ----------------------------------------------------------------------------
+# generic mixture over materialised tensors (distributions.py:34-77)
+# ----------------------------------------------------------------------------
+def _gmm_dims(loc, ml):
+    B, K, C = loc.shape[:3]
+    Cm = ml.shape[2]
+    P = int(np.prod(loc.shape[3:])) if loc.dim() > 3 else 1
+    if ml.shape[0] != B or ml.shape[1] != K or ml.shape[3:] != loc.shape[3:] \
+            or Cm not in (1, C):
+        raise ScaeHipError(f"unsupported mixture shapes loc {tuple(loc.shape)}"
+                           f" logits {tuple(ml.shape)}")
+    return B, K, C, Cm, P
+
+
+class _GmmLogProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc, ml, sigma, x):
+        _need_hip(loc, ml, sigma, x)
+        loc, ml, sigma, x = _c(loc), _c(ml), _c(sigma), _c(x)
+        B, K, C, Cm, P = _gmm_dims(loc, ml)
+        out = torch.empty_like(x)
+        _lib.call("scae_gmm_log_prob_fwd_f32", _p(loc), _p(ml), _p(sigma),
+                  _p(x), _p(out), B, K, C, Cm, P, _stream(loc))
+        ctx.save_for_backward(loc, ml, sigma, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, ml, sigma, x = ctx.saved_tensors
+        B, K, C, Cm, P = _gmm_dims(loc, ml)
+        g = g.contiguous()
+        g_loc, g_ml = torch.empty_like(loc), torch.empty_like(ml)
+        g_sig = torch.empty(B, device=loc.device, dtype=loc.dtype)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[3] else None
+        _lib.call("scae_gmm_log_prob_bwd_f32", _p(loc), _p(ml), _p(sigma),
+                  _p(x), _p(g), _p(g_loc), _p(g_ml), _p(g_sig), _p(g_x), B, K,
+                  C, Cm, P, _stream(loc))
+        return g_loc, g_ml, g_sig.sum().view_as(sigma), g_x
+
+
+def _check_gmm_x(loc, x):
+    if tuple(x.shape) != (loc.shape[0], *loc.shape[2:]):
+        raise ScaeHipError(f"x {tuple(x.shape)} does not match loc "
+                           f"{tuple(loc.shape)}")
+
+
+def gmm_log_prob(loc, mixing_logits, sigma, x):
+    """loc (B,K,C,*), mixing_logits (B,K,1|C,*), sigma 1-element tensor."""
+    if sigma.numel() != 1:
+        raise ScaeHipError("only a scalar mixture scale is supported")
+    _check_gmm_x(loc, x)
+    return _GmmLogProb.apply(loc, mixing_logits, sigma.reshape(1), x)
+
+
+def gmm_mean(loc, mixing_logits):
+    _need_hip(loc, mixing_logits)
+    loc, ml = _c(loc.detach()), _c(mixing_logits.detach())
+    B, K, C, Cm, P = _gmm_dims(loc, ml)
+    out = torch.empty(B, *loc.shape[2:], device=loc.device, dtype=loc.dtype)
+    _lib.call("scae_gmm_mean_f32", _p(loc), _p(ml), _p(out), B, K, C, Cm, P,
+              _stream(loc))
+    return out
+
+
+def gmm_mode(loc, mixing_logits, sigma, maximum=False):
+    _need_hip(loc, mixing_logits, sigma)
+    loc, ml = _c(loc.detach()), _c(mixing_logits.detach())
+    B, K, C, Cm, P = _gmm_dims(loc, ml)
+    if maximum and Cm == 1 and C > 1:
+        # same failure as the reference's in-place broadcast, distributions.py:65
+        raise RuntimeError(f"output with shape {list(ml.shape)} doesn't match "
+                           f"the broadcast shape {list(loc.shape)}")
+    out = torch.empty(B, *loc.shape[2:], device=loc.device, dtype=loc.dtype)
+    _lib.call("scae_gmm_mode_f32", _p(loc), _p(ml), _p(_c(sigma.detach())),
+              _p(out), int(maximum), B, K, C, Cm, P, _stream(loc))
+    return out

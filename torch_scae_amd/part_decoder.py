@@ -1,0 +1,118 @@
+"""Template-based part decoder on the HIP kernel K1 (reference:
+torch_scae/part_decoder.py)."""
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .distributions import GaussianMixture, _NormalView
+from .general_utils import AttrDict, prod
+from .nn_ext import MLP, relu1
+from .nn_utils import choose_activation
+
+
+class TemplateGenerator(nn.Module):
+    """Learned templates, optionally coloured per capsule from its features
+    (part_decoder.py:31-110)."""
+
+    def __init__(self, n_templates, n_channels, template_size,
+                 template_nonlin='relu1', dim_feature=None,
+                 colorize_templates=False, color_nonlin='relu1'):
+        super().__init__()
+        self.n_templates = n_templates
+        self.template_size = template_size
+        self.n_channels = n_channels
+        self.template_nonlin = choose_activation(template_nonlin)
+        self.dim_feature = dim_feature
+        self.colorize_templates = colorize_templates
+        self.color_nonlin = choose_activation(color_nonlin)
+
+        # mutually orthogonal templates at init (part_decoder.py:60-69)
+        shape = (1, n_templates, n_channels, *template_size)
+        n_elems = prod(shape[2:])
+        n = max(n_templates, n_elems)
+        basis = np.linalg.qr(np.random.uniform(size=[n, n]))[0]
+        basis = basis[:n_templates, :n_elems].reshape(shape).astype(np.float32)
+        basis = (basis - basis.min()) / (basis.max() - basis.min())
+        self.template_logits = nn.Parameter(torch.from_numpy(basis))
+        if colorize_templates:
+            self.templates_color_mlp = MLP(sizes=[dim_feature, 32, n_channels])
+
+    def forward(self, feature=None, batch_size=None):
+        """feature [B, M, F] or None (+ batch_size) ->
+        AttrDict(raw_templates (1,M,C,h,w), templates (B,M,C,h,w))."""
+        if feature is not None:
+            batch_size = feature.shape[0]
+        raw_templates = self.template_nonlin(self.template_logits)
+        if self.colorize_templates and feature is not None:
+            n_templates = feature.shape[1]
+            color = self.templates_color_mlp(
+                feature.reshape(batch_size * n_templates, -1))
+            if self.color_nonlin == relu1:
+                color = color + .99      # out of place (part_decoder.py:97-98)
+            color = self.color_nonlin(color).view(batch_size, n_templates, -1)
+            templates = raw_templates * color[:, :, :, None, None]
+        else:
+            templates = raw_templates.repeat(batch_size, 1, 1, 1, 1)
+        return AttrDict(raw_templates=raw_templates, templates=templates)
+
+
+class TemplateBasedImageDecoder(nn.Module):
+    """Affine-warps every template (and its alpha map) into the image frame
+    and returns the per-pixel Gaussian mixture over the M templates plus a
+    background component (part_decoder.py:113-243)."""
+
+    def __init__(self, n_templates: int, template_size: Tuple[int, int],
+                 output_size: Tuple[int, int], learn_output_scale=False,
+                 use_alpha_channel=False, background_value=True):
+        super().__init__()
+        self.n_templates = n_templates
+        self.template_size = template_size
+        self.output_size = output_size
+        self.learn_output_scale = learn_output_scale
+        self.use_alpha_channel = use_alpha_channel
+        self.background_value = background_value
+
+        if use_alpha_channel:
+            self.templates_alpha = nn.Parameter(
+                torch.zeros(1, n_templates, 1, *template_size))
+        else:
+            self.temperature_logit = nn.Parameter(torch.rand(1))
+        if learn_output_scale:
+            self.scale = nn.Parameter(torch.rand(1))
+        self.bg_mixing_logit = nn.Parameter(torch.tensor([0.0]))
+        if background_value:
+            self.bg_value = nn.Parameter(torch.tensor([0.0]))
+
+    def forward(self, templates, pose, presence=None, bg_image=None):
+        """templates (B,M,C,h,w), pose [B,M,6], presence [B,M] or None,
+        bg_image [B,C,H,W] or None -> AttrDict(transformed_templates
+        (B,M+1,C,H,W), mixing_logits (B,M+1,1|C,H,W), pdf)."""
+        if bg_image is None and not self.background_value:
+            # the reference reads self.bg_value here (part_decoder.py:192)
+            raise AttributeError("'TemplateBasedImageDecoder' object has no "
+                                 "attribute 'bg_value'")
+        if pose.shape[-1] != 6 or pose.shape[:2] != templates.shape[:2]:
+            raise ValueError("pose must be [B, n_templates, 6]")
+        inputs = ops.DecoderInputs(
+            tuple(self.output_size),
+            templates=templates,
+            templates_alpha=self.templates_alpha if self.use_alpha_channel
+            else None,
+            pose=pose, presence=presence, bg_image=bg_image,
+            bg_value=self.bg_value if self.background_value else None,
+            bg_mixing_logit=self.bg_mixing_logit,
+            temperature_logit=None if self.use_alpha_channel
+            else self.temperature_logit,
+            out_scale=self.scale if self.learn_output_scale else None)
+        transformed_templates, mixing_logits = ops.render_templates(inputs)
+        if self.learn_output_scale:
+            scale = nn.functional.softplus(self.scale) + 1e-4
+        else:
+            scale = torch.ones(1, device=templates.device)
+        pdf = GaussianMixture(_NormalView(transformed_templates, scale),
+                              mixing_logits, _decoder_inputs=inputs)
+        return AttrDict(transformed_templates=transformed_templates,
+                        mixing_logits=mixing_logits, pdf=pdf)

@@ -1,0 +1,79 @@
+"""Part-capsule image encoder (reference: torch_scae/part_encoder.py).
+
+The convolutions stay on MIOpen (they are library GEMM/conv work, not part of
+the hand-written hot path); the pose non-linearity runs on HIP kernel K5."""
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from . import cv_ops
+from .general_utils import AttrDict
+from .nn_ext import Conv2dStack, multiple_attention_pooling_2d
+from .nn_utils import measure_shape, rand_like
+
+
+class CNNEncoder(nn.Module):
+    def __init__(self, input_shape, out_channels, kernel_sizes, strides,
+                 activation=nn.ReLU, activate_final=True):
+        super().__init__()
+        self.network = Conv2dStack(in_channels=input_shape[0],
+                                   out_channels=out_channels,
+                                   kernel_sizes=kernel_sizes, strides=strides,
+                                   activation=activation,
+                                   activate_final=activate_final)
+        self.output_shape = measure_shape(self.network,
+                                          input_shape=input_shape)
+
+    def forward(self, image):
+        return self.network(image)
+
+
+class CapsuleImageEncoder(nn.Module):
+    """image -> per part capsule: pose (6), presence, special features
+    (part_encoder.py:47-113)."""
+
+    def __init__(self, input_shape: Tuple[int, int, int], encoder: CNNEncoder,
+                 n_caps: int, n_poses: int, n_special_features: int = 0,
+                 noise_scale: float = 4., similarity_transform: bool = False):
+        super().__init__()
+        self.input_shape = input_shape
+        self.encoder = encoder
+        self.n_caps = n_caps
+        self.n_poses = n_poses
+        self.n_special_features = n_special_features
+        self.noise_scale = noise_scale
+        self.similarity_transform = similarity_transform
+
+        self.img_embedding_bias = nn.Parameter(
+            torch.zeros(tuple(encoder.output_shape), dtype=torch.float32))
+        self.caps_dim_splits = [n_poses, 1, n_special_features]
+        self.n_total_caps_dims = sum(self.caps_dim_splits)
+        self.att_conv = nn.Conv2d(encoder.output_shape[0],
+                                  n_caps * (self.n_total_caps_dims + 1),
+                                  kernel_size=1, stride=1)
+        self.output_shapes = AttrDict(pose=(n_caps, n_poses),
+                                      presence=(n_caps,),
+                                      feature=(n_caps, n_special_features))
+
+    def forward(self, image):
+        batch_size = image.shape[0]
+        h = self.encoder(image) + self.img_embedding_bias.unsqueeze(0)
+        h = self.att_conv(h)
+        h = multiple_attention_pooling_2d(h, self.n_caps)
+        h = h.view(batch_size, self.n_caps, self.n_total_caps_dims)
+        pose, presence_logit, special_feature = torch.split(
+            h, self.caps_dim_splits, -1)
+        if self.n_special_features == 0:
+            special_feature = None
+        presence_logit = presence_logit.squeeze(-1)
+        if self.training and self.noise_scale > 0.:
+            noise = (rand_like(presence_logit) - .5) * self.noise_scale
+            presence_logit = presence_logit + noise
+        presence = torch.sigmoid(presence_logit)
+        pose = cv_ops.geometric_transform(pose, self.similarity_transform)
+        return AttrDict(pose=pose, presence=presence, feature=special_feature)
+
+
+# BASELINE.json's north star names this class `part_encoder.PCAE`.
+PCAE = CapsuleImageEncoder

@@ -1,0 +1,156 @@
+"""Set-transformer object encoder on the HIP attention kernel K2 (reference:
+torch_scae/set_transformer.py).  Projections, LayerNorm and the feed-forward
+layer are library ops; the masked softmax(QK^T)V core is ``ops.qkv_attention``
+(fp32 MFMA)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def qkv_attention(queries, keys, values, presence=None):
+    """Transformer-like attention with a soft presence mask on the keys.
+
+    queries [B, N, d_k], keys [B, M, d_k], values [B, M, d_v], presence None or
+    [B, M] -> [B, N, d_v]   (set_transformer.py:24-47).
+
+    The mask is the reference's arithmetic, not a -inf shortcut: the kernel
+    subtracts (1 - presence) * 1e32 from the fp32 logits, divides by
+    sqrt(d_k) and takes a max-subtracted softmax.
+    """
+    return ops.qkv_attention(queries, keys, values, presence)
+
+
+class MultiHeadQKVAttention(nn.Module):
+    """Multi-head attention with head-padded projections
+    (set_transformer.py:50-104)."""
+
+    def __init__(self, d_k, d_v, n_heads):
+        super().__init__()
+        self.d_k = d_k
+        self.d_v = d_v
+        self.n_heads = n_heads
+        d_k_p = int(math.ceil(d_k / n_heads)) * n_heads
+        d_v_p = int(math.ceil(d_v / n_heads)) * n_heads
+        self.q_projector = nn.Linear(d_k, d_k_p)
+        self.k_projector = nn.Linear(d_k, d_k_p)
+        self.v_projector = nn.Linear(d_v, d_v_p)
+        self.o_projector = nn.Linear(d_v_p, d_v)
+
+    def forward(self, queries, keys, values, presence=None):
+        assert queries.shape[2] == keys.shape[2]
+        assert keys.shape[1] == values.shape[1]
+        if presence is not None:
+            assert values.shape[:2] == presence.shape
+        B, N = queries.shape[:2]
+        M = values.shape[1]
+        H = self.n_heads
+
+        q = self.q_projector(queries)
+        k = self.k_projector(keys)
+        v = self.v_projector(values)
+        if H > 1:      # (B, n, H*d) -> (H*B, n, d), head-major like the reference
+            q, k, v = (t.view(B, n, H, -1).permute(2, 0, 1, 3)
+                       .reshape(H * B, n, -1)
+                       for t, n in ((q, N), (k, M), (v, M)))
+            if presence is not None:
+                presence = presence.repeat(H, 1)
+        o = qkv_attention(q, k, v, presence)
+        if H > 1:
+            o = o.view(H, B, N, -1).permute(1, 2, 0, 3).reshape(B, N, -1)
+        return self.o_projector(o)
+
+
+class MAB(nn.Module):
+    """Multi-head attention block (set_transformer.py:107-133)."""
+
+    def __init__(self, d, n_heads, layer_norm=False):
+        super().__init__()
+        self.layer_norm = layer_norm
+        self.mqkv = MultiHeadQKVAttention(d_k=d, d_v=d, n_heads=n_heads)
+        if layer_norm:
+            self.ln0 = nn.LayerNorm(d)
+            self.ln1 = nn.LayerNorm(d)
+        self.fc = nn.Linear(d, d)
+
+    def forward(self, queries, keys, presence=None):
+        h = self.mqkv(queries, keys, keys, presence) + queries
+        if presence is not None:
+            assert presence.shape[1] == queries.shape[1] == keys.shape[1]
+            h = h * presence.unsqueeze(-1)
+        if self.layer_norm:
+            h = self.ln0(h)
+        h = h + F.relu(self.fc(h))
+        if self.layer_norm:
+            h = self.ln1(h)
+        return h
+
+
+class SAB(nn.Module):
+    def __init__(self, d, n_heads, layer_norm=False):
+        super().__init__()
+        self.mab = MAB(d=d, n_heads=n_heads, layer_norm=layer_norm)
+
+    def forward(self, x, presence=None):
+        return self.mab(x, x, presence)
+
+
+class ISAB(nn.Module):
+    def __init__(self, d, n_heads, n_inducing_points, layer_norm=False):
+        super().__init__()
+        self.mab0 = MAB(d=d, n_heads=n_heads, layer_norm=layer_norm)
+        self.mab1 = MAB(d=d, n_heads=n_heads, layer_norm=layer_norm)
+        self.I = nn.Parameter(torch.zeros(1, n_inducing_points, d))
+        with torch.no_grad():
+            nn.init.xavier_uniform_(self.I)
+
+    def forward(self, x, presence=None):
+        h = self.mab0(self.I.expand(x.shape[0], -1, -1), x, presence)
+        return self.mab1(x, h)
+
+
+class PMA(nn.Module):
+    def __init__(self, d, n_heads, n_seeds, layer_norm=False):
+        super().__init__()
+        self.mab = MAB(d=d, n_heads=n_heads, layer_norm=layer_norm)
+        self.S = nn.Parameter(torch.zeros(1, n_seeds, d))
+        with torch.no_grad():
+            nn.init.xavier_uniform_(self.S)
+
+    def forward(self, x, presence=None):
+        return self.mab(self.S.expand(x.shape[0], -1, -1), x, presence)
+
+
+class SetTransformer(nn.Module):
+    """Permutation-invariant transformer (set_transformer.py:174-223):
+    fc1 -> n_layers x SAB/ISAB -> fc2 -> attention from learned seeds."""
+
+    def __init__(self, dim_in, dim_hidden, dim_out, n_outputs, n_layers,
+                 n_heads, layer_norm=False, n_inducing_points: int = None):
+        super().__init__()
+        self.fc1 = nn.Linear(dim_in, dim_hidden)
+        if n_inducing_points is None:
+            blocks = [SAB(d=dim_hidden, n_heads=n_heads, layer_norm=layer_norm)
+                      for _ in range(n_layers)]
+        else:
+            blocks = [ISAB(d=dim_hidden, n_heads=n_heads,
+                           n_inducing_points=n_inducing_points,
+                           layer_norm=layer_norm) for _ in range(n_layers)]
+        self.sabs = nn.ModuleList(blocks)
+        self.fc2 = nn.Linear(dim_hidden, dim_out)
+        self.seeds = nn.Parameter(torch.zeros(1, n_outputs, dim_out))
+        with torch.no_grad():
+            nn.init.xavier_uniform_(self.seeds)
+        self.multi_head_attention = MultiHeadQKVAttention(
+            d_k=dim_out, d_v=dim_out, n_heads=n_heads)
+
+    def forward(self, x, presence=None):
+        h = self.fc1(x)
+        for sab in self.sabs:
+            h = sab(h, presence)
+        z = self.fc2(h)
+        seeds = self.seeds.expand(x.shape[0], -1, -1)
+        return self.multi_head_attention(seeds, z, z, presence)

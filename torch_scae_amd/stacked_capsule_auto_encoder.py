@@ -1,0 +1,205 @@
+"""Stacked Capsule Auto-Encoder: wiring + composite loss over the HIP-backed
+blocks (reference: torch_scae/stacked_capsule_auto_encoder.py)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .object_decoder import sparsity_loss
+
+
+class SCAE(nn.Module):
+    """Stacked Capsule Auto-Encoder (constructor arguments and defaults as in
+    stacked_capsule_auto_encoder.py:25-49)."""
+
+    def __init__(self, part_encoder, template_generator, part_decoder,
+                 obj_encoder, obj_decoder, n_classes=None, vote_type='soft',
+                 presence_type='enc', stop_grad_caps_input=True,
+                 stop_grad_caps_target=True, recon_mse_weight=0,
+                 part_caps_sparsity_weight=0., cpr_dynamic_reg_weight=0.,
+                 caps_ll_weight=0., prior_sparsity_loss_type='l2',
+                 prior_within_example_sparsity_weight=0.,
+                 prior_between_example_sparsity_weight=0.,
+                 prior_within_example_constant=None,
+                 posterior_sparsity_loss_type='entropy',
+                 posterior_within_example_sparsity_weight=0.,
+                 posterior_between_example_sparsity_weight=0.,
+                 reconstruct_alternatives=True):
+        super().__init__()
+        self.part_encoder = part_encoder
+        self.template_generator = template_generator
+        self.part_decoder = part_decoder
+        self.obj_encoder = obj_encoder
+        self.obj_decoder = obj_decoder
+        self.n_classes = n_classes
+        self.vote_type = vote_type
+        self.presence_type = presence_type
+        self.stop_grad_caps_input = stop_grad_caps_input
+        self.stop_grad_caps_target = stop_grad_caps_target
+
+        if n_classes:
+            n_obj = obj_decoder.n_obj_capsules
+            self.prior_classifier = nn.Sequential(nn.Linear(n_obj, n_classes),
+                                                  nn.Softmax(-1))
+            self.posterior_classifier = nn.Sequential(
+                nn.Linear(n_obj, n_classes), nn.Softmax(-1))
+        else:
+            self.prior_classifier = None
+            self.posterior_classifier = None
+
+        self.cpr_dynamic_reg_weight = cpr_dynamic_reg_weight
+        self.caps_ll_weight = caps_ll_weight
+        self.recon_mse_weight = recon_mse_weight
+        self.prior_sparsity_loss_type = prior_sparsity_loss_type
+        self.prior_within_example_sparsity_weight = \
+            prior_within_example_sparsity_weight
+        self.prior_between_example_sparsity_weight = \
+            prior_between_example_sparsity_weight
+        self.prior_within_example_constant = prior_within_example_constant
+        self.posterior_sparsity_loss_type = posterior_sparsity_loss_type
+        self.posterior_within_example_sparsity_weight = \
+            posterior_within_example_sparsity_weight
+        self.posterior_between_example_sparsity_weight = \
+            posterior_between_example_sparsity_weight
+        self.part_caps_sparsity_weight = part_caps_sparsity_weight
+        self.reconstruct_alternatives = reconstruct_alternatives
+
+    # -- forward -------------------------------------------------------------
+    def forward(self, image):
+        """image (B,C,H,W) -> AttrDict (stacked_capsule_auto_encoder.py:92-215)."""
+        if self.vote_type not in ('enc', 'soft', 'hard'):
+            raise ValueError(f'Invalid vote_type: {self.vote_type}')
+        if self.presence_type not in ('enc', 'soft', 'hard'):
+            raise ValueError(f'Invalid presence_type: {self.presence_type}')
+        batch_size = image.shape[0]
+        parts = self.part_encoder(image)
+        templates = self.template_generator(feature=parts.feature,
+                                            batch_size=batch_size).templates
+
+        # object encoder input: [pose, 1 - presence | feature | templates];
+        # pose / presence / templates detached, the feature skip-connection
+        # is not (:105-124)
+        part_param = torch.cat([parts.pose,
+                                1. - parts.presence.unsqueeze(-1)], -1)
+        input_presence = parts.presence
+        input_templates = templates
+        if self.stop_grad_caps_input:
+            part_param = part_param.detach()
+            input_presence = input_presence.detach()
+            input_templates = templates.detach()
+        pieces = [part_param]
+        if parts.feature is not None:
+            pieces.append(parts.feature)
+        pieces.append(input_templates.flatten(2))
+        obj_encoding = self.obj_encoder(torch.cat(pieces, -1), input_presence)
+
+        target_pose, target_presence = parts.pose, parts.presence
+        if self.stop_grad_caps_target:
+            target_pose = target_pose.detach()
+            target_presence = target_presence.detach()
+        res = self.obj_decoder(obj_encoding, target_pose, target_presence)
+        res.part_presence = parts.presence
+
+        dec_pose = {'enc': parts.pose, 'soft': res.soft_winner,
+                    'hard': res.winner}[self.vote_type]
+        dec_presence = {'enc': parts.presence,
+                        'soft': res.soft_winner_presence,
+                        'hard': res.winner_presence}[self.presence_type]
+        res.rec = self.part_decoder(templates=templates, pose=dec_pose,
+                                    presence=dec_presence)
+
+        if self.reconstruct_alternatives:      # :164-195
+            with torch.no_grad():
+                res.bottom_up_rec = self.part_decoder(
+                    templates=templates, pose=parts.pose,
+                    presence=parts.presence)
+                res.top_down_rec = self.part_decoder(
+                    templates=templates, pose=res.winner,
+                    presence=parts.presence)
+                n_obj = res.vote.shape[1]
+                td_presence = parts.presence.repeat_interleave(n_obj, dim=0) \
+                    * res.vote_presence_binary.flatten(0, 1)
+                res.top_down_per_caps_rec = self.part_decoder(
+                    templates=templates.repeat_interleave(n_obj, dim=0),
+                    pose=res.vote.flatten(0, 1), presence=td_presence)
+
+        res.templates = templates
+        res.template_presence = parts.presence
+        res.transformed_templates = res.rec.transformed_templates
+
+        if self.n_classes is not None:
+            assert self.prior_classifier is not None
+            assert self.posterior_classifier is not None
+            res.prior_cls_prob = self.prior_classifier(
+                res.caps_presence.detach())
+            # as in the reference (:211) the posterior probabilities also go
+            # through prior_classifier
+            res.posterior_cls_prob = self.prior_classifier(
+                res.posterior_mixing_prob.sum(-1).detach())
+        return res
+
+    # -- loss ----------------------------------------------------------------
+    def loss(self, res, reconstruction_target, label=None):
+        """-> (loss, log dict)   (stacked_capsule_auto_encoder.py:217-287)."""
+        log = dict()
+        rec_ll_per_pixel = res.rec.pdf.log_prob(reconstruction_target)
+        rec_ll = rec_ll_per_pixel.flatten(1).sum(-1).mean()
+        loss = -rec_ll
+        log.update(rec_ll_loss=-rec_ll)
+
+        if self.recon_mse_weight > 0:
+            mse = ((reconstruction_target - res.rec.pdf.mode()) ** 2) \
+                .flatten(1).sum(-1).mean()
+            loss = loss + self.recon_mse_weight * mse
+            log.update(mse=mse)
+
+        if self.part_caps_sparsity_weight > 0:
+            part_caps_l1 = res.part_presence.sum(-1).mean()
+            loss = loss + self.part_caps_sparsity_weight * part_caps_l1
+            log.update(part_caps_loss=part_caps_l1)
+
+        loss = loss - self.caps_ll_weight * res.log_prob
+        log.update(log_prob_loss=-res.log_prob)
+
+        # both sparsity blocks are gated by the PRIOR weights (:243, :258)
+        if self.prior_within_example_sparsity_weight > 0 \
+                or self.prior_between_example_sparsity_weight > 0:
+            within, between = sparsity_loss(
+                self.prior_sparsity_loss_type, res.caps_presence,
+                n_classes=self.n_classes,
+                within_example_constant=self.prior_within_example_constant)
+            loss = loss + (self.prior_within_example_sparsity_weight * within
+                           + self.prior_between_example_sparsity_weight
+                           * between)
+            log.update(prior_within_sparsity_loss=within,
+                       prior_between_sparsity_loss=between)
+
+            n_points = res.posterior_mixing_prob.shape[-1]
+            mass_explained_by_capsule = res.posterior_mixing_prob.sum(-1)
+            within, between = sparsity_loss(
+                self.posterior_sparsity_loss_type,
+                mass_explained_by_capsule / n_points, n_classes=self.n_classes)
+            loss = loss + (
+                self.posterior_within_example_sparsity_weight * within
+                + self.posterior_between_example_sparsity_weight * between)
+            log.update(posterior_within_sparsity_loss=within,
+                       posterior_between_sparsity_loss=between)
+
+        loss = loss + self.cpr_dynamic_reg_weight * res.cpr_dynamic_reg_loss
+        log.update(cpr_dynamic_reg_loss=res.cpr_dynamic_reg_loss)
+
+        if label is not None:
+            assert self.n_classes is not None
+            # cross_entropy over probabilities, as the reference does (:281)
+            prior_cls_xe = F.cross_entropy(res.prior_cls_prob, target=label)
+            posterior_cls_xe = F.cross_entropy(res.posterior_cls_prob,
+                                               target=label)
+            loss = loss + prior_cls_xe + posterior_cls_xe
+            log.update(prior_cls_xe=prior_cls_xe,
+                       posterior_cls_xe=posterior_cls_xe)
+        return loss, log
+
+    def calculate_accuracy(self, res, label: torch.Tensor):
+        prior_acc = (res.prior_cls_prob.argmax(-1) == label).float().mean()
+        posterior_acc = (res.posterior_cls_prob.argmax(-1)
+                         == label).float().mean()
+        return torch.max(prior_acc, posterior_acc)
