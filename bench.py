@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one SCAE training step (forward +
+SCAE.loss + backward [+ gradient all-reduce] + RMSprop step) on synthetic
+MNIST-shaped batches, BASELINE.json's metric / configs[1]:
+MNIST 40x40, 24 part / 24 object capsules, bs=128 per GPU, fp32.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (contract in the task brief), extended with
+  roofline     : the dominant hot-path kernel (K1) timed live with HIP events
+  cpu_baseline : the oracle (CPU restatement of the reference) timed on the
+                 host cores of this box, same config, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[1] (the configuration the metric is quoted on)
+    "mnist_24_24_bs128": dict(
+        model=dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24,
+                   n_obj_caps=24,
+                   scae_params=dict(reconstruct_alternatives=False)),
+        batch=128),
+    # the reference's hydra default (configs/model/mnist.yaml): 40 / 32
+    "mnist_40_32_bs128": dict(
+        model=dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=40,
+                   n_obj_caps=32,
+                   scae_params=dict(reconstruct_alternatives=False)),
+        batch=128),
+    # BASELINE.json configs[4]
+    "cifar_32_32_bs256": dict(
+        model=dict(image_shape=(3, 32, 32), n_classes=10, n_part_caps=32,
+                   n_obj_caps=32,
+                   scae_params=dict(reconstruct_alternatives=False)),
+        batch=256),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="mnist_24_24_bs128",
+                    choices=sorted(CONFIGS))
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    return ap.parse_args()
+
+
+def build_model(cfg, seed):
+    from torch_scae_amd import factory
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return factory.make_scae(cfg["model"])
+
+
+# ----------------------------------------------------------------------------
+def k1_algorithmic_bytes(cfg):
+    """Algorithmic HBM bytes per IMAGE of the three K1 kernels (DESIGN.md,
+    section 'Kernels'; SURVEY.md 8d conventions: compact inputs read once,
+    contract outputs written once, fp32)."""
+    m = cfg["model"]
+    C, H, W = m["image_shape"]
+    M = m["n_part_caps"]
+    K, hw, HW = M + 1, 11 * 11, H * W
+    compact = (M * C * hw + M * hw + 6 * M + M) * 4       # templates, alpha, pose, presence
+    return {
+        "render_fwd_kernel": compact + (K * C * HW + K * HW) * 4,
+        "logprob_fwd_kernel": compact + C * HW * 4 + (2 * C * HW + HW) * 4,
+        "render_bwd_kernel": compact + (3 * C * HW + HW) * 4
+        + (M * C * hw + M * hw + 7 * M + 4 * K) * 4,
+    }
+
+
+def time_k1_kernels(cfg, device, reps=40):
+    """Average duration of each K1 kernel: `reps` back-to-back launches
+    captured in a HIP graph and bracketed by HIP events on the launch stream
+    (torch.cuda.Event records on the stream the kernels are enqueued on)."""
+    from torch_scae_amd import ops
+    from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
+    m = cfg["model"]
+    B = cfg["batch"]
+    C, H, W = m["image_shape"]
+    M = m["n_part_caps"]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    dec = TemplateBasedImageDecoder(M, (11, 11), (H, W),
+                                    use_alpha_channel=True).to(device)
+    with torch.no_grad():
+        dec.templates_alpha.copy_(torch.randn(dec.templates_alpha.shape,
+                                              generator=g) * 0.5)
+    templates = torch.rand(B, M, C, 11, 11, generator=g).to(device)
+    pose = torch.randn(B, M, 6, generator=g) * 0.3
+    pose[:, :, 0] += 1.0
+    pose[:, :, 4] += 1.0
+    pose = pose.to(device)
+    presence = torch.rand(B, M, generator=g).to(device)
+    x = torch.rand(B, C, H, W, generator=g).to(device)
+    inputs = ops.DecoderInputs((H, W), templates=templates,
+                               templates_alpha=dec.templates_alpha.detach(),
+                               pose=pose, presence=presence,
+                               bg_value=dec.bg_value.detach(),
+                               bg_mixing_logit=dec.bg_mixing_logit.detach())
+    req = ops.DecoderInputs((H, W), templates=templates.clone().requires_grad_(),
+                            templates_alpha=dec.templates_alpha.detach(),
+                            pose=pose, presence=presence,
+                            bg_value=dec.bg_value.detach(),
+                            bg_mixing_logit=dec.bg_mixing_logit.detach())
+    glp = torch.ones(B, C, H, W, device=device)
+
+    def render():
+        ops.render_templates(inputs)
+
+    def logprob():
+        ops.render_gmm_log_prob(inputs, x)
+
+    lp = ops.render_gmm_log_prob(req, x)
+
+    def bwd():
+        torch.autograd.grad(lp, req.templates, glp, retain_graph=True)
+
+    out = {}
+    for name, fn in (("render_fwd_kernel", render),
+                     ("logprob_fwd_kernel", logprob),
+                     ("render_bwd_kernel", bwd)):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(reps):
+                fn()
+        graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), \
+            torch.cuda.Event(enable_timing=True)
+        best = float("inf")
+        for _ in range(5):
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        out[name] = best * 1e-3 / reps          # seconds per launch
+        del graph
+    return out
+
+
+def roofline(cfg, device):
+    dur = time_k1_kernels(cfg, device)
+    alg = k1_algorithmic_bytes(cfg)
+    B = cfg["batch"]
+    name = max(dur, key=dur.get)                # the dominant K1 kernel
+    achieved = alg[name] * B / dur[name] / 1e9
+    return {
+        "kernel": name, "bound": "hbm", "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "us_per_launch": round(dur[name] * 1e6, 2),
+        "all_k1_kernels": {
+            k: {"us": round(dur[k] * 1e6, 2),
+                "GBps": round(alg[k] * B / dur[k] / 1e9, 1),
+                "bytes_per_image": alg[k]} for k in dur},
+        "note": "traffic: see profiles/ (rocprofv3 --pmc pass)",
+    }
+
+
+def cpu_baseline(cfg, steps):
+    """The oracle (kind 'port': our CPU restatement of the reference, pinned
+    to reference-captured vectors) timed on this box's host cores."""
+    from oracle import scae_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    model = build_model(cfg, seed=0)
+    sd = model.state_dict()
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = O.prepare_model_params(**cfg["model"])
+    B = cfg["batch"]
+    m = cfg["model"]
+    g = torch.Generator().manual_seed(0)
+    image = torch.rand(B, *m["image_shape"], generator=g)
+    label = torch.randint(0, 10, (B,), generator=g)
+    M, Oc = m["n_part_caps"], m["n_obj_caps"]
+
+    def step():
+        noise = (torch.rand(B, M), torch.rand(B, Oc, 1), torch.rand(B, Oc, M))
+        O.train_step(P, ocfg, image, label, noise)
+
+    for _ in range(3):
+        step()
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(B / med, 1), "unit": "images/sec",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of the same workload (B={B}) after 3 "
+                      f"warm-up, median; fwd+loss+bwd, no optimiser",
+            "ms_per_step": round(med * 1e3, 2)}
+
+
+# ----------------------------------------------------------------------------
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch "
+                         f"with torch.distributed.run --nproc-per-node "
+                         f"{args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from torch_scae_amd.train_step import TrainStep
+    cfg = CONFIGS[args.workload]
+    B = cfg["batch"]
+    model = build_model(cfg, seed=0).to(device).train()
+    step = TrainStep(model, B, cfg["model"]["image_shape"],
+                     use_graph=not args.no_graph,
+                     optimizer=not args.no_optimizer)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    n_batches = 8
+    images = torch.rand(n_batches, B, *cfg["model"]["image_shape"],
+                        generator=g).to(device)
+    labels = torch.randint(0, 10, (n_batches, B), generator=g).to(device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(images[i % n_batches], labels[i % n_batches])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(images[i % n_batches], labels[i % n_batches])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(step.loss)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        result = {
+            "metric": "images/sec SCAE fwd+bwd, MNIST 40x40 bs=128, 1/2/4/8 MI355X",
+            "value": round(B * world * args.steps / elapsed, 1),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": args.workload, "per_gpu_batch": B,
+                "global_batch": B * world,
+                "step": "forward + SCAE.loss + backward"
+                        + (" + RCCL all-reduce of one flat fp32 grad buffer"
+                           if world > 1 else "")
+                        + ("" if args.no_optimizer else " + RMSprop step"),
+                "hip_graph": not args.no_graph,
+                "parallelism": f"dp{world}",
+                "final_loss": round(final_loss, 3),
+            },
+        }
+        if not args.no_roofline:
+            result["roofline"] = roofline(cfg, device)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

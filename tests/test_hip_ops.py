@@ -442,6 +442,9 @@ def test_image_decoder_vs_oracle_full_size(B, M, C, HW, ts, alpha, scale):
                      "grad " + name)
     for k, p in dec.named_parameters():
         ref = P["d." + k].grad
+        if ref is None:          # parameter unused in this mode
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+            continue
         assert_close(p.grad, ref, 1e-4 * max(1.0, float(ref.abs().max())),
                      5e-4, "pgrad " + k)
 

@@ -1,0 +1,74 @@
+"""One SCAE training step = forward + SCAE.loss + backward (+ gradient
+all-reduce + optimiser), optionally captured once into a HIP graph and
+replayed: at B=128 the step is launch-latency bound, so
+removing the per-launch host cost matters more than any single kernel.
+
+Mirrors the semantics of the reference's BaseExperiment.training_step
+(torch_scae_experiments/base_experiment.py:109-126)."""
+import torch
+
+from .data_parallel import (FlatParameters, RMSpropFlat, all_reduce_gradients,
+                            broadcast_parameters, world)
+
+
+class TrainStep:
+    def __init__(self, model, batch_size, image_shape, lr=3e-5, use_graph=True,
+                 optimizer=True):
+        self.model = model
+        self.device = next(model.parameters()).device
+        self.flat = FlatParameters(model)
+        broadcast_parameters(self.flat)
+        # eps = 1e-2 / bs**2 as in configs/optimizer/rmsprop.yaml
+        self.opt = RMSpropFlat(self.flat, lr=lr, momentum=0.9,
+                               eps=1e-2 / float(batch_size) ** 2) \
+            if optimizer else None
+        self.image = torch.zeros(batch_size, *image_shape, device=self.device)
+        self.label = torch.zeros(batch_size, dtype=torch.long,
+                                 device=self.device)
+        self.loss = torch.zeros((), device=self.device)
+        self.use_graph = use_graph
+        self.graph = None
+        self.world = world()[1]
+
+    def _fwd_bwd(self):
+        self.flat.zero_grad()
+        res = self.model(self.image)
+        loss, _ = self.model.loss(res, self.image, self.label)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _finish(self):
+        all_reduce_gradients(self.flat)
+        if self.opt is not None:
+            self.opt.step()
+
+    def _capture(self):
+        # warm up on a side stream (allocator, lazy init), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                self._fwd_bwd()
+                self.flat.rebind_grads()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._fwd_bwd()
+            if self.world == 1:
+                self._finish()
+
+    def __call__(self, image, label):
+        """image / label may be device tensors; copied into the static inputs."""
+        self.image.copy_(image, non_blocking=True)
+        self.label.copy_(label, non_blocking=True)
+        if self.use_graph:
+            if self.graph is None:
+                self._capture()
+            self.graph.replay()
+            if self.world > 1:
+                self._finish()
+        else:
+            self._fwd_bwd()
+            self.flat.rebind_grads()
+            self._finish()
+        return self.loss
