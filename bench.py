@@ -89,79 +89,73 @@ def k1_algorithmic_bytes(cfg):
     }
 
 
-def time_k1_kernels(cfg, device, reps=40):
-    """Average duration of each K1 kernel: `reps` back-to-back launches
-    captured in a HIP graph and bracketed by HIP events on the launch stream
-    (torch.cuda.Event records on the stream the kernels are enqueued on)."""
-    from torch_scae_amd import ops
-    from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
+def time_k1_kernels(cfg, device, reps=200):
+    """Average duration of each K1 kernel: `reps` back-to-back launches through
+    the C ABI on torch's current HIP stream, bracketed by HIP events recorded
+    on that same stream (torch.cuda.Event records on the current stream).
+    All buffers are pre-allocated; nothing else runs in the timed region."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
     m = cfg["model"]
     B = cfg["batch"]
     C, H, W = m["image_shape"]
     M = m["n_part_caps"]
+    K = M + 1
     g = torch.Generator(device="cpu").manual_seed(0)
-    dec = TemplateBasedImageDecoder(M, (11, 11), (H, W),
-                                    use_alpha_channel=True).to(device)
-    with torch.no_grad():
-        dec.templates_alpha.copy_(torch.randn(dec.templates_alpha.shape,
-                                              generator=g) * 0.5)
+    f = lambda *s: torch.empty(*s, device=device)   # noqa: E731
     templates = torch.rand(B, M, C, 11, 11, generator=g).to(device)
+    alpha = (torch.randn(M, 11, 11, generator=g) * 0.5).to(device)
     pose = torch.randn(B, M, 6, generator=g) * 0.3
     pose[:, :, 0] += 1.0
     pose[:, :, 4] += 1.0
     pose = pose.to(device)
     presence = torch.rand(B, M, generator=g).to(device)
     x = torch.rand(B, C, H, W, generator=g).to(device)
-    inputs = ops.DecoderInputs((H, W), templates=templates,
-                               templates_alpha=dec.templates_alpha.detach(),
-                               pose=pose, presence=presence,
-                               bg_value=dec.bg_value.detach(),
-                               bg_mixing_logit=dec.bg_mixing_logit.detach())
-    req = ops.DecoderInputs((H, W), templates=templates.clone().requires_grad_(),
-                            templates_alpha=dec.templates_alpha.detach(),
-                            pose=pose, presence=presence,
-                            bg_value=dec.bg_value.detach(),
-                            bg_mixing_logit=dec.bg_mixing_logit.detach())
+    bg_value = torch.zeros(1, device=device)
+    bg_ml = torch.zeros(1, device=device)
+    tensors = [templates, alpha, pose, presence, None, bg_value, bg_ml, None,
+               None]
+    desc, _ = ops._make_desc(tensors, (H, W))
+    dref = ctypes.byref(desc)
+    tt, ml = f(B, K, C, H, W), f(B, K, 1, H, W)
+    lp, lse_post, lse_prior = f(B, C, H, W), f(B, C, H, W), f(B, 1, H, W)
     glp = torch.ones(B, C, H, W, device=device)
+    g_t, g_a = f(B, M, C, 11, 11), f(B, M, 11, 11)
+    g_pose, g_pres, g_scal = f(B, M, 6), f(B, M), f(B, K, 4)
+    p, st = ops._p, ops._stream(x)
+    lib = _lib.load()
 
     def render():
-        ops.render_templates(inputs)
+        return lib.scae_template_render_fwd_f32(dref, p(tt), p(ml), st)
 
     def logprob():
-        ops.render_gmm_log_prob(inputs, x)
-
-    lp = ops.render_gmm_log_prob(req, x)
+        return lib.scae_render_gmm_logprob_fwd_f32(dref, p(x), p(lp),
+                                                   p(lse_post), p(lse_prior),
+                                                   st)
 
     def bwd():
-        torch.autograd.grad(lp, req.templates, glp, retain_graph=True)
+        return lib.scae_render_gmm_bwd_f32(
+            dref, p(x), p(lse_post), p(lse_prior), p(glp), None, None, p(g_t),
+            p(g_a), p(g_pose), p(g_pres), None, p(g_scal), st)
 
     out = {}
     for name, fn in (("render_fwd_kernel", render),
                      ("logprob_fwd_kernel", logprob),
                      ("render_bwd_kernel", bwd)):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        for _ in range(5):
+            assert fn() == 0
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        best = float("inf")
+        for _ in range(3):
+            e0.record()
             for _ in range(reps):
                 fn()
-        graph.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), \
-            torch.cuda.Event(enable_timing=True)
-        best = float("inf")
-        for _ in range(5):
-            e0.record()
-            graph.replay()
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
         out[name] = best * 1e-3 / reps          # seconds per launch
-        del graph
     return out
 
 
@@ -184,11 +178,24 @@ def roofline(cfg, device):
     }
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the
+    cgroup CPU quota (the GPU box shows 256 logical CPUs but grants 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, steps):
     """The oracle (kind 'port': our CPU restatement of the reference, pinned
     to reference-captured vectors) timed on this box's host cores."""
     from oracle import scae_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     model = build_model(cfg, seed=0)
     sd = model.state_dict()
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}

@@ -136,15 +136,23 @@ def test_scae_vs_oracle_full_size(name):
         if p.grad is None:
             continue
         ref = p.grad
-        # Parameter gradients are sums over the batch of per-sample terms
-        # gated by ~1.5 M ReLU units (every reference MLP ends in a ReLU): a
-        # pre-activation within fp32 round-off of zero flips its gate between
-        # two correct fp32 evaluations and moves one per-sample term by
-        # O(1e-3).  Hence a bound relative to the tensor's scale here; the
-        # kernels' own gradients are held to 1e-4 in test_hip_ops.py and on
-        # the golden models above.
-        assert_close(grads[k], ref, 1e-3 * max(1.0, float(ref.abs().max())),
-                     1e-3, "grad " + k)
+        # Parameter gradients are batch sums of per-sample terms gated by
+        # ~1.5 M ReLU units (every reference MLP ends in a ReLU).  A
+        # pre-activation within fp32 round-off of zero leaves the forward
+        # unchanged (checked to 1e-4 above) but flips that unit's gate between
+        # two equally valid fp32 evaluations, moving ONE sample's contribution
+        # to a few weight rows by O(|grad|/B).  So: all but a sliver of the
+        # entries must meet the 1e-4 bar, and no entry may be off by more than
+        # a single-sample share.  The kernels' own gradients are held to 1e-4
+        # everywhere in test_hip_ops.py and on the golden models above.
+        got = grads[k].detach().cpu()
+        scale = max(1.0, float(ref.abs().max()))
+        err = (got - ref).abs()
+        bad = err > (1e-4 * scale + 1e-3 * ref.abs())
+        assert int(bad.sum()) <= max(8, 2e-2 * bad.numel()), \
+            f"grad {k}: {int(bad.sum())}/{bad.numel()} entries off"
+        assert float(err.max()) <= 4.0 / B * scale, \
+            f"grad {k}: max err {float(err.max()):.3e} (scale {scale:.3e})"
 
 
 def test_scae_forward_is_stochastic_like_the_reference():

@@ -51,8 +51,10 @@ class TrainStep:
                 self._fwd_bwd()
                 self.flat.rebind_grads()
         torch.cuda.current_stream().wait_stream(s)
+        # capture on the SAME stream the warm-up ran on: autograd caches each
+        # parameter's AccumulateGrad node together with its stream
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=s):
             self._fwd_bwd()
             if self.world == 1:
                 self._finish()
