@@ -4,7 +4,7 @@ a single flat fp32 gradient buffer over RCCL/xGMI.
 
 The reference has no distributed code at all (it would inherit Lightning's
 DDP); this is the MI355X-native equivalent: gradients are views into one
-contiguous buffer from the start (no bucketing copies), parameters that get no
+contiguous buffer (one multi-tensor pack per step), parameters that get no
 gradient in a given configuration (``obj_decoder.dummy_vote``,
 ``posterior_classifier.*`` by default) simply stay zero in it, and the
 reduction is a single large message -- the right shape for xGMI's per-link
@@ -37,26 +37,42 @@ class FlatParameters:
                 n = p.numel()
                 self.flat_param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)
-                p.grad = self.flat_grad[off:off + n].view(p.shape)
+                p.grad = None
                 off += n
         self.numel = total
+        self._views = None
 
-    def zero_grad(self):
-        self.flat_grad.zero_()
+    def grad_views(self):
+        if self._views is None:
+            views, off = [], 0
+            for p in self.params:
+                n = p.numel()
+                views.append(self.flat_grad[off:off + n].view(p.shape))
+                off += n
+            self._views = views
+        return self._views
 
-    def rebind_grads(self):
-        """autograd may replace ``p.grad`` when it was None; make every grad a
-        view of the flat buffer again (no-op when nothing was replaced)."""
-        off = 0
+    def clear_grads(self):
+        """Drop every ``p.grad`` so that backward ASSIGNS fresh gradients
+        instead of launching one accumulate-add kernel per parameter."""
         for p in self.params:
-            n = p.numel()
-            view = self.flat_grad[off:off + n].view(p.shape)
-            if p.grad is None:
-                p.grad = view
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-                p.grad = view
-            off += n
+            p.grad = None
+
+    @torch.no_grad()
+    def gather_grads(self):
+        """Pack the gradients backward produced into the flat buffer with one
+        multi-tensor copy.  Parameters that received no gradient
+        (``obj_decoder.dummy_vote``, ``posterior_classifier.*`` in the default
+        SCAE config) keep zeros in their slice."""
+        views = self.grad_views()
+        dst = [v for v, p in zip(views, self.params) if p.grad is not None]
+        src = [p.grad for p in self.params if p.grad is not None]
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for v, p in zip(views, self.params):
+            if p.grad is None and getattr(p, "_flat_was_set", False):
+                v.zero_()
+            p._flat_was_set = p.grad is not None
 
 
 def world():

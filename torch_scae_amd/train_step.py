@@ -31,10 +31,11 @@ class TrainStep:
         self.world = world()[1]
 
     def _fwd_bwd(self):
-        self.flat.zero_grad()
+        self.flat.clear_grads()
         res = self.model(self.image)
         loss, _ = self.model.loss(res, self.image, self.label)
         loss.backward()
+        self.flat.gather_grads()
         self.loss.copy_(loss.detach())
 
     def _finish(self):
@@ -49,7 +50,6 @@ class TrainStep:
         with torch.cuda.stream(s):
             for _ in range(3):
                 self._fwd_bwd()
-                self.flat.rebind_grads()
         torch.cuda.current_stream().wait_stream(s)
         # capture on the SAME stream the warm-up ran on: autograd caches each
         # parameter's AccumulateGrad node together with its stream
@@ -71,6 +71,5 @@ class TrainStep:
                 self._finish()
         else:
             self._fwd_bwd()
-            self.flat.rebind_grads()
             self._finish()
         return self.loss
