@@ -81,6 +81,41 @@ int scae_qkv_attention_bwd_f32(const float *q, const float *k, const float *v,
                                int dv, float sqrt_dk, void *stream);
 
 /* ------------------------------------------------------------------------
+ * K2b  fused set-transformer trunk   replaces set_transformer.py:212-219
+ *      (fc1 -> n_layers x SAB(x, x, presence) -> fc2; SAB/MAB :107-142 with
+ *      n_heads = 1), forward and backward in one launch each.
+ *   input x (B,N,Din) is given as 1..4 column segments (so the caller never
+ *   materialises the reference's torch.cat, stacked_capsule_auto_encoder.py
+ *   :105-124): segment s holds element (b,n,j) at seg_ptr[s][b*batch_stride +
+ *   n*row_stride + j], j < seg_width[s]; sum of widths = Din.
+ *   presence (B,N) nullable.  params: ONE packed buffer,
+ *     [W1 (D,Din), b1 (D)] + per layer [Wq,bq,Wk,bk,Wv,bv,Wo,bo,
+ *     (ln0.weight, ln0.bias), Wf,bf, (ln1.weight, ln1.bias)] + [W2 (Dout,D),
+ *     b2 (Dout)], every matrix row-major (out,in) like nn.Linear.weight;
+ *     scae_set_encoder_param_count() gives its length.
+ *   z (B,N,Dout) = fc2 output; hsave (B,L+1,N,D) workspace kept for backward.
+ *   Limits: N <= 64, D in {8,16,32}, n_heads = 1.
+ *   backward: gz (B,N,Dout) -> seg_grad[s] (B,N,width) contiguous, nullable
+ *   per segment; pg_partial (scae_set_encoder_grid(B), P) per-workgroup
+ *   parameter gradients in the packed layout (caller sums over dim 0).
+ * ---------------------------------------------------------------------- */
+int scae_set_encoder_param_count(int D, int Din, int Dout, int L, int layer_norm);
+int scae_set_encoder_grid(int B);
+/* 1 if the shape fits the kernels (LDS budget of the backward pass), else 0 */
+int scae_set_encoder_supported(int N, int D, int Din, int Dout, int L, int layer_norm);
+int scae_set_encoder_fwd_f32(int nseg, const float *const *seg_ptr, const int *seg_width,
+                             const int *seg_row_stride, const int64_t *seg_batch_stride,
+                             const float *presence, const float *params, float *z,
+                             float *hsave, int B, int N, int D, int Din, int Dout, int L,
+                             int layer_norm, void *stream);
+int scae_set_encoder_bwd_f32(int nseg, const float *const *seg_ptr, const int *seg_width,
+                             const int *seg_row_stride, const int64_t *seg_batch_stride,
+                             float *const *seg_grad, const float *presence,
+                             const float *params, const float *hsave, const float *gz,
+                             float *pg_partial, int B, int N, int D, int Din, int Dout,
+                             int L, int layer_norm, void *stream);
+
+/* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225
  *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
  *   all_param (B,O,A), A = 6V+6+1+2V, the output of the per-capsule MLPs,

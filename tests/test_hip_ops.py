@@ -497,3 +497,67 @@ def test_part_encoder_vs_golden(name, shape, sim, train):
         r = enc(c["in/image"].cuda())
     for k in ("pose", "presence", "feature"):
         assert_close(r[k], c["out/" + k], 2e-5, 1e-4, k)
+
+
+# ----------------------------------------------------------- K2b fused trunk
+@pytest.mark.parametrize("B,N,widths,D,Dout,L,ln,pres", [
+    (128, 24, (7, 16, 121), 16, 256, 3, True, "mixed"),   # cfg-2
+    (9, 32, (7, 16, 363), 16, 256, 3, True, "rand"),      # cfg-5 shape
+    (5, 64, (11,), 16, 70, 2, False, None),               # max set, no LN
+    (4, 64, (11,), 32, 70, 2, False, None),               # over the LDS budget -> unfused path
+    (3, 1, (5, 3), 8, 9, 1, True, "ones"),                # degenerate
+    (300, 10, (13,), 16, 24, 1, True, "mixed"),           # B > grid: block loop
+])
+def test_fused_set_encoder_vs_oracle(B, N, widths, D, Dout, L, ln, pres):
+    from torch_scae_amd.set_transformer import SetTransformer
+    torch.manual_seed(B + N)
+    Din = sum(widths)
+    st = SetTransformer(dim_in=Din, dim_hidden=D, dim_out=Dout, n_outputs=4,
+                        n_layers=L, n_heads=1, layer_norm=ln)
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for p in st.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    P = {"m." + k: v.clone().requires_grad_(True)
+         for k, v in st.state_dict().items()}
+    # segments as strided views of one wider buffer (like the part encoder's
+    # split outputs)
+    wide = torch.randn(B, N, Din + 5, generator=g)
+    p = None
+    if pres == "rand":
+        p = torch.rand(B, N, generator=g)
+    elif pres == "ones":
+        p = torch.ones(B, N)
+    elif pres == "mixed":
+        p = torch.ones(B, N)
+        p[:, ::3] = torch.rand(B, len(range(0, N, 3)), generator=g)
+    w = torch.randn(B, N, Dout, generator=g)
+
+    xc = wide[..., 2:2 + Din].clone().requires_grad_(True)
+    h = O._linear(P, "m.fc1", xc)
+    for l in range(L):
+        h = O.sab(P, f"m.sabs.{l}", h, p, 1, ln)
+    zo = O._linear(P, "m.fc2", h)
+    (zo * w).sum().backward()
+
+    st = st.cuda()
+    wide_g = wide.cuda()
+    segs, col = [], 2
+    for wd in widths:
+        segs.append(wide_g[..., col:col + wd].detach().requires_grad_(True))
+        col += wd
+    zg = st.encode_segments(segs, dev(p))
+    (zg * w.cuda()).sum().backward()
+    assert_close(zg, zo, 1e-4, 1e-4, "z")
+    gx = torch.cat([s.grad for s in segs], -1)
+    assert_close(gx, xc.grad, 1e-4 * max(1.0, float(xc.grad.abs().max())),
+                 2e-4, "gx")
+    sd_grads = {k: q.grad for k, q in st.named_parameters()}
+    for k, q in P.items():
+        name = k[2:]
+        if q.grad is None:
+            continue
+        ref = q.grad
+        assert_close(sd_grads[name], ref,
+                     2e-4 * max(1.0, float(ref.abs().max())), 5e-4,
+                     "grad " + name)

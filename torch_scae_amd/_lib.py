@@ -36,6 +36,12 @@ SIGNATURES = {
                                    c_int, c_int, c_float, P],
     "scae_qkv_attention_bwd_f32": [P, P, P, P, P, P, P, P, P, c_int, c_int,
                                    c_int, c_int, c_int, c_float, P],
+    "scae_set_encoder_param_count": [c_int] * 5,
+    "scae_set_encoder_grid": [c_int],
+    "scae_set_encoder_supported": [c_int] * 6,
+    "scae_set_encoder_fwd_f32": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7 + [P],
+    "scae_set_encoder_bwd_f32": [c_int, P, P, P, P, P, P, P, P, P, P]
+                                + [c_int] * 7 + [P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

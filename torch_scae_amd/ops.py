@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
-__all__ = ["geometric_transform", "qkv_attention", "capsule_votes",
+__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "capsule_votes",
            "capsule_likelihood", "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
@@ -126,6 +126,77 @@ class _QKVAttention(torch.autograd.Function):
 
 def qkv_attention(queries, keys, values, presence=None):
     return _QKVAttention.apply(queries, keys, values, presence)
+
+
+# ----------------------------------------------------------------------------
+# K2b fused set-transformer trunk (set_transformer.py:212-219)
+# ----------------------------------------------------------------------------
+def _seg_arrays(segs):
+    n = len(segs)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in segs])
+    widths = (ctypes.c_int * n)(*[t.shape[2] for t in segs])
+    rs = (ctypes.c_int * n)(*[t.stride(1) for t in segs])
+    bs = (ctypes.c_int64 * n)(*[t.stride(0) for t in segs])
+    return ptrs, widths, rs, bs
+
+
+class _SetEncoder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, presence, packed, meta, *segs):
+        D, Dout, L, layer_norm = meta
+        _need_hip(presence, packed, *segs)
+        segs = [t if t.stride(2) == 1 else t.contiguous() for t in segs]
+        presence, packed = _c(presence), packed.contiguous()
+        B, N = segs[0].shape[:2]
+        Din = sum(t.shape[2] for t in segs)
+        lib = _lib.load()
+        assert packed.numel() == lib.scae_set_encoder_param_count(
+            D, Din, Dout, L, int(layer_norm))
+        z = torch.empty(B, N, Dout, device=packed.device, dtype=packed.dtype)
+        hsave = torch.empty(B, L + 1, N, D, device=packed.device,
+                            dtype=packed.dtype)
+        ptrs, widths, rs, bs = _seg_arrays(segs)
+        _lib.call("scae_set_encoder_fwd_f32", len(segs), ptrs, widths, rs, bs,
+                  _p(presence), _p(packed), _p(z), _p(hsave), B, N, D, Din,
+                  Dout, L, int(layer_norm), _stream(packed))
+        ctx.save_for_backward(packed, hsave, *segs,
+                              *([presence] if presence is not None else []))
+        ctx.has_presence = presence is not None
+        ctx.nseg = len(segs)
+        ctx.dims = (B, N, D, Din, Dout, L, int(layer_norm))
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        packed, hsave = ctx.saved_tensors[:2]
+        segs = list(ctx.saved_tensors[2:2 + ctx.nseg])
+        presence = ctx.saved_tensors[2 + ctx.nseg] if ctx.has_presence else None
+        B, N, D, Din, Dout, L, ln = ctx.dims
+        gz = gz.contiguous()
+        grid = _lib.load().scae_set_encoder_grid(B)
+        partial = torch.empty(grid, packed.numel(), device=packed.device,
+                              dtype=packed.dtype)
+        gsegs = [torch.empty(B, N, t.shape[2], device=t.device, dtype=t.dtype)
+                 if ctx.needs_input_grad[3 + i] else None
+                 for i, t in enumerate(segs)]
+        ptrs, widths, rs, bs = _seg_arrays(segs)
+        gptrs = (ctypes.c_void_p * len(segs))(
+            *[None if g is None else g.data_ptr() for g in gsegs])
+        _lib.call("scae_set_encoder_bwd_f32", len(segs), ptrs, widths, rs, bs,
+                  gptrs, _p(presence), _p(packed), _p(hsave), _p(gz),
+                  _p(partial), B, N, D, Din, Dout, L, ln, _stream(packed))
+        return (None, partial.sum(0), None, *gsegs)
+
+
+def set_encoder(segments, presence, packed_params, dim_hidden, dim_out,
+                n_layers, layer_norm):
+    """fc1 -> n_layers x SAB -> fc2 on a set given as column segments
+    (each (B, N, w_i)); returns (B, N, dim_out)."""
+    if presence is not None and presence.requires_grad:
+        raise ScaeHipError("the fused trunk treats presence as a constant")
+    return _SetEncoder.apply(presence, packed_params,
+                             (dim_hidden, dim_out, n_layers, bool(layer_norm)),
+                             *segments)
 
 
 # ----------------------------------------------------------------------------

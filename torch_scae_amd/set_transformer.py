@@ -147,10 +147,54 @@ class SetTransformer(nn.Module):
         self.multi_head_attention = MultiHeadQKVAttention(
             d_k=dim_out, d_v=dim_out, n_heads=n_heads)
 
-    def forward(self, x, presence=None):
-        h = self.fc1(x)
+    # -- fused trunk ---------------------------------------------------------
+    def _fusable(self, n_items, presence):
+        if not (all(isinstance(b, SAB) for b in self.sabs)
+                and self.multi_head_attention.n_heads == 1
+                and (presence is None or not presence.requires_grad)):
+            return False
+        layer_norm = bool(self.sabs) and self.sabs[0].mab.layer_norm
+        from . import _lib
+        return bool(_lib.load().scae_set_encoder_supported(
+            n_items, self.fc1.out_features, self.fc1.in_features,
+            self.fc2.out_features, len(self.sabs), int(layer_norm)))
+
+    def _packed_trunk(self):
+        """All trunk parameters as one flat buffer in the layout the fused
+        kernel reads (include/scae_hip.h, K2b)."""
+        parts = [self.fc1.weight, self.fc1.bias]
+        for sab in self.sabs:
+            m = sab.mab
+            for lin in (m.mqkv.q_projector, m.mqkv.k_projector,
+                        m.mqkv.v_projector, m.mqkv.o_projector):
+                parts += [lin.weight, lin.bias]
+            if m.layer_norm:
+                parts += [m.ln0.weight, m.ln0.bias]
+            parts += [m.fc.weight, m.fc.bias]
+            if m.layer_norm:
+                parts += [m.ln1.weight, m.ln1.bias]
+        parts += [self.fc2.weight, self.fc2.bias]
+        return torch.cat([p.reshape(-1) for p in parts])
+
+    def encode_segments(self, segments, presence=None):
+        """fc1 -> blocks -> fc2 on the set whose features are the column-wise
+        concatenation of ``segments`` (each (B, N, w)); the concat itself is
+        only materialised on the unfused path."""
+        if segments[0].is_cuda and self._fusable(segments[0].shape[1], presence):
+            layer_norm = bool(self.sabs) and self.sabs[0].mab.layer_norm
+            return ops.set_encoder(segments, presence, self._packed_trunk(),
+                                   self.fc1.out_features,
+                                   self.fc2.out_features, len(self.sabs),
+                                   layer_norm)
+        h = self.fc1(torch.cat(list(segments), -1))
         for sab in self.sabs:
             h = sab(h, presence)
-        z = self.fc2(h)
-        seeds = self.seeds.expand(x.shape[0], -1, -1)
+        return self.fc2(h)
+
+    def forward_segments(self, segments, presence=None):
+        z = self.encode_segments(segments, presence)
+        seeds = self.seeds.expand(z.shape[0], -1, -1)
         return self.multi_head_attention(seeds, z, z, presence)
+
+    def forward(self, x, presence=None):
+        return self.forward_segments([x], presence)

@@ -78,19 +78,22 @@ class SCAE(nn.Module):
         # object encoder input: [pose, 1 - presence | feature | templates];
         # pose / presence / templates detached, the feature skip-connection
         # is not (:105-124)
-        part_param = torch.cat([parts.pose,
-                                1. - parts.presence.unsqueeze(-1)], -1)
-        input_presence = parts.presence
-        input_templates = templates
+        in_pose, in_presence, in_templates = \
+            parts.pose, parts.presence, templates
         if self.stop_grad_caps_input:
-            part_param = part_param.detach()
-            input_presence = input_presence.detach()
-            input_templates = templates.detach()
-        pieces = [part_param]
+            in_pose, in_presence, in_templates = \
+                in_pose.detach(), in_presence.detach(), in_templates.detach()
+        segments = [in_pose, 1. - in_presence.unsqueeze(-1)]
         if parts.feature is not None:
-            pieces.append(parts.feature)
-        pieces.append(input_templates.flatten(2))
-        obj_encoding = self.obj_encoder(torch.cat(pieces, -1), input_presence)
+            segments.append(parts.feature)
+        segments.append(in_templates.flatten(2))
+        if hasattr(self.obj_encoder, "forward_segments"):
+            # fused trunk: the concat is never materialised
+            obj_encoding = self.obj_encoder.forward_segments(segments,
+                                                             in_presence)
+        else:
+            obj_encoding = self.obj_encoder(torch.cat(segments, -1),
+                                            in_presence)
 
         target_pose, target_presence = parts.pose, parts.presence
         if self.stop_grad_caps_target:
