@@ -195,6 +195,39 @@ int scae_capsule_likelihood_bwd_f32(
     int B, int O, int M, void *stream);
 
 /* ------------------------------------------------------------------------
+ * K6  fused tail of SCAE.loss        replaces stacked_capsule_auto_encoder.py
+ *     :238-285 + object_decoder.py:433-493 (+ math_ops.py) and their backward
+ *   lpp (B,M) log_prob_per_point; posterior (B,O+1,M); caps_presence (B,O);
+ *   cls_w (ncls,O), cls_b (ncls): prior_classifier.0 (both classification
+ *   terms go through it, like the reference :207-212); label (B) int64
+ *   nullable (no classification terms).
+ *   prior_type / post_type: 0 'l2', 1 'entropy', 2 'kl'; sparsity_on: the
+ *   reference's gate (prior weights > 0, :243/:258); weights5 (HOST array) =
+ *   [caps_ll, prior_within, prior_between, posterior_within,
+ *   posterior_between]; within_const: prior_within_example_constant or NaN
+ *   (= n_caps/n_classes); n_classes_cfg: SCAE.n_classes (l2 constants).
+ *   out8: [tail loss, log_prob, prior_within, prior_between, post_within,
+ *   post_between, prior_cls_xe, posterior_cls_xe]; tail loss = -w0*log_prob +
+ *   w1*pw + w2*pb + w3*qw + w4*qb + xe + xe.
+ *   backward: gout8 (8) -> g_lpp, g_posterior, g_caps_presence, g_cls_w,
+ *   g_cls_b (classifier inputs are detached in the reference).
+ * ---------------------------------------------------------------------- */
+int scae_loss_tail_supported(int B, int O, int ncls);
+int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
+                           const float *caps_presence, const float *cls_w,
+                           const float *cls_b, const int64_t *label, float *out8, int B,
+                           int O, int M, int ncls, int n_classes_cfg, int prior_type,
+                           int post_type, int sparsity_on, const float *weights5,
+                           float within_const, void *stream);
+int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
+                           const float *caps_presence, const float *cls_w,
+                           const float *cls_b, const int64_t *label, const float *gout8,
+                           float *g_lpp, float *g_posterior, float *g_caps_presence,
+                           float *g_cls_w, float *g_cls_b, int B, int O, int M, int ncls,
+                           int n_classes_cfg, int prior_type, int post_type, int sparsity_on,
+                           const float *weights5, float within_const, void *stream);
+
+/* ------------------------------------------------------------------------
  * K1  template render + Gaussian-mixture image likelihood
  *     replaces part_decoder.py:174-237 (affine_grid + 2x grid_sample +
  *     background + presence), distributions.py:34-47 (mixture log_prob) and

@@ -561,3 +561,59 @@ def test_fused_set_encoder_vs_oracle(B, N, widths, D, Dout, L, ln, pres):
         assert_close(sd_grads[name], ref,
                      2e-4 * max(1.0, float(ref.abs().max())), 5e-4,
                      "grad " + name)
+
+
+# ------------------------------------------------------------- K6 loss tail
+@pytest.mark.parametrize("prior,post,use_label,const", [
+    ("l2", "entropy", True, None),       # the default SCAE config
+    ("entropy", "l2", True, 1.5),
+    ("kl", "kl", False, None),
+    ("l2", "l2", True, None),
+])
+def test_loss_tail_vs_oracle(prior, post, use_label, const):
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Oc, M, ncls = 128, 24, 24, 10
+    lpp = torch.randn(B, M, generator=g)
+    post_full = torch.softmax(torch.randn(B, Oc + 1, M, generator=g), 1)
+    cp = torch.rand(B, Oc, generator=g)
+    cp[0, 0] = 0.0
+    W = torch.randn(ncls, Oc, generator=g) * 0.3
+    bb = torch.randn(ncls, generator=g) * 0.1
+    label = torch.randint(0, ncls, (B,), generator=g)
+    weights = [1.0, 2.0, 0.35, 0.7, 0.2]
+
+    def ref(lpp, post_full, cp, W, bb):
+        log_prob = lpp.sum() / B
+        pw, pb = O.sparsity_loss(prior, cp, n_classes=ncls,
+                                 within_example_constant=const)
+        mass = post_full[:, :-1].sum(-1)
+        qw, qb = O.sparsity_loss(post, mass / M, n_classes=ncls)
+        tot = -weights[0] * log_prob + weights[1] * pw + weights[2] * pb \
+            + weights[3] * qw + weights[4] * qb
+        xe1 = xe2 = torch.zeros(())
+        if use_label:
+            import torch.nn.functional as F
+            p1 = torch.softmax(F.linear(cp.detach(), W, bb), -1)
+            p2 = torch.softmax(F.linear(mass.detach(), W, bb), -1)
+            xe1, xe2 = F.cross_entropy(p1, label), F.cross_entropy(p2, label)
+            tot = tot + xe1 + xe2
+        return torch.stack([tot, log_prob, pw, pb, qw, qb, xe1, xe2])
+
+    ins_c = [t.clone().requires_grad_(True) for t in (lpp, post_full, cp, W, bb)]
+    out_c = ref(*ins_c)
+    out_c[0].backward()
+    ins_g = [leaf(t) for t in (lpp, post_full, cp, W, bb)]
+    out_g = ops.loss_tail(ins_g[0], ins_g[1], ins_g[2], ins_g[3], ins_g[4],
+                          label.cuda() if use_label else None, ncls, prior,
+                          post, True, weights, const)
+    out_g[0].backward()
+    assert_close(out_g, out_c, 1e-4, 1e-4, "tail outputs")
+    names = ("lpp", "posterior", "caps_presence", "cls_w", "cls_b")
+    for nme, a, b in zip(names, ins_g, ins_c):
+        if b.grad is None:
+            assert a.grad is None or float(a.grad.abs().sum()) == 0.0, nme
+            continue
+        assert_close(a.grad, b.grad,
+                     1e-4 * max(1.0, float(b.grad.abs().max())), 2e-4,
+                     "grad " + nme)

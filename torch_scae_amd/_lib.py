@@ -48,6 +48,9 @@ SIGNATURES = {
                                   + [c_int] * 6 + [P],
     "scae_capsule_likelihood_fwd_f32": [P] * 17 + [c_int] * 3 + [P],
     "scae_capsule_likelihood_bwd_f32": [P] * 22 + [c_int] * 3 + [P],
+    "scae_loss_tail_supported": [c_int] * 3,
+    "scae_loss_tail_fwd_f32": [P] * 7 + [c_int] * 8 + [POINTER(c_float), c_float, P],
+    "scae_loss_tail_bwd_f32": [P] * 12 + [c_int] * 8 + [POINTER(c_float), c_float, P],
     "scae_template_render_fwd_f32": [POINTER(DecoderDesc), P, P, P],
     "scae_render_gmm_logprob_fwd_f32": [POINTER(DecoderDesc), P, P, P, P, P],
     "scae_render_gmm_bwd_f32": [POINTER(DecoderDesc)] + [P] * 12 + [P],

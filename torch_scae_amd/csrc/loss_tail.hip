@@ -1,0 +1,411 @@
+// K6 -- fused tail of SCAE.loss for gfx950.  Replaces ~125 launch-bound ATen
+// ops (forward + autograd backward) of stacked_capsule_auto_encoder.py:238-285
+// and object_decoder.py:433-493:
+//   capsule log-likelihood term, prior sparsity (l2 | entropy | kl) on
+//   caps_presence, posterior sparsity on the capsule mass / n_points, and the
+//   two "cross_entropy over probabilities" classification terms (both through
+//   prior_classifier, as the reference does, :207-212, :281-282).
+// Everything is O(B*O) data: ONE workgroup, tensors staged in LDS, block
+// reductions by wave shuffles.  The backward kernel recomputes the forward
+// statistics and writes every gradient once (no atomics).
+#include "common.h"
+
+namespace {
+constexpr int NT = 256;
+constexpr int MAXCLS = 32;
+
+struct TailArgs {
+  const float *lpp;        // (B,M)   log_prob_per_point
+  const float *posterior;  // (B,O+1,M)
+  const float *cp;         // (B,O)   caps_presence
+  const float *cls_w;      // (ncls,O) nullable
+  const float *cls_b;      // (ncls)
+  const int64_t *label;    // (B) nullable
+  int B, O, M, ncls;
+  int prior_type, post_type;  // 0 l2, 1 entropy, 2 kl
+  int sparsity_on;            // reference gate: prior weights > 0
+  float w_ll, w_pw, w_pb, w_qw, w_qb;  // loss weights
+  float l2_within_const, l2_between_const, l2_within_const_post, l2_between_const_post;
+};
+
+__device__ __forceinline__ float block_total(float v, float *red) {
+  float a[1] = {v};
+  scae::block_sum<1, NT>(a, red);
+  if (threadIdx.x == 0) red[15] = a[0];
+  __syncthreads();
+  const float r = red[15];
+  __syncthreads();
+  return r;
+}
+
+// -sum p log_safe(p*k) terms: value and d/dp
+__device__ __forceinline__ float ent_term(float p, float k) {
+  return -p * scae::log_safe(p * k);
+}
+__device__ __forceinline__ float ent_term_grad(float p, float k) {
+  const float q = p * k;
+  return q < scae::kLogSafeEps ? 1e8f : -(logf(q) + 1.f);
+}
+
+// shared statistics of one (B,O) activation matrix x
+struct Stats {
+  float *x;     // [B*O]
+  float *row;   // [B]  sum over o
+  float *col;   // [O]  sum over b
+};
+
+__device__ void row_col_sums(const Stats &s, int B, int O) {
+  for (int b = threadIdx.x; b < B; b += NT) {
+    float t = 0.f;
+    for (int o = 0; o < O; ++o) t += s.x[b * O + o];
+    s.row[b] = t;
+  }
+  for (int o = threadIdx.x; o < O; o += NT) {
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += s.x[b * O + o];
+    s.col[o] = t;
+  }
+  __syncthreads();
+}
+
+// (within, between) of sparsity_loss(type, x); object_decoder.py:433-493
+__device__ void sparsity_fwd(const Stats &s, int B, int O, int type, float cw, float cb,
+                             float *red, float &within, float &between) {
+  float w = 0.f, bt = 0.f;
+  if (type == 0) {
+    for (int b = threadIdx.x; b < B; b += NT) {
+      const float d = s.row[b] - cw;
+      w += d * d;
+    }
+    for (int o = threadIdx.x; o < O; o += NT) {
+      const float d = s.col[o] - cb;
+      bt += d * d;
+    }
+    within = block_total(w, red) / B;
+    between = block_total(bt, red) / O;
+  } else {
+    const float k = type == 2 ? (float)O : 1.f;
+    for (int i = threadIdx.x; i < B * O; i += NT) {
+      const int b = i / O;
+      w += ent_term(s.x[i] / (s.row[b] + 1e-8f), k);
+    }
+    float tot = 0.f;
+    for (int o = 0; o < O; ++o) tot += s.col[o];
+    for (int o = threadIdx.x; o < O; o += NT) bt += ent_term(s.col[o] / (tot + 1e-8f), k);
+    within = block_total(w, red) / B;
+    between = -block_total(bt, red);
+  }
+}
+
+// g[b,o] += gw * d within/dx + gb * d between/dx
+__device__ void sparsity_bwd(const Stats &s, int B, int O, int type, float cw, float cb,
+                             float gw, float gb, float *g, float *tmp_row /*[B]*/) {
+  if (type == 0) {
+    for (int i = threadIdx.x; i < B * O; i += NT) {
+      const int b = i / O, o = i - b * O;
+      g[i] += gw * 2.f * (s.row[b] - cw) / B + gb * 2.f * (s.col[o] - cb) / O;
+    }
+  } else {
+    const float k = type == 2 ? (float)O : 1.f;
+    float tot = 0.f;
+    for (int o = 0; o < O; ++o) tot += s.col[o];
+    const float tinv = 1.f / (tot + 1e-8f);
+    // between: d(-H(bp))/dx[b,o] = -(sum_j dH/dbp_j dbp_j/dt_o), t_o = col sums
+    float dot_b = 0.f;
+    for (int o = 0; o < O; ++o) dot_b += ent_term_grad(s.col[o] * tinv, k) * s.col[o] * tinv;
+    for (int b = threadIdx.x; b < B; b += NT) {
+      const float rinv = 1.f / (s.row[b] + 1e-8f);
+      float dot_w = 0.f;
+      for (int j = 0; j < O; ++j)
+        dot_w += ent_term_grad(s.x[b * O + j] * rinv, k) * s.x[b * O + j] * rinv;
+      tmp_row[b] = dot_w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * O; i += NT) {
+      const int b = i / O, o = i - b * O;
+      const float rinv = 1.f / (s.row[b] + 1e-8f);
+      const float dot_w = tmp_row[b];
+      const float dw = (ent_term_grad(s.x[i] * rinv, k) - dot_w) * rinv / B;
+      const float db = -(ent_term_grad(s.col[o] * tinv, k) - dot_b) * tinv;
+      g[i] += gw * dw + gb * db;
+    }
+  }
+}
+
+// softmax(prior_classifier(x[b])) then cross_entropy(probs, label): value and
+// gradient w.r.t. the classifier logits (x is detached in the reference)
+__device__ __forceinline__ float cls_xe(const TailArgs &a, const float *xrow, int label,
+                                        float (&glogit)[MAXCLS]) {
+  float z[MAXCLS], p[MAXCLS];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < MAXCLS; ++c) {
+    if (c < a.ncls) {
+      float t = a.cls_b[c];
+      for (int o = 0; o < a.O; ++o) t = fmaf(xrow[o], a.cls_w[c * a.O + o], t);
+      z[c] = t;
+      mx = fmaxf(mx, t);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXCLS; ++c)
+    if (c < a.ncls) {
+      p[c] = expf(z[c] - mx);
+      sum += p[c];
+    }
+  float mx2 = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < MAXCLS; ++c)
+    if (c < a.ncls) {
+      p[c] /= sum;
+      mx2 = fmaxf(mx2, p[c]);
+    }
+  float sum2 = 0.f, plabel = 0.f;
+  float q[MAXCLS];
+#pragma unroll
+  for (int c = 0; c < MAXCLS; ++c)
+    if (c < a.ncls) {
+      q[c] = expf(p[c] - mx2);
+      sum2 += q[c];
+      if (c == label) plabel = p[c];
+    }
+  const float xe = mx2 + logf(sum2) - plabel;  // -log_softmax(p)[label]
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXCLS; ++c)
+    if (c < a.ncls) {
+      q[c] = q[c] / sum2 - (c == label ? 1.f : 0.f);  // d xe / d p_c
+      dot = fmaf(p[c], q[c], dot);
+    }
+#pragma unroll
+  for (int c = 0; c < MAXCLS; ++c) glogit[c] = c < a.ncls ? p[c] * (q[c] - dot) : 0.f;
+  return xe;
+}
+
+struct Carve {
+  float *cp, *mass, *row_c, *col_c, *row_m, *col_m, *red, *gl;
+};
+__device__ Carve carve(float *smem, int B, int O, int ncls) {
+  Carve c;
+  c.cp = smem;
+  c.mass = c.cp + B * O;
+  c.row_c = c.mass + B * O;
+  c.col_c = c.row_c + B;
+  c.row_m = c.col_c + O;
+  c.col_m = c.row_m + B;
+  c.red = c.col_m + O;
+  c.gl = c.red + 16;  // [2][B][ncls] classifier logit grads (backward only)
+  return c;
+}
+
+__device__ void load_stats(const TailArgs &a, const Carve &c) {
+  const int B = a.B, O = a.O, M = a.M;
+  for (int i = threadIdx.x; i < B * O; i += NT) {
+    const int b = i / O, o = i - b * O;
+    c.cp[i] = a.cp[i];
+    const float *pr = a.posterior + ((size_t)b * (O + 1) + o) * M;
+    float t = 0.f;
+    for (int m = 0; m < M; ++m) t += pr[m];
+    c.mass[i] = t / M;  // mass_explained_by_capsule / n_points (:260-266)
+  }
+  __syncthreads();
+  row_col_sums(Stats{c.cp, c.row_c, c.col_c}, B, O);
+  row_col_sums(Stats{c.mass, c.row_m, c.col_m}, B, O);
+}
+
+// out: [0] tail loss  [1] log_prob  [2] prior_within [3] prior_between
+//      [4] post_within [5] post_between [6] prior_cls_xe [7] posterior_cls_xe
+__global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, float *out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int B = a.B, O = a.O;
+  const Carve c = carve(smem, B, O, a.ncls);
+  load_stats(a, c);
+  float lp = 0.f;
+  for (int i = threadIdx.x; i < B * a.M; i += NT) lp += a.lpp[i];
+  const float log_prob = block_total(lp, c.red) / B;
+  float pw = 0.f, pb = 0.f, qw = 0.f, qb = 0.f;
+  if (a.sparsity_on) {
+    sparsity_fwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
+                 a.l2_between_const, c.red, pw, pb);
+    sparsity_fwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type, a.l2_within_const_post,
+                 a.l2_between_const_post, c.red, qw, qb);
+  }
+  float xe1 = 0.f, xe2 = 0.f;
+  if (a.label) {
+    float t1 = 0.f, t2 = 0.f;
+    float gl[MAXCLS];
+    for (int b = threadIdx.x; b < B; b += NT) {
+      t1 += cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
+    }
+    xe1 = block_total(t1, c.red) / B;
+    // posterior classifier input: the un-normalised capsule mass (:210-212)
+    for (int i = threadIdx.x; i < B * O; i += NT) c.cp[i] = c.mass[i] * a.M;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += NT)
+      t2 += cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
+    xe2 = block_total(t2, c.red) / B;
+  }
+  if (threadIdx.x == 0) {
+    out[1] = log_prob;
+    out[2] = pw;
+    out[3] = pb;
+    out[4] = qw;
+    out[5] = qb;
+    out[6] = xe1;
+    out[7] = xe2;
+    out[0] = -a.w_ll * log_prob + a.w_pw * pw + a.w_pb * pb + a.w_qw * qw + a.w_qb * qb + xe1 +
+             xe2;
+  }
+}
+
+__global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, const float *gout /*[8]*/,
+                                                      float *g_lpp, float *g_post, float *g_cp,
+                                                      float *g_w, float *g_b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int B = a.B, O = a.O, M = a.M;
+  const Carve c = carve(smem, B, O, a.ncls);
+  load_stats(a, c);
+  // d(total)/d(component): the tail loss plus whatever flowed into the
+  // individually exposed log entries
+  const float g0 = gout[0];
+  const float g_lp = -a.w_ll * g0 + gout[1];
+  const float g_pw = a.w_pw * g0 + gout[2], g_pb = a.w_pb * g0 + gout[3];
+  const float g_qw = a.w_qw * g0 + gout[4], g_qb = a.w_qb * g0 + gout[5];
+  const float g_x1 = g0 + gout[6], g_x2 = g0 + gout[7];
+
+  for (int i = threadIdx.x; i < B * M; i += NT) g_lpp[i] = g_lp / B;
+
+  // reuse LDS: gradient accumulators for cp and mass/M
+  float *gc = c.gl + 2 * B * MAXCLS;  // [B*O]
+  float *gm = gc + B * O;             // [B*O]
+  float *tmp = gm + B * O;            // [B]
+  for (int i = threadIdx.x; i < B * O; i += NT) gc[i] = gm[i] = 0.f;
+  __syncthreads();
+  if (a.sparsity_on) {
+    sparsity_bwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
+                 a.l2_between_const, g_pw, g_pb, gc, tmp);
+    __syncthreads();
+    sparsity_bwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type, a.l2_within_const_post,
+                 a.l2_between_const_post, g_qw, g_qb, gm, tmp);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B * O; i += NT) g_cp[i] = gc[i];
+  // posterior (B,O+1,M): mass/M = sum_m post / M; the dummy row gets zero
+  for (int i = threadIdx.x; i < B * (O + 1) * M; i += NT) {
+    const int m = i % M, bo = i / M, o = bo % (O + 1), b = bo / (O + 1);
+    (void)m;
+    g_post[i] = o < O ? gm[b * O + o] / M : 0.f;
+  }
+  // classifier parameter gradients (inputs are detached)
+  if (a.label && g_w) {
+    float gl[MAXCLS];
+    for (int b = threadIdx.x; b < B; b += NT) {
+      cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
+#pragma unroll
+      for (int cc = 0; cc < MAXCLS; ++cc)
+        if (cc < a.ncls) c.gl[b * MAXCLS + cc] = gl[cc] * g_x1 / B;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * O; i += NT) gc[i] = c.mass[i] * M;  // second input
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += NT) {
+      cls_xe(a, gc + b * O, (int)a.label[b], gl);
+#pragma unroll
+      for (int cc = 0; cc < MAXCLS; ++cc)
+        if (cc < a.ncls) c.gl[(B + b) * MAXCLS + cc] = gl[cc] * g_x2 / B;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.ncls * O; i += NT) {
+      const int cc = i / O, o = i - cc * O;
+      float t = 0.f;
+      for (int b = 0; b < B; ++b)
+        t += c.gl[b * MAXCLS + cc] * c.cp[b * O + o] + c.gl[(B + b) * MAXCLS + cc] * gc[b * O + o];
+      g_w[i] = t;
+    }
+    for (int cc = threadIdx.x; cc < a.ncls; cc += NT) {
+      float t = 0.f;
+      for (int b = 0; b < B; ++b) t += c.gl[b * MAXCLS + cc] + c.gl[(B + b) * MAXCLS + cc];
+      g_b[cc] = t;
+    }
+  }
+}
+
+size_t tail_lds(int B, int O, bool bwd) {
+  size_t f = 2 * (size_t)B * O + 2 * B + 2 * O + 16;
+  if (bwd) f += 2 * (size_t)B * MAXCLS + 2 * (size_t)B * O + B;
+  return f * sizeof(float);
+}
+}  // namespace
+
+extern "C" int scae_loss_tail_supported(int B, int O, int ncls) {
+  return (B > 0 && O > 0 && ncls <= MAXCLS && tail_lds(B, O, true) <= 150 * 1024) ? 1 : 0;
+}
+
+static int fill_tail(TailArgs &a, const float *lpp, const float *posterior, const float *cp,
+                     const float *cls_w, const float *cls_b, const int64_t *label, int B,
+                     int O, int M, int ncls, int n_classes_cfg, int prior_type, int post_type,
+                     int sparsity_on, const float *weights /*5*/, float within_const) {
+  if (!lpp || !posterior || !cp || !weights || B <= 0 || O <= 0 || M <= 0)
+    return SCAE_ERR_BAD_ARG;
+  if (label && (!cls_w || !cls_b || ncls <= 0)) return SCAE_ERR_BAD_ARG;
+  if (prior_type < 0 || prior_type > 2 || post_type < 0 || post_type > 2) return SCAE_ERR_BAD_ARG;
+  if (!scae_loss_tail_supported(B, O, ncls)) return SCAE_ERR_UNSUPPORTED;
+  a = TailArgs{lpp, posterior, cp, cls_w, cls_b, label, B, O, M, ncls, prior_type, post_type,
+               sparsity_on, weights[0], weights[1], weights[2], weights[3], weights[4],
+               0.f, 0.f, 0.f, 0.f};
+  const float nc = n_classes_cfg > 0 ? (float)n_classes_cfg : 1.f;
+  // capsule_l2_loss constants (object_decoder.py:443-449); the posterior call
+  // never passes within_example_constant (:262-266)
+  a.l2_within_const = within_const == within_const ? within_const : (float)O / nc;
+  a.l2_between_const = (float)B / nc;
+  a.l2_within_const_post = (float)O / nc;
+  a.l2_between_const_post = (float)B / nc;
+  return SCAE_OK;
+}
+
+extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
+                                      const float *caps_presence, const float *cls_w,
+                                      const float *cls_b, const int64_t *label, float *out8,
+                                      int B, int O, int M, int ncls, int n_classes_cfg,
+                                      int prior_type, int post_type, int sparsity_on,
+                                      const float *weights5, float within_const, void *stream) {
+  TailArgs a;
+  int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
+                     n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
+  if (rc) return rc;
+  SCAE_REQUIRE(out8);
+  const size_t lds = tail_lds(B, O, false);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(tail_fwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, out8);
+  return scae_launch_status();
+}
+
+extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
+                                      const float *caps_presence, const float *cls_w,
+                                      const float *cls_b, const int64_t *label,
+                                      const float *gout8, float *g_lpp, float *g_posterior,
+                                      float *g_caps_presence, float *g_cls_w, float *g_cls_b,
+                                      int B, int O, int M, int ncls, int n_classes_cfg,
+                                      int prior_type, int post_type, int sparsity_on,
+                                      const float *weights5, float within_const, void *stream) {
+  TailArgs a;
+  int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
+                     n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
+  if (rc) return rc;
+  SCAE_REQUIRE(gout8 && g_lpp && g_posterior && g_caps_presence);
+  if (label) SCAE_REQUIRE(g_cls_w && g_cls_b);
+  const size_t lds = tail_lds(B, O, true);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, gout8,
+                     g_lpp, g_posterior, g_caps_presence, g_cls_w, g_cls_b);
+  return scae_launch_status();
+}

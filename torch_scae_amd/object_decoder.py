@@ -124,6 +124,8 @@ class CapsuleLikelihood:
             self.vote, self.scale, self.vote_presence, self.dummy_vote, x,
             presence.float() if presence is not None else None)
         return AttrDict(
+            _log_prob_per_point=lpp,           # inputs of the fused loss tail
+            _posterior_full=posterior,
             log_prob=lpp.sum() / batch_size,
             vote_presence_binary=binary,
             winner=winner,

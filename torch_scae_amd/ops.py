@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
-__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "capsule_votes",
+__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "loss_tail", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
@@ -335,6 +335,74 @@ def capsule_likelihood(vote, scale, vote_presence, dummy_vote, x,
     soft_winner_presence, posterior (B,O+1,M), mixing_log_prob, mixing_logit)"""
     return _CapsuleLikelihood.apply(vote, scale, vote_presence, dummy_vote, x,
                                     presence)
+
+
+# ----------------------------------------------------------------------------
+# K6 fused tail of SCAE.loss (stacked_capsule_auto_encoder.py:238-285)
+# ----------------------------------------------------------------------------
+_SPARSITY_TYPES = {"l2": 0, "entropy": 1, "kl": 2}
+
+
+def loss_tail_supported(B, O, n_classes):
+    return bool(_lib.load().scae_loss_tail_supported(B, O, n_classes or 0))
+
+
+class _LossTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lpp, posterior, caps_presence, cls_w, cls_b, label, cfg):
+        _need_hip(lpp, posterior, caps_presence, cls_w, cls_b)
+        lpp, posterior, caps_presence = _c(lpp), _c(posterior), _c(caps_presence)
+        cls_w, cls_b, label = _c(cls_w), _c(cls_b), _c(label)
+        B, O1, M = posterior.shape
+        O = O1 - 1
+        ncls = 0 if cls_w is None else cls_w.shape[0]
+        (n_classes_cfg, prior_type, post_type, sparsity_on, weights,
+         within_const) = cfg
+        w5 = (ctypes.c_float * 5)(*weights)
+        ints = (B, O, M, ncls, int(n_classes_cfg or 0), prior_type, post_type,
+                int(sparsity_on))
+        out = torch.empty(8, device=lpp.device, dtype=lpp.dtype)
+        wc = float("nan") if within_const is None else float(within_const)
+        lab = None if label is None else ctypes.c_void_p(label.data_ptr())
+        _lib.call("scae_loss_tail_fwd_f32", _p(lpp), _p(posterior),
+                  _p(caps_presence), _p(cls_w), _p(cls_b), lab, _p(out), *ints,
+                  w5, wc, _stream(lpp))
+        ctx.save_for_backward(lpp, posterior, caps_presence,
+                              *([cls_w, cls_b, label] if label is not None
+                                else []))
+        ctx.has_label = label is not None
+        ctx.call = (ints, tuple(weights), wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lpp, posterior, cp = ctx.saved_tensors[:3]
+        cls_w = cls_b = label = None
+        if ctx.has_label:
+            cls_w, cls_b, label = ctx.saved_tensors[3:6]
+        ints, weights, wc = ctx.call
+        g_lpp, g_post, g_cp = (torch.empty_like(t) for t in (lpp, posterior, cp))
+        g_w = torch.empty_like(cls_w) if cls_w is not None else None
+        g_b = torch.empty_like(cls_b) if cls_b is not None else None
+        w5 = (ctypes.c_float * 5)(*weights)
+        lab = None if label is None else ctypes.c_void_p(label.data_ptr())
+        _lib.call("scae_loss_tail_bwd_f32", _p(lpp), _p(posterior), _p(cp),
+                  _p(cls_w), _p(cls_b), lab, _p(gout.contiguous()), _p(g_lpp),
+                  _p(g_post), _p(g_cp), _p(g_w), _p(g_b), *ints, w5, wc,
+                  _stream(lpp))
+        return g_lpp, g_post, g_cp, g_w, g_b, None, None
+
+
+def loss_tail(lpp, posterior, caps_presence, cls_w, cls_b, label, n_classes,
+              prior_type, post_type, sparsity_on, weights, within_const=None):
+    """-> tensor (8): [tail loss, log_prob, prior_within, prior_between,
+    posterior_within, posterior_between, prior_cls_xe, posterior_cls_xe]."""
+    if label is None:
+        cls_w = cls_b = None
+    cfg = (n_classes, _SPARSITY_TYPES[prior_type], _SPARSITY_TYPES[post_type],
+           bool(sparsity_on), [float(w) for w in weights], within_const)
+    return _LossTail.apply(lpp, posterior, caps_presence, cls_w, cls_b, label,
+                           cfg)
 
 
 # ----------------------------------------------------------------------------

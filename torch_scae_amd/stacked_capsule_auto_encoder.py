@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .object_decoder import sparsity_loss
 
 
@@ -62,6 +63,7 @@ class SCAE(nn.Module):
             posterior_between_example_sparsity_weight
         self.part_caps_sparsity_weight = part_caps_sparsity_weight
         self.reconstruct_alternatives = reconstruct_alternatives
+        self.fuse_loss_tail = True     # set False for the op-by-op loss
 
     # -- forward -------------------------------------------------------------
     def forward(self, image):
@@ -160,12 +162,42 @@ class SCAE(nn.Module):
             loss = loss + self.part_caps_sparsity_weight * part_caps_l1
             log.update(part_caps_loss=part_caps_l1)
 
+        sparsity_on = (self.prior_within_example_sparsity_weight > 0
+                       or self.prior_between_example_sparsity_weight > 0)
+        if self._fused_tail_ok(res, label):
+            # one kernel for the capsule-likelihood, sparsity and
+            # classification terms (and one for their backward)
+            t = ops.loss_tail(
+                res._log_prob_per_point, res._posterior_full,
+                res.caps_presence,
+                self.prior_classifier[0].weight if label is not None else None,
+                self.prior_classifier[0].bias if label is not None else None,
+                label, self.n_classes, self.prior_sparsity_loss_type,
+                self.posterior_sparsity_loss_type, sparsity_on,
+                [self.caps_ll_weight,
+                 self.prior_within_example_sparsity_weight,
+                 self.prior_between_example_sparsity_weight,
+                 self.posterior_within_example_sparsity_weight,
+                 self.posterior_between_example_sparsity_weight],
+                self.prior_within_example_constant)
+            loss = loss + t[0]
+            log.update(log_prob_loss=-t[1])
+            if sparsity_on:
+                log.update(prior_within_sparsity_loss=t[2],
+                           prior_between_sparsity_loss=t[3],
+                           posterior_within_sparsity_loss=t[4],
+                           posterior_between_sparsity_loss=t[5])
+            loss = loss + self.cpr_dynamic_reg_weight * res.cpr_dynamic_reg_loss
+            log.update(cpr_dynamic_reg_loss=res.cpr_dynamic_reg_loss)
+            if label is not None:
+                log.update(prior_cls_xe=t[6], posterior_cls_xe=t[7])
+            return loss, log
+
         loss = loss - self.caps_ll_weight * res.log_prob
         log.update(log_prob_loss=-res.log_prob)
 
         # both sparsity blocks are gated by the PRIOR weights (:243, :258)
-        if self.prior_within_example_sparsity_weight > 0 \
-                or self.prior_between_example_sparsity_weight > 0:
+        if sparsity_on:
             within, between = sparsity_loss(
                 self.prior_sparsity_loss_type, res.caps_presence,
                 n_classes=self.n_classes,
@@ -200,6 +232,22 @@ class SCAE(nn.Module):
             log.update(prior_cls_xe=prior_cls_xe,
                        posterior_cls_xe=posterior_cls_xe)
         return loss, log
+
+    def _fused_tail_ok(self, res, label):
+        if not self.fuse_loss_tail or "_posterior_full" not in res:
+            return False
+        if label is not None and self.n_classes is None:
+            return False
+        if self.prior_sparsity_loss_type not in ("l2", "entropy", "kl") or \
+                self.posterior_sparsity_loss_type not in ("l2", "entropy", "kl"):
+            return False
+        cp = res.caps_presence
+        if not cp.is_cuda or (self.n_classes is None
+                              and "l2" in (self.prior_sparsity_loss_type,
+                                           self.posterior_sparsity_loss_type)):
+            return False
+        return ops.loss_tail_supported(cp.shape[0], cp.shape[1],
+                                       self.n_classes)
 
     def calculate_accuracy(self, res, label: torch.Tensor):
         prior_acc = (res.prior_cls_prob.argmax(-1) == label).float().mean()
