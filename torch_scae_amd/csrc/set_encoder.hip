@@ -6,27 +6,34 @@
 // Why one kernel: at the reference's sizes (24 capsules x 16 hidden dims) a
 // SAB is ~15 launch-bound ATen ops forward and ~40 backward; three of them
 // plus fc1/fc2 were ~190 of the ~500 launches of a training step while doing
-// < 0.1 GFLOP.  Here one wavefront owns one set: lane n holds row n of every
-// (N x D) activation in registers, K/V/P tiles live in LDS, all weights of the
-// trunk (a few thousand floats) are staged in LDS once per workgroup.  The
-// D = 16 contractions are far below an MFMA tile, so this trunk uses VALU
-// FMAs; the matrix cores are used by the wide (d = 256) output attention
-// (set_attention.hip).  The backward kernel recomputes each block from its
-// saved input, needs no atomics (every weight-gradient entry has one owning
-// lane; per-workgroup partial sums are reduced by the caller) and is
-// bit-reproducible.
+// < 0.1 GFLOP.  One workgroup (4 wavefronts) owns one set.  Every (N x D)
+// activation is an LDS tile and each stage is ELEMENT-parallel: lane (n, i)
+// produces one output element from a 16-byte-vectorised dot product of an
+// activation row and a weight row, so dependent chains are D long instead of
+// D*D (a first, row-per-lane version of this kernel was latency bound:
+// 132 us forward / 335 us backward).  LayerNorm and the softmax use D-lane /
+// 16-lane xor-shuffle reductions.  All trunk weights are staged in LDS once
+// per workgroup, rows padded so that 16 lanes reading 16 different rows hit
+// 16 different 16-byte bank groups.  The D = 16 contractions are far below an
+// MFMA tile, so this trunk uses VALU FMAs; the matrix cores serve the wide
+// (d = 256) output attention (set_attention.hip).  The backward kernel
+// recomputes each block from its saved input, needs no atomics (every
+// weight-gradient entry has one owning lane; per-workgroup partial sums are
+// reduced by the caller) and is bit-reproducible.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
 
-constexpr int NT = 64;        // one wavefront per workgroup; lane = set element
-constexpr int NMAX = 64;      // max set size
-constexpr int MAXSEG = 4;     // input given as up to 4 column segments
+constexpr int NT = 256;
+constexpr int NMAX = 64;   // max set size
+constexpr int MAXSEG = 4;  // input given as up to 4 column segments
 constexpr float kLnEps = 1e-5f;
 
 struct Seg {
-  const float *ptr;   // (B, N, width) view: element (b, n, j) at ptr[b*bs + n*rs + j]
-  float *grad;        // nullable, contiguous (B, N, width)
+  const float *ptr;  // element (b, n, j) at ptr[b*bs + n*rs + j]
+  float *grad;       // nullable, contiguous (B, N, width)
   int width, rs;
   long bs;
 };
@@ -44,386 +51,341 @@ struct StArgs {
   float sqrt_d;
 };
 
-// packed global parameter layout (floats), D = hidden width:
+// packed GLOBAL parameter layout (floats), D = hidden width:
 //   W1 [D][Din], b1 [D]
 //   per layer: Wq,bq, Wk,bk, Wv,bv, Wo,bo, (ln0w, ln0b), Wf,bf, (ln1w, ln1b)
 //   W2 [Dout][D], b2 [Dout]
+// matrices in a layer are numbered q=0 k=1 v=2 o=3 f=4
 template <int D>
 struct Layout {
   int Din, Dout, L, ln;
+  static constexpr int TS = D + 4;  // padded row stride of LDS tiles / matrices
   __host__ __device__ int layer_size() const { return 5 * (D * D + D) + (ln ? 4 * D : 0); }
-  __host__ __device__ int off_w1() const { return 0; }
   __host__ __device__ int off_b1() const { return D * Din; }
   __host__ __device__ int off_layer(int l) const { return D * Din + D + l * layer_size(); }
-  // within a layer
-  __host__ __device__ int o_wq() const { return 0; }
-  __host__ __device__ int o_bq() const { return D * D; }
-  __host__ __device__ int o_wk() const { return D * D + D; }
-  __host__ __device__ int o_bk() const { return 2 * D * D + D; }
-  __host__ __device__ int o_wv() const { return 2 * (D * D + D); }
-  __host__ __device__ int o_bv() const { return 3 * D * D + 2 * D; }
-  __host__ __device__ int o_wo() const { return 3 * (D * D + D); }
-  __host__ __device__ int o_bo() const { return 4 * D * D + 3 * D; }
-  __host__ __device__ int o_ln0() const { return 4 * (D * D + D); }
-  __host__ __device__ int o_wf() const { return 4 * (D * D + D) + (ln ? 2 * D : 0); }
-  __host__ __device__ int o_bf() const { return o_wf() + D * D; }
-  __host__ __device__ int o_ln1() const { return o_bf() + D; }
+  __host__ __device__ int g_w(int m) const {  // matrix m inside a layer (global layout)
+    return m < 4 ? m * (D * D + D) : 4 * (D * D + D) + (ln ? 2 * D : 0);
+  }
+  __host__ __device__ int g_b(int m) const { return g_w(m) + D * D; }
+  __host__ __device__ int g_ln0() const { return 4 * (D * D + D); }
+  __host__ __device__ int g_ln1() const { return g_b(4) + D; }
   __host__ __device__ int off_w2() const { return off_layer(L); }
   __host__ __device__ int off_b2() const { return off_w2() + Dout * D; }
   __host__ __device__ int total() const { return off_b2() + Dout; }
-  // LDS copy of the weights: W1 is stored transposed ([Din][D]) and everything
-  // is shifted so that each matrix starts 16-byte aligned
-  __host__ __device__ int lds_w1t() const { return 0; }
-  __host__ __device__ int lds_b1() const { return D * Din; }
-  __host__ __device__ int lds_layer(int l) const { return D * Din + D + l * layer_size(); }
-  __host__ __device__ int lds_total() const { return lds_layer(L); }  // fc2 stays in L2
+  // LDS copies: W1 rows padded to DinS, layer matrices padded to TS
+  __host__ __device__ int DinS() const {
+    int s = (Din + 3) & ~3;
+    if (((s >> 2) & 1) == 0) s += 4;  // odd number of 16-byte units per row
+    return s;
+  }
+  __host__ __device__ int l_w(int m) const { return m * D * TS; }
+  __host__ __device__ int l_b(int m) const { return 5 * D * TS + m * D; }
+  __host__ __device__ int l_ln0() const { return 5 * D * TS + 5 * D; }
+  __host__ __device__ int l_ln1() const { return l_ln0() + 2 * D; }
+  __host__ __device__ int lds_layer_size() const { return 5 * D * TS + 9 * D; }
 };
 
-// y = W x + b,  W [D][D] row-major in LDS (16-byte aligned rows)
-template <int D>
-__device__ __forceinline__ void linear(const float *W, const float *bias, const float (&x)[D],
-                                       float (&y)[D]) {
+// ---- lane-group reductions (groups of G consecutive lanes, G | 64) ---------
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    float acc = bias[i];
-    const float4 *w4 = reinterpret_cast<const float4 *>(W + i * D);
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
 #pragma unroll
-    for (int j = 0; j < D / 4; ++j) {
-      const float4 w = w4[j];
-      acc = fmaf(x[4 * j], w.x, acc);
-      acc = fmaf(x[4 * j + 1], w.y, acc);
-      acc = fmaf(x[4 * j + 2], w.z, acc);
-      acc = fmaf(x[4 * j + 3], w.w, acc);
-    }
-    y[i] = acc;
-  }
+  for (int off = G / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
 }
 
-// gx += W^T gy
-template <int D>
-__device__ __forceinline__ void linear_t(const float *W, const float (&gy)[D], float (&gx)[D]) {
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const float4 *w4 = reinterpret_cast<const float4 *>(W + i * D);
-#pragma unroll
-    for (int j = 0; j < D / 4; ++j) {
-      const float4 w = w4[j];
-      gx[4 * j] = fmaf(gy[i], w.x, gx[4 * j]);
-      gx[4 * j + 1] = fmaf(gy[i], w.y, gx[4 * j + 1]);
-      gx[4 * j + 2] = fmaf(gy[i], w.z, gx[4 * j + 2]);
-      gx[4 * j + 3] = fmaf(gy[i], w.w, gx[4 * j + 3]);
-    }
-  }
-}
-
-template <int D>
-__device__ __forceinline__ void layer_norm(const float (&x)[D], const float *gamma,
-                                           const float *beta, float (&xhat)[D], float &rstd,
-                                           float (&y)[D]) {
-  float mean = 0.f;
-#pragma unroll
-  for (int i = 0; i < D; ++i) mean += x[i];
-  mean *= (1.f / D);
-  float var = 0.f;
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const float d = x[i] - mean;
-    var = fmaf(d, d, var);
-  }
-  rstd = 1.f / sqrtf(var * (1.f / D) + kLnEps);
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    xhat[i] = (x[i] - mean) * rstd;
-    y[i] = fmaf(xhat[i], gamma[i], beta[i]);
-  }
-}
-
-// gx = LayerNorm backward of gy (row-wise)
-template <int D>
-__device__ __forceinline__ void layer_norm_bwd(const float (&gy)[D], const float *gamma,
-                                               const float (&xhat)[D], float rstd,
-                                               float (&gx)[D]) {
-  float s1 = 0.f, s2 = 0.f;
-  float gh[D];
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    gh[i] = gy[i] * gamma[i];
-    s1 += gh[i];
-    s2 = fmaf(gh[i], xhat[i], s2);
-  }
-  s1 *= (1.f / D);
-  s2 *= (1.f / D);
-#pragma unroll
-  for (int i = 0; i < D; ++i) gx[i] = (gh[i] - s1 - xhat[i] * s2) * rstd;
-}
-
-template <int D>
-__device__ __forceinline__ void store_row(float *tile, int n, const float (&x)[D]) {
-  float4 *p = reinterpret_cast<float4 *>(tile + n * (D + 4));
-#pragma unroll
-  for (int j = 0; j < D / 4; ++j) p[j] = make_float4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
-}
-
-// acc += sum_j a[j] * row[j]   (row: 16-byte aligned LDS)
-template <int D>
-__device__ __forceinline__ float dot_row(const float (&a)[D], const float *row) {
-  const float4 *p = reinterpret_cast<const float4 *>(row);
+// dot product of two 16-byte aligned rows of n4 float4
+__device__ __forceinline__ float dot4(const float *a, const float *b, int n4) {
+  const float4 *pa = reinterpret_cast<const float4 *>(a);
+  const float4 *pb = reinterpret_cast<const float4 *>(b);
   float acc = 0.f;
-#pragma unroll
-  for (int j = 0; j < D / 4; ++j) {
-    const float4 r = p[j];
-    acc = fmaf(a[4 * j], r.x, acc);
-    acc = fmaf(a[4 * j + 1], r.y, acc);
-    acc = fmaf(a[4 * j + 2], r.z, acc);
-    acc = fmaf(a[4 * j + 3], r.w, acc);
+  for (int j = 0; j < n4; ++j) {
+    const float4 x = pa[j], y = pb[j];
+    acc = fmaf(x.x, y.x, acc);
+    acc = fmaf(x.y, y.y, acc);
+    acc = fmaf(x.z, y.z, acc);
+    acc = fmaf(x.w, y.w, acc);
   }
   return acc;
 }
 template <int D>
-__device__ __forceinline__ void axpy_row(float s, const float *row, float (&y)[D]) {
-  const float4 *p = reinterpret_cast<const float4 *>(row);
+__device__ __forceinline__ float dotD(const float *a, const float *b) {
+  const float4 *pa = reinterpret_cast<const float4 *>(a);
+  const float4 *pb = reinterpret_cast<const float4 *>(b);
+  float acc = 0.f;
 #pragma unroll
   for (int j = 0; j < D / 4; ++j) {
-    const float4 r = p[j];
-    y[4 * j] = fmaf(s, r.x, y[4 * j]);
-    y[4 * j + 1] = fmaf(s, r.y, y[4 * j + 1]);
-    y[4 * j + 2] = fmaf(s, r.z, y[4 * j + 2]);
-    y[4 * j + 3] = fmaf(s, r.w, y[4 * j + 3]);
+    const float4 x = pa[j], y = pb[j];
+    acc = fmaf(x.x, y.x, acc);
+    acc = fmaf(x.y, y.y, acc);
+    acc = fmaf(x.z, y.z, acc);
+    acc = fmaf(x.w, y.w, acc);
   }
+  return acc;
+}
+// sum_k g[k] * W[k][i]  (column i of a TS-strided matrix; lanes i consecutive)
+template <int D>
+__device__ __forceinline__ float dot_col(const float *grow, const float *W, int i) {
+  constexpr int TS = D + 4;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc = fmaf(grow[k], W[k * TS + i], acc);
+  return acc;
 }
 
-// One SAB forward for lane-row n.  K / V rows go through LDS tiles s_k / s_v,
-// the attention probabilities through s_p ([NMAX][NMAX+1], own row per lane).
-// Everything the backward needs is returned by reference.
 template <int D>
-struct BlockState {
-  float q[D], a[D], xhat0[D], h1n[D], t[D], xhat1[D];
-  float rstd0, rstd1, pn;
+struct Tiles {  // LDS carve
+  float *w1, *b1, *lw, *x;
+  float *H, *Q, *K, *V, *A, *H1, *T, *XH0, *XH1, *G, *GN, *GH1, *GO, *GA, *GQ, *GK, *GV;
+  float *S, *GS, *rstd0, *rstd1, *pg;
 };
 
 template <int D>
-__device__ __forceinline__ void sab_forward(const Layout<D> &lay, const float *W /*layer base in LDS*/,
-                                            const float *presence_b, int N, int lane,
-                                            float sqrt_d, const float (&h)[D], float *s_k,
-                                            float *s_v, float *s_p, BlockState<D> &st,
-                                            float (&out)[D]) {
+__host__ __device__ size_t carve(const Layout<D> &lay, int N, bool bwd, float *base,
+                                 Tiles<D> *out) {
   constexpr int TS = D + 4;
-  const int ps = N + 1;           // row stride of the probability tile
-  const bool live = lane < N;     // lanes beyond the set only keep barriers company
-  float k[D], v[D];
-  linear<D>(W + lay.o_wq(), W + lay.o_bq(), h, st.q);
-  linear<D>(W + lay.o_wk(), W + lay.o_bk(), h, k);
-  linear<D>(W + lay.o_wv(), W + lay.o_bv(), h, v);
-  __syncthreads();  // previous readers of the tiles are done
-  if (live) {
-    store_row<D>(s_k, lane, k);
-    store_row<D>(s_v, lane, v);
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    float *p = base ? base + o : nullptr;
+    o += (n + 3) & ~(size_t)3;
+    return p;
+  };
+  Tiles<D> r{};
+  r.w1 = take((size_t)D * lay.DinS());
+  r.b1 = take(D);
+  r.lw = take((size_t)lay.L * lay.lds_layer_size());
+  r.x = bwd ? nullptr : take((size_t)N * lay.DinS());
+  const size_t tile = (size_t)N * TS;
+  r.H = take(tile);
+  r.Q = take(tile);
+  r.K = take(tile);
+  r.V = take(tile);
+  r.A = take(tile);
+  r.H1 = take(tile);
+  r.S = take((size_t)N * (N + 1));
+  if (bwd) {
+    r.T = take(tile);
+    r.XH0 = take(tile);
+    r.XH1 = take(tile);
+    r.G = take(tile);
+    r.GN = take(tile);
+    r.GH1 = take(tile);
+    r.GO = take(tile);
+    r.GA = take(tile);
+    r.GQ = take(tile);
+    r.GK = take(tile);
+    r.GV = take(tile);
+    r.GS = take((size_t)N * (N + 1));
+    r.rstd0 = take(N);
+    r.rstd1 = take(N);
+    r.pg = take((size_t)lay.L * lay.layer_size());
+  }
+  if (out) *out = r;
+  return o;
+}
+
+template <int D>
+__device__ void stage_weights(const Layout<D> &lay, const float *params, const Tiles<D> &t) {
+  constexpr int TS = D + 4;
+  const int Din = lay.Din, DinS = lay.DinS();
+  for (int i = threadIdx.x; i < D * DinS; i += NT) {
+    const int r = i / DinS, c = i - r * DinS;
+    t.w1[i] = c < Din ? params[r * Din + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < D; i += NT) t.b1[i] = params[lay.off_b1() + i];
+  for (int l = 0; l < lay.L; ++l) {
+    const float *g = params + lay.off_layer(l);
+    float *w = t.lw + l * lay.lds_layer_size();
+    for (int i = threadIdx.x; i < 5 * D * D; i += NT) {
+      const int m = i / (D * D), rc = i - m * D * D, r = rc / D, c = rc - r * D;
+      w[lay.l_w(m) + r * TS + c] = g[lay.g_w(m) + rc];
+    }
+    for (int i = threadIdx.x; i < 5 * D; i += NT) {
+      const int m = i / D, c = i - m * D;
+      w[lay.l_b(m) + c] = g[lay.g_b(m) + c];
+    }
+    if (lay.ln)
+      for (int i = threadIdx.x; i < 2 * D; i += NT) {
+        w[lay.l_ln0() + i] = g[lay.g_ln0() + i];
+        w[lay.l_ln1() + i] = g[lay.g_ln1() + i];
+      }
+  }
+}
+
+// One SAB forward on LDS tiles: reads t.H, leaves the block output in t.H.
+// KEEP: also store what the backward needs (T, XH0, XH1, rstd0/1).
+// Ends with a __syncthreads().
+template <int D, bool KEEP>
+__device__ void sab_forward(const Layout<D> &lay, const float *W, const float *presence_b,
+                            int N, float sqrt_d, const Tiles<D> &t) {
+  constexpr int TS = D + 4;
+  const int NS = N + 1;
+  const int tid = threadIdx.x;
+  // s1: Q, K, V projections
+  for (int e = tid; e < N * D; e += NT) {
+    const int n = e / D, i = e - n * D;
+    const float *h = t.H + n * TS;
+    t.Q[n * TS + i] = W[lay.l_b(0) + i] + dotD<D>(h, W + lay.l_w(0) + i * TS);
+    t.K[n * TS + i] = W[lay.l_b(1) + i] + dotD<D>(h, W + lay.l_w(1) + i * TS);
+    t.V[n * TS + i] = W[lay.l_b(2) + i] + dotD<D>(h, W + lay.l_w(2) + i * TS);
   }
   __syncthreads();
-  // routing = (q k^T - (1 - presence) 1e32) / sqrt(d); softmax over keys
-  float *prow = s_p + (live ? lane : 0) * ps;
-  const int Nl = live ? N : 0;
-  float mx = -INFINITY;
-  for (int m = 0; m < Nl; ++m) {
-    float s = dot_row<D>(st.q, s_k + m * TS);
+  // s2: routing = (q k^T - (1 - presence) 1e32) / sqrt(d)   (set_transformer.py:40-43)
+  for (int e = tid; e < N * N; e += NT) {
+    const int n = e / N, m = e - n * N;
+    float s = dotD<D>(t.Q + n * TS, t.K + m * TS);
     if (presence_b) s = s - (1.f - presence_b[m]) * 1e32f;
-    s = s / sqrt_d;
-    prow[m] = s;
-    mx = fmaxf(mx, s);
+    t.S[n * NS + m] = s / sqrt_d;
   }
-  float sum = 0.f;
-  for (int m = 0; m < Nl; ++m) {
-    const float e = expf(prow[m] - mx);
-    prow[m] = e;
-    sum += e;
-  }
+  __syncthreads();
+  // s3: row softmax, 16 lanes per row
+  for (int e = tid; e < ((N * 16 + NT - 1) / NT) * NT; e += NT) {
+    const int n = e >> 4, l = e & 15;
+    float v[NMAX / 16];
+    float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < D; ++i) st.a[i] = 0.f;
-  for (int m = 0; m < Nl; ++m) {
-    const float p = prow[m] / sum;
-    prow[m] = p;
-    axpy_row<D>(p, s_v + m * TS, st.a);
-  }
-  float o[D], r[D];
-  linear<D>(W + lay.o_wo(), W + lay.o_bo(), st.a, o);
-  st.pn = presence_b ? presence_b[lane < N ? lane : 0] : 1.f;
-#pragma unroll
-  for (int i = 0; i < D; ++i) r[i] = (o[i] + h[i]) * st.pn;  // residual, presence gate
-  if (lay.ln) {
-    layer_norm<D>(r, W + lay.o_ln0(), W + lay.o_ln0() + D, st.xhat0, st.rstd0, st.h1n);
-  } else {
-#pragma unroll
-    for (int i = 0; i < D; ++i) st.h1n[i] = r[i];
-  }
-  linear<D>(W + lay.o_wf(), W + lay.o_bf(), st.h1n, st.t);
-  float h2[D];
-#pragma unroll
-  for (int i = 0; i < D; ++i) h2[i] = st.h1n[i] + fmaxf(st.t[i], 0.f);
-  if (lay.ln) {
-    layer_norm<D>(h2, W + lay.o_ln1(), W + lay.o_ln1() + D, st.xhat1, st.rstd1, out);
-  } else {
-#pragma unroll
-    for (int i = 0; i < D; ++i) out[i] = h2[i];
-  }
-}
-
-template <int D>
-__device__ __forceinline__ void stage_weights(const Layout<D> &lay, const float *params,
-                                              float *s_w) {
-  const int Din = lay.Din;
-  for (int i = threadIdx.x; i < D * Din; i += NT) {  // W1 -> transposed
-    const int r = i / Din, c = i - r * Din;
-    s_w[lay.lds_w1t() + c * D + r] = params[lay.off_w1() + i];
-  }
-  const int rest = lay.off_w2() - lay.off_b1();
-  for (int i = threadIdx.x; i < rest; i += NT) s_w[lay.lds_b1() + i] = params[lay.off_b1() + i];
-}
-
-template <int D>
-__device__ __forceinline__ void stage_input(const StArgs &a, int b, float *s_x, int DinP) {
-  int col = 0;
-  for (int s = 0; s < a.nseg; ++s) {
-    const Seg &sg = a.seg[s];
-    for (int i = threadIdx.x; i < a.N * sg.width; i += NT) {
-      const int n = i / sg.width, j = i - n * sg.width;
-      s_x[n * DinP + col + j] = sg.ptr[(size_t)b * sg.bs + (size_t)n * sg.rs + j];
+    for (int k = 0; k < NMAX / 16; ++k) {
+      const int m = l + 16 * k;
+      v[k] = (n < N && m < N) ? t.S[n * NS + m] : -INFINITY;
+      mx = fmaxf(mx, v[k]);
     }
-    col += sg.width;
+    mx = group_max<16>(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NMAX / 16; ++k) {
+      v[k] = v[k] == -INFINITY ? 0.f : expf(v[k] - mx);
+      sum += v[k];
+    }
+    sum = group_sum<16>(sum);
+#pragma unroll
+    for (int k = 0; k < NMAX / 16; ++k) {
+      const int m = l + 16 * k;
+      if (n < N && m < N) t.S[n * NS + m] = v[k] / sum;
+    }
   }
+  __syncthreads();
+  // s4: A = P V
+  for (int e = tid; e < N * D; e += NT) {
+    const int n = e / D, i = e - n * D;
+    float acc = 0.f;
+    for (int m = 0; m < N; ++m) acc = fmaf(t.S[n * NS + m], t.V[m * TS + i], acc);
+    t.A[n * TS + i] = acc;
+  }
+  __syncthreads();
+  // s5: r = (Wo a + bo + h) * presence_n ; LN0 -> H1
+  for (int e = tid; e < ((N * D + NT - 1) / NT) * NT; e += NT) {
+    const bool ok = e < N * D;
+    const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
+    const float pn = presence_b ? presence_b[n] : 1.f;
+    const float r = (W[lay.l_b(3) + i] + dotD<D>(t.A + n * TS, W + lay.l_w(3) + i * TS) +
+                     t.H[n * TS + i]) * pn;
+    float y = r;
+    if (lay.ln) {
+      const float mean = group_sum<D>(r) * (1.f / D);
+      const float d = r - mean;
+      const float rstd = 1.f / sqrtf(group_sum<D>(d * d) * (1.f / D) + kLnEps);
+      const float xh = d * rstd;
+      y = fmaf(xh, W[lay.l_ln0() + i], W[lay.l_ln0() + D + i]);
+      if (KEEP && ok) {
+        t.XH0[n * TS + i] = xh;
+        if (i == 0) t.rstd0[n] = rstd;
+      }
+    }
+    if (ok) t.H1[n * TS + i] = y;
+  }
+  __syncthreads();
+  // s6: h2 = h1n + relu(Wf h1n + bf) ; LN1 -> H
+  for (int e = tid; e < ((N * D + NT - 1) / NT) * NT; e += NT) {
+    const bool ok = e < N * D;
+    const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
+    const float tv = W[lay.l_b(4) + i] + dotD<D>(t.H1 + n * TS, W + lay.l_w(4) + i * TS);
+    const float h2 = t.H1[n * TS + i] + fmaxf(tv, 0.f);
+    float y = h2;
+    if (lay.ln) {
+      const float mean = group_sum<D>(h2) * (1.f / D);
+      const float d = h2 - mean;
+      const float rstd = 1.f / sqrtf(group_sum<D>(d * d) * (1.f / D) + kLnEps);
+      const float xh = d * rstd;
+      y = fmaf(xh, W[lay.l_ln1() + i], W[lay.l_ln1() + D + i]);
+      if (KEEP && ok) {
+        t.XH1[n * TS + i] = xh;
+        if (i == 0) t.rstd1[n] = rstd;
+      }
+    }
+    if (KEEP && ok) t.T[n * TS + i] = tv;
+    if (ok) t.H[n * TS + i] = y;
+  }
+  __syncthreads();
 }
-
-// LDS carve shared by forward and backward
-template <int D>
-struct Smem {
-  int w, x, k, v, p, total_fwd;
-  // with_x: the forward keeps the input rows in LDS; the backward reads them
-  // from global memory instead (it only needs them column-wise, coalesced)
-  __host__ __device__ Smem(const Layout<D> &lay, int N, int DinP, bool with_x) {
-    w = 0;
-    x = (lay.lds_total() + 3) & ~3;
-    k = (x + (with_x ? N * DinP : 0) + 3) & ~3;
-    v = k + N * (D + 4);
-    p = v + N * (D + 4);
-    total_fwd = (p + N * (N + 1) + 3) & ~3;
-  }
-};
 
 template <int D>
 __global__ __launch_bounds__(NT) void st_fwd_kernel(StArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Layout<D> lay{a.Din, a.Dout, a.L, a.layer_norm};
-  const int N = a.N, Din = a.Din, DinP = Din | 1, lane = threadIdx.x;
-  const Smem<D> sm(lay, N, DinP, true);
-  float *s_w = smem + sm.w, *s_x = smem + sm.x, *s_k = smem + sm.k, *s_v = smem + sm.v,
-        *s_p = smem + sm.p;
   constexpr int TS = D + 4;
-  stage_weights<D>(lay, a.params, s_w);
-  const int n = lane < N ? lane : 0;
+  const Layout<D> lay{a.Din, a.Dout, a.L, a.layer_norm};
+  const int N = a.N, Din = a.Din, DinS = lay.DinS(), tid = threadIdx.x;
+  Tiles<D> t;
+  carve<D>(lay, N, false, smem, &t);
+  stage_weights<D>(lay, a.params, t);
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
-    stage_input<D>(a, b, s_x, DinP);
+    {  // stage the input rows (zero padded to DinS)
+      int col = 0;
+      for (int s = 0; s < a.nseg; ++s) {
+        const Seg &sg = a.seg[s];
+        for (int i = tid; i < N * sg.width; i += NT) {
+          const int n = i / sg.width, j = i - n * sg.width;
+          t.x[n * DinS + col + j] = sg.ptr[(size_t)b * sg.bs + (size_t)n * sg.rs + j];
+        }
+        col += sg.width;
+      }
+      const int pad = DinS - Din;
+      for (int i = tid; i < N * pad; i += NT) t.x[(i / pad) * DinS + Din + (i % pad)] = 0.f;
+    }
     __syncthreads();
     const float *presence_b = a.presence ? a.presence + (size_t)b * N : nullptr;
-    float h[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) h[i] = s_w[lay.lds_b1() + i];
-    for (int j = 0; j < Din; ++j) axpy_row<D>(s_x[n * DinP + j], s_w + lay.lds_w1t() + j * D, h);
-
+    for (int e = tid; e < N * D; e += NT) {  // fc1
+      const int n = e / D, i = e - n * D;
+      t.H[n * TS + i] = t.b1[i] + dot4(t.x + n * DinS, t.w1 + i * DinS, DinS / 4);
+    }
+    __syncthreads();
     float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
-    for (int l = 0; l < a.L; ++l) {
-      if (lane < N) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) hs[((size_t)l * N + lane) * D + i] = h[i];
-      }
-      BlockState<D> st;
-      float out[D];
-      sab_forward<D>(lay, s_w + lay.lds_layer(l), presence_b, N, lane, a.sqrt_d, h, s_k, s_v,
-                     s_p, st, out);
-#pragma unroll
-      for (int i = 0; i < D; ++i) h[i] = out[i];
+    for (int l = 0; l <= a.L; ++l) {
+      for (int e = tid; e < N * D; e += NT)
+        hs[(size_t)l * N * D + e] = t.H[(e / D) * TS + (e % D)];
+      if (l < a.L)
+        sab_forward<D, false>(lay, t.lw + l * lay.lds_layer_size(), presence_b, N, a.sqrt_d, t);
     }
-    if (lane < N) {
-#pragma unroll
-      for (int i = 0; i < D; ++i) hs[((size_t)a.L * N + lane) * D + i] = h[i];
+    // fc2: z[n][c] = b2[c] + h[n] . W2[c]   (W2 rows straight from L2)
+    const float *W2 = a.params + lay.off_w2();
+    for (int e = tid; e < N * a.Dout; e += NT) {
+      const int n = e / a.Dout, c = e - n * a.Dout;
+      a.z[((size_t)b * N + n) * a.Dout + c] =
+          a.params[lay.off_b2() + c] + dotD<D>(t.H + n * TS, W2 + (size_t)c * D);
     }
-    // fc2: lanes own output columns, rows come from an LDS tile
-    __syncthreads();
-    if (lane < N) store_row<D>(s_k, lane, h);
-    __syncthreads();
-    for (int c = lane; c < a.Dout; c += NT) {
-      float w[D];
-#pragma unroll
-      for (int j = 0; j < D; ++j) w[j] = a.params[lay.off_w2() + c * D + j];
-      const float bias = a.params[lay.off_b2() + c];
-      for (int m = 0; m < N; ++m)
-        a.z[((size_t)b * N + m) * a.Dout + c] = bias + dot_row<D>(w, s_k + m * TS);
-    }
-  }
-}
-
-// dW[i][j] += sum_n gy[n][i] x[n][j] for one D x D matrix (+ bias grad).
-// gy / x are LDS tiles; lane owns row i = lane % D, column block lane / D.
-template <int D>
-__device__ __forceinline__ void weight_grad(const float *s_gy, const float *s_xin, int N,
-                                            float *pg_w, float *pg_b) {
-  constexpr int TS = D + 4;
-  constexpr int NB = NT / D;        // column blocks handled in parallel
-  constexpr int CW = D / NB;        // columns per lane
-  const int i = threadIdx.x % D, cb = threadIdx.x / D;
-  float acc[CW];
-#pragma unroll
-  for (int c = 0; c < CW; ++c) acc[c] = 0.f;
-  float bacc = 0.f;
-  for (int m = 0; m < N; ++m) {
-    const float g = s_gy[m * TS + i];
-    bacc += g;
-#pragma unroll
-    for (int c = 0; c < CW; ++c) acc[c] = fmaf(g, s_xin[m * TS + cb * CW + c], acc[c]);
-  }
-#pragma unroll
-  for (int c = 0; c < CW; ++c) pg_w[i * D + cb * CW + c] += acc[c];
-  if (pg_b && cb == 0) pg_b[i] += bacc;
-}
-
-// per-feature sums over rows of a tile product:  gamma += sum_n gy*xhat, beta += sum_n gy
-template <int D>
-__device__ __forceinline__ void ln_param_grad(const float *s_gy, const float *s_xhat, int N,
-                                              float *pg_gamma) {
-  constexpr int TS = D + 4;
-  if (threadIdx.x < D) {
-    float ga = 0.f, be = 0.f;
-    for (int m = 0; m < N; ++m) {
-      const float g = s_gy[m * TS + threadIdx.x];
-      ga = fmaf(g, s_xhat[m * TS + threadIdx.x], ga);
-      be += g;
-    }
-    pg_gamma[threadIdx.x] += ga;
-    pg_gamma[D + threadIdx.x] += be;
   }
 }
 
 template <int D>
 __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Layout<D> lay{a.Din, a.Dout, a.L, a.layer_norm};
-  const int N = a.N, Din = a.Din, DinP = Din | 1, lane = threadIdx.x;
-  const Smem<D> sm(lay, N, DinP, false);
   constexpr int TS = D + 4;
-  const int ps = N + 1;
-  float *s_w = smem + sm.w, *s_k = smem + sm.k, *s_v = smem + sm.v, *s_p = smem + sm.p;
-  float *s_gs = smem + sm.total_fwd;               // [N][max(N, 64) + 1]
-  const int gs_stride = (N > NT ? N : NT) + 1;
-  float *s_t0 = s_gs + ((N * gs_stride + 3) & ~3); // four more [N][TS] tiles
-  float *s_t1 = s_t0 + N * TS;
-  float *s_t2 = s_t1 + N * TS;
-  float *s_t3 = s_t2 + N * TS;
-  float *s_pg = s_t3 + N * TS;                     // [P] parameter-gradient accumulators
+  const Layout<D> lay{a.Din, a.Dout, a.L, a.layer_norm};
+  const int N = a.N, Din = a.Din, DinS = lay.DinS(), tid = threadIdx.x, NS = N + 1;
   const int P = lay.total();
-  stage_weights<D>(lay, a.params, s_w);
-  for (int i = lane; i < P; i += NT) s_pg[i] = 0.f;
-  const int n = lane < N ? lane : 0;
-  const bool live = lane < N;
+  Tiles<D> t;
+  carve<D>(lay, N, true, smem, &t);
+  stage_weights<D>(lay, a.params, t);
+  for (int i = tid; i < a.L * lay.layer_size(); i += NT) t.pg[i] = 0.f;
+  float *part = a.pg_partial + (size_t)blockIdx.x * P;  // this workgroup's partial grads
+  const float *W2 = a.params + lay.off_w2();
+  bool first = true;
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
@@ -431,224 +393,216 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
     const float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
     const float *gzb = a.gz + (size_t)b * N * a.Dout;
 
-    // ---- fc2 backward ---------------------------------------------------
-    float hL[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) hL[i] = hs[((size_t)a.L * N + n) * D + i];
-    if (live) store_row<D>(s_k, lane, hL);
+    // ---- fc2 backward -----------------------------------------------------
+    for (int e = tid; e < N * D; e += NT)
+      t.H[(e / D) * TS + (e % D)] = hs[(size_t)a.L * N * D + e];
     __syncthreads();
-    float g[D];  // gradient w.r.t. the current block output, lane-row n
-#pragma unroll
-    for (int i = 0; i < D; ++i) g[i] = 0.f;
-    for (int c0 = 0; c0 < a.Dout; c0 += NT) {
-      const int c = c0 + lane;
-      const bool cl = c < a.Dout;
-      // (1) lanes = columns: dW2 / db2, and park the gz tile in LDS
-      float acc[D];
-#pragma unroll
-      for (int j = 0; j < D; ++j) acc[j] = 0.f;
-      float bacc = 0.f;
-      __syncthreads();
-      for (int m = 0; m < N; ++m) {
-        const float gv = cl ? gzb[(size_t)m * a.Dout + c] : 0.f;
-        s_gs[m * gs_stride + lane] = gv;
-        bacc += gv;
-        axpy_row<D>(gv, s_k + m * TS, acc);
+    for (int e = tid; e < N * D; e += NT) {  // G = gz W2
+      const int n = e / D, j = e - n * D;
+      const float *gr = gzb + (size_t)n * a.Dout;
+      float acc = 0.f;
+      for (int c = 0; c < a.Dout; ++c) acc = fmaf(gr[c], W2[(size_t)c * D + j], acc);
+      t.G[n * TS + j] = acc;
+    }
+    for (int e = tid; e < a.Dout * D; e += NT) {  // dW2[c][j] = sum_n gz[n][c] h[n][j]
+      const int c = e / D, j = e - c * D;
+      float acc = 0.f, bacc = 0.f;
+      for (int n = 0; n < N; ++n) {
+        const float g = gzb[(size_t)n * a.Dout + c];
+        acc = fmaf(g, t.H[n * TS + j], acc);
+        bacc += g;
       }
-      if (cl) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) s_pg[lay.off_w2() + c * D + j] += acc[j];
-        s_pg[lay.off_b2() + c] += bacc;
-      }
-      __syncthreads();
-      // (2) lanes = rows: g += gz[n][c] * W2[c][:]
-      const int cn = min(NT, a.Dout - c0);
-      for (int cc = 0; cc < cn; ++cc) {
-        const float gv = s_gs[n * gs_stride + cc];
-        const float *w2 = a.params + lay.off_w2() + (size_t)(c0 + cc) * D;
-#pragma unroll
-        for (int j = 0; j < D; ++j) g[j] = fmaf(gv, w2[j], g[j]);
+      float *pw = part + lay.off_w2() + e;
+      *pw = first ? acc : *pw + acc;
+      if (j == 0) {
+        float *pb = part + lay.off_b2() + c;
+        *pb = first ? bacc : *pb + bacc;
       }
     }
+    __syncthreads();
 
-    // ---- SAB blocks, last to first ---------------------------------------
+    // ---- SAB blocks, last to first ----------------------------------------
     for (int l = a.L - 1; l >= 0; --l) {
-      const float *W = s_w + lay.lds_layer(l);
-      float *PG = s_pg + lay.off_layer(l);
-      float h[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) h[i] = hs[((size_t)l * N + n) * D + i];
-      BlockState<D> st;
-      float out[D];
-      sab_forward<D>(lay, W, presence_b, N, lane, a.sqrt_d, h, s_k, s_v, s_p, st, out);
-      if (!live) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) g[i] = 0.f;
-      }
-      // LN1 backward
-      float g_h2[D];
-      if (lay.ln) {
-        __syncthreads();
-        if (live) {
-          store_row<D>(s_t0, lane, g);
-          store_row<D>(s_t1, lane, st.xhat1);
+      const float *W = t.lw + l * lay.lds_layer_size();
+      float *PG = t.pg + l * lay.layer_size();
+      const float *hin = hs + (size_t)l * N * D;  // the block's input (global, L2)
+      for (int e = tid; e < N * D; e += NT) t.H[(e / D) * TS + (e % D)] = hin[e];
+      __syncthreads();
+      sab_forward<D, true>(lay, W, presence_b, N, a.sqrt_d, t);
+
+      // b1: LN1 backward, ReLU gate
+      for (int e = tid; e < ((N * D + NT - 1) / NT) * NT; e += NT) {
+        const bool ok = e < N * D;
+        const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
+        const float g = ok ? t.G[n * TS + i] : 0.f;
+        float g_h2 = g;
+        if (lay.ln) {
+          const float xh = t.XH1[n * TS + i];
+          const float gh = g * W[lay.l_ln1() + i];
+          const float s1 = group_sum<D>(gh) * (1.f / D);
+          const float s2 = group_sum<D>(gh * xh) * (1.f / D);
+          g_h2 = (gh - s1 - xh * s2) * t.rstd1[n];
         }
-        __syncthreads();
-        ln_param_grad<D>(s_t0, s_t1, N, PG + lay.o_ln1());
-        layer_norm_bwd<D>(g, W + lay.o_ln1(), st.xhat1, st.rstd1, g_h2);
-      } else {
-#pragma unroll
-        for (int i = 0; i < D; ++i) g_h2[i] = g[i];
-      }
-      // h2 = h1n + relu(Wf h1n + bf)
-      float g_t[D], g_h1n[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        g_t[i] = st.t[i] > 0.f ? g_h2[i] : 0.f;
-        g_h1n[i] = g_h2[i];
-      }
-      linear_t<D>(W + lay.o_wf(), g_t, g_h1n);
-      __syncthreads();
-      if (live) {
-        store_row<D>(s_t0, lane, g_t);
-        store_row<D>(s_t1, lane, st.h1n);
-      }
-      __syncthreads();
-      weight_grad<D>(s_t0, s_t1, N, PG + lay.o_wf(), PG + lay.o_bf());
-      // LN0 backward
-      float g_r[D];
-      if (lay.ln) {
-        __syncthreads();
-        if (live) {
-          store_row<D>(s_t0, lane, g_h1n);
-          store_row<D>(s_t1, lane, st.xhat0);
-        }
-        __syncthreads();
-        ln_param_grad<D>(s_t0, s_t1, N, PG + lay.o_ln0());
-        layer_norm_bwd<D>(g_h1n, W + lay.o_ln0(), st.xhat0, st.rstd0, g_r);
-      } else {
-#pragma unroll
-        for (int i = 0; i < D; ++i) g_r[i] = g_h1n[i];
-      }
-      // r = (o + h) * presence_n
-      float g_o[D], g_h[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        g_o[i] = live ? g_r[i] * st.pn : 0.f;
-        g_h[i] = g_o[i];
-      }
-      // o = Wo a + bo
-      float g_a[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) g_a[i] = 0.f;
-      linear_t<D>(W + lay.o_wo(), g_o, g_a);
-      __syncthreads();
-      if (live) {
-        store_row<D>(s_t0, lane, g_o);
-        store_row<D>(s_t1, lane, st.a);
-        store_row<D>(s_t2, lane, g_a);
-        store_row<D>(s_t3, lane, st.q);
-      }
-      __syncthreads();
-      weight_grad<D>(s_t0, s_t1, N, PG + lay.o_wo(), PG + lay.o_bo());
-      // a = P v ; softmax ; s = q k^T / sqrt(d)
-      const float *prow = s_p + n * ps;
-      float *gsrow = s_gs + n * gs_stride;
-      const int Nl = live ? N : 0;
-      float dotp = 0.f;
-      for (int m = 0; m < Nl; ++m) {
-        const float gp = dot_row<D>(g_a, s_v + m * TS);  // dL/dP[n][m]
-        gsrow[m] = gp;
-        dotp = fmaf(prow[m], gp, dotp);
-      }
-      float g_q[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) g_q[i] = 0.f;
-      for (int m = 0; m < Nl; ++m) {
-        const float gs = prow[m] * (gsrow[m] - dotp) / a.sqrt_d;
-        gsrow[m] = gs;
-        axpy_row<D>(gs, s_k + m * TS, g_q);
-      }
-      __syncthreads();
-      // transposed sums: lane m gathers over query rows
-      float g_k[D], g_v[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) g_k[i] = g_v[i] = 0.f;
-      if (live) {
-        for (int r = 0; r < N; ++r) {
-          axpy_row<D>(s_gs[r * gs_stride + lane], s_t3 + r * TS, g_k);
-          axpy_row<D>(s_p[r * ps + lane], s_t2 + r * TS, g_v);
+        if (ok) {
+          t.GH1[n * TS + i] = g_h2;
+          t.T[n * TS + i] = t.T[n * TS + i] > 0.f ? g_h2 : 0.f;  // g_t, in place
         }
       }
-      linear_t<D>(W + lay.o_wq(), g_q, g_h);
-      linear_t<D>(W + lay.o_wk(), g_k, g_h);
-      linear_t<D>(W + lay.o_wv(), g_v, g_h);
-      // weight grads of the three input projections (x = h)
       __syncthreads();
-      if (live) {
-        store_row<D>(s_t0, lane, g_q);
-        store_row<D>(s_t1, lane, h);
-        store_row<D>(s_t2, lane, g_k);
-        store_row<D>(s_t3, lane, g_v);
+      // b2: through Wf, LN0 backward, presence gate
+      for (int e = tid; e < ((N * D + NT - 1) / NT) * NT; e += NT) {
+        const bool ok = e < N * D;
+        const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
+        const float g_h1n = t.GH1[n * TS + i] + dot_col<D>(t.T + n * TS, W + lay.l_w(4), i);
+        float g_r = g_h1n;
+        if (lay.ln) {
+          const float xh = t.XH0[n * TS + i];
+          const float gh = g_h1n * W[lay.l_ln0() + i];
+          const float s1 = group_sum<D>(gh) * (1.f / D);
+          const float s2 = group_sum<D>(gh * xh) * (1.f / D);
+          g_r = (gh - s1 - xh * s2) * t.rstd0[n];
+        }
+        if (ok) {
+          t.GO[n * TS + i] = g_r * (presence_b ? presence_b[n] : 1.f);
+          t.GH1[n * TS + i] = g_h1n;  // own element: kept for the LN0 parameter grads
+        }
       }
       __syncthreads();
-      weight_grad<D>(s_t0, s_t1, N, PG + lay.o_wq(), PG + lay.o_bq());
-      weight_grad<D>(s_t2, s_t1, N, PG + lay.o_wk(), PG + lay.o_bk());
-      weight_grad<D>(s_t3, s_t1, N, PG + lay.o_wv(), PG + lay.o_bv());
+      // b3: through Wo
+      for (int e = tid; e < N * D; e += NT) {
+        const int n = e / D, i = e - n * D;
+        t.GA[n * TS + i] = dot_col<D>(t.GO + n * TS, W + lay.l_w(3), i);
+      }
+      __syncthreads();
+      // b4: dL/dP
+      for (int e = tid; e < N * N; e += NT) {
+        const int n = e / N, m = e - n * N;
+        t.GS[n * NS + m] = dotD<D>(t.GA + n * TS, t.V + m * TS);
+      }
+      __syncthreads();
+      // b5: softmax backward, 16 lanes per row
+      for (int e = tid; e < ((N * 16 + NT - 1) / NT) * NT; e += NT) {
+        const int n = e >> 4, l16 = e & 15;
+        float p[NMAX / 16], gp[NMAX / 16];
+        float dot = 0.f;
 #pragma unroll
-      for (int i = 0; i < D; ++i) g[i] = g_h[i];
+        for (int k = 0; k < NMAX / 16; ++k) {
+          const int m = l16 + 16 * k;
+          const bool in = n < N && m < N;
+          p[k] = in ? t.S[n * NS + m] : 0.f;
+          gp[k] = in ? t.GS[n * NS + m] : 0.f;
+          dot = fmaf(p[k], gp[k], dot);
+        }
+        dot = group_sum<16>(dot);
+#pragma unroll
+        for (int k = 0; k < NMAX / 16; ++k) {
+          const int m = l16 + 16 * k;
+          if (n < N && m < N) t.GS[n * NS + m] = p[k] * (gp[k] - dot) / a.sqrt_d;
+        }
+      }
+      __syncthreads();
+      // b6: dQ, dK, dV
+      for (int e = tid; e < N * D; e += NT) {
+        const int n = e / D, i = e - n * D;
+        float gq = 0.f, gk = 0.f, gv = 0.f;
+        for (int m = 0; m < N; ++m) {
+          gq = fmaf(t.GS[n * NS + m], t.K[m * TS + i], gq);
+          gk = fmaf(t.GS[m * NS + n], t.Q[m * TS + i], gk);
+          gv = fmaf(t.S[m * NS + n], t.GA[m * TS + i], gv);
+        }
+        t.GQ[n * TS + i] = gq;
+        t.GK[n * TS + i] = gk;
+        t.GV[n * TS + i] = gv;
+      }
+      __syncthreads();
+      // b7: gradient w.r.t. the block input -> GN ; weight / bias / LN grads
+      for (int e = tid; e < N * D; e += NT) {
+        const int n = e / D, i = e - n * D;
+        t.GN[n * TS + i] = t.GO[n * TS + i] + dot_col<D>(t.GQ + n * TS, W + lay.l_w(0), i) +
+                           dot_col<D>(t.GK + n * TS, W + lay.l_w(1), i) +
+                           dot_col<D>(t.GV + n * TS, W + lay.l_w(2), i);
+      }
+      for (int e = tid; e < 5 * D * D; e += NT) {  // dW_m[i][j] = sum_n gy[n][i] x[n][j]
+        const int m = e / (D * D), rc = e - m * D * D, i = rc / D, j = rc - i * D;
+        const float *gy = m == 0 ? t.GQ : m == 1 ? t.GK : m == 2 ? t.GV : m == 3 ? t.GO : t.T;
+        float acc = 0.f;
+        if (m < 3) {
+          for (int n = 0; n < N; ++n) acc = fmaf(gy[n * TS + i], hin[n * D + j], acc);
+        } else {
+          const float *xin = m == 3 ? t.A : t.H1;
+          for (int n = 0; n < N; ++n) acc = fmaf(gy[n * TS + i], xin[n * TS + j], acc);
+        }
+        PG[lay.g_w(m) + rc] += acc;
+      }
+      for (int e = tid; e < 5 * D; e += NT) {  // bias grads: column sums
+        const int m = e / D, i = e - m * D;
+        const float *gy = m == 0 ? t.GQ : m == 1 ? t.GK : m == 2 ? t.GV : m == 3 ? t.GO : t.T;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += gy[n * TS + i];
+        PG[lay.g_b(m) + i] += acc;
+      }
+      if (lay.ln)
+        for (int e = tid; e < 4 * D; e += NT) {  // LN gamma / beta column sums
+          const int which = e / D, i = e - which * D;
+          const float *gy = which < 2 ? t.GH1 : t.G;
+          const float *xh = which < 2 ? t.XH0 : t.XH1;
+          float acc = 0.f;
+          for (int n = 0; n < N; ++n)
+            acc += (which & 1) ? gy[n * TS + i] : gy[n * TS + i] * xh[n * TS + i];
+          PG[(which < 2 ? lay.g_ln0() : lay.g_ln1()) + (which & 1) * D + i] += acc;
+        }
+      __syncthreads();
+      {  // next block's output gradient
+        float *tmp = t.G;
+        t.G = t.GN;
+        t.GN = tmp;
+      }
     }
 
-    // ---- fc1 backward -----------------------------------------------------
-    if (!live) {
-#pragma unroll
-      for (int i = 0; i < D; ++i) g[i] = 0.f;
-    }
-    __syncthreads();
-    if (live) store_row<D>(s_t0, lane, g);
-    __syncthreads();
-    for (int j = lane; j < Din; j += NT) {  // dW1[:, j]; x read column-wise from global
+    // ---- fc1 backward -------------------------------------------------------
+    for (int e = tid; e < D * Din; e += NT) {  // dW1[i][j] = sum_n g[n][i] x[n][j]
+      const int i = e / Din, j = e - i * Din;
       int sj = 0, cj = j;
       while (cj >= a.seg[sj].width) cj -= a.seg[sj++].width;
       const Seg &xs = a.seg[sj];
       const float *xcol = xs.ptr + (size_t)b * xs.bs + cj;
-      float acc[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) acc[i] = 0.f;
-      for (int m = 0; m < N; ++m) axpy_row<D>(xcol[(size_t)m * xs.rs], s_t0 + m * TS, acc);
-#pragma unroll
-      for (int i = 0; i < D; ++i) s_pg[lay.off_w1() + i * Din + j] += acc[i];
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc = fmaf(t.G[n * TS + i], xcol[(size_t)n * xs.rs], acc);
+      float *pw = part + e;
+      *pw = first ? acc : *pw + acc;
     }
-    if (lane < D) {
-      float bacc = 0.f;
-      for (int m = 0; m < N; ++m) bacc += s_t0[m * TS + lane];
-      s_pg[lay.off_b1() + lane] += bacc;
+    for (int i = tid; i < D; i += NT) {
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc += t.G[n * TS + i];
+      float *pb = part + lay.off_b1() + i;
+      *pb = first ? acc : *pb + acc;
     }
-    // input gradients for the segments that want one
-    int col = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-      const Seg &sg = a.seg[s];
-      if (sg.grad && live) {
-        for (int j = 0; j < sg.width; ++j)
-          sg.grad[((size_t)b * N + lane) * sg.width + j] =
-              dot_row<D>(g, s_w + lay.lds_w1t() + (col + j) * D);
+    {  // input gradients for the segments that want one
+      int col = 0;
+      for (int s = 0; s < a.nseg; ++s) {
+        const Seg &sg = a.seg[s];
+        if (sg.grad) {
+          for (int e = tid; e < N * sg.width; e += NT) {
+            const int n = e / sg.width, j = e - n * sg.width;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) acc = fmaf(t.G[n * TS + i], t.w1[i * DinS + col + j], acc);
+            sg.grad[((size_t)b * N + n) * sg.width + j] = acc;
+          }
+        }
+        col += sg.width;
       }
-      col += sg.width;
     }
+    first = false;
   }
   __syncthreads();
-  float *dst = a.pg_partial + (size_t)blockIdx.x * P;
-  for (int i = lane; i < P; i += NT) dst[i] = s_pg[i];
+  for (int i = tid; i < a.L * lay.layer_size(); i += NT) part[lay.off_layer(0) + i] = t.pg[i];
 }
 
 template <int D>
 size_t lds_bytes(const StArgs &a, bool bwd) {
   const Layout<D> lay{a.Din, a.Dout, a.L, a.layer_norm};
-  const Smem<D> sm(lay, a.N, a.Din | 1, !bwd);
-  size_t f = sm.total_fwd;
-  const int gs_stride = (a.N > NT ? a.N : NT) + 1;
-  if (bwd) f += ((a.N * gs_stride + 3) & ~3) + 4 * a.N * (D + 4) + lay.total();
-  return f * sizeof(float);
+  return carve<D>(lay, a.N, bwd, nullptr, nullptr) * sizeof(float);
 }
 
 template <int D>
@@ -704,7 +658,7 @@ extern "C" int scae_set_encoder_param_count(int D, int Din, int Dout, int L, int
   return D * Din + D + L * (5 * (D * D + D) + (layer_norm ? 4 * D : 0)) + Dout * D + Dout;
 }
 
-extern "C" int scae_set_encoder_grid(int B) { return B < 256 ? B : 256; }
+extern "C" int scae_set_encoder_grid(int B) { return B < 512 ? B : 512; }
 
 extern "C" int scae_set_encoder_supported(int N, int D, int Din, int Dout, int L,
                                           int layer_norm) {
@@ -717,9 +671,9 @@ extern "C" int scae_set_encoder_supported(int N, int D, int Din, int Dout, int L
   a.layer_norm = layer_norm;
   size_t need;
   switch (D) {
-    case 8: need = lds_bytes<8>(a, true); break;
-    case 16: need = lds_bytes<16>(a, true); break;
-    case 32: need = lds_bytes<32>(a, true); break;
+    case 8: need = std::max(lds_bytes<8>(a, true), lds_bytes<8>(a, false)); break;
+    case 16: need = std::max(lds_bytes<16>(a, true), lds_bytes<16>(a, false)); break;
+    case 32: need = std::max(lds_bytes<32>(a, true), lds_bytes<32>(a, false)); break;
     default: return 0;
   }
   return need <= 160 * 1024 ? 1 : 0;
