@@ -11,7 +11,7 @@
 #include "common.h"
 
 namespace {
-constexpr int NT = 256;
+constexpr int NT = 1024;
 constexpr int MAXCLS = 32;
 
 struct TailArgs {
@@ -31,9 +31,9 @@ struct TailArgs {
 __device__ __forceinline__ float block_total(float v, float *red) {
   float a[1] = {v};
   scae::block_sum<1, NT>(a, red);
-  if (threadIdx.x == 0) red[15] = a[0];
+  if (threadIdx.x == 0) red[31] = a[0];
   __syncthreads();
-  const float r = red[15];
+  const float r = red[31];
   __syncthreads();
   return r;
 }
@@ -60,10 +60,15 @@ __device__ void row_col_sums(const Stats &s, int B, int O) {
     for (int o = 0; o < O; ++o) t += s.x[b * O + o];
     s.row[b] = t;
   }
-  for (int o = threadIdx.x; o < O; o += NT) {
+  // column sums: 16 lanes per column, each takes every 16th row
+  for (int e = threadIdx.x; e < ((O * 16 + NT - 1) / NT) * NT; e += NT) {
+    const int o = e >> 4, l = e & 15;
     float t = 0.f;
-    for (int b = 0; b < B; ++b) t += s.x[b * O + o];
-    s.col[o] = t;
+    if (o < O)
+      for (int b = l; b < B; b += 16) t += s.x[b * O + o];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (o < O && l == 0) s.col[o] = t;
   }
   __syncthreads();
 }
@@ -195,7 +200,7 @@ __device__ Carve carve(float *smem, int B, int O, int ncls) {
   c.row_m = c.col_c + O;
   c.col_m = c.row_m + B;
   c.red = c.col_m + O;
-  c.gl = c.red + 16;  // [2][B][ncls] classifier logit grads (backward only)
+  c.gl = c.red + 32;  // [2][B][ncls] classifier logit grads (backward only)
   return c;
 }
 
@@ -206,7 +211,15 @@ __device__ void load_stats(const TailArgs &a, const Carve &c) {
     c.cp[i] = a.cp[i];
     const float *pr = a.posterior + ((size_t)b * (O + 1) + o) * M;
     float t = 0.f;
-    for (int m = 0; m < M; ++m) t += pr[m];
+    if ((M & 3) == 0) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(pr);
+      for (int m = 0; m < M / 4; ++m) {
+        const float4 v = p4[m];
+        t += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int m = 0; m < M; ++m) t += pr[m];
+    }
     c.mass[i] = t / M;  // mass_explained_by_capsule / n_points (:260-266)
   }
   __syncthreads();
@@ -294,8 +307,7 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, const float *g
   // posterior (B,O+1,M): mass/M = sum_m post / M; the dummy row gets zero
   for (int i = threadIdx.x; i < B * (O + 1) * M; i += NT) {
     const int m = i % M, bo = i / M, o = bo % (O + 1), b = bo / (O + 1);
-    (void)m;
-    g_post[i] = o < O ? gm[b * O + o] / M : 0.f;
+        g_post[i] = o < O ? gm[b * O + o] / M : 0.f;
   }
   // classifier parameter gradients (inputs are detached)
   if (a.label && g_w) {
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, const float *g
 }
 
 size_t tail_lds(int B, int O, bool bwd) {
-  size_t f = 2 * (size_t)B * O + 2 * B + 2 * O + 16;
+  size_t f = 2 * (size_t)B * O + 2 * B + 2 * O + 32;
   if (bwd) f += 2 * (size_t)B * MAXCLS + 2 * (size_t)B * O + B;
   return f * sizeof(float);
 }

@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 512;  // 8 waves: every (N x D) stage of a 24 x 16 set is one pass
 constexpr int NMAX = 64;   // max set size
 constexpr int MAXSEG = 4;  // input given as up to 4 column segments
 constexpr float kLnEps = 1e-5f;
@@ -103,46 +103,76 @@ __device__ __forceinline__ float group_max(float v) {
 __device__ __forceinline__ float dot4(const float *a, const float *b, int n4) {
   const float4 *pa = reinterpret_cast<const float4 *>(a);
   const float4 *pb = reinterpret_cast<const float4 *>(b);
-  float acc = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains
+#pragma unroll 4
   for (int j = 0; j < n4; ++j) {
     const float4 x = pa[j], y = pb[j];
-    acc = fmaf(x.x, y.x, acc);
-    acc = fmaf(x.y, y.y, acc);
-    acc = fmaf(x.z, y.z, acc);
-    acc = fmaf(x.w, y.w, acc);
+    a0 = fmaf(x.x, y.x, a0);
+    a1 = fmaf(x.y, y.y, a1);
+    a2 = fmaf(x.z, y.z, a2);
+    a3 = fmaf(x.w, y.w, a3);
   }
-  return acc;
+  return (a0 + a1) + (a2 + a3);
 }
 template <int D>
 __device__ __forceinline__ float dotD(const float *a, const float *b) {
   const float4 *pa = reinterpret_cast<const float4 *>(a);
   const float4 *pb = reinterpret_cast<const float4 *>(b);
-  float acc = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains
 #pragma unroll
   for (int j = 0; j < D / 4; ++j) {
     const float4 x = pa[j], y = pb[j];
-    acc = fmaf(x.x, y.x, acc);
-    acc = fmaf(x.y, y.y, acc);
-    acc = fmaf(x.z, y.z, acc);
-    acc = fmaf(x.w, y.w, acc);
+    a0 = fmaf(x.x, y.x, a0);
+    a1 = fmaf(x.y, y.y, a1);
+    a2 = fmaf(x.z, y.z, a2);
+    a3 = fmaf(x.w, y.w, a3);
   }
-  return acc;
+  return (a0 + a1) + (a2 + a3);
 }
 // sum_k g[k] * W[k][i]  (column i of a TS-strided matrix; lanes i consecutive)
 template <int D>
 __device__ __forceinline__ float dot_col(const float *grow, const float *W, int i) {
   constexpr int TS = D + 4;
-  float acc = 0.f;
+  float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-  for (int k = 0; k < D; ++k) acc = fmaf(grow[k], W[k * TS + i], acc);
-  return acc;
+  for (int k = 0; k < D; k += 2) {
+    a0 = fmaf(grow[k], W[k * TS + i], a0);
+    a1 = fmaf(grow[k + 1], W[(k + 1) * TS + i], a1);
+  }
+  return a0 + a1;
+}
+
+// element (b, n, col) of the segmented input; static walk over the segment
+// table (a runtime-indexed kernel-argument array would be spilled to scratch)
+__device__ __forceinline__ float load_x(const StArgs &a, int b, int n, int col) {
+  float v = 0.f;
+  int c0 = 0;
+#pragma unroll
+  for (int s = 0; s < MAXSEG; ++s) {
+    if (s < a.nseg) {
+      const int w = a.seg[s].width;
+      if (col >= c0 && col < c0 + w)
+        v = a.seg[s].ptr[(size_t)b * a.seg[s].bs + (size_t)n * a.seg[s].rs + (col - c0)];
+      c0 += w;
+    }
+  }
+  return v;
 }
 
 template <int D>
-struct Tiles {  // LDS carve
-  float *w1, *b1, *lw, *x;
-  float *H, *Q, *K, *V, *A, *H1, *T, *XH0, *XH1, *G, *GN, *GH1, *GO, *GA, *GQ, *GK, *GV;
-  float *S, *GS, *rstd0, *rstd1, *pg;
+struct Tiles {  // LDS carve.  The (N x TS) activation tiles are addressed as
+                // base + index * tile so that only one pointer stays live
+                // (25 separate tile pointers overflowed the SGPR file and the
+                // compiler spilled the whole struct to scratch memory).
+  float *w1, *b1, *lw, *x, *tiles, *S, *GS, *rstd0, *rstd1, *pg, *scr;
+  int tile;
+#define SCAE_TILE(name, k) \
+  __device__ __forceinline__ float *name() const { return tiles + (k) * tile; }
+  SCAE_TILE(H, 0) SCAE_TILE(Q, 1) SCAE_TILE(K, 2) SCAE_TILE(V, 3) SCAE_TILE(A, 4)
+  SCAE_TILE(H1, 5) SCAE_TILE(T, 6) SCAE_TILE(XH0, 7) SCAE_TILE(XH1, 8) SCAE_TILE(G, 9)
+  SCAE_TILE(GN, 10) SCAE_TILE(GH1, 11) SCAE_TILE(GO, 12) SCAE_TILE(GA, 13)
+  SCAE_TILE(GQ, 14) SCAE_TILE(GK, 15) SCAE_TILE(GV, 16) SCAE_TILE(HIN, 17)
+#undef SCAE_TILE
 };
 
 template <int D>
@@ -160,39 +190,27 @@ __host__ __device__ size_t carve(const Layout<D> &lay, int N, bool bwd, float *b
   r.b1 = take(D);
   r.lw = take((size_t)lay.L * lay.lds_layer_size());
   r.x = bwd ? nullptr : take((size_t)N * lay.DinS());
-  const size_t tile = (size_t)N * TS;
-  r.H = take(tile);
-  r.Q = take(tile);
-  r.K = take(tile);
-  r.V = take(tile);
-  r.A = take(tile);
-  r.H1 = take(tile);
+  r.tile = N * TS;  // multiple of 4 floats
+  r.tiles = take((size_t)r.tile * (bwd ? 18 : 6));
   r.S = take((size_t)N * (N + 1));
   if (bwd) {
-    r.T = take(tile);
-    r.XH0 = take(tile);
-    r.XH1 = take(tile);
-    r.G = take(tile);
-    r.GN = take(tile);
-    r.GH1 = take(tile);
-    r.GO = take(tile);
-    r.GA = take(tile);
-    r.GQ = take(tile);
-    r.GK = take(tile);
-    r.GV = take(tile);
     r.GS = take((size_t)N * (N + 1));
     r.rstd0 = take(N);
     r.rstd1 = take(N);
     r.pg = take((size_t)lay.L * lay.layer_size());
+    // staging scratch: max(gz chunk [N][65] + W2 chunk [64][TS], x chunk [N][129])
+    const size_t s1 = (size_t)N * 65 + 64 * TS, s2 = (size_t)N * 129;
+    r.scr = take(s1 > s2 ? s1 : s2);
   }
   if (out) *out = r;
   return o;
 }
 
 template <int D>
-__device__ void stage_weights(const Layout<D> &lay, const float *params, const Tiles<D> &t) {
+__device__ __forceinline__ void stage_weights(const Layout<D> &lay, const float *params, const Tiles<D> &t) {
   constexpr int TS = D + 4;
   const int Din = lay.Din, DinS = lay.DinS();
+#pragma unroll 4
   for (int i = threadIdx.x; i < D * DinS; i += NT) {
     const int r = i / DinS, c = i - r * DinS;
     t.w1[i] = c < Din ? params[r * Din + c] : 0.f;
@@ -201,6 +219,7 @@ __device__ void stage_weights(const Layout<D> &lay, const float *params, const T
   for (int l = 0; l < lay.L; ++l) {
     const float *g = params + lay.off_layer(l);
     float *w = t.lw + l * lay.lds_layer_size();
+#pragma unroll 4
     for (int i = threadIdx.x; i < 5 * D * D; i += NT) {
       const int m = i / (D * D), rc = i - m * D * D, r = rc / D, c = rc - r * D;
       w[lay.l_w(m) + r * TS + c] = g[lay.g_w(m) + rc];
@@ -217,11 +236,11 @@ __device__ void stage_weights(const Layout<D> &lay, const float *params, const T
   }
 }
 
-// One SAB forward on LDS tiles: reads t.H, leaves the block output in t.H.
+// One SAB forward on LDS tiles: reads t.H(), leaves the block output in t.H().
 // KEEP: also store what the backward needs (T, XH0, XH1, rstd0/1).
 // Ends with a __syncthreads().
 template <int D, bool KEEP>
-__device__ void sab_forward(const Layout<D> &lay, const float *W, const float *presence_b,
+__device__ __forceinline__ void sab_forward(const Layout<D> &lay, const float *W, const float *presence_b,
                             int N, float sqrt_d, const Tiles<D> &t) {
   constexpr int TS = D + 4;
   const int NS = N + 1;
@@ -229,16 +248,16 @@ __device__ void sab_forward(const Layout<D> &lay, const float *W, const float *p
   // s1: Q, K, V projections
   for (int e = tid; e < N * D; e += NT) {
     const int n = e / D, i = e - n * D;
-    const float *h = t.H + n * TS;
-    t.Q[n * TS + i] = W[lay.l_b(0) + i] + dotD<D>(h, W + lay.l_w(0) + i * TS);
-    t.K[n * TS + i] = W[lay.l_b(1) + i] + dotD<D>(h, W + lay.l_w(1) + i * TS);
-    t.V[n * TS + i] = W[lay.l_b(2) + i] + dotD<D>(h, W + lay.l_w(2) + i * TS);
+    const float *h = t.H() + n * TS;
+    t.Q()[n * TS + i] = W[lay.l_b(0) + i] + dotD<D>(h, W + lay.l_w(0) + i * TS);
+    t.K()[n * TS + i] = W[lay.l_b(1) + i] + dotD<D>(h, W + lay.l_w(1) + i * TS);
+    t.V()[n * TS + i] = W[lay.l_b(2) + i] + dotD<D>(h, W + lay.l_w(2) + i * TS);
   }
   __syncthreads();
   // s2: routing = (q k^T - (1 - presence) 1e32) / sqrt(d)   (set_transformer.py:40-43)
   for (int e = tid; e < N * N; e += NT) {
     const int n = e / N, m = e - n * N;
-    float s = dotD<D>(t.Q + n * TS, t.K + m * TS);
+    float s = dotD<D>(t.Q() + n * TS, t.K() + m * TS);
     if (presence_b) s = s - (1.f - presence_b[m]) * 1e32f;
     t.S[n * NS + m] = s / sqrt_d;
   }
@@ -273,8 +292,9 @@ __device__ void sab_forward(const Layout<D> &lay, const float *W, const float *p
   for (int e = tid; e < N * D; e += NT) {
     const int n = e / D, i = e - n * D;
     float acc = 0.f;
-    for (int m = 0; m < N; ++m) acc = fmaf(t.S[n * NS + m], t.V[m * TS + i], acc);
-    t.A[n * TS + i] = acc;
+#pragma unroll 4
+    for (int m = 0; m < N; ++m) acc = fmaf(t.S[n * NS + m], t.V()[m * TS + i], acc);
+    t.A()[n * TS + i] = acc;
   }
   __syncthreads();
   // s5: r = (Wo a + bo + h) * presence_n ; LN0 -> H1
@@ -282,8 +302,8 @@ __device__ void sab_forward(const Layout<D> &lay, const float *W, const float *p
     const bool ok = e < N * D;
     const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
     const float pn = presence_b ? presence_b[n] : 1.f;
-    const float r = (W[lay.l_b(3) + i] + dotD<D>(t.A + n * TS, W + lay.l_w(3) + i * TS) +
-                     t.H[n * TS + i]) * pn;
+    const float r = (W[lay.l_b(3) + i] + dotD<D>(t.A() + n * TS, W + lay.l_w(3) + i * TS) +
+                     t.H()[n * TS + i]) * pn;
     float y = r;
     if (lay.ln) {
       const float mean = group_sum<D>(r) * (1.f / D);
@@ -292,19 +312,19 @@ __device__ void sab_forward(const Layout<D> &lay, const float *W, const float *p
       const float xh = d * rstd;
       y = fmaf(xh, W[lay.l_ln0() + i], W[lay.l_ln0() + D + i]);
       if (KEEP && ok) {
-        t.XH0[n * TS + i] = xh;
+        t.XH0()[n * TS + i] = xh;
         if (i == 0) t.rstd0[n] = rstd;
       }
     }
-    if (ok) t.H1[n * TS + i] = y;
+    if (ok) t.H1()[n * TS + i] = y;
   }
   __syncthreads();
   // s6: h2 = h1n + relu(Wf h1n + bf) ; LN1 -> H
   for (int e = tid; e < ((N * D + NT - 1) / NT) * NT; e += NT) {
     const bool ok = e < N * D;
     const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
-    const float tv = W[lay.l_b(4) + i] + dotD<D>(t.H1 + n * TS, W + lay.l_w(4) + i * TS);
-    const float h2 = t.H1[n * TS + i] + fmaxf(tv, 0.f);
+    const float tv = W[lay.l_b(4) + i] + dotD<D>(t.H1() + n * TS, W + lay.l_w(4) + i * TS);
+    const float h2 = t.H1()[n * TS + i] + fmaxf(tv, 0.f);
     float y = h2;
     if (lay.ln) {
       const float mean = group_sum<D>(h2) * (1.f / D);
@@ -313,12 +333,12 @@ __device__ void sab_forward(const Layout<D> &lay, const float *W, const float *p
       const float xh = d * rstd;
       y = fmaf(xh, W[lay.l_ln1() + i], W[lay.l_ln1() + D + i]);
       if (KEEP && ok) {
-        t.XH1[n * TS + i] = xh;
+        t.XH1()[n * TS + i] = xh;
         if (i == 0) t.rstd1[n] = rstd;
       }
     }
-    if (KEEP && ok) t.T[n * TS + i] = tv;
-    if (ok) t.H[n * TS + i] = y;
+    if (KEEP && ok) t.T()[n * TS + i] = tv;
+    if (ok) t.H()[n * TS + i] = y;
   }
   __syncthreads();
 }
@@ -337,13 +357,18 @@ __global__ __launch_bounds__(NT) void st_fwd_kernel(StArgs a) {
     __syncthreads();
     {  // stage the input rows (zero padded to DinS)
       int col = 0;
-      for (int s = 0; s < a.nseg; ++s) {
-        const Seg &sg = a.seg[s];
-        for (int i = tid; i < N * sg.width; i += NT) {
-          const int n = i / sg.width, j = i - n * sg.width;
-          t.x[n * DinS + col + j] = sg.ptr[(size_t)b * sg.bs + (size_t)n * sg.rs + j];
+#pragma unroll
+      for (int s = 0; s < MAXSEG; ++s) {
+        if (s < a.nseg) {
+          const int w = a.seg[s].width;
+#pragma unroll 4
+          for (int i = tid; i < N * w; i += NT) {
+            const int n = i / w, j = i - n * w;
+            t.x[n * DinS + col + j] =
+                a.seg[s].ptr[(size_t)b * a.seg[s].bs + (size_t)n * a.seg[s].rs + j];
+          }
+          col += w;
         }
-        col += sg.width;
       }
       const int pad = DinS - Din;
       for (int i = tid; i < N * pad; i += NT) t.x[(i / pad) * DinS + Din + (i % pad)] = 0.f;
@@ -352,13 +377,13 @@ __global__ __launch_bounds__(NT) void st_fwd_kernel(StArgs a) {
     const float *presence_b = a.presence ? a.presence + (size_t)b * N : nullptr;
     for (int e = tid; e < N * D; e += NT) {  // fc1
       const int n = e / D, i = e - n * D;
-      t.H[n * TS + i] = t.b1[i] + dot4(t.x + n * DinS, t.w1 + i * DinS, DinS / 4);
+      t.H()[n * TS + i] = t.b1[i] + dot4(t.x + n * DinS, t.w1 + i * DinS, DinS / 4);
     }
     __syncthreads();
     float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
     for (int l = 0; l <= a.L; ++l) {
       for (int e = tid; e < N * D; e += NT)
-        hs[(size_t)l * N * D + e] = t.H[(e / D) * TS + (e % D)];
+        hs[(size_t)l * N * D + e] = t.H()[(e / D) * TS + (e % D)];
       if (l < a.L)
         sab_forward<D, false>(lay, t.lw + l * lay.lds_layer_size(), presence_b, N, a.sqrt_d, t);
     }
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(NT) void st_fwd_kernel(StArgs a) {
     for (int e = tid; e < N * a.Dout; e += NT) {
       const int n = e / a.Dout, c = e - n * a.Dout;
       a.z[((size_t)b * N + n) * a.Dout + c] =
-          a.params[lay.off_b2() + c] + dotD<D>(t.H + n * TS, W2 + (size_t)c * D);
+          a.params[lay.off_b2() + c] + dotD<D>(t.H() + n * TS, W2 + (size_t)c * D);
     }
   }
 }
@@ -389,44 +414,60 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
+    float *G = t.G(), *GN = t.GN();  // ping-pong: gradient w.r.t. the current block output
     const float *presence_b = a.presence ? a.presence + (size_t)b * N : nullptr;
     const float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
     const float *gzb = a.gz + (size_t)b * N * a.Dout;
 
     // ---- fc2 backward -----------------------------------------------------
     for (int e = tid; e < N * D; e += NT)
-      t.H[(e / D) * TS + (e % D)] = hs[(size_t)a.L * N * D + e];
+      t.H()[(e / D) * TS + (e % D)] = hs[(size_t)a.L * N * D + e];
     __syncthreads();
-    for (int e = tid; e < N * D; e += NT) {  // G = gz W2
-      const int n = e / D, j = e - n * D;
-      const float *gr = gzb + (size_t)n * a.Dout;
-      float acc = 0.f;
-      for (int c = 0; c < a.Dout; ++c) acc = fmaf(gr[c], W2[(size_t)c * D + j], acc);
-      t.G[n * TS + j] = acc;
-    }
-    for (int e = tid; e < a.Dout * D; e += NT) {  // dW2[c][j] = sum_n gz[n][c] h[n][j]
-      const int c = e / D, j = e - c * D;
-      float acc = 0.f, bacc = 0.f;
-      for (int n = 0; n < N; ++n) {
-        const float g = gzb[(size_t)n * a.Dout + c];
-        acc = fmaf(g, t.H[n * TS + j], acc);
-        bacc += g;
+    for (int c0 = 0; c0 < a.Dout; c0 += 64) {  // Dout walked in 64-column chunks via LDS
+      const int cn = min(64, a.Dout - c0);
+      float *sg = t.scr, *sw = t.scr + N * 65;
+#pragma unroll 4
+      for (int e = tid; e < N * cn; e += NT) {
+        const int n = e / cn, cc = e - n * cn;
+        sg[n * 65 + cc] = gzb[(size_t)n * a.Dout + c0 + cc];
       }
-      float *pw = part + lay.off_w2() + e;
-      *pw = first ? acc : *pw + acc;
-      if (j == 0) {
-        float *pb = part + lay.off_b2() + c;
-        *pb = first ? bacc : *pb + bacc;
+      for (int e = tid; e < cn * D; e += NT) sw[(e / D) * TS + (e % D)] = W2[(size_t)c0 * D + e];
+      __syncthreads();
+      for (int e = tid; e < N * D; e += NT) {  // G += gz W2
+        const int n = e / D, j = e - n * D;
+        float acc = c0 == 0 ? 0.f : G[n * TS + j];
+#pragma unroll 8
+        for (int cc = 0; cc < cn; ++cc) acc = fmaf(sg[n * 65 + cc], sw[cc * TS + j], acc);
+        G[n * TS + j] = acc;
       }
+      for (int e = tid; e < cn * D; e += NT) {  // dW2[c][j] = sum_n gz[n][c] h[n][j]
+        const int cc = e / D, j = e - cc * D;
+        float acc = 0.f, bacc = 0.f;
+        for (int n = 0; n < N; ++n) {
+          const float g = sg[n * 65 + cc];
+          acc = fmaf(g, t.H()[n * TS + j], acc);
+          bacc += g;
+        }
+        float *pw = part + lay.off_w2() + (size_t)c0 * D + e;
+        *pw = first ? acc : *pw + acc;
+        if (j == 0) {
+          float *pb = part + lay.off_b2() + c0 + cc;
+          *pb = first ? bacc : *pb + bacc;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
 
     // ---- SAB blocks, last to first ----------------------------------------
     for (int l = a.L - 1; l >= 0; --l) {
       const float *W = t.lw + l * lay.lds_layer_size();
       float *PG = t.pg + l * lay.layer_size();
       const float *hin = hs + (size_t)l * N * D;  // the block's input (global, L2)
-      for (int e = tid; e < N * D; e += NT) t.H[(e / D) * TS + (e % D)] = hin[e];
+      for (int e = tid; e < N * D; e += NT) {
+        const float h = hin[e];
+        t.H()[(e / D) * TS + (e % D)] = h;
+        t.HIN()[(e / D) * TS + (e % D)] = h;
+      }
       __syncthreads();
       sab_forward<D, true>(lay, W, presence_b, N, a.sqrt_d, t);
 
@@ -434,18 +475,18 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
       for (int e = tid; e < ((N * D + NT - 1) / NT) * NT; e += NT) {
         const bool ok = e < N * D;
         const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
-        const float g = ok ? t.G[n * TS + i] : 0.f;
+        const float g = ok ? G[n * TS + i] : 0.f;
         float g_h2 = g;
         if (lay.ln) {
-          const float xh = t.XH1[n * TS + i];
+          const float xh = t.XH1()[n * TS + i];
           const float gh = g * W[lay.l_ln1() + i];
           const float s1 = group_sum<D>(gh) * (1.f / D);
           const float s2 = group_sum<D>(gh * xh) * (1.f / D);
           g_h2 = (gh - s1 - xh * s2) * t.rstd1[n];
         }
         if (ok) {
-          t.GH1[n * TS + i] = g_h2;
-          t.T[n * TS + i] = t.T[n * TS + i] > 0.f ? g_h2 : 0.f;  // g_t, in place
+          t.GH1()[n * TS + i] = g_h2;
+          t.T()[n * TS + i] = t.T()[n * TS + i] > 0.f ? g_h2 : 0.f;  // g_t, in place
         }
       }
       __syncthreads();
@@ -453,31 +494,31 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
       for (int e = tid; e < ((N * D + NT - 1) / NT) * NT; e += NT) {
         const bool ok = e < N * D;
         const int n = ok ? e / D : 0, i = ok ? e - n * D : 0;
-        const float g_h1n = t.GH1[n * TS + i] + dot_col<D>(t.T + n * TS, W + lay.l_w(4), i);
+        const float g_h1n = t.GH1()[n * TS + i] + dot_col<D>(t.T() + n * TS, W + lay.l_w(4), i);
         float g_r = g_h1n;
         if (lay.ln) {
-          const float xh = t.XH0[n * TS + i];
+          const float xh = t.XH0()[n * TS + i];
           const float gh = g_h1n * W[lay.l_ln0() + i];
           const float s1 = group_sum<D>(gh) * (1.f / D);
           const float s2 = group_sum<D>(gh * xh) * (1.f / D);
           g_r = (gh - s1 - xh * s2) * t.rstd0[n];
         }
         if (ok) {
-          t.GO[n * TS + i] = g_r * (presence_b ? presence_b[n] : 1.f);
-          t.GH1[n * TS + i] = g_h1n;  // own element: kept for the LN0 parameter grads
+          t.GO()[n * TS + i] = g_r * (presence_b ? presence_b[n] : 1.f);
+          t.GH1()[n * TS + i] = g_h1n;  // own element: kept for the LN0 parameter grads
         }
       }
       __syncthreads();
       // b3: through Wo
       for (int e = tid; e < N * D; e += NT) {
         const int n = e / D, i = e - n * D;
-        t.GA[n * TS + i] = dot_col<D>(t.GO + n * TS, W + lay.l_w(3), i);
+        t.GA()[n * TS + i] = dot_col<D>(t.GO() + n * TS, W + lay.l_w(3), i);
       }
       __syncthreads();
       // b4: dL/dP
       for (int e = tid; e < N * N; e += NT) {
         const int n = e / N, m = e - n * N;
-        t.GS[n * NS + m] = dotD<D>(t.GA + n * TS, t.V + m * TS);
+        t.GS[n * NS + m] = dotD<D>(t.GA() + n * TS, t.V() + m * TS);
       }
       __syncthreads();
       // b5: softmax backward, 16 lanes per row
@@ -505,92 +546,115 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
       for (int e = tid; e < N * D; e += NT) {
         const int n = e / D, i = e - n * D;
         float gq = 0.f, gk = 0.f, gv = 0.f;
+#pragma unroll 4
         for (int m = 0; m < N; ++m) {
-          gq = fmaf(t.GS[n * NS + m], t.K[m * TS + i], gq);
-          gk = fmaf(t.GS[m * NS + n], t.Q[m * TS + i], gk);
-          gv = fmaf(t.S[m * NS + n], t.GA[m * TS + i], gv);
+          gq = fmaf(t.GS[n * NS + m], t.K()[m * TS + i], gq);
+          gk = fmaf(t.GS[m * NS + n], t.Q()[m * TS + i], gk);
+          gv = fmaf(t.S[m * NS + n], t.GA()[m * TS + i], gv);
         }
-        t.GQ[n * TS + i] = gq;
-        t.GK[n * TS + i] = gk;
-        t.GV[n * TS + i] = gv;
+        t.GQ()[n * TS + i] = gq;
+        t.GK()[n * TS + i] = gk;
+        t.GV()[n * TS + i] = gv;
       }
       __syncthreads();
       // b7: gradient w.r.t. the block input -> GN ; weight / bias / LN grads
       for (int e = tid; e < N * D; e += NT) {
         const int n = e / D, i = e - n * D;
-        t.GN[n * TS + i] = t.GO[n * TS + i] + dot_col<D>(t.GQ + n * TS, W + lay.l_w(0), i) +
-                           dot_col<D>(t.GK + n * TS, W + lay.l_w(1), i) +
-                           dot_col<D>(t.GV + n * TS, W + lay.l_w(2), i);
+        GN[n * TS + i] = t.GO()[n * TS + i] + dot_col<D>(t.GQ() + n * TS, W + lay.l_w(0), i) +
+                           dot_col<D>(t.GK() + n * TS, W + lay.l_w(1), i) +
+                           dot_col<D>(t.GV() + n * TS, W + lay.l_w(2), i);
       }
-      for (int e = tid; e < 5 * D * D; e += NT) {  // dW_m[i][j] = sum_n gy[n][i] x[n][j]
+      // dW[i][j] += sum_n gy[n][i] x[n][j], db[i] += sum_n gy[n][i]; one call per
+      // matrix with compile-time tile pointers (a runtime-selected pointer table
+      // would push the whole tile struct to scratch memory)
+      for (int e = tid; e < 5 * D * D; e += NT) {  // all five matrices in one pass
         const int m = e / (D * D), rc = e - m * D * D, i = rc / D, j = rc - i * D;
-        const float *gy = m == 0 ? t.GQ : m == 1 ? t.GK : m == 2 ? t.GV : m == 3 ? t.GO : t.T;
-        float acc = 0.f;
-        if (m < 3) {
-          for (int n = 0; n < N; ++n) acc = fmaf(gy[n * TS + i], hin[n * D + j], acc);
-        } else {
-          const float *xin = m == 3 ? t.A : t.H1;
-          for (int n = 0; n < N; ++n) acc = fmaf(gy[n * TS + i], xin[n * TS + j], acc);
+        // tile indices (see Tiles): gy = GQ,GK,GV,GO,T ; x = HIN,HIN,HIN,A,H1
+        const int gi = m < 3 ? 14 + m : (m == 3 ? 12 : 6);
+        const int xi = m < 3 ? 17 : (m == 3 ? 4 : 5);
+        const float *gy = t.tiles + gi * t.tile, *xin = t.tiles + xi * t.tile;
+        float a0 = 0.f, a1 = 0.f;
+        int n = 0;
+        for (; n + 1 < N; n += 2) {
+          a0 = fmaf(gy[n * TS + i], xin[n * TS + j], a0);
+          a1 = fmaf(gy[(n + 1) * TS + i], xin[(n + 1) * TS + j], a1);
         }
-        PG[lay.g_w(m) + rc] += acc;
+        if (n < N) a0 = fmaf(gy[n * TS + i], xin[n * TS + j], a0);
+        PG[lay.g_w(m) + rc] += a0 + a1;
       }
       for (int e = tid; e < 5 * D; e += NT) {  // bias grads: column sums
         const int m = e / D, i = e - m * D;
-        const float *gy = m == 0 ? t.GQ : m == 1 ? t.GK : m == 2 ? t.GV : m == 3 ? t.GO : t.T;
+        const int gi = m < 3 ? 14 + m : (m == 3 ? 12 : 6);
+        const float *gy = t.tiles + gi * t.tile;
         float acc = 0.f;
         for (int n = 0; n < N; ++n) acc += gy[n * TS + i];
         PG[lay.g_b(m) + i] += acc;
       }
-      if (lay.ln)
-        for (int e = tid; e < 4 * D; e += NT) {  // LN gamma / beta column sums
-          const int which = e / D, i = e - which * D;
-          const float *gy = which < 2 ? t.GH1 : t.G;
-          const float *xh = which < 2 ? t.XH0 : t.XH1;
-          float acc = 0.f;
-          for (int n = 0; n < N; ++n)
-            acc += (which & 1) ? gy[n * TS + i] : gy[n * TS + i] * xh[n * TS + i];
-          PG[(which < 2 ? lay.g_ln0() : lay.g_ln1()) + (which & 1) * D + i] += acc;
-        }
+      if (lay.ln) {  // LN gamma / beta: column sums of gy * xhat and gy
+        auto lngrad = [&](const float *gy, const float *xh, int off) {
+          for (int e = tid; e < 2 * D; e += NT) {
+            const int beta = e / D, i = e - beta * D;
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n)
+              acc += beta ? gy[n * TS + i] : gy[n * TS + i] * xh[n * TS + i];
+            PG[off + e] += acc;
+          }
+        };
+        lngrad(t.GH1(), t.XH0(), lay.g_ln0());
+        lngrad(G, t.XH1(), lay.g_ln1());
+      }
       __syncthreads();
       {  // next block's output gradient
-        float *tmp = t.G;
-        t.G = t.GN;
-        t.GN = tmp;
+        float *tmp = G;
+        G = GN;
+        GN = tmp;
       }
     }
 
     // ---- fc1 backward -------------------------------------------------------
-    for (int e = tid; e < D * Din; e += NT) {  // dW1[i][j] = sum_n g[n][i] x[n][j]
-      const int i = e / Din, j = e - i * Din;
-      int sj = 0, cj = j;
-      while (cj >= a.seg[sj].width) cj -= a.seg[sj++].width;
-      const Seg &xs = a.seg[sj];
-      const float *xcol = xs.ptr + (size_t)b * xs.bs + cj;
-      float acc = 0.f;
-      for (int n = 0; n < N; ++n) acc = fmaf(t.G[n * TS + i], xcol[(size_t)n * xs.rs], acc);
-      float *pw = part + e;
-      *pw = first ? acc : *pw + acc;
+    for (int j0 = 0; j0 < Din; j0 += 128) {  // Din walked in 128-column chunks via LDS
+      const int jn = min(128, Din - j0);
+      __syncthreads();
+#pragma unroll 4
+      for (int e = tid; e < N * jn; e += NT) {
+        const int n = e / jn, jj = e - n * jn;
+        t.scr[n * 129 + jj] = load_x(a, b, n, j0 + jj);
+      }
+      __syncthreads();
+      for (int e = tid; e < D * jn; e += NT) {  // dW1[i][j] = sum_n g[n][i] x[n][j]
+        const int i = e / jn, jj = e - i * jn;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int n = 0; n < N; ++n) acc = fmaf(G[n * TS + i], t.scr[n * 129 + jj], acc);
+        float *pw = part + (size_t)i * Din + j0 + jj;
+        *pw = first ? acc : *pw + acc;
+      }
     }
     for (int i = tid; i < D; i += NT) {
       float acc = 0.f;
-      for (int n = 0; n < N; ++n) acc += t.G[n * TS + i];
+      for (int n = 0; n < N; ++n) acc += G[n * TS + i];
       float *pb = part + lay.off_b1() + i;
       *pb = first ? acc : *pb + acc;
     }
     {  // input gradients for the segments that want one
       int col = 0;
-      for (int s = 0; s < a.nseg; ++s) {
-        const Seg &sg = a.seg[s];
-        if (sg.grad) {
-          for (int e = tid; e < N * sg.width; e += NT) {
-            const int n = e / sg.width, j = e - n * sg.width;
-            float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < D; ++i) acc = fmaf(t.G[n * TS + i], t.w1[i * DinS + col + j], acc);
-            sg.grad[((size_t)b * N + n) * sg.width + j] = acc;
+      for (int s = 0; s < MAXSEG; ++s) {
+        if (s < a.nseg) {
+          const int w = a.seg[s].width;
+          float *gdst = a.seg[s].grad;
+          if (gdst) {
+            for (int e = tid; e < N * w; e += NT) {
+              const int n = e / w, j = e - n * w;
+              float acc = 0.f;
+#pragma unroll
+              for (int i = 0; i < D; ++i)
+                acc = fmaf(G[n * TS + i], t.w1[i * DinS + col + j], acc);
+              gdst[((size_t)b * N + n) * w + j] = acc;
+            }
           }
+          col += w;
         }
-        col += sg.width;
       }
     }
     first = false;
