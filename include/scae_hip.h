@@ -94,6 +94,8 @@ int scae_qkv_attention_bwd_f32(const float *q, const float *k, const float *v,
  *     b2 (Dout)], every matrix row-major (out,in) like nn.Linear.weight;
  *     scae_set_encoder_param_count() gives its length.
  *   z (B,N,Dout) = fc2 output; hsave (B,L+1,N,D) workspace kept for backward.
+ *   Dout = 0 selects "trunk only": no W2/b2 in params, z (B,N,D) receives the
+ *   last block's output (the caller folds fc2 into the output attention, K2c).
  *   Limits: N <= 64, D in {8,16,32}, n_heads = 1.
  *   backward: gz (B,N,Dout) -> seg_grad[s] (B,N,width) contiguous, nullable
  *   per segment; pg_partial (scae_set_encoder_grid(B), P) per-workgroup
@@ -114,6 +116,31 @@ int scae_set_encoder_bwd_f32(int nseg, const float *const *seg_ptr, const int *s
                              const float *params, const float *hsave, const float *gz,
                              float *pg_partial, int B, int N, int D, int Din, int Dout,
                              int L, int layer_norm, void *stream);
+
+/* ------------------------------------------------------------------------
+ * K2c  output attention with folded projections
+ *      replaces set_transformer.py:218-223 (fc2 + MultiHeadQKVAttention(seeds,
+ *      z, z, presence), n_heads = 1) given the trunk output h (B,N,D):
+ *        K' = h wk^T + bk,  V' = h wv^T + bv   (wk = Wk W2 etc., folded by the
+ *        caller; bo and the value bias ride inside bv because softmax rows sum
+ *        to one),  out = softmax((q K'^T - (1-presence) 1e32)/sqrt(C)) V'
+ *   q (O,C) = q_projector(seeds) (batch invariant); wk, wv (C,D); bk, bv (C);
+ *   out (B,O,C); probs (B,O,N) nullable (inspection only).
+ *   backward: gout (B,O,C) -> gh (B,N,D); partial (scae_seed_attention_grid(B),
+ *   O*C + 2*C*D + 2*C) = per-workgroup [gq | gwk | gbk | gwv | gbv] (caller
+ *   sums over dim 0).  Limits: N, O <= 64, D in {8,16,32}, C % 8 == 0, LDS.
+ * ---------------------------------------------------------------------- */
+int scae_seed_attention_grid(int B);
+int scae_seed_attention_supported(int N, int O, int D, int C);
+int scae_seed_attention_fwd_f32(const float *h, const float *q, const float *wk,
+                                const float *bk, const float *wv, const float *bv,
+                                const float *presence, float *out, float *probs, int B,
+                                int N, int O, int D, int C, void *stream);
+int scae_seed_attention_bwd_f32(const float *h, const float *q, const float *wk,
+                                const float *bk, const float *wv, const float *bv,
+                                const float *presence, const float *gout, float *gh,
+                                float *partial, int B, int N, int O, int D, int C,
+                                void *stream);
 
 /* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225

@@ -42,6 +42,10 @@ SIGNATURES = {
     "scae_set_encoder_fwd_f32": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7 + [P],
     "scae_set_encoder_bwd_f32": [c_int, P, P, P, P, P, P, P, P, P, P]
                                 + [c_int] * 7 + [P],
+    "scae_seed_attention_grid": [c_int],
+    "scae_seed_attention_supported": [c_int] * 4,
+    "scae_seed_attention_fwd_f32": [P] * 9 + [c_int] * 5 + [P],
+    "scae_seed_attention_bwd_f32": [P] * 10 + [c_int] * 5 + [P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

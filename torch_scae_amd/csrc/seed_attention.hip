@@ -1,0 +1,381 @@
+// K2c -- output attention of the set transformer, gfx950:
+//   MultiHeadQKVAttention(seeds, z, z, presence) with z = fc2(h)
+//   (set_transformer.py:218-223 + :68-104 with n_heads = 1).
+//
+// Algebra used (exact up to fp32 re-association): z enters the attention only
+// through the linear maps k = Wk z + bk and v = Wv z + bv, and the output
+// projection is linear too, so with h the (N x D) trunk output
+//     K' = h (Wk W2)^T + (Wk b2 + bk)                         (N x C)
+//     V' = h (Wo Wv W2)^T + (Wo (Wv b2 + bv) + bo)            (N x C)
+//     out = softmax((q K'^T - (1 - presence) 1e32) / sqrt(C)) V'
+// (rows of the softmax sum to one, which is what lets bo ride inside V').
+// The three C x C = 256 x 256 projections of 3072 rows each -- ~1.2 GFLOP
+// forward, the largest GEMMs of the object encoder -- collapse into two
+// (C x D) = 256 x 16 maps that are evaluated INSIDE this kernel from LDS; the
+// folding products themselves are a few tiny batch-invariant GEMMs done by the
+// caller (and differentiated by autograd).  q = Wq seeds + bq is batch
+// invariant as well and is passed in.
+//
+// One workgroup (8 waves) per set, element-parallel stages on LDS tiles like
+// set_encoder.hip; the presence mask arithmetic is the reference's fp32
+// sequence.  Backward recomputes K', V', writes h-gradients once and leaves
+// per-workgroup partial parameter gradients for the caller to sum.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+constexpr int NT = 512;
+constexpr int NMAX = 64;
+
+struct SaArgs {
+  const float *h;         // (B,N,D)
+  const float *q;         // (O,C)
+  const float *wk, *bk;   // (C,D), (C)
+  const float *wv, *bv;   // (C,D), (C)
+  const float *presence;  // (B,N) nullable
+  float *out;             // (B,O,C)
+  float *probs;           // (B,O,N)
+  const float *gout;      // bwd (B,O,C)
+  float *gh;              // bwd (B,N,D)
+  float *partial;         // bwd (grid, O*C + 2*C*D + 2*C): [gq | gwk | gbk | gwv | gbv]
+  int B, N, O, C;
+  float sqrt_c;
+};
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ float dot4(const float *a, const float *b, int n4) {
+  const float4 *pa = reinterpret_cast<const float4 *>(a);
+  const float4 *pb = reinterpret_cast<const float4 *>(b);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+  for (int j = 0; j < n4; ++j) {
+    const float4 x = pa[j], y = pb[j];
+    a0 = fmaf(x.x, y.x, a0);
+    a1 = fmaf(x.y, y.y, a1);
+    a2 = fmaf(x.z, y.z, a2);
+    a3 = fmaf(x.w, y.w, a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int D>
+struct Carve {
+  float *h, *q, *wk, *wv, *bk, *bv, *K, *V, *S, *GO, *GS;
+  int CS;  // padded row stride of the (.. x C) tiles
+};
+
+template <int D>
+__host__ __device__ size_t carve(int N, int O, int C, bool bwd, float *base, Carve<D> *out) {
+  constexpr int TS = D + 4;
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    float *p = base ? base + o : nullptr;
+    o += (n + 3) & ~(size_t)3;
+    return p;
+  };
+  Carve<D> r{};
+  r.CS = C + 4;  // C multiple of 8 -> (C+4)/4 odd: conflict-free row-per-lane b128 reads
+  r.h = take((size_t)N * TS);
+  r.q = take((size_t)O * r.CS);
+  r.wk = take((size_t)C * TS);
+  r.wv = take((size_t)C * TS);
+  r.bk = take(C);
+  r.bv = take(C);
+  r.K = take((size_t)N * r.CS);
+  r.V = take((size_t)N * r.CS);
+  r.S = take((size_t)O * (N + 1));
+  if (bwd) {
+    r.GO = take((size_t)O * r.CS);
+    r.GS = take((size_t)O * (N + 1));
+  }
+  if (out) *out = r;
+  return o;
+}
+
+template <int D>
+__device__ __forceinline__ void stage_common(const SaArgs &a, const Carve<D> &c) {
+  constexpr int TS = D + 4;
+  const int C = a.C, O = a.O, tid = threadIdx.x;
+#pragma unroll 4
+  for (int e = tid; e < C * D; e += NT) {
+    const int r = e / D, j = e - r * D;
+    c.wk[r * TS + j] = a.wk[e];
+    c.wv[r * TS + j] = a.wv[e];
+  }
+  for (int e = tid; e < C; e += NT) {
+    c.bk[e] = a.bk[e];
+    c.bv[e] = a.bv[e];
+  }
+#pragma unroll 4
+  for (int e = tid; e < O * C; e += NT) {
+    const int o = e / C, cc = e - o * C;
+    c.q[o * c.CS + cc] = a.q[e];
+  }
+}
+
+// K', V', routing, softmax for sample b; leaves P in c.S.  Ends with a barrier.
+template <int D>
+__device__ __forceinline__ void forward_core(const SaArgs &a, const Carve<D> &c, int b) {
+  constexpr int TS = D + 4;
+  const int N = a.N, O = a.O, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
+  for (int e = tid; e < N * D; e += NT)
+    c.h[(e / D) * TS + (e % D)] = a.h[(size_t)b * N * D + e];
+  __syncthreads();
+  for (int e = tid; e < N * C; e += NT) {  // K' and V'
+    const int m = e / C, cc = e - m * C;
+    c.K[m * CS + cc] = c.bk[cc] + dot4(c.h + m * TS, c.wk + cc * TS, D / 4);
+    c.V[m * CS + cc] = c.bv[cc] + dot4(c.h + m * TS, c.wv + cc * TS, D / 4);
+  }
+  __syncthreads();
+  const float *pres = a.presence ? a.presence + (size_t)b * N : nullptr;
+  for (int e = tid; e < O * N; e += NT) {  // routing (set_transformer.py:40-43)
+    const int o = e / N, m = e - o * N;
+    float s = dot4(c.q + o * CS, c.K + m * CS, C / 4);
+    if (pres) s = s - (1.f - pres[m]) * 1e32f;
+    c.S[o * NS + m] = s / a.sqrt_c;
+  }
+  __syncthreads();
+  for (int e = tid; e < ((O * 16 + NT - 1) / NT) * NT; e += NT) {  // softmax, 16 lanes / row
+    const int o = e >> 4, l = e & 15;
+    float v[NMAX / 16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NMAX / 16; ++k) {
+      const int m = l + 16 * k;
+      v[k] = (o < O && m < N) ? c.S[o * NS + m] : -INFINITY;
+      mx = fmaxf(mx, v[k]);
+    }
+    mx = group_max<16>(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NMAX / 16; ++k) {
+      v[k] = v[k] == -INFINITY ? 0.f : expf(v[k] - mx);
+      sum += v[k];
+    }
+    sum = group_sum<16>(sum);
+#pragma unroll
+    for (int k = 0; k < NMAX / 16; ++k) {
+      const int m = l + 16 * k;
+      if (o < O && m < N) c.S[o * NS + m] = v[k] / sum;
+    }
+  }
+  __syncthreads();
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void sa_fwd_kernel(SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  Carve<D> c;
+  carve<D>(a.N, a.O, a.C, false, smem, &c);
+  const int N = a.N, O = a.O, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
+  stage_common<D>(a, c);
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();
+    forward_core<D>(a, c, b);
+    if (a.probs)
+      for (int e = tid; e < O * N; e += NT)
+        a.probs[(size_t)b * O * N + e] = c.S[(e / N) * NS + (e % N)];
+    for (int e = tid; e < O * C; e += NT) {  // out = P V'
+      const int o = e / C, cc = e - o * C;
+      float a0 = 0.f, a1 = 0.f;
+      int m = 0;
+      for (; m + 1 < N; m += 2) {
+        a0 = fmaf(c.S[o * NS + m], c.V[m * CS + cc], a0);
+        a1 = fmaf(c.S[o * NS + m + 1], c.V[(m + 1) * CS + cc], a1);
+      }
+      if (m < N) a0 = fmaf(c.S[o * NS + m], c.V[m * CS + cc], a0);
+      a.out[((size_t)b * O + o) * C + cc] = a0 + a1;
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void sa_bwd_kernel(SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TS = D + 4;
+  Carve<D> c;
+  carve<D>(a.N, a.O, a.C, true, smem, &c);
+  const int N = a.N, O = a.O, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
+  stage_common<D>(a, c);
+  const size_t P = (size_t)O * C + 2 * (size_t)C * D + 2 * C;
+  float *part = a.partial + blockIdx.x * P;
+  float *p_gq = part, *p_gwk = part + (size_t)O * C, *p_gbk = p_gwk + (size_t)C * D,
+        *p_gwv = p_gbk + C, *p_gbv = p_gwv + (size_t)C * D;
+  bool first = true;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();
+    forward_core<D>(a, c, b);  // recompute K', V', P
+#pragma unroll 4
+    for (int e = tid; e < O * C; e += NT)
+      c.GO[(e / C) * CS + (e % C)] = a.gout[(size_t)b * O * C + e];
+    __syncthreads();
+    for (int e = tid; e < O * N; e += NT) {  // dL/dP
+      const int o = e / N, m = e - o * N;
+      c.GS[o * NS + m] = dot4(c.GO + o * CS, c.V + m * CS, C / 4);
+    }
+    __syncthreads();
+    for (int e = tid; e < ((O * 16 + NT - 1) / NT) * NT; e += NT) {  // softmax backward
+      const int o = e >> 4, l = e & 15;
+      float p[NMAX / 16], gp[NMAX / 16];
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < NMAX / 16; ++k) {
+        const int m = l + 16 * k;
+        const bool in = o < O && m < N;
+        p[k] = in ? c.S[o * NS + m] : 0.f;
+        gp[k] = in ? c.GS[o * NS + m] : 0.f;
+        dot = fmaf(p[k], gp[k], dot);
+      }
+      dot = group_sum<16>(dot);
+#pragma unroll
+      for (int k = 0; k < NMAX / 16; ++k) {
+        const int m = l + 16 * k;
+        if (o < O && m < N) c.GS[o * NS + m] = p[k] * (gp[k] - dot) / a.sqrt_c;
+      }
+    }
+    // (V' is dead once dL/dP is known: its tile now receives dL/dV')
+    for (int e = tid; e < N * C; e += NT) {
+      const int m = e / C, cc = e - m * C;
+      float acc = 0.f;
+#pragma unroll 4
+      for (int o = 0; o < O; ++o) acc = fmaf(c.S[o * NS + m], c.GO[o * CS + cc], acc);
+      c.V[m * CS + cc] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < O * C; e += NT) {  // dq (batch-invariant query): partial sum
+      const int o = e / C, cc = e - o * C;
+      float acc = 0.f;
+#pragma unroll 4
+      for (int m = 0; m < N; ++m) acc = fmaf(c.GS[o * NS + m], c.K[m * CS + cc], acc);
+      p_gq[e] = first ? acc : p_gq[e] + acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * C; e += NT) {  // dL/dK' into the K' tile
+      const int m = e / C, cc = e - m * C;
+      float acc = 0.f;
+#pragma unroll 4
+      for (int o = 0; o < O; ++o) acc = fmaf(c.GS[o * NS + m], c.q[o * CS + cc], acc);
+      c.K[m * CS + cc] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * D; e += NT) {  // dh = dK' Wk2 + dV' Wvo
+      const int m = e / D, j = e - m * D;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+      for (int cc = 0; cc < C; ++cc) {
+        a0 = fmaf(c.K[m * CS + cc], c.wk[cc * TS + j], a0);
+        a1 = fmaf(c.V[m * CS + cc], c.wv[cc * TS + j], a1);
+      }
+      a.gh[(size_t)b * N * D + e] = a0 + a1;
+    }
+    for (int e = tid; e < C * D; e += NT) {  // dWk2, dWvo (+ biases)
+      const int cc = e / D, j = e - cc * D;
+      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+      for (int m = 0; m < N; ++m) {
+        const float gk = c.K[m * CS + cc], gv = c.V[m * CS + cc], hv = c.h[m * TS + j];
+        a0 = fmaf(gk, hv, a0);
+        a1 = fmaf(gv, hv, a1);
+        b0 += gk;
+        b1 += gv;
+      }
+      p_gwk[e] = first ? a0 : p_gwk[e] + a0;
+      p_gwv[e] = first ? a1 : p_gwv[e] + a1;
+      if (j == 0) {
+        p_gbk[cc] = first ? b0 : p_gbk[cc] + b0;
+        p_gbv[cc] = first ? b1 : p_gbv[cc] + b1;
+      }
+    }
+    first = false;
+  }
+}
+
+template <int D>
+size_t lds_bytes(int N, int O, int C, bool bwd) {
+  return carve<D>(N, O, C, bwd, nullptr, nullptr) * sizeof(float);
+}
+
+int check(const SaArgs &a, int D) {
+  if (a.B <= 0 || a.N <= 0 || a.O <= 0 || a.C <= 0) return SCAE_ERR_BAD_ARG;
+  if (a.N > NMAX || a.O > NMAX || (a.C & 7) || (D != 8 && D != 16 && D != 32))
+    return SCAE_ERR_UNSUPPORTED;
+  return SCAE_OK;
+}
+
+template <int D>
+int launch(const SaArgs &a, bool bwd, hipStream_t st) {
+  const size_t lds = lds_bytes<D>(a.N, a.O, a.C, bwd);
+  if (lds > 160 * 1024) return SCAE_ERR_UNSUPPORTED;
+  const void *fn = bwd ? reinterpret_cast<const void *>(sa_bwd_kernel<D>)
+                       : reinterpret_cast<const void *>(sa_fwd_kernel<D>);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int grid = a.B < 512 ? a.B : 512;
+  if (bwd)
+    hipLaunchKernelGGL(sa_bwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
+  else
+    hipLaunchKernelGGL(sa_fwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
+  return scae_launch_status();
+}
+}  // namespace
+
+extern "C" int scae_seed_attention_grid(int B) { return B < 512 ? B : 512; }
+
+extern "C" int scae_seed_attention_supported(int N, int O, int D, int C) {
+  if (N <= 0 || O <= 0 || N > NMAX || O > NMAX || C <= 0 || (C & 7)) return 0;
+  size_t need;
+  switch (D) {
+    case 8: need = lds_bytes<8>(N, O, C, true); break;
+    case 16: need = lds_bytes<16>(N, O, C, true); break;
+    case 32: need = lds_bytes<32>(N, O, C, true); break;
+    default: return 0;
+  }
+  return need <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int scae_seed_attention_fwd_f32(const float *h, const float *q, const float *wk,
+                                           const float *bk, const float *wv, const float *bv,
+                                           const float *presence, float *out, float *probs,
+                                           int B, int N, int O, int D, int C, void *stream) {
+  SCAE_REQUIRE(h && q && wk && bk && wv && bv && out);
+  SaArgs a{h, q, wk, bk, wv, bv, presence, out, probs, nullptr, nullptr, nullptr,
+           B, N, O, C, sqrtf((float)C)};
+  int rc = check(a, D);
+  if (rc) return rc;
+  switch (D) {
+    case 8: return launch<8>(a, false, (hipStream_t)stream);
+    case 16: return launch<16>(a, false, (hipStream_t)stream);
+    default: return launch<32>(a, false, (hipStream_t)stream);
+  }
+}
+
+extern "C" int scae_seed_attention_bwd_f32(const float *h, const float *q, const float *wk,
+                                           const float *bk, const float *wv, const float *bv,
+                                           const float *presence, const float *gout, float *gh,
+                                           float *partial, int B, int N, int O, int D, int C,
+                                           void *stream) {
+  SCAE_REQUIRE(h && q && wk && bk && wv && bv && gout && gh && partial);
+  SaArgs a{h, q, wk, bk, wv, bv, presence, nullptr, nullptr, gout, gh, partial,
+           B, N, O, C, sqrtf((float)C)};
+  int rc = check(a, D);
+  if (rc) return rc;
+  switch (D) {
+    case 8: return launch<8>(a, true, (hipStream_t)stream);
+    case 16: return launch<16>(a, true, (hipStream_t)stream);
+    default: return launch<32>(a, true, (hipStream_t)stream);
+  }
+}

@@ -387,6 +387,10 @@ __global__ __launch_bounds__(NT) void st_fwd_kernel(StArgs a) {
       if (l < a.L)
         sab_forward<D, false>(lay, t.lw + l * lay.lds_layer_size(), presence_b, N, a.sqrt_d, t);
     }
+    if (a.Dout == 0) {  // trunk only: the caller folds fc2 into what follows
+      for (int e = tid; e < N * D; e += NT)
+        a.z[(size_t)b * N * D + e] = t.H()[(e / D) * TS + (e % D)];
+    }
     // fc2: z[n][c] = b2[c] + h[n] . W2[c]   (W2 rows straight from L2)
     const float *W2 = a.params + lay.off_w2();
     for (int e = tid; e < N * a.Dout; e += NT) {
@@ -423,6 +427,11 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
     for (int e = tid; e < N * D; e += NT)
       t.H()[(e / D) * TS + (e % D)] = hs[(size_t)a.L * N * D + e];
     __syncthreads();
+    if (a.Dout == 0) {  // no fc2: gz is already the gradient of the trunk output
+      for (int e = tid; e < N * D; e += NT)
+        G[(e / D) * TS + (e % D)] = a.gz[(size_t)b * N * D + e];
+      __syncthreads();
+    }
     for (int c0 = 0; c0 < a.Dout; c0 += 64) {  // Dout walked in 64-column chunks via LDS
       const int cn = min(64, a.Dout - c0);
       float *sg = t.scr, *sw = t.scr + N * 65;
@@ -693,7 +702,7 @@ int fill_args(StArgs &a, int nseg, const float *const *seg_ptr, const int *seg_w
   if (nseg < 1 || nseg > MAXSEG || !seg_ptr || !seg_width || !seg_row_stride ||
       !seg_batch_stride || !params)
     return SCAE_ERR_BAD_ARG;
-  if (B <= 0 || N <= 0 || Din <= 0 || Dout <= 0 || L < 0) return SCAE_ERR_BAD_ARG;
+  if (B <= 0 || N <= 0 || Din <= 0 || Dout < 0 || L < 0) return SCAE_ERR_BAD_ARG;
   if (N > NMAX || (D != 8 && D != 16 && D != 32)) return SCAE_ERR_UNSUPPORTED;
   int tot = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -726,7 +735,7 @@ extern "C" int scae_set_encoder_grid(int B) { return B < 512 ? B : 512; }
 
 extern "C" int scae_set_encoder_supported(int N, int D, int Din, int Dout, int L,
                                           int layer_norm) {
-  if (N <= 0 || N > NMAX || Din <= 0 || Dout <= 0 || L < 0) return 0;
+  if (N <= 0 || N > NMAX || Din <= 0 || Dout < 0 || L < 0) return 0;
   StArgs a{};
   a.N = N;
   a.Din = Din;

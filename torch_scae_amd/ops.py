@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
-__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "loss_tail", "loss_tail_supported", "capsule_votes",
+__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "seed_attention", "seed_attention_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
@@ -152,7 +152,8 @@ class _SetEncoder(torch.autograd.Function):
         lib = _lib.load()
         assert packed.numel() == lib.scae_set_encoder_param_count(
             D, Din, Dout, L, int(layer_norm))
-        z = torch.empty(B, N, Dout, device=packed.device, dtype=packed.dtype)
+        z = torch.empty(B, N, Dout if Dout else D, device=packed.device,
+                        dtype=packed.dtype)
         hsave = torch.empty(B, L + 1, N, D, device=packed.device,
                             dtype=packed.dtype)
         ptrs, widths, rs, bs = _seg_arrays(segs)
@@ -197,6 +198,58 @@ def set_encoder(segments, presence, packed_params, dim_hidden, dim_out,
     return _SetEncoder.apply(presence, packed_params,
                              (dim_hidden, dim_out, n_layers, bool(layer_norm)),
                              *segments)
+
+
+# ----------------------------------------------------------------------------
+# K2c output attention with folded projections (set_transformer.py:218-223)
+# ----------------------------------------------------------------------------
+def seed_attention_supported(N, O, D, C):
+    return bool(_lib.load().scae_seed_attention_supported(N, O, D, C))
+
+
+class _SeedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, q, wk, bk, wv, bv, presence):
+        _need_hip(h, q, wk, bk, wv, bv, presence)
+        h, q, wk, bk, wv, bv, presence = (_c(t) for t in (h, q, wk, bk, wv, bv,
+                                                          presence))
+        B, N, D = h.shape
+        O, C = q.shape
+        out = torch.empty(B, O, C, device=h.device, dtype=h.dtype)
+        _lib.call("scae_seed_attention_fwd_f32", _p(h), _p(q), _p(wk), _p(bk),
+                  _p(wv), _p(bv), _p(presence), _p(out), None, B, N, O, D, C,
+                  _stream(h))
+        ctx.save_for_backward(h, q, wk, bk, wv, bv,
+                              *([presence] if presence is not None else []))
+        ctx.has_presence = presence is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, q, wk, bk, wv, bv = ctx.saved_tensors[:6]
+        presence = ctx.saved_tensors[6] if ctx.has_presence else None
+        B, N, D = h.shape
+        O, C = q.shape
+        grid = _lib.load().scae_seed_attention_grid(B)
+        npar = O * C + 2 * C * D + 2 * C
+        partial = torch.empty(grid, npar, device=h.device, dtype=h.dtype)
+        gh = torch.empty_like(h)
+        _lib.call("scae_seed_attention_bwd_f32", _p(h), _p(q), _p(wk), _p(bk),
+                  _p(wv), _p(bv), _p(presence), _p(gout.contiguous()), _p(gh),
+                  _p(partial), B, N, O, D, C, _stream(h))
+        g = partial.sum(0)
+        o1, o2, o3, o4 = O * C, O * C + C * D, O * C + C * D + C, \
+            O * C + 2 * C * D + C
+        return (gh, g[:o1].view(O, C), g[o1:o2].view(C, D), g[o2:o3],
+                g[o3:o4].view(C, D), g[o4:], None)
+
+
+def seed_attention(h, q, wk, bk, wv, bv, presence=None):
+    """out (B,O,C) = softmax((q K'^T - (1-presence) 1e32)/sqrt(C)) V' with
+    K' = h wk^T + bk, V' = h wv^T + bv."""
+    if presence is not None and presence.requires_grad:
+        raise ScaeHipError("seed_attention treats presence as a constant")
+    return _SeedAttention.apply(h, q, wk, bk, wv, bv, presence)
 
 
 # ----------------------------------------------------------------------------

@@ -159,7 +159,7 @@ class SetTransformer(nn.Module):
             n_items, self.fc1.out_features, self.fc1.in_features,
             self.fc2.out_features, len(self.sabs), int(layer_norm)))
 
-    def _packed_trunk(self):
+    def _packed_trunk(self, with_fc2=True):
         """All trunk parameters as one flat buffer in the layout the fused
         kernel reads (include/scae_hip.h, K2b)."""
         parts = [self.fc1.weight, self.fc1.bias]
@@ -173,7 +173,8 @@ class SetTransformer(nn.Module):
             parts += [m.fc.weight, m.fc.bias]
             if m.layer_norm:
                 parts += [m.ln1.weight, m.ln1.bias]
-        parts += [self.fc2.weight, self.fc2.bias]
+        if with_fc2:
+            parts += [self.fc2.weight, self.fc2.bias]
         return torch.cat([p.reshape(-1) for p in parts])
 
     def encode_segments(self, segments, presence=None):
@@ -191,7 +192,35 @@ class SetTransformer(nn.Module):
             h = sab(h, presence)
         return self.fc2(h)
 
+    def _folded_attention_ok(self, n_items, presence):
+        mha = self.multi_head_attention
+        return (self._fusable(n_items, presence)
+                and ops.seed_attention_supported(
+                    n_items, self.seeds.shape[1], self.fc1.out_features,
+                    mha.o_projector.out_features)
+                and mha.q_projector.out_features == mha.o_projector.out_features)
+
     def forward_segments(self, segments, presence=None):
+        if segments[0].is_cuda and \
+                self._folded_attention_ok(segments[0].shape[1], presence):
+            # trunk without fc2, then the output attention with fc2 and the
+            # k / v / o projections folded into two (C x D) maps (kernel K2c);
+            # the folding products are tiny batch-invariant GEMMs
+            layer_norm = bool(self.sabs) and self.sabs[0].mab.layer_norm
+            h = ops.set_encoder(segments, presence,
+                                self._packed_trunk(with_fc2=False),
+                                self.fc1.out_features, 0, len(self.sabs),
+                                layer_norm)
+            mha, w2, b2 = self.multi_head_attention, self.fc2.weight, \
+                self.fc2.bias
+            q = mha.q_projector(self.seeds[0])                      # (O, C)
+            wk = mha.k_projector.weight @ w2                        # (C, D)
+            bk = mha.k_projector.weight @ b2 + mha.k_projector.bias
+            wv2 = mha.v_projector.weight @ w2
+            bv2 = mha.v_projector.weight @ b2 + mha.v_projector.bias
+            wv = mha.o_projector.weight @ wv2
+            bv = mha.o_projector.weight @ bv2 + mha.o_projector.bias
+            return ops.seed_attention(h, q, wk, bk, wv, bv, presence)
         z = self.encode_segments(segments, presence)
         seeds = self.seeds.expand(z.shape[0], -1, -1)
         return self.multi_head_attention(seeds, z, z, presence)
