@@ -32,6 +32,7 @@ using scae::sigmoidf_;
 using scae::softplusf_;
 
 constexpr int NT = 256;
+constexpr int SLICES = 8;  // row slices per texel in the backward gather
 
 struct Taps {
   int i00, i01, i10, i11;      // texel offsets inside one th*tw plane (clamped)
@@ -291,7 +292,9 @@ __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
 // ---------------------------------------------------------------------------
 // pixel-index footprint [lo, hi] (clipped to [0, n-1]) of  centre +- half
 __device__ __forceinline__ void clip_range(float centre, float half, int n, int &lo, int &hi) {
-  const float lo_f = centre - half - 1.5f, hi_f = centre + half + 1.5f;
+  // a pixel outside the exact footprint has weight <= 0; the slack only has to
+  // cover fp32 error of the inverse map (one more pixel is added by truncation)
+  const float lo_f = centre - half - 0.05f, hi_f = centre + half + 0.05f;
   if (!(lo_f == lo_f) || !(hi_f == hi_f)) {  // NaN: degenerate pose, take everything
     lo = 0;
     hi = n - 1;
@@ -323,8 +326,8 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
 
   float *s_tmpl = smem;                        // C*tsz
   float *s_alpha = s_tmpl + C * tsz;           // tsz
-  float *s_acc = s_alpha + tsz;                // 2 slices * (C+1) * tsz
-  float *s_red = s_acc + 2 * (C + 1) * tsz;    // 11 * (NT/64)
+  float *s_acc = s_alpha + tsz;                // SLICES * (C+1) * tsz
+  float *s_red = s_acc + SLICES * (C + 1) * tsz;  // 11 * (NT/64)
   float *s_g = s_red + 11 * (NT / 64);         // (C+1) * npc: per-pixel grads
 
   const bool is_bg = (k == M);
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
     for (int i = tid; i < C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
     for (int i = tid; i < tsz; i += NT)
       s_alpha[i] = alpha_mode ? d.templates_alpha[(size_t)k * tsz + i] : 0.f;
-    for (int i = tid; i < 2 * (C + 1) * tsz; i += NT) s_acc[i] = 0.f;
+    for (int i = tid; i < SLICES * (C + 1) * tsz; i += NT) s_acc[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) a[i] = d.pose[(size_t)(b * M + k) * 6 + i];
     lsp = d.presence ? log_safe(d.presence[b * M + k]) : 0.f;
@@ -352,7 +355,10 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
   const float det = ax * by - bx * ay;
   const float inv_det = 1.f / det;  // inf / NaN for degenerate poses -> full range
   const float inv_ax = 1.f / ax, inv_ay = 1.f / ay;
-  const int slices = (2 * tsz <= NT) ? 2 : 1;
+  // phase-2 work items are (texel, row slice): slice s takes footprint rows
+  // i_lo + s, i_lo + s + SLICES, ... so that magnified templates (few active
+  // texels with large footprints) still spread over all four waves
+  constexpr int slices = SLICES;
 
   // accumulators: 6 pose grads, d/d log_safe(presence), bg_value, bg_ml,
   // temperature, sigma
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
         float mlv = 0.f, sp = 0.f;
         if (alpha_mode) {
           mlv = (is_bg ? sc.bg_ml : av + lsp);
-          sp = expf(mlv - lse_prior[(size_t)b * HW + p]);
+          sp = __expf(mlv - lse_prior[(size_t)b * HW + p]);
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -395,12 +401,12 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
           const float gc = g_logprob[o];
           if (!alpha_mode) {
             mlv = tv[c] / sc.temperature + lsp;
-            sp = expf(mlv - lse_prior[o]);
+            sp = __expf(mlv - lse_prior[o]);
           }
           const float diff = x[o] - tv[c];
           const float lp =
               -(diff * diff) * (0.5f * sc.inv_var) - sc.log_sigma - scae::kHalfLog2Pi;
-          const float w = expf(lp + mlv - lse_post[o]);
+          const float w = __expf(lp + mlv - lse_post[o]);
           gtt[c] = gc * w * diff * sc.inv_var;
           const float gml = gc * (w - sp);
           acc[10] += gc * w * (diff * diff * sc.inv_var - 1.f) / sc.sigma;
@@ -460,9 +466,28 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
     __syncthreads();
 
     // ---- phase 2: texel-parallel gather ---------------------------------
-    for (int item = tid; item < slices * tsz; item += NT) {
-      const int slice = item / tsz, e = item - slice * tsz;
-      const int ty = e / tw, tx = e - ty * tw;
+    // only texels the chunk's pixels can reach get a lane: their range is the
+    // image of the chunk rectangle's corners under the affine map, +-1 texel
+    int tx0 = 0, tx1 = tw - 1, ty0 = 0, ty1 = th - 1;
+    {
+      const float jx = ax * (float)(W - 1), iy0 = (float)r0, iy1 = (float)(r1 - 1);
+      const float xa = bx * iy0 + cx, xb = bx * iy1 + cx;
+      const float xmin = fminf(xa, xb) + fminf(jx, 0.f), xmax = fmaxf(xa, xb) + fmaxf(jx, 0.f);
+      const float jy = ay * (float)(W - 1);
+      const float ya = by * iy0 + cy, yb = by * iy1 + cy;
+      const float ymin = fminf(ya, yb) + fminf(jy, 0.f), ymax = fmaxf(ya, yb) + fmaxf(jy, 0.f);
+      if (xmin == xmin && xmax == xmax && ymin == ymin && ymax == ymax) {  // no NaN
+        tx0 = (int)fminf(fmaxf(floorf(xmin - 0.01f), 0.f), (float)tw);
+        tx1 = (int)fmaxf(fminf(ceilf(xmax + 0.01f), (float)(tw - 1)), -1.f);
+        ty0 = (int)fminf(fmaxf(floorf(ymin - 0.01f), 0.f), (float)th);
+        ty1 = (int)fmaxf(fminf(ceilf(ymax + 0.01f), (float)(th - 1)), -1.f);
+      }
+    }
+    const int atw = max(tx1 - tx0 + 1, 0), ath = max(ty1 - ty0 + 1, 0), atsz = atw * ath;
+    for (int item = tid; item < slices * atsz; item += NT) {
+      const int slice = item / atsz, ea = item - slice * atsz;
+      const int ty = ty0 + ea / atw, tx = tx0 + (ea - (ea / atw) * atw);
+      const int e = ty * tw + tx;
       // pixels (j, i) whose sample position lies within +-1 texel of (tx, ty)
       const float u = (float)tx - cx, v = (float)ty - cy;
       int j_lo, j_hi, i_lo, i_hi;
@@ -483,15 +508,15 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
         float lo = (float)j_lo, hi = (float)j_hi;
         if (fabsf(ax) > 1e-12f) {
           const float c0 = (-1.f - rx) * inv_ax, c1 = (1.f - rx) * inv_ax;
-          lo = fmaxf(lo, fminf(c0, c1) - 1.f);
-          hi = fminf(hi, fmaxf(c0, c1) + 1.f);
+          lo = fmaxf(lo, fminf(c0, c1) - 0.05f);
+          hi = fminf(hi, fmaxf(c0, c1) + 0.05f);
         } else if (!(fabsf(rx) < 1.f)) {
           continue;
         }
         if (fabsf(ay) > 1e-12f) {
           const float c0 = (-1.f - ry) * inv_ay, c1 = (1.f - ry) * inv_ay;
-          lo = fmaxf(lo, fminf(c0, c1) - 1.f);
-          hi = fminf(hi, fmaxf(c0, c1) + 1.f);
+          lo = fmaxf(lo, fminf(c0, c1) - 0.05f);
+          hi = fminf(hi, fmaxf(c0, c1) + 0.05f);
         } else if (!(fabsf(ry) < 1.f)) {
           continue;
         }
@@ -520,12 +545,20 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
     float *o_t = g_templates + (size_t)(b * M + k) * C * tsz;
     for (int i = tid; i < C * tsz; i += NT) {
       const int c = i / tsz, e = i - c * tsz;
-      o_t[i] = s_acc[c * tsz + e] + s_acc[((C + 1) + c) * tsz + e];
+      float acc = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < SLICES; ++sl) acc += s_acc[(sl * (C + 1) + c) * tsz + e];
+      o_t[i] = acc;
     }
     if (alpha_mode) {
       float *o_a = g_alpha_partial + (size_t)(b * M + k) * tsz;
       for (int e = tid; e < tsz; e += NT)
-        o_a[e] = s_acc[C * tsz + e] + s_acc[((C + 1) + C) * tsz + e];
+      {
+        float acc = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < SLICES; ++sl) acc += s_acc[(sl * (C + 1) + C) * tsz + e];
+        o_a[e] = acc;
+      }
     }
   }
   if (tid == 0) {
@@ -791,7 +824,7 @@ int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post
   // per-pixel gradient planes of one chunk of output rows live in LDS
   int rows = (int)((40 * 1024 / sizeof(float)) / ((size_t)(d->C + 1) * d->W));
   rows = rows < 1 ? 1 : (rows > d->H ? d->H : rows);
-  const size_t lds = sizeof(float) * (3 * (size_t)(d->C + 1) * tsz + 11 * (NT / 64) +
+  const size_t lds = sizeof(float) * ((1 + SLICES) * (size_t)(d->C + 1) * tsz + 11 * (NT / 64) +
                                       (size_t)(d->C + 1) * rows * d->W);
   const dim3 grid(d->M + 1, d->B);
   const bool fused = (g_tt == nullptr && g_ml == nullptr);
