@@ -165,16 +165,26 @@ def roofline(cfg, device):
     B = cfg["batch"]
     name = max(dur, key=dur.get)                # the dominant K1 kernel
     achieved = alg[name] * B / dur[name] / 1e9
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes
+    # (profiles/r01/k1_pmc.json; counters cannot be read from inside this run)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "k1_pmc.json")
+    if os.path.exists(pmc) and cfg is CONFIGS["mnist_24_24_bs128"]:
+        k = json.load(open(pmc))["kernels"].get(name)
+        if k:
+            traffic = k["hbm_bytes_per_launch_raw"]
     return {
         "kernel": name, "bound": "hbm", "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "us_per_launch": round(dur[name] * 1e6, 2),
         "all_k1_kernels": {
             k: {"us": round(dur[k] * 1e6, 2),
                 "GBps": round(alg[k] * B / dur[k] / 1e9, 1),
                 "bytes_per_image": alg[k]} for k in dur},
-        "note": "traffic: see profiles/ (rocprofv3 --pmc pass)",
+        "algorithmic_bytes_per_launch": alg[name] * B,
+        "note": "traffic = FETCH_SIZE+WRITE_SIZE per launch from "
+                "profiles/r01/k1_pmc.json (separate rocprofv3 --pmc passes)",
     }
 
 
