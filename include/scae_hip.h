@@ -143,6 +143,22 @@ int scae_seed_attention_bwd_f32(const float *h, const float *q, const float *wk,
                                 void *stream);
 
 /* ------------------------------------------------------------------------
+ * K7  batched fp32 MFMA GEMM with fused epilogue -- the per-capsule MLPs of
+ *     CapsuleLayer (object_decoder.py:86-107, :137-158: a Python loop of 4*O
+ *     tiny GEMMs in the reference), forward and backward:
+ *       C[g][m][n] = epi( sum_k A[g](m,k) * B[g](n,k) ),   g < batch
+ *     A(m,k) = A[g*a_batch + (a_kcontig ? m*lda + k : k*lda + m)], B likewise;
+ *     C[g*c_batch + m*ldc + n].  epi: + bias[g*bias_batch + n*bias_ld]
+ *     (nullable), ReLU if relu, then zeroed where mask[g*mask_batch +
+ *     m*ldmask + n] <= 0 (nullable; the ReLU gate of the backward pass).
+ * ---------------------------------------------------------------------- */
+int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
+                  const float *mask, int batch, int M, int N, int K, int a_kcontig, int lda,
+                  int64_t a_batch, int b_kcontig, int ldb, int64_t b_batch, int ldc,
+                  int64_t c_batch, int bias_ld, int64_t bias_batch, int ldmask,
+                  int64_t mask_batch, int relu, void *stream);
+
+/* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225
  *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
  *   all_param (B,O,A), A = 6V+6+1+2V, the output of the per-capsule MLPs,

@@ -46,6 +46,9 @@ SIGNATURES = {
     "scae_seed_attention_supported": [c_int] * 4,
     "scae_seed_attention_fwd_f32": [P] * 9 + [c_int] * 5 + [P],
     "scae_seed_attention_bwd_f32": [P] * 10 + [c_int] * 5 + [P],
+    "scae_gemm_f32": [P] * 5 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
+                                              c_int, c_int64, c_int, c_int64,
+                                              c_int, c_int64, c_int, P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

@@ -85,6 +85,10 @@ class GroupedMLP(nn.Module):
                 for j in range(self.n_layers)]
 
     def forward(self, x):
+        if x.is_cuda:      # batched fp32-MFMA GEMMs with fused bias / ReLU (K7)
+            from . import ops
+            return ops.grouped_mlp(x, self.weights, self.biases,
+                                   ones_input=self.ones_input)
         h = x.transpose(0, 1)                                  # (G, B, in)
         for j, w in enumerate(self.weights):
             wt = w.transpose(1, 2)                             # (G, in, out)

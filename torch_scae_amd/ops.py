@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
-__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "seed_attention", "seed_attention_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
+__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
@@ -250,6 +250,114 @@ def seed_attention(h, q, wk, bk, wv, bv, presence=None):
     if presence is not None and presence.requires_grad:
         raise ScaeHipError("seed_attention treats presence as a constant")
     return _SeedAttention.apply(h, q, wk, bk, wv, bv, presence)
+
+
+# ----------------------------------------------------------------------------
+# K7 per-capsule MLPs on the batched MFMA GEMM (object_decoder.py:137-158)
+# ----------------------------------------------------------------------------
+def _gemm(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
+          bias=None, bias_ld=1, bias_b=0, mask=None, ldmask=0, mask_b=0,
+          relu=False, ref=None):
+    _lib.call("scae_gemm_f32", A, B, C, bias, mask, batch, M, N, K, int(a_k),
+              lda, a_b, int(b_k), ldb, b_b, ldc, c_b, bias_ld, bias_b, ldmask,
+              mask_b, int(relu), _stream(ref))
+
+
+def _off(t, nfloats=0):
+    return ctypes.c_void_p(t.data_ptr() + 4 * nfloats)
+
+
+class _GroupedMLP(torch.autograd.Function):
+    """relu(.. relu(x W0^T + b0) .. Wn^T + bn) for G independent groups.
+    x (B, G, Kin) with unit last stride; W_l (G, N_l, K_l [+1 if ones_input and
+    l == 0]); b_l (G, N_l) or None; returns (B, G, N_last) contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, ones_input, n_layers, *wb):
+        _need_hip(x, *wb)
+        if x.stride(2) != 1:
+            x = x.contiguous()
+        weights = [w.contiguous() for w in wb[:n_layers]]
+        biases = [None if b is None else b.contiguous() for b in wb[n_layers:]]
+        B, G, Kin = x.shape
+        if ones_input and biases[0] is not None:
+            raise ScaeHipError("ones_input with a bias is not built")
+        acts = []                      # post-ReLU outputs of every layer
+        cur, cur_ld, cur_b, K = x, x.stride(0), x.stride(1), Kin
+        for l, (w, b) in enumerate(zip(weights, biases)):
+            N, ldb = w.shape[1], w.shape[2]
+            last = l == n_layers - 1
+            if last:
+                out = torch.empty(B, G, N, device=x.device, dtype=x.dtype)
+                ldc, c_b = G * N, N
+            else:
+                out = torch.empty(G, B, N, device=x.device, dtype=x.dtype)
+                ldc, c_b = N, B * N
+            if l == 0 and ones_input:   # implicit trailing 1.0 input column
+                bias, bias_ld, bias_b = _off(w, Kin), ldb, N * ldb
+            elif b is not None:
+                bias, bias_ld, bias_b = _p(b), 1, N
+            else:
+                bias, bias_ld, bias_b = None, 1, 0
+            _gemm(_p(cur), _p(w), _p(out), G, B, N, K, True, cur_ld, cur_b, True,
+                  ldb, N * ldb, ldc, c_b, bias, bias_ld, bias_b, relu=True,
+                  ref=x)
+            acts.append(out)
+            cur, cur_ld, cur_b, K = out, N, B * N, N
+        ctx.save_for_backward(x, *weights, *acts)
+        ctx.meta = (bool(ones_input), n_layers,
+                    [b is not None for b in biases])
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        ones_input, L, has_bias = ctx.meta
+        x = ctx.saved_tensors[0]
+        weights = ctx.saved_tensors[1:1 + L]
+        acts = ctx.saved_tensors[1 + L:]
+        B, G, Kin = x.shape
+        dev, dt = x.device, x.dtype
+        # gradient w.r.t. the last pre-activation, layout (B, G, N)
+        gpre = torch.ops.aten.threshold_backward(gy.contiguous(), acts[-1], 0.0)
+        g_ld, g_b = G * gpre.shape[2], gpre.shape[2]
+        gws, gbs = [None] * L, [None] * L
+        gx = None
+        for l in range(L - 1, -1, -1):
+            w = weights[l]
+            N, ldb = w.shape[1], w.shape[2]
+            K = ldb - (1 if (l == 0 and ones_input) else 0)
+            if l == 0:
+                xin, x_ld, x_b = x, x.stride(0), x.stride(1)
+            else:
+                xin, x_ld, x_b = acts[l - 1], K, B * K
+            gw = torch.empty_like(w)
+            # gW[g] (N x K) = gpre^T x : both operands k(=batch)-strided
+            _gemm(_p(gpre), _p(xin), _p(gw), G, N, K, B, False, g_ld, g_b,
+                  False, x_ld, x_b, ldb, N * ldb, ref=x)
+            gsum = gpre.sum(0 if l == L - 1 else 1)          # (G, N)
+            if l == 0 and ones_input:
+                gw[:, :, K] = gsum
+            if has_bias[l]:
+                gbs[l] = gsum
+            gws[l] = gw
+            if l > 0:
+                # g wrt previous pre-activation = (gpre W) gated by its ReLU
+                gprev = torch.empty(G, B, K, device=dev, dtype=dt)
+                _gemm(_p(gpre), _p(w), _p(gprev), G, B, K, N, True, g_ld, g_b,
+                      False, ldb, N * ldb, K, B * K, mask=_p(acts[l - 1]),
+                      ldmask=K, mask_b=B * K, ref=x)
+                gpre, g_ld, g_b = gprev, K, B * K
+            elif ctx.needs_input_grad[0]:
+                gx = torch.empty(B, G, K, device=dev, dtype=dt)
+                _gemm(_p(gpre), _p(w), _p(gx), G, B, K, N, True, g_ld, g_b,
+                      False, ldb, N * ldb, G * K, K, ref=x)
+        return (gx, None, None, *gws, *gbs)
+
+
+def grouped_mlp(x, weights, biases, ones_input=False):
+    """ReLU MLPs of G independent groups; x (B, G, Kin) -> (B, G, N_last)."""
+    biases = list(biases) if biases is not None else [None] * len(weights)
+    return _GroupedMLP.apply(x, ones_input, len(weights), *weights, *biases)
 
 
 # ----------------------------------------------------------------------------
