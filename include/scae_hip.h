@@ -159,6 +159,40 @@ int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
                   int64_t mask_batch, int relu, void *stream);
 
 /* ------------------------------------------------------------------------
+ * K8  3x3 "valid" convolutions of the CNN encoder as implicit GEMMs on the
+ *     fp32 matrix cores      replaces part_encoder.py:26-44 / nn_ext.py:34-59
+ *     (Conv2d(k=3, stride, padding=0) + ReLU) and their autograd backward.
+ *   Activations NHWC: in (B,IH,IW,Cin) -> out (B,OH,OW,Cout), OH=(IH-3)/s+1.
+ *   relayout: w (Cout,Cin,3,3) -> wf (Cout,9,Cin), wd (Cin,9,Cout).
+ *   first_*: direct kernels for the image layer (NCHW image, small Cin; w in
+ *     the reference layout, Cout % 64 == 0); first_wgrad writes partial sums
+ *     (scae_conv3x3_first_wgrad_rows(B,Cout), Cout, Cin*9+1) (last column:
+ *     bias) for the caller to sum over the rows.
+ *   fwd:   out = relu(conv(in, wf) + bias)        Cin, Cout % 64 == 0, s <= 2
+ *   dgrad: din = conv^T(dpre, wd), zeroed where gate <= 0 (gate (B,IH,IW,Cin)
+ *          = the producing layer's ReLU output, nullable)
+ *   wgrad: dw (Cout,Cin,3,3) = sum_pixels dpre x in and (db nullable) db (Cout)
+ *          = sum_pixels dpre; partial is a workspace of
+ *          scae_conv3x3_wgrad_splits(B,OH,OW,Cin,Cout) * (9*Cout*Cin + Cout) floats.
+ * ---------------------------------------------------------------------- */
+int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout, int Cin,
+                              void *stream);
+int scae_conv3x3_first_fwd_f32(const float *img, const float *w, const float *bias,
+                               float *out, int B, int Cin, int IH, int IW, int Cout,
+                               int stride, void *stream);
+int scae_conv3x3_first_wgrad_rows(int B, int Cout);
+int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img, float *partial, int B,
+                                 int Cin, int IH, int IW, int Cout, int stride, void *stream);
+int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias, float *out,
+                         int B, int IH, int IW, int Cin, int Cout, int stride, void *stream);
+int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const float *gate, float *din,
+                           int B, int IH, int IW, int Cin, int Cout, int stride, void *stream);
+int scae_conv3x3_wgrad_splits(int B, int OH, int OW, int Cin, int Cout);
+int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float *partial, float *dw,
+                           float *db, int B, int IH, int IW, int Cin, int Cout, int stride,
+                           void *stream);
+
+/* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225
  *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
  *   all_param (B,O,A), A = 6V+6+1+2V, the output of the per-capsule MLPs,

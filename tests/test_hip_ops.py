@@ -617,3 +617,62 @@ def test_loss_tail_vs_oracle(prior, post, use_label, const):
         assert_close(a.grad, b.grad,
                      1e-4 * max(1.0, float(b.grad.abs().max())), 2e-4,
                      "grad " + nme)
+
+
+# --------------------------------------------------------------------------
+# K8 CNN encoder convolutions (part_encoder.py:26-44) vs torch's conv2d in fp64
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C0,HW,chans,strides", [
+    (5, 1, 40, [128, 128, 128, 128], [2, 2, 1, 1]),    # cfg-2 MNIST encoder
+    (3, 3, 32, [64, 128, 64], [1, 2, 1]),
+    (2, 3, 21, [64, 64], [2, 2]),                      # odd sizes, ragged tiles
+    (130, 1, 17, [64, 64, 64], [1, 1, 2]),
+    (64, 1, 40, [64, 64], [1, 1]),         # enough pixels for the 64x64 tiles
+    (48, 2, 40, [64, 64], [1, 2]),         # 64x64 tiles, strided data gradient
+    (3, 1, 12, [384, 384], [1, 1]),        # 64x64 weight-gradient tiles
+])
+def test_conv_stack_vs_conv2d(B, C0, HW, chans, strides):
+    import torch.nn.functional as F
+    from torch_scae_amd import ops
+    assert ops.conv_stack_supported(C0, chans, [3] * len(chans), strides)
+    g = torch.Generator().manual_seed(B * 100 + HW)
+    image = torch.rand(B, C0, HW, HW, generator=g)
+    ws, bs, cin = [], [], C0
+    for c in chans:
+        bound = 1.0 / (cin * 9) ** 0.5
+        ws.append((torch.rand(c, cin, 3, 3, generator=g) * 2 - 1) * bound)
+        bs.append((torch.rand(c, generator=g) * 2 - 1) * bound)
+        cin = c
+
+    def run(dev, dt):
+        w = [t.to(dev, dt).requires_grad_() for t in ws]
+        b = [t.to(dev, dt).requires_grad_() for t in bs]
+        x = image.to(dev, dt)
+        if dev == "cpu":
+            y = x
+            for wi, bi, s in zip(w, b, strides):
+                y = F.relu(F.conv2d(y, wi, bi, stride=s))
+        else:
+            y = ops.conv_stack(x, w, b, strides)
+        return y, w, b
+
+    y_ref, w_ref, b_ref = run("cpu", torch.float64)
+    y, w, b = run("cuda", torch.float32)
+    assert y.shape == y_ref.shape
+    assert_close(y, y_ref.float(), rtol=2e-4, atol=2e-5, what="conv out")
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy.double())
+    y.backward(gy.cuda())
+    for l in range(len(chans)):
+        scale = float(w_ref[l].grad.abs().max())
+        assert_close(w[l].grad, w_ref[l].grad.float(), rtol=1e-3,
+                     atol=2e-4 * scale, what=f"dW{l}")
+        assert_close(b[l].grad, b_ref[l].grad.float(), rtol=1e-3,
+                     atol=2e-4 * float(b_ref[l].grad.abs().max()),
+                     what=f"db{l}")
+
+
+def test_conv_stack_falls_back_for_small_channel_counts():
+    from torch_scae_amd import ops
+    assert not ops.conv_stack_supported(1, [8, 8], [3, 3], [2, 1])
+    assert not ops.conv_stack_supported(1, [64, 64], [3, 5], [2, 1])

@@ -49,6 +49,14 @@ SIGNATURES = {
     "scae_gemm_f32": [P] * 5 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
                                               c_int, c_int64, c_int, c_int64,
                                               c_int, c_int64, c_int, P],
+    "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
+    "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
+    "scae_conv3x3_first_wgrad_rows": [c_int] * 2,
+    "scae_conv3x3_first_wgrad_f32": [P] * 3 + [c_int] * 6 + [P],
+    "scae_conv3x3_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
+    "scae_conv3x3_dgrad_f32": [P] * 4 + [c_int] * 6 + [P],
+    "scae_conv3x3_wgrad_splits": [c_int] * 5,
+    "scae_conv3x3_wgrad_f32": [P] * 5 + [c_int] * 6 + [P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

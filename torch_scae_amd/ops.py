@@ -15,7 +15,8 @@ from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
-           "capsule_likelihood", "render_templates", "render_gmm_log_prob",
+           "capsule_likelihood", "conv_stack", "conv_stack_supported",
+           "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
 
@@ -250,6 +251,102 @@ def seed_attention(h, q, wk, bk, wv, bv, presence=None):
     if presence is not None and presence.requires_grad:
         raise ScaeHipError("seed_attention treats presence as a constant")
     return _SeedAttention.apply(h, q, wk, bk, wv, bv, presence)
+
+
+# ----------------------------------------------------------------------------
+# K8 CNN encoder: 3x3 valid conv + ReLU stack (part_encoder.py:26-44)
+# ----------------------------------------------------------------------------
+def conv_stack_supported(in_channels, out_channels, kernel_sizes, strides):
+    """Shapes the implicit-GEMM kernels are built for."""
+    chans = [in_channels] + list(out_channels)
+    return (len(out_channels) >= 1 and in_channels <= 4
+            and all(k == 3 for k in kernel_sizes)
+            and all(s in (1, 2) for s in strides)
+            and all(c % 64 == 0 for c in out_channels)
+            and all(c <= 1024 for c in chans))
+
+
+class _ConvStack(torch.autograd.Function):
+    """relu(conv3x3(.. relu(conv3x3(image)) ..)): image (B, C, H, W) NCHW ->
+    (B, C_last, OH, OW) as a channels-last view.  Intermediates are NHWC."""
+
+    @staticmethod
+    def forward(ctx, image, strides, *wb):
+        _need_hip(image, *wb)
+        L = len(strides)
+        image = image.contiguous()
+        weights = [w.contiguous() for w in wb[:L]]
+        biases = [b.contiguous() for b in wb[L:]]
+        B, C0, H, W = image.shape
+        dev, st = image.device, _stream(image)
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=image.dtype)
+        c1, s = weights[0].shape[0], strides[0]
+        oh, ow = (H - 3) // s + 1, (W - 3) // s + 1
+        act = new(B, oh, ow, c1)
+        _lib.call("scae_conv3x3_first_fwd_f32", _p(image), _p(weights[0]),
+                  _p(biases[0]), _p(act), B, C0, H, W, c1, s, st)
+        acts, wds = [act], []
+        for l in range(1, L):
+            w, s = weights[l], strides[l]
+            co, ci = w.shape[0], w.shape[1]
+            ih, iw = act.shape[1], act.shape[2]
+            wf, wd = new(co, 9, ci), new(ci, 9, co)
+            _lib.call("scae_conv3x3_relayout_f32", _p(w), _p(wf), _p(wd), co,
+                      ci, st)
+            out = new(B, (ih - 3) // s + 1, (iw - 3) // s + 1, co)
+            _lib.call("scae_conv3x3_fwd_f32", _p(act), _p(wf), _p(biases[l]),
+                      _p(out), B, ih, iw, ci, co, s, st)
+            acts.append(out)
+            wds.append(wd)
+            act = out
+        ctx.save_for_backward(image, *acts, *wds)
+        ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights])
+        return act.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        strides, wshapes = ctx.meta
+        L = len(strides)
+        image = ctx.saved_tensors[0]
+        acts = ctx.saved_tensors[1:1 + L]
+        wds = ctx.saved_tensors[1 + L:]
+        B, C0, H, W = image.shape
+        dev, dt, st = image.device, image.dtype, _stream(image)
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
+        dpre = torch.ops.aten.threshold_backward(
+            gy.permute(0, 2, 3, 1).contiguous(), acts[-1], 0.0)
+        gws, gbs = [None] * L, [None] * L
+        for l in range(L - 1, 0, -1):
+            co, ci = wshapes[l][0], wshapes[l][1]
+            xin, s = acts[l - 1], strides[l]
+            ih, iw, oh, ow = xin.shape[1], xin.shape[2], dpre.shape[1], dpre.shape[2]
+            splits = _lib.load().scae_conv3x3_wgrad_splits(B, oh, ow, ci, co)
+            partial = new(splits * (9 * co * ci + co))
+            gw, gb = new(co, ci, 3, 3), new(co)
+            _lib.call("scae_conv3x3_wgrad_f32", _p(dpre), _p(xin), _p(partial),
+                      _p(gw), _p(gb), B, ih, iw, ci, co, s, st)
+            gbs[l] = gb
+            gws[l] = gw
+            din = new(B, ih, iw, ci)
+            _lib.call("scae_conv3x3_dgrad_f32", _p(dpre), _p(wds[l - 1]),
+                      _p(xin), _p(din), B, ih, iw, ci, co, s, st)
+            dpre = din
+        c1 = wshapes[0][0]
+        k1 = C0 * 9 + 1
+        partial = new(_lib.load().scae_conv3x3_first_wgrad_rows(B, c1), c1, k1)
+        _lib.call("scae_conv3x3_first_wgrad_f32", _p(dpre), _p(image),
+                  _p(partial), B, C0, H, W, c1, strides[0], st)
+        g1 = partial.sum(0)
+        gws[0] = g1[:, :k1 - 1].reshape(c1, C0, 3, 3)
+        gbs[0] = g1[:, k1 - 1]
+        return (None, None, *gws, *gbs)
+
+
+def conv_stack(image, weights, biases, strides):
+    """ReLU(conv3x3) stack of the part-capsule encoder on the HIP kernels.
+    The image receives no gradient (it is the data)."""
+    return _ConvStack.apply(image, tuple(int(s) for s in strides), *weights,
+                            *biases)
 
 
 # ----------------------------------------------------------------------------

@@ -1,13 +1,14 @@
 """Part-capsule image encoder (reference: torch_scae/part_encoder.py).
 
-The convolutions stay on MIOpen (they are library GEMM/conv work, not part of
-the hand-written hot path); the pose non-linearity runs on HIP kernel K5."""
+The 3x3 conv + ReLU stack runs on the implicit-GEMM MFMA kernels (K8) for the
+reference's channel counts, the 1x1 attention conv on the library, the pose
+non-linearity on HIP kernel K5."""
 from typing import Tuple
 
 import torch
 import torch.nn as nn
 
-from . import cv_ops
+from . import cv_ops, ops
 from .general_utils import AttrDict
 from .nn_ext import Conv2dStack, multiple_attention_pooling_2d
 from .nn_utils import measure_shape, rand_like
@@ -24,8 +25,19 @@ class CNNEncoder(nn.Module):
                                    activate_final=activate_final)
         self.output_shape = measure_shape(self.network,
                                           input_shape=input_shape)
+        self.strides = [int(s) for s in strides]
+        # the 3x3 / ReLU / 64-multiple-channel stacks of the reference configs
+        # run on the implicit-GEMM HIP kernels; other shapes stay on MIOpen
+        self._hip_stack = (activation is nn.ReLU and activate_final
+                           and ops.conv_stack_supported(
+                               input_shape[0], out_channels, kernel_sizes,
+                               strides))
 
     def forward(self, image):
+        if self._hip_stack and image.is_cuda and image.dtype == torch.float32:
+            convs = [m for m in self.network if isinstance(m, nn.Conv2d)]
+            return ops.conv_stack(image, [c.weight for c in convs],
+                                  [c.bias for c in convs], self.strides)
         return self.network(image)
 
 
