@@ -143,6 +143,36 @@ int scae_seed_attention_bwd_f32(const float *h, const float *q, const float *wk,
                                 void *stream);
 
 /* ------------------------------------------------------------------------
+ * K2d  batch-invariant weight folding feeding K2c
+ *      replaces the per-element fc2 / q,k,v,o projector Linear layers of
+ *      set_transformer.py:218-223, :36-75 by parameter-only products:
+ *        q   = seeds Wq^T + bq                   (O,C)
+ *        wkf = Wk W2,       bkf = Wk b2 + bk     (C,D), (C)
+ *        wvf = Wo Wv W2,    bvf = Wo (Wv b2 + bv) + bo
+ *      wv2e (C,D+1) = [Wv W2 | Wv b2 + bv] is kept for the backward pass.
+ *      backward: gradients of (q, wkf, bkf, wvf, bvf) -> gradients of all
+ *      eleven parameters; gv2e, t1: (C,D+1) workspaces.
+ *      Limits: C % 64 == 0, C <= 512 (scae_seed_fold_supported).
+ * ---------------------------------------------------------------------- */
+typedef struct scae_seed_fold_desc {
+  const float *seeds;                   /* (O,C) */
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo; /* (C,C) / (C) */
+  const float *w2, *b2;                 /* fc2: (C,D), (C) */
+  float *q, *wkf, *bkf, *wvf, *bvf;     /* outputs */
+  float *wv2e;                          /* (C,D+1) output kept for backward */
+  int O, C, D;
+} scae_seed_fold_desc;
+typedef struct scae_seed_fold_grads {
+  const float *g_q, *g_wkf, *g_bkf, *g_wvf, *g_bvf; /* incoming gradients */
+  float *d_seeds, *d_wq, *d_bq, *d_wk, *d_bk, *d_wv, *d_bv, *d_wo, *d_bo, *d_w2, *d_b2;
+  float *gv2e, *t1;                     /* (C,D+1) workspaces */
+} scae_seed_fold_grads;
+int scae_seed_fold_supported(int O, int C, int D);
+int scae_seed_fold_fwd_f32(const scae_seed_fold_desc *desc, void *stream);
+int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc, const scae_seed_fold_grads *grads,
+                           void *stream);
+
+/* ------------------------------------------------------------------------
  * K7  batched fp32 MFMA GEMM with fused epilogue -- the per-capsule MLPs of
  *     CapsuleLayer (object_decoder.py:86-107, :137-158: a Python loop of 4*O
  *     tiny GEMMs in the reference), forward and backward:

@@ -676,3 +676,44 @@ def test_conv_stack_falls_back_for_small_channel_counts():
     from torch_scae_amd import ops
     assert not ops.conv_stack_supported(1, [8, 8], [3, 3], [2, 1])
     assert not ops.conv_stack_supported(1, [64, 64], [3, 5], [2, 1])
+
+
+# --------------------------------------------------------------------------
+# K2d weight folding (set_transformer.py:218-223 projections) vs fp64 algebra
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("O,C,D", [(24, 256, 16), (5, 64, 8), (32, 512, 32),
+                                   (3, 128, 7)])
+def test_seed_fold_vs_fp64(O, C, D):
+    from torch_scae_amd import ops
+    assert ops.seed_fold_supported(O, C, D)
+    g = torch.Generator().manual_seed(O * C + D)
+    shapes = [(O, C), (C, C), (C,), (C, C), (C,), (C, C), (C,), (C, C), (C,),
+              (C, D), (C,)]
+    vals = [torch.randn(*s, generator=g) / (s[-1] ** 0.5) for s in shapes]
+
+    def fold(seeds, wq, bq, wk, bk, wv, bv, wo, bo, w2, b2):
+        q = seeds @ wq.T + bq
+        wv2, bv2 = wv @ w2, wv @ b2 + bv
+        return q, wk @ w2, wk @ b2 + bk, wo @ wv2, wo @ bv2 + bo
+
+    ref_in = [v.double().requires_grad_() for v in vals]
+    ref_out = fold(*ref_in)
+    hip_in = [v.cuda().requires_grad_() for v in vals]
+    hip_out = ops.seed_fold(*hip_in)
+    names = ["q", "wkf", "bkf", "wvf", "bvf"]
+    for n, a, b in zip(names, hip_out, ref_out):
+        assert_close(a, b.float(), rtol=1e-4, atol=1e-5, what=n)
+    gouts = [torch.randn(o.shape, generator=g) for o in ref_out]
+    torch.autograd.backward(ref_out, [t.double() for t in gouts])
+    torch.autograd.backward(hip_out, [t.cuda() for t in gouts])
+    pn = ["seeds", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "w2", "b2"]
+    for n, a, b in zip(pn, hip_in, ref_in):
+        scale = float(b.grad.abs().max())
+        assert_close(a.grad, b.grad.float(), rtol=1e-4, atol=1e-5 * scale,
+                     what="d_" + n)
+    # partially-used outputs: missing gradients count as zeros
+    hip_in2 = [v.cuda().requires_grad_() for v in vals]
+    out2 = ops.seed_fold(*hip_in2)
+    out2[0].sum().backward()
+    assert float(hip_in2[3].grad.abs().max()) == 0.0
+    assert_close(hip_in2[2].grad, torch.full((C,), float(O)), what="d_bq")

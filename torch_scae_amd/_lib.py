@@ -25,6 +25,22 @@ class DecoderDesc(Structure):
                 ("tw", c_int), ("H", c_int), ("W", c_int)]
 
 
+class SeedFoldDesc(Structure):
+    """struct scae_seed_fold_desc"""
+    _fields_ = [(n, P) for n in (
+        "seeds", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "w2", "b2",
+        "q", "wkf", "bkf", "wvf", "bvf", "wv2e")] + \
+        [("O", c_int), ("C", c_int), ("D", c_int)]
+
+
+class SeedFoldGrads(Structure):
+    """struct scae_seed_fold_grads"""
+    _fields_ = [(n, P) for n in (
+        "g_q", "g_wkf", "g_bkf", "g_wvf", "g_bvf", "d_seeds", "d_wq", "d_bq",
+        "d_wk", "d_bk", "d_wv", "d_bv", "d_wo", "d_bo", "d_w2", "d_b2",
+        "gv2e", "t1")]
+
+
 # name -> argtypes; mirrors include/scae_hip.h one to one
 SIGNATURES = {
     "scae_abi_version": [],
@@ -46,6 +62,9 @@ SIGNATURES = {
     "scae_seed_attention_supported": [c_int] * 4,
     "scae_seed_attention_fwd_f32": [P] * 9 + [c_int] * 5 + [P],
     "scae_seed_attention_bwd_f32": [P] * 10 + [c_int] * 5 + [P],
+    "scae_seed_fold_supported": [c_int] * 3,
+    "scae_seed_fold_fwd_f32": [POINTER(SeedFoldDesc), P],
+    "scae_seed_fold_bwd_f32": [POINTER(SeedFoldDesc), POINTER(SeedFoldGrads), P],
     "scae_gemm_f32": [P] * 5 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
                                               c_int, c_int64, c_int, c_int64,
                                               c_int, c_int64, c_int, P],

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
-__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
+__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "conv_stack", "conv_stack_supported",
            "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
@@ -251,6 +251,78 @@ def seed_attention(h, q, wk, bk, wv, bv, presence=None):
     if presence is not None and presence.requires_grad:
         raise ScaeHipError("seed_attention treats presence as a constant")
     return _SeedAttention.apply(h, q, wk, bk, wv, bv, presence)
+
+
+# ----------------------------------------------------------------------------
+# K2d weight folding for the output attention (set_transformer.py:218-223)
+# ----------------------------------------------------------------------------
+def seed_fold_supported(O, C, D):
+    return bool(_lib.load().scae_seed_fold_supported(O, C, D))
+
+
+_FOLD_INPUTS = ("seeds", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "w2",
+                "b2")
+
+
+def _fold_desc(inputs, outputs, O, C, D):
+    d = _lib.SeedFoldDesc()
+    for name, t in zip(_FOLD_INPUTS, inputs):
+        setattr(d, name, t.data_ptr())
+    for name, t in zip(("q", "wkf", "bkf", "wvf", "bvf", "wv2e"), outputs):
+        setattr(d, name, t.data_ptr())
+    d.O, d.C, d.D = O, C, D
+    return d
+
+
+class _SeedFold(torch.autograd.Function):
+    """(seeds, Wq, bq, Wk, bk, Wv, bv, Wo, bo, W2, b2) -> (q, wkf, bkf, wvf,
+    bvf) consumed by seed_attention."""
+
+    @staticmethod
+    def forward(ctx, *inputs):
+        _need_hip(*inputs)
+        inputs = tuple(t.contiguous() for t in inputs)
+        seeds, w2 = inputs[0], inputs[9]
+        O, C = seeds.shape
+        D = w2.shape[1]
+        new = lambda *shape: torch.empty(*shape, device=seeds.device,
+                                         dtype=seeds.dtype)
+        outs = (new(O, C), new(C, D), new(C), new(C, D), new(C), new(C, D + 1))
+        desc = _fold_desc(inputs, outs, O, C, D)
+        _lib.call("scae_seed_fold_fwd_f32", ctypes.byref(desc), _stream(seeds))
+        ctx.save_for_backward(*inputs, *outs)
+        return outs[:5]
+
+    @staticmethod
+    def backward(ctx, g_q, g_wkf, g_bkf, g_wvf, g_bvf):
+        inputs, outs = ctx.saved_tensors[:11], ctx.saved_tensors[11:]
+        seeds, w2 = inputs[0], inputs[9]
+        O, C = seeds.shape
+        D = w2.shape[1]
+        zeros = lambda ref: torch.zeros_like(ref)
+        incoming = [g if g is not None else zeros(o) for g, o in
+                    zip((g_q, g_wkf, g_bkf, g_wvf, g_bvf), outs)]
+        incoming = [g.contiguous() for g in incoming]
+        grads = [torch.empty_like(t) for t in inputs]
+        work = torch.empty(2, C, D + 1, device=seeds.device, dtype=seeds.dtype)
+        desc = _fold_desc(inputs, outs, O, C, D)
+        g = _lib.SeedFoldGrads()
+        for name, t in zip(("g_q", "g_wkf", "g_bkf", "g_wvf", "g_bvf"),
+                           incoming):
+            setattr(g, name, t.data_ptr())
+        for name, t in zip(_FOLD_INPUTS, grads):
+            setattr(g, "d_" + name, t.data_ptr())
+        g.gv2e, g.t1 = work[0].data_ptr(), work[1].data_ptr()
+        _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(desc), ctypes.byref(g),
+                  _stream(seeds))
+        return tuple(grads)
+
+
+def seed_fold(seeds, wq, bq, wk, bk, wv, bv, wo, bo, w2, b2):
+    """Parameter-only products feeding seed_attention:
+    q = seeds wq^T + bq, wkf = wk w2, bkf = wk b2 + bk, wvf = wo wv w2,
+    bvf = wo (wv b2 + bv) + bo."""
+    return _SeedFold.apply(seeds, wq, bq, wk, bk, wv, bv, wo, bo, w2, b2)
 
 
 # ----------------------------------------------------------------------------

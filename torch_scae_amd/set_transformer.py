@@ -213,6 +213,15 @@ class SetTransformer(nn.Module):
                                 layer_norm)
             mha, w2, b2 = self.multi_head_attention, self.fc2.weight, \
                 self.fc2.bias
+            C, D = w2.shape
+            if ops.seed_fold_supported(self.seeds.shape[1], C, D):
+                q, wk, bk, wv, bv = ops.seed_fold(
+                    self.seeds[0], mha.q_projector.weight,
+                    mha.q_projector.bias, mha.k_projector.weight,
+                    mha.k_projector.bias, mha.v_projector.weight,
+                    mha.v_projector.bias, mha.o_projector.weight,
+                    mha.o_projector.bias, w2, b2)
+                return ops.seed_attention(h, q, wk, bk, wv, bv, presence)
             q = mha.q_projector(self.seeds[0])                      # (O, C)
             wk = mha.k_projector.weight @ w2                        # (C, D)
             bk = mha.k_projector.weight @ b2 + mha.k_projector.bias
