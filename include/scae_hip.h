@@ -181,12 +181,15 @@ int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc, const scae_seed_fold
  *     C[g*c_batch + m*ldc + n].  epi: + bias[g*bias_batch + n*bias_ld]
  *     (nullable), ReLU if relu, then zeroed where mask[g*mask_batch +
  *     m*ldmask + n] <= 0 (nullable; the ReLU gate of the backward pass).
+ *     asum (nullable, needs a_kcontig == 0): asum[g*asum_batch + m] =
+ *     sum_k A[g](m,k), the bias gradient that goes with a weight-gradient GEMM.
+ *     Also serves the 1x1 attention convolution of part_encoder.py:71-73.
  * ---------------------------------------------------------------------- */
 int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
-                  const float *mask, int batch, int M, int N, int K, int a_kcontig, int lda,
-                  int64_t a_batch, int b_kcontig, int ldb, int64_t b_batch, int ldc,
-                  int64_t c_batch, int bias_ld, int64_t bias_batch, int ldmask,
-                  int64_t mask_batch, int relu, void *stream);
+                  const float *mask, float *asum, int batch, int M, int N, int K,
+                  int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
+                  int64_t b_batch, int ldc, int64_t c_batch, int bias_ld, int64_t bias_batch,
+                  int ldmask, int64_t mask_batch, int64_t asum_batch, int relu, void *stream);
 
 /* ------------------------------------------------------------------------
  * K8  3x3 "valid" convolutions of the CNN encoder as implicit GEMMs on the

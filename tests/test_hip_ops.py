@@ -717,3 +717,45 @@ def test_seed_fold_vs_fp64(O, C, D):
     out2[0].sum().backward()
     assert float(hip_in2[3].grad.abs().max()) == 0.0
     assert_close(hip_in2[2].grad, torch.full((C,), float(O)), what="d_bq")
+
+
+# --------------------------------------------------------------------------
+# K7 batched MFMA GEMM: all operand layouts, ragged shapes, epilogues
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("G,M,N,K,ak,bk", [
+    (3, 70, 45, 37, True, True),       # ragged, scalar loads / stores
+    (2, 64, 128, 96, True, False),
+    (5, 33, 17, 130, False, True),
+    (4, 128, 64, 200, False, False),
+    (1, 3200, 576, 128, True, True),   # the 1x1 attention conv (64x64 tiles)
+    (40, 256, 128, 64, False, False),  # enough tiles for the 64x64 shape
+])
+def test_gemm_layouts_and_epilogues(G, M, N, K, ak, bk):
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(G * M + N * K)
+    A = torch.randn(G, M, K, generator=g)
+    Bm = torch.randn(G, N, K, generator=g)
+    bias = torch.randn(G, N, generator=g)
+    mask = torch.randn(G, M, N, generator=g)
+    ref = torch.einsum("gmk,gnk->gmn", A.double(), Bm.double())
+    a_dev = (A if ak else A.transpose(1, 2).contiguous()).cuda()
+    b_dev = (Bm if bk else Bm.transpose(1, 2).contiguous()).cuda()
+    lda, ldb = (K if ak else M), (K if bk else N)
+    tol = dict(rtol=2e-4, atol=2e-4 * K ** 0.5)
+
+    def run(**kw):
+        out = torch.full((G, M, N), float("nan"), device="cuda")
+        ops._gemm(ops._p(a_dev), ops._p(b_dev), ops._p(out), G, M, N, K, ak,
+                  lda, M * K, bk, ldb, N * K, N, M * N, ref=out, **kw)
+        return out
+
+    assert_close(run(), ref.float(), what="plain", **tol)
+    bias_d, mask_d = bias.cuda(), mask.cuda()
+    want = torch.relu(ref + bias.double()[:, None, :]) * (mask > 0)
+    got = run(bias=ops._p(bias_d), bias_ld=1, bias_b=N, relu=True,
+              mask=ops._p(mask_d), ldmask=N, mask_b=M * N)
+    assert_close(got, want.float(), what="bias+relu+gate", **tol)
+    if not ak:
+        asum = torch.full((G, M), float("nan"), device="cuda")
+        run(asum=ops._p(asum), asum_b=M)
+        assert_close(asum, A.double().sum(2).float(), what="asum", **tol)

@@ -65,9 +65,9 @@ SIGNATURES = {
     "scae_seed_fold_supported": [c_int] * 3,
     "scae_seed_fold_fwd_f32": [POINTER(SeedFoldDesc), P],
     "scae_seed_fold_bwd_f32": [POINTER(SeedFoldDesc), POINTER(SeedFoldGrads), P],
-    "scae_gemm_f32": [P] * 5 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
+    "scae_gemm_f32": [P] * 6 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
                                               c_int, c_int64, c_int, c_int64,
-                                              c_int, c_int64, c_int, P],
+                                              c_int, c_int64, c_int64, c_int, P],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_first_wgrad_rows": [c_int] * 2,

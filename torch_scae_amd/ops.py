@@ -426,10 +426,10 @@ def conv_stack(image, weights, biases, strides):
 # ----------------------------------------------------------------------------
 def _gemm(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
           bias=None, bias_ld=1, bias_b=0, mask=None, ldmask=0, mask_b=0,
-          relu=False, ref=None):
-    _lib.call("scae_gemm_f32", A, B, C, bias, mask, batch, M, N, K, int(a_k),
-              lda, a_b, int(b_k), ldb, b_b, ldc, c_b, bias_ld, bias_b, ldmask,
-              mask_b, int(relu), _stream(ref))
+          relu=False, asum=None, asum_b=0, ref=None):
+    _lib.call("scae_gemm_f32", A, B, C, bias, mask, asum, batch, M, N, K,
+              int(a_k), lda, a_b, int(b_k), ldb, b_b, ldc, c_b, bias_ld, bias_b,
+              ldmask, mask_b, asum_b, int(relu), _stream(ref))
 
 
 def _off(t, nfloats=0):
@@ -500,10 +500,16 @@ class _GroupedMLP(torch.autograd.Function):
             else:
                 xin, x_ld, x_b = acts[l - 1], K, B * K
             gw = torch.empty_like(w)
-            # gW[g] (N x K) = gpre^T x : both operands k(=batch)-strided
+            # gW[g] (N x K) = gpre^T x : both operands k(=batch)-strided; the
+            # bias gradient sum_b gpre is emitted by the same launch
+            if has_bias[l] or (l == 0 and ones_input):
+                gsum = torch.empty(G, N, device=dev, dtype=dt)
+                asum, asum_b = _p(gsum), N
+            else:
+                gsum, asum, asum_b = None, None, 0
             _gemm(_p(gpre), _p(xin), _p(gw), G, N, K, B, False, g_ld, g_b,
-                  False, x_ld, x_b, ldb, N * ldb, ref=x)
-            gsum = gpre.sum(0 if l == L - 1 else 1)          # (G, N)
+                  False, x_ld, x_b, ldb, N * ldb, asum=asum, asum_b=asum_b,
+                  ref=x)
             if l == 0 and ones_input:
                 gw[:, :, K] = gsum
             if has_bias[l]:
