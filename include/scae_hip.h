@@ -226,6 +226,21 @@ int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float *partial, f
                            void *stream);
 
 /* ------------------------------------------------------------------------
+ * K9  attention pooling of the part-capsule head
+ *     replaces nn_ext.py:76-101 (multiple_soft_attention +
+ *     multiple_attention_pooling_2d) as used by part_encoder.py:74.
+ *   y (B,HW,A*P): NHWC output of the 1x1 attention conv (K7 GEMM); per capsule
+ *   a the channels a*P .. a*P+P-2 are features, a*P+P-1 the attention logit.
+ *   out (B,A,P-1) = sum_pix y[pix][a*P+p] * softmax_pix(logit)[pix]
+ *   backward: g (B,A,P-1) -> dy (B,HW,A*P).
+ * ---------------------------------------------------------------------- */
+int scae_attention_pool_supported(int HW, int A, int P);
+int scae_attention_pool_fwd_f32(const float *y, float *out, int B, int HW, int A, int P,
+                                void *stream);
+int scae_attention_pool_bwd_f32(const float *y, const float *g, float *dy, int B, int HW,
+                                int A, int P, void *stream);
+
+/* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225
  *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
  *   all_param (B,O,A), A = 6V+6+1+2V, the output of the per-capsule MLPs,

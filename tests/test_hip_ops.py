@@ -759,3 +759,40 @@ def test_gemm_layouts_and_epilogues(G, M, N, K, ak, bk):
         asum = torch.full((G, M), float("nan"), device="cuda")
         run(asum=ops._p(asum), asum_b=M)
         assert_close(asum, A.double().sum(2).float(), what="asum", **tol)
+
+
+# --------------------------------------------------------------------------
+# K9 1x1 attention conv + attention pooling (part_encoder.py:71-74,
+# nn_ext.py:76-101) vs the composed torch ops in fp64
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,H,W,A,P", [(128, 128, 5, 5, 24, 24),
+                                         (6, 8, 3, 4, 5, 9),
+                                         (7, 64, 6, 6, 32, 24),
+                                         (3, 20, 1, 1, 4, 2)])
+def test_attention_conv_pool_vs_torch(B, C, H, W, A, P):
+    import torch.nn.functional as F
+    from torch_scae_amd import ops
+    from torch_scae_amd.nn_ext import multiple_attention_pooling_2d
+    assert ops.attention_pool_supported(H * W, A, P)
+    g = torch.Generator().manual_seed(B + C + A)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(A * P, C, generator=g) / C ** 0.5
+    b = torch.randn(A * P, generator=g)
+    gout = torch.randn(B, A, P - 1, generator=g)
+
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    ref = multiple_attention_pooling_2d(
+        F.conv2d(xr, wr.view(A * P, C, 1, 1), br), A).view(B, A, P - 1)
+    ref.backward(gout.double())
+
+    xh = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous().cuda() \
+        .requires_grad_()
+    wh, bh = w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    out = ops.attention_conv_pool(xh, wh, bh, A)
+    out.backward(gout.cuda())
+    assert_close(out, ref.float(), rtol=1e-4, atol=1e-5, what="pooled")
+    for name, a, r in (("dx", xh.grad, xr.grad.permute(0, 2, 3, 1)
+                        .reshape(B, H * W, C)), ("dw", wh.grad, wr.grad),
+                       ("db", bh.grad, br.grad)):
+        assert_close(a, r.float(), rtol=2e-4,
+                     atol=2e-5 * max(1.0, float(r.abs().max())), what=name)

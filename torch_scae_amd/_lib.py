@@ -76,6 +76,9 @@ SIGNATURES = {
     "scae_conv3x3_dgrad_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_wgrad_splits": [c_int] * 5,
     "scae_conv3x3_wgrad_f32": [P] * 5 + [c_int] * 6 + [P],
+    "scae_attention_pool_supported": [c_int] * 3,
+    "scae_attention_pool_fwd_f32": [P, P] + [c_int] * 4 + [P],
+    "scae_attention_pool_bwd_f32": [P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

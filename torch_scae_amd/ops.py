@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
-           "capsule_likelihood", "conv_stack", "conv_stack_supported",
+           "capsule_likelihood", "attention_conv_pool", "attention_pool_supported", "conv_stack", "conv_stack_supported",
            "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
@@ -419,6 +419,66 @@ def conv_stack(image, weights, biases, strides):
     The image receives no gradient (it is the data)."""
     return _ConvStack.apply(image, tuple(int(s) for s in strides), *weights,
                             *biases)
+
+
+# ----------------------------------------------------------------------------
+# K9 part-capsule head: 1x1 attention conv + attention pooling
+# (part_encoder.py:71-74, nn_ext.py:76-101)
+# ----------------------------------------------------------------------------
+def attention_pool_supported(HW, A, P):
+    return bool(_lib.load().scae_attention_pool_supported(HW, A, P))
+
+
+class _AttentionConvPool(torch.autograd.Function):
+    """x (B, HW, C) NHWC features, weight (A*P, C), bias (A*P) -> (B, A, P-1):
+    y = x weight^T + bias, then per capsule the softmax-over-pixels of its
+    last channel pools its other P-1 channels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, n_caps):
+        _need_hip(x, weight, bias)
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        B, HW, C = x.shape
+        AP = weight.shape[0]
+        P = AP // n_caps
+        y = torch.empty(B, HW, AP, device=x.device, dtype=x.dtype)
+        _gemm(_p(x), _p(weight), _p(y), 1, B * HW, AP, C, True, C, 0, True, C,
+              0, AP, 0, bias=_p(bias), bias_ld=1, ref=x)
+        out = torch.empty(B, n_caps, P - 1, device=x.device, dtype=x.dtype)
+        _lib.call("scae_attention_pool_fwd_f32", _p(y), _p(out), B, HW, n_caps,
+                  P, _stream(x))
+        ctx.save_for_backward(x, weight, y)
+        ctx.n_caps = n_caps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        B, HW, C = x.shape
+        AP, A = weight.shape[0], ctx.n_caps
+        P = AP // A
+        dy = torch.empty_like(y)
+        _lib.call("scae_attention_pool_bwd_f32", _p(y), _p(g.contiguous()),
+                  _p(dy), B, HW, A, P, _stream(x))
+        # weight / bias gradient: dy^T x split over groups of images (the
+        # launch also emits the column sums of dy), summed afterwards
+        gsz = max(d for d in range(1, B + 1)
+                  if B % d == 0 and (d == 1 or HW * d <= 256))
+        S, kper, slab = B // gsz, HW * gsz, AP * C + AP
+        part = torch.empty(S, slab, device=x.device, dtype=x.dtype)
+        _gemm(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP, kper * AP,
+              False, C, kper * C, C, slab, asum=_off(part, AP * C), asum_b=slab,
+              ref=x)
+        gsum = part.sum(0)
+        dx = torch.empty_like(x)
+        _gemm(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP, 0, False,
+              C, 0, C, 0, ref=x)
+        return dx, gsum[:AP * C].view(AP, C), gsum[AP * C:], None
+
+
+def attention_conv_pool(x, weight, bias, n_caps):
+    """1x1 conv (as a GEMM over NHWC pixels) + multiple_attention_pooling_2d."""
+    return _AttentionConvPool.apply(x, weight, bias, n_caps)
 
 
 # ----------------------------------------------------------------------------

@@ -70,10 +70,21 @@ class CapsuleImageEncoder(nn.Module):
 
     def forward(self, image):
         batch_size = image.shape[0]
-        h = self.encoder(image) + self.img_embedding_bias.unsqueeze(0)
-        h = self.att_conv(h)
-        h = multiple_attention_pooling_2d(h, self.n_caps)
-        h = h.view(batch_size, self.n_caps, self.n_total_caps_dims)
+        h = self.encoder(image)
+        C, H, W = h.shape[1:]
+        if h.is_cuda and h.dtype == torch.float32 and \
+                ops.attention_pool_supported(H * W, self.n_caps,
+                                             self.n_total_caps_dims + 1):
+            # NHWC pixels x (1x1 conv as a GEMM) -> attention pooling kernel
+            x = h.permute(0, 2, 3, 1) + self.img_embedding_bias.permute(1, 2, 0)
+            h = ops.attention_conv_pool(
+                x.reshape(batch_size, H * W, C),
+                self.att_conv.weight.view(-1, C), self.att_conv.bias,
+                self.n_caps)
+        else:
+            h = self.att_conv(h + self.img_embedding_bias.unsqueeze(0))
+            h = multiple_attention_pooling_2d(h, self.n_caps)
+            h = h.view(batch_size, self.n_caps, self.n_total_caps_dims)
         pose, presence_logit, special_feature = torch.split(
             h, self.caps_dim_splits, -1)
         if self.n_special_features == 0:
