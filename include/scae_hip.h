@@ -152,7 +152,8 @@ int scae_seed_attention_bwd_f32(const float *h, const float *q, const float *wk,
  *      wv2e (C,D+1) = [Wv W2 | Wv b2 + bv] is kept for the backward pass.
  *      backward: gradients of (q, wkf, bkf, wvf, bvf) -> gradients of all
  *      eleven parameters; gv2e, t1: (C,D+1) workspaces.
- *      Limits: C % 64 == 0, C <= 512 (scae_seed_fold_supported).
+ *      Limits: C % 64 == 0, C <= 1024, D in {8,16,32}, O <= 64
+ *      (scae_seed_fold_supported).
  * ---------------------------------------------------------------------- */
 typedef struct scae_seed_fold_desc {
   const float *seeds;                   /* (O,C) */
@@ -239,6 +240,18 @@ int scae_attention_pool_fwd_f32(const float *y, float *out, int B, int HW, int A
                                 void *stream);
 int scae_attention_pool_bwd_f32(const float *y, const float *g, float *dy, int B, int HW,
                                 int A, int P, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Optimiser step on the flat parameter buffer
+ *     replaces torch.optim.RMSprop(lr, momentum, eps) of
+ *     base_experiment.py:44-77 (alpha = 0.99, weight_decay = 0, not centered):
+ *       v <- alpha v + (1-alpha) g^2;  buf <- momentum buf + g/(sqrt(v)+eps);
+ *       p <- p - lr buf        (momentum == 0: p <- p - lr g/(sqrt(v)+eps),
+ *       buf may be NULL).  All buffers n floats, 16-byte aligned.
+ * ---------------------------------------------------------------------- */
+int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg, float *buf,
+                          int64_t n, float lr, float alpha, float eps, float momentum,
+                          void *stream);
 
 /* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225

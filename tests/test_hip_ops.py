@@ -682,7 +682,7 @@ def test_conv_stack_falls_back_for_small_channel_counts():
 # K2d weight folding (set_transformer.py:218-223 projections) vs fp64 algebra
 # --------------------------------------------------------------------------
 @pytest.mark.parametrize("O,C,D", [(24, 256, 16), (5, 64, 8), (32, 512, 32),
-                                   (3, 128, 7)])
+                                   (3, 128, 16), (9, 1024, 8)])
 def test_seed_fold_vs_fp64(O, C, D):
     from torch_scae_amd import ops
     assert ops.seed_fold_supported(O, C, D)
@@ -796,3 +796,33 @@ def test_attention_conv_pool_vs_torch(B, C, H, W, A, P):
                        ("db", bh.grad, br.grad)):
         assert_close(a, r.float(), rtol=2e-4,
                      atol=2e-5 * max(1.0, float(r.abs().max())), what=name)
+
+
+# --------------------------------------------------------------------------
+# fused RMSprop step (base_experiment.py:44-77) vs torch.optim.RMSprop
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("momentum", [0.9, 0.0])
+def test_rmsprop_flat_vs_torch_optim(momentum):
+    import torch.nn as nn
+    from torch_scae_amd.data_parallel import FlatParameters, RMSpropFlat
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Linear(13, 7), nn.ReLU(), nn.Linear(7, 5)).cuda()
+    ref = nn.Sequential(nn.Linear(13, 7), nn.ReLU(), nn.Linear(7, 5)).cuda()
+    ref.load_state_dict(net.state_dict())
+    flat = FlatParameters(net)
+    opt = RMSpropFlat(flat, lr=1e-2, eps=1e-4, momentum=momentum)
+    ropt = torch.optim.RMSprop(ref.parameters(), lr=1e-2, eps=1e-4,
+                               momentum=momentum)
+    for it in range(4):
+        x = torch.randn(9, 13, device="cuda")
+        for m, o in ((net, None), (ref, ropt)):
+            if o is None:
+                flat.clear_grads()
+            else:
+                o.zero_grad()
+            m(x).square().sum().backward()
+        flat.gather_grads()
+        opt.step()
+        ropt.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert_close(a, b, rtol=1e-5, atol=1e-6, what="param after 4 steps")

@@ -10,6 +10,8 @@ gradient in a given configuration (``obj_decoder.dummy_vote``,
 reduction is a single large message -- the right shape for xGMI's per-link
 bound rings.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -113,6 +115,15 @@ class RMSpropFlat:
     @torch.no_grad()
     def step(self):
         g = self.flat.flat_grad
+        if g.is_cuda:      # one fused pass over the four flat buffers
+            from . import _lib
+            P = ctypes.c_void_p
+            _lib.call("scae_rmsprop_step_f32", P(self.flat.flat_param.data_ptr()),
+                      P(g.data_ptr()), P(self.square_avg.data_ptr()),
+                      P(self.buf.data_ptr()), g.numel(), self.lr, self.alpha,
+                      self.eps, self.momentum,
+                      P(torch.cuda.current_stream(g.device).cuda_stream))
+            return
         self.square_avg.mul_(self.alpha).addcmul_(g, g, value=1 - self.alpha)
         avg = self.square_avg.sqrt().add_(self.eps)
         if self.momentum > 0:
