@@ -55,16 +55,17 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ 
   const float *bptr[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int id = tid + NT * i, m = m0 + (id >> 3), kq = (id & 7) << 2;
+    const int id = tid + NT * i, m = m0 + id / QPR, kq = 4 * (id % QPR);
     abase[i] = -1;
     if (m < M) {
       const int n = m / (g.OH * g.OW), rem = m - n * g.OH * g.OW, oh = rem / g.OW,
                 ow = rem - oh * g.OW;
       abase[i] = (((long)n * g.IH + oh * g.stride) * g.IW + ow * g.stride) * g.Cin + kq;
     }
-    bptr[i] = wf + (size_t)(n0 + (id >> 3)) * K + kq;
+    bptr[i] = wf + (size_t)(n0 + id / QPR) * K + kq;
   }
-  auto fetch = [&](int k0, Quads<NQ> &ra, Quads<NQ> &rb) {
+  auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
+    const int k0 = c * BK;
     const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin, kh = tap / 3, kw = tap - kh * 3;
     const int off = (kh * g.IW + kw) * g.Cin + ci0;
 #pragma unroll
@@ -73,16 +74,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ 
       rb.v[i] = ld4(bptr[i] + k0);
     }
   };
-  Quads<NQ> ra, rb;
-  fetch(0, ra, rb);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
-    deposit<SK, true>(As, ra);
-    deposit<SK, true>(Bs, rb);
-    __syncthreads();
-    if (k0 + BK < K) fetch(k0 + BK, ra, rb);
-    mma_chunk<SK, true, true>(As, Bs, acc, wid, r, q);
-  }
+  tile_mainloop<STAGES, SK, true, true>(K / BK, As, Bs, acc, wid, r, q, fetch,
+                                        [](const Quads<NQ> &) {});
   tile_epilogue<SK>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
     const int m = m0 + row, n = n0 + col;
     if (m >= M) return;
@@ -114,13 +107,13 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
   const float *bptr[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int id = tid + NT * i, m = m0 + (id >> 3), kq = (id & 7) << 2;
+    const int id = tid + NT * i, m = m0 + id / QPR, kq = 4 * (id % QPR);
     pn[i] = -1, pih[i] = 0, piw[i] = 0;
     if (m < M) {
       const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
       pn[i] = n * g.OH * g.OW, pih[i] = g.stride * a + ph, piw[i] = g.stride * b + pw;
     }
-    bptr[i] = wd + (size_t)(n0 + (id >> 3)) * KT + kq;
+    bptr[i] = wd + (size_t)(n0 + id / QPR) * KT + kq;
   }
   auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
     const int t = c / cpt, co0 = (c - t * cpt) * BK;
@@ -131,21 +124,13 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
       const int dh = pih[i] - kh, dw = piw[i] - kw, oh = dh >> sh, ow = dw >> sh;
       const bool ok = pn[i] >= 0 && dh >= 0 && dw >= 0 && oh < g.OH && ow < g.OW;
       ra.v[i] = ok ? ld4(dpre + (size_t)(pn[i] + oh * g.OW + ow) * g.Cout + co0 +
-                         (((tid + NT * i) & 7) << 2))
+                         4 * ((tid + NT * i) % QPR))
                    : zero4();
       rb.v[i] = ld4(bptr[i] + koff);
     }
   };
-  Quads<NQ> ra, rb;
-  fetch(0, ra, rb);
-  for (int c = 0; c < nchunk; ++c) {
-    __syncthreads();
-    deposit<SK, true>(As, ra);
-    deposit<SK, true>(Bs, rb);
-    __syncthreads();
-    if (c + 1 < nchunk) fetch(c + 1, ra, rb);
-    mma_chunk<SK, true, true>(As, Bs, acc, wid, r, q);
-  }
+  tile_mainloop<STAGES, SK, true, true>(nchunk, As, Bs, acc, wid, r, q, fetch,
+                                        [](const Quads<NQ> &) {});
   tile_epilogue<SK>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
     const int m = m0 + row;
     if (m >= M) return;
@@ -176,7 +161,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict_
   const int co0 = blockIdx.y * T, ci0 = blockIdx.x * T;
   const bool want_bias = tap == 0 && blockIdx.x == 0;  // workgroup-uniform
   float4 bsum = zero4();
-  auto fetch = [&](int k0, Quads<NQ> &ra, Quads<NQ> &rb) {
+  auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
+    const int k0 = kbeg + c * BK;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int id = tid + NT * i, m = k0 + id / (T / 4), rq = 4 * (id % (T / 4));
@@ -190,23 +176,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict_
       }
     }
   };
-  if (kbeg < kend) {
-    Quads<NQ> ra, rb;
-    fetch(kbeg, ra, rb);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      __syncthreads();
-      deposit<SK, false>(As, ra);
-      deposit<SK, false>(Bs, rb);
-      if (want_bias) {
+  const int nchunk = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+  tile_mainloop<STAGES, SK, false, false>(nchunk, As, Bs, acc, wid, r, q, fetch,
+                                          [&](const Quads<NQ> &ra) {
+    if (want_bias) {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i)
-          bsum.x += ra.v[i].x, bsum.y += ra.v[i].y, bsum.z += ra.v[i].z, bsum.w += ra.v[i].w;
-      }
-      __syncthreads();
-      if (k0 + BK < kend) fetch(k0 + BK, ra, rb);
-      mma_chunk<SK, false, false>(As, Bs, acc, wid, r, q);
+      for (int i = 0; i < NQ; ++i)
+        bsum.x += ra.v[i].x, bsum.y += ra.v[i].y, bsum.z += ra.v[i].z, bsum.w += ra.v[i].w;
     }
-  }
+  });
   float *dst = partial + (size_t)(split * 9 + tap) * g.Cout * g.Cin;
   tile_epilogue<SK>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
     *reinterpret_cast<float4 *>(dst + (size_t)(co0 + row) * g.Cin + ci0 + col) = v;
@@ -364,12 +342,14 @@ struct WgradPlan {
   int splits;
 };
 WgradPlan wgrad_plan(int M, int Cin, int Cout) {
+  // 64x64 tiles (half the L2 traffic per flop of the 32x32 shape); the grid is
+  // filled by splitting the pixel (K) dimension instead: >= 512 workgroups of
+  // >= 8 K chunks each, measured best on the encoder's 128-channel layers
   WgradPlan p;
   const long tiles64 = (long)(Cin / 64) * (Cout / 64) * 9;
-  p.small = tiles64 < 256;
-  const long tiles = p.small ? tiles64 * 4 : tiles64;
-  long s = (1024 + tiles - 1) / tiles;            // aim for >= 1024 workgroups ...
-  const long cap = (M / BK) / 8;                  // ... of >= 8 K chunks each
+  p.small = false;
+  long s = (512 + tiles64 - 1) / tiles64;
+  const long cap = (M / BK) / 8;
   s = s > cap ? cap : s;
   p.splits = (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
   return p;

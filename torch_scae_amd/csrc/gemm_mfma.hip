@@ -42,8 +42,8 @@ __device__ __forceinline__ void fetch(Quads<Tile<SK>::NQ> &q, const float *X, in
     const int id = threadIdx.x + NT * i;
     int row, k;  // first element of the quad
     if (KC) {
-      row = row0 + (id >> 3);
-      k = k0 + ((id & 7) << 2);
+      row = row0 + id / QPR;
+      k = k0 + 4 * (id % QPR);
     } else {
       k = k0 + id / (T / 4);
       row = row0 + 4 * (id % (T / 4));
@@ -83,25 +83,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  Quads<NQ> ra, rb;
-  fetch<SK, AK>(ra, A, g.lda, m0, g.M, 0, g.K, avec);
-  fetch<SK, BKC>(rb, B, g.ldb, n0, g.N, 0, g.K, bvec);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    __syncthreads();  // the previous chunk's fragment reads are done
-    deposit<SK, AK>(As, ra);
-    deposit<SK, BKC>(Bs, rb);
-    if (want_asum) {
+  tile_mainloop<STAGES, SK, AK, BKC>(
+      (g.K + BK - 1) / BK, As, Bs, acc, wid, r, q,
+      [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
+        fetch<SK, AK>(ra, A, g.lda, m0, g.M, c * BK, g.K, avec);
+        fetch<SK, BKC>(rb, B, g.ldb, n0, g.N, c * BK, g.K, bvec);
+      },
+      [&](const Quads<NQ> &ra) {
+        if (want_asum) {
 #pragma unroll
-      for (int i = 0; i < NQ; ++i)
-        asum.x += ra.v[i].x, asum.y += ra.v[i].y, asum.z += ra.v[i].z, asum.w += ra.v[i].w;
-    }
-    __syncthreads();
-    if (k0 + BK < g.K) {  // prefetch: in flight while the MFMAs below run
-      fetch<SK, AK>(ra, A, g.lda, m0, g.M, k0 + BK, g.K, avec);
-      fetch<SK, BKC>(rb, B, g.ldb, n0, g.N, k0 + BK, g.K, bvec);
-    }
-    mma_chunk<SK, AK, BKC>(As, Bs, acc, wid, r, q);
-  }
+          for (int i = 0; i < NQ; ++i)
+            asum.x += ra.v[i].x, asum.y += ra.v[i].y, asum.z += ra.v[i].z, asum.w += ra.v[i].w;
+        }
+      });
   float *C = g.C + z * g.c_batch;
   const float *bias = g.bias ? g.bias + z * g.bias_batch : nullptr;
   const float *mask = g.mask ? g.mask + z * g.mask_batch : nullptr;

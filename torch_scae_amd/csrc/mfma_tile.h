@@ -7,9 +7,8 @@
 //    SK: 32 x 32 output tile; the 4 waves split every K chunk four ways and are
 //        summed through LDS at the end -- 4x the workgroups for the small
 //        problems of this model, which would otherwise leave CUs idle.
-// Operand tiles are k-contiguous [rows][BK + 2] (stride = 2 mod 32 banks) or
-// k-strided [BK][T + 16] (stride = 16 mod 32), both conflict-free for the
-// row-per-lane fragment reads.  Accumulators leave through per-wave LDS slabs
+// Operand tiles are k-contiguous [rows][BK + 4 | BK + 2] or k-strided
+// [BK][T + 16] (stride = 16 mod 32), conflict-free for the fragment reads.  Accumulators leave through per-wave LDS slabs
 // as float4 rows.
 #pragma once
 #include "common.h"
@@ -17,18 +16,36 @@
 namespace scae_tile {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = 256;
-constexpr int BK = 32;
-constexpr int LDK = BK + 2;  // k-contiguous tile [rows][LDK]
-constexpr int LDR = 36;      // epilogue slab [32][LDR]: b128 rows on distinct banks
+#ifndef SCAE_TILE_BK
+#define SCAE_TILE_BK 32
+#endif
+constexpr int BK = SCAE_TILE_BK;  // K chunk per LDS stage
+constexpr int QPR = BK / 4;        // float4 quads per k-contiguous tile row
+// k-contiguous tile [rows][LDK].  When both operands are k-contiguous ("VEC")
+// every lane owns a run of consecutive k of its rows and reads it with
+// ds_read_b128 (row stride BK+4 floats = an odd number of 16-byte units);
+// otherwise lanes read single floats at k = 4s + q (stride BK+2 = 2 mod 32).
+constexpr int LDKV = BK + 4, LDKS = BK + 2;
+constexpr int LDR = 36;  // epilogue slab [32][LDR]: b128 rows on distinct banks
+#ifndef SCAE_TILE_STAGES
+#define SCAE_TILE_STAGES 4
+#endif
+constexpr int STAGES = SCAE_TILE_STAGES;  // register prefetch depth of the K loop
 
 template <bool SK>
 struct Tile {
-  static constexpr int T = SK ? 32 : 64;  // tile rows = tile cols
-  static constexpr int NQ = T / 32;       // float4 per thread per operand per chunk
-  static constexpr int LDT = T + 16;      // k-strided tile [BK][LDT]
-  static constexpr int OPER = BK * LDT > T * LDK ? BK * LDT : T * LDK;
+  static constexpr int T = SK ? 32 : 64;   // tile rows = tile cols
+  static constexpr int NQ = T * QPR / NT;  // float4 per thread per operand per chunk
+  static constexpr int LDT = T + 16;       // k-strided tile [BK][LDT]
+  static constexpr int OPER = BK * LDT > T * LDKV ? BK * LDT : T * LDKV;
   static constexpr int SMEM = 2 * OPER > 4 * 32 * LDR ? 2 * OPER : 4 * 32 * LDR;
 };
+
+// vector fragment reads need both operands k-contiguous and >= 4 k per lane
+template <bool SK, bool AK, bool BKC>
+constexpr bool use_vec() {
+  return AK && BKC && (SK ? BK / 16 : BK / 4) >= 4;
+}
 
 template <int NQ>
 struct Quads {
@@ -40,16 +57,18 @@ __device__ __forceinline__ float4 ld4(const float *p) {
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// registers -> LDS.  KC: tile[row][k] (row = id / 8, k quad = id % 8);
+// registers -> LDS.  KC: tile[row][k] (row = id / QPR, k quad = id % QPR);
 // otherwise tile[k][row] (k = id / (T/4), row quad = id % (T/4)).
-template <bool SK, bool KC>
+template <bool SK, bool KC, bool VEC>
 __device__ __forceinline__ void deposit(float *tile, const Quads<Tile<SK>::NQ> &q) {
   constexpr int T = Tile<SK>::T, LDT = Tile<SK>::LDT;
 #pragma unroll
   for (int i = 0; i < Tile<SK>::NQ; ++i) {
     const int id = threadIdx.x + NT * i;
-    if (KC) {
-      float *p = tile + (id >> 3) * LDK + ((id & 7) << 2);
+    if (KC && VEC) {
+      *reinterpret_cast<float4 *>(tile + (id / QPR) * LDKV + 4 * (id % QPR)) = q.v[i];
+    } else if (KC) {
+      float *p = tile + (id / QPR) * LDKS + 4 * (id % QPR);  // 8-byte aligned
       *reinterpret_cast<float2 *>(p) = make_float2(q.v[i].x, q.v[i].y);
       *reinterpret_cast<float2 *>(p + 2) = make_float2(q.v[i].z, q.v[i].w);
     } else {
@@ -58,30 +77,79 @@ __device__ __forceinline__ void deposit(float *tile, const Quads<Tile<SK>::NQ> &
   }
 }
 
-// the MFMAs of one K chunk.  !SK: wave (wid>>1, wid&1) owns a 32x32 sub-tile and
-// runs all 8 k-steps; SK: every wave covers the whole 32x32 tile for k-steps
-// 2*wid, 2*wid+1.  AK / BKC: operand tile is k-contiguous.
+// The MFMAs of one K chunk.  !SK: wave (wid>>1, wid&1) owns a 32x32 sub-tile
+// and covers all BK k; SK: every wave covers the whole 32x32 tile for its
+// quarter of the chunk.  v_mfma_f32_16x16x4_f32 takes A[r][k_q], B[c][k_q] from
+// lane (r, q): which four k one instruction contracts is free as long as A
+// and B agree, so in VEC mode lane q owns KL consecutive k (vector LDS reads,
+// 4 MFMA steps per ds_read_b128), otherwise k = 4s + q.
 template <bool SK, bool AK, bool BKC>
 __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, f32x4 (&acc)[2][2],
                                           int wid, int r, int q) {
   constexpr int LDT = Tile<SK>::LDT;
+  constexpr bool VEC = use_vec<SK, AK, BKC>();
+  constexpr int KW = SK ? BK / 4 : BK;  // k covered by this wave
+  constexpr int KL = KW / 4;            // per lane
   const int ro = SK ? 0 : 32 * (wid >> 1), co = SK ? 0 : 32 * (wid & 1);
-  const int kb = SK ? 8 * wid : 0;
+  const int kw0 = SK ? KW * wid : 0;
+  constexpr int US = KL < 4 ? KL : 4;  // MFMA steps per fragment load
 #pragma unroll
-  for (int s = 0; s < (SK ? 2 : 8); ++s) {
-    const int kk = kb + 4 * s;
-    float a[2], b[2];
+  for (int s4 = 0; s4 < KL; s4 += US) {
+    float a[2][US], b[2][US];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = ro + 16 * i + r, col = co + 16 * i + r;
-      a[i] = AK ? As[row * LDK + kk + q] : As[(kk + q) * LDT + row];
-      b[i] = BKC ? Bs[col * LDK + kk + q] : Bs[(kk + q) * LDT + col];
+      if (VEC) {
+        const float4 av = ld4(As + row * LDKV + kw0 + KL * q + s4);
+        const float4 bv = ld4(Bs + col * LDKV + kw0 + KL * q + s4);
+        a[i][0] = av.x, a[i][1] = av.y, a[i][2] = av.z, a[i][3] = av.w;
+        b[i][0] = bv.x, b[i][1] = bv.y, b[i][2] = bv.z, b[i][3] = bv.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+          const int k = kw0 + 4 * (s4 + u) + q;
+          a[i][u] = AK ? As[row * LDKS + k] : As[k * LDT + row];
+          b[i][u] = BKC ? Bs[col * LDKS + k] : Bs[k * LDT + col];
+        }
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int u = 0; u < US; ++u)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
+  }
+}
+
+// The K loop: chunk c is fetched into registers ST chunks before it is needed
+// (fetch(c, ra, rb)), so that ST-1 chunks of MFMAs -- times the waves resident
+// on the SIMD -- cover the L2 / HBM latency of the operand loads; `staged(ra)`
+// sees every A chunk as it is deposited (bias-gradient hook).
+template <int ST, bool SK, bool AK, bool BKC, class Fetch, class Staged>
+__device__ __forceinline__ void tile_mainloop(int nchunk, float *As, float *Bs,
+                                              f32x4 (&acc)[2][2], int wid, int r, int q,
+                                              Fetch fetch, Staged staged) {
+  constexpr int NQ = Tile<SK>::NQ;
+  Quads<NQ> ra[ST], rb[ST];
+#pragma unroll
+  for (int s = 0; s < ST; ++s)
+    if (s < nchunk) fetch(s, ra[s], rb[s]);
+  for (int c0 = 0; c0 < nchunk; c0 += ST) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      const int c = c0 + s;
+      if (c < nchunk) {   // workgroup-uniform
+        __syncthreads();  // the previous chunk's fragment reads are done
+        deposit<SK, AK, use_vec<SK, AK, BKC>()>(As, ra[s]);
+        deposit<SK, BKC, use_vec<SK, AK, BKC>()>(Bs, rb[s]);
+        staged(ra[s]);
+        __syncthreads();
+        if (c + ST < nchunk) fetch(c + ST, ra[s], rb[s]);
+        mma_chunk<SK, AK, BKC>(As, Bs, acc, wid, r, q);
+      }
+    }
   }
 }
 
