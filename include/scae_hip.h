@@ -240,6 +240,21 @@ int scae_attention_pool_fwd_f32(const float *y, float *out, int B, int HW, int A
                                 void *stream);
 int scae_attention_pool_bwd_f32(const float *y, const float *g, float *dy, int B, int HW,
                                 int A, int P, void *stream);
+/* The same pooling with the rest of CapsuleImageEncoder.forward fused behind it
+ * (part_encoder.py:75-92, n_poses = 6): the pooled row of capsule a is
+ * [pose (6) | presence logit | special features (P-8)];
+ *   pose (B,A,6)   = geometric_transform(pooled[..., :6], similarity) (K5 math)
+ *   presence (B,A) = sigmoid(pooled[..., 6] + (noise_u - .5) * noise_scale)
+ *   feature (B,A,P-8) (nullable when P == 8); noise_u (B,A) U[0,1) or NULL;
+ *   pooled (B,A,P-1) is kept for the backward pass, whose incoming gradients
+ *   g_pose / g_presence / g_feature may each be NULL (= zeros). */
+int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, float noise_scale,
+                              int similarity, float *pooled, float *pose, float *presence,
+                              float *feature, int B, int HW, int A, int P, void *stream);
+int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *noise_u,
+                              float noise_scale, int similarity, const float *g_pose,
+                              const float *g_presence, const float *g_feature, float *dy,
+                              int B, int HW, int A, int P, void *stream);
 
 /* ------------------------------------------------------------------------
  * Optimiser step on the flat parameter buffer

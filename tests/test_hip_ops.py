@@ -826,3 +826,57 @@ def test_rmsprop_flat_vs_torch_optim(momentum):
         ropt.step()
     for a, b in zip(net.parameters(), ref.parameters()):
         assert_close(a, b, rtol=1e-5, atol=1e-6, what="param after 4 steps")
+
+
+@pytest.mark.parametrize("B,C,H,W,A,F,sim,noisy", [
+    (128, 128, 5, 5, 24, 16, False, True),
+    (5, 8, 3, 4, 5, 0, True, False),
+    (7, 64, 2, 2, 6, 3, False, True),
+])
+def test_capsule_head_vs_oracle(B, C, H, W, A, F, sim, noisy):
+    """part_encoder.py:71-92 end to end (conv1x1, pooling, split, noise,
+    sigmoid, geometric_transform) against the composed fp64 reference ops."""
+    import torch.nn.functional as Fn
+    from torch_scae_amd import ops
+    from torch_scae_amd.nn_ext import multiple_attention_pooling_2d
+    P = 6 + 1 + F + 1
+    g = torch.Generator().manual_seed(B * 7 + A)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(A * P, C, generator=g) / C ** 0.5
+    b = torch.randn(A * P, generator=g)
+    u = torch.rand(B, A, generator=g) if noisy else None
+    scale = 4.0
+    gouts = [torch.randn(B, A, 6, generator=g), torch.randn(B, A, generator=g),
+             torch.randn(B, A, F, generator=g)]
+
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    h = multiple_attention_pooling_2d(
+        Fn.conv2d(xr, wr.view(A * P, C, 1, 1), br), A).view(B, A, P - 1)
+    pose_r = O.geometric_transform(h[..., :6], similarity=sim)
+    logit = h[..., 6]
+    if noisy:
+        logit = logit + (u.double() - .5) * scale
+    pres_r, feat_r = torch.sigmoid(logit), h[..., 7:]
+    loss = (pose_r * gouts[0].double()).sum() + (pres_r * gouts[1].double()).sum()
+    if F:
+        loss = loss + (feat_r * gouts[2].double()).sum()
+    loss.backward()
+
+    xh = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous().cuda() \
+        .requires_grad_()
+    wh, bh = w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    pose, pres, feat = ops.capsule_head(
+        xh, wh, bh, A, u.cuda() if noisy else None, scale, sim)
+    assert (feat is None) == (F == 0)
+    assert_close(pose, pose_r.float(), rtol=1e-4, atol=1e-5, what="pose")
+    assert_close(pres, pres_r.float(), rtol=1e-4, atol=1e-5, what="presence")
+    lh = (pose * gouts[0].cuda()).sum() + (pres * gouts[1].cuda()).sum()
+    if F:
+        assert_close(feat, feat_r.float(), rtol=1e-4, atol=1e-5, what="feat")
+        lh = lh + (feat * gouts[2].cuda()).sum()
+    lh.backward()
+    for name, a, r in (("dx", xh.grad, xr.grad.permute(0, 2, 3, 1)
+                        .reshape(B, H * W, C)), ("dw", wh.grad, wr.grad),
+                       ("db", bh.grad, br.grad)):
+        assert_close(a, r.float(), rtol=5e-4,
+                     atol=5e-5 * max(1.0, float(r.abs().max())), what=name)

@@ -81,6 +81,8 @@ SIGNATURES = {
     "scae_attention_pool_bwd_f32": [P, P, P] + [c_int] * 4 + [P],
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, c_float, c_float,
                               c_float, P],
+    "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
+    "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

@@ -8,7 +8,7 @@
 // that pixel-per-lane and channel-per-lane accesses are both conflict-free).
 // The reference runs this as view / softmax / mul / reshape / sum kernels plus
 // their autograd graph; here it is one launch forward and one backward.
-#include "common.h"
+#include "geometric_transform.h"
 
 namespace {
 constexpr int NT = 256;
@@ -17,12 +17,20 @@ struct PoolArgs {
   const float *y, *g;
   float *out, *dy;
   int B, HW, A, P;
+  // fused capsule head (part_encoder.py:75-92), all nullable: the pooled row of
+  // capsule a is [pose (6) | presence logit | special features (P-8)]
+  const float *noise_u;  // (B,A) U[0,1) draws, logit += (u - .5) * noise_scale
+  float noise_scale;
+  int similarity;
+  float *pose, *presence, *feature;                  // forward outputs
+  const float *pooled, *g_pose, *g_presence, *g_feature;  // backward inputs
 };
 
 __host__ __device__ inline int padded(int AP) { return AP | 1; }
 inline size_t lds_floats(int HW, int A, int P, bool bwd) {
   size_t n = (size_t)HW * padded(A * P) + (size_t)A * HW;  // ys, mask
-  if (bwd) n += (size_t)A * HW + (size_t)A * (P - 1) + A;  // t, gs, s
+  n += bwd ? (size_t)A * HW + (size_t)A * (P - 1) + A      // t, gs, s
+           : (size_t)A * (P - 1);                           // pooled (head mode)
   return n;
 }
 
@@ -68,12 +76,34 @@ __global__ __launch_bounds__(NT) void pool_fwd_kernel(PoolArgs k) {
   __syncthreads();
   softmax_masks(mask, ys, HW, A, P, APp);
   __syncthreads();
+  float *pooled = mask + A * HW;  // [A*(P-1)], head mode only
   for (int e = threadIdx.x; e < A * (P - 1); e += NT) {
     const int a = e / (P - 1), p = e - a * (P - 1);
     float s = 0.f;
     for (int pix = 0; pix < HW; ++pix) s = fmaf(ys[pix * APp + a * P + p], mask[a * HW + pix], s);
     k.out[(size_t)b * A * (P - 1) + e] = s;
+    if (k.pose) pooled[e] = s;
   }
+  if (!k.pose) return;
+  __syncthreads();
+  const int F = P - 8;  // special features per capsule
+  for (int a = threadIdx.x; a < A; a += NT) {
+    const float *row = pooled + a * (P - 1);
+    scae_gt::GtState st;
+    scae_gt::gt_eval(row, 1, st);
+    float o[6];
+    scae_gt::gt_rows(st, k.similarity, o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) k.pose[((size_t)b * A + a) * 6 + j] = o[j];
+    float logit = row[6];
+    if (k.noise_u) logit += (k.noise_u[(size_t)b * A + a] - .5f) * k.noise_scale;
+    k.presence[(size_t)b * A + a] = scae::sigmoidf_(logit);
+  }
+  if (k.feature)
+    for (int e = threadIdx.x; e < A * F; e += NT) {
+      const int a = e / F, f = e - a * F;
+      k.feature[(size_t)b * A * F + e] = pooled[a * (P - 1) + 7 + f];
+    }
 }
 
 // g (B, A, P-1) -> dy (B, HW, A*P)
@@ -83,7 +113,33 @@ __global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
   float *ys = lds, *mask = ys + HW * APp, *t = mask + A * HW, *gs = t + A * HW,
         *sa = gs + A * (P - 1);
   stage_y(ys, k.y + (size_t)b * HW * AP, HW, AP, APp);
-  for (int e = threadIdx.x; e < A * (P - 1); e += NT) gs[e] = k.g[(size_t)b * A * (P - 1) + e];
+  if (k.pooled) {  // head mode: pull (g_pose, g_presence, g_feature) back to the pooled row
+    const int F = P - 8;
+    for (int a = threadIdx.x; a < A; a += NT) {
+      const float *row = k.pooled + ((size_t)b * A + a) * (P - 1);
+      float raw[6], go[6], gp[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        raw[j] = row[j];
+        go[j] = k.g_pose ? k.g_pose[((size_t)b * A + a) * 6 + j] : 0.f;
+      }
+      scae_gt::GtState st;
+      scae_gt::gt_eval(raw, 1, st);
+      scae_gt::gt_backward(st, k.similarity, go, gp);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) gs[a * (P - 1) + j] = gp[j];
+      float logit = row[6];
+      if (k.noise_u) logit += (k.noise_u[(size_t)b * A + a] - .5f) * k.noise_scale;
+      const float sg = scae::sigmoidf_(logit);
+      gs[a * (P - 1) + 6] = k.g_presence ? k.g_presence[(size_t)b * A + a] * sg * (1.f - sg) : 0.f;
+    }
+    for (int e = threadIdx.x; e < A * F; e += NT) {
+      const int a = e / F, f = e - a * F;
+      gs[a * (P - 1) + 7 + f] = k.g_feature ? k.g_feature[(size_t)b * A * F + e] : 0.f;
+    }
+  } else {
+    for (int e = threadIdx.x; e < A * (P - 1); e += NT) gs[e] = k.g[(size_t)b * A * (P - 1) + e];
+  }
   __syncthreads();
   softmax_masks(mask, ys, HW, A, P, APp);
   // t[a][pix] = d out / d mask = sum_p g[a][p] y[pix][a*P + p]   (lanes over pixels)
@@ -122,7 +178,8 @@ extern "C" int scae_attention_pool_supported(int HW, int A, int P) {
 
 extern "C" int scae_attention_pool_fwd_f32(const float *y, float *out, int B, int HW, int A,
                                            int P, void *stream) {
-  PoolArgs k{y, nullptr, out, nullptr, B, HW, A, P};
+  PoolArgs k{};
+  k.y = y, k.out = out, k.B = B, k.HW = HW, k.A = A, k.P = P;
   int rc = check(k);
   if (rc) return rc;
   SCAE_REQUIRE(y && out);
@@ -133,10 +190,46 @@ extern "C" int scae_attention_pool_fwd_f32(const float *y, float *out, int B, in
 
 extern "C" int scae_attention_pool_bwd_f32(const float *y, const float *g, float *dy, int B,
                                            int HW, int A, int P, void *stream) {
-  PoolArgs k{y, g, nullptr, dy, B, HW, A, P};
+  PoolArgs k{};
+  k.y = y, k.g = g, k.dy = dy, k.B = B, k.HW = HW, k.A = A, k.P = P;
   int rc = check(k);
   if (rc) return rc;
   SCAE_REQUIRE(y && g && dy);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(NT), lds_floats(HW, A, P, true) * sizeof(float),
+                     (hipStream_t)stream, k);
+  return scae_launch_status();
+}
+
+extern "C" int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, float noise_scale,
+                                         int similarity, float *pooled, float *pose,
+                                         float *presence, float *feature, int B, int HW, int A,
+                                         int P, void *stream) {
+  PoolArgs k{};
+  k.y = y, k.out = pooled, k.B = B, k.HW = HW, k.A = A, k.P = P;
+  k.noise_u = noise_u, k.noise_scale = noise_scale, k.similarity = similarity;
+  k.pose = pose, k.presence = presence, k.feature = feature;
+  int rc = check(k);
+  if (rc) return rc;
+  if (P < 8) return SCAE_ERR_UNSUPPORTED;  // 6 pose + presence + attention logit
+  SCAE_REQUIRE(y && pooled && pose && presence && (feature || P == 8));
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(NT), lds_floats(HW, A, P, false) * sizeof(float),
+                     (hipStream_t)stream, k);
+  return scae_launch_status();
+}
+
+extern "C" int scae_capsule_head_bwd_f32(const float *y, const float *pooled,
+                                         const float *noise_u, float noise_scale, int similarity,
+                                         const float *g_pose, const float *g_presence,
+                                         const float *g_feature, float *dy, int B, int HW, int A,
+                                         int P, void *stream) {
+  PoolArgs k{};
+  k.y = y, k.dy = dy, k.B = B, k.HW = HW, k.A = A, k.P = P;
+  k.noise_u = noise_u, k.noise_scale = noise_scale, k.similarity = similarity;
+  k.pooled = pooled, k.g_pose = g_pose, k.g_presence = g_presence, k.g_feature = g_feature;
+  int rc = check(k);
+  if (rc) return rc;
+  if (P < 8) return SCAE_ERR_UNSUPPORTED;
+  SCAE_REQUIRE(y && pooled && dy);
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(NT), lds_floats(HW, A, P, true) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
-           "capsule_likelihood", "attention_conv_pool", "attention_pool_supported", "conv_stack", "conv_stack_supported",
+           "capsule_likelihood", "attention_conv_pool", "attention_pool_supported", "capsule_head", "conv_stack", "conv_stack_supported",
            "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
@@ -429,6 +429,35 @@ def attention_pool_supported(HW, A, P):
     return bool(_lib.load().scae_attention_pool_supported(HW, A, P))
 
 
+def _conv1x1_fwd(x, weight, bias):
+    """y (B, HW, AP) = x (B, HW, C) weight^T + bias on the K7 GEMM."""
+    B, HW, C = x.shape
+    AP = weight.shape[0]
+    y = torch.empty(B, HW, AP, device=x.device, dtype=x.dtype)
+    _gemm(_p(x), _p(weight), _p(y), 1, B * HW, AP, C, True, C, 0, True, C, 0,
+          AP, 0, bias=_p(bias), bias_ld=1, ref=x)
+    return y
+
+
+def _conv1x1_bwd(x, weight, dy):
+    """-> (dx, dweight, dbias) of the 1x1 conv given dy (B, HW, AP)."""
+    B, HW, C = x.shape
+    AP = weight.shape[0]
+    # weight / bias gradient: dy^T x split over groups of images (the launch
+    # also emits the column sums of dy), summed afterwards
+    gsz = max(d for d in range(1, B + 1)
+              if B % d == 0 and (d == 1 or HW * d <= 256))
+    S, kper, slab = B // gsz, HW * gsz, AP * C + AP
+    part = torch.empty(S, slab, device=x.device, dtype=x.dtype)
+    _gemm(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP, kper * AP, False,
+          C, kper * C, C, slab, asum=_off(part, AP * C), asum_b=slab, ref=x)
+    gsum = part.sum(0)
+    dx = torch.empty_like(x)
+    _gemm(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP, 0, False, C,
+          0, C, 0, ref=x)
+    return dx, gsum[:AP * C].view(AP, C), gsum[AP * C:]
+
+
 class _AttentionConvPool(torch.autograd.Function):
     """x (B, HW, C) NHWC features, weight (A*P, C), bias (A*P) -> (B, A, P-1):
     y = x weight^T + bias, then per capsule the softmax-over-pixels of its
@@ -439,11 +468,8 @@ class _AttentionConvPool(torch.autograd.Function):
         _need_hip(x, weight, bias)
         x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
         B, HW, C = x.shape
-        AP = weight.shape[0]
-        P = AP // n_caps
-        y = torch.empty(B, HW, AP, device=x.device, dtype=x.dtype)
-        _gemm(_p(x), _p(weight), _p(y), 1, B * HW, AP, C, True, C, 0, True, C,
-              0, AP, 0, bias=_p(bias), bias_ld=1, ref=x)
+        P = weight.shape[0] // n_caps
+        y = _conv1x1_fwd(x, weight, bias)
         out = torch.empty(B, n_caps, P - 1, device=x.device, dtype=x.dtype)
         _lib.call("scae_attention_pool_fwd_f32", _p(y), _p(out), B, HW, n_caps,
                   P, _stream(x))
@@ -455,25 +481,66 @@ class _AttentionConvPool(torch.autograd.Function):
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         B, HW, C = x.shape
-        AP, A = weight.shape[0], ctx.n_caps
-        P = AP // A
+        A = ctx.n_caps
         dy = torch.empty_like(y)
         _lib.call("scae_attention_pool_bwd_f32", _p(y), _p(g.contiguous()),
-                  _p(dy), B, HW, A, P, _stream(x))
-        # weight / bias gradient: dy^T x split over groups of images (the
-        # launch also emits the column sums of dy), summed afterwards
-        gsz = max(d for d in range(1, B + 1)
-                  if B % d == 0 and (d == 1 or HW * d <= 256))
-        S, kper, slab = B // gsz, HW * gsz, AP * C + AP
-        part = torch.empty(S, slab, device=x.device, dtype=x.dtype)
-        _gemm(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP, kper * AP,
-              False, C, kper * C, C, slab, asum=_off(part, AP * C), asum_b=slab,
-              ref=x)
-        gsum = part.sum(0)
-        dx = torch.empty_like(x)
-        _gemm(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP, 0, False,
-              C, 0, C, 0, ref=x)
-        return dx, gsum[:AP * C].view(AP, C), gsum[AP * C:], None
+                  _p(dy), B, HW, A, weight.shape[0] // A, _stream(x))
+        return (*_conv1x1_bwd(x, weight, dy), None)
+
+
+class _CapsuleHead(torch.autograd.Function):
+    """The whole head of CapsuleImageEncoder.forward (part_encoder.py:71-92,
+    n_poses = 6): 1x1 conv, attention pooling, split, presence noise +
+    sigmoid, geometric_transform -> (pose (B,A,6), presence (B,A), feature
+    (B,A,F) or None)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, noise_u, n_caps, noise_scale, similarity):
+        _need_hip(x, weight, bias, noise_u)
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        noise_u = _c(noise_u)
+        B, HW, C = x.shape
+        P = weight.shape[0] // n_caps
+        F = P - 8
+        y = _conv1x1_fwd(x, weight, bias)
+        new = lambda *shape: torch.empty(*shape, device=x.device, dtype=x.dtype)
+        pooled, pose, presence = new(B, n_caps, P - 1), new(B, n_caps, 6), \
+            new(B, n_caps)
+        feature = new(B, n_caps, F) if F > 0 else None
+        _lib.call("scae_capsule_head_fwd_f32", _p(y), _p(noise_u),
+                  float(noise_scale), int(similarity), _p(pooled), _p(pose),
+                  _p(presence), _p(feature), B, HW, n_caps, P, _stream(x))
+        ctx.save_for_backward(x, weight, y, pooled,
+                              *([noise_u] if noise_u is not None else []))
+        ctx.meta = (n_caps, float(noise_scale), int(similarity),
+                    noise_u is not None)
+        ctx.set_materialize_grads(False)
+        if feature is None:
+            feature = new(B, n_caps, 0)
+            ctx.mark_non_differentiable(feature)
+        return pose, presence, feature
+
+    @staticmethod
+    def backward(ctx, g_pose, g_presence, g_feature):
+        x, weight, y, pooled = ctx.saved_tensors[:4]
+        A, noise_scale, similarity, has_noise = ctx.meta
+        noise_u = ctx.saved_tensors[4] if has_noise else None
+        B, HW, C = x.shape
+        dy = torch.empty_like(y)
+        _lib.call("scae_capsule_head_bwd_f32", _p(y), _p(pooled), _p(noise_u),
+                  noise_scale, similarity, _p(_c(g_pose)), _p(_c(g_presence)),
+                  _p(_c(g_feature)), _p(dy), B, HW, A, weight.shape[0] // A,
+                  _stream(x))
+        return (*_conv1x1_bwd(x, weight, dy), None, None, None, None)
+
+
+def capsule_head(x, weight, bias, n_caps, noise_u=None, noise_scale=0.,
+                 similarity=False):
+    """Fused part-capsule head; see ``_CapsuleHead``.  feature is None when
+    the capsules have no special features."""
+    pose, presence, feature = _CapsuleHead.apply(
+        x, weight, bias, noise_u, n_caps, noise_scale, similarity)
+    return pose, presence, (feature if feature.shape[-1] > 0 else None)
 
 
 def attention_conv_pool(x, weight, bias, n_caps):

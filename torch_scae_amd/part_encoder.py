@@ -72,15 +72,25 @@ class CapsuleImageEncoder(nn.Module):
         batch_size = image.shape[0]
         h = self.encoder(image)
         C, H, W = h.shape[1:]
+        noisy = self.training and self.noise_scale > 0.
         if h.is_cuda and h.dtype == torch.float32 and \
                 ops.attention_pool_supported(H * W, self.n_caps,
                                              self.n_total_caps_dims + 1):
             # NHWC pixels x (1x1 conv as a GEMM) -> attention pooling kernel
             x = h.permute(0, 2, 3, 1) + self.img_embedding_bias.permute(1, 2, 0)
-            h = ops.attention_conv_pool(
-                x.reshape(batch_size, H * W, C),
-                self.att_conv.weight.view(-1, C), self.att_conv.bias,
-                self.n_caps)
+            x = x.reshape(batch_size, H * W, C)
+            weight = self.att_conv.weight.view(-1, C)
+            if self.n_poses == 6:
+                # ... with the split / noise / sigmoid / pose non-linearity
+                # fused behind the pooling
+                noise = rand_like(x.new_empty(batch_size, self.n_caps)) \
+                    if noisy else None
+                pose, presence, feature = ops.capsule_head(
+                    x, weight, self.att_conv.bias, self.n_caps, noise,
+                    self.noise_scale, self.similarity_transform)
+                return AttrDict(pose=pose, presence=presence, feature=feature)
+            h = ops.attention_conv_pool(x, weight, self.att_conv.bias,
+                                        self.n_caps)
         else:
             h = self.att_conv(h + self.img_embedding_bias.unsqueeze(0))
             h = multiple_attention_pooling_2d(h, self.n_caps)
@@ -90,7 +100,7 @@ class CapsuleImageEncoder(nn.Module):
         if self.n_special_features == 0:
             special_feature = None
         presence_logit = presence_logit.squeeze(-1)
-        if self.training and self.noise_scale > 0.:
+        if noisy:
             noise = (rand_like(presence_logit) - .5) * self.noise_scale
             presence_logit = presence_logit + noise
         presence = torch.sigmoid(presence_logit)
