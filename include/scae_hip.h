@@ -269,6 +269,32 @@ int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg, fl
                           void *stream);
 
 /* ------------------------------------------------------------------------
+ * K10  coloured templates      replaces TemplateGenerator.forward,
+ *      part_decoder.py:78-110 (colorize_templates = True):
+ *        raw (M,C,hw)        = nonlin_t(logits)
+ *        colour (B,M,C)      = nonlin_c'(relu(W2 relu(W1 feature + b1) + b2))
+ *                              (nonlin_c' = sigmoid, or relu1(. + .99))
+ *        templates (B,M,C,hw) = raw * colour
+ *      nonlin codes: 0 sigmoid, 1 relu1 (nn_ext.py:139-140).
+ *      w1 (H1,F), b1 (H1), w2 (C,H1), b2 (C); feature (B,M,F).
+ *      backward: g_templates (B,M,C,hw), g_raw (M,C,hw, nullable) ->
+ *      g_logits (M,C,hw), g_feature (B,M,F), partial (B, H1*F + H1 + C*H1 + C)
+ *      = per-image [dW1 | db1 | dW2 | db2] for the caller to sum over dim 0.
+ * ---------------------------------------------------------------------- */
+int scae_template_color_supported(int M, int C, int F, int H1);
+int scae_template_color_fwd_f32(const float *logits, const float *feature, const float *w1,
+                                const float *b1, const float *w2, const float *b2, float *raw,
+                                float *templates, float *color, int B, int M, int C, int hw,
+                                int F, int H1, int template_nonlin, int color_nonlin,
+                                void *stream);
+int scae_template_color_bwd_f32(const float *logits, const float *feature, const float *w1,
+                                const float *b1, const float *w2, const float *b2,
+                                const float *color, const float *g_templates,
+                                const float *g_raw, float *g_logits, float *g_feature,
+                                float *partial, int B, int M, int C, int hw, int F, int H1,
+                                int template_nonlin, int color_nonlin, void *stream);
+
+/* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225
  *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
  *   all_param (B,O,A), A = 6V+6+1+2V, the output of the per-capsule MLPs,

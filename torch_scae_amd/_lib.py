@@ -83,6 +83,9 @@ SIGNATURES = {
                               c_float, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
+    "scae_template_color_supported": [c_int] * 4,
+    "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],
+    "scae_template_color_bwd_f32": [P] * 12 + [c_int] * 8 + [P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
-           "capsule_likelihood", "attention_conv_pool", "attention_pool_supported", "capsule_head", "conv_stack", "conv_stack_supported",
+           "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "conv_stack", "conv_stack_supported",
            "render_templates", "render_gmm_log_prob",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
@@ -546,6 +546,68 @@ def capsule_head(x, weight, bias, n_caps, noise_u=None, noise_scale=0.,
 def attention_conv_pool(x, weight, bias, n_caps):
     """1x1 conv (as a GEMM over NHWC pixels) + multiple_attention_pooling_2d."""
     return _AttentionConvPool.apply(x, weight, bias, n_caps)
+
+
+# ----------------------------------------------------------------------------
+# K10 coloured templates (part_decoder.py:78-110)
+# ----------------------------------------------------------------------------
+_NONLIN_CODE = {"sigmoid": 0, "relu1": 1}
+
+
+def template_color_supported(M, C, F, H1, template_nonlin, color_nonlin):
+    return (template_nonlin in _NONLIN_CODE and color_nonlin in _NONLIN_CODE
+            and bool(_lib.load().scae_template_color_supported(M, C, F, H1)))
+
+
+class _ColoredTemplates(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, feature, w1, b1, w2, b2, tnl, cnl):
+        _need_hip(logits, feature, w1, b1, w2, b2)
+        logits, feature, w1, b1, w2, b2 = (t.contiguous() for t in (
+            logits, feature, w1, b1, w2, b2))
+        _, M, C, th, tw = logits.shape
+        B, F, H1 = feature.shape[0], feature.shape[2], w1.shape[0]
+        new = lambda *shape: torch.empty(*shape, device=logits.device,
+                                         dtype=logits.dtype)
+        raw, templates, color = new(1, M, C, th, tw), new(B, M, C, th, tw), \
+            new(B, M, C)
+        _lib.call("scae_template_color_fwd_f32", _p(logits), _p(feature),
+                  _p(w1), _p(b1), _p(w2), _p(b2), _p(raw), _p(templates),
+                  _p(color), B, M, C, th * tw, F, H1, tnl, cnl, _stream(logits))
+        ctx.save_for_backward(logits, feature, w1, b1, w2, b2, color)
+        ctx.codes = (tnl, cnl)
+        ctx.set_materialize_grads(False)
+        return raw, templates
+
+    @staticmethod
+    def backward(ctx, g_raw, g_templates):
+        logits, feature, w1, b1, w2, b2, color = ctx.saved_tensors
+        _, M, C, th, tw = logits.shape
+        B, F, H1 = feature.shape[0], feature.shape[2], w1.shape[0]
+        if g_templates is None:
+            g_templates = torch.zeros(B, M, C, th, tw, device=logits.device,
+                                      dtype=logits.dtype)
+        n1, n2, n3 = H1 * F, H1 * F + H1, H1 * F + H1 + C * H1
+        g_logits, g_feature = torch.empty_like(logits), torch.empty_like(feature)
+        partial = torch.empty(B, n3 + C, device=logits.device,
+                              dtype=logits.dtype)
+        _lib.call("scae_template_color_bwd_f32", _p(logits), _p(feature),
+                  _p(w1), _p(b1), _p(w2), _p(b2), _p(color),
+                  _p(g_templates.contiguous()), _p(_c(g_raw)), _p(g_logits),
+                  _p(g_feature), _p(partial), B, M, C, th * tw, F, H1,
+                  *ctx.codes, _stream(logits))
+        g = partial.sum(0)
+        return (g_logits, g_feature, g[:n1].view(H1, F), g[n1:n2],
+                g[n2:n3].view(C, H1), g[n3:], None, None)
+
+
+def colored_templates(template_logits, feature, w1, b1, w2, b2,
+                      template_nonlin, color_nonlin):
+    """-> (raw_templates (1,M,C,h,w), templates (B,M,C,h,w)); nonlin names
+    'sigmoid' | 'relu1'."""
+    return _ColoredTemplates.apply(template_logits, feature, w1, b1, w2, b2,
+                                   _NONLIN_CODE[template_nonlin],
+                                   _NONLIN_CODE[color_nonlin])
 
 
 # ----------------------------------------------------------------------------

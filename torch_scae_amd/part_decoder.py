@@ -24,6 +24,7 @@ class TemplateGenerator(nn.Module):
         self.n_templates = n_templates
         self.template_size = template_size
         self.n_channels = n_channels
+        self._nonlin_names = (template_nonlin, color_nonlin)
         self.template_nonlin = choose_activation(template_nonlin)
         self.dim_feature = dim_feature
         self.colorize_templates = colorize_templates
@@ -45,6 +46,19 @@ class TemplateGenerator(nn.Module):
         AttrDict(raw_templates (1,M,C,h,w), templates (B,M,C,h,w))."""
         if feature is not None:
             batch_size = feature.shape[0]
+        if self.colorize_templates and feature is not None and \
+                feature.is_cuda and feature.dtype == torch.float32 and \
+                len(self.templates_color_mlp) == 4 and \
+                ops.template_color_supported(
+                    feature.shape[1], self.n_channels, feature.shape[2],
+                    self.templates_color_mlp[0].out_features,
+                    *self._nonlin_names):
+            # non-linearities, colour MLP and the product in one kernel
+            mlp = self.templates_color_mlp
+            raw_templates, templates = ops.colored_templates(
+                self.template_logits, feature, mlp[0].weight, mlp[0].bias,
+                mlp[2].weight, mlp[2].bias, *self._nonlin_names)
+            return AttrDict(raw_templates=raw_templates, templates=templates)
         raw_templates = self.template_nonlin(self.template_logits)
         if self.colorize_templates and feature is not None:
             n_templates = feature.shape[1]
