@@ -880,3 +880,42 @@ def test_capsule_head_vs_oracle(B, C, H, W, A, F, sim, noisy):
                        ("db", bh.grad, br.grad)):
         assert_close(a, r.float(), rtol=5e-4,
                      atol=5e-5 * max(1.0, float(r.abs().max())), what=name)
+
+
+# --------------------------------------------------------------------------
+# K10 coloured templates (part_decoder.py:78-110) vs the oracle, fwd + grads
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("tnl,cnl,C,F,ts", [("sigmoid", "sigmoid", 1, 16, 11),
+                                            ("relu1", "relu1", 3, 5, 7),
+                                            ("sigmoid", "relu1", 2, 16, 4)])
+def test_colored_templates_vs_oracle(tnl, cnl, C, F, ts):
+    from torch_scae_amd.part_decoder import TemplateGenerator
+    torch.manual_seed(11)
+    B, M = 9, 6
+    tg = TemplateGenerator(M, C, (ts, ts), template_nonlin=tnl, dim_feature=F,
+                           colorize_templates=True, color_nonlin=cnl)
+    with torch.no_grad():     # spread the logits over both clamp regions
+        tg.template_logits.mul_(1.6).sub_(.3)
+    feature = torch.randn(B, M, F)
+    gt, gr = torch.randn(B, M, C, ts, ts), torch.randn(1, M, C, ts, ts)
+    cfg = dict(template_nonlin=tnl, color_nonlin=cnl, colorize_templates=True)
+
+    P = {"tg." + k: v.detach().clone().requires_grad_()
+         for k, v in tg.state_dict().items()}
+    f_ref = feature.clone().requires_grad_()
+    ref = O.template_generator(P, "tg", f_ref, B, cfg)
+    ((ref.templates * gt).sum() + (ref.raw_templates * gr).sum()).backward()
+
+    tg = tg.cuda()
+    f_hip = feature.cuda().requires_grad_()
+    out = tg(feature=f_hip)
+    ((out.templates * gt.cuda()).sum()
+     + (out.raw_templates * gr.cuda()).sum()).backward()
+    assert_close(out.templates, ref.templates, rtol=1e-5, atol=1e-6,
+                 what="templates")
+    assert_close(out.raw_templates, ref.raw_templates, rtol=1e-5, atol=1e-6,
+                 what="raw")
+    assert_close(f_hip.grad, f_ref.grad, rtol=1e-4, atol=1e-5, what="d_feature")
+    for name, p in tg.named_parameters():
+        assert_close(p.grad, P["tg." + name].grad, rtol=1e-4, atol=2e-5,
+                     what="d_" + name)
