@@ -385,25 +385,40 @@ int scae_capsule_likelihood_bwd_f32(
  *   [caps_ll, prior_within, prior_between, posterior_within,
  *   posterior_between]; within_const: prior_within_example_constant or NaN
  *   (= n_caps/n_classes); n_classes_cfg: SCAE.n_classes (l2 constants).
- *   out8: [tail loss, log_prob, prior_within, prior_between, post_within,
- *   post_between, prior_cls_xe, posterior_cls_xe]; tail loss = -w0*log_prob +
- *   w1*pw + w2*pb + w3*qw + w4*qb + xe + xe.
- *   backward: gout8 (8) -> g_lpp, g_posterior, g_caps_presence, g_cls_w,
+ *   out12: [loss, log_prob, prior_within, prior_between, post_within,
+ *   post_between, prior_cls_xe, posterior_cls_xe, rec_ll, -rec_ll, -log_prob,
+ *   reg]; loss = -w0*log_prob + w1*pw + w2*pb + w3*qw + w4*qb + xe + xe
+ *                - rec_ll + w_reg*reg.
+ *   extras (nullable): the remaining terms of the training loss, so that the
+ *   whole scalar (:217-287) leaves one kernel -- rec_sums (n_rec) = K1's tile
+ *   sums of the reconstruction log-likelihood (rec_ll = sum / B, :222-224), reg
+ *   (1) = cpr_dynamic_reg_loss with its weight w_reg (:270-272); g_rec_sums /
+ *   g_reg receive their gradients in the backward pass.
+ *   backward: gout12 (12) -> g_lpp, g_posterior, g_caps_presence, g_cls_w,
  *   g_cls_b (classifier inputs are detached in the reference).
  * ---------------------------------------------------------------------- */
+typedef struct scae_loss_extras {
+  const float *rec_sums;
+  int n_rec;
+  const float *reg;
+  float w_reg;
+  float *g_rec_sums, *g_reg;
+} scae_loss_extras;
 int scae_loss_tail_supported(int B, int O, int ncls);
 int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                            const float *caps_presence, const float *cls_w,
-                           const float *cls_b, const int64_t *label, float *out8, int B,
-                           int O, int M, int ncls, int n_classes_cfg, int prior_type,
-                           int post_type, int sparsity_on, const float *weights5,
-                           float within_const, void *stream);
+                           const float *cls_b, const int64_t *label,
+                           const scae_loss_extras *extras, float *out12, int B, int O, int M,
+                           int ncls, int n_classes_cfg, int prior_type, int post_type,
+                           int sparsity_on, const float *weights5, float within_const,
+                           void *stream);
 int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
                            const float *caps_presence, const float *cls_w,
-                           const float *cls_b, const int64_t *label, const float *gout8,
-                           float *g_lpp, float *g_posterior, float *g_caps_presence,
-                           float *g_cls_w, float *g_cls_b, int B, int O, int M, int ncls,
-                           int n_classes_cfg, int prior_type, int post_type, int sparsity_on,
+                           const float *cls_b, const int64_t *label,
+                           const scae_loss_extras *extras, const float *gout12, float *g_lpp,
+                           float *g_posterior, float *g_caps_presence, float *g_cls_w,
+                           float *g_cls_b, int B, int O, int M, int ncls, int n_classes_cfg,
+                           int prior_type, int post_type, int sparsity_on,
                            const float *weights5, float within_const, void *stream);
 
 /* ------------------------------------------------------------------------
@@ -469,6 +484,21 @@ int scae_render_gmm_bwd_f32(const scae_decoder_desc *d, const float *x,
                             float *g_alpha_partial, float *g_pose,
                             float *g_presence, float *g_bg_image,
                             float *g_scalar_partial, void *stream);
+/* Tile-sum variant for the training loss (stacked_capsule_auto_encoder.py:222-224
+ * only ever needs rec_ll = mean_b sum_{c,h,w} log_prob): the forward emits one
+ * partial sum per (image, pixel tile) -- tile_sums (B, scae_render_gmm_logprob_tiles(d)),
+ * summed in a fixed order -- instead of the per-pixel map, and the backward
+ * takes the gradient of those sums (B, tiles). */
+int scae_render_gmm_logprob_tiles(const scae_decoder_desc *d);
+int scae_render_gmm_logprob_sums_fwd_f32(const scae_decoder_desc *d, const float *x,
+                                         float *tile_sums, float *lse_post, float *lse_prior,
+                                         void *stream);
+int scae_render_gmm_sums_bwd_f32(const scae_decoder_desc *d, const float *x,
+                                 const float *lse_post, const float *lse_prior,
+                                 const float *g_tile_sums, float *g_templates,
+                                 float *g_alpha_partial, float *g_pose, float *g_presence,
+                                 float *g_bg_image, float *g_scalar_partial, void *stream);
+
 
 /* generic mixture over materialised tensors: distributions.py:34-47.
  *   loc (B,K,C,P), mixing_logits (B,K,Cm,P) with Cm in {1,C}, sigma (1) device

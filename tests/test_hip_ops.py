@@ -608,7 +608,8 @@ def test_loss_tail_vs_oracle(prior, post, use_label, const):
                           label.cuda() if use_label else None, ncls, prior,
                           post, True, weights, const)
     out_g[0].backward()
-    assert_close(out_g, out_c, 1e-4, 1e-4, "tail outputs")
+    assert_close(out_g[:8], out_c, 1e-4, 1e-4, "tail outputs")
+    assert float(out_g[10]) == -float(out_g[1]) and float(out_g[8]) == 0.0
     names = ("lpp", "posterior", "caps_presence", "cls_w", "cls_b")
     for nme, a, b in zip(names, ins_g, ins_c):
         if b.grad is None:
@@ -617,6 +618,25 @@ def test_loss_tail_vs_oracle(prior, post, use_label, const):
         assert_close(a.grad, b.grad,
                      1e-4 * max(1.0, float(b.grad.abs().max())), 2e-4,
                      "grad " + nme)
+
+
+    # the remaining scalar terms of the training loss folded in: reconstruction
+    # tile sums (rec_ll = sum / B) and the dynamic regulariser
+    rec = torch.randn(B, 7)
+    reg = torch.rand(1)
+    ins_e = [leaf(t) for t in (lpp, post_full, cp, W, bb, rec, reg)]
+    out_e = ops.loss_tail(*ins_e[:5], label.cuda() if use_label else None, ncls,
+                          prior, post, True, weights, const, rec_sums=ins_e[5],
+                          reg=ins_e[6], w_reg=0.37)
+    out_e[0].backward()
+    rec_ll = float(rec.double().sum() / B)
+    want = float(out_c[0]) - rec_ll + 0.37 * float(reg)
+    assert abs(float(out_e[0]) - want) <= 1e-4 * max(1.0, abs(want))
+    assert abs(float(out_e[8]) - rec_ll) <= 1e-5 * max(1.0, abs(rec_ll))
+    assert float(out_e[9]) == -float(out_e[8])
+    assert_close(ins_e[5].grad, torch.full((B, 7), -1.0 / B), 1e-7, 1e-6, "g_rec")
+    assert_close(ins_e[6].grad, torch.tensor([0.37]), 1e-7, 1e-6, "g_reg")
+    assert_close(ins_e[0].grad, ins_g[0].grad, 1e-7, 1e-6, "g_lpp with extras")
 
 
 # --------------------------------------------------------------------------

@@ -25,6 +25,12 @@ class DecoderDesc(Structure):
                 ("tw", c_int), ("H", c_int), ("W", c_int)]
 
 
+class LossExtras(Structure):
+    """struct scae_loss_extras"""
+    _fields_ = [("rec_sums", P), ("n_rec", c_int), ("reg", P),
+                ("w_reg", c_float), ("g_rec_sums", P), ("g_reg", P)]
+
+
 class SeedFoldDesc(Structure):
     """struct scae_seed_fold_desc"""
     _fields_ = [(n, P) for n in (
@@ -93,11 +99,16 @@ SIGNATURES = {
     "scae_capsule_likelihood_fwd_f32": [P] * 17 + [c_int] * 3 + [P],
     "scae_capsule_likelihood_bwd_f32": [P] * 22 + [c_int] * 3 + [P],
     "scae_loss_tail_supported": [c_int] * 3,
-    "scae_loss_tail_fwd_f32": [P] * 7 + [c_int] * 8 + [POINTER(c_float), c_float, P],
-    "scae_loss_tail_bwd_f32": [P] * 12 + [c_int] * 8 + [POINTER(c_float), c_float, P],
+    "scae_loss_tail_fwd_f32": [P] * 6 + [POINTER(LossExtras), P] + [c_int] * 8
+    + [POINTER(c_float), c_float, P],
+    "scae_loss_tail_bwd_f32": [P] * 6 + [POINTER(LossExtras)] + [P] * 6
+    + [c_int] * 8 + [POINTER(c_float), c_float, P],
     "scae_template_render_fwd_f32": [POINTER(DecoderDesc), P, P, P],
     "scae_render_gmm_logprob_fwd_f32": [POINTER(DecoderDesc), P, P, P, P, P],
     "scae_render_gmm_bwd_f32": [POINTER(DecoderDesc)] + [P] * 12 + [P],
+    "scae_render_gmm_logprob_tiles": [POINTER(DecoderDesc)],
+    "scae_render_gmm_logprob_sums_fwd_f32": [POINTER(DecoderDesc)] + [P] * 4 + [P],
+    "scae_render_gmm_sums_bwd_f32": [POINTER(DecoderDesc)] + [P] * 10 + [P],
     "scae_gmm_log_prob_fwd_f32": [P] * 5 + [c_int] * 4 + [c_int64, P],
     "scae_gmm_log_prob_bwd_f32": [P] * 9 + [c_int] * 4 + [c_int64, P],
     "scae_gmm_mean_f32": [P] * 3 + [c_int] * 4 + [c_int64, P],

@@ -229,7 +229,7 @@ __device__ void load_stats(const TailArgs &a, const Carve &c) {
 
 // out: [0] tail loss  [1] log_prob  [2] prior_within [3] prior_between
 //      [4] post_within [5] post_between [6] prior_cls_xe [7] posterior_cls_xe
-__global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, float *out) {
+__global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, scae_loss_extras x, float *out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int B = a.B, O = a.O;
   const Carve c = carve(smem, B, O, a.ncls);
@@ -259,7 +259,20 @@ __global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, float *out) {
       t2 += cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
     xe2 = block_total(t2, c.red) / B;
   }
+  // reconstruction term (stacked_capsule_auto_encoder.py:222-224) from K1's tile
+  // sums, and the dynamic-regularisation scalar
+  float rec = 0.f;
+  if (x.rec_sums) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < x.n_rec; i += NT) t += x.rec_sums[i];
+    rec = block_total(t, c.red) / B;
+  }
   if (threadIdx.x == 0) {
+    const float reg = x.reg ? x.reg[0] : 0.f;
+    out[8] = rec;
+    out[9] = -rec;
+    out[10] = -log_prob;
+    out[11] = reg;
     out[1] = log_prob;
     out[2] = pw;
     out[3] = pb;
@@ -268,13 +281,14 @@ __global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, float *out) {
     out[6] = xe1;
     out[7] = xe2;
     out[0] = -a.w_ll * log_prob + a.w_pw * pw + a.w_pb * pb + a.w_qw * qw + a.w_qb * qb + xe1 +
-             xe2;
+             xe2 - rec + x.w_reg * reg;
   }
 }
 
-__global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, const float *gout /*[8]*/,
-                                                      float *g_lpp, float *g_post, float *g_cp,
-                                                      float *g_w, float *g_b) {
+__global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extras x,
+                                                      const float *gout /*[12]*/, float *g_lpp,
+                                                      float *g_post, float *g_cp, float *g_w,
+                                                      float *g_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int B = a.B, O = a.O, M = a.M;
   const Carve c = carve(smem, B, O, a.ncls);
@@ -282,7 +296,12 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, const float *g
   // d(total)/d(component): the tail loss plus whatever flowed into the
   // individually exposed log entries
   const float g0 = gout[0];
-  const float g_lp = -a.w_ll * g0 + gout[1];
+  const float g_lp = -a.w_ll * g0 + gout[1] - gout[10];
+  if (x.g_rec_sums) {
+    const float gr = (-g0 + gout[8] - gout[9]) / B;
+    for (int i = threadIdx.x; i < x.n_rec; i += NT) x.g_rec_sums[i] = gr;
+  }
+  if (x.g_reg && threadIdx.x == 0) x.g_reg[0] = x.w_reg * g0 + gout[11];
   const float g_pw = a.w_pw * g0 + gout[2], g_pb = a.w_pb * g0 + gout[3];
   const float g_qw = a.w_qw * g0 + gout[4], g_qb = a.w_qb * g0 + gout[5];
   const float g_x1 = g0 + gout[6], g_x2 = g0 + gout[7];
@@ -378,29 +397,34 @@ static int fill_tail(TailArgs &a, const float *lpp, const float *posterior, cons
 
 extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                                       const float *caps_presence, const float *cls_w,
-                                      const float *cls_b, const int64_t *label, float *out8,
-                                      int B, int O, int M, int ncls, int n_classes_cfg,
-                                      int prior_type, int post_type, int sparsity_on,
-                                      const float *weights5, float within_const, void *stream) {
+                                      const float *cls_b, const int64_t *label,
+                                      const scae_loss_extras *extras, float *out12, int B,
+                                      int O, int M, int ncls, int n_classes_cfg, int prior_type,
+                                      int post_type, int sparsity_on, const float *weights5,
+                                      float within_const, void *stream) {
   TailArgs a;
   int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
                      n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
   if (rc) return rc;
-  SCAE_REQUIRE(out8);
+  SCAE_REQUIRE(out12);
+  scae_loss_extras x{};
+  if (extras) x = *extras;
+  if (x.rec_sums && x.n_rec <= 0) return SCAE_ERR_BAD_ARG;
   const size_t lds = tail_lds(B, O, false);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(tail_fwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, out8);
+  hipLaunchKernelGGL(tail_fwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, x, out12);
   return scae_launch_status();
 }
 
 extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
                                       const float *caps_presence, const float *cls_w,
                                       const float *cls_b, const int64_t *label,
-                                      const float *gout8, float *g_lpp, float *g_posterior,
+                                      const scae_loss_extras *extras, const float *gout12,
+                                      float *g_lpp, float *g_posterior,
                                       float *g_caps_presence, float *g_cls_w, float *g_cls_b,
                                       int B, int O, int M, int ncls, int n_classes_cfg,
                                       int prior_type, int post_type, int sparsity_on,
@@ -409,7 +433,11 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
   int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
                      n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
   if (rc) return rc;
-  SCAE_REQUIRE(gout8 && g_lpp && g_posterior && g_caps_presence);
+  SCAE_REQUIRE(gout12 && g_lpp && g_posterior && g_caps_presence);
+  scae_loss_extras x{};
+  if (extras) x = *extras;
+  if (x.rec_sums && (x.n_rec <= 0 || !x.g_rec_sums)) return SCAE_ERR_BAD_ARG;
+  if (x.reg && !x.g_reg) return SCAE_ERR_BAD_ARG;
   if (label) SCAE_REQUIRE(g_cls_w && g_cls_b);
   const size_t lds = tail_lds(B, O, true);
   if (lds > 48 * 1024) {
@@ -417,7 +445,7 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, gout8,
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, x, gout12,
                      g_lpp, g_posterior, g_caps_presence, g_cls_w, g_cls_b);
   return scae_launch_status();
 }

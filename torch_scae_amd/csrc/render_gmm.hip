@@ -182,8 +182,11 @@ __global__ __launch_bounds__(NT) void render_fwd_kernel(scae_decoder_desc d,
 template <int C, int KSPLIT>
 __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
     scae_decoder_desc d, const float *__restrict__ x, float *__restrict__ log_prob,
-    float *__restrict__ lse_post, float *__restrict__ lse_prior, int pix_per_block) {
+    float *__restrict__ lse_post, float *__restrict__ lse_prior, int pix_per_block,
+    float *__restrict__ block_sums) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float s_sum[NT / 64];
+  float lp_sum = 0.f;  // this lane's share of sum_{c,p} log_prob (block_sums mode)
   const int b = blockIdx.y, tid = threadIdx.x;
   const int M = d.M, HW = d.H * d.W, tsz = d.th * d.tw;
   const bool alpha_mode = d.templates_alpha != nullptr;
@@ -275,12 +278,18 @@ __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
         const float lpost = post[c].value();
         const float lprior = prior[alpha_mode ? 0 : c].value();
         const size_t o = (size_t)(b * C + c) * HW + p;
-        log_prob[o] = lpost - lprior;
+        if (log_prob) log_prob[o] = lpost - lprior;
+        lp_sum += lpost - lprior;
         lse_post[o] = lpost;
         if (!alpha_mode) lse_prior[o] = lprior;
       }
       if (alpha_mode) lse_prior[(size_t)b * HW + p] = prior[0].value();
     }
+  }
+  if (block_sums) {  // sum over this workgroup's pixels and channels, fixed order
+    float a[1] = {lp_sum};
+    scae::block_sum<1, NT>(a, s_sum);
+    if (tid == 0) block_sums[(size_t)b * gridDim.x + blockIdx.x] = a[0];
   }
 }
 
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
     float *__restrict__ g_templates, float *__restrict__ g_alpha_partial,
     float *__restrict__ g_pose, float *__restrict__ g_presence,
     float *__restrict__ g_bg_image, float *__restrict__ g_scalar_partial,
-    int rows_per_chunk) {
+    int rows_per_chunk, const float *__restrict__ g_tile, int lp_tiles, int lp_ppb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int M = d.M, K = M + 1, W = d.W, H = d.H, HW = H * W, tw = d.tw, th = d.th;
@@ -398,7 +407,8 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const size_t o = (size_t)(b * C + c) * HW + p;
-          const float gc = g_logprob[o];
+          // per-pixel gradient, or the gradient of the log-prob tile sum the pixel is in
+          const float gc = g_tile ? g_tile[b * lp_tiles + p / lp_ppb] : g_logprob[o];
           if (!alpha_mode) {
             mlv = tv[c] / sc.temperature + lsp;
             sp = __expf(mlv - lse_prior[o]);
@@ -783,29 +793,42 @@ extern "C" int scae_template_render_fwd_f32(const scae_decoder_desc *d,
 }
 
 namespace {
-template <int C>
-int launch_logprob_fwd(const scae_decoder_desc *d, const float *x, float *log_prob,
-                       float *lse_post, float *lse_prior, hipStream_t st) {
-  const int HW = d->H * d->W, tsz = d->th * d->tw;
-  const size_t lds = sizeof(float) * ((size_t)d->M * d->C * tsz +
-                                      (d->templates_alpha ? (size_t)d->M * tsz : 0) +
-                                      (size_t)d->M * 7);
+// pixel tiling of the log-prob kernel: lanes per pixel, pixels per workgroup
+struct LpTiling {
+  int ksplit, ppb, tiles;
+};
+LpTiling lp_tiling(const scae_decoder_desc *d) {
+  const int HW = d->H * d->W;
   // component split across lanes: more lanes per pixel when the batch alone
   // cannot fill 256 CUs
   const long pixels = (long)d->B * HW;
-  const int ksplit = pixels >= 256L * 1024 * 4 ? 1 : (pixels >= 256L * 1024 ? 2 : 4);
-  int ppb = 4 * NT / ksplit;  // four pixel rounds per workgroup amortise the LDS fill
-  if (ppb > HW) ppb = ((HW + (NT / ksplit) - 1) / (NT / ksplit)) * (NT / ksplit);
-  const dim3 grid((HW + ppb - 1) / ppb, d->B);
+  LpTiling t;
+  t.ksplit = pixels >= 256L * 1024 * 4 ? 1 : (pixels >= 256L * 1024 ? 2 : 4);
+  t.ppb = 4 * NT / t.ksplit;  // four pixel rounds per workgroup amortise the LDS fill
+  if (t.ppb > HW) t.ppb = ((HW + (NT / t.ksplit) - 1) / (NT / t.ksplit)) * (NT / t.ksplit);
+  t.tiles = (HW + t.ppb - 1) / t.ppb;
+  return t;
+}
+
+template <int C>
+int launch_logprob_fwd(const scae_decoder_desc *d, const float *x, float *log_prob,
+                       float *lse_post, float *lse_prior, float *block_sums, hipStream_t st) {
+  const int tsz = d->th * d->tw;
+  const size_t lds = sizeof(float) * ((size_t)d->M * d->C * tsz +
+                                      (d->templates_alpha ? (size_t)d->M * tsz : 0) +
+                                      (size_t)d->M * 7);
+  const LpTiling t = lp_tiling(d);
+  const int ppb = t.ppb;
+  const dim3 grid(t.tiles, d->B);
   int rc;
 #define SCAE_LAUNCH_LP(KS)                                                            \
   rc = set_lds(logprob_fwd_kernel<C, KS>, lds);                                       \
   if (rc) return rc;                                                                  \
   hipLaunchKernelGGL((logprob_fwd_kernel<C, KS>), grid, dim3(NT), lds, st, *d, x,     \
-                     log_prob, lse_post, lse_prior, ppb)
-  if (ksplit == 1) {
+                     log_prob, lse_post, lse_prior, ppb, block_sums)
+  if (t.ksplit == 1) {
     SCAE_LAUNCH_LP(1);
-  } else if (ksplit == 2) {
+  } else if (t.ksplit == 2) {
     SCAE_LAUNCH_LP(2);
   } else {
     SCAE_LAUNCH_LP(4);
@@ -819,8 +842,9 @@ int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post
                const float *lse_prior, const float *g_logprob, const float *g_tt,
                const float *g_ml, float *g_templates, float *g_alpha_partial,
                float *g_pose, float *g_presence, float *g_bg_image,
-               float *g_scalar_partial, hipStream_t st) {
+               float *g_scalar_partial, const float *g_tile, hipStream_t st) {
   const int tsz = d->th * d->tw;
+  const LpTiling lt = lp_tiling(d);
   // per-pixel gradient planes of one chunk of output rows live in LDS
   int rows = (int)((40 * 1024 / sizeof(float)) / ((size_t)(d->C + 1) * d->W));
   rows = rows < 1 ? 1 : (rows > d->H ? d->H : rows);
@@ -835,14 +859,14 @@ int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post
     hipLaunchKernelGGL((render_bwd_kernel<C, true>), grid, dim3(NT), lds, st, *d, x,
                        lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,
                        g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,
-                       rows);
+                       rows, g_tile, lt.tiles, lt.ppb);
   } else {
     rc = set_lds(render_bwd_kernel<C, false>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((render_bwd_kernel<C, false>), grid, dim3(NT), lds, st, *d, x,
                        lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,
                        g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,
-                       rows);
+                       rows, g_tile, lt.tiles, lt.ppb);
   }
   return scae_launch_status();
 }
@@ -864,7 +888,43 @@ extern "C" int scae_render_gmm_logprob_fwd_f32(const scae_decoder_desc *d, const
   if (rc) return rc;
   SCAE_REQUIRE(x && log_prob && lse_post && lse_prior);
 #define CALL(CC) \
-  launch_logprob_fwd<CC>(d, x, log_prob, lse_post, lse_prior, (hipStream_t)stream)
+  launch_logprob_fwd<CC>(d, x, log_prob, lse_post, lse_prior, nullptr, (hipStream_t)stream)
+  SCAE_DISPATCH_C(d->C, CALL)
+#undef CALL
+}
+
+extern "C" int scae_render_gmm_logprob_tiles(const scae_decoder_desc *d) {
+  if (check_desc(d)) return 0;
+  return lp_tiling(d).tiles;
+}
+
+extern "C" int scae_render_gmm_logprob_sums_fwd_f32(const scae_decoder_desc *d, const float *x,
+                                                    float *tile_sums, float *lse_post,
+                                                    float *lse_prior, void *stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  SCAE_REQUIRE(x && tile_sums && lse_post && lse_prior);
+#define CALL(CC) \
+  launch_logprob_fwd<CC>(d, x, nullptr, lse_post, lse_prior, tile_sums, (hipStream_t)stream)
+  SCAE_DISPATCH_C(d->C, CALL)
+#undef CALL
+}
+
+extern "C" int scae_render_gmm_sums_bwd_f32(const scae_decoder_desc *d, const float *x,
+                                            const float *lse_post, const float *lse_prior,
+                                            const float *g_tile_sums, float *g_templates,
+                                            float *g_alpha_partial, float *g_pose,
+                                            float *g_presence, float *g_bg_image,
+                                            float *g_scalar_partial, void *stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  SCAE_REQUIRE(g_templates && g_pose && g_scalar_partial && x && lse_post && lse_prior &&
+               g_tile_sums);
+  if (d->templates_alpha) SCAE_REQUIRE(g_alpha_partial);
+#define CALL(CC)                                                                          \
+  launch_bwd<CC>(d, x, lse_post, lse_prior, nullptr, nullptr, nullptr, g_templates,       \
+                 g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,       \
+                 g_tile_sums, (hipStream_t)stream)
   SCAE_DISPATCH_C(d->C, CALL)
 #undef CALL
 }
@@ -884,7 +944,7 @@ extern "C" int scae_render_gmm_bwd_f32(const scae_decoder_desc *d, const float *
 #define CALL(CC)                                                                       \
   launch_bwd<CC>(d, x, lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,        \
                  g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,    \
-                 (hipStream_t)stream)
+                 nullptr, (hipStream_t)stream)
   SCAE_DISPATCH_C(d->C, CALL)
 #undef CALL
 }

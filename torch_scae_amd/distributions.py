@@ -68,6 +68,14 @@ class GaussianMixture:
                               x.reshape(self._out_shape5()))
         return lp.view(self._out_shape())
 
+    def log_prob_tile_sums(self, x):
+        """Partial sums (B, tiles) of ``log_prob(x)`` whose total is
+        sum_{b,c,h,w} log_prob -- all the training loss needs -- or None when
+        the mixture was not built from compact decoder inputs."""
+        if self._decoder_inputs is None or x.requires_grad:
+            return None
+        return ops.render_gmm_log_prob_sums(self._decoder_inputs, x)
+
     def mode(self, straight_through_gradient=False, maximum=False):
         """distributions.py:50-77: value of the component with the largest
         mixing log-prob (``maximum``: plus its density at its own mean)."""

@@ -16,7 +16,7 @@ from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "conv_stack", "conv_stack_supported",
-           "render_templates", "render_gmm_log_prob",
+           "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
 
@@ -874,60 +874,89 @@ def loss_tail_supported(B, O, n_classes):
 
 class _LossTail(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lpp, posterior, caps_presence, cls_w, cls_b, label, cfg):
-        _need_hip(lpp, posterior, caps_presence, cls_w, cls_b)
+    def forward(ctx, lpp, posterior, caps_presence, cls_w, cls_b, label,
+                rec_sums, reg, cfg):
+        _need_hip(lpp, posterior, caps_presence, cls_w, cls_b, rec_sums, reg)
         lpp, posterior, caps_presence = _c(lpp), _c(posterior), _c(caps_presence)
         cls_w, cls_b, label = _c(cls_w), _c(cls_b), _c(label)
+        rec_sums, reg = _c(rec_sums), _c(reg)
         B, O1, M = posterior.shape
         O = O1 - 1
         ncls = 0 if cls_w is None else cls_w.shape[0]
         (n_classes_cfg, prior_type, post_type, sparsity_on, weights,
-         within_const) = cfg
+         within_const, w_reg) = cfg
         w5 = (ctypes.c_float * 5)(*weights)
         ints = (B, O, M, ncls, int(n_classes_cfg or 0), prior_type, post_type,
                 int(sparsity_on))
-        out = torch.empty(8, device=lpp.device, dtype=lpp.dtype)
+        out = torch.empty(12, device=lpp.device, dtype=lpp.dtype)
         wc = float("nan") if within_const is None else float(within_const)
         lab = None if label is None else ctypes.c_void_p(label.data_ptr())
+        ex = _lib.LossExtras()
+        if rec_sums is not None:
+            ex.rec_sums, ex.n_rec = rec_sums.data_ptr(), rec_sums.numel()
+        if reg is not None:
+            ex.reg, ex.w_reg = reg.data_ptr(), float(w_reg)
         _lib.call("scae_loss_tail_fwd_f32", _p(lpp), _p(posterior),
-                  _p(caps_presence), _p(cls_w), _p(cls_b), lab, _p(out), *ints,
-                  w5, wc, _stream(lpp))
+                  _p(caps_presence), _p(cls_w), _p(cls_b), lab, ctypes.byref(ex),
+                  _p(out), *ints, w5, wc, _stream(lpp))
         ctx.save_for_backward(lpp, posterior, caps_presence,
                               *([cls_w, cls_b, label] if label is not None
-                                else []))
-        ctx.has_label = label is not None
-        ctx.call = (ints, tuple(weights), wc)
+                                else []),
+                              *([rec_sums] if rec_sums is not None else []),
+                              *([reg] if reg is not None else []))
+        ctx.has = (label is not None, rec_sums is not None, reg is not None)
+        ctx.call = (ints, tuple(weights), wc, float(w_reg))
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        lpp, posterior, cp = ctx.saved_tensors[:3]
-        cls_w = cls_b = label = None
-        if ctx.has_label:
-            cls_w, cls_b, label = ctx.saved_tensors[3:6]
-        ints, weights, wc = ctx.call
+        saved = list(ctx.saved_tensors)
+        lpp, posterior, cp = saved[:3]
+        rest = saved[3:]
+        has_label, has_rec, has_reg = ctx.has
+        cls_w = cls_b = label = rec_sums = reg = None
+        if has_label:
+            cls_w, cls_b, label = rest[:3]
+            rest = rest[3:]
+        if has_rec:
+            rec_sums, rest = rest[0], rest[1:]
+        if has_reg:
+            reg = rest[0]
+        ints, weights, wc, w_reg = ctx.call
         g_lpp, g_post, g_cp = (torch.empty_like(t) for t in (lpp, posterior, cp))
         g_w = torch.empty_like(cls_w) if cls_w is not None else None
         g_b = torch.empty_like(cls_b) if cls_b is not None else None
+        g_rec = torch.empty_like(rec_sums) if has_rec else None
+        g_reg = torch.empty_like(reg) if has_reg else None
+        ex = _lib.LossExtras()
+        if has_rec:
+            ex.rec_sums, ex.n_rec = rec_sums.data_ptr(), rec_sums.numel()
+            ex.g_rec_sums = g_rec.data_ptr()
+        if has_reg:
+            ex.reg, ex.w_reg, ex.g_reg = reg.data_ptr(), w_reg, g_reg.data_ptr()
         w5 = (ctypes.c_float * 5)(*weights)
         lab = None if label is None else ctypes.c_void_p(label.data_ptr())
         _lib.call("scae_loss_tail_bwd_f32", _p(lpp), _p(posterior), _p(cp),
-                  _p(cls_w), _p(cls_b), lab, _p(gout.contiguous()), _p(g_lpp),
-                  _p(g_post), _p(g_cp), _p(g_w), _p(g_b), *ints, w5, wc,
-                  _stream(lpp))
-        return g_lpp, g_post, g_cp, g_w, g_b, None, None
+                  _p(cls_w), _p(cls_b), lab, ctypes.byref(ex),
+                  _p(gout.contiguous()), _p(g_lpp), _p(g_post), _p(g_cp),
+                  _p(g_w), _p(g_b), *ints, w5, wc, _stream(lpp))
+        return g_lpp, g_post, g_cp, g_w, g_b, None, g_rec, g_reg, None
 
 
 def loss_tail(lpp, posterior, caps_presence, cls_w, cls_b, label, n_classes,
-              prior_type, post_type, sparsity_on, weights, within_const=None):
-    """-> tensor (8): [tail loss, log_prob, prior_within, prior_between,
-    posterior_within, posterior_between, prior_cls_xe, posterior_cls_xe]."""
+              prior_type, post_type, sparsity_on, weights, within_const=None,
+              rec_sums=None, reg=None, w_reg=0.):
+    """-> tensor (12): [loss, log_prob, prior_within, prior_between,
+    posterior_within, posterior_between, prior_cls_xe, posterior_cls_xe,
+    rec_ll, -rec_ll, -log_prob, reg]; loss also carries -rec_ll (from K1's
+    tile sums ``rec_sums``) and w_reg * reg when those are given."""
     if label is None:
         cls_w = cls_b = None
     cfg = (n_classes, _SPARSITY_TYPES[prior_type], _SPARSITY_TYPES[post_type],
-           bool(sparsity_on), [float(w) for w in weights], within_const)
+           bool(sparsity_on), [float(w) for w in weights], within_const,
+           float(w_reg))
     return _LossTail.apply(lpp, posterior, caps_presence, cls_w, cls_b, label,
-                           cfg)
+                           rec_sums, reg, cfg)
 
 
 # ----------------------------------------------------------------------------
@@ -961,7 +990,7 @@ def _make_desc(tensors, output_size):
 
 
 def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
-                      g_lp, g_tt, g_ml):
+                      g_lp, g_tt, g_ml, g_tile=None):
     (templates, alpha, pose, presence, bg_image, bg_value, bg_ml, temp,
      out_scale) = ctx_tensors
     d, (B, M, C, th, tw, H, W) = _make_desc(ctx_tensors, output_size)
@@ -973,10 +1002,16 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
     g_presence = torch.empty_like(presence) if presence is not None else None
     g_bg_image = torch.empty_like(bg_image) if bg_image is not None else None
     g_scal = torch.empty(B, M + 1, 4, device=dev, dtype=dt)
-    _lib.call("scae_render_gmm_bwd_f32", ctypes.byref(d), _p(x), _p(lse_post),
-              _p(lse_prior), _p(g_lp), _p(g_tt), _p(g_ml), _p(g_templates),
-              _p(g_alpha_p), _p(g_pose), _p(g_presence), _p(g_bg_image),
-              _p(g_scal), _stream(templates))
+    if g_tile is not None:
+        _lib.call("scae_render_gmm_sums_bwd_f32", ctypes.byref(d), _p(x),
+                  _p(lse_post), _p(lse_prior), _p(g_tile), _p(g_templates),
+                  _p(g_alpha_p), _p(g_pose), _p(g_presence), _p(g_bg_image),
+                  _p(g_scal), _stream(templates))
+    else:
+        _lib.call("scae_render_gmm_bwd_f32", ctypes.byref(d), _p(x),
+                  _p(lse_post), _p(lse_prior), _p(g_lp), _p(g_tt), _p(g_ml),
+                  _p(g_templates), _p(g_alpha_p), _p(g_pose), _p(g_presence),
+                  _p(g_bg_image), _p(g_scal), _stream(templates))
     gs = g_scal.sum((0, 1))
     return (g_templates,
             None if alpha is None else g_alpha_p.sum(0).view_as(alpha),
@@ -1065,6 +1100,58 @@ class _RenderGmmLogProb(torch.autograd.Function):
         # the reconstruction target gets no gradient on this path (the
         # reference feeds it the input image, which never requires grad)
         return (None, None, *grads)
+
+
+class _RenderGmmLogProbSums(torch.autograd.Function):
+    """fused path for the training loss: per (image, pixel tile) sums of
+    log_prob(x) instead of the per-pixel map -> (B, tiles)."""
+
+    @staticmethod
+    def forward(ctx, output_size, x, *tensors):
+        t = _prep_decoder(tensors)
+        _need_hip(x)
+        x = x.detach().contiguous()
+        d, (B, M, C, th, tw, H, W) = _make_desc(t, output_size)
+        dev, dt = t[0].device, t[0].dtype
+        Cm = 1 if t[1] is not None else C
+        tiles = _lib.load().scae_render_gmm_logprob_tiles(ctypes.byref(d))
+        sums = torch.empty(B, tiles, device=dev, dtype=dt)
+        lse_post = torch.empty(B, C, H, W, device=dev, dtype=dt)
+        lse_prior = torch.empty(B, Cm, H, W, device=dev, dtype=dt)
+        _lib.call("scae_render_gmm_logprob_sums_fwd_f32", ctypes.byref(d),
+                  _p(x), _p(sums), _p(lse_post), _p(lse_prior), _stream(x))
+        ctx.save_for_backward(x, lse_post, lse_prior,
+                              *[v for v in t if v is not None])
+        ctx.present = [v is not None for v in t]
+        ctx.output_size = output_size
+        ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
+        return sums
+
+    @staticmethod
+    def backward(ctx, g_sums):
+        x, lse_post, lse_prior = ctx.saved_tensors[:3]
+        it = iter(ctx.saved_tensors[3:])
+        t = [next(it) if p else None for p in ctx.present]
+        grads = list(_decoder_backward(t, ctx.output_size, ctx.needs_input_grad,
+                                       x, lse_post, lse_prior, None, None, None,
+                                       g_tile=g_sums.contiguous()))
+        if grads[1] is not None:
+            grads[1] = grads[1].view(ctx.alpha_shape)
+        return (None, None, *grads)
+
+
+def render_gmm_log_prob_sums(inputs: "DecoderInputs", x):
+    """(B, tiles) partial sums of the mixture log-likelihood of ``x``; their
+    total is sum_{b,c,h,w} log_prob."""
+    B, M, C = inputs.templates.shape[:3]
+    if tuple(x.shape) != (B, C, *inputs.output_size):
+        raise ValueError(f"log_prob target must be {(B, C, *inputs.output_size)}"
+                         f", got {tuple(x.shape)}")
+    if x.requires_grad:
+        raise ScaeHipError("fused log_prob does not differentiate w.r.t. its "
+                           "target; use the materialised mixture for that")
+    return _RenderGmmLogProbSums.apply(inputs.output_size, x,
+                                       *inputs.tensors())
 
 
 def render_templates(inputs: DecoderInputs):

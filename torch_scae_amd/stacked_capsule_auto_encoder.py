@@ -146,6 +146,51 @@ class SCAE(nn.Module):
     def loss(self, res, reconstruction_target, label=None):
         """-> (loss, log dict)   (stacked_capsule_auto_encoder.py:217-287)."""
         log = dict()
+        sparsity_on = (self.prior_within_example_sparsity_weight > 0
+                       or self.prior_between_example_sparsity_weight > 0)
+        fused_tail = self._fused_tail_ok(res, label)
+
+        def tail(rec_sums=None, reg=None):
+            # one kernel for the capsule-likelihood, sparsity and
+            # classification terms (and one for their backward)
+            return ops.loss_tail(
+                res._log_prob_per_point, res._posterior_full,
+                res.caps_presence,
+                self.prior_classifier[0].weight if label is not None else None,
+                self.prior_classifier[0].bias if label is not None else None,
+                label, self.n_classes, self.prior_sparsity_loss_type,
+                self.posterior_sparsity_loss_type, sparsity_on,
+                [self.caps_ll_weight,
+                 self.prior_within_example_sparsity_weight,
+                 self.prior_between_example_sparsity_weight,
+                 self.posterior_within_example_sparsity_weight,
+                 self.posterior_between_example_sparsity_weight],
+                self.prior_within_example_constant, rec_sums=rec_sums, reg=reg,
+                w_reg=self.cpr_dynamic_reg_weight)
+
+        def tail_log(t):
+            log.update(log_prob_loss=t[10])
+            if sparsity_on:
+                log.update(prior_within_sparsity_loss=t[2],
+                           prior_between_sparsity_loss=t[3],
+                           posterior_within_sparsity_loss=t[4],
+                           posterior_between_sparsity_loss=t[5])
+            log.update(cpr_dynamic_reg_loss=res.cpr_dynamic_reg_loss)
+            if label is not None:
+                log.update(prior_cls_xe=t[6], posterior_cls_xe=t[7])
+
+        rec_sums = None
+        if fused_tail and self.recon_mse_weight <= 0 and \
+                self.part_caps_sparsity_weight <= 0:
+            rec_sums = res.rec.pdf.log_prob_tile_sums(reconstruction_target)
+        if rec_sums is not None:
+            # the whole training scalar from the tail kernel: K1 hands it
+            # per-tile sums of the reconstruction log-likelihood
+            t = tail(rec_sums, res.cpr_dynamic_reg_loss.reshape(1))
+            log.update(rec_ll_loss=t[9])
+            tail_log(t)
+            return t[0], log
+
         rec_ll_per_pixel = res.rec.pdf.log_prob(reconstruction_target)
         rec_ll = rec_ll_per_pixel.flatten(1).sum(-1).mean()
         loss = -rec_ll
@@ -162,35 +207,11 @@ class SCAE(nn.Module):
             loss = loss + self.part_caps_sparsity_weight * part_caps_l1
             log.update(part_caps_loss=part_caps_l1)
 
-        sparsity_on = (self.prior_within_example_sparsity_weight > 0
-                       or self.prior_between_example_sparsity_weight > 0)
-        if self._fused_tail_ok(res, label):
-            # one kernel for the capsule-likelihood, sparsity and
-            # classification terms (and one for their backward)
-            t = ops.loss_tail(
-                res._log_prob_per_point, res._posterior_full,
-                res.caps_presence,
-                self.prior_classifier[0].weight if label is not None else None,
-                self.prior_classifier[0].bias if label is not None else None,
-                label, self.n_classes, self.prior_sparsity_loss_type,
-                self.posterior_sparsity_loss_type, sparsity_on,
-                [self.caps_ll_weight,
-                 self.prior_within_example_sparsity_weight,
-                 self.prior_between_example_sparsity_weight,
-                 self.posterior_within_example_sparsity_weight,
-                 self.posterior_between_example_sparsity_weight],
-                self.prior_within_example_constant)
+        if fused_tail:
+            t = tail()
             loss = loss + t[0]
-            log.update(log_prob_loss=-t[1])
-            if sparsity_on:
-                log.update(prior_within_sparsity_loss=t[2],
-                           prior_between_sparsity_loss=t[3],
-                           posterior_within_sparsity_loss=t[4],
-                           posterior_between_sparsity_loss=t[5])
             loss = loss + self.cpr_dynamic_reg_weight * res.cpr_dynamic_reg_loss
-            log.update(cpr_dynamic_reg_loss=res.cpr_dynamic_reg_loss)
-            if label is not None:
-                log.update(prior_cls_xe=t[6], posterior_cls_xe=t[7])
+            tail_log(t)
             return loss, log
 
         loss = loss - self.caps_ll_weight * res.log_prob
