@@ -449,6 +449,64 @@ def test_image_decoder_vs_oracle_full_size(B, M, C, HW, ts, alpha, scale):
                      5e-4, "pgrad " + k)
 
 
+@pytest.mark.parametrize("B,M,C,HW,ts,alpha", [
+    (128, 24, 1, (40, 40), (11, 11), True),
+    (4, 5, 3, (17, 23), (7, 9), False),
+])
+def test_log_prob_tile_sums_match_per_pixel_path(B, M, C, HW, ts, alpha):
+    """K1's tile-sum variant (training loss) against its per-pixel variant:
+    same total, and with non-uniform tile weights the same gradients."""
+    from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
+    torch.manual_seed(1)
+    g = torch.Generator().manual_seed(9)
+    dec = TemplateBasedImageDecoder(M, ts, HW, use_alpha_channel=alpha).cuda()
+    templates = torch.rand(B, M, C, *ts, generator=g)
+    pose = torch.randn(B, M, 6, generator=g) * 0.5
+    pose[:, :, 0] += 1.0
+    pose[:, :, 4] += 1.0
+    presence = torch.rand(B, M, generator=g)
+    x = torch.rand(B, C, *HW, generator=g).cuda()
+
+    def run(sums):
+        ins = [leaf(t) for t in (templates, pose, presence)]
+        for p in dec.parameters():
+            p.grad = None
+        pdf = dec(*ins).pdf
+        if sums:
+            out = pdf.log_prob_tile_sums(x)               # (B, tiles)
+            tiles = out.shape[1]
+            w = torch.linspace(0.5, 1.5, B * tiles, device="cuda").view(B, tiles)
+            (out * w).sum().backward()
+            return out, w, [t.grad for t in ins] + [p.grad for p in dec.parameters()]
+        return pdf.log_prob(x), None, ins
+
+    sums, w, g_sums = run(True)
+    lp, _, ins = run(False)
+    HWn = HW[0] * HW[1]
+    tiles = sums.shape[1]
+    assert_close(sums.sum(1), lp.flatten(1).sum(1), 1e-3, 1e-5, "image totals")
+    # recover the tiling from the ABI and replay the same weights per pixel
+    per_tile = None
+    for cand in range(1, HWn + 1):
+        if -(-HWn // cand) == tiles:
+            t0 = lp.flatten(2)[:, :, :cand].sum((1, 2))
+            if torch.allclose(t0, sums[:, 0], rtol=1e-4, atol=1e-3):
+                per_tile = cand
+                break
+    assert per_tile is not None, "tile size not recoverable"
+    wpix = w.repeat_interleave(per_tile, 1)[:, :HWn].view(B, 1, *HW)
+    for p in dec.parameters():
+        p.grad = None
+    (lp * wpix).sum().backward()
+    g_pix = [t.grad for t in ins] + [p.grad for p in dec.parameters()]
+    for a, b in zip(g_sums, g_pix):
+        if b is None:
+            assert a is None
+            continue
+        assert_close(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-4,
+                     "grad via tile sums")
+
+
 def test_image_decoder_error_behaviour():
     from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
     dec = TemplateBasedImageDecoder(2, (5, 5), (8, 8), use_alpha_channel=True,
