@@ -199,9 +199,9 @@ int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
  *   Activations NHWC: in (B,IH,IW,Cin) -> out (B,OH,OW,Cout), OH=(IH-3)/s+1.
  *   relayout: w (Cout,Cin,3,3) -> wf (Cout,9,Cin), wd (Cin,9,Cout).
  *   first_*: direct kernels for the image layer (NCHW image, small Cin; w in
- *     the reference layout, Cout % 64 == 0); first_wgrad writes partial sums
- *     (scae_conv3x3_first_wgrad_rows(B,Cout), Cout, Cin*9+1) (last column:
- *     bias) for the caller to sum over the rows.
+ *     the reference layout, Cout % 64 == 0); first_wgrad writes
+ *     scae_conv3x3_first_wgrad_rows(B,Cout) partial rows, each
+ *     [dW (Cout,Cin*9) | db (Cout)], for the caller to sum over the rows.
  *   fwd:   out = relu(conv(in, wf) + bias)        Cin, Cout % 64 == 0, s <= 2
  *   dgrad: din = conv^T(dpre, wd), zeroed where gate <= 0 (gate (B,IH,IW,Cin)
  *          = the producing layer's ReLU output, nullable)
@@ -293,6 +293,20 @@ int scae_template_color_bwd_f32(const float *logits, const float *feature, const
                                 const float *g_raw, float *g_logits, float *g_feature,
                                 float *partial, int B, int M, int C, int hw, int F, int H1,
                                 int template_nonlin, int color_nonlin, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Column sums of a (rows, cols) matrix of partial gradients, written to up to
+ * 8 contiguous destinations: column j in [begin, end) of segment i goes to
+ * segments[i].dst[j - begin] (columns in no segment are dropped).  `segments`
+ * is a HOST array.  Replaces `partial.sum(0)` + per-parameter slice copies
+ * behind the partial-gradient outputs of K1, K2b, K2c, K3, K8, K9 and K10.
+ * ---------------------------------------------------------------------- */
+typedef struct scae_sum_segment {
+  float *dst;
+  int64_t begin, end;
+} scae_sum_segment;
+int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
+                      const scae_sum_segment *segments, int n_segments, void *stream);
 
 /* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225

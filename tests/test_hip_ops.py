@@ -997,3 +997,25 @@ def test_colored_templates_vs_oracle(tnl, cnl, C, F, ts):
     for name, p in tg.named_parameters():
         assert_close(p.grad, P["tg." + name].grad, rtol=1e-4, atol=2e-5,
                      what="d_" + name)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 5), (16, 300), (128, 14848),
+                                       (1024, 1280), (3, 70000)])
+def test_sum_rows_scatter(rows, cols):
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    src = torch.randn(rows, cols, generator=g)
+    want = src.double().sum(0)
+    cuts = sorted({0, cols // 7, cols // 3, cols // 2, cols - 1, cols})
+    shapes = [(b - a,) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    outs = ops._sum_rows(src.cuda(), shapes)
+    pos = 0
+    for o in outs:
+        assert_close(o, want[pos:pos + o.numel()].float(), 1e-5 * rows ** 0.5,
+                     1e-5, "segment")
+        pos += o.numel()
+    # explicit starts: a window in the middle, the rest dropped
+    if cols >= 8:
+        (mid,) = ops._sum_rows(src.cuda(), [(2, 2)], starts=[cols // 2])
+        assert_close(mid.flatten(), want[cols // 2:cols // 2 + 4].float(),
+                     1e-5 * rows ** 0.5, 1e-5, "window")

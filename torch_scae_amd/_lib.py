@@ -25,6 +25,11 @@ class DecoderDesc(Structure):
                 ("tw", c_int), ("H", c_int), ("W", c_int)]
 
 
+class SumSegment(Structure):
+    """struct scae_sum_segment"""
+    _fields_ = [("dst", P), ("begin", c_int64), ("end", c_int64)]
+
+
 class LossExtras(Structure):
     """struct scae_loss_extras"""
     _fields_ = [("rec_sums", P), ("n_rec", c_int), ("reg", P),
@@ -92,6 +97,7 @@ SIGNATURES = {
     "scae_template_color_supported": [c_int] * 4,
     "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],
     "scae_template_color_bwd_f32": [P] * 12 + [c_int] * 8 + [P],
+    "scae_sum_rows_f32": [P, c_int64, c_int64, POINTER(SumSegment), c_int, P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8

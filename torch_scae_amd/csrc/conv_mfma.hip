@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__rest
   }
 }
 
-// weight/bias gradient partials: partial[(n*slices + slice)*parts + part][co][CIN*9 + 1]
-// (last column: bias); the caller sums the rows.
+// weight/bias gradient partials: partial[(n*slices + slice)*parts + part] = one row
+// [dW (Cout, CIN*9) | db (Cout)]; the caller sums the rows.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__restrict__ dpre,
                                                                const float *__restrict__ img,
@@ -318,9 +318,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
           acc[ci * 9 + t] = fmaf(d, src[(ci * g.IH + t / 3) * g.IW + t % 3], acc[ci * 9 + t]);
       acc[K1 - 1] += d;
     }
-    float *dst = partial + (((size_t)blockIdx.x * f.parts + part) * g.Cout + co) * K1;
+    // row layout [dW (Cout x CIN*9) | db (Cout)]
+    float *row = partial + ((size_t)blockIdx.x * f.parts + part) * g.Cout * K1;
 #pragma unroll
-    for (int k = 0; k < K1; ++k) dst[k] = acc[k];
+    for (int k = 0; k < K1 - 1; ++k) row[(size_t)co * (K1 - 1) + k] = acc[k];
+    row[(size_t)g.Cout * (K1 - 1) + co] = acc[K1 - 1];
   }
 }
 

@@ -48,6 +48,30 @@ def _detached(t):
     return None if t is None else t.detach()
 
 
+def _sum_rows(partial, shapes, starts=None):
+    """Column sums of ``partial`` (rows, cols) scattered into fresh contiguous
+    tensors of the given shapes; consecutive column ranges unless ``starts``
+    gives each one's first column.  One launch (scae_sum_rows_f32)."""
+    rows, cols = partial.shape
+    outs, segs = [], (_lib.SumSegment * len(shapes))()
+    pos = 0
+    for i, shape in enumerate(shapes):
+        o = torch.empty(shape, device=partial.device, dtype=partial.dtype)
+        if starts is not None:
+            pos = starts[i]
+        segs[i].dst, segs[i].begin, segs[i].end = o.data_ptr(), pos, \
+            pos + o.numel()
+        pos += o.numel()
+        outs.append(o)
+    for k in range(0, len(shapes), 8):
+        n = min(8, len(shapes) - k)
+        _lib.call("scae_sum_rows_f32", _p(partial), rows, cols,
+                  ctypes.cast(ctypes.byref(segs, k * ctypes.sizeof(
+                      _lib.SumSegment)), ctypes.POINTER(_lib.SumSegment)), n,
+                  _stream(partial))
+    return outs
+
+
 # ----------------------------------------------------------------------------
 # K5 geometric_transform (cv_ops.py:20-76)
 # ----------------------------------------------------------------------------
@@ -187,7 +211,7 @@ class _SetEncoder(torch.autograd.Function):
         _lib.call("scae_set_encoder_bwd_f32", len(segs), ptrs, widths, rs, bs,
                   gptrs, _p(presence), _p(packed), _p(hsave), _p(gz),
                   _p(partial), B, N, D, Din, Dout, L, ln, _stream(packed))
-        return (None, partial.sum(0), None, *gsegs)
+        return (None, _sum_rows(partial, [packed.shape])[0], None, *gsegs)
 
 
 def set_encoder(segments, presence, packed_params, dim_hidden, dim_out,
@@ -238,11 +262,9 @@ class _SeedAttention(torch.autograd.Function):
         _lib.call("scae_seed_attention_bwd_f32", _p(h), _p(q), _p(wk), _p(bk),
                   _p(wv), _p(bv), _p(presence), _p(gout.contiguous()), _p(gh),
                   _p(partial), B, N, O, D, C, _stream(h))
-        g = partial.sum(0)
-        o1, o2, o3, o4 = O * C, O * C + C * D, O * C + C * D + C, \
-            O * C + 2 * C * D + C
-        return (gh, g[:o1].view(O, C), g[o1:o2].view(C, D), g[o2:o3],
-                g[o3:o4].view(C, D), g[o4:], None)
+        gq, gwk, gbk, gwv, gbv = _sum_rows(
+            partial, [(O, C), (C, D), (C,), (C, D), (C,)])
+        return gh, gq, gwk, gbk, gwv, gbv, None
 
 
 def seed_attention(h, q, wk, bk, wv, bv, presence=None):
@@ -408,9 +430,8 @@ class _ConvStack(torch.autograd.Function):
         partial = new(_lib.load().scae_conv3x3_first_wgrad_rows(B, c1), c1, k1)
         _lib.call("scae_conv3x3_first_wgrad_f32", _p(dpre), _p(image),
                   _p(partial), B, C0, H, W, c1, strides[0], st)
-        g1 = partial.sum(0)
-        gws[0] = g1[:, :k1 - 1].reshape(c1, C0, 3, 3)
-        gbs[0] = g1[:, k1 - 1]
+        gws[0], gbs[0] = _sum_rows(partial.view(partial.shape[0], -1),
+                                   [(c1, C0, 3, 3), (c1,)])
         return (None, None, *gws, *gbs)
 
 
@@ -451,11 +472,11 @@ def _conv1x1_bwd(x, weight, dy):
     part = torch.empty(S, slab, device=x.device, dtype=x.dtype)
     _gemm(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP, kper * AP, False,
           C, kper * C, C, slab, asum=_off(part, AP * C), asum_b=slab, ref=x)
-    gsum = part.sum(0)
+    gw, gb = _sum_rows(part, [(AP, C), (AP,)])
     dx = torch.empty_like(x)
     _gemm(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP, 0, False, C,
           0, C, 0, ref=x)
-    return dx, gsum[:AP * C].view(AP, C), gsum[AP * C:]
+    return dx, gw, gb
 
 
 class _AttentionConvPool(torch.autograd.Function):
@@ -596,9 +617,9 @@ class _ColoredTemplates(torch.autograd.Function):
                   _p(g_templates.contiguous()), _p(_c(g_raw)), _p(g_logits),
                   _p(g_feature), _p(partial), B, M, C, th * tw, F, H1,
                   *ctx.codes, _stream(logits))
-        g = partial.sum(0)
-        return (g_logits, g_feature, g[:n1].view(H1, F), g[n1:n2],
-                g[n2:n3].view(C, H1), g[n3:], None, None)
+        gw1, gb1, gw2, gb2 = _sum_rows(partial,
+                                       [(H1, F), (H1,), (C, H1), (C,)])
+        return g_logits, g_feature, gw1, gb1, gw2, gb2, None, None
 
 
 def colored_templates(template_logits, feature, w1, b1, w2, b2,
@@ -773,8 +794,11 @@ class _CapsuleVotes(torch.autograd.Function):
         _lib.call("scae_capsule_votes_bwd_f32", *[_p(t) for t in args],
                   ctx.noise_scale, *[_p(g) for g in grads], _p(gall), _p(gin),
                   *ctx.flags, _stream(all_param))
-        gsum = gall.sum(0)                     # (O, A): bias gradients
-        g_static = gin.sum(0).view_as(args[1])
+        # bias gradients: batch sums of column blocks of gall (B, O*A); each
+        # capsule's block lands in its row of the (.., O, ..) parameter
+        A = all_param.shape[2]
+        (g_static,) = _sum_rows(gin.view(B, -1), [args[1].shape])
+        gsum = _sum_rows(gall.view(B, O * A), [(O, A)])[0]
         g_cvr = gsum[:, 6 * V:6 * V + 6].reshape(args[2].shape)
         g_caps = gsum[:, 6 * V + 6].reshape(args[3].shape)
         g_vote = gsum[:, 6 * V + 7:7 * V + 7].reshape(args[4].shape)
@@ -1014,7 +1038,8 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
                   _p(g_bg_image), _p(g_scal), _stream(templates))
     gs = g_scal.sum((0, 1))
     return (g_templates,
-            None if alpha is None else g_alpha_p.sum(0).view_as(alpha),
+            None if alpha is None else _sum_rows(g_alpha_p.view(B, -1),
+                                                 [alpha.shape])[0],
             g_pose, g_presence, g_bg_image,
             None if bg_value is None else gs[0:1].view_as(bg_value),
             None if bg_ml is None else gs[1:2].view_as(bg_ml),
