@@ -322,7 +322,8 @@ int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
  *     scale (B,O,V) (:225), vote_presence (B,O,V) (:217-219),
  *     logit_caps (B,O), logit_vote (B,O,V) (noised logits, :211-212),
  *     reg_partial (B,O): per-(b,o) sum of cpr_dynamic^2 (caller: sum/2/B,
- *     :170).
+ *     :170); caps_presence (B,O) = max_v vote_presence with its first
+ *     maximiser caps_arg (B,O) int32 (object_decoder.py:411; both nullable).
  * ---------------------------------------------------------------------- */
 int scae_capsule_votes_fwd_f32(const float *all_param, const float *cpr_static,
                                const float *bias_cvr, const float *bias_caps,
@@ -330,13 +331,14 @@ int scae_capsule_votes_fwd_f32(const float *all_param, const float *cpr_static,
                                const float *noise_caps, const float *noise_vote,
                                float noise_scale, float *vote, float *scale,
                                float *vote_presence, float *logit_caps,
-                               float *logit_vote, float *reg_partial, int B,
-                               int O, int V, int similarity,
-                               int learn_vote_scale, int allow_deformations,
-                               void *stream);
+                               float *logit_vote, float *reg_partial,
+                               float *caps_presence, int *caps_arg, int B, int O, int V,
+                               int similarity, int learn_vote_scale,
+                               int allow_deformations, void *stream);
 /* incoming grads (all nullable = zero): gvote (B,O,V,6) gscale (B,O,V)
  * gvote_presence (B,O,V) glogit_caps (B,O) glogit_vote (B,O,V);
- * greg: d loss / d cpr_dynamic_reg_loss, a DEVICE scalar, nullable.
+ * greg: d loss / d cpr_dynamic_reg_loss, a DEVICE scalar, nullable;
+ * gcaps_presence (B,O) nullable, routed to vote caps_arg of each capsule.
  * outputs: gall_param (B,O,A); gcpr_in (B,O,V,6) = grad wrt
  * (cpr_dynamic + cpr_static) (caller sums over B for cpr_static; the bias
  * grads are the batch sums of the matching gall_param slices). */
@@ -346,10 +348,10 @@ int scae_capsule_votes_bwd_f32(const float *all_param, const float *cpr_static,
                                const float *noise_caps, const float *noise_vote,
                                float noise_scale, const float *gvote,
                                const float *gscale, const float *gvote_presence,
-                               const float *glogit_caps,
-                               const float *glogit_vote, const float *greg,
-                               float *gall_param, float *gcpr_in, int B, int O,
-                               int V, int similarity, int learn_vote_scale,
+                               const float *glogit_caps, const float *glogit_vote,
+                               const float *greg, const float *gcaps_presence,
+                               const int *caps_arg, float *gall_param, float *gcpr_in,
+                               int B, int O, int V, int similarity, int learn_vote_scale,
                                int allow_deformations, void *stream);
 
 /* ------------------------------------------------------------------------
@@ -386,6 +388,20 @@ int scae_capsule_likelihood_bwd_f32(
     const float *g_mixing_logit, float *gvote, float *gscale,
     float *gvote_presence, float *gx, float *gpresence, float *gdummy_partial,
     int B, int O, int M, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Class probabilities of SCAE.forward
+ *     replaces stacked_capsule_auto_encoder.py:205-212:
+ *     prior_prob (B,ncls) = softmax(w caps_presence + bias),
+ *     post_prob  (B,ncls) = softmax(w sum_m posterior[:, :O, m] + bias)
+ *     with caps_presence (B,O), posterior (B,O+1,M), w (ncls,O), bias (ncls)
+ *     = prior_classifier.0 (the reference routes both through it).
+ *     Limits: O <= 64, ncls <= 32.
+ * ---------------------------------------------------------------------- */
+int scae_class_probs_supported(int O, int ncls);
+int scae_class_probs_f32(const float *caps_presence, const float *posterior, const float *w,
+                         const float *bias, float *prior_prob, float *post_prob, int B, int O,
+                         int M, int ncls, void *stream);
 
 /* ------------------------------------------------------------------------
  * K6  fused tail of SCAE.loss        replaces stacked_capsule_auto_encoder.py

@@ -1019,3 +1019,29 @@ def test_sum_rows_scatter(rows, cols):
         (mid,) = ops._sum_rows(src.cuda(), [(2, 2)], starts=[cols // 2])
         assert_close(mid.flatten(), want[cols // 2:cols // 2 + 4].float(),
                      1e-5 * rows ** 0.5, 1e-5, "window")
+
+
+def test_class_probs_vs_torch():
+    """stacked_capsule_auto_encoder.py:205-212 in one launch, incl. the
+    classifier gradients of the un-fused loss path."""
+    import torch.nn.functional as F
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, Oc, M, ncls = 37, 24, 24, 10
+    cp = torch.rand(B, Oc, generator=g)
+    post = torch.softmax(torch.randn(B, Oc + 1, M, generator=g), 1)
+    W = torch.randn(ncls, Oc, generator=g) * 0.4
+    bb = torch.randn(ncls, generator=g) * 0.1
+    label = torch.randint(0, ncls, (B,), generator=g)
+    Wr, br = W.clone().requires_grad_(), bb.clone().requires_grad_()
+    p1 = torch.softmax(F.linear(cp, Wr, br), -1)
+    p2 = torch.softmax(F.linear(post[:, :-1].sum(-1), Wr, br), -1)
+    (F.cross_entropy(p1, label) + F.cross_entropy(p2, label)).backward()
+    Wh, bh = leaf(W), leaf(bb)
+    q1, q2 = ops.class_probs(cp.cuda(), post.cuda(), Wh, bh)
+    assert_close(q1, p1, 1e-6, 1e-5, "prior_cls_prob")
+    assert_close(q2, p2, 1e-6, 1e-5, "posterior_cls_prob")
+    (F.cross_entropy(q1, label.cuda()) + F.cross_entropy(q2, label.cuda())) \
+        .backward()
+    assert_close(Wh.grad, Wr.grad, 1e-6, 1e-4, "d_w")
+    assert_close(bh.grad, br.grad, 1e-6, 1e-4, "d_b")

@@ -98,9 +98,11 @@ SIGNATURES = {
     "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],
     "scae_template_color_bwd_f32": [P] * 12 + [c_int] * 8 + [P],
     "scae_sum_rows_f32": [P, c_int64, c_int64, POINTER(SumSegment), c_int, P],
-    "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 6
+    "scae_class_probs_supported": [c_int] * 2,
+    "scae_class_probs_f32": [P] * 6 + [c_int] * 4 + [P],
+    "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 8
                                   + [c_int] * 6 + [P],
-    "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 8
+    "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 10
                                   + [c_int] * 6 + [P],
     "scae_capsule_likelihood_fwd_f32": [P] * 17 + [c_int] * 3 + [P],
     "scae_capsule_likelihood_bwd_f32": [P] * 22 + [c_int] * 3 + [P],

@@ -84,7 +84,8 @@ struct VoteArgs {
 __global__ __launch_bounds__(NT) void votes_fwd_kernel(
     VoteArgs a, float *__restrict__ vote, float *__restrict__ scale,
     float *__restrict__ vote_presence, float *__restrict__ logit_caps,
-    float *__restrict__ logit_vote, float *__restrict__ reg_partial) {
+    float *__restrict__ logit_vote, float *__restrict__ reg_partial,
+    float *__restrict__ caps_presence, int *__restrict__ caps_arg) {
   const int bo = blockIdx.x, o = bo % a.O, V = a.V, lane = threadIdx.x;
   const int A = 8 * V + 7;
   const float *ap = a.all_param + (size_t)bo * A;
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(NT) void votes_fwd_kernel(
   if (lane == 0) logit_caps[bo] = lc;
 
   float reg = 0.f;
+  float best = -INFINITY;  // caps_presence = max_v vote_presence (object_decoder.py:411),
+  int best_v = 0x7fffffff;  // first maximiser
   for (int v = lane; v < V; v += NT) {
     float pr[6];
 #pragma unroll
@@ -124,7 +127,9 @@ __global__ __launch_bounds__(NT) void votes_fwd_kernel(
     float lv = ap[6 * V + 7 + v] + a.bias_vote[o * V + v];
     if (a.noise_vote) lv += (a.noise_vote[(size_t)bo * V + v] - 0.5f) * a.noise_scale;
     logit_vote[(size_t)bo * V + v] = lv;
-    vote_presence[(size_t)bo * V + v] = pc * scae::sigmoidf_(lv);
+    const float vpv = pc * scae::sigmoidf_(lv);
+    vote_presence[(size_t)bo * V + v] = vpv;
+    if (vpv > best) best = vpv, best_v = v;
     float sc = 1.f;
     if (a.learn_vote_scale)
       sc = scae::softplusf_(ap[7 * V + 7 + v] + a.bias_scale[o * V + v] + .5f) + 1e-2f;
@@ -132,13 +137,26 @@ __global__ __launch_bounds__(NT) void votes_fwd_kernel(
   }
   reg = scae::wave_sum(reg);
   if (lane == 0) reg_partial[bo] = reg;
+  if (caps_presence) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(best_v, off, 64);
+      if (ov > best || (ov == best && oi < best_v)) best = ov, best_v = oi;
+    }
+    if (lane == 0) {
+      caps_presence[bo] = best;
+      caps_arg[bo] = best_v;
+    }
+  }
 }
 
 __global__ __launch_bounds__(NT) void votes_bwd_kernel(
     VoteArgs a, const float *__restrict__ gvote, const float *__restrict__ gscale,
     const float *__restrict__ gvp, const float *__restrict__ glc,
     const float *__restrict__ glv, const float *__restrict__ greg,
-    float *__restrict__ gall, float *__restrict__ gcpr_in) {
+    float *__restrict__ gall, float *__restrict__ gcpr_in,
+    const float *__restrict__ g_caps_presence, const int *__restrict__ caps_arg) {
   const int bo = blockIdx.x, o = bo % a.O, V = a.V, lane = threadIdx.x;
   const int A = 8 * V + 7;
   const float *ap = a.all_param + (size_t)bo * A;
@@ -195,7 +213,8 @@ __global__ __launch_bounds__(NT) void votes_bwd_kernel(
     float lv = ap[6 * V + 7 + v] + a.bias_vote[o * V + v];
     if (a.noise_vote) lv += (a.noise_vote[(size_t)bo * V + v] - 0.5f) * a.noise_scale;
     const float pv = scae::sigmoidf_(lv);
-    const float g_vp = gvp ? gvp[(size_t)bo * V + v] : 0.f;
+    float g_vp = gvp ? gvp[(size_t)bo * V + v] : 0.f;
+    if (g_caps_presence && caps_arg[bo] == v) g_vp += g_caps_presence[bo];
     gpc += g_vp * pv;
     float g_lv = g_vp * pc * pv * (1.f - pv);
     if (glv) g_lv += glv[(size_t)bo * V + v];
@@ -234,16 +253,18 @@ extern "C" int scae_capsule_votes_fwd_f32(
     const float *bias_caps, const float *bias_vote, const float *bias_scale,
     const float *noise_caps, const float *noise_vote, float noise_scale, float *vote,
     float *scale, float *vote_presence, float *logit_caps, float *logit_vote,
-    float *reg_partial, int B, int O, int V, int similarity, int learn_vote_scale,
-    int allow_deformations, void *stream) {
+    float *reg_partial, float *caps_presence, int *caps_arg, int B, int O, int V,
+    int similarity, int learn_vote_scale, int allow_deformations, void *stream) {
   VoteArgs a{all_param, cpr_static, bias_cvr, bias_caps, bias_vote, bias_scale,
              noise_caps, noise_vote, noise_scale, B, O, V, similarity, learn_vote_scale,
              allow_deformations};
   int rc = check_votes(a);
   if (rc) return rc;
   SCAE_REQUIRE(vote && scale && vote_presence && logit_caps && logit_vote && reg_partial);
+  SCAE_REQUIRE(!caps_presence == !caps_arg);
   hipLaunchKernelGGL(votes_fwd_kernel, dim3(B * O), dim3(NT), 0, (hipStream_t)stream, a,
-                     vote, scale, vote_presence, logit_caps, logit_vote, reg_partial);
+                     vote, scale, vote_presence, logit_caps, logit_vote, reg_partial,
+                     caps_presence, caps_arg);
   return scae_launch_status();
 }
 
@@ -253,16 +274,17 @@ extern "C" int scae_capsule_votes_bwd_f32(
     const float *noise_caps, const float *noise_vote, float noise_scale,
     const float *gvote, const float *gscale, const float *gvote_presence,
     const float *glogit_caps, const float *glogit_vote, const float *greg,
-    float *gall_param, float *gcpr_in, int B, int O, int V, int similarity,
-    int learn_vote_scale, int allow_deformations, void *stream) {
+    const float *gcaps_presence, const int *caps_arg, float *gall_param, float *gcpr_in,
+    int B, int O, int V, int similarity, int learn_vote_scale, int allow_deformations,
+    void *stream) {
   VoteArgs a{all_param, cpr_static, bias_cvr, bias_caps, bias_vote, bias_scale,
              noise_caps, noise_vote, noise_scale, B, O, V, similarity, learn_vote_scale,
              allow_deformations};
   int rc = check_votes(a);
   if (rc) return rc;
-  SCAE_REQUIRE(gall_param && gcpr_in);
+  SCAE_REQUIRE(gall_param && gcpr_in && (!gcaps_presence || caps_arg));
   hipLaunchKernelGGL(votes_bwd_kernel, dim3(B * O), dim3(NT), 0, (hipStream_t)stream, a,
                      gvote, gscale, gvote_presence, glogit_caps, glogit_vote, greg,
-                     gall_param, gcpr_in);
+                     gall_param, gcpr_in, gcaps_presence, caps_arg);
   return scae_launch_status();
 }

@@ -93,7 +93,7 @@ class CapsuleLayer(nn.Module):
         """feature [B, O, F] -> AttrDict(vote (B,O,V,3,3), scale,
         vote_presence, presence_logit_per_caps, presence_logit_per_vote,
         cpr_dynamic_reg_loss)."""
-        vote6, scale, vote_presence, logit_caps, logit_vote, reg = \
+        vote6, scale, vote_presence, logit_caps, logit_vote, reg, _ = \
             self._votes(feature, parent_transform, parent_presence)
         last_row = vote6.new_tensor([0., 0., 1.]).expand(*vote6.shape[:-1], 3)
         vote = torch.cat([vote6, last_row], -1).view(*vote6.shape[:-1], 3, 3)
@@ -154,14 +154,14 @@ class CapsuleObjectDecoder(nn.Module):
                 part_presence: torch.Tensor = None):
         """obj_encoding [B, O, D], part_pose [B, M, P], part_presence [B, M]
         or None -> AttrDict (object_decoder.py:393-428)."""
-        vote, scale, vote_presence, logit_caps, logit_vote, reg = \
-            self.capsule_layer._votes(obj_encoding)
+        vote, scale, vote_presence, logit_caps, logit_vote, reg, \
+            caps_presence = self.capsule_layer._votes(obj_encoding)
         res = AttrDict(vote=vote,             # (B, O, V, 6): rows 0..1 only
                        scale=scale, vote_presence=vote_presence,
                        presence_logit_per_caps=logit_caps,
                        presence_logit_per_vote=logit_vote,
                        cpr_dynamic_reg_loss=reg)
-        res.caps_presence = res.vote_presence.max(-1)[0]
+        res.caps_presence = caps_presence     # = vote_presence.max(-1)[0]
         likelihood = CapsuleLikelihood(vote=res.vote, scale=res.scale,
                                        vote_presence=res.vote_presence,
                                        dummy_vote=self.dummy_vote)

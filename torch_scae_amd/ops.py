@@ -570,6 +570,56 @@ def attention_conv_pool(x, weight, bias, n_caps):
 
 
 # ----------------------------------------------------------------------------
+# class probabilities of SCAE.forward (stacked_capsule_auto_encoder.py:205-212)
+# ----------------------------------------------------------------------------
+def class_probs_supported(O, ncls):
+    return bool(_lib.load().scae_class_probs_supported(O, ncls))
+
+
+class _ClassProbs(torch.autograd.Function):
+    """(caps_presence, posterior (B,O+1,M)) detached -> softmax(linear(.)) for
+    the prior and the posterior capsule activations, both through the same
+    classifier.  Differentiable w.r.t. the classifier only (as in the
+    reference, whose inputs are detached); the rarely-needed backward runs the
+    plain ops."""
+
+    @staticmethod
+    def forward(ctx, caps_presence, posterior, weight, bias):
+        _need_hip(caps_presence, posterior, weight, bias)
+        cp, post = caps_presence.detach().contiguous(), \
+            posterior.detach().contiguous()
+        weight, bias = weight.contiguous(), bias.contiguous()
+        B, O1, M = post.shape
+        ncls = weight.shape[0]
+        prior = torch.empty(B, ncls, device=cp.device, dtype=cp.dtype)
+        posterior_prob = torch.empty_like(prior)
+        _lib.call("scae_class_probs_f32", _p(cp), _p(post), _p(weight), _p(bias),
+                  _p(prior), _p(posterior_prob), B, O1 - 1, M, ncls, _stream(cp))
+        ctx.save_for_backward(cp, post, weight, bias)
+        ctx.set_materialize_grads(False)
+        return prior, posterior_prob
+
+    @staticmethod
+    def backward(ctx, g_prior, g_post):
+        cp, post, weight, bias = ctx.saved_tensors
+        with torch.enable_grad():
+            w, b = weight.detach().requires_grad_(), bias.detach().requires_grad_()
+            outs, gs = [], []
+            for x, g in ((cp, g_prior), (post[:, :-1].sum(-1), g_post)):
+                if g is not None:
+                    outs.append(torch.softmax(
+                        torch.nn.functional.linear(x, w, b), -1))
+                    gs.append(g)
+            gw, gb = torch.autograd.grad(outs, (w, b), gs) if outs else (None,
+                                                                         None)
+        return None, None, gw, gb
+
+
+def class_probs(caps_presence, posterior, weight, bias):
+    return _ClassProbs.apply(caps_presence, posterior, weight, bias)
+
+
+# ----------------------------------------------------------------------------
 # K10 coloured templates (part_decoder.py:78-110)
 # ----------------------------------------------------------------------------
 _NONLIN_CODE = {"sigmoid": 0, "relu1": 1}
@@ -766,22 +816,26 @@ class _CapsuleVotes(torch.autograd.Function):
         lc = torch.empty(B, O, 1, device=dev, dtype=dt)
         lv = torch.empty(B, O, V, device=dev, dtype=dt)
         reg = torch.empty(B, O, device=dev, dtype=dt)
+        caps_presence = torch.empty(B, O, device=dev, dtype=dt)
+        caps_arg = torch.empty(B, O, device=dev, dtype=torch.int32)
         flags = (B, O, V, int(similarity), int(learn_vote_scale),
                  int(allow_deformations))
         _lib.call("scae_capsule_votes_fwd_f32", *[_p(t) for t in args],
                   float(noise_scale), _p(vote), _p(scale), _p(vp), _p(lc),
-                  _p(lv), _p(reg), *flags, _stream(all_param))
-        ctx.save_for_backward(*[t for t in args if t is not None])
+                  _p(lv), _p(reg), _p(caps_presence), _p(caps_arg), *flags,
+                  _stream(all_param))
+        ctx.save_for_backward(caps_arg, *[t for t in args if t is not None])
         ctx.has_noise = (args[6] is not None, args[7] is not None)
         ctx.noise_scale = float(noise_scale)
         ctx.flags = flags
-        reg_loss = reg.sum() / 2 / B          # l2_loss(.)/B, :170
+        reg_loss = reg.sum() * (0.5 / B)      # l2_loss(.)/B, :170
         ctx.set_materialize_grads(False)
-        return vote, scale, vp, lc, lv, reg_loss
+        return vote, scale, vp, lc, lv, reg_loss, caps_presence
 
     @staticmethod
-    def backward(ctx, gvote, gscale, gvp, glc, glv, greg):
+    def backward(ctx, gvote, gscale, gvp, glc, glv, greg, gcp):
         saved = list(ctx.saved_tensors)
+        caps_arg = saved.pop(0)
         args = saved[:6]
         args.append(saved.pop(6) if ctx.has_noise[0] else None)
         args.append(saved[6] if ctx.has_noise[1] else None)
@@ -790,10 +844,10 @@ class _CapsuleVotes(torch.autograd.Function):
         gall = torch.empty_like(all_param)
         gin = torch.empty(B, O, V, 6, device=all_param.device,
                           dtype=all_param.dtype)
-        grads = [_c(g) for g in (gvote, gscale, gvp, glc, glv, greg)]
+        grads = [_c(g) for g in (gvote, gscale, gvp, glc, glv, greg, gcp)]
         _lib.call("scae_capsule_votes_bwd_f32", *[_p(t) for t in args],
-                  ctx.noise_scale, *[_p(g) for g in grads], _p(gall), _p(gin),
-                  *ctx.flags, _stream(all_param))
+                  ctx.noise_scale, *[_p(g) for g in grads], _p(caps_arg),
+                  _p(gall), _p(gin), *ctx.flags, _stream(all_param))
         # bias gradients: batch sums of column blocks of gall (B, O*A); each
         # capsule's block lands in its row of the (.., O, ..) parameter
         A = all_param.shape[2]
@@ -812,7 +866,8 @@ def capsule_votes(all_param, cpr_static, bias_cvr, bias_caps, bias_vote,
                   similarity=False, learn_vote_scale=True,
                   allow_deformations=True):
     """-> vote (B,O,V,6), scale, vote_presence, presence_logit_per_caps
-    (B,O,1), presence_logit_per_vote (B,O,V), cpr_dynamic_reg_loss ()."""
+    (B,O,1), presence_logit_per_vote (B,O,V), cpr_dynamic_reg_loss (),
+    caps_presence (B,O) = vote_presence.max(-1)."""
     return _CapsuleVotes.apply(all_param, cpr_static, bias_cvr, bias_caps,
                                bias_vote, bias_scale, noise_caps, noise_vote,
                                noise_scale, similarity, learn_vote_scale,

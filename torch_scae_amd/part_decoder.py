@@ -97,6 +97,8 @@ class TemplateBasedImageDecoder(nn.Module):
         if learn_output_scale:
             self.scale = nn.Parameter(torch.rand(1))
         self.bg_mixing_logit = nn.Parameter(torch.tensor([0.0]))
+        # the fixed output scale of the not-learned case (part_decoder.py:201)
+        self.register_buffer("_unit_scale", torch.ones(1), persistent=False)
         if background_value:
             self.bg_value = nn.Parameter(torch.tensor([0.0]))
 
@@ -125,7 +127,7 @@ class TemplateBasedImageDecoder(nn.Module):
         if self.learn_output_scale:
             scale = nn.functional.softplus(self.scale) + 1e-4
         else:
-            scale = torch.ones(1, device=templates.device)
+            scale = self._unit_scale
         pdf = GaussianMixture(_NormalView(transformed_templates, scale),
                               mixing_logits, _decoder_inputs=inputs)
         return AttrDict(transformed_templates=transformed_templates,

@@ -134,6 +134,16 @@ class SCAE(nn.Module):
         if self.n_classes is not None:
             assert self.prior_classifier is not None
             assert self.posterior_classifier is not None
+            linear = self.prior_classifier[0]
+            if "_posterior_full" in res and res.caps_presence.is_cuda and \
+                    len(self.prior_classifier) == 2 and \
+                    ops.class_probs_supported(res.caps_presence.shape[1],
+                                              self.n_classes):
+                # both heads (and the capsule-mass reduction) in one launch
+                res.prior_cls_prob, res.posterior_cls_prob = ops.class_probs(
+                    res.caps_presence, res._posterior_full, linear.weight,
+                    linear.bias)
+                return res
             res.prior_cls_prob = self.prior_classifier(
                 res.caps_presence.detach())
             # as in the reference (:211) the posterior probabilities also go
