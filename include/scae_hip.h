@@ -297,13 +297,15 @@ int scae_template_color_bwd_f32(const float *logits, const float *feature, const
 /* ------------------------------------------------------------------------
  * Column sums of a (rows, cols) matrix of partial gradients, written to up to
  * 8 contiguous destinations: column j in [begin, end) of segment i goes to
- * segments[i].dst[j - begin] (columns in no segment are dropped).  `segments`
- * is a HOST array.  Replaces `partial.sum(0)` + per-parameter slice copies
+ * segments[i].dst[j - begin]; with period > 0 the window [begin, end) of
+ * every period-wide block of columns is gathered instead:
+ * dst[(j / period) * (end - begin) + j % period - begin].  Columns in no
+ * segment are dropped; segments may overlap.  `segments` is a HOST array.  Replaces `partial.sum(0)` + per-parameter slice copies
  * behind the partial-gradient outputs of K1, K2b, K2c, K3, K8, K9 and K10.
  * ---------------------------------------------------------------------- */
 typedef struct scae_sum_segment {
   float *dst;
-  int64_t begin, end;
+  int64_t begin, end, period;
 } scae_sum_segment;
 int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
                       const scae_sum_segment *segments, int n_segments, void *stream);
@@ -433,6 +435,9 @@ typedef struct scae_loss_extras {
   const float *reg;
   float w_reg;
   float *g_rec_sums, *g_reg;
+  float *loss;          /* forward: also receives out12[0] (a separate scalar) */
+  const float *g_loss;  /* backward: gradient of that scalar, added to gout12[0];
+                           gout12 may then be NULL (= zeros) */
 } scae_loss_extras;
 int scae_loss_tail_supported(int B, int O, int ncls);
 int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,

@@ -27,13 +27,15 @@ class DecoderDesc(Structure):
 
 class SumSegment(Structure):
     """struct scae_sum_segment"""
-    _fields_ = [("dst", P), ("begin", c_int64), ("end", c_int64)]
+    _fields_ = [("dst", P), ("begin", c_int64), ("end", c_int64),
+                ("period", c_int64)]
 
 
 class LossExtras(Structure):
     """struct scae_loss_extras"""
     _fields_ = [("rec_sums", P), ("n_rec", c_int), ("reg", P),
-                ("w_reg", c_float), ("g_rec_sums", P), ("g_reg", P)]
+                ("w_reg", c_float), ("g_rec_sums", P), ("g_reg", P),
+                ("loss", P), ("g_loss", P)]
 
 
 class SeedFoldDesc(Structure):

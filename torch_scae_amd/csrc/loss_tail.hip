@@ -282,6 +282,7 @@ __global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, scae_loss_extr
     out[7] = xe2;
     out[0] = -a.w_ll * log_prob + a.w_pw * pw + a.w_pb * pb + a.w_qw * qw + a.w_qb * qb + xe1 +
              xe2 - rec + x.w_reg * reg;
+    if (x.loss) x.loss[0] = out[0];
   }
 }
 
@@ -295,16 +296,21 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
   load_stats(a, c);
   // d(total)/d(component): the tail loss plus whatever flowed into the
   // individually exposed log entries
-  const float g0 = gout[0];
-  const float g_lp = -a.w_ll * g0 + gout[1] - gout[10];
+  // d/d(loss) may arrive on the 12-vector, on the separate scalar, or both
+  float go[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) go[i] = gout ? gout[i] : 0.f;
+  if (x.g_loss) go[0] += x.g_loss[0];
+  const float g0 = go[0];
+  const float g_lp = -a.w_ll * g0 + go[1] - go[10];
   if (x.g_rec_sums) {
-    const float gr = (-g0 + gout[8] - gout[9]) / B;
+    const float gr = (-g0 + go[8] - go[9]) / B;
     for (int i = threadIdx.x; i < x.n_rec; i += NT) x.g_rec_sums[i] = gr;
   }
-  if (x.g_reg && threadIdx.x == 0) x.g_reg[0] = x.w_reg * g0 + gout[11];
-  const float g_pw = a.w_pw * g0 + gout[2], g_pb = a.w_pb * g0 + gout[3];
-  const float g_qw = a.w_qw * g0 + gout[4], g_qb = a.w_qb * g0 + gout[5];
-  const float g_x1 = g0 + gout[6], g_x2 = g0 + gout[7];
+  if (x.g_reg && threadIdx.x == 0) x.g_reg[0] = x.w_reg * g0 + go[11];
+  const float g_pw = a.w_pw * g0 + go[2], g_pb = a.w_pb * g0 + go[3];
+  const float g_qw = a.w_qw * g0 + go[4], g_qb = a.w_qb * g0 + go[5];
+  const float g_x1 = g0 + go[6], g_x2 = g0 + go[7];
 
   for (int i = threadIdx.x; i < B * M; i += NT) g_lpp[i] = g_lp / B;
 
@@ -433,7 +439,8 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
   int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
                      n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
   if (rc) return rc;
-  SCAE_REQUIRE(gout12 && g_lpp && g_posterior && g_caps_presence);
+  SCAE_REQUIRE(g_lpp && g_posterior && g_caps_presence);
+  if (!gout12 && !(extras && extras->g_loss)) return SCAE_ERR_BAD_ARG;
   scae_loss_extras x{};
   if (extras) x = *extras;
   if (x.rec_sums && (x.n_rec <= 0 || !x.g_rec_sums)) return SCAE_ERR_BAD_ARG;

@@ -38,11 +38,15 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(const float *__restrict__ 
   float tot = 0.f;
 #pragma unroll
   for (int p = 0; p < PY; ++p) tot += red[p][cx];
-  for (int i = 0; i < segs.n; ++i)
-    if (j >= segs.s[i].begin && j < segs.s[i].end) {
-      segs.s[i].dst[j - segs.s[i].begin] = tot;
-      break;
+  for (int i = 0; i < segs.n; ++i) {
+    const scae_sum_segment &g = segs.s[i];
+    if (g.period > 0) {  // the same column window of every period-wide block
+      const long blk = j / g.period, c = j - blk * g.period;
+      if (c >= g.begin && c < g.end) g.dst[blk * (g.end - g.begin) + c - g.begin] = tot;
+    } else if (j >= g.begin && j < g.end) {
+      g.dst[j - g.begin] = tot;
     }
+  }
 }
 }  // namespace
 
@@ -54,8 +58,9 @@ extern "C" int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
   segs.n = n_segments;
   for (int i = 0; i < n_segments; ++i) {
     segs.s[i] = segments[i];
-    SCAE_REQUIRE(segs.s[i].dst && segs.s[i].begin >= 0 && segs.s[i].end <= cols &&
-                 segs.s[i].begin < segs.s[i].end);
+    SCAE_REQUIRE(segs.s[i].dst && segs.s[i].begin >= 0 && segs.s[i].begin < segs.s[i].end &&
+                 segs.s[i].period >= 0 &&
+                 segs.s[i].end <= (segs.s[i].period > 0 ? segs.s[i].period : cols));
   }
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 16) {

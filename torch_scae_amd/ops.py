@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
-__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_supported", "capsule_votes",
+__all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_scalar", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "conv_stack", "conv_stack_supported",
            "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
@@ -48,20 +48,24 @@ def _detached(t):
     return None if t is None else t.detach()
 
 
-def _sum_rows(partial, shapes, starts=None):
+def _sum_rows(partial, shapes, starts=None, period=0):
     """Column sums of ``partial`` (rows, cols) scattered into fresh contiguous
     tensors of the given shapes; consecutive column ranges unless ``starts``
-    gives each one's first column.  One launch (scae_sum_rows_f32)."""
+    gives each one's first column.  With ``period`` the columns form blocks
+    of that width and output i gathers columns [starts[i], starts[i] + w_i) of
+    every block (w_i = numel / number of blocks).  One launch."""
     rows, cols = partial.shape
     outs, segs = [], (_lib.SumSegment * len(shapes))()
+    nblk = cols // period if period else 1
     pos = 0
     for i, shape in enumerate(shapes):
         o = torch.empty(shape, device=partial.device, dtype=partial.dtype)
         if starts is not None:
             pos = starts[i]
-        segs[i].dst, segs[i].begin, segs[i].end = o.data_ptr(), pos, \
-            pos + o.numel()
-        pos += o.numel()
+        width = o.numel() // nblk
+        segs[i].dst, segs[i].begin, segs[i].end = o.data_ptr(), pos, pos + width
+        segs[i].period = period
+        pos += width
         outs.append(o)
     for k in range(0, len(shapes), 8):
         n = min(8, len(shapes) - k)
@@ -852,11 +856,9 @@ class _CapsuleVotes(torch.autograd.Function):
         # capsule's block lands in its row of the (.., O, ..) parameter
         A = all_param.shape[2]
         (g_static,) = _sum_rows(gin.view(B, -1), [args[1].shape])
-        gsum = _sum_rows(gall.view(B, O * A), [(O, A)])[0]
-        g_cvr = gsum[:, 6 * V:6 * V + 6].reshape(args[2].shape)
-        g_caps = gsum[:, 6 * V + 6].reshape(args[3].shape)
-        g_vote = gsum[:, 6 * V + 7:7 * V + 7].reshape(args[4].shape)
-        g_scale = gsum[:, 7 * V + 7:].reshape(args[5].shape)
+        g_cvr, g_caps, g_vote, g_scale = _sum_rows(
+            gall.view(B, O * A), [t.shape for t in args[2:6]],
+            starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=A)
         return (gall, g_static, g_cvr, g_caps, g_vote, g_scale, None, None,
                 None, None, None, None)
 
@@ -975,6 +977,8 @@ class _LossTail(torch.autograd.Function):
             ex.rec_sums, ex.n_rec = rec_sums.data_ptr(), rec_sums.numel()
         if reg is not None:
             ex.reg, ex.w_reg = reg.data_ptr(), float(w_reg)
+        loss = torch.empty((), device=lpp.device, dtype=lpp.dtype)
+        ex.loss = loss.data_ptr()
         _lib.call("scae_loss_tail_fwd_f32", _p(lpp), _p(posterior),
                   _p(caps_presence), _p(cls_w), _p(cls_b), lab, ctypes.byref(ex),
                   _p(out), *ints, w5, wc, _stream(lpp))
@@ -985,10 +989,11 @@ class _LossTail(torch.autograd.Function):
                               *([reg] if reg is not None else []))
         ctx.has = (label is not None, rec_sums is not None, reg is not None)
         ctx.call = (ints, tuple(weights), wc, float(w_reg))
-        return out
+        ctx.set_materialize_grads(False)
+        return loss, out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, g_loss, gout):
         saved = list(ctx.saved_tensors)
         lpp, posterior, cp = saved[:3]
         rest = saved[3:]
@@ -1013,22 +1018,30 @@ class _LossTail(torch.autograd.Function):
             ex.g_rec_sums = g_rec.data_ptr()
         if has_reg:
             ex.reg, ex.w_reg, ex.g_reg = reg.data_ptr(), w_reg, g_reg.data_ptr()
+        if g_loss is None and gout is None:
+            gout = torch.zeros(12, device=lpp.device, dtype=lpp.dtype)
+        if g_loss is not None:
+            g_loss = g_loss.contiguous()
+            ex.g_loss = g_loss.data_ptr()
         w5 = (ctypes.c_float * 5)(*weights)
         lab = None if label is None else ctypes.c_void_p(label.data_ptr())
         _lib.call("scae_loss_tail_bwd_f32", _p(lpp), _p(posterior), _p(cp),
                   _p(cls_w), _p(cls_b), lab, ctypes.byref(ex),
-                  _p(gout.contiguous()), _p(g_lpp), _p(g_post), _p(g_cp),
+                  _p(_c(gout)), _p(g_lpp), _p(g_post), _p(g_cp),
                   _p(g_w), _p(g_b), *ints, w5, wc, _stream(lpp))
         return g_lpp, g_post, g_cp, g_w, g_b, None, g_rec, g_reg, None
 
 
-def loss_tail(lpp, posterior, caps_presence, cls_w, cls_b, label, n_classes,
-              prior_type, post_type, sparsity_on, weights, within_const=None,
-              rec_sums=None, reg=None, w_reg=0.):
-    """-> tensor (12): [loss, log_prob, prior_within, prior_between,
-    posterior_within, posterior_between, prior_cls_xe, posterior_cls_xe,
-    rec_ll, -rec_ll, -log_prob, reg]; loss also carries -rec_ll (from K1's
-    tile sums ``rec_sums``) and w_reg * reg when those are given."""
+def loss_tail_scalar(lpp, posterior, caps_presence, cls_w, cls_b, label,
+                     n_classes, prior_type, post_type, sparsity_on, weights,
+                     within_const=None, rec_sums=None, reg=None, w_reg=0.):
+    """-> (loss (), tensor (12)).  The 12-vector: [loss, log_prob,
+    prior_within, prior_between, posterior_within, posterior_between,
+    prior_cls_xe, posterior_cls_xe, rec_ll, -rec_ll, -log_prob, reg]; loss
+    also carries -rec_ll (from K1's tile sums ``rec_sums``) and w_reg * reg
+    when those are given.  The loss is returned as its own 0-dim output too, so
+    that ``loss.backward()`` seeds one scalar instead of scattering into the
+    vector."""
     if label is None:
         cls_w = cls_b = None
     cfg = (n_classes, _SPARSITY_TYPES[prior_type], _SPARSITY_TYPES[post_type],
@@ -1036,6 +1049,11 @@ def loss_tail(lpp, posterior, caps_presence, cls_w, cls_b, label, n_classes,
            float(w_reg))
     return _LossTail.apply(lpp, posterior, caps_presence, cls_w, cls_b, label,
                            rec_sums, reg, cfg)
+
+
+def loss_tail(*args, **kwargs):
+    """``loss_tail_scalar(...)[1]``: the 12-vector only."""
+    return loss_tail_scalar(*args, **kwargs)[1]
 
 
 # ----------------------------------------------------------------------------

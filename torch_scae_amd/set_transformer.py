@@ -216,7 +216,8 @@ class SetTransformer(nn.Module):
             C, D = w2.shape
             if ops.seed_fold_supported(self.seeds.shape[1], C, D):
                 q, wk, bk, wv, bv = ops.seed_fold(
-                    self.seeds[0], mha.q_projector.weight,
+                    self.seeds.view(self.seeds.shape[1:]),
+                    mha.q_projector.weight,
                     mha.q_projector.bias, mha.k_projector.weight,
                     mha.k_projector.bias, mha.v_projector.weight,
                     mha.v_projector.bias, mha.o_projector.weight,

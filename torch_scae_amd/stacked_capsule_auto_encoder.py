@@ -163,7 +163,7 @@ class SCAE(nn.Module):
         def tail(rec_sums=None, reg=None):
             # one kernel for the capsule-likelihood, sparsity and
             # classification terms (and one for their backward)
-            return ops.loss_tail(
+            return ops.loss_tail_scalar(
                 res._log_prob_per_point, res._posterior_full,
                 res.caps_presence,
                 self.prior_classifier[0].weight if label is not None else None,
@@ -196,10 +196,10 @@ class SCAE(nn.Module):
         if rec_sums is not None:
             # the whole training scalar from the tail kernel: K1 hands it
             # per-tile sums of the reconstruction log-likelihood
-            t = tail(rec_sums, res.cpr_dynamic_reg_loss.reshape(1))
+            loss, t = tail(rec_sums, res.cpr_dynamic_reg_loss.reshape(1))
             log.update(rec_ll_loss=t[9])
             tail_log(t)
-            return t[0], log
+            return loss, log
 
         rec_ll_per_pixel = res.rec.pdf.log_prob(reconstruction_target)
         rec_ll = rec_ll_per_pixel.flatten(1).sum(-1).mean()
@@ -218,8 +218,8 @@ class SCAE(nn.Module):
             log.update(part_caps_loss=part_caps_l1)
 
         if fused_tail:
-            t = tail()
-            loss = loss + t[0]
+            tail_loss, t = tail()
+            loss = loss + tail_loss
             loss = loss + self.cpr_dynamic_reg_weight * res.cpr_dynamic_reg_loss
             tail_log(t)
             return loss, log
