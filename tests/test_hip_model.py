@@ -183,3 +183,42 @@ def test_invalid_vote_type():
     model = factory.make_scae(cfg).cuda()
     with pytest.raises(ValueError):
         model(torch.rand(2, 1, 40, 40, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_flat_gradient_slots_match_plain_backward():
+    """With FlatParameters the ops write parameter gradients straight into
+    the flat buffer (GradSlot); the packed result must equal the gradients of
+    a plain backward, for two consecutive steps (slots are re-armed)."""
+    import copy
+    from torch_scae_amd import factory
+    from torch_scae_amd.data_parallel import FlatParameters
+    from torch_scae_amd.nn_utils import fixed_noise
+    torch.manual_seed(5)
+    model = factory.make_scae(dict(image_shape=(1, 40, 40), n_classes=10,
+                                   n_part_caps=24, n_obj_caps=24)).cuda()
+    plain = copy.deepcopy(model)
+    flat = FlatParameters(model)
+    g = torch.Generator().manual_seed(1)
+    for step in range(2):
+        image = torch.rand(16, 1, 40, 40, generator=g).cuda()
+        label = torch.randint(0, 10, (16,), generator=g).cuda()
+        draws = [torch.rand(16, 24, generator=g), torch.rand(16, 24, 1, generator=g),
+                 torch.rand(16, 24, 24, generator=g)]
+        for m in (model, plain):
+            if m is model:
+                flat.clear_grads()
+            else:
+                m.zero_grad(set_to_none=True)
+            with fixed_noise([d.clone() for d in draws]):
+                res = m(image)
+                loss, _ = m.loss(res, image, label)
+            loss.backward()
+        flat.gather_grads()
+        in_place = sum(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                       for p, v in zip(flat.params, flat.grad_views()))
+        assert in_place >= 20, in_place      # convs, capsule MLPs, projectors
+        for (name, p), v, q in zip(model.named_parameters(), flat.grad_views(),
+                                   plain.parameters()):
+            want = q.grad if q.grad is not None else torch.zeros_like(q)
+            assert torch.equal(v, want), (step, name)

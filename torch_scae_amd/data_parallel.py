@@ -16,6 +16,31 @@ import torch
 import torch.distributed as dist
 
 
+class GradSlot:
+    """Where a parameter's gradient lives in the flat buffer.  The HIP ops'
+    backward passes ask for it (``ops._grad_out``) and write the gradient
+    there directly; autograd then adopts that view as ``p.grad`` and the
+    per-step pack has nothing to copy for this parameter.  One taker per
+    step: a second gradient of the same parameter is accumulated by autograd
+    as usual."""
+
+    def __init__(self, flat_grad, offset, shape):
+        self.flat_grad, self.offset, self.shape = flat_grad, offset, shape
+        self.numel = 1
+        for d in shape:
+            self.numel *= d
+        self.taken = False
+
+    def take(self):
+        if self.taken:
+            return None
+        self.taken = True
+        # a fresh tensor object every time: autograd only adopts a gradient
+        # nobody else holds a reference to
+        return self.flat_grad[self.offset:self.offset + self.numel] \
+            .view(self.shape)
+
+
 class FlatParameters:
     """Re-homes every parameter (and its gradient) of ``module`` into two flat
     fp32 buffers.  ``param.data`` / ``param.grad`` become views, so optimisers,
@@ -40,6 +65,7 @@ class FlatParameters:
                 self.flat_param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = None
+                p._scae_grad_slot = GradSlot(self.flat_grad, off, tuple(p.shape))
                 off += n
         self.numel = total
         self._views = None
@@ -59,6 +85,7 @@ class FlatParameters:
         instead of launching one accumulate-add kernel per parameter."""
         for p in self.params:
             p.grad = None
+            p._scae_grad_slot.taken = False
 
     @torch.no_grad()
     def gather_grads(self):
@@ -67,10 +94,12 @@ class FlatParameters:
         (``obj_decoder.dummy_vote``, ``posterior_classifier.*`` in the default
         SCAE config) keep zeros in their slice."""
         views = self.grad_views()
-        dst = [v for v, p in zip(views, self.params) if p.grad is not None]
-        src = [p.grad for p in self.params if p.grad is not None]
-        if dst:
-            torch._foreach_copy_(dst, src)
+        pairs = [(v, p.grad) for v, p in zip(views, self.params)
+                 if p.grad is not None
+                 # written in place by the op that produced it (GradSlot)
+                 and p.grad.data_ptr() != v.data_ptr()]
+        if pairs:
+            torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
         for v, p in zip(views, self.params):
             if p.grad is None and getattr(p, "_flat_was_set", False):
                 v.zero_()

@@ -48,18 +48,36 @@ def _detached(t):
     return None if t is None else t.detach()
 
 
-def _sum_rows(partial, shapes, starts=None, period=0):
+def _slot(t):
+    """The flat-gradient slot of a parameter (data_parallel.GradSlot) or None."""
+    return getattr(t, "_scae_grad_slot", None) if t is not None else None
+
+
+def _grad_out(slot, like, shape=None):
+    """Buffer for a gradient of ``shape`` (default ``like.shape``): the
+    parameter's slot in the flat gradient buffer when it has an unclaimed one,
+    else a fresh tensor on ``like``'s device."""
+    shape = tuple(like.shape if shape is None else shape)
+    if slot is not None and tuple(slot.shape) == shape:
+        v = slot.take()
+        if v is not None:
+            return v
+    return torch.empty(shape, device=like.device, dtype=like.dtype)
+
+
+def _sum_rows(partial, shapes, starts=None, period=0, outs=None):
     """Column sums of ``partial`` (rows, cols) scattered into fresh contiguous
     tensors of the given shapes; consecutive column ranges unless ``starts``
     gives each one's first column.  With ``period`` the columns form blocks
     of that width and output i gathers columns [starts[i], starts[i] + w_i) of
     every block (w_i = numel / number of blocks).  One launch."""
     rows, cols = partial.shape
-    outs, segs = [], (_lib.SumSegment * len(shapes))()
+    given, outs, segs = outs, [], (_lib.SumSegment * len(shapes))()
     nblk = cols // period if period else 1
     pos = 0
     for i, shape in enumerate(shapes):
-        o = torch.empty(shape, device=partial.device, dtype=partial.dtype)
+        o = given[i] if given is not None and given[i] is not None else \
+            torch.empty(shape, device=partial.device, dtype=partial.dtype)
         if starts is not None:
             pos = starts[i]
         width = o.numel() // nblk
@@ -307,6 +325,7 @@ class _SeedFold(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *inputs):
         _need_hip(*inputs)
+        ctx.slots = [_slot(t) for t in inputs]
         inputs = tuple(t.contiguous() for t in inputs)
         seeds, w2 = inputs[0], inputs[9]
         O, C = seeds.shape
@@ -329,7 +348,7 @@ class _SeedFold(torch.autograd.Function):
         incoming = [g if g is not None else zeros(o) for g, o in
                     zip((g_q, g_wkf, g_bkf, g_wvf, g_bvf), outs)]
         incoming = [g.contiguous() for g in incoming]
-        grads = [torch.empty_like(t) for t in inputs]
+        grads = [_grad_out(sl, t) for sl, t in zip(ctx.slots, inputs)]
         work = torch.empty(2, C, D + 1, device=seeds.device, dtype=seeds.dtype)
         desc = _fold_desc(inputs, outs, O, C, D)
         g = _lib.SeedFoldGrads()
@@ -399,6 +418,8 @@ class _ConvStack(torch.autograd.Function):
             act = out
         ctx.save_for_backward(image, *acts, *wds)
         ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights])
+        ctx.slots = [_slot(t) for t in wb]
+        ctx.refs = [tuple(t.shape) for t in wb]
         return act.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -411,6 +432,10 @@ class _ConvStack(torch.autograd.Function):
         B, C0, H, W = image.shape
         dev, dt, st = image.device, image.dtype, _stream(image)
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
+
+        def gout(i):     # gradient buffer of weight / bias i (flat slot if any)
+            return _grad_out(ctx.slots[i], image, ctx.refs[i])
+
         dpre = torch.ops.aten.threshold_backward(
             gy.permute(0, 2, 3, 1).contiguous(), acts[-1], 0.0)
         gws, gbs = [None] * L, [None] * L
@@ -420,7 +445,7 @@ class _ConvStack(torch.autograd.Function):
             ih, iw, oh, ow = xin.shape[1], xin.shape[2], dpre.shape[1], dpre.shape[2]
             splits = _lib.load().scae_conv3x3_wgrad_splits(B, oh, ow, ci, co)
             partial = new(splits * (9 * co * ci + co))
-            gw, gb = new(co, ci, 3, 3), new(co)
+            gw, gb = gout(l), gout(L + l)
             _lib.call("scae_conv3x3_wgrad_f32", _p(dpre), _p(xin), _p(partial),
                       _p(gw), _p(gb), B, ih, iw, ci, co, s, st)
             gbs[l] = gb
@@ -435,7 +460,8 @@ class _ConvStack(torch.autograd.Function):
         _lib.call("scae_conv3x3_first_wgrad_f32", _p(dpre), _p(image),
                   _p(partial), B, C0, H, W, c1, strides[0], st)
         gws[0], gbs[0] = _sum_rows(partial.view(partial.shape[0], -1),
-                                   [(c1, C0, 3, 3), (c1,)])
+                                   [(c1, C0, 3, 3), (c1,)],
+                                   outs=[gout(0), gout(L)])
         return (None, None, *gws, *gbs)
 
 
@@ -740,6 +766,7 @@ class _GroupedMLP(torch.autograd.Function):
         ctx.save_for_backward(x, *weights, *acts)
         ctx.meta = (bool(ones_input), n_layers,
                     [b is not None for b in biases])
+        ctx.slots = [_slot(t) for t in wb]
         return acts[-1]
 
     @staticmethod
@@ -763,10 +790,13 @@ class _GroupedMLP(torch.autograd.Function):
                 xin, x_ld, x_b = x, x.stride(0), x.stride(1)
             else:
                 xin, x_ld, x_b = acts[l - 1], K, B * K
-            gw = torch.empty_like(w)
+            gw = _grad_out(ctx.slots[l], w)
             # gW[g] (N x K) = gpre^T x : both operands k(=batch)-strided; the
             # bias gradient sum_b gpre is emitted by the same launch
-            if has_bias[l] or (l == 0 and ones_input):
+            if has_bias[l]:
+                gsum = _grad_out(ctx.slots[L + l], w, (G, N))
+                asum, asum_b = _p(gsum), N
+            elif l == 0 and ones_input:
                 gsum = torch.empty(G, N, device=dev, dtype=dt)
                 asum, asum_b = _p(gsum), N
             else:
