@@ -5,8 +5,8 @@
 //   caps_presence, posterior sparsity on the capsule mass / n_points, and the
 //   two "cross_entropy over probabilities" classification terms (both through
 //   prior_classifier, as the reference does, :207-212, :281-282).
-// Everything is O(B*O) data: ONE workgroup, tensors staged in LDS, block
-// reductions by wave shuffles.  The backward kernel recomputes the forward
+// Everything is O(B*O) data: one workgroup per independent group of terms,
+// tensors staged in LDS, block reductions by wave shuffles.  The backward kernel recomputes the forward
 // statistics and writes every gradient once (no atomics).
 #include "common.h"
 
@@ -204,11 +204,14 @@ __device__ Carve carve(float *smem, int B, int O, int ncls) {
   return c;
 }
 
-__device__ void load_stats(const TailArgs &a, const Carve &c) {
+// stages caps_presence and / or the capsule mass with their row / column sums
+__device__ void load_stats(const TailArgs &a, const Carve &c, bool want_cp, bool want_mass,
+                           bool sums = true) {
   const int B = a.B, O = a.O, M = a.M;
   for (int i = threadIdx.x; i < B * O; i += NT) {
     const int b = i / O, o = i - b * O;
-    c.cp[i] = a.cp[i];
+    if (want_cp) c.cp[i] = a.cp[i];
+    if (!want_mass) continue;
     const float *pr = a.posterior + ((size_t)b * (O + 1) + o) * M;
     float t = 0.f;
     if ((M & 3) == 0) {
@@ -223,148 +226,165 @@ __device__ void load_stats(const TailArgs &a, const Carve &c) {
     c.mass[i] = t / M;  // mass_explained_by_capsule / n_points (:260-266)
   }
   __syncthreads();
-  row_col_sums(Stats{c.cp, c.row_c, c.col_c}, B, O);
-  row_col_sums(Stats{c.mass, c.row_m, c.col_m}, B, O);
+  if (!sums) return;
+  if (want_cp) row_col_sums(Stats{c.cp, c.row_c, c.col_c}, B, O);
+  if (want_mass) row_col_sums(Stats{c.mass, c.row_m, c.col_m}, B, O);
 }
 
 // out: [0] tail loss  [1] log_prob  [2] prior_within [3] prior_between
 //      [4] post_within [5] post_between [6] prior_cls_xe [7] posterior_cls_xe
+// The terms are independent until the final weighted sum, so they run as three
+// workgroups (blockIdx.x = role) on three CUs; tail_combine_kernel then forms
+// the scalar.  role 0: capsule log-likelihood, reconstruction term, regulariser;
+// role 1: prior sparsity + prior classification; role 2: the posterior pair.
 __global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, scae_loss_extras x, float *out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int B = a.B, O = a.O;
+  const int B = a.B, O = a.O, role = blockIdx.x;
   const Carve c = carve(smem, B, O, a.ncls);
-  load_stats(a, c);
-  float lp = 0.f;
-  for (int i = threadIdx.x; i < B * a.M; i += NT) lp += a.lpp[i];
-  const float log_prob = block_total(lp, c.red) / B;
-  float pw = 0.f, pb = 0.f, qw = 0.f, qb = 0.f;
-  if (a.sparsity_on) {
-    sparsity_fwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
-                 a.l2_between_const, c.red, pw, pb);
-    sparsity_fwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type, a.l2_within_const_post,
-                 a.l2_between_const_post, c.red, qw, qb);
-  }
-  float xe1 = 0.f, xe2 = 0.f;
-  if (a.label) {
-    float t1 = 0.f, t2 = 0.f;
-    float gl[MAXCLS];
-    for (int b = threadIdx.x; b < B; b += NT) {
-      t1 += cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
+  if (role == 0) {
+    float lp = 0.f;
+    for (int i = threadIdx.x; i < B * a.M; i += NT) lp += a.lpp[i];
+    const float log_prob = block_total(lp, c.red) / B;
+    // reconstruction term (stacked_capsule_auto_encoder.py:222-224) from K1's tile
+    // sums, and the dynamic-regularisation scalar
+    float rec = 0.f;
+    if (x.rec_sums) {
+      float t = 0.f;
+      for (int i = threadIdx.x; i < x.n_rec; i += NT) t += x.rec_sums[i];
+      rec = block_total(t, c.red) / B;
     }
-    xe1 = block_total(t1, c.red) / B;
-    // posterior classifier input: the un-normalised capsule mass (:210-212)
-    for (int i = threadIdx.x; i < B * O; i += NT) c.cp[i] = c.mass[i] * a.M;
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += NT)
-      t2 += cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
-    xe2 = block_total(t2, c.red) / B;
+    if (threadIdx.x == 0) {
+      out[1] = log_prob;
+      out[8] = rec;
+      out[9] = -rec;
+      out[10] = -log_prob;
+      out[11] = x.reg ? x.reg[0] : 0.f;
+    }
+    return;
   }
-  // reconstruction term (stacked_capsule_auto_encoder.py:222-224) from K1's tile
-  // sums, and the dynamic-regularisation scalar
-  float rec = 0.f;
-  if (x.rec_sums) {
+  const bool prior = role == 1;
+  load_stats(a, c, prior, !prior);
+  float within = 0.f, between = 0.f;
+  if (a.sparsity_on) {
+    if (prior)
+      sparsity_fwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
+                   a.l2_between_const, c.red, within, between);
+    else
+      sparsity_fwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type, a.l2_within_const_post,
+                   a.l2_between_const_post, c.red, within, between);
+  }
+  float xe = 0.f;
+  if (a.label) {
+    // posterior classifier input: the un-normalised capsule mass (:210-212)
+    if (!prior) {
+      for (int i = threadIdx.x; i < B * O; i += NT) c.cp[i] = c.mass[i] * a.M;
+      __syncthreads();
+    }
     float t = 0.f;
-    for (int i = threadIdx.x; i < x.n_rec; i += NT) t += x.rec_sums[i];
-    rec = block_total(t, c.red) / B;
+    float gl[MAXCLS];
+    for (int b = threadIdx.x; b < B; b += NT) t += cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
+    xe = block_total(t, c.red) / B;
   }
   if (threadIdx.x == 0) {
-    const float reg = x.reg ? x.reg[0] : 0.f;
-    out[8] = rec;
-    out[9] = -rec;
-    out[10] = -log_prob;
-    out[11] = reg;
-    out[1] = log_prob;
-    out[2] = pw;
-    out[3] = pb;
-    out[4] = qw;
-    out[5] = qb;
-    out[6] = xe1;
-    out[7] = xe2;
-    out[0] = -a.w_ll * log_prob + a.w_pw * pw + a.w_pb * pb + a.w_qw * qw + a.w_qb * qb + xe1 +
-             xe2 - rec + x.w_reg * reg;
-    if (x.loss) x.loss[0] = out[0];
+    out[prior ? 2 : 4] = within;
+    out[prior ? 3 : 5] = between;
+    out[prior ? 6 : 7] = xe;
   }
 }
 
+__global__ void tail_combine_kernel(TailArgs a, scae_loss_extras x, float *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float loss = -a.w_ll * out[1] + a.w_pw * out[2] + a.w_pb * out[3] + a.w_qw * out[4] +
+                     a.w_qb * out[5] + out[6] + out[7] - out[8] + x.w_reg * out[11];
+  out[0] = loss;
+  if (x.loss) x.loss[0] = loss;
+}
+
+// Backward: four independent workgroups (blockIdx.x = role), disjoint outputs.
+// role 0: g_lpp, g_rec_sums, g_reg; role 1: prior sparsity -> g_caps_presence;
+// role 2: posterior sparsity -> g_posterior; role 3: both classification terms
+// -> g_cls_w, g_cls_b.
 __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extras x,
                                                       const float *gout /*[12]*/, float *g_lpp,
                                                       float *g_post, float *g_cp, float *g_w,
                                                       float *g_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int B = a.B, O = a.O, M = a.M;
+  const int B = a.B, O = a.O, M = a.M, role = blockIdx.x;
   const Carve c = carve(smem, B, O, a.ncls);
-  load_stats(a, c);
-  // d(total)/d(component): the tail loss plus whatever flowed into the
-  // individually exposed log entries
-  // d/d(loss) may arrive on the 12-vector, on the separate scalar, or both
+  // d(total)/d(component): the loss plus whatever flowed into the individually
+  // exposed log entries; d/d(loss) may arrive on the 12-vector, on the separate
+  // scalar, or both
   float go[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) go[i] = gout ? gout[i] : 0.f;
   if (x.g_loss) go[0] += x.g_loss[0];
   const float g0 = go[0];
-  const float g_lp = -a.w_ll * g0 + go[1] - go[10];
-  if (x.g_rec_sums) {
-    const float gr = (-g0 + go[8] - go[9]) / B;
-    for (int i = threadIdx.x; i < x.n_rec; i += NT) x.g_rec_sums[i] = gr;
+  if (role == 0) {
+    const float g_lp = -a.w_ll * g0 + go[1] - go[10];
+    if (x.g_rec_sums) {
+      const float gr = (-g0 + go[8] - go[9]) / B;
+      for (int i = threadIdx.x; i < x.n_rec; i += NT) x.g_rec_sums[i] = gr;
+    }
+    if (x.g_reg && threadIdx.x == 0) x.g_reg[0] = x.w_reg * g0 + go[11];
+    for (int i = threadIdx.x; i < B * M; i += NT) g_lpp[i] = g_lp / B;
+    return;
   }
-  if (x.g_reg && threadIdx.x == 0) x.g_reg[0] = x.w_reg * g0 + go[11];
-  const float g_pw = a.w_pw * g0 + go[2], g_pb = a.w_pb * g0 + go[3];
-  const float g_qw = a.w_qw * g0 + go[4], g_qb = a.w_qb * g0 + go[5];
+  // reuse LDS: a gradient accumulator over (B,O) and a per-row scratch
+  float *gacc = c.gl + 2 * B * MAXCLS;  // [B*O]
+  float *tmp = gacc + 2 * B * O;        // [B]
+  if (role == 1 || role == 2) {
+    const bool prior = role == 1;
+    load_stats(a, c, prior, !prior);
+    for (int i = threadIdx.x; i < B * O; i += NT) gacc[i] = 0.f;
+    __syncthreads();
+    if (a.sparsity_on) {
+      if (prior)
+        sparsity_bwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
+                     a.l2_between_const, a.w_pw * g0 + go[2], a.w_pb * g0 + go[3], gacc, tmp);
+      else
+        sparsity_bwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type,
+                     a.l2_within_const_post, a.l2_between_const_post, a.w_qw * g0 + go[4],
+                     a.w_qb * g0 + go[5], gacc, tmp);
+    }
+    __syncthreads();
+    if (prior) {
+      for (int i = threadIdx.x; i < B * O; i += NT) g_cp[i] = gacc[i];
+    } else {
+      // posterior (B,O+1,M): mass/M = sum_m post / M; the dummy row gets zero
+      for (int i = threadIdx.x; i < B * (O + 1) * M; i += NT) {
+        const int bo = i / M, o = bo % (O + 1), b = bo / (O + 1);
+        g_post[i] = o < O ? gacc[b * O + o] / M : 0.f;
+      }
+    }
+    return;
+  }
+  // role 3: classifier parameter gradients (inputs are detached)
+  if (!(a.label && g_w)) return;
   const float g_x1 = g0 + go[6], g_x2 = g0 + go[7];
-
-  for (int i = threadIdx.x; i < B * M; i += NT) g_lpp[i] = g_lp / B;
-
-  // reuse LDS: gradient accumulators for cp and mass/M
-  float *gc = c.gl + 2 * B * MAXCLS;  // [B*O]
-  float *gm = gc + B * O;             // [B*O]
-  float *tmp = gm + B * O;            // [B]
-  for (int i = threadIdx.x; i < B * O; i += NT) gc[i] = gm[i] = 0.f;
+  load_stats(a, c, true, true, false);
+  float gl[MAXCLS];
+  for (int i = threadIdx.x; i < B * O; i += NT) gacc[i] = c.mass[i] * M;  // second input
   __syncthreads();
-  if (a.sparsity_on) {
-    sparsity_bwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
-                 a.l2_between_const, g_pw, g_pb, gc, tmp);
-    __syncthreads();
-    sparsity_bwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type, a.l2_within_const_post,
-                 a.l2_between_const_post, g_qw, g_qb, gm, tmp);
+  for (int e = threadIdx.x; e < 2 * B; e += NT) {
+    const int which = e / B, b = e - which * B;
+    cls_xe(a, (which ? gacc : c.cp) + b * O, (int)a.label[b], gl);
+    const float gx = which ? g_x2 : g_x1;
+#pragma unroll
+    for (int cc = 0; cc < MAXCLS; ++cc)
+      if (cc < a.ncls) c.gl[e * MAXCLS + cc] = gl[cc] * gx / B;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < B * O; i += NT) g_cp[i] = gc[i];
-  // posterior (B,O+1,M): mass/M = sum_m post / M; the dummy row gets zero
-  for (int i = threadIdx.x; i < B * (O + 1) * M; i += NT) {
-    const int m = i % M, bo = i / M, o = bo % (O + 1), b = bo / (O + 1);
-        g_post[i] = o < O ? gm[b * O + o] / M : 0.f;
+  for (int i = threadIdx.x; i < a.ncls * O; i += NT) {
+    const int cc = i / O, o = i - cc * O;
+    float t = 0.f;
+    for (int b = 0; b < B; ++b)
+      t += c.gl[b * MAXCLS + cc] * c.cp[b * O + o] + c.gl[(B + b) * MAXCLS + cc] * gacc[b * O + o];
+    g_w[i] = t;
   }
-  // classifier parameter gradients (inputs are detached)
-  if (a.label && g_w) {
-    float gl[MAXCLS];
-    for (int b = threadIdx.x; b < B; b += NT) {
-      cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
-#pragma unroll
-      for (int cc = 0; cc < MAXCLS; ++cc)
-        if (cc < a.ncls) c.gl[b * MAXCLS + cc] = gl[cc] * g_x1 / B;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < B * O; i += NT) gc[i] = c.mass[i] * M;  // second input
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += NT) {
-      cls_xe(a, gc + b * O, (int)a.label[b], gl);
-#pragma unroll
-      for (int cc = 0; cc < MAXCLS; ++cc)
-        if (cc < a.ncls) c.gl[(B + b) * MAXCLS + cc] = gl[cc] * g_x2 / B;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < a.ncls * O; i += NT) {
-      const int cc = i / O, o = i - cc * O;
-      float t = 0.f;
-      for (int b = 0; b < B; ++b)
-        t += c.gl[b * MAXCLS + cc] * c.cp[b * O + o] + c.gl[(B + b) * MAXCLS + cc] * gc[b * O + o];
-      g_w[i] = t;
-    }
-    for (int cc = threadIdx.x; cc < a.ncls; cc += NT) {
-      float t = 0.f;
-      for (int b = 0; b < B; ++b) t += c.gl[b * MAXCLS + cc] + c.gl[(B + b) * MAXCLS + cc];
-      g_b[cc] = t;
-    }
+  for (int cc = threadIdx.x; cc < a.ncls; cc += NT) {
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += c.gl[b * MAXCLS + cc] + c.gl[(B + b) * MAXCLS + cc];
+    g_b[cc] = t;
   }
 }
 
@@ -422,7 +442,8 @@ extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(tail_fwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, x, out12);
+  hipLaunchKernelGGL(tail_fwd_kernel, dim3(3), dim3(NT), lds, (hipStream_t)stream, a, x, out12);
+  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, x, out12);
   return scae_launch_status();
 }
 
@@ -452,7 +473,7 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, a, x, gout12,
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(4), dim3(NT), lds, (hipStream_t)stream, a, x, gout12,
                      g_lpp, g_posterior, g_caps_presence, g_cls_w, g_cls_b);
   return scae_launch_status();
 }
