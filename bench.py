@@ -8,7 +8,8 @@ MNIST 40x40, 24 part / 24 object capsules, bs=128 per GPU, fp32.
   (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 Prints ONE JSON line on rank 0 (contract in the task brief), extended with
-  roofline     : the dominant hot-path kernel (K1) timed live with HIP events
+  roofline     : the dominant hand-written kernel (K8 conv data gradient) timed
+                 live with HIP events, K1 / other K8 kernels alongside
   cpu_baseline : the oracle (CPU restatement of the reference) timed on the
                  host cores of this box, same config, bounded sample.
 """
@@ -46,6 +47,7 @@ CONFIGS = {
         batch=256),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_FP32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz)
 
 
 def parse():
@@ -159,32 +161,119 @@ def time_k1_kernels(cfg, device, reps=200):
     return out
 
 
+def conv_layers(cfg):
+    """(IH, Cin, Cout, stride) of the implicit-GEMM layers of the CNN encoder
+    (every layer but the first), from the model the workload builds."""
+    from torch_scae_amd import factory
+    m = factory.make_scae(dict(cfg["model"]))
+    convs = [c for c in m.part_encoder.encoder.network
+             if isinstance(c, torch.nn.Conv2d)]
+    H = cfg["model"]["image_shape"][1]
+    out = []
+    for i, c in enumerate(convs):
+        if i > 0:
+            out.append((H, c.in_channels, c.out_channels, c.stride[0]))
+        H = (H - 3) // c.stride[0] + 1
+    return out
+
+
+def time_k8_kernels(cfg, device, reps=50):
+    """Average duration of every K8 implicit-GEMM launch of one step (forward,
+    data gradient, weight gradient of each encoder layer), timed like the K1
+    kernels: raw C-ABI launches on torch's current stream between HIP events."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
+    lib, B = _lib.load(), cfg["batch"]
+    p, I = ops._p, ctypes.c_int
+    out = {}
+    for li, (IH, Ci, Co, s) in enumerate(conv_layers(cfg)):
+        OH = (IH - 3) // s + 1
+        f = lambda *sh: torch.randn(*sh, device=device)   # noqa: E731
+        x, w, bias = f(B, IH, IH, Ci), f(Co, Ci, 3, 3), f(Co)
+        wf, wd = f(Co, 9, Ci), f(Ci, 9, Co)
+        y, dy, dx, dw, db = f(B, OH, OH, Co), f(B, OH, OH, Co), f(B, IH, IH, Ci), \
+            f(Co, Ci, 3, 3), f(Co)
+        st = ops._stream(x)
+        lib.scae_conv3x3_relayout_f32(p(w), p(wf), p(wd), Co, Ci, st)
+        splits = lib.scae_conv3x3_wgrad_splits(B, OH, OH, Ci, Co)
+        part = f(splits * (9 * Co * Ci + Co))
+        geo = (I(B), I(IH), I(IH), I(Ci), I(Co), I(s))
+        calls = {
+            "conv_fwd_kernel": lambda: lib.scae_conv3x3_fwd_f32(
+                p(x), p(wf), p(bias), p(y), *geo, st),
+            "conv_dgrad_kernel": lambda: lib.scae_conv3x3_dgrad_f32(
+                p(dy), p(wd), p(x), p(dx), *geo, st),
+            "conv_wgrad_kernel": lambda: lib.scae_conv3x3_wgrad_f32(
+                p(dy), p(x), p(part), p(dw), p(db), *geo, st),
+        }
+        flops = 2.0 * B * OH * OH * Co * 9 * Ci        # MACs x 2, all 3 passes
+        for name, fn in calls.items():
+            for _ in range(5):
+                assert fn() == 0
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            best = float("inf")
+            for _ in range(3):
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            out.setdefault(name, []).append(
+                dict(layer=li + 2, seconds=best * 1e-3 / reps, flops=flops))
+    return out
+
+
 def roofline(cfg, device):
-    dur = time_k1_kernels(cfg, device)
+    """Roofline of the dominant hand-written kernel of the step.  By rocprofv3
+    total time per step that is the implicit-GEMM data-gradient kernel of the
+    CNN encoder (K8, MFMA-bound): achieved = algorithmic FLOPs of its launches
+    (2 x MACs of the convolution, zero-padding work not counted) / their
+    measured duration.  The K1 likelihood kernels (HBM/VALU) and the other K8
+    passes are reported alongside."""
+    k1 = time_k1_kernels(cfg, device)
     alg = k1_algorithmic_bytes(cfg)
     B = cfg["batch"]
-    name = max(dur, key=dur.get)                # the dominant K1 kernel
-    achieved = alg[name] * B / dur[name] / 1e9
+    k8 = time_k8_kernels(cfg, device)
+    name = "conv_dgrad_kernel"
+    launches = k8[name]
+    secs = sum(l["seconds"] for l in launches)
+    flops = sum(l["flops"] for l in launches)
+    achieved = flops / secs / 1e12
     # HBM traffic per launch from the committed rocprofv3 --pmc passes
-    # (profiles/r01/k1_pmc.json; counters cannot be read from inside this run)
+    # (counters cannot be read from inside this run)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "k1_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r01", "k8_pmc.json")
     if os.path.exists(pmc) and cfg is CONFIGS["mnist_24_24_bs128"]:
         k = json.load(open(pmc))["kernels"].get(name)
         if k:
             traffic = k["hbm_bytes_per_launch_raw"]
+    others = {
+        k: {"us": round(v * 1e6, 2), "bound": "hbm",
+            "GBps": round(alg[k] * B / v / 1e9, 1),
+            "frac": round(alg[k] * B / v / 1e9 / HBM_PEAK_GBS, 4),
+            "bytes_per_image": alg[k]} for k, v in k1.items()}
+    for k, ls in k8.items():
+        t, fl = sum(l["seconds"] for l in ls), sum(l["flops"] for l in ls)
+        others[k] = {"us_per_step": round(t * 1e6, 2), "launches": len(ls),
+                     "bound": "mfma", "TFLOPs": round(fl / t / 1e12, 1),
+                     "frac": round(fl / t / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4)}
     return {
-        "kernel": name, "bound": "hbm", "achieved": round(achieved, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "us_per_launch": round(dur[name] * 1e6, 2),
-        "all_k1_kernels": {
-            k: {"us": round(dur[k] * 1e6, 2),
-                "GBps": round(alg[k] * B / dur[k] / 1e9, 1),
-                "bytes_per_image": alg[k]} for k in dur},
-        "algorithmic_bytes_per_launch": alg[name] * B,
-        "note": "traffic = FETCH_SIZE+WRITE_SIZE per launch from "
-                "profiles/r01/k1_pmc.json (separate rocprofv3 --pmc passes)",
+        "kernel": name, "bound": "mfma", "achieved": round(achieved, 1),
+        "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / MFMA_FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+        "us_per_launch": round(secs / len(launches) * 1e6, 2),
+        "launches_per_step": len(launches),
+        "algorithmic_flops_per_launch": flops / len(launches),
+        "per_layer_us": [round(l["seconds"] * 1e6, 2) for l in launches],
+        "other_kernels": others,
+        "note": "achieved/us_per_launch/algorithmic_flops_per_launch are "
+                "averages over the kernel's launches of one step (one per "
+                "encoder layer); traffic = FETCH_SIZE+WRITE_SIZE per launch "
+                "from profiles/r01/k8_pmc.json (separate rocprofv3 --pmc "
+                "passes); K1 byte figures: DESIGN.md section 4",
     }
 
 
