@@ -7,8 +7,9 @@
 // step as Wf[co][tap][ci] (forward) and Wd[ci][tap][co] (data gradient).
 //   forward : out[m][co]      = relu(sum_{tap,ci} in[pix(m,tap)][ci] Wf[co][tap][ci] + b)
 //   dgrad   : din[m'][ci]     = gate(sum_{tap,co} dpre[opix(m',tap)][co] Wd[ci][tap][co])
-//             blockIdx.z = stride-parity class of the input pixel, so that no
-//             tile multiplies structurally-zero taps
+//             tiles hold input pixels that are reached by the same set of taps
+//             (border / stride-parity classes), so that no tile multiplies
+//             structurally-zero taps
 //   wgrad   : dW[tap][co][ci] = sum_m dpre[m][co] in[pix(m,tap)][ci]   (split over m),
 //             db[co] = sum_m dpre[m][co] falls out of the staged A operand
 // All passes share one MFMA tile loop (v_mfma_f32_16x16x4_f32, exact fp32
@@ -86,23 +87,80 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ 
   });
 }
 
-// ---- data gradient: grid (Cin/T, ceil(M0/T), stride^2) ---------------------------
-// din rows of parity class (ph, pw): (n, a, b) -> input pixel (s*a + ph, s*b + pw).
-// gate: the ReLU output of the producing layer at the same pixels, or nullptr.
+// ---- data gradient ------------------------------------------------------------------
+// din[pixel][ci] = gate(sum over the taps that reach the pixel of dpre[.][co] Wd[ci][tap][co]).
+// An input row ih receives tap kh iff (ih - kh) is a multiple of the stride and
+// (ih - kh)/s < OH: near the border (and for one stride parity) most of the nine
+// taps miss.  Rows are therefore grouped into classes of equal valid-kh set,
+// columns likewise; a workgroup tile holds pixels of ONE (row class, column
+// class) pair and walks exactly that pair's taps -- no MFMA multiplies a
+// structural zero (on a 7x7 input 51 % of the gather formulation would), and
+// the operand fetch needs no bounds checks.  gate: the ReLU output of the
+// producing layer at the same pixels, or nullptr.
+constexpr int DG_MAXDIM = 128;  // input height / width covered by the class tables
+struct DgradPlan {
+  int nrc, ncc;                      // row / column classes (<= 8 each)
+  unsigned char rmask[8], cmask[8];  // bit kh (kw) set: the tap reaches the class
+  short rcount[8], ccount[8], rstart[8], cstart[8];
+  unsigned char rlist[DG_MAXDIM], clist[DG_MAXDIM];  // ih (iw) of each class, ascending
+  int tile_start[65];                // first tile (along grid.y) of class pair z
+};
+
+// classes of one axis: returns the number of classes.  Stride 1: one class per
+// distinct valid-tap set (interior + the border rows).  Stride 2: one class per
+// parity (tap sets differ mainly by parity there; splitting the single border
+// row off each parity fragments the tiles for no gain -- measured), the class
+// mask is the union and the fetch bounds-checks.
+inline int dgrad_axis(int I, int O, int stride, unsigned char *mask, short *count, short *start,
+                      unsigned char *list) {
+  auto taps = [&](int i) {
+    int m = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int d = i - k;
+      if (d >= 0 && d % stride == 0 && d / stride < O) m |= 1 << k;
+    }
+    return m;
+  };
+  int n = 0, pos = 0;
+  for (int want = 0; want < (stride == 1 ? 8 : stride); ++want) {
+    int cnt = 0, m = 0;
+    for (int i = 0; i < I; ++i)
+      if ((stride == 1 ? taps(i) : i % stride) == want) {
+        list[pos + cnt++] = (unsigned char)i;
+        m |= taps(i);
+      }
+    if (cnt) {
+      mask[n] = (unsigned char)m, count[n] = (short)cnt, start[n] = (short)pos;
+      pos += cnt, ++n;
+    }
+  }
+  return n;
+}
+
 template <bool SK>
 __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict__ dpre,
                                                         const float *__restrict__ wd,
                                                         const float *__restrict__ gate,
-                                                        float *__restrict__ din, ConvGeom g) {
-  const int ph = blockIdx.z / g.stride, pw = blockIdx.z % g.stride;
-  const int AH = (g.IH - ph + g.stride - 1) / g.stride, AW = (g.IW - pw + g.stride - 1) / g.stride;
-  const int M = g.B * AH * AW, KT = 9 * g.Cout;
-  if ((int)blockIdx.y * Tile<SK>::T >= M) return;
+                                                        float *__restrict__ din, ConvGeom g,
+                                                        DgradPlan pl) {
   SCAE_TILE_PROLOGUE
-  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T, sh = g.stride - 1;  // stride 1 or 2
-  // valid taps of this class: kh = ph + s*u, kw = pw + s*v (< 3); each Cout/32 chunks
-  const int nw = (2 - pw) / g.stride + 1, ntap = ((2 - ph) / g.stride + 1) * nw;
-  const int cpt = g.Cout / BK, nchunk = ntap * cpt;
+  // class pair of this tile: the number of class starts at or before it
+  const int nz = pl.nrc * pl.ncc;
+  const int z = __popcll(__ballot(lane + 1 < nz && (int)blockIdx.y >= pl.tile_start[min(lane + 1, 64)]));
+  const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
+  const int AH = pl.rcount[rc], AW = pl.ccount[cc], M = g.B * AH * AW, KT = 9 * g.Cout;
+  const int m0 = ((int)blockIdx.y - pl.tile_start[z]) * T, n0 = blockIdx.x * T;
+  const int sh = g.stride - 1;  // stride 1 or 2
+  // the class pair's taps: set bits of rmask x cmask
+  const int rm = pl.rmask[rc], cm = pl.cmask[cc];
+  const int nkh = __popc(rm), nkw = __popc(cm);
+  auto nth_bit = [](int mask, int n) {  // n-th set bit of a 3-bit mask
+    const int k0 = (mask & 1) ? 0 : ((mask & 2) ? 1 : 2);
+    if (n == 0) return k0;
+    const int rest = mask & ~(1 << k0);
+    return (n == 1 && (rest & 2)) ? 1 : 2;
+  };
+  const int cpt = g.Cout / BK, nchunk = nkh * nkw * cpt;
   int pn[NQ], pih[NQ], piw[NQ];
   const float *bptr[NQ];
 #pragma unroll
@@ -111,16 +169,20 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
     pn[i] = -1, pih[i] = 0, piw[i] = 0;
     if (m < M) {
       const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
-      pn[i] = n * g.OH * g.OW, pih[i] = g.stride * a + ph, piw[i] = g.stride * b + pw;
+      pn[i] = n * g.OH * g.OW;
+      pih[i] = pl.rlist[pl.rstart[rc] + a], piw[i] = pl.clist[pl.cstart[cc] + b];
     }
     bptr[i] = wd + (size_t)(n0 + id / QPR) * KT + kq;
   }
   auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
     const int t = c / cpt, co0 = (c - t * cpt) * BK;
-    const int kh = ph + g.stride * (t / nw), kw = pw + g.stride * (t % nw);
+    const int ti = t / nkw, tj = t - ti * nkw;
+    const int kh = nth_bit(rm, ti), kw = nth_bit(cm, tj);
     const int koff = (kh * 3 + kw) * g.Cout + co0;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
+      // (ih - kh) is a multiple of the stride for every tap of the class; the
+      // range check only ever fails on the merged classes of stride 2
       const int dh = pih[i] - kh, dw = piw[i] - kw, oh = dh >> sh, ow = dw >> sh;
       const bool ok = pn[i] >= 0 && dh >= 0 && dw >= 0 && oh < g.OH && ow < g.OW;
       ra.v[i] = ok ? ld4(dpre + (size_t)(pn[i] + oh * g.OW + ow) * g.Cout + co0 +
@@ -135,8 +197,8 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
     const int m = m0 + row;
     if (m >= M) return;
     const int nb = m / (AH * AW), rem = m - nb * AH * AW, a = rem / AW, b = rem - a * AW;
-    const size_t o =
-        (((size_t)nb * g.IH + g.stride * a + ph) * g.IW + g.stride * b + pw) * g.Cin + n0 + col;
+    const int ih = pl.rlist[pl.rstart[rc] + a], iw = pl.clist[pl.cstart[cc] + b];
+    const size_t o = (((size_t)nb * g.IH + ih) * g.IW + iw) * g.Cin + n0 + col;
     if (gate) {
       const float4 gt = ld4(gate + o);
       v.x = gt.x > 0.f ? v.x : 0.f, v.y = gt.y > 0.f ? v.y : 0.f;
@@ -445,15 +507,28 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
   int rc = check_geom(g, true);
   if (rc) return rc;
   SCAE_REQUIRE(dpre && wd && din);
-  // class (0,0) is the largest; smaller classes leave their surplus tiles early
-  const int M0 = B * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride);
-  const int Z = stride * stride;
-  if (small_tiles((long)(Cin / 64) * ((M0 + 63) / 64) * Z))
-    hipLaunchKernelGGL(conv_dgrad_kernel<true>, dim3(Cin / 32, (M0 + 31) / 32, Z), dim3(NT), 0,
-                       (hipStream_t)stream, dpre, wd, gate, din, g);
-  else
-    hipLaunchKernelGGL(conv_dgrad_kernel<false>, dim3(Cin / 64, (M0 + 63) / 64, Z), dim3(NT), 0,
-                       (hipStream_t)stream, dpre, wd, gate, din, g);
+  if (IH > DG_MAXDIM || IW > DG_MAXDIM) return SCAE_ERR_UNSUPPORTED;
+  DgradPlan pl;
+  pl.nrc = dgrad_axis(IH, g.OH, stride, pl.rmask, pl.rcount, pl.rstart, pl.rlist);
+  pl.ncc = dgrad_axis(IW, g.OW, stride, pl.cmask, pl.ccount, pl.cstart, pl.clist);
+  auto tiles = [&](int T) {  // fills tile_start for tile size T, returns the total
+    int tot = 0;
+    for (int z = 0; z < pl.nrc * pl.ncc; ++z) {
+      pl.tile_start[z] = tot;
+      tot += (B * pl.rcount[z / pl.ncc] * pl.ccount[z % pl.ncc] + T - 1) / T;
+    }
+    pl.tile_start[pl.nrc * pl.ncc] = tot;
+    return tot;
+  };
+  if (small_tiles((long)(Cin / 64) * tiles(64))) {
+    const int ny = tiles(32);
+    hipLaunchKernelGGL(conv_dgrad_kernel<true>, dim3(Cin / 32, ny), dim3(NT), 0,
+                       (hipStream_t)stream, dpre, wd, gate, din, g, pl);
+  } else {
+    const int ny = tiles(64);
+    hipLaunchKernelGGL(conv_dgrad_kernel<false>, dim3(Cin / 64, ny), dim3(NT), 0,
+                       (hipStream_t)stream, dpre, wd, gate, din, g, pl);
+  }
   return scae_launch_status();
 }
 
