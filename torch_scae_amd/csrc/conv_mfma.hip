@@ -223,6 +223,18 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict_
   const int co0 = blockIdx.y * T, ci0 = blockIdx.x * T;
   const bool want_bias = tap == 0 && blockIdx.x == 0;  // workgroup-uniform
   float4 bsum = zero4();
+  // each thread stages pixel m = kbeg + c*BK + (its k slot) of chunk c; the
+  // mainloop fetches chunks in ascending order exactly once, so (n, oh, ow) of
+  // that pixel is carried from chunk to chunk instead of re-divided
+  int pn[NQ], poh[NQ], pow_[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int m = kbeg + (tid + NT * i) / (T / 4);
+    pn[i] = m / (g.OH * g.OW);
+    const int rem = m - pn[i] * g.OH * g.OW;
+    poh[i] = rem / g.OW, pow_[i] = rem - poh[i] * g.OW;
+  }
+  const int dq = BK / g.OW, dr = BK - dq * g.OW;
   auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
     const int k0 = kbeg + c * BK;
 #pragma unroll
@@ -230,12 +242,16 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict_
       const int id = tid + NT * i, m = k0 + id / (T / 4), rq = 4 * (id % (T / 4));
       ra.v[i] = rb.v[i] = zero4();
       if (m < kend) {
-        const int n = m / (g.OH * g.OW), rem = m - n * g.OH * g.OW, oh = rem / g.OW,
-                  ow = rem - oh * g.OW;
-        const size_t pix = ((size_t)n * g.IH + oh * g.stride + kh) * g.IW + ow * g.stride + kw;
+        const size_t pix = ((size_t)pn[i] * g.IH + poh[i] * g.stride + kh) * g.IW +
+                           pow_[i] * g.stride + kw;
         ra.v[i] = ld4(dpre + (size_t)m * g.Cout + co0 + rq);
         rb.v[i] = ld4(in + pix * g.Cin + ci0 + rq);
       }
+      pow_[i] += dr;  // advance by BK pixels
+      const int carry = pow_[i] >= g.OW;
+      pow_[i] -= carry ? g.OW : 0;
+      poh[i] += dq + carry;
+      while (poh[i] >= g.OH) poh[i] -= g.OH, ++pn[i];
     }
   };
   const int nchunk = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
