@@ -222,3 +222,69 @@ def test_flat_gradient_slots_match_plain_backward():
                                    plain.parameters()):
             want = q.grad if q.grad is not None else torch.zeros_like(q)
             assert torch.equal(v, want), (step, name)
+
+
+@pytest.mark.gpu
+def test_training_step_trajectory_vs_oracle_and_torch_rmsprop():
+    """the build's counterpart of BaseExperiment.training_step
+    + RMSprop(lr, momentum .9, eps 1e-2/bs^2) (base_experiment.py:44-77,
+    :109-126) against the oracle stepped by stock torch.optim.RMSprop: three
+    steps, same noise, loss trajectory / log keys / final parameters."""
+    from torch_scae_amd import factory
+    from torch_scae_amd.nn_utils import fixed_noise
+    from torch_scae_amd.train_step import TrainStep
+    cfg = dict(image_shape=(1, 16, 16), n_classes=4, n_part_caps=5,
+               n_obj_caps=4,
+               pcae_cnn_encoder_params=dict(out_channels=[64, 64],
+                                            kernel_sizes=[3, 3],
+                                            strides=[2, 1]),
+               pcae_template_generator_params=dict(template_size=(5, 5)),
+               ocae_encoder_set_transformer_params=dict(dim_hidden=8,
+                                                        dim_out=64, n_layers=2),
+               ocae_decoder_capsule_params=dict(dim_caps=4, hidden_sizes=(8,)),
+               scae_params=dict(reconstruct_alternatives=False))
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.normal_(0, 0.1)
+    B, lr, wd = 4, 2e-3, 1e-3
+    P = {k: v.clone().requires_grad_(True)
+         for k, v in model.state_dict().items()}
+    ocfg = O.prepare_model_params(**cfg)
+    ropt = torch.optim.RMSprop(list(P.values()), lr=lr, momentum=0.9,
+                               eps=1e-2 / B ** 2, weight_decay=wd)
+    model = model.cuda().train()
+    step = TrainStep(model, B, (1, 16, 16), lr=lr, use_graph=False,
+                     weight_decay=wd, lr_decay_rate=0.5)
+    g = torch.Generator().manual_seed(7)
+    for it in range(3):
+        image = torch.rand(B, 1, 16, 16, generator=g)
+        label = torch.randint(0, 4, (B,), generator=g)
+        noise = [torch.rand(B, 5, generator=g), torch.rand(B, 4, 1, generator=g),
+                 torch.rand(B, 4, 5, generator=g)]
+        ref_loss, ref_log, ref_grads = O.train_step(P, ocfg, image, label,
+                                                    noise)
+        ropt.zero_grad(set_to_none=True)
+        for k, p in P.items():
+            p.grad = ref_grads[k]
+        ropt.step()
+        with fixed_noise([n.clone() for n in noise]):
+            out = step.training_step(image.cuda(), label.cuda())
+        assert abs(float(out["loss"]) - float(ref_loss)) <= \
+            1e-4 * max(1.0, abs(float(ref_loss))), (it, float(out["loss"]),
+                                                    float(ref_loss))
+        assert set(out["log"]) == set(ref_log) | {"loss", "accuracy"}, \
+            set(out["log"]) ^ set(ref_log)
+        for k, v in ref_log.items():
+            assert abs(float(out["log"][k]) - float(v)) <= \
+                1e-4 * max(1.0, abs(float(v))), (it, k)
+        if it == 1:      # "epoch end": ExponentialLR on both sides
+            step.end_epoch()
+            for grp in ropt.param_groups:
+                grp["lr"] *= 0.5
+    sd = model.state_dict()
+    for k, p in P.items():
+        assert_close(sd[k].cpu(), p.detach(), 1e-4, 2e-3, "param " + k)

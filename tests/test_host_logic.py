@@ -149,3 +149,43 @@ def test_fixed_noise_replay_and_shape_check():
     with nn_utils.fixed_noise([a]):
         with pytest.raises(ValueError):
             nn_utils.rand_like(torch.empty(4, 4))
+
+
+def test_checkpoint_interchange_roundtrip():
+    """Lightning-prefixed reference checkpoints load, and export back."""
+    from torch_scae_amd import checkpoint, factory
+    cfg = dict(image_shape=(1, 28, 28), n_classes=3, n_part_caps=4,
+               n_obj_caps=3)
+    torch.manual_seed(0)
+    a, b = factory.make_scae(cfg), factory.make_scae(cfg)
+    ck = checkpoint.to_reference_checkpoint(a, epoch=7)
+    assert all(k.startswith("scae.") for k in ck["state_dict"])
+    # per-capsule keys of the reference layout, not the stacked ones
+    assert any(".mlps.0.0.weight" in k for k in ck["state_dict"])
+    checkpoint.load_reference_checkpoint(b, ck)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(),
+                                  b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    # a bare state_dict (no wrapper, no prefix) is accepted too
+    checkpoint.load_reference_checkpoint(b, a.state_dict())
+
+
+def test_mnist_pad_and_translate():
+    """mnist/experiment.py:23-40: pad 28 -> 40, integer shifts within +-6."""
+    from torch_scae_amd.data import pad_and_translate
+    g = torch.Generator().manual_seed(0)
+    digits = torch.randint(0, 256, (9, 1, 28, 28), generator=g,
+                           dtype=torch.uint8)
+    shifts = torch.tensor([[0, 0], [6, 6], [-6, -6], [3, -2], [-1, 5],
+                           [6, -6], [0, 4], [-5, 0], [2, 2]])
+    out = pad_and_translate(digits, (40, 40), shifts=shifts)
+    assert out.shape == (9, 1, 40, 40) and out.dtype == torch.float32
+    for b, (dy, dx) in enumerate(shifts.tolist()):
+        want = torch.zeros(40, 40)
+        want[6 + dy:34 + dy, 6 + dx:34 + dx] = digits[b, 0].float() / 255
+        assert torch.equal(out[b, 0], want), b
+    rnd = pad_and_translate(digits, (40, 40), generator=g)
+    assert torch.allclose(rnd.flatten(1).sum(1),
+                          digits.float().flatten(1).sum(1) / 255)
+    assert torch.equal(pad_and_translate(digits[:, :, :, :], (28, 28)),
+                       digits.float() / 255)

@@ -105,6 +105,21 @@ class FlatParameters:
                 v.zero_()
             p._flat_was_set = p.grad is not None
 
+    def active_ranges(self):
+        """[(offset, numel)] of the maximal runs of parameters that received a
+        gradient in the last backward (torch optimisers skip ``grad is None``
+        parameters altogether -- it matters with weight decay)."""
+        runs, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            if getattr(p, "_flat_was_set", True):
+                if runs and runs[-1][0] + runs[-1][1] == off:
+                    runs[-1][1] += n
+                else:
+                    runs.append([off, n])
+            off += n
+        return [tuple(r) for r in runs]
+
 
 def world():
     if dist.is_available() and dist.is_initialized():
@@ -131,28 +146,55 @@ def all_reduce_gradients(flat: FlatParameters, async_op=False):
 class RMSpropFlat:
     """RMSprop with momentum on the flat buffers -- the reference's default
     optimiser (torch.optim.RMSprop(lr, momentum=0.9, eps=1e-2/bs**2,
-    weight_decay=0), base_experiment.py:44-77), evaluated as a handful of
-    whole-buffer elementwise ops instead of one small launch per tensor."""
+    weight_decay), base_experiment.py:44-77) as ONE fused pass over the flat
+    buffers on a HIP device (a handful of whole-buffer ops on CPU tensors, which
+    only the host-logic tests use).  The learning rate lives in device memory
+    so that ``decay_lr`` (the per-epoch ExponentialLR of :73-76) takes effect
+    inside an already captured HIP graph."""
 
     def __init__(self, flat: FlatParameters, lr=3e-5, alpha=0.99, eps=1e-8,
-                 momentum=0.9):
+                 momentum=0.9, weight_decay=0.0):
         self.flat = flat
         self.lr, self.alpha, self.eps, self.momentum = lr, alpha, eps, momentum
+        self.weight_decay = weight_decay
         self.square_avg = torch.zeros_like(flat.flat_param)
         self.buf = torch.zeros_like(flat.flat_param)
+        self.lr_dev = torch.full((1,), lr, device=flat.flat_param.device,
+                                 dtype=flat.flat_param.dtype)
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self.lr_dev.fill_(self.lr)
+
+    def decay_lr(self, gamma):
+        """One ExponentialLR step (call once per epoch, gamma = decay_rate)."""
+        self.set_lr(self.lr * gamma)
 
     @torch.no_grad()
     def step(self):
         g = self.flat.flat_grad
+        # parameters without a gradient are left alone, like torch.optim does;
+        # without weight decay a zero gradient already is a no-op
+        ranges = self.flat.active_ranges() if self.weight_decay != 0 else \
+            [(0, g.numel())]
         if g.is_cuda:      # one fused pass over the four flat buffers
             from . import _lib
             P = ctypes.c_void_p
-            _lib.call("scae_rmsprop_step_f32", P(self.flat.flat_param.data_ptr()),
-                      P(g.data_ptr()), P(self.square_avg.data_ptr()),
-                      P(self.buf.data_ptr()), g.numel(), self.lr, self.alpha,
-                      self.eps, self.momentum,
-                      P(torch.cuda.current_stream(g.device).cuda_stream))
+            st = P(torch.cuda.current_stream(g.device).cuda_stream)
+            for off, n in ranges:
+                ptr = lambda t: P(t.data_ptr() + 4 * off)   # noqa: E731
+                _lib.call("scae_rmsprop_step_f32", ptr(self.flat.flat_param),
+                          ptr(g), ptr(self.square_avg), ptr(self.buf), n,
+                          self.lr, P(self.lr_dev.data_ptr()), self.alpha,
+                          self.eps, self.momentum, self.weight_decay, st)
             return
+        if self.weight_decay != 0:
+            keep = torch.zeros_like(g, dtype=torch.bool)
+            for off, n in ranges:
+                keep[off:off + n] = True
+            saved = (self.flat.flat_param.clone(), self.square_avg.clone(),
+                     self.buf.clone())
+            g = g.add(self.flat.flat_param, alpha=self.weight_decay)
         self.square_avg.mul_(self.alpha).addcmul_(g, g, value=1 - self.alpha)
         avg = self.square_avg.sqrt().add_(self.eps)
         if self.momentum > 0:
@@ -160,3 +202,7 @@ class RMSpropFlat:
             self.flat.flat_param.add_(self.buf, alpha=-self.lr)
         else:
             self.flat.flat_param.addcdiv_(g, avg, value=-self.lr)
+        if self.weight_decay != 0:
+            for cur, old in zip((self.flat.flat_param, self.square_avg,
+                                 self.buf), saved):
+                cur.copy_(torch.where(keep, cur, old))

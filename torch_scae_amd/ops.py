@@ -960,8 +960,12 @@ class _CapsuleLikelihood(torch.autograd.Function):
                   _p(widx), *[_p(g) for g in gin], _p(gvote), _p(gscale),
                   _p(gvp), _p(gx), _p(gpres), _p(gdummy), B, O, M,
                   _stream(vote))
-        return (gvote, gscale, gvp, gdummy.sum(0).view(ctx.dummy_shape), gx,
-                gpres)
+        # the dummy vote only reaches the (soft) winner outputs: without a
+        # gradient on those it gets none at all, as in the reference
+        g_dummy = None
+        if g_w is not None or g_s is not None:
+            g_dummy = _sum_rows(gdummy.view(B, -1), [ctx.dummy_shape])[0]
+        return gvote, gscale, gvp, g_dummy, gx, gpres
 
 
 def capsule_likelihood(vote, scale, vote_presence, dummy_vote, x,

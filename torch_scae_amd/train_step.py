@@ -13,30 +13,47 @@ from .data_parallel import (FlatParameters, RMSpropFlat, all_reduce_gradients,
 
 class TrainStep:
     def __init__(self, model, batch_size, image_shape, lr=3e-5, use_graph=True,
-                 optimizer=True):
+                 optimizer=True, momentum=0.9, weight_decay=0.0,
+                 lr_decay_rate=0.997):
         self.model = model
         self.device = next(model.parameters()).device
         self.flat = FlatParameters(model)
         broadcast_parameters(self.flat)
         # eps = 1e-2 / bs**2 as in configs/optimizer/rmsprop.yaml
-        self.opt = RMSpropFlat(self.flat, lr=lr, momentum=0.9,
-                               eps=1e-2 / float(batch_size) ** 2) \
+        self.opt = RMSpropFlat(self.flat, lr=lr, momentum=momentum,
+                               eps=1e-2 / float(batch_size) ** 2,
+                               weight_decay=weight_decay) \
             if optimizer else None
+        self.lr_decay_rate = lr_decay_rate
+        self.log = None          # device tensors of the last step's log dict
         self.image = torch.zeros(batch_size, *image_shape, device=self.device)
         self.label = torch.zeros(batch_size, dtype=torch.long,
                                  device=self.device)
         self.loss = torch.zeros((), device=self.device)
         self.use_graph = use_graph
+        self._with_log = False
         self.graph = None
         self.world = world()[1]
 
     def _fwd_bwd(self):
         self.flat.clear_grads()
         res = self.model(self.image)
-        loss, _ = self.model.loss(res, self.image, self.label)
+        loss, info = self.model.loss(res, self.image, self.label)
         loss.backward()
         self.flat.gather_grads()
         self.loss.copy_(loss.detach())
+        if self._with_log:
+            # the `log` dict of BaseExperiment.training_step (:118-125)
+            acc = self.model.calculate_accuracy(res, self.label) \
+                if self.model.n_classes is not None else None
+            fresh = dict(loss=loss.detach(), **{k: v.detach()
+                                                for k, v in info.items()})
+            if acc is not None:
+                fresh["accuracy"] = acc.detach()
+            if self.log is None:
+                self.log = {k: torch.zeros_like(v) for k, v in fresh.items()}
+            for k, v in fresh.items():
+                self.log[k].copy_(v)
 
     def _finish(self):
         all_reduce_gradients(self.flat)
@@ -73,3 +90,18 @@ class TrainStep:
             self._fwd_bwd()
             self._finish()
         return self.loss
+
+    def training_step(self, image, label):
+        """-> {'loss': tensor, 'log': {...}} like BaseExperiment.training_step
+        (base_experiment.py:109-126); the log values are device tensors that
+        the next call overwrites.  Builds the step with the log outputs on
+        first use (costs a few extra small kernels per step)."""
+        if not self._with_log:
+            self._with_log, self.graph = True, None
+        loss = self(image, label)
+        return dict(loss=loss, log=self.log)
+
+    def end_epoch(self):
+        """Per-epoch ExponentialLR step (base_experiment.py:73-76)."""
+        if self.opt is not None and self.lr_decay_rate:
+            self.opt.decay_lr(self.lr_decay_rate)
