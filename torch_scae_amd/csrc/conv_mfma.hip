@@ -351,8 +351,10 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__rest
 #pragma unroll
     for (int k = 0; k < CIN * 9; ++k) wr[k] = w[(size_t)co * CIN * 9 + k];
     const float b = bias[co];
+    // (oh, ow) of pixel p carried along instead of divided out per pixel
+    int oh = (pbeg + part) / g.OW, ow = (pbeg + part) - oh * g.OW;
+    float *dst = out + ((size_t)n * P + pbeg + part) * g.Cout + co;
     for (int p = pbeg + part; p < pend; p += f.parts) {
-      const int oh = p / g.OW, ow = p - oh * g.OW;
       const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
       float acc = b;
 #pragma unroll
@@ -360,7 +362,10 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__rest
 #pragma unroll
         for (int t = 0; t < 9; ++t)
           acc = fmaf(src[(ci * g.IH + t / 3) * g.IW + t % 3], wr[ci * 9 + t], acc);
-      out[((size_t)n * P + p) * g.Cout + co] = fmaxf(acc, 0.f);
+      *dst = fmaxf(acc, 0.f);
+      dst += (size_t)f.parts * g.Cout;
+      ow += f.parts;
+      while (ow >= g.OW) ow -= g.OW, ++oh;
     }
   }
 }
@@ -377,30 +382,57 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
   const FirstSplit f = first_split(g.B, g.Cout);
   const int n = blockIdx.x / f.slices, slice = blockIdx.x % f.slices;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  stage_image(s_img, img, n, CIN * g.IH * g.IW);
+  const int img_floats = CIN * g.IH * g.IW;
+  float *s_red = s_img + img_floats;  // [parts][Cout][K1] cross-wave sums (parts > 1)
+  stage_image(s_img, img, n, img_floats);
   const int P = g.OH * g.OW, per = (P + f.slices - 1) / f.slices;
   const int pbeg = slice * per, pend = min(P, pbeg + per);
+  // row layout [dW (Cout x CIN*9) | db (Cout)]
+  float *row = partial + (size_t)blockIdx.x * g.Cout * K1;
   for (int wi = wave; wi < f.nchunk * f.parts; wi += 4) {
     const int co = (wi % f.nchunk) * 64 + lane, part = wi / f.nchunk;
     float acc[K1];
 #pragma unroll
     for (int k = 0; k < K1; ++k) acc[k] = 0.f;
-    for (int p = pbeg + part; p < pend; p += f.parts) {
-      const int oh = p / g.OW, ow = p - oh * g.OW;
-      const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
-      const float d = dpre[((size_t)n * P + p) * g.Cout + co];
+    int oh = (pbeg + part) / g.OW, ow = (pbeg + part) - oh * g.OW;
+    const size_t dstep = (size_t)f.parts * g.Cout;
+    const float *dp = dpre + ((size_t)n * P + pbeg + part) * g.Cout + co;
+    for (int p = pbeg + part; p < pend; p += 4 * f.parts) {
+      float d[4];  // four gradient loads in flight
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
+      for (int u = 0; u < 4; ++u) d[u] = p + u * f.parts < pend ? dp[u * dstep] : 0.f;
+      dp += 4 * dstep;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-          acc[ci * 9 + t] = fmaf(d, src[(ci * g.IH + t / 3) * g.IW + t % 3], acc[ci * 9 + t]);
-      acc[K1 - 1] += d;
+      for (int u = 0; u < 4; ++u) {
+        const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+            acc[ci * 9 + t] =
+                fmaf(d[u], src[(ci * g.IH + t / 3) * g.IW + t % 3], acc[ci * 9 + t]);
+        acc[K1 - 1] += d[u];
+        ow += f.parts;  // past the slice the products are with d = 0; keep src inside the image
+        while (ow >= g.OW) ow -= g.OW, oh = oh + 1 < g.OH ? oh + 1 : oh;
+      }
     }
-    // row layout [dW (Cout x CIN*9) | db (Cout)]
-    float *row = partial + ((size_t)blockIdx.x * f.parts + part) * g.Cout * K1;
+    if (f.parts == 1) {
 #pragma unroll
-    for (int k = 0; k < K1 - 1; ++k) row[(size_t)co * (K1 - 1) + k] = acc[k];
-    row[(size_t)g.Cout * (K1 - 1) + co] = acc[K1 - 1];
+      for (int k = 0; k < K1 - 1; ++k) row[(size_t)co * (K1 - 1) + k] = acc[k];
+      row[(size_t)g.Cout * (K1 - 1) + co] = acc[K1 - 1];
+    } else {
+#pragma unroll
+      for (int k = 0; k < K1; ++k) s_red[((size_t)part * g.Cout + co) * K1 + k] = acc[k];
+    }
+  }
+  if (f.parts > 1) {  // the waves that shared a channel chunk meet here
+    __syncthreads();
+    for (int e = threadIdx.x; e < g.Cout * K1; e += 256) {
+      float t = 0.f;
+      for (int part = 0; part < f.parts; ++part) t += s_red[(size_t)part * g.Cout * K1 + e];
+      const int co = e / K1, k = e - co * K1;
+      row[k < K1 - 1 ? (size_t)co * (K1 - 1) + k : (size_t)g.Cout * (K1 - 1) + co] = t;
+    }
   }
 }
 
@@ -472,7 +504,7 @@ extern "C" int scae_conv3x3_first_fwd_f32(const float *img, const float *w, cons
 extern "C" int scae_conv3x3_first_wgrad_rows(int B, int Cout) {
   if (B <= 0 || Cout <= 0 || Cout % 64) return 0;
   const FirstSplit f = first_split(B, Cout);
-  return B * f.slices * f.parts;
+  return B * f.slices;
 }
 
 extern "C" int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img, float *partial,
@@ -484,7 +516,8 @@ extern "C" int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img,
   SCAE_REQUIRE(dpre && img && partial);
   if (Cout % 64) return SCAE_ERR_UNSUPPORTED;
   const FirstSplit f = first_split(B, Cout);
-  const size_t lds = (size_t)Cin * IH * IW * sizeof(float);
+  const size_t lds = ((size_t)Cin * IH * IW +
+                      (f.parts > 1 ? (size_t)f.parts * Cout * (Cin * 9 + 1) : 0)) * sizeof(float);
   if (lds > 64 * 1024) return SCAE_ERR_UNSUPPORTED;
 #define SCAE_FIRST_WGRAD(CI)                                                                 \
   case CI:                                                                                   \
