@@ -192,6 +192,30 @@ int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
                   int64_t b_batch, int ldc, int64_t c_batch, int bias_ld, int64_t bias_batch,
                   int ldmask, int64_t mask_batch, int64_t asum_batch, int relu, void *stream);
 
+/* Two independent GEMMs of the kind above in ONE launch (e.g. the weight- and
+ * the data-gradient GEMM of a layer, which wait for the same incoming
+ * gradient and are each too small to fill the device).  Fields as the
+ * arguments of scae_gemm_f32. */
+typedef struct scae_gemm_desc {
+  const float *A, *B;
+  float *C;
+  const float *bias, *mask;
+  float *asum;
+  int batch, M, N, K;
+  int a_kcontig, lda;
+  int64_t a_batch;
+  int b_kcontig, ldb;
+  int64_t b_batch;
+  int ldc;
+  int64_t c_batch;
+  int bias_ld;
+  int64_t bias_batch;
+  int ldmask;
+  int64_t mask_batch, asum_batch;
+  int relu;
+} scae_gemm_desc;
+int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
+
 /* ------------------------------------------------------------------------
  * K8  3x3 "valid" convolutions of the CNN encoder as implicit GEMMs on the
  *     fp32 matrix cores      replaces part_encoder.py:26-44 / nn_ext.py:34-59

@@ -1045,3 +1045,27 @@ def test_class_probs_vs_torch():
         .backward()
     assert_close(Wh.grad, Wr.grad, 1e-6, 1e-4, "d_w")
     assert_close(bh.grad, br.grad, 1e-6, 1e-4, "d_b")
+
+
+def test_gemm_pair_equals_two_launches():
+    """scae_gemm_pair_f32: two differently shaped / laid out problems at once."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(4)
+    A0, B0 = torch.randn(3, 70, 37, generator=g), torch.randn(3, 45, 37, generator=g)
+    A1, B1 = torch.randn(5, 129, 33, generator=g), torch.randn(5, 64, 129, generator=g)
+    a0, b0, a1 = A0.cuda(), B0.cuda(), A1.cuda()         # A1 is (G, K, M)
+    b1 = B1.transpose(1, 2).contiguous().cuda()          # both k-strided
+    c0 = torch.full((3, 70, 45), float("nan"), device="cuda")
+    c1 = torch.full((5, 33, 64), float("nan"), device="cuda")
+    asum = torch.full((5, 33), float("nan"), device="cuda")
+    ops._gemm_pair(
+        ops._gemm_desc(ops._p(a0), ops._p(b0), ops._p(c0), 3, 70, 45, 37, True,
+                       37, 70 * 37, True, 37, 45 * 37, 45, 70 * 45, relu=True),
+        ops._gemm_desc(ops._p(a1), ops._p(b1), ops._p(c1), 5, 33, 64, 129,
+                       False, 33, 129 * 33, False, 64, 129 * 64, 64, 33 * 64,
+                       asum=ops._p(asum), asum_b=33), c0)
+    want0 = torch.relu(torch.einsum("gmk,gnk->gmn", A0.double(), B0.double()))
+    want1 = torch.einsum("gkm,gnk->gmn", A1.double(), B1.double())
+    assert_close(c0, want0.float(), 2e-4, 2e-3, "first")
+    assert_close(c1, want1.float(), 2e-4, 3e-3, "second")
+    assert_close(asum, A1.double().sum(1).float(), 2e-4, 2e-3, "asum")

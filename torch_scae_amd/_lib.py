@@ -25,6 +25,18 @@ class DecoderDesc(Structure):
                 ("tw", c_int), ("H", c_int), ("W", c_int)]
 
 
+class GemmDesc(Structure):
+    """struct scae_gemm_desc"""
+    _fields_ = [("A", P), ("B", P), ("C", P), ("bias", P), ("mask", P),
+                ("asum", P), ("batch", c_int), ("M", c_int), ("N", c_int),
+                ("K", c_int), ("a_kcontig", c_int), ("lda", c_int),
+                ("a_batch", c_int64), ("b_kcontig", c_int), ("ldb", c_int),
+                ("b_batch", c_int64), ("ldc", c_int), ("c_batch", c_int64),
+                ("bias_ld", c_int), ("bias_batch", c_int64), ("ldmask", c_int),
+                ("mask_batch", c_int64), ("asum_batch", c_int64),
+                ("relu", c_int)]
+
+
 class SumSegment(Structure):
     """struct scae_sum_segment"""
     _fields_ = [("dst", P), ("begin", c_int64), ("end", c_int64),
@@ -81,6 +93,7 @@ SIGNATURES = {
     "scae_gemm_f32": [P] * 6 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
                                               c_int, c_int64, c_int, c_int64,
                                               c_int, c_int64, c_int64, c_int, P],
+    "scae_gemm_pair_f32": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_first_wgrad_rows": [c_int] * 2,

@@ -64,14 +64,15 @@ __device__ __forceinline__ void fetch(Quads<Tile<SK>::NQ> &q, const float *X, in
   }
 }
 
+// one output tile of problem `g`, batch element z (workgroup-uniform arguments)
 template <bool SK, bool AK, bool BKC>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z) {
   using TL = Tile<SK>;
   constexpr int T = TL::T, NQ = TL::NQ;
-  __shared__ __attribute__((aligned(16))) float smem[TL::SMEM];
   float *As = smem, *Bs = smem + TL::OPER;
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T, z = blockIdx.z;
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+  if (m0 >= g.M || n0 >= g.N) return;
   const float *A = g.A + z * g.a_batch, *B = g.B + z * g.b_batch;
   const bool avec = (g.lda & 3) == 0 && (g.a_batch & 3) == 0 && ((size_t)g.A & 15) == 0;
   const bool bvec = (g.ldb & 3) == 0 && (g.b_batch & 3) == 0 && ((size_t)g.B & 15) == 0;
@@ -133,6 +134,32 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
   }
 }
 
+template <bool SK, bool AK, bool BKC>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
+  gemm_tile<SK, AK, BKC>(g, smem, blockIdx.z);
+}
+
+// Two independent problems in one launch (blockIdx.z < nz0: the first): the
+// weight-gradient and data-gradient GEMMs of a layer both only wait for the
+// same incoming gradient, and each is too small to fill the device.
+struct GemmPair {
+  GemmArgs g[2];
+  int nz0, layout[2];  // layout = 2*a_kcontig + b_kcontig
+};
+template <bool SK>
+__global__ __launch_bounds__(NT) void gemm_pair_kernel(GemmPair p) {
+  __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
+  const int which = (int)blockIdx.z >= p.nz0, z = blockIdx.z - (which ? p.nz0 : 0);
+  const GemmArgs &g = p.g[which];
+  switch (p.layout[which]) {  // workgroup-uniform
+    case 3: gemm_tile<SK, true, true>(g, smem, z); break;
+    case 2: gemm_tile<SK, true, false>(g, smem, z); break;
+    case 1: gemm_tile<SK, false, true>(g, smem, z); break;
+    default: gemm_tile<SK, false, false>(g, smem, z); break;
+  }
+}
+
 template <bool SK>
 void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
   constexpr int T = Tile<SK>::T;
@@ -164,5 +191,39 @@ extern "C" int scae_gemm_f32(const float *A, const float *B, float *C, const flo
     launch<true>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
   else
     launch<false>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
+  return scae_launch_status();
+}
+
+static int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
+  if (!d || !d->A || !d->B || !d->C || d->batch <= 0 || d->M <= 0 || d->N <= 0 || d->K <= 0)
+    return SCAE_ERR_BAD_ARG;
+  if (d->asum && d->a_kcontig) return SCAE_ERR_UNSUPPORTED;
+  g = GemmArgs{d->A, d->B, d->bias, d->mask, d->C, d->asum, (long)d->a_batch, (long)d->b_batch,
+               (long)d->c_batch, (long)d->bias_batch, (long)d->mask_batch, (long)d->asum_batch,
+               d->lda, d->ldb, d->ldc, d->bias_ld, d->ldmask, d->M, d->N, d->K, d->relu};
+  return SCAE_OK;
+}
+
+extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second,
+                                  void *stream) {
+  GemmPair p;
+  int rc = fill_args(p.g[0], first);
+  if (rc) return rc;
+  rc = fill_args(p.g[1], second);
+  if (rc) return rc;
+  p.nz0 = first->batch;
+  p.layout[0] = 2 * (first->a_kcontig != 0) + (first->b_kcontig != 0);
+  p.layout[1] = 2 * (second->a_kcontig != 0) + (second->b_kcontig != 0);
+  const int M = first->M > second->M ? first->M : second->M;
+  const int N = first->N > second->N ? first->N : second->N;
+  const long tiles64 = (long)((first->N + 63) / 64) * ((first->M + 63) / 64) * first->batch +
+                       (long)((second->N + 63) / 64) * ((second->M + 63) / 64) * second->batch;
+  const int nz = first->batch + second->batch;
+  if (tiles64 < 1024)
+    hipLaunchKernelGGL(gemm_pair_kernel<true>, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(NT),
+                       0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(gemm_pair_kernel<false>, dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(NT),
+                       0, (hipStream_t)stream, p);
   return scae_launch_status();
 }

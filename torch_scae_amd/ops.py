@@ -500,12 +500,14 @@ def _conv1x1_bwd(x, weight, dy):
               if B % d == 0 and (d == 1 or HW * d <= 256))
     S, kper, slab = B // gsz, HW * gsz, AP * C + AP
     part = torch.empty(S, slab, device=x.device, dtype=x.dtype)
-    _gemm(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP, kper * AP, False,
-          C, kper * C, C, slab, asum=_off(part, AP * C), asum_b=slab, ref=x)
-    gw, gb = _sum_rows(part, [(AP, C), (AP,)])
     dx = torch.empty_like(x)
-    _gemm(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP, 0, False, C,
-          0, C, 0, ref=x)
+    _gemm_pair(
+        _gemm_desc(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP,
+                   kper * AP, False, C, kper * C, C, slab,
+                   asum=_off(part, AP * C), asum_b=slab),
+        _gemm_desc(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP, 0,
+                   False, C, 0, C, 0), x)
+    gw, gb = _sum_rows(part, [(AP, C), (AP,)])
     return dx, gw, gb
 
 
@@ -722,6 +724,31 @@ def _gemm(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
               ldmask, mask_b, asum_b, int(relu), _stream(ref))
 
 
+def _gemm_desc(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
+               bias=None, bias_ld=1, bias_b=0, mask=None, ldmask=0, mask_b=0,
+               relu=False, asum=None, asum_b=0):
+    """The arguments of ``_gemm`` as a struct scae_gemm_desc (A .. asum are
+    ctypes pointers as returned by ``_p`` / ``_off``)."""
+    d = _lib.GemmDesc()
+    for name, ptr in (("A", A), ("B", B), ("C", C), ("bias", bias),
+                      ("mask", mask), ("asum", asum)):
+        setattr(d, name, None if ptr is None else ptr.value)
+    d.batch, d.M, d.N, d.K = batch, M, N, K
+    d.a_kcontig, d.lda, d.a_batch = int(a_k), lda, a_b
+    d.b_kcontig, d.ldb, d.b_batch = int(b_k), ldb, b_b
+    d.ldc, d.c_batch = ldc, c_b
+    d.bias_ld, d.bias_batch = bias_ld, bias_b
+    d.ldmask, d.mask_batch, d.asum_batch, d.relu = ldmask, mask_b, asum_b, \
+        int(relu)
+    return d
+
+
+def _gemm_pair(first, second, ref):
+    """Two independent GEMMs (``_gemm_desc``) in one launch."""
+    _lib.call("scae_gemm_pair_f32", ctypes.byref(first), ctypes.byref(second),
+              _stream(ref))
+
+
 def _off(t, nfloats=0):
     return ctypes.c_void_p(t.data_ptr() + 4 * nfloats)
 
@@ -801,25 +828,35 @@ class _GroupedMLP(torch.autograd.Function):
                 asum, asum_b = _p(gsum), N
             else:
                 gsum, asum, asum_b = None, None, 0
-            _gemm(_p(gpre), _p(xin), _p(gw), G, N, K, B, False, g_ld, g_b,
-                  False, x_ld, x_b, ldb, N * ldb, asum=asum, asum_b=asum_b,
-                  ref=x)
+            wgrad = _gemm_desc(_p(gpre), _p(xin), _p(gw), G, N, K, B, False,
+                               g_ld, g_b, False, x_ld, x_b, ldb, N * ldb,
+                               asum=asum, asum_b=asum_b)
+            # the data gradient of the layer only waits for gpre as well:
+            # both GEMMs go out in one launch
+            dgrad = gnext = None
+            if l > 0:
+                # g wrt previous pre-activation = (gpre W) gated by its ReLU
+                gnext = torch.empty(G, B, K, device=dev, dtype=dt)
+                dgrad = _gemm_desc(_p(gpre), _p(w), _p(gnext), G, B, K, N, True,
+                                   g_ld, g_b, False, ldb, N * ldb, K, B * K,
+                                   mask=_p(acts[l - 1]), ldmask=K, mask_b=B * K)
+            elif ctx.needs_input_grad[0]:
+                gx = torch.empty(B, G, K, device=dev, dtype=dt)
+                dgrad = _gemm_desc(_p(gpre), _p(w), _p(gx), G, B, K, N, True,
+                                   g_ld, g_b, False, ldb, N * ldb, G * K, K)
+            if dgrad is not None:
+                _gemm_pair(wgrad, dgrad, x)
+            else:
+                _gemm(_p(gpre), _p(xin), _p(gw), G, N, K, B, False, g_ld, g_b,
+                      False, x_ld, x_b, ldb, N * ldb, asum=asum, asum_b=asum_b,
+                      ref=x)
             if l == 0 and ones_input:
                 gw[:, :, K] = gsum
             if has_bias[l]:
                 gbs[l] = gsum
             gws[l] = gw
             if l > 0:
-                # g wrt previous pre-activation = (gpre W) gated by its ReLU
-                gprev = torch.empty(G, B, K, device=dev, dtype=dt)
-                _gemm(_p(gpre), _p(w), _p(gprev), G, B, K, N, True, g_ld, g_b,
-                      False, ldb, N * ldb, K, B * K, mask=_p(acts[l - 1]),
-                      ldmask=K, mask_b=B * K, ref=x)
-                gpre, g_ld, g_b = gprev, K, B * K
-            elif ctx.needs_input_grad[0]:
-                gx = torch.empty(B, G, K, device=dev, dtype=dt)
-                _gemm(_p(gpre), _p(w), _p(gx), G, B, K, N, True, g_ld, g_b,
-                      False, ldb, N * ldb, G * K, K, ref=x)
+                gpre, g_ld, g_b = gnext, K, B * K
         return (gx, None, None, *gws, *gbs)
 
 
