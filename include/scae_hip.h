@@ -286,7 +286,8 @@ int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *
  *     base_experiment.py:44-77 (alpha = 0.99, weight_decay = 0, not centered):
  *       v <- alpha v + (1-alpha) g^2;  buf <- momentum buf + g/(sqrt(v)+eps);
  *       p <- p - lr buf        (momentum == 0: p <- p - lr g/(sqrt(v)+eps),
- *       buf may be NULL); g <- g + weight_decay p first.  lr_dev (nullable):
+ *       buf may be NULL); g <- grad_scale * g + weight_decay p first (grad_scale:
+ *       e.g. 1/world_size after a SUM all-reduce).  lr_dev (nullable):
  *       the learning rate in device memory, read instead of `lr` -- lets the
  *       per-epoch ExponentialLR schedule (:73-76) change it under graph replay.
  *       All buffers n floats, at the same offset within a 16-byte line
@@ -294,7 +295,7 @@ int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *
  * ---------------------------------------------------------------------- */
 int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg, float *buf,
                           int64_t n, float lr, const float *lr_dev, float alpha, float eps,
-                          float momentum, float weight_decay, void *stream);
+                          float momentum, float weight_decay, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------
  * K10  coloured templates      replaces TemplateGenerator.forward,

@@ -72,9 +72,19 @@ def _worker(rank, world, port, out):
     flat.clear_grads()
     net(shard).square().sum(1).mean().backward()
     flat.gather_grads()
+    summed = flat.flat_grad.clone()
     all_reduce_gradients(flat)
     out[rank] = (flat.flat_grad.clone(), None)
+    # the path TrainStep takes: SUM all-reduce, 1/world folded into the step
+    dist.all_reduce(summed)
+    twin = make_net()
+    twin.load_state_dict(net.state_dict())
+    tflat = FlatParameters(twin)
+    tflat.flat_grad.copy_(summed)
+    topt = RMSpropFlat(tflat, lr=1e-2, eps=1e-3)
+    topt.step(grad_scale=1.0 / world)
     opt.step()
+    assert torch.allclose(tflat.flat_param, flat.flat_param, atol=1e-7)
     out[rank] = (out[rank][0], flat.flat_param.clone())
     dist.destroy_process_group()
 

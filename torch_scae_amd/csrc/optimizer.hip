@@ -15,11 +15,12 @@ struct OptArgs {
   const float *g;
   const float *lr_dev;  // learning rate in device memory (schedules under graph replay) or NULL
   long n;
-  float lr, alpha, eps, momentum, weight_decay;
+  float lr, alpha, eps, momentum, weight_decay, grad_scale;
 };
 
 __device__ __forceinline__ void update(float &p, float &v, float &b, float g, const OptArgs &a,
                                        float lr) {
+  g *= a.grad_scale;  // e.g. 1/world_size after a SUM all-reduce
   if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);  // torch: grad.add(param, alpha=wd)
   v = a.alpha * v + (1.f - a.alpha) * g * g;
   const float step = g / (sqrtf(v) + a.eps);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(OptArgs a, int head) {
 extern "C" int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg,
                                      float *buf, int64_t n, float lr, const float *lr_dev,
                                      float alpha, float eps, float momentum, float weight_decay,
-                                     void *stream) {
+                                     float grad_scale, void *stream) {
   SCAE_REQUIRE(param && grad && square_avg && n > 0);
   if (momentum > 0.f && !buf) return SCAE_ERR_BAD_ARG;
   // the four buffers are slices of equally laid out flat buffers: same phase
@@ -78,7 +79,7 @@ extern "C" int scae_rmsprop_step_f32(float *param, const float *grad, float *squ
   int head = (int)((16 - phase) & 15) / 4;
   if (head > n) head = (int)n;
   OptArgs a{param, square_avg, momentum > 0.f ? buf : nullptr, grad, lr_dev, (long)n, lr, alpha,
-            eps, momentum, weight_decay};
+            eps, momentum, weight_decay, grad_scale};
   long blocks = (n / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
   hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a,

@@ -133,12 +133,14 @@ def broadcast_parameters(flat: FlatParameters, src=0):
         dist.broadcast(flat.flat_param, src=src)
 
 
-def all_reduce_gradients(flat: FlatParameters, async_op=False):
-    """grad <- mean over ranks, one all-reduce of the flat buffer."""
+def all_reduce_gradients(flat: FlatParameters, async_op=False, average=True):
+    """grad <- mean over ranks (``average=False``: the sum, for an optimiser
+    step that folds the 1/world scale in), one all-reduce of the flat buffer."""
     _, n = world()
     if n == 1:
         return None
-    flat.flat_grad.div_(n)
+    if average:
+        flat.flat_grad.div_(n)
     return dist.all_reduce(flat.flat_grad, op=dist.ReduceOp.SUM,
                            async_op=async_op)
 
@@ -171,7 +173,9 @@ class RMSpropFlat:
         self.set_lr(self.lr * gamma)
 
     @torch.no_grad()
-    def step(self):
+    def step(self, grad_scale=1.0):
+        """``grad_scale`` multiplies the gradient on the fly (1/world after a
+        SUM all-reduce)."""
         g = self.flat.flat_grad
         # parameters without a gradient are left alone, like torch.optim does;
         # without weight decay a zero gradient already is a no-op
@@ -186,8 +190,11 @@ class RMSpropFlat:
                 _lib.call("scae_rmsprop_step_f32", ptr(self.flat.flat_param),
                           ptr(g), ptr(self.square_avg), ptr(self.buf), n,
                           self.lr, P(self.lr_dev.data_ptr()), self.alpha,
-                          self.eps, self.momentum, self.weight_decay, st)
+                          self.eps, self.momentum, self.weight_decay,
+                          float(grad_scale), st)
             return
+        if grad_scale != 1.0:
+            g = g * grad_scale
         if self.weight_decay != 0:
             keep = torch.zeros_like(g, dtype=torch.bool)
             for off, n in ranges:

@@ -56,9 +56,10 @@ class TrainStep:
                 self.log[k].copy_(v)
 
     def _finish(self):
-        all_reduce_gradients(self.flat)
+        # SUM all-reduce; the 1/world scale rides in the optimiser kernel
+        all_reduce_gradients(self.flat, average=self.opt is None)
         if self.opt is not None:
-            self.opt.step()
+            self.opt.step(grad_scale=1.0 / self.world)
 
     def _capture(self):
         # warm up on a side stream (allocator, lazy init), then capture
