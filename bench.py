@@ -39,6 +39,12 @@ CONFIGS = {
                    n_obj_caps=32,
                    scae_params=dict(reconstruct_alternatives=False)),
         batch=128),
+    # BASELINE.json configs[2] shape (the reference quotes it in bf16; fp32 here)
+    "mnist_48_64_bs1024": dict(
+        model=dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=48,
+                   n_obj_caps=64,
+                   scae_params=dict(reconstruct_alternatives=False)),
+        batch=1024),
     # BASELINE.json configs[4]
     "cifar_32_32_bs256": dict(
         model=dict(image_shape=(3, 32, 32), n_classes=10, n_part_caps=32,
