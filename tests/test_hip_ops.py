@@ -1069,3 +1069,26 @@ def test_gemm_pair_equals_two_launches():
     assert_close(c0, want0.float(), 2e-4, 2e-3, "first")
     assert_close(c1, want1.float(), 2e-4, 3e-3, "second")
     assert_close(asum, A1.double().sum(1).float(), 2e-4, 2e-3, "asum")
+
+
+@pytest.mark.parametrize("maximum", [False, True])
+def test_gmm_mode_straight_through_vs_oracle(maximum):
+    """distributions.py:50-77 with straight_through_gradient=True."""
+    from torch_scae_amd.distributions import GaussianMixture
+    g = torch.Generator().manual_seed(12)
+    B, K, C, H, W = 3, 5, 1, 6, 7
+    loc = torch.rand(B, K, C, H, W, generator=g)
+    ml = torch.randn(B, K, 1, H, W, generator=g)
+    scale = torch.tensor([0.7])
+    lr, mr = loc.clone().requires_grad_(), ml.clone().requires_grad_()
+    ref = O.gmm_mode(lr, scale, mr, straight_through_gradient=True,
+                     maximum=maximum)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    lh, mh = leaf(loc), leaf(ml)
+    pdf = GaussianMixture.make_from_stats(lh, scale.cuda(), mh)
+    out = pdf.mode(straight_through_gradient=True, maximum=maximum)
+    out.backward(gout.cuda())
+    assert_close(out, ref, 1e-6, 1e-5, "mode")
+    assert_close(lh.grad, lr.grad, 1e-6, 1e-5, "d_loc")
+    assert_close(mh.grad, mr.grad, 1e-6, 1e-5, "d_logits")

@@ -8,6 +8,8 @@ Two flavours share the reference's class name and methods:
     decoder inputs, and ``log_prob`` takes the fused render+mixture kernel
     (K1) that never reads the (B,K,C,H,W) tensors back from HBM.
 """
+import math
+
 import torch
 
 from . import ops
@@ -80,8 +82,26 @@ class GaussianMixture:
         """distributions.py:50-77: value of the component with the largest
         mixing log-prob (``maximum``: plus its density at its own mean)."""
         if straight_through_gradient:
-            raise NotImplementedError(
-                "straight-through mode gradients are not built yet")
+            # distributions.py:62-75 with the straight-through estimator: the
+            # hard one-hot in the forward value, softmax gradients w.r.t. the
+            # mixing coefficients.  A rarely used inspection path: composed
+            # from device tensor ops rather than a dedicated kernel.
+            mlp = self.mixing_log_prob()
+            loc = self.dist.loc
+            if maximum:
+                sigma = self._sigma().to(loc.dtype)
+                extra = (-torch.log(sigma) - 0.5 * math.log(2 * math.pi)) \
+                    .expand(loc.shape)       # N(loc; loc, sigma)
+                if torch.broadcast_shapes(mlp.shape, extra.shape) != mlp.shape:
+                    raise RuntimeError(
+                        f"output with shape {list(mlp.shape)} doesn't match "
+                        f"the broadcast shape {list(loc.shape)}")
+                mlp = mlp + extra
+            hard = torch.nn.functional.one_hot(mlp.argmax(1), mlp.shape[1]) \
+                .movedim(-1, 1).to(mlp.dtype)
+            soft = torch.softmax(mlp, 1)
+            mask = (hard - soft).detach() + soft
+            return torch.sum(mask * loc, 1)
         return ops.gmm_mode(self._loc5(), self._ml5(), self._sigma(),
                             maximum).view(self._out_shape())
 
