@@ -16,7 +16,7 @@
 // caller (and differentiated by autograd).  q = Wq seeds + bq is batch
 // invariant as well and is passed in.
 //
-// One workgroup (8 waves) per set, element-parallel stages on LDS tiles like
+// One workgroup (16 waves) per set, element-parallel stages on LDS tiles like
 // set_encoder.hip; the presence mask arithmetic is the reference's fp32
 // sequence.  Backward recomputes K', V', writes h-gradients once and leaves
 // per-workgroup partial parameter gradients for the caller to sum.
@@ -25,7 +25,7 @@
 #include "common.h"
 
 namespace {
-constexpr int NT = 512;
+constexpr int NT = 1024;
 constexpr int NMAX = 64;
 
 struct SaArgs {
