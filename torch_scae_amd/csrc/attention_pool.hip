@@ -12,7 +12,7 @@
 #include "geometric_transform.h"
 
 namespace {
-constexpr int NT = 256;
+constexpr int NT = 512;
 
 struct PoolArgs {
   const float *y, *g;

@@ -13,7 +13,7 @@
 #include "common.h"
 
 namespace {
-constexpr int NT = 256;
+constexpr int NT = 1024;
 constexpr int OMAX = 64;  // capsules per lane group: 16 lanes x 4
 constexpr float kLog001 = -4.605170185988091f;  // np.log(0.01), object_decoder.py:274
 

@@ -11,7 +11,7 @@
 #include "common.h"
 
 namespace {
-constexpr int NT = 256;
+constexpr int NT = 1024;
 
 struct TcArgs {
   const float *logits;   // (M,C,hw)
