@@ -307,10 +307,12 @@ int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg, fl
  *      nonlin codes: 0 sigmoid, 1 relu1 (nn_ext.py:139-140).
  *      w1 (H1,F), b1 (H1), w2 (C,H1), b2 (C); feature (B,M,F).
  *      backward: g_templates (B,M,C,hw), g_raw (M,C,hw, nullable) ->
- *      g_logits (M,C,hw), g_feature (B,M,F), partial (B, H1*F + H1 + C*H1 + C)
- *      = per-image [dW1 | db1 | dW2 | db2] for the caller to sum over dim 0.
+ *      g_logits (M,C,hw), g_feature (B,M,F), partial
+ *      (scae_template_color_partial_rows(B,M), H1*F + H1 + C*H1 + C) =
+ *      per-workgroup [dW1 | db1 | dW2 | db2] for the caller to sum over dim 0.
  * ---------------------------------------------------------------------- */
 int scae_template_color_supported(int M, int C, int F, int H1);
+int scae_template_color_partial_rows(int B, int M);
 int scae_template_color_fwd_f32(const float *logits, const float *feature, const float *w1,
                                 const float *b1, const float *w2, const float *b2, float *raw,
                                 float *templates, float *color, int B, int M, int C, int hw,

@@ -110,6 +110,7 @@ SIGNATURES = {
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
     "scae_template_color_supported": [c_int] * 4,
+    "scae_template_color_partial_rows": [c_int] * 2,
     "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],
     "scae_template_color_bwd_f32": [P] * 12 + [c_int] * 8 + [P],
     "scae_sum_rows_f32": [P, c_int64, c_int64, POINTER(SumSegment), c_int, P],

@@ -26,6 +26,7 @@ struct TcArgs {
   float *g_logits;       // (M,C,hw)
   int B, M, C, hw, F, H1;
   int tnl, cnl;          // 0 sigmoid, 1 relu1
+  int splits;            // capsule groups per image (grid = B * splits)
 };
 
 // nn_ext.py:139-140: relu6(6x)/6, evaluated as written
@@ -48,15 +49,15 @@ __device__ __forceinline__ float nonlin_grad(float x, int kind) {
 struct Lds {
   float *w1, *b1, *w2, *b2, *feat, *h1, *pre2;
 };
-__device__ __forceinline__ Lds carve(float *base, const TcArgs &k) {
+__device__ __forceinline__ Lds carve(float *base, const TcArgs &k, int M) {
   Lds l;
   l.w1 = base;
   l.b1 = l.w1 + k.H1 * k.F;
   l.w2 = l.b1 + k.H1;
   l.b2 = l.w2 + k.C * k.H1;
   l.feat = l.b2 + k.C;
-  l.h1 = l.feat + k.M * k.F;
-  l.pre2 = l.h1 + k.M * k.H1;
+  l.h1 = l.feat + M * k.F;
+  l.pre2 = l.h1 + M * k.H1;
   return l;
 }
 inline size_t lds_floats(int M, int C, int F, int H1, bool bwd) {
@@ -66,24 +67,25 @@ inline size_t lds_floats(int M, int C, int F, int H1, bool bwd) {
   return n;
 }
 
-// stages the MLP and evaluates it for the M capsules of image b:
+// stages the MLP and evaluates it for M capsules whose features start at `feature`:
 // h1 (post-ReLU), pre2 (second layer pre-activation)
-__device__ __forceinline__ void mlp_forward(const Lds &l, const TcArgs &k, int b) {
+__device__ __forceinline__ void mlp_forward(const Lds &l, const TcArgs &k, const float *feature,
+                                            int M) {
   const int t = threadIdx.x;
   for (int e = t; e < k.H1 * k.F; e += NT) l.w1[e] = k.w1[e];
   for (int e = t; e < k.H1; e += NT) l.b1[e] = k.b1[e];
   for (int e = t; e < k.C * k.H1; e += NT) l.w2[e] = k.w2[e];
   for (int e = t; e < k.C; e += NT) l.b2[e] = k.b2[e];
-  for (int e = t; e < k.M * k.F; e += NT) l.feat[e] = k.feature[(size_t)b * k.M * k.F + e];
+  for (int e = t; e < M * k.F; e += NT) l.feat[e] = feature[e];
   __syncthreads();
-  for (int e = t; e < k.M * k.H1; e += NT) {
+  for (int e = t; e < M * k.H1; e += NT) {
     const int m = e / k.H1, j = e - m * k.H1;
     float s = l.b1[j];
     for (int f = 0; f < k.F; ++f) s = fmaf(l.feat[m * k.F + f], l.w1[j * k.F + f], s);
     l.h1[e] = fmaxf(s, 0.f);
   }
   __syncthreads();
-  for (int e = t; e < k.M * k.C; e += NT) {
+  for (int e = t; e < M * k.C; e += NT) {
     const int m = e / k.C, c = e - m * k.C;
     float s = l.b2[c];
     for (int j = 0; j < k.H1; ++j) s = fmaf(l.h1[m * k.H1 + j], l.w2[c * k.H1 + j], s);
@@ -103,70 +105,77 @@ __device__ __forceinline__ float color_grad(float pre2, int cnl) {
   return cnl == 0 ? nonlin_grad(pre2, 0) : relu1_grad(pre2 + .99f);
 }
 
+// One workgroup per (image b, group of M capsules starting at m0): capsules are
+// independent, and an image alone would leave half of the CUs idle at B=128.
 __global__ __launch_bounds__(NT) void tc_fwd_kernel(TcArgs k) {
   extern __shared__ float lds[];
-  const Lds l = carve(lds, k);
-  const int b = blockIdx.x, t = threadIdx.x, MC = k.M * k.C;
-  mlp_forward(l, k, b);
+  const int M = k.M / k.splits, b = blockIdx.x / k.splits, m0 = (blockIdx.x % k.splits) * M;
+  const Lds l = carve(lds, k, M);
+  const int t = threadIdx.x, MC = M * k.C;
+  const size_t cap0 = (size_t)b * k.M + m0;  // global index of the group's first capsule
+  mlp_forward(l, k, k.feature + cap0 * k.F, M);
   for (int e = t; e < MC; e += NT) {
     const float col = color_of(l.pre2[e], k.cnl);
     l.pre2[e] = col;
-    k.color[(size_t)b * MC + e] = col;
+    k.color[cap0 * k.C + e] = col;
   }
   __syncthreads();
-  float *dst = k.templates + (size_t)b * MC * k.hw;
+  float *dst = k.templates + cap0 * k.C * k.hw;
+  const float *logits = k.logits + (size_t)m0 * k.C * k.hw;
   for (int e = t; e < MC * k.hw; e += NT) {
-    const float r = nonlin(k.logits[e], k.tnl);
+    const float r = nonlin(logits[e], k.tnl);
     dst[e] = r * l.pre2[e / k.hw];
-    if (b == 0) k.raw[e] = r;
+    if (b == 0) k.raw[(size_t)m0 * k.C * k.hw + e] = r;
   }
 }
 
 __global__ __launch_bounds__(NT) void tc_bwdA_kernel(TcArgs k) {
   extern __shared__ float lds[];
-  const Lds l = carve(lds, k);
-  float *g2 = l.pre2 + k.M * k.C, *g1 = g2 + k.M * k.C;
-  const int b = blockIdx.x, t = threadIdx.x, MC = k.M * k.C, wave = t >> 6, lane = t & 63;
-  mlp_forward(l, k, b);
+  const int M = k.M / k.splits, b = blockIdx.x / k.splits, m0 = (blockIdx.x % k.splits) * M;
+  const Lds l = carve(lds, k, M);
+  float *g2 = l.pre2 + M * k.C, *g1 = g2 + M * k.C;
+  const int t = threadIdx.x, MC = M * k.C, wave = t >> 6, lane = t & 63;
+  const size_t cap0 = (size_t)b * k.M + m0;
+  mlp_forward(l, k, k.feature + cap0 * k.F, M);
   // g_colour[m,c] = sum_t g_templates[b,m,c,t] * raw[m,c,t]; then through the colour
   // non-linearity and the second ReLU -> g2 (gradient w.r.t. pre2)
+  const float *logits = k.logits + (size_t)m0 * k.C * k.hw;
   for (int pair = wave; pair < MC; pair += NT / 64) {
-    const float *g = k.g_templates + ((size_t)b * MC + pair) * k.hw;
+    const float *g = k.g_templates + (cap0 * k.C + pair) * k.hw;
     float s = 0.f;
-    for (int i = lane; i < k.hw; i += 64)
-      s = fmaf(g[i], nonlin(k.logits[pair * k.hw + i], k.tnl), s);
+    for (int i = lane; i < k.hw; i += 64) s = fmaf(g[i], nonlin(logits[pair * k.hw + i], k.tnl), s);
     s = scae::wave_sum(s);
     if (lane == 0) g2[pair] = s * color_grad(l.pre2[pair], k.cnl);
   }
   __syncthreads();
-  for (int e = t; e < k.M * k.H1; e += NT) {  // g1: gradient w.r.t. the first pre-activation
+  for (int e = t; e < M * k.H1; e += NT) {  // g1: gradient w.r.t. the first pre-activation
     const int m = e / k.H1, j = e - m * k.H1;
     float s = 0.f;
     for (int c = 0; c < k.C; ++c) s = fmaf(g2[m * k.C + c], l.w2[c * k.H1 + j], s);
     g1[e] = l.h1[e] > 0.f ? s : 0.f;
   }
   __syncthreads();
-  for (int e = t; e < k.M * k.F; e += NT) {
+  for (int e = t; e < M * k.F; e += NT) {
     const int m = e / k.F, f = e - m * k.F;
     float s = 0.f;
     for (int j = 0; j < k.H1; ++j) s = fmaf(g1[m * k.H1 + j], l.w1[j * k.F + f], s);
-    k.g_feature[(size_t)b * k.M * k.F + e] = s;
+    k.g_feature[cap0 * k.F + e] = s;
   }
-  // per-image weight-gradient partials: [dW1 | db1 | dW2 | db2]
+  // per-workgroup weight-gradient partials: [dW1 | db1 | dW2 | db2]
   const int n1 = k.H1 * k.F, n2 = n1 + k.H1, n3 = n2 + k.C * k.H1, n4 = n3 + k.C;
-  float *part = k.partial + (size_t)b * n4;
+  float *part = k.partial + (size_t)blockIdx.x * n4;
   for (int e = t; e < n4; e += NT) {
     float s = 0.f;
     if (e < n1) {
       const int j = e / k.F, f = e - j * k.F;
-      for (int m = 0; m < k.M; ++m) s = fmaf(g1[m * k.H1 + j], l.feat[m * k.F + f], s);
+      for (int m = 0; m < M; ++m) s = fmaf(g1[m * k.H1 + j], l.feat[m * k.F + f], s);
     } else if (e < n2) {
-      for (int m = 0; m < k.M; ++m) s += g1[m * k.H1 + e - n1];
+      for (int m = 0; m < M; ++m) s += g1[m * k.H1 + e - n1];
     } else if (e < n3) {
       const int c = (e - n2) / k.H1, j = (e - n2) - c * k.H1;
-      for (int m = 0; m < k.M; ++m) s = fmaf(g2[m * k.C + c], l.h1[m * k.H1 + j], s);
+      for (int m = 0; m < M; ++m) s = fmaf(g2[m * k.C + c], l.h1[m * k.H1 + j], s);
     } else {
-      for (int m = 0; m < k.M; ++m) s += g2[m * k.C + e - n3];
+      for (int m = 0; m < M; ++m) s += g2[m * k.C + e - n3];
     }
     part[e] = s;
   }
@@ -194,6 +203,17 @@ __global__ __launch_bounds__(1024) void tc_bwdB_kernel(TcArgs k) {
   }
 }
 
+// capsule groups per image: enough workgroups to cover the 256 CUs twice
+inline int tc_splits(int B, int M) {
+  int s = 1;
+  for (int d = 1; d <= M && d <= 8; ++d)
+    if (M % d == 0) {
+      s = d;
+      if ((long)B * d >= 512) break;
+    }
+  return s;
+}
+
 int check(const TcArgs &k) {
   if (k.B <= 0 || k.M <= 0 || k.C <= 0 || k.hw <= 0 || k.F <= 0 || k.H1 <= 0)
     return SCAE_ERR_BAD_ARG;
@@ -219,10 +239,12 @@ extern "C" int scae_template_color_fwd_f32(const float *logits, const float *fea
   k.raw = raw, k.templates = templates, k.color = color;
   k.B = B, k.M = M, k.C = C, k.hw = hw, k.F = F, k.H1 = H1;
   k.tnl = template_nonlin, k.cnl = color_nonlin;
+  k.splits = tc_splits(B, M);
   int rc = check(k);
   if (rc) return rc;
   SCAE_REQUIRE(logits && feature && w1 && b1 && w2 && b2 && raw && templates && color);
-  hipLaunchKernelGGL(tc_fwd_kernel, dim3(B), dim3(NT), lds_floats(M, C, F, H1, false) * sizeof(float),
+  hipLaunchKernelGGL(tc_fwd_kernel, dim3(B * k.splits), dim3(NT),
+                     lds_floats(M / k.splits, C, F, H1, false) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();
 }
@@ -241,14 +263,20 @@ extern "C" int scae_template_color_bwd_f32(const float *logits, const float *fea
   k.g_feature = g_feature, k.partial = partial;
   k.B = B, k.M = M, k.C = C, k.hw = hw, k.F = F, k.H1 = H1;
   k.tnl = template_nonlin, k.cnl = color_nonlin;
+  k.splits = tc_splits(B, M);
   int rc = check(k);
   if (rc) return rc;
   SCAE_REQUIRE(logits && feature && w1 && b1 && w2 && b2 && color && g_templates && g_logits &&
                g_feature && partial);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(tc_bwdA_kernel, dim3(B), dim3(NT), lds_floats(M, C, F, H1, true) * sizeof(float),
+  hipLaunchKernelGGL(tc_bwdA_kernel, dim3(B * k.splits), dim3(NT),
+                     lds_floats(M / k.splits, C, F, H1, true) * sizeof(float),
                      st, k);
   const int n = M * C * hw;
   hipLaunchKernelGGL(tc_bwdB_kernel, dim3((n + 255) / 256), dim3(256, 4), 0, st, k);
   return scae_launch_status();
+}
+
+extern "C" int scae_template_color_partial_rows(int B, int M) {
+  return B > 0 && M > 0 ? B * tc_splits(B, M) : 0;
 }

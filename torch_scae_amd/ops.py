@@ -692,7 +692,8 @@ class _ColoredTemplates(torch.autograd.Function):
                                       dtype=logits.dtype)
         n1, n2, n3 = H1 * F, H1 * F + H1, H1 * F + H1 + C * H1
         g_logits, g_feature = torch.empty_like(logits), torch.empty_like(feature)
-        partial = torch.empty(B, n3 + C, device=logits.device,
+        rows = _lib.load().scae_template_color_partial_rows(B, M)
+        partial = torch.empty(rows, n3 + C, device=logits.device,
                               dtype=logits.dtype)
         _lib.call("scae_template_color_bwd_f32", _p(logits), _p(feature),
                   _p(w1), _p(b1), _p(w2), _p(b2), _p(color),
