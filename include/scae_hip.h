@@ -126,11 +126,15 @@ int scae_set_encoder_bwd_f32(int nseg, const float *const *seg_ptr, const int *s
  *        to one),  out = softmax((q K'^T - (1-presence) 1e32)/sqrt(C)) V'
  *   q (O,C) = q_projector(seeds) (batch invariant); wk, wv (C,D); bk, bv (C);
  *   out (B,O,C); probs (B,O,N) nullable (inspection only).
- *   backward: gout (B,O,C) -> gh (B,N,D); partial (scae_seed_attention_grid(B),
- *   O*C + 2*C*D + 2*C) = per-workgroup [gq | gwk | gbk | gwv | gbv] (caller
- *   sums over dim 0).  Limits: N, O <= 64, D in {8,16,32}, C % 8 == 0, LDS.
+ *   A set is shared out over S = scae_seed_attention_splits(B,O) workgroups
+ *   (groups of queries).  backward: gout (B,O,C) -> gh (S,B,N,D), one slab
+ *   per query group (caller sums over dim 0); partial
+ *   (scae_seed_attention_grid(B,O), O*C + 2*C*D + 2*C) = per-workgroup
+ *   [gq | gwk | gbk | gwv | gbv] (caller sums over dim 0).
+ *   Limits: N, O <= 64, D in {8,16,32}, C % 8 == 0, LDS.
  * ---------------------------------------------------------------------- */
-int scae_seed_attention_grid(int B);
+int scae_seed_attention_splits(int B, int O);
+int scae_seed_attention_grid(int B, int O);
 int scae_seed_attention_supported(int N, int O, int D, int C);
 int scae_seed_attention_fwd_f32(const float *h, const float *q, const float *wk,
                                 const float *bk, const float *wv, const float *bv,

@@ -83,7 +83,8 @@ SIGNATURES = {
     "scae_set_encoder_fwd_f32": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7 + [P],
     "scae_set_encoder_bwd_f32": [c_int, P, P, P, P, P, P, P, P, P, P]
                                 + [c_int] * 7 + [P],
-    "scae_seed_attention_grid": [c_int],
+    "scae_seed_attention_splits": [c_int] * 2,
+    "scae_seed_attention_grid": [c_int] * 2,
     "scae_seed_attention_supported": [c_int] * 4,
     "scae_seed_attention_fwd_f32": [P] * 9 + [c_int] * 5 + [P],
     "scae_seed_attention_bwd_f32": [P] * 10 + [c_int] * 5 + [P],

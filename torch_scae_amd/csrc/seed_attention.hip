@@ -41,6 +41,7 @@ struct SaArgs {
   float *partial;         // bwd (grid, O*C + 2*C*D + 2*C): [gq | gwk | gbk | gwv | gbv]
   int B, N, O, C;
   float sqrt_c;
+  int splits;  // query groups per set (grid = B * splits workgroups)
 };
 
 template <int G>
@@ -105,10 +106,11 @@ __host__ __device__ size_t carve(int N, int O, int C, bool bwd, float *base, Car
   return o;
 }
 
+// weights, and the Og query rows starting at o0 (local row index in the tiles)
 template <int D>
-__device__ __forceinline__ void stage_common(const SaArgs &a, const Carve<D> &c) {
+__device__ __forceinline__ void stage_common(const SaArgs &a, const Carve<D> &c, int o0, int Og) {
   constexpr int TS = D + 4;
-  const int C = a.C, O = a.O, tid = threadIdx.x;
+  const int C = a.C, O = Og, tid = threadIdx.x;
 #pragma unroll 4
   for (int e = tid; e < C * D; e += NT) {
     const int r = e / D, j = e - r * D;
@@ -122,15 +124,15 @@ __device__ __forceinline__ void stage_common(const SaArgs &a, const Carve<D> &c)
 #pragma unroll 4
   for (int e = tid; e < O * C; e += NT) {
     const int o = e / C, cc = e - o * C;
-    c.q[o * c.CS + cc] = a.q[e];
+    c.q[o * c.CS + cc] = a.q[(size_t)o0 * C + e];
   }
 }
 
 // K', V', routing, softmax for sample b; leaves P in c.S.  Ends with a barrier.
 template <int D>
-__device__ __forceinline__ void forward_core(const SaArgs &a, const Carve<D> &c, int b) {
+__device__ __forceinline__ void forward_core(const SaArgs &a, const Carve<D> &c, int b, int Og) {
   constexpr int TS = D + 4;
-  const int N = a.N, O = a.O, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
+  const int N = a.N, O = Og, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
   for (int e = tid; e < N * D; e += NT)
     c.h[(e / D) * TS + (e % D)] = a.h[(size_t)b * N * D + e];
   __syncthreads();
@@ -175,19 +177,23 @@ __device__ __forceinline__ void forward_core(const SaArgs &a, const Carve<D> &c,
   __syncthreads();
 }
 
+// Workgroup (set b, query group s): the O queries are independent given K', V',
+// so a set is shared out over `splits` workgroups (each recomputes the cheap K', V')
+// -- one workgroup per set would leave half of the CUs idle at B = 128.
 template <int D>
 __global__ __launch_bounds__(NT) void sa_fwd_kernel(SaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Og = a.O / a.splits, o0 = (blockIdx.x % a.splits) * Og;
   Carve<D> c;
-  carve<D>(a.N, a.O, a.C, false, smem, &c);
-  const int N = a.N, O = a.O, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
-  stage_common<D>(a, c);
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  carve<D>(a.N, Og, a.C, false, smem, &c);
+  const int N = a.N, O = Og, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
+  stage_common<D>(a, c, o0, Og);
+  for (int b = blockIdx.x / a.splits; b < a.B; b += gridDim.x / a.splits) {
     __syncthreads();
-    forward_core<D>(a, c, b);
+    forward_core<D>(a, c, b, Og);
     if (a.probs)
       for (int e = tid; e < O * N; e += NT)
-        a.probs[(size_t)b * O * N + e] = c.S[(e / N) * NS + (e % N)];
+        a.probs[((size_t)b * a.O + o0) * N + e] = c.S[(e / N) * NS + (e % N)];
     for (int e = tid; e < O * C; e += NT) {  // out = P V'
       const int o = e / C, cc = e - o * C;
       float a0 = 0.f, a1 = 0.f;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(NT) void sa_fwd_kernel(SaArgs a) {
         a1 = fmaf(c.S[o * NS + m + 1], c.V[(m + 1) * CS + cc], a1);
       }
       if (m < N) a0 = fmaf(c.S[o * NS + m], c.V[m * CS + cc], a0);
-      a.out[((size_t)b * O + o) * C + cc] = a0 + a1;
+      a.out[((size_t)b * a.O + o0 + o) * C + cc] = a0 + a1;
     }
   }
 }
@@ -206,21 +212,27 @@ template <int D>
 __global__ __launch_bounds__(NT) void sa_bwd_kernel(SaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TS = D + 4;
+  const int Og = a.O / a.splits, grp = blockIdx.x % a.splits, o0 = grp * Og;
   Carve<D> c;
-  carve<D>(a.N, a.O, a.C, true, smem, &c);
-  const int N = a.N, O = a.O, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
-  stage_common<D>(a, c);
-  const size_t P = (size_t)O * C + 2 * (size_t)C * D + 2 * C;
+  carve<D>(a.N, Og, a.C, true, smem, &c);
+  const int N = a.N, O = Og, C = a.C, CS = c.CS, NS = N + 1, tid = threadIdx.x;
+  stage_common<D>(a, c, o0, Og);
+  const size_t P = (size_t)a.O * C + 2 * (size_t)C * D + 2 * C;
   float *part = a.partial + blockIdx.x * P;
-  float *p_gq = part, *p_gwk = part + (size_t)O * C, *p_gbk = p_gwk + (size_t)C * D,
-        *p_gwv = p_gbk + C, *p_gbv = p_gwv + (size_t)C * D;
+  // this workgroup's query rows of the dq block; the other groups' rows stay zero
+  for (int e = tid; e < a.O * C; e += NT)
+    if (e < o0 * C || e >= (o0 + Og) * C) part[e] = 0.f;
+  float *p_gq = part + (size_t)o0 * C, *p_gwk = part + (size_t)a.O * C,
+        *p_gbk = p_gwk + (size_t)C * D, *p_gwv = p_gbk + C, *p_gbv = p_gwv + (size_t)C * D;
+  // h-gradient of this query group: gh is (splits, B, N, D), summed by the caller
+  float *gh = a.gh + (size_t)grp * a.B * N * D;
   bool first = true;
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  for (int b = blockIdx.x / a.splits; b < a.B; b += gridDim.x / a.splits) {
     __syncthreads();
-    forward_core<D>(a, c, b);  // recompute K', V', P
+    forward_core<D>(a, c, b, Og);  // recompute K', V', P
 #pragma unroll 4
     for (int e = tid; e < O * C; e += NT)
-      c.GO[(e / C) * CS + (e % C)] = a.gout[(size_t)b * O * C + e];
+      c.GO[(e / C) * CS + (e % C)] = a.gout[((size_t)b * a.O + o0) * C + e];
     __syncthreads();
     for (int e = tid; e < O * N; e += NT) {  // dL/dP
       const int o = e / N, m = e - o * N;
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(NT) void sa_bwd_kernel(SaArgs a) {
         a0 = fmaf(c.K[m * CS + cc], c.wk[cc * TS + j], a0);
         a1 = fmaf(c.V[m * CS + cc], c.wv[cc * TS + j], a1);
       }
-      a.gh[(size_t)b * N * D + e] = a0 + a1;
+      gh[(size_t)b * N * D + e] = a0 + a1;
     }
     for (int e = tid; e < C * D; e += NT) {  // dWk2, dWvo (+ biases)
       const int cc = e / D, j = e - cc * D;
@@ -314,9 +326,22 @@ int check(const SaArgs &a, int D) {
   return SCAE_OK;
 }
 
+// query groups per set: the smallest divisor of O that gives >= 256 workgroups (one per CU:
+// the LDS tiles allow one resident workgroup per CU, so more groups would queue)
+int sa_splits(int B, int O) {
+  int s = 1;
+  for (int d = 1; d <= O && d <= 4; ++d)
+    if (O % d == 0) {
+      s = d;
+      if ((long)B * d >= 256) break;
+    }
+  return s;
+}
+
 template <int D>
-int launch(const SaArgs &a, bool bwd, hipStream_t st) {
-  const size_t lds = lds_bytes<D>(a.N, a.O, a.C, bwd);
+int launch(SaArgs a, bool bwd, hipStream_t st) {
+  a.splits = sa_splits(a.B, a.O);
+  const size_t lds = lds_bytes<D>(a.N, a.O / a.splits, a.C, bwd);
   if (lds > 160 * 1024) return SCAE_ERR_UNSUPPORTED;
   const void *fn = bwd ? reinterpret_cast<const void *>(sa_bwd_kernel<D>)
                        : reinterpret_cast<const void *>(sa_fwd_kernel<D>);
@@ -324,7 +349,7 @@ int launch(const SaArgs &a, bool bwd, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const int grid = a.B < 512 ? a.B : 512;
+  const int grid = scae_seed_attention_grid(a.B, a.O);
   if (bwd)
     hipLaunchKernelGGL(sa_bwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
   else
@@ -333,7 +358,13 @@ int launch(const SaArgs &a, bool bwd, hipStream_t st) {
 }
 }  // namespace
 
-extern "C" int scae_seed_attention_grid(int B) { return B < 512 ? B : 512; }
+extern "C" int scae_seed_attention_splits(int B, int O) {
+  return B > 0 && O > 0 ? sa_splits(B, O) : 0;
+}
+extern "C" int scae_seed_attention_grid(int B, int O) {
+  if (B <= 0 || O <= 0) return 0;
+  return (B < 512 ? B : 512) * sa_splits(B, O);
+}
 
 extern "C" int scae_seed_attention_supported(int N, int O, int D, int C) {
   if (N <= 0 || O <= 0 || N > NMAX || O > NMAX || C <= 0 || (C & 7)) return 0;

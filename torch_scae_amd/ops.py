@@ -277,13 +277,17 @@ class _SeedAttention(torch.autograd.Function):
         presence = ctx.saved_tensors[6] if ctx.has_presence else None
         B, N, D = h.shape
         O, C = q.shape
-        grid = _lib.load().scae_seed_attention_grid(B)
+        lib = _lib.load()
+        grid, S = lib.scae_seed_attention_grid(B, O), \
+            lib.scae_seed_attention_splits(B, O)
         npar = O * C + 2 * C * D + 2 * C
         partial = torch.empty(grid, npar, device=h.device, dtype=h.dtype)
-        gh = torch.empty_like(h)
+        gh = torch.empty(S, B, N, D, device=h.device, dtype=h.dtype)
         _lib.call("scae_seed_attention_bwd_f32", _p(h), _p(q), _p(wk), _p(bk),
                   _p(wv), _p(bv), _p(presence), _p(gout.contiguous()), _p(gh),
                   _p(partial), B, N, O, D, C, _stream(h))
+        # one h-gradient slab per query group
+        gh = gh[0] if S == 1 else _sum_rows(gh.view(S, -1), [(B, N, D)])[0]
         gq, gwk, gbk, gwv, gbv = _sum_rows(
             partial, [(O, C), (C, D), (C,), (C, D), (C,)])
         return gh, gq, gwk, gbk, gwv, gbv, None
