@@ -30,7 +30,9 @@ class TrainStep:
         self.label = torch.zeros(batch_size, dtype=torch.long,
                                  device=self.device)
         self.loss = torch.zeros((), device=self.device)
+        self._one = torch.ones((), device=self.device)   # d loss / d loss
         self.use_graph = use_graph
+        self._capturing = False
         self._with_log = False
         self.graph = None
         self.world = world()[1]
@@ -39,9 +41,14 @@ class TrainStep:
         self.flat.clear_grads()
         res = self.model(self.image)
         loss, info = self.model.loss(res, self.image, self.label)
-        loss.backward()
+        loss.backward(self._one)     # a resident seed: no ones_like fill per step
         self.flat.gather_grads()
-        self.loss.copy_(loss.detach())
+        if self._capturing:
+            # the captured loss tensor lives in the graph's private pool at a
+            # fixed address: expose it instead of copying it out every replay
+            self.loss = loss.detach()
+        else:
+            self.loss.copy_(loss.detach())
         if self._with_log:
             # the `log` dict of BaseExperiment.training_step (:118-125)
             acc = self.model.calculate_accuracy(res, self.label) \
@@ -73,7 +80,9 @@ class TrainStep:
         # parameter's AccumulateGrad node together with its stream
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=s):
+            self._capturing = True
             self._fwd_bwd()
+            self._capturing = False
             if self.world == 1:
                 self._finish()
 
