@@ -520,6 +520,8 @@ typedef struct scae_decoder_desc {
   const float *temperature_logit;
   const float *out_scale;
   int B, M, C, th, tw, H, W;
+  int template_repeat; /* > 1: templates is (B / template_repeat, M, C, th, tw) and images
+                          r*k .. r*k + r-1 share template set k (forward only) */
 } scae_decoder_desc;
 
 /* materialise transformed_templates (B,K,C,H,W) and mixing_logits

@@ -22,7 +22,8 @@ class DecoderDesc(Structure):
                 ("bg_mixing_logit", P), ("temperature_logit", P),
                 ("out_scale", P),
                 ("B", c_int), ("M", c_int), ("C", c_int), ("th", c_int),
-                ("tw", c_int), ("H", c_int), ("W", c_int)]
+                ("tw", c_int), ("H", c_int), ("W", c_int),
+                ("template_repeat", c_int)]
 
 
 class GemmDesc(Structure):

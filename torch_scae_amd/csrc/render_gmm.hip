@@ -105,6 +105,13 @@ __device__ __forceinline__ void tap_value_grad(const float *plane, const Taps &t
   dy = (v10 - v00) * wx0 + (v11 - v01) * wx1;
 }
 
+// template set of image b: consecutive groups of `template_repeat` images share one
+// (stacked_capsule_auto_encoder.py:188-195 decodes every object capsule's votes with the
+// image's templates: B*O virtual images, B template sets)
+__device__ __forceinline__ int tb(const scae_decoder_desc &d, int b) {
+  return d.template_repeat > 1 ? b / d.template_repeat : b;
+}
+
 struct Scalars {
   float sigma, inv_var, log_sigma;  // Normal scale of every component
   float temperature;                // temperature mode only
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(NT) void render_fwd_kernel(scae_decoder_desc d,
 
   float *s_tmpl = smem;             // C * tsz
   float *s_alpha = smem + C * tsz;  // tsz (alpha mode)
-  const float *g_tmpl = d.templates + (size_t)(b * M + k) * C * tsz;
+  const float *g_tmpl = d.templates + (size_t)(tb(d, b) * M + k) * C * tsz;
   for (int i = tid; i < C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
   if (alpha_mode)
     for (int i = tid; i < tsz; i += NT) s_alpha[i] = d.templates_alpha[(size_t)k * tsz + i];
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
   float *s_pose = s_alpha + (alpha_mode ? M * tsz : 0);  // M*6
   float *s_lsp = s_pose + M * 6;                       // M
   {
-    const float *g_tmpl = d.templates + (size_t)b * M * C * tsz;
+    const float *g_tmpl = d.templates + (size_t)tb(d, b) * M * C * tsz;
     for (int i = tid; i < M * C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
     if (alpha_mode)
       for (int i = tid; i < M * tsz; i += NT) s_alpha[i] = d.templates_alpha[i];
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
   float a[6] = {0, 0, 0, 0, 0, 0};
   float lsp = 0.f;
   if (!is_bg) {
-    const float *g_tmpl = d.templates + (size_t)(b * M + k) * C * tsz;
+    const float *g_tmpl = d.templates + (size_t)(tb(d, b) * M + k) * C * tsz;
     for (int i = tid; i < C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
     for (int i = tid; i < tsz; i += NT)
       s_alpha[i] = alpha_mode ? d.templates_alpha[(size_t)k * tsz + i] : 0.f;
@@ -761,6 +768,8 @@ int check_desc(const scae_decoder_desc *d) {
     return SCAE_ERR_BAD_ARG;
   if (!d->bg_image && !d->bg_value) return SCAE_ERR_BAD_ARG;
   if (d->templates_alpha && !d->bg_mixing_logit) return SCAE_ERR_BAD_ARG;
+  if (d->template_repeat < 0 || (d->template_repeat > 1 && d->B % d->template_repeat))
+    return SCAE_ERR_BAD_ARG;
   if (!d->templates_alpha && !d->temperature_logit) return SCAE_ERR_BAD_ARG;
   if (d->C > SCAE_MAX_CHANNELS) return SCAE_ERR_UNSUPPORTED;
   if ((d->C + 1) * d->th * d->tw > SCAE_RENDER_MAX_TEMPLATE_ELEMS) return SCAE_ERR_UNSUPPORTED;
@@ -920,6 +929,7 @@ extern "C" int scae_render_gmm_sums_bwd_f32(const scae_decoder_desc *d, const fl
   if (rc) return rc;
   SCAE_REQUIRE(g_templates && g_pose && g_scalar_partial && x && lse_post && lse_prior &&
                g_tile_sums);
+  if (d->template_repeat > 1) return SCAE_ERR_UNSUPPORTED;
   if (d->templates_alpha) SCAE_REQUIRE(g_alpha_partial);
 #define CALL(CC)                                                                          \
   launch_bwd<CC>(d, x, lse_post, lse_prior, nullptr, nullptr, nullptr, g_templates,       \
@@ -939,6 +949,7 @@ extern "C" int scae_render_gmm_bwd_f32(const scae_decoder_desc *d, const float *
   int rc = check_desc(d);
   if (rc) return rc;
   SCAE_REQUIRE(g_templates && g_pose && g_scalar_partial);
+  if (d->template_repeat > 1) return SCAE_ERR_UNSUPPORTED;  // forward-only (no_grad) feature
   if (d->templates_alpha) SCAE_REQUIRE(g_alpha_partial);
   if (!g_tt && !g_ml) SCAE_REQUIRE(x && lse_post && lse_prior && g_logprob);
 #define CALL(CC)                                                                       \

@@ -1154,11 +1154,14 @@ class DecoderInputs:
 def _make_desc(tensors, output_size):
     (templates, alpha, pose, presence, bg_image, bg_value, bg_ml, temp,
      out_scale) = tensors
-    B, M, C, th, tw = templates.shape
+    B0, M, C, th, tw = templates.shape
+    B = pose.shape[0]            # B0 template sets may serve B = r * B0 images
+    if B % B0:
+        raise ValueError(f"{B} poses cannot share {B0} template sets")
     H, W = output_size
     d = DecoderDesc(_p(templates), _p(alpha), _p(pose), _p(presence),
                     _p(bg_image), _p(bg_value), _p(bg_ml), _p(temp),
-                    _p(out_scale), B, M, C, th, tw, H, W)
+                    _p(out_scale), B, M, C, th, tw, H, W, B // B0)
     return d, (B, M, C, th, tw, H, W)
 
 
@@ -1317,7 +1320,8 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
 def render_gmm_log_prob_sums(inputs: "DecoderInputs", x):
     """(B, tiles) partial sums of the mixture log-likelihood of ``x``; their
     total is sum_{b,c,h,w} log_prob."""
-    B, M, C = inputs.templates.shape[:3]
+    M, C = inputs.templates.shape[1:3]
+    B = inputs.pose.shape[0]
     if tuple(x.shape) != (B, C, *inputs.output_size):
         raise ValueError(f"log_prob target must be {(B, C, *inputs.output_size)}"
                          f", got {tuple(x.shape)}")
@@ -1333,7 +1337,8 @@ def render_templates(inputs: DecoderInputs):
 
 
 def render_gmm_log_prob(inputs: DecoderInputs, x):
-    B, M, C = inputs.templates.shape[:3]
+    M, C = inputs.templates.shape[1:3]
+    B = inputs.pose.shape[0]
     if tuple(x.shape) != (B, C, *inputs.output_size):
         raise ValueError(f"log_prob target must be {(B, C, *inputs.output_size)}"
                          f", got {tuple(x.shape)}")

@@ -110,8 +110,15 @@ class TemplateBasedImageDecoder(nn.Module):
             # the reference reads self.bg_value here (part_decoder.py:192)
             raise AttributeError("'TemplateBasedImageDecoder' object has no "
                                  "attribute 'bg_value'")
-        if pose.shape[-1] != 6 or pose.shape[:2] != templates.shape[:2]:
+        if pose.shape[-1] != 6 or pose.shape[1] != templates.shape[1] or \
+                pose.shape[0] % templates.shape[0]:
             raise ValueError("pose must be [B, n_templates, 6]")
+        if pose.shape[0] != templates.shape[0] and torch.is_grad_enabled() \
+                and templates.requires_grad:
+            # consecutive groups of images sharing a template set is a
+            # forward-only feature of the kernels
+            templates = templates.repeat_interleave(
+                pose.shape[0] // templates.shape[0], dim=0)
         inputs = ops.DecoderInputs(
             tuple(self.output_size),
             templates=templates,

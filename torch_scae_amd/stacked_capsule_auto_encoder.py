@@ -123,9 +123,11 @@ class SCAE(nn.Module):
                 n_obj = res.vote.shape[1]
                 td_presence = parts.presence.repeat_interleave(n_obj, dim=0) \
                     * res.vote_presence_binary.flatten(0, 1)
+                # B*O virtual images, each group of O sharing its image's
+                # templates (the kernels index them, nothing is repeated)
                 res.top_down_per_caps_rec = self.part_decoder(
-                    templates=templates.repeat_interleave(n_obj, dim=0),
-                    pose=res.vote.flatten(0, 1), presence=td_presence)
+                    templates=templates, pose=res.vote.flatten(0, 1),
+                    presence=td_presence)
 
         res.templates = templates
         res.template_presence = parts.presence
