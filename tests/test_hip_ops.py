@@ -300,6 +300,8 @@ def test_capsule_layer_error_behaviour():
         CapsuleLayer(3, 4, 5, 6, noise_type="bogus").cuda()(x)
     with pytest.raises(NameError):      # reference crashes the same way
         CapsuleLayer(3, 4, 5, 6, caps_dropout_rate=0.5).cuda()(x)
+    with pytest.raises(RuntimeError):   # so does its LogisticNormal noise
+        CapsuleLayer(3, 4, 5, 6, noise_type="logistic", noise_scale=4.).cuda()(x)
     with pytest.raises(ValueError):
         sparsity_loss("nope", x[0])
 

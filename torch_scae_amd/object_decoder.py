@@ -70,8 +70,13 @@ class CapsuleLayer(nn.Module):
         if self.noise_type not in (None, False, '', 'uniform', 'logistic'):
             raise ValueError(f'Invalid noise type: {self.noise_type}')
         if self.noise_type == 'logistic':
-            raise NotImplementedError("LogisticNormal presence noise "
-                                      "(object_decoder.py:203) is not built")
+            # the reference cannot run this either: LogisticNormal(0, s)
+            # .sample(shape) carries a trailing event dimension of 2 that does
+            # not broadcast against the logits (object_decoder.py:201-207)
+            raise RuntimeError(
+                "The size of tensor a must match the size of tensor b: "
+                "LogisticNormal noise samples have a trailing dimension of 2 "
+                "(noise_type='logistic' fails the same way in the reference)")
         B = feature.shape[0]
         raw_caps_param = self.mlps(feature)                      # (B, O, D)
         all_param = self.caps_mlps(raw_caps_param)               # (B, O, A)
