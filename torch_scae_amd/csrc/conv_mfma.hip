@@ -31,29 +31,32 @@ struct ConvGeom {
   int B, IH, IW, OH, OW, Cin, Cout, stride;
 };
 
-#define SCAE_TILE_PROLOGUE                                                      \
-  using TL = Tile<SK>;                                                          \
+// MODE: workgroup shape of mfma_tile.h (a `bool SK` argument selects 0 / 1)
+#define SCAE_TILE_PROLOGUE_M(MODE)                                              \
+  using TL = Tile<MODE>;                                                        \
   constexpr int T = TL::T, NQ = TL::NQ;                                         \
   __shared__ __attribute__((aligned(16))) float smem[TL::SMEM];                 \
   float *As = smem, *Bs = smem + TL::OPER;                                      \
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, r = lane & 15,  \
             q = lane >> 4;                                                      \
-  f32x4 acc[2][2];                                                              \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+  f32x4 acc[2][TL::NJ];                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TL::NJ; ++j) \
       acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define SCAE_TILE_PROLOGUE SCAE_TILE_PROLOGUE_M(SK)
 
-// ---- forward: grid (Cout/T, ceil(M/T)) ------------------------------------------
-template <bool SK>
+// ---- forward: grid (Cout/TB, ceil(M/TA)) -----------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ in,
                                                       const float *__restrict__ wf,
                                                       const float *__restrict__ bias,
                                                       float *__restrict__ out, ConvGeom g) {
-  SCAE_TILE_PROLOGUE
+  SCAE_TILE_PROLOGUE_M(MODE)
+  constexpr int TB = TL::TB, NQB = TL::NQB;
   const int M = g.B * g.OH * g.OW, K = 9 * g.Cin;
-  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * TB;
   // each thread stages the same rows every chunk: resolve their pixels once
   long abase[NQ];
-  const float *bptr[NQ];
+  const float *bptr[NQB];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int id = tid + NT * i, m = m0 + id / QPR, kq = 4 * (id % QPR);
@@ -63,21 +66,24 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ 
                 ow = rem - oh * g.OW;
       abase[i] = (((long)n * g.IH + oh * g.stride) * g.IW + ow * g.stride) * g.Cin + kq;
     }
-    bptr[i] = wf + (size_t)(n0 + id / QPR) * K + kq;
   }
-  auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
+#pragma unroll
+  for (int i = 0; i < NQB; ++i) {
+    const int id = tid + NT * i;
+    bptr[i] = wf + (size_t)(n0 + id / QPR) * K + 4 * (id % QPR);
+  }
+  auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQB> &rb) {
     const int k0 = c * BK;
     const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin, kh = tap / 3, kw = tap - kh * 3;
     const int off = (kh * g.IW + kw) * g.Cin + ci0;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      ra.v[i] = abase[i] >= 0 ? ld4(in + abase[i] + off) : zero4();
-      rb.v[i] = ld4(bptr[i] + k0);
-    }
+    for (int i = 0; i < NQ; ++i) ra.v[i] = abase[i] >= 0 ? ld4(in + abase[i] + off) : zero4();
+#pragma unroll
+    for (int i = 0; i < NQB; ++i) rb.v[i] = ld4(bptr[i] + k0);
   };
-  tile_mainloop<STAGES, SK, true, true>(K / BK, As, Bs, acc, wid, r, q, fetch,
-                                        [](const Quads<NQ> &) {});
-  tile_epilogue<SK>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
+  tile_mainloop<STAGES, MODE, true, true>(K / BK, As, Bs, acc, wid, r, q, fetch,
+                                          [](const Quads<NQ> &) {});
+  tile_epilogue<MODE>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
     const int m = m0 + row, n = n0 + col;
     if (m >= M) return;
     const float4 b = ld4(bias + n);
@@ -137,19 +143,20 @@ inline int dgrad_axis(int I, int O, int stride, unsigned char *mask, short *coun
   return n;
 }
 
-template <bool SK>
+template <int MODE>
 __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict__ dpre,
                                                         const float *__restrict__ wd,
                                                         const float *__restrict__ gate,
                                                         float *__restrict__ din, ConvGeom g,
                                                         DgradPlan pl) {
-  SCAE_TILE_PROLOGUE
+  SCAE_TILE_PROLOGUE_M(MODE)
+  constexpr int TB = TL::TB, NQB = TL::NQB;
   // class pair of this tile: the number of class starts at or before it
   const int nz = pl.nrc * pl.ncc;
   const int z = __popcll(__ballot(lane + 1 < nz && (int)blockIdx.y >= pl.tile_start[min(lane + 1, 64)]));
   const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
   const int AH = pl.rcount[rc], AW = pl.ccount[cc], M = g.B * AH * AW, KT = 9 * g.Cout;
-  const int m0 = ((int)blockIdx.y - pl.tile_start[z]) * T, n0 = blockIdx.x * T;
+  const int m0 = ((int)blockIdx.y - pl.tile_start[z]) * T, n0 = blockIdx.x * TB;
   const int sh = g.stride - 1;  // stride 1 or 2
   // the class pair's taps: set bits of rmask x cmask
   const int rm = pl.rmask[rc], cm = pl.cmask[cc];
@@ -162,19 +169,23 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
   };
   const int cpt = g.Cout / BK, nchunk = nkh * nkw * cpt;
   int pn[NQ], pih[NQ], piw[NQ];
-  const float *bptr[NQ];
+  const float *bptr[NQB];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int id = tid + NT * i, m = m0 + id / QPR, kq = 4 * (id % QPR);
+    const int id = tid + NT * i, m = m0 + id / QPR;
     pn[i] = -1, pih[i] = 0, piw[i] = 0;
     if (m < M) {
       const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
       pn[i] = n * g.OH * g.OW;
       pih[i] = pl.rlist[pl.rstart[rc] + a], piw[i] = pl.clist[pl.cstart[cc] + b];
     }
-    bptr[i] = wd + (size_t)(n0 + id / QPR) * KT + kq;
   }
-  auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
+#pragma unroll
+  for (int i = 0; i < NQB; ++i) {
+    const int id = tid + NT * i;
+    bptr[i] = wd + (size_t)(n0 + id / QPR) * KT + 4 * (id % QPR);
+  }
+  auto fetch = [&](int c, Quads<NQ> &ra, Quads<NQB> &rb) {
     const int t = c / cpt, co0 = (c - t * cpt) * BK;
     const int ti = t / nkw, tj = t - ti * nkw;
     const int kh = nth_bit(rm, ti), kw = nth_bit(cm, tj);
@@ -188,12 +199,13 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
       ra.v[i] = ok ? ld4(dpre + (size_t)(pn[i] + oh * g.OW + ow) * g.Cout + co0 +
                          4 * ((tid + NT * i) % QPR))
                    : zero4();
-      rb.v[i] = ld4(bptr[i] + koff);
     }
+#pragma unroll
+    for (int i = 0; i < NQB; ++i) rb.v[i] = ld4(bptr[i] + koff);
   };
-  tile_mainloop<STAGES, SK, true, true>(nchunk, As, Bs, acc, wid, r, q, fetch,
-                                        [](const Quads<NQ> &) {});
-  tile_epilogue<SK>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
+  tile_mainloop<STAGES, MODE, true, true>(nchunk, As, Bs, acc, wid, r, q, fetch,
+                                          [](const Quads<NQ> &) {});
+  tile_epilogue<MODE>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
     const int m = m0 + row;
     if (m >= M) return;
     const int nb = m / (AH * AW), rem = m - nb * AH * AW, a = rem / AW, b = rem - a * AW;
@@ -446,8 +458,15 @@ int check_geom(const ConvGeom &g, bool gemm) {
   return SCAE_OK;
 }
 
-// 64x64 tiles once they fill the chip a few times over, 32x32 split-K tiles below
+// 64x64 tiles once they fill the chip a few times over; below that split-K tiles:
+// 32x64 while those still give enough workgroups (measured on the 128-channel
+// encoder layers at B=128: the forward gains 12-14 % down to ~390 wide tiles, the
+// data gradient -- shorter K per class, costlier prologue -- only well above 512),
+// else 32x32
 inline bool small_tiles(long tiles64) { return tiles64 < 1024; }
+inline int tile_mode(long tiles64, long tiles_wide, long wide_min) {
+  return !small_tiles(tiles64) ? 0 : (tiles_wide >= wide_min ? 2 : 1);
+}
 
 struct WgradPlan {
   bool small;
@@ -540,12 +559,21 @@ extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const floa
   if (rc) return rc;
   SCAE_REQUIRE(in && wf && bias && out);
   const int M = B * g.OH * g.OW;
-  if (small_tiles((long)(Cout / 64) * ((M + 63) / 64)))
-    hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3(Cout / 32, (M + 31) / 32), dim3(NT), 0,
-                       (hipStream_t)stream, in, wf, bias, out, g);
-  else
-    hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3(Cout / 64, (M + 63) / 64), dim3(NT), 0,
-                       (hipStream_t)stream, in, wf, bias, out, g);
+  hipStream_t st = (hipStream_t)stream;
+  switch (tile_mode((long)(Cout / 64) * ((M + 63) / 64), (long)(Cout / 64) * ((M + 31) / 32),
+                    300)) {
+    case 0:
+      hipLaunchKernelGGL(conv_fwd_kernel<0>, dim3(Cout / 64, (M + 63) / 64), dim3(NT), 0, st, in,
+                         wf, bias, out, g);
+      break;
+    case 2:
+      hipLaunchKernelGGL(conv_fwd_kernel<2>, dim3(Cout / 64, (M + 31) / 32), dim3(NT), 0, st, in,
+                         wf, bias, out, g);
+      break;
+    default:
+      hipLaunchKernelGGL(conv_fwd_kernel<1>, dim3(Cout / 32, (M + 31) / 32), dim3(NT), 0, st, in,
+                         wf, bias, out, g);
+  }
   return scae_launch_status();
 }
 
@@ -569,14 +597,20 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
     pl.tile_start[pl.nrc * pl.ncc] = tot;
     return tot;
   };
-  if (small_tiles((long)(Cin / 64) * tiles(64))) {
-    const int ny = tiles(32);
-    hipLaunchKernelGGL(conv_dgrad_kernel<true>, dim3(Cin / 32, ny), dim3(NT), 0,
-                       (hipStream_t)stream, dpre, wd, gate, din, g, pl);
-  } else {
+  hipStream_t st = (hipStream_t)stream;
+  const int mode = tile_mode((long)(Cin / 64) * tiles(64), (long)(Cin / 64) * tiles(32), 600);
+  if (mode == 0) {
     const int ny = tiles(64);
-    hipLaunchKernelGGL(conv_dgrad_kernel<false>, dim3(Cin / 64, ny), dim3(NT), 0,
-                       (hipStream_t)stream, dpre, wd, gate, din, g, pl);
+    hipLaunchKernelGGL(conv_dgrad_kernel<0>, dim3(Cin / 64, ny), dim3(NT), 0, st, dpre, wd, gate,
+                       din, g, pl);
+  } else {
+    const int ny = tiles(32);
+    if (mode == 2)
+      hipLaunchKernelGGL(conv_dgrad_kernel<2>, dim3(Cin / 64, ny), dim3(NT), 0, st, dpre, wd,
+                         gate, din, g, pl);
+    else
+      hipLaunchKernelGGL(conv_dgrad_kernel<1>, dim3(Cin / 32, ny), dim3(NT), 0, st, dpre, wd,
+                         gate, din, g, pl);
   }
   return scae_launch_status();
 }
