@@ -463,7 +463,10 @@ int check_geom(const ConvGeom &g, bool gemm) {
 // encoder layers at B=128: the forward gains 12-14 % down to ~390 wide tiles, the
 // data gradient -- shorter K per class, costlier prologue -- only well above 512),
 // else 32x32
-inline bool small_tiles(long tiles64) { return tiles64 < 1024; }
+#ifndef SCAE_SMALL_TILES
+#define SCAE_SMALL_TILES 1024
+#endif
+inline bool small_tiles(long tiles64) { return tiles64 < SCAE_SMALL_TILES; }
 inline int tile_mode(long tiles64, long tiles_wide, long wide_min) {
   return !small_tiles(tiles64) ? 0 : (tiles_wide >= wide_min ? 2 : 1);
 }
