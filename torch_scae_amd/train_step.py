@@ -33,6 +33,7 @@ class TrainStep:
         self._one = torch.ones((), device=self.device)   # d loss / d loss
         self.use_graph = use_graph
         self._capturing = False
+        self._stream = None
         self._with_log = False
         self.graph = None
         self.world = world()[1]
@@ -69,8 +70,12 @@ class TrainStep:
             self.opt.step(grad_scale=1.0 / self.world)
 
     def _capture(self):
-        # warm up on a side stream (allocator, lazy init), then capture
-        s = torch.cuda.Stream()
+        # warm up on a side stream (allocator, lazy init), then capture; the
+        # same stream for every (re-)capture: autograd keeps each parameter's
+        # AccumulateGrad node, and with it the stream it first ran on
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        s = self._stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(3):
