@@ -316,9 +316,11 @@ extern "C" int scae_capsule_likelihood_fwd_f32(
   if (rc) return rc;
   LkArgs a{vote, scale, vote_presence, dummy_vote, x, presence, B, O, M};
   const size_t lds = lk_lds(O, M, false);
-  if (lds > 48 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void *>(likelihood_fwd_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(likelihood_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL(likelihood_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(NT), lds,
                      (hipStream_t)stream, a, log_prob_per_point, vote_presence_binary, winner,
                      winner_presence, winner_idx, is_from_capsule, soft_winner,
@@ -341,9 +343,11 @@ extern "C" int scae_capsule_likelihood_bwd_f32(
   if (rc) return rc;
   LkArgs a{vote, scale, vote_presence, dummy_vote, x, presence, B, O, M};
   const size_t lds = lk_lds(O, M, true);
-  if (lds > 48 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void *>(likelihood_bwd_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(likelihood_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL(likelihood_bwd_kernel, dim3(B < 1024 ? B : 1024), dim3(NT), lds,
                      (hipStream_t)stream, a, winner_idx, g_lpp, g_winner, g_winner_presence,
                      g_soft_winner, g_soft_winner_presence, g_posterior, g_mixing_log_prob,
