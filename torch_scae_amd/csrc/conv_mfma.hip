@@ -482,7 +482,10 @@ WgradPlan wgrad_plan(int M, int Cin, int Cout) {
   WgradPlan p;
   const long tiles64 = (long)(Cin / 64) * (Cout / 64) * 9;
   p.small = false;
-  long s = (512 + tiles64 - 1) / tiles64;
+#ifndef SCAE_WGRAD_BLOCKS
+#define SCAE_WGRAD_BLOCKS 512
+#endif
+  long s = (SCAE_WGRAD_BLOCKS + tiles64 - 1) / tiles64;
   const long cap = (M / BK) / 8;
   s = s > cap ? cap : s;
   p.splits = (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
