@@ -239,6 +239,10 @@ int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second
  * ---------------------------------------------------------------------- */
 int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout, int Cin,
                               void *stream);
+/* the same for n_layers <= 8 layers in one launch; the five arrays are HOST arrays */
+int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const *w, float *const *wf,
+                                    float *const *wd, const int *Cout, const int *Cin,
+                                    void *stream);
 int scae_conv3x3_first_fwd_f32(const float *img, const float *w, const float *bias,
                                float *out, int B, int Cin, int IH, int IW, int Cout,
                                int stride, void *stream);

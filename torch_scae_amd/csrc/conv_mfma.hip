@@ -303,6 +303,22 @@ __global__ void relayout_weights_kernel(const float *__restrict__ w, float *__re
   wd[((size_t)ci * 9 + tap) * Cout + co] = v;
 }
 
+// the same for up to 8 layers in one launch (blockIdx.y = layer)
+struct RelayoutBatch {
+  const float *w[8];
+  float *wf[8], *wd[8];
+  int Cout[8], Cin[8];
+};
+__global__ void relayout_batch_kernel(RelayoutBatch r) {
+  const int l = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Cout = r.Cout[l], Cin = r.Cin[l];
+  if (e >= Cout * Cin * 9) return;
+  const int co = e / (Cin * 9), rem = e - co * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
+  const float v = r.w[l][e];
+  r.wf[l][((size_t)co * 9 + tap) * Cin + ci] = v;
+  r.wd[l][((size_t)ci * 9 + tap) * Cout + co] = v;
+}
+
 // dW[co][ci][tap] = sum_split partial[(split*9+tap)][co][ci]; db[co] = sum_split bias partials
 __global__ void reduce_wgrad_kernel(const float *__restrict__ partial, float *__restrict__ dw,
                                     float *__restrict__ db, int Cout, int Cin, int splits) {
@@ -499,6 +515,22 @@ extern "C" int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, i
   const int n = Cout * Cin * 9;
   hipLaunchKernelGGL(relayout_weights_kernel, dim3((n + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, w, wf, wd, Cout, Cin);
+  return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const *w,
+                                               float *const *wf, float *const *wd,
+                                               const int *Cout, const int *Cin, void *stream) {
+  SCAE_REQUIRE(n_layers > 0 && n_layers <= 8 && w && wf && wd && Cout && Cin);
+  RelayoutBatch r{};
+  int nmax = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    SCAE_REQUIRE(w[l] && wf[l] && wd[l] && Cout[l] > 0 && Cin[l] > 0);
+    r.w[l] = w[l], r.wf[l] = wf[l], r.wd[l] = wd[l], r.Cout[l] = Cout[l], r.Cin[l] = Cin[l];
+    nmax = nmax > Cout[l] * Cin[l] * 9 ? nmax : Cout[l] * Cin[l] * 9;
+  }
+  hipLaunchKernelGGL(relayout_batch_kernel, dim3((nmax + 255) / 256, n_layers), dim3(256), 0,
+                     (hipStream_t)stream, r);
   return scae_launch_status();
 }
 

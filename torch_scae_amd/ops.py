@@ -380,7 +380,7 @@ def seed_fold(seeds, wq, bq, wk, bk, wv, bv, wo, bo, w2, b2):
 def conv_stack_supported(in_channels, out_channels, kernel_sizes, strides):
     """Shapes the implicit-GEMM kernels are built for."""
     chans = [in_channels] + list(out_channels)
-    return (len(out_channels) >= 1 and in_channels <= 4
+    return (1 <= len(out_channels) <= 9 and in_channels <= 4
             and all(k == 3 for k in kernel_sizes)
             and all(s in (1, 2) for s in strides)
             and all(c % 64 == 0 for c in out_channels)
@@ -406,19 +406,26 @@ class _ConvStack(torch.autograd.Function):
         act = new(B, oh, ow, c1)
         _lib.call("scae_conv3x3_first_fwd_f32", _p(image), _p(weights[0]),
                   _p(biases[0]), _p(act), B, C0, H, W, c1, s, st)
-        acts, wds = [act], []
+        acts, wds, wfs = [act], [], []
+        for l in range(1, L):
+            co, ci = weights[l].shape[0], weights[l].shape[1]
+            wfs.append(new(co, 9, ci))
+            wds.append(new(ci, 9, co))
+        if L > 1:       # every layer's filter re-layout in one launch
+            n = L - 1
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            ints = lambda v: (ctypes.c_int * n)(*v)
+            _lib.call("scae_conv3x3_relayout_batch_f32", n, arr(weights[1:]),
+                      arr(wfs), arr(wds), ints([w.shape[0] for w in weights[1:]]),
+                      ints([w.shape[1] for w in weights[1:]]), st)
         for l in range(1, L):
             w, s = weights[l], strides[l]
             co, ci = w.shape[0], w.shape[1]
             ih, iw = act.shape[1], act.shape[2]
-            wf, wd = new(co, 9, ci), new(ci, 9, co)
-            _lib.call("scae_conv3x3_relayout_f32", _p(w), _p(wf), _p(wd), co,
-                      ci, st)
             out = new(B, (ih - 3) // s + 1, (iw - 3) // s + 1, co)
-            _lib.call("scae_conv3x3_fwd_f32", _p(act), _p(wf), _p(biases[l]),
-                      _p(out), B, ih, iw, ci, co, s, st)
+            _lib.call("scae_conv3x3_fwd_f32", _p(act), _p(wfs[l - 1]),
+                      _p(biases[l]), _p(out), B, ih, iw, ci, co, s, st)
             acts.append(out)
-            wds.append(wd)
             act = out
         ctx.save_for_backward(image, *acts, *wds)
         ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights])
