@@ -236,6 +236,8 @@ int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second
  *   wgrad: dw (Cout,Cin,3,3) = sum_pixels dpre x in and (db nullable) db (Cout)
  *          = sum_pixels dpre; partial is a workspace of
  *          scae_conv3x3_wgrad_splits(B,OH,OW,Cin,Cout) * (9*Cout*Cin + Cout) floats.
+ *          dw == NULL leaves the partials unreduced; wgrad_reduce_batch then
+ *          reduces the partials of up to 8 layers in one launch (HOST arrays).
  * ---------------------------------------------------------------------- */
 int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout, int Cin,
                               void *stream);
@@ -257,6 +259,9 @@ int scae_conv3x3_wgrad_splits(int B, int OH, int OW, int Cin, int Cout);
 int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float *partial, float *dw,
                            float *db, int B, int IH, int IW, int Cin, int Cout, int stride,
                            void *stream);
+int scae_conv3x3_wgrad_reduce_batch_f32(int n_layers, const float *const *partial,
+                                        float *const *dw, float *const *db, const int *Cout,
+                                        const int *Cin, const int *splits, void *stream);
 
 /* ------------------------------------------------------------------------
  * K9  attention pooling of the part-capsule head

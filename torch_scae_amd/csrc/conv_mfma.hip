@@ -320,10 +320,10 @@ __global__ void relayout_batch_kernel(RelayoutBatch r) {
 }
 
 // dW[co][ci][tap] = sum_split partial[(split*9+tap)][co][ci]; db[co] = sum_split bias partials
-__global__ void reduce_wgrad_kernel(const float *__restrict__ partial, float *__restrict__ dw,
-                                    float *__restrict__ db, int Cout, int Cin, int splits) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // over (tap, co, ci): coalesced reads
-  const int n = 9 * Cout * Cin;
+__device__ __forceinline__ void reduce_wgrad(const float *__restrict__ partial,
+                                             float *__restrict__ dw, float *__restrict__ db,
+                                             int Cout, int Cin, int splits, int e) {
+  const int n = 9 * Cout * Cin;  // e over (tap, co, ci): coalesced reads
   if (e < n) {
     const int tap = e / (Cout * Cin), rem = e - tap * Cout * Cin, co = rem / Cin,
               ci = rem - co * Cin;
@@ -336,6 +336,21 @@ __global__ void reduce_wgrad_kernel(const float *__restrict__ partial, float *__
     for (int s = 0; s < splits; ++s) acc += partial[(size_t)splits * n + (size_t)s * Cout + e - n];
     db[e - n] = acc;
   }
+}
+__global__ void reduce_wgrad_kernel(const float *__restrict__ partial, float *__restrict__ dw,
+                                    float *__restrict__ db, int Cout, int Cin, int splits) {
+  reduce_wgrad(partial, dw, db, Cout, Cin, splits, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// ... for up to 8 layers in one launch (blockIdx.y = layer)
+struct ReduceBatch {
+  const float *partial[8];
+  float *dw[8], *db[8];
+  int Cout[8], Cin[8], splits[8];
+};
+__global__ void reduce_wgrad_batch_kernel(ReduceBatch r) {
+  const int l = blockIdx.y;
+  reduce_wgrad(r.partial[l], r.dw[l], r.db[l], r.Cout[l], r.Cin[l], r.splits[l],
+               blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---- first layer (image, C_in <= 4): direct kernels ----------------------------
@@ -664,7 +679,7 @@ extern "C" int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float 
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, true);
   if (rc) return rc;
-  SCAE_REQUIRE(dpre && in && partial && dw);
+  SCAE_REQUIRE(dpre && in && partial);
   const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
   if (p.small)
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(Cin / 32, Cout / 32, 9 * p.splits), dim3(NT),
@@ -672,8 +687,29 @@ extern "C" int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float 
   else
     hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(Cin / 64, Cout / 64, 9 * p.splits),
                        dim3(NT), 0, (hipStream_t)stream, dpre, in, partial, g, p.splits);
-  const int n = 9 * Cout * Cin + Cout;
-  hipLaunchKernelGGL(reduce_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, partial, dw, db, Cout, Cin, p.splits);
+  if (dw) {  // else: the caller reduces later (scae_conv3x3_wgrad_reduce_batch_f32)
+    const int n = 9 * Cout * Cin + Cout;
+    hipLaunchKernelGGL(reduce_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, partial, dw, db, Cout, Cin, p.splits);
+  }
+  return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_wgrad_reduce_batch_f32(int n_layers, const float *const *partial,
+                                                   float *const *dw, float *const *db,
+                                                   const int *Cout, const int *Cin,
+                                                   const int *splits, void *stream) {
+  SCAE_REQUIRE(n_layers > 0 && n_layers <= 8 && partial && dw && db && Cout && Cin && splits);
+  ReduceBatch r{};
+  int nmax = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    SCAE_REQUIRE(partial[l] && dw[l] && Cout[l] > 0 && Cin[l] > 0 && splits[l] > 0);
+    r.partial[l] = partial[l], r.dw[l] = dw[l], r.db[l] = db[l];
+    r.Cout[l] = Cout[l], r.Cin[l] = Cin[l], r.splits[l] = splits[l];
+    const int n = 9 * Cout[l] * Cin[l] + Cout[l];
+    nmax = nmax > n ? nmax : n;
+  }
+  hipLaunchKernelGGL(reduce_wgrad_batch_kernel, dim3((nmax + 255) / 256, n_layers), dim3(256), 0,
+                     (hipStream_t)stream, r);
   return scae_launch_status();
 }

@@ -450,6 +450,7 @@ class _ConvStack(torch.autograd.Function):
         dpre = torch.ops.aten.threshold_backward(
             gy.permute(0, 2, 3, 1).contiguous(), acts[-1], 0.0)
         gws, gbs = [None] * L, [None] * L
+        pending = []       # (partial, gw, gb, co, ci, splits): reduced in one launch
         for l in range(L - 1, 0, -1):
             co, ci = wshapes[l][0], wshapes[l][1]
             xin, s = acts[l - 1], strides[l]
@@ -458,13 +459,19 @@ class _ConvStack(torch.autograd.Function):
             partial = new(splits * (9 * co * ci + co))
             gw, gb = gout(l), gout(L + l)
             _lib.call("scae_conv3x3_wgrad_f32", _p(dpre), _p(xin), _p(partial),
-                      _p(gw), _p(gb), B, ih, iw, ci, co, s, st)
-            gbs[l] = gb
-            gws[l] = gw
+                      None, None, B, ih, iw, ci, co, s, st)
+            pending.append((partial, gw, gb, co, ci, splits))
+            gws[l], gbs[l] = gw, gb
             din = new(B, ih, iw, ci)
             _lib.call("scae_conv3x3_dgrad_f32", _p(dpre), _p(wds[l - 1]),
                       _p(xin), _p(din), B, ih, iw, ci, co, s, st)
             dpre = din
+        if pending:
+            n = len(pending)
+            arr = lambda k: (ctypes.c_void_p * n)(*[p[k].data_ptr() for p in pending])
+            ints = lambda k: (ctypes.c_int * n)(*[p[k] for p in pending])
+            _lib.call("scae_conv3x3_wgrad_reduce_batch_f32", n, arr(0), arr(1),
+                      arr(2), ints(3), ints(4), ints(5), st)
         c1 = wshapes[0][0]
         k1 = C0 * 9 + 1
         partial = new(_lib.load().scae_conv3x3_first_wgrad_rows(B, c1), c1, k1)
