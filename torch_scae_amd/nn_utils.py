@@ -67,6 +67,11 @@ def rand_like(tensor):
     return torch.rand_like(tensor)
 
 
+def replaying():
+    """True inside a ``fixed_noise`` block."""
+    return bool(_replay)
+
+
 @contextlib.contextmanager
 def fixed_noise(draws):
     """Replay ``draws`` (a list of U[0,1) tensors) for the ``rand_like`` calls

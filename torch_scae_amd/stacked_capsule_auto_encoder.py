@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import nn_utils, ops
 from .object_decoder import sparsity_loss
 
 
@@ -72,6 +72,32 @@ class SCAE(nn.Module):
             raise ValueError(f'Invalid vote_type: {self.vote_type}')
         if self.presence_type not in ('enc', 'soft', 'hard'):
             raise ValueError(f'Invalid presence_type: {self.presence_type}')
+        batch_size = image.shape[0]
+        if image.is_cuda and not nn_utils.replaying():
+            # the three presence-noise draws of one forward (part_encoder.py:106,
+            # object_decoder.py:201) as ONE device RNG launch, handed to the
+            # modules through the replay hook
+            with nn_utils.fixed_noise(self._draw_noise(image)):
+                return self._forward(image)
+        return self._forward(image)
+
+    def _draw_noise(self, image):
+        enc, layer = self.part_encoder, self.obj_decoder.capsule_layer
+        B = image.shape[0]
+        shapes = []
+        if self.training and getattr(enc, "noise_scale", 0.) > 0. \
+                and hasattr(enc, "n_caps"):
+            shapes.append((B, enc.n_caps))
+        if getattr(layer, "noise_type", None) == 'uniform' \
+                and hasattr(layer, "n_votes"):
+            shapes += [(B, layer.n_caps, 1), (B, layer.n_caps, layer.n_votes)]
+        if len(shapes) < 2:
+            return []                  # nothing to merge: modules draw themselves
+        sizes = [int(torch.Size(s).numel()) for s in shapes]
+        flat = torch.rand(sum(sizes), device=image.device, dtype=image.dtype)
+        return [c.view(s) for c, s in zip(flat.split(sizes), shapes)]
+
+    def _forward(self, image):
         batch_size = image.shape[0]
         parts = self.part_encoder(image)
         templates = self.template_generator(feature=parts.feature,
