@@ -283,11 +283,14 @@ int scae_attention_pool_bwd_f32(const float *y, const float *g, float *dy, int B
  *   pose (B,A,6)   = geometric_transform(pooled[..., :6], similarity) (K5 math)
  *   presence (B,A) = sigmoid(pooled[..., 6] + (noise_u - .5) * noise_scale)
  *   feature (B,A,P-8) (nullable when P == 8); noise_u (B,A) U[0,1) or NULL;
+ *   absence (B,A) = 1 - presence (nullable; the set-transformer input of
+ *   stacked_capsule_auto_encoder.py:113);
  *   pooled (B,A,P-1) is kept for the backward pass, whose incoming gradients
  *   g_pose / g_presence / g_feature may each be NULL (= zeros). */
 int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, float noise_scale,
                               int similarity, float *pooled, float *pose, float *presence,
-                              float *feature, int B, int HW, int A, int P, void *stream);
+                              float *feature, float *absence, int B, int HW, int A, int P,
+                              void *stream);
 int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *noise_u,
                               float noise_scale, int similarity, const float *g_pose,
                               const float *g_presence, const float *g_feature, float *dy,

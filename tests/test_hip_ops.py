@@ -951,8 +951,9 @@ def test_capsule_head_vs_oracle(B, C, H, W, A, F, sim, noisy):
     xh = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous().cuda() \
         .requires_grad_()
     wh, bh = w.cuda().requires_grad_(), b.cuda().requires_grad_()
-    pose, pres, feat = ops.capsule_head(
+    pose, pres, feat, absence = ops.capsule_head(
         xh, wh, bh, A, u.cuda() if noisy else None, scale, sim)
+    assert torch.equal(absence, 1. - pres.detach().unsqueeze(-1))
     assert (feat is None) == (F == 0)
     assert_close(pose, pose_r.float(), rtol=1e-4, atol=1e-5, what="pose")
     assert_close(pres, pres_r.float(), rtol=1e-4, atol=1e-5, what="presence")

@@ -111,7 +111,7 @@ SIGNATURES = {
     "scae_attention_pool_bwd_f32": [P, P, P] + [c_int] * 4 + [P],
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
                               c_float, c_float, c_float, P],
-    "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
+    "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
     "scae_template_color_supported": [c_int] * 4,
     "scae_template_color_partial_rows": [c_int] * 2,

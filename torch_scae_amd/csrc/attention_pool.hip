@@ -25,6 +25,7 @@ struct PoolArgs {
   float noise_scale;
   int similarity;
   float *pose, *presence, *feature;                  // forward outputs
+  float *absence;                                    // 1 - presence (nullable)
   const float *pooled, *g_pose, *g_presence, *g_feature;  // backward inputs
 };
 
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(NT) void pool_fwd_kernel(PoolArgs k) {
     for (int j = 0; j < 6; ++j) k.pose[(cap0 + a) * 6 + j] = o[j];
     float logit = row[6];
     if (k.noise_u) logit += (k.noise_u[cap0 + a] - .5f) * k.noise_scale;
-    k.presence[cap0 + a] = scae::sigmoidf_(logit);
+    const float pr = scae::sigmoidf_(logit);
+    k.presence[cap0 + a] = pr;
+    if (k.absence) k.absence[cap0 + a] = 1.f - pr;  // set-transformer input, :113
   }
   if (k.feature)
     for (int e = threadIdx.x; e < A * F; e += NT) {
@@ -229,13 +232,13 @@ extern "C" int scae_attention_pool_bwd_f32(const float *y, const float *g, float
 
 extern "C" int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, float noise_scale,
                                          int similarity, float *pooled, float *pose,
-                                         float *presence, float *feature, int B, int HW, int A,
-                                         int P, void *stream) {
+                                         float *presence, float *feature, float *absence, int B,
+                                         int HW, int A, int P, void *stream) {
   PoolArgs k{};
   k.y = y, k.out = pooled, k.B = B, k.HW = HW, k.A = A, k.P = P;
   k.splits = pool_splits(B, A);
   k.noise_u = noise_u, k.noise_scale = noise_scale, k.similarity = similarity;
-  k.pose = pose, k.presence = presence, k.feature = feature;
+  k.pose = pose, k.presence = presence, k.feature = feature, k.absence = absence;
   int rc = check(k);
   if (rc) return rc;
   if (P < 8) return SCAE_ERR_UNSUPPORTED;  // 6 pose + presence + attention logit

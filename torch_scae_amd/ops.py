@@ -578,9 +578,11 @@ class _CapsuleHead(torch.autograd.Function):
         pooled, pose, presence = new(B, n_caps, P - 1), new(B, n_caps, 6), \
             new(B, n_caps)
         feature = new(B, n_caps, F) if F > 0 else None
+        absence = new(B, n_caps, 1)
         _lib.call("scae_capsule_head_fwd_f32", _p(y), _p(noise_u),
                   float(noise_scale), int(similarity), _p(pooled), _p(pose),
-                  _p(presence), _p(feature), B, HW, n_caps, P, _stream(x))
+                  _p(presence), _p(feature), _p(absence), B, HW, n_caps, P,
+                  _stream(x))
         ctx.save_for_backward(x, weight, y, pooled,
                               *([noise_u] if noise_u is not None else []))
         ctx.meta = (n_caps, float(noise_scale), int(similarity),
@@ -589,10 +591,11 @@ class _CapsuleHead(torch.autograd.Function):
         if feature is None:
             feature = new(B, n_caps, 0)
             ctx.mark_non_differentiable(feature)
-        return pose, presence, feature
+        ctx.mark_non_differentiable(absence)
+        return pose, presence, feature, absence
 
     @staticmethod
-    def backward(ctx, g_pose, g_presence, g_feature):
+    def backward(ctx, g_pose, g_presence, g_feature, _g_absence):
         x, weight, y, pooled = ctx.saved_tensors[:4]
         A, noise_scale, similarity, has_noise = ctx.meta
         noise_u = ctx.saved_tensors[4] if has_noise else None
@@ -608,10 +611,11 @@ class _CapsuleHead(torch.autograd.Function):
 def capsule_head(x, weight, bias, n_caps, noise_u=None, noise_scale=0.,
                  similarity=False):
     """Fused part-capsule head; see ``_CapsuleHead``.  feature is None when
-    the capsules have no special features."""
-    pose, presence, feature = _CapsuleHead.apply(
+    the capsules have no special features.  Also returns 1 - presence
+    (B,A,1), detached -- the set-transformer input of SCAE.forward."""
+    pose, presence, feature, absence = _CapsuleHead.apply(
         x, weight, bias, noise_u, n_caps, noise_scale, similarity)
-    return pose, presence, (feature if feature.shape[-1] > 0 else None)
+    return pose, presence, (feature if feature.shape[-1] > 0 else None), absence
 
 
 def attention_conv_pool(x, weight, bias, n_caps):

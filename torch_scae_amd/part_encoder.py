@@ -85,10 +85,11 @@ class CapsuleImageEncoder(nn.Module):
                 # fused behind the pooling
                 noise = rand_like(x.new_empty(batch_size, self.n_caps)) \
                     if noisy else None
-                pose, presence, feature = ops.capsule_head(
+                pose, presence, feature, absence = ops.capsule_head(
                     x, weight, self.att_conv.bias, self.n_caps, noise,
                     self.noise_scale, self.similarity_transform)
-                return AttrDict(pose=pose, presence=presence, feature=feature)
+                return AttrDict(pose=pose, presence=presence, feature=feature,
+                                _absence=absence)
             h = ops.attention_conv_pool(x, weight, self.att_conv.bias,
                                         self.n_caps)
         else:

@@ -111,7 +111,10 @@ class SCAE(nn.Module):
         if self.stop_grad_caps_input:
             in_pose, in_presence, in_templates = \
                 in_pose.detach(), in_presence.detach(), in_templates.detach()
-        segments = [in_pose, 1. - in_presence.unsqueeze(-1)]
+        # 1 - presence: already emitted (detached) by the fused capsule head
+        absence = parts._absence if self.stop_grad_caps_input and \
+            "_absence" in parts else 1. - in_presence.unsqueeze(-1)
+        segments = [in_pose, absence]
         if parts.feature is not None:
             segments.append(parts.feature)
         segments.append(in_templates.flatten(2))
