@@ -13,41 +13,30 @@ __global__ __launch_bounds__(64) void class_probs_kernel(
     const float *__restrict__ cp, const float *__restrict__ posterior,
     const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ prior_prob,
     float *__restrict__ post_prob, int O, int M, int ncls) {
+  __shared__ float s_x[2][64], s_l[2][MAXCLS];
   const int b = blockIdx.x, lane = threadIdx.x;
-  float x0 = 0.f, x1 = 0.f;
-  if (lane < O) {
-    x0 = cp[(size_t)b * O + lane];
+  if (lane < O) {  // lane = capsule: the two classifier inputs
+    s_x[0][lane] = cp[(size_t)b * O + lane];
     const float *p = posterior + ((size_t)b * (O + 1) + lane) * M;
-    for (int m = 0; m < M; ++m) x1 += p[m];
+    float mass = 0.f;
+    for (int m = 0; m < M; ++m) mass += p[m];
+    s_x[1][lane] = mass;
   }
-  float l0[MAXCLS], l1[MAXCLS];
-  float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c) {
-    l0[c] = l1[c] = -INFINITY;
-    if (c < ncls) {
-      const float wv = lane < O ? w[c * O + lane] : 0.f;
-      l0[c] = scae::wave_sum(x0 * wv) + bias[c];
-      l1[c] = scae::wave_sum(x1 * wv) + bias[c];
-      m0 = fmaxf(m0, l0[c]);
-      m1 = fmaxf(m1, l1[c]);
-    }
+  __syncthreads();
+  if (lane < 2 * ncls) {  // lane = (input, class): one logit each
+    const int which = lane / ncls, c = lane - which * ncls;
+    float t = bias[c];
+    for (int o = 0; o < O; ++o) t = fmaf(s_x[which][o], w[c * O + o], t);
+    s_l[which][c] = t;
   }
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c)
-    if (c < ncls) {
-      l0[c] = expf(l0[c] - m0);
-      l1[c] = expf(l1[c] - m1);
-      s0 += l0[c];
-      s1 += l1[c];
-    }
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c)
-    if (c < ncls && lane == c) {
-      prior_prob[(size_t)b * ncls + c] = l0[c] / s0;
-      post_prob[(size_t)b * ncls + c] = l1[c] / s1;
-    }
+  __syncthreads();
+  if (lane < 2 * ncls) {
+    const int which = lane / ncls, c = lane - which * ncls;
+    float mx = -INFINITY, sum = 0.f;
+    for (int k = 0; k < ncls; ++k) mx = fmaxf(mx, s_l[which][k]);
+    for (int k = 0; k < ncls; ++k) sum += expf(s_l[which][k] - mx);
+    (which ? post_prob : prior_prob)[(size_t)b * ncls + c] = expf(s_l[which][c] - mx) / sum;
+  }
 }
 }  // namespace
 
