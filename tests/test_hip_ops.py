@@ -711,6 +711,8 @@ def test_loss_tail_vs_oracle(prior, post, use_label, const):
     (48, 2, 40, [64, 64], [1, 2]),         # 64x64 tiles, strided data gradient
     (3, 1, 12, [384, 384], [1, 1]),        # 64x64 weight-gradient tiles
     (128, 1, 40, [128, 128, 128], [2, 2, 1]),   # cfg-2 sizes: 32x64 split-K tiles
+    (4, 4, 11, [64], [1]),                 # image layer only, 4 input channels
+    (2, 2, 30, [128, 64, 64, 64, 64], [2, 1, 1, 1, 1]),   # five layers
 ])
 def test_conv_stack_vs_conv2d(B, C0, HW, chans, strides):
     import torch.nn.functional as F
@@ -760,8 +762,31 @@ def test_conv_stack_vs_conv2d(B, C0, HW, chans, strides):
 
 def test_conv_stack_falls_back_for_small_channel_counts():
     from torch_scae_amd import ops
+    from torch_scae_amd.part_encoder import CNNEncoder
     assert not ops.conv_stack_supported(1, [8, 8], [3, 3], [2, 1])
     assert not ops.conv_stack_supported(1, [64, 64], [3, 5], [2, 1])
+    assert not ops.conv_stack_supported(1, [64, 64], [3, 3], [3, 1])
+    assert not ops.conv_stack_supported(5, [64], [3], [1])
+    # unsupported shapes still run (library convolutions), same module surface
+    torch.manual_seed(0)
+    enc = CNNEncoder((1, 20, 20), [8, 8], [3, 3], [3, 1]).cuda()
+    x = torch.rand(2, 1, 20, 20, device="cuda")
+    y = enc(x)
+    assert tuple(y.shape[1:]) == tuple(enc.output_shape) == (8, 4, 4)
+    y.sum().backward()
+    assert enc.network[0].weight.grad is not None
+
+
+def test_mnist_transform_on_device():
+    from torch_scae_amd.data import pad_and_translate
+    g = torch.Generator().manual_seed(3)
+    digits = torch.randint(0, 256, (64, 1, 28, 28), generator=g, dtype=torch.uint8)
+    shifts = torch.randint(-6, 7, (64, 2), generator=g)
+    a = pad_and_translate(digits, (40, 40), shifts=shifts)
+    b = pad_and_translate(digits.cuda(), (40, 40), shifts=shifts)
+    # (x / 255 may round differently on the device: 1 ulp)
+    assert b.is_cuda and torch.allclose(a, b.cpu(), rtol=0, atol=1e-7)
+    assert torch.equal(a == 0, b.cpu() == 0)          # same placement
 
 
 # --------------------------------------------------------------------------
