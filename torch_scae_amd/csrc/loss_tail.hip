@@ -350,10 +350,19 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
     if (prior) {
       for (int i = threadIdx.x; i < B * O; i += NT) g_cp[i] = gacc[i];
     } else {
-      // posterior (B,O+1,M): mass/M = sum_m post / M; the dummy row gets zero
-      for (int i = threadIdx.x; i < B * (O + 1) * M; i += NT) {
-        const int bo = i / M, o = bo % (O + 1), b = bo / (O + 1);
-        g_post[i] = o < O ? gacc[b * O + o] / M : 0.f;
+      // posterior (B,O+1,M): mass/M = sum_m post / M, i.e. one value per (b, o) row
+      // of M entries; the dummy row gets zero.  One row per thread: no per-element
+      // index divisions, 16-byte stores when M allows
+      for (int bo = threadIdx.x; bo < B * (O + 1); bo += NT) {
+        const int b = bo / (O + 1), o = bo - b * (O + 1);
+        const float v = o < O ? gacc[b * O + o] / M : 0.f;
+        float *row = g_post + (size_t)bo * M;
+        if ((M & 3) == 0) {
+          const float4 v4 = make_float4(v, v, v, v);
+          for (int m = 0; m < M / 4; ++m) reinterpret_cast<float4 *>(row)[m] = v4;
+        } else {
+          for (int m = 0; m < M; ++m) row[m] = v;
+        }
       }
     }
     return;
@@ -374,17 +383,29 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
       if (cc < a.ncls) c.gl[e * MAXCLS + cc] = gl[cc] * gx / B;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.ncls * O; i += NT) {
-    const int cc = i / O, o = i - cc * O;
+  // g_w[cc][o] = sum_b glogit * input, g_b[cc] = sum_b glogit: few outputs with a
+  // 2B-long sum each -> four lanes per output, interleaved over b, meet by shuffle
+  const int nout = a.ncls * O + a.ncls;
+  for (int e = threadIdx.x; e < ((nout * 4 + NT - 1) / NT) * NT; e += NT) {
+    const int out = e >> 2, part = e & 3;
     float t = 0.f;
-    for (int b = 0; b < B; ++b)
-      t += c.gl[b * MAXCLS + cc] * c.cp[b * O + o] + c.gl[(B + b) * MAXCLS + cc] * gacc[b * O + o];
-    g_w[i] = t;
-  }
-  for (int cc = threadIdx.x; cc < a.ncls; cc += NT) {
-    float t = 0.f;
-    for (int b = 0; b < B; ++b) t += c.gl[b * MAXCLS + cc] + c.gl[(B + b) * MAXCLS + cc];
-    g_b[cc] = t;
+    if (out < a.ncls * O) {
+      const int cc = out / O, o = out - cc * O;
+      for (int b = part; b < B; b += 4)
+        t += c.gl[b * MAXCLS + cc] * c.cp[b * O + o] +
+             c.gl[(B + b) * MAXCLS + cc] * gacc[b * O + o];
+    } else if (out < nout) {
+      const int cc = out - a.ncls * O;
+      for (int b = part; b < B; b += 4) t += c.gl[b * MAXCLS + cc] + c.gl[(B + b) * MAXCLS + cc];
+    }
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (part == 0 && out < nout) {
+      if (out < a.ncls * O)
+        g_w[out] = t;
+      else
+        g_b[out - a.ncls * O] = t;
+    }
   }
 }
 
