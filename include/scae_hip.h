@@ -48,6 +48,16 @@ int scae_abi_version(void);
 const char *scae_error_string(int code);
 
 /* ------------------------------------------------------------------------
+ * Presence-logit noise     replaces torch.rand_like (part_encoder.py:106,
+ *     object_decoder.py:201): out[0..n) ~ U[0,1), Philox4x32-10 keyed by
+ *     state[0] (seed) and counted by state[1] (launches so far), which the
+ *     kernel itself advances -- so a replayed HIP graph draws fresh noise.
+ *     state: 3 uint64 of device memory {seed, 0, 0} owned by the caller; one
+ *     state per stream of concurrent use.
+ * ---------------------------------------------------------------------- */
+int scae_uniform_f32(float *out, int64_t n, uint64_t *state, void *stream);
+
+/* ------------------------------------------------------------------------
  * K5  geometric_transform            replaces cv_ops.py:20-76
  *   pose (n,6) -> out (n,6), or (n,9) when as_matrix (third row 0,0,1).
  *   similarity / nonlinear / as_matrix: the reference's three flags.
@@ -186,15 +196,17 @@ int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc, const scae_seed_fold
  *     C[g*c_batch + m*ldc + n].  epi: + bias[g*bias_batch + n*bias_ld]
  *     (nullable), ReLU if relu, then zeroed where mask[g*mask_batch +
  *     m*ldmask + n] <= 0 (nullable; the ReLU gate of the backward pass).
- *     asum (nullable, needs a_kcontig == 0): asum[g*asum_batch + m] =
- *     sum_k A[g](m,k), the bias gradient that goes with a weight-gradient GEMM.
+ *     asum (nullable, needs a_kcontig == 0): asum[g*asum_batch + m*asum_ld] =
+ *     sum_k A[g](m,k), the bias gradient that goes with a weight-gradient GEMM
+ *     (asum_ld <= 0 means 1; a stride lets it land in a column of C).
  *     Also serves the 1x1 attention convolution of part_encoder.py:71-73.
  * ---------------------------------------------------------------------- */
 int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
                   const float *mask, float *asum, int batch, int M, int N, int K,
                   int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
                   int64_t b_batch, int ldc, int64_t c_batch, int bias_ld, int64_t bias_batch,
-                  int ldmask, int64_t mask_batch, int64_t asum_batch, int relu, void *stream);
+                  int ldmask, int64_t mask_batch, int64_t asum_batch, int asum_ld, int relu,
+                  void *stream);
 
 /* Two independent GEMMs of the kind above in ONE launch (e.g. the weight- and
  * the data-gradient GEMM of a layer, which wait for the same incoming
@@ -216,7 +228,7 @@ typedef struct scae_gemm_desc {
   int64_t bias_batch;
   int ldmask;
   int64_t mask_batch, asum_batch;
-  int relu;
+  int relu, asum_ld;
 } scae_gemm_desc;
 int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
 
@@ -357,6 +369,18 @@ typedef struct scae_sum_segment {
 int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
                       const scae_sum_segment *segments, int n_segments, void *stream);
 
+/* Up to 8 scaled full sums in ONE launch: dst[i][0] = scale[i] * sum(src[i][0..n[i]))
+ * (one workgroup each, fixed order).  The scalar outputs of the forward pass:
+ * cpr_dynamic_reg_loss = sum(reg_partial)/2/B (object_decoder.py:170) and
+ * log_prob = sum(log_prob_per_point)/B (:301-306). */
+typedef struct scae_scaled_sum {
+  const float *src;
+  int64_t n;
+  float scale;
+  float *dst;
+} scae_scaled_sum;
+int scae_scaled_sums_f32(const scae_scaled_sum *jobs, int n_jobs, void *stream);
+
 /* ------------------------------------------------------------------------
  * K3  capsule votes                  replaces object_decoder.py:160-225
  *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
@@ -390,7 +414,10 @@ int scae_capsule_votes_fwd_f32(const float *all_param, const float *cpr_static,
  * gcaps_presence (B,O) nullable, routed to vote caps_arg of each capsule.
  * outputs: gall_param (B,O,A); gcpr_in (B,O,V,6) = grad wrt
  * (cpr_dynamic + cpr_static) (caller sums over B for cpr_static; the bias
- * grads are the batch sums of the matching gall_param slices). */
+ * grads are the batch sums of the matching gall_param slices);
+ * gall_param_gated (B,O,A), nullable: gall_param zeroed where all_param <= 0,
+ * i.e. the gradient w.r.t. the pre-activation of the ReLU that produced
+ * all_param (saves the caller a threshold_backward launch). */
 int scae_capsule_votes_bwd_f32(const float *all_param, const float *cpr_static,
                                const float *bias_cvr, const float *bias_caps,
                                const float *bias_vote, const float *bias_scale,
@@ -400,7 +427,8 @@ int scae_capsule_votes_bwd_f32(const float *all_param, const float *cpr_static,
                                const float *glogit_caps, const float *glogit_vote,
                                const float *greg, const float *gcaps_presence,
                                const int *caps_arg, float *gall_param, float *gcpr_in,
-                               int B, int O, int V, int similarity, int learn_vote_scale,
+                               float *gall_param_gated, int B, int O, int V,
+                               int similarity, int learn_vote_scale,
                                int allow_deformations, void *stream);
 
 /* ------------------------------------------------------------------------

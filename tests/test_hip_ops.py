@@ -870,6 +870,12 @@ def test_gemm_layouts_and_epilogues(G, M, N, K, ak, bk):
         asum = torch.full((G, M), float("nan"), device="cuda")
         run(asum=ops._p(asum), asum_b=M)
         assert_close(asum, A.double().sum(2).float(), what="asum", **tol)
+        # strided destination (a column of a wider matrix)
+        wide = torch.full((G, M, 3), float("nan"), device="cuda")
+        run(asum=ops._off(wide, 2), asum_b=3 * M, asum_ld=3)
+        assert_close(wide[:, :, 2], A.double().sum(2).float(),
+                     what="strided asum", **tol)
+        assert bool(torch.isnan(wide[:, :, :2]).all())
 
 
 # --------------------------------------------------------------------------
@@ -1126,3 +1132,44 @@ def test_gmm_mode_straight_through_vs_oracle(maximum):
     assert_close(out, ref, 1e-6, 1e-5, "mode")
     assert_close(lh.grad, lr.grad, 1e-6, 1e-5, "d_loc")
     assert_close(mh.grad, mr.grad, 1e-6, 1e-5, "d_logits")
+
+
+# --------------------------------------------------------------------------
+# device-resident noise generator (replaces torch.rand_like on the hot path)
+# --------------------------------------------------------------------------
+def test_uniform_generator_statistics_and_state():
+    from torch_scae_amd import ops
+    ref = torch.zeros(1, device="cuda")
+    torch.manual_seed(1234)
+    a = ops.uniform(79872, ref)
+    b = ops.uniform(79872, ref)
+    assert a.shape == (79872,) and a.dtype == torch.float32
+    assert float(a.min()) >= 0.0 and float(a.max()) < 1.0
+    assert abs(float(a.mean()) - 0.5) < 5e-3
+    assert abs(float(a.var()) - 1.0 / 12.0) < 2e-3
+    assert not torch.equal(a, b)                 # the state advanced
+    # neighbouring draws are uncorrelated
+    assert abs(float(((a[:-1] - .5) * (a[1:] - .5)).mean())) < 2e-3
+    torch.manual_seed(1234)                      # re-seeding restarts it
+    assert torch.equal(ops.uniform(79872, ref), a)
+    odd = ops.uniform(5, ref)                    # ragged tail of a group of 4
+    assert odd.shape == (5,) and float(odd.max()) < 1.0
+
+
+def test_uniform_generator_advances_under_graph_replay():
+    from torch_scae_amd import ops
+    ref = torch.zeros(1, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.uniform(1000, ref)                   # creates the stream's state
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = ops.uniform(1000, ref)
+    g.replay()
+    first = out.clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(first, out)
+    assert 0.0 <= float(out.min()) and float(out.max()) < 1.0

@@ -35,13 +35,18 @@ class GemmDesc(Structure):
                 ("b_batch", c_int64), ("ldc", c_int), ("c_batch", c_int64),
                 ("bias_ld", c_int), ("bias_batch", c_int64), ("ldmask", c_int),
                 ("mask_batch", c_int64), ("asum_batch", c_int64),
-                ("relu", c_int)]
+                ("relu", c_int), ("asum_ld", c_int)]
 
 
 class SumSegment(Structure):
     """struct scae_sum_segment"""
     _fields_ = [("dst", P), ("begin", c_int64), ("end", c_int64),
                 ("period", c_int64)]
+
+
+class ScaledSum(Structure):
+    """struct scae_scaled_sum"""
+    _fields_ = [("src", P), ("n", c_int64), ("scale", c_float), ("dst", P)]
 
 
 class LossExtras(Structure):
@@ -71,6 +76,7 @@ class SeedFoldGrads(Structure):
 SIGNATURES = {
     "scae_abi_version": [],
     "scae_error_string": [c_int],
+    "scae_uniform_f32": [P, c_int64, P, P],
     "scae_geometric_transform_fwd_f32": [P, P, c_int64, c_int, c_int, c_int, P],
     "scae_geometric_transform_bwd_f32": [P, P, P, c_int64, c_int, c_int, c_int,
                                          P],
@@ -94,7 +100,8 @@ SIGNATURES = {
     "scae_seed_fold_bwd_f32": [POINTER(SeedFoldDesc), POINTER(SeedFoldGrads), P],
     "scae_gemm_f32": [P] * 6 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
                                               c_int, c_int64, c_int, c_int64,
-                                              c_int, c_int64, c_int64, c_int, P],
+                                              c_int, c_int64, c_int64, c_int, c_int,
+                                              P],
     "scae_gemm_pair_f32": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_relayout_batch_f32": [c_int, P, P, P, P, P, P],
@@ -118,11 +125,12 @@ SIGNATURES = {
     "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],
     "scae_template_color_bwd_f32": [P] * 12 + [c_int] * 8 + [P],
     "scae_sum_rows_f32": [P, c_int64, c_int64, POINTER(SumSegment), c_int, P],
+    "scae_scaled_sums_f32": [POINTER(ScaledSum), c_int, P],
     "scae_class_probs_supported": [c_int] * 2,
     "scae_class_probs_f32": [P] * 6 + [c_int] * 4 + [P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 8
                                   + [c_int] * 6 + [P],
-    "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 10
+    "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 11
                                   + [c_int] * 6 + [P],
     "scae_capsule_likelihood_fwd_f32": [P] * 17 + [c_int] * 3 + [P],
     "scae_capsule_likelihood_bwd_f32": [P] * 22 + [c_int] * 3 + [P],

@@ -156,11 +156,19 @@ __global__ __launch_bounds__(NT) void votes_bwd_kernel(
     const float *__restrict__ gvp, const float *__restrict__ glc,
     const float *__restrict__ glv, const float *__restrict__ greg,
     float *__restrict__ gall, float *__restrict__ gcpr_in,
-    const float *__restrict__ g_caps_presence, const int *__restrict__ caps_arg) {
+    const float *__restrict__ g_caps_presence, const int *__restrict__ caps_arg,
+    float *__restrict__ gall_gated) {
   const int bo = blockIdx.x, o = bo % a.O, V = a.V, lane = threadIdx.x;
   const int A = 8 * V + 7;
   const float *ap = a.all_param + (size_t)bo * A;
   float *ga = gall + (size_t)bo * A;
+  // optional second copy zeroed where all_param <= 0: all_param is a ReLU
+  // output, so this is the gradient w.r.t. the producing layer's pre-activation
+  float *gg = gall_gated ? gall_gated + (size_t)bo * A : nullptr;
+  auto put = [&](int i, float v) {
+    ga[i] = v;
+    if (gg) gg[i] = ap[i] > 0.f ? v : 0.f;
+  };
 
   float cv[6];
 #pragma unroll
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(NT) void votes_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       gcpr_in[((size_t)bo * V + v) * 6 + i] = gin[i];
-      ga[v * 6 + i] = a.allow_deformations ? gin[i] + reg_w * dyn[i] : 0.f;
+      put(v * 6 + i, a.allow_deformations ? gin[i] + reg_w * dyn[i] : 0.f);
     }
 
     float lv = ap[6 * V + 7 + v] + a.bias_vote[o * V + v];
@@ -218,12 +226,12 @@ __global__ __launch_bounds__(NT) void votes_bwd_kernel(
     gpc += g_vp * pv;
     float g_lv = g_vp * pc * pv * (1.f - pv);
     if (glv) g_lv += glv[(size_t)bo * V + v];
-    ga[6 * V + 7 + v] = g_lv;
+    put(6 * V + 7 + v, g_lv);
     float g_sc = 0.f;
     if (a.learn_vote_scale && gscale)
       g_sc = gscale[(size_t)bo * V + v] *
              scae::softplus_grad(ap[7 * V + 7 + v] + a.bias_scale[o * V + v] + .5f);
-    ga[7 * V + 7 + v] = g_sc;
+    put(7 * V + 7 + v, g_sc);
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) gC[i] = scae::wave_sum(gC[i]);
@@ -232,10 +240,10 @@ __global__ __launch_bounds__(NT) void votes_bwd_kernel(
     float gin[6];
     xf_backward(C, a.similarity, gC, gin);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ga[6 * V + i] = gin[i];
+    for (int i = 0; i < 6; ++i) put(6 * V + i, gin[i]);
     float g_lc = gpc * pc * (1.f - pc);
     if (glc) g_lc += glc[bo];
-    ga[6 * V + 6] = g_lc;
+    put(6 * V + 6, g_lc);
   }
 }
 
@@ -275,8 +283,8 @@ extern "C" int scae_capsule_votes_bwd_f32(
     const float *gvote, const float *gscale, const float *gvote_presence,
     const float *glogit_caps, const float *glogit_vote, const float *greg,
     const float *gcaps_presence, const int *caps_arg, float *gall_param, float *gcpr_in,
-    int B, int O, int V, int similarity, int learn_vote_scale, int allow_deformations,
-    void *stream) {
+    float *gall_param_gated, int B, int O, int V, int similarity, int learn_vote_scale,
+    int allow_deformations, void *stream) {
   VoteArgs a{all_param, cpr_static, bias_cvr, bias_caps, bias_vote, bias_scale,
              noise_caps, noise_vote, noise_scale, B, O, V, similarity, learn_vote_scale,
              allow_deformations};
@@ -285,6 +293,6 @@ extern "C" int scae_capsule_votes_bwd_f32(
   SCAE_REQUIRE(gall_param && gcpr_in && (!gcaps_presence || caps_arg));
   hipLaunchKernelGGL(votes_bwd_kernel, dim3(B * O), dim3(NT), 0, (hipStream_t)stream, a,
                      gvote, gscale, gvote_presence, glogit_caps, glogit_vote, greg,
-                     gall_param, gcpr_in, gcaps_presence, caps_arg);
+                     gall_param, gcpr_in, gcaps_presence, caps_arg, gall_param_gated);
   return scae_launch_status();
 }

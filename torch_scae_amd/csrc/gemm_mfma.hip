@@ -10,7 +10,8 @@
 // gate (multiply by mask[m][n] > 0) so that the backward pass hands the next
 // layer the gradient w.r.t. its pre-activation directly.  With a k-strided A
 // the kernel can also emit asum[m] = sum_k A(m, k) -- the bias gradient of a
-// weight-gradient GEMM -- from the operand registers it stages anyway.
+// weight-gradient GEMM -- from the operand registers it stages anyway (written
+// with stride asum_ld, so it can land in a column of the weight gradient).
 //
 // Tile loop: mfma_tile.h (64 x 64 tiles, or 32 x 32 split-K tiles when the
 // former would give the 256 CUs too few workgroups).  fp32 MFMA is exact fp32
@@ -25,7 +26,7 @@ struct GemmArgs {
   float *C, *asum;
   long a_batch, b_batch, c_batch, bias_batch, mask_batch, asum_batch;
   int lda, ldb, ldc, bias_ld, ldmask;
-  int M, N, K, relu;
+  int M, N, K, relu, asum_ld;
 };
 
 // One (T x 32) operand tile = T*8 quads of 4 floats fetched into registers (so
@@ -129,7 +130,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
     if (tid < T && m0 + tid < g.M) {
       float sum = 0.f;
       for (int j = 0; j < NT / (T / 4); ++j) sum += smem[4 * (tid / 4 + (T / 4) * j) + (tid & 3)];
-      g.asum[z * g.asum_batch + m0 + tid] = sum;
+      g.asum[z * g.asum_batch + (size_t)(m0 + tid) * g.asum_ld] = sum;
     }
   }
 }
@@ -180,12 +181,12 @@ extern "C" int scae_gemm_f32(const float *A, const float *B, float *C, const flo
                              int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
                              int64_t b_batch, int ldc, int64_t c_batch, int bias_ld,
                              int64_t bias_batch, int ldmask, int64_t mask_batch,
-                             int64_t asum_batch, int relu, void *stream) {
+                             int64_t asum_batch, int asum_ld, int relu, void *stream) {
   SCAE_REQUIRE(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0);
   if (asum && a_kcontig) return SCAE_ERR_UNSUPPORTED;
   GemmArgs g{A, B, bias, mask, C, asum, (long)a_batch, (long)b_batch, (long)c_batch,
              (long)bias_batch, (long)mask_batch, (long)asum_batch, lda, ldb, ldc, bias_ld,
-             ldmask, M, N, K, relu};
+             ldmask, M, N, K, relu, asum_ld > 0 ? asum_ld : 1};
   const long tiles64 = (long)((N + 63) / 64) * ((M + 63) / 64) * batch;
   if (tiles64 < 1024)
     launch<true>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
@@ -200,7 +201,8 @@ static int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
   if (d->asum && d->a_kcontig) return SCAE_ERR_UNSUPPORTED;
   g = GemmArgs{d->A, d->B, d->bias, d->mask, d->C, d->asum, (long)d->a_batch, (long)d->b_batch,
                (long)d->c_batch, (long)d->bias_batch, (long)d->mask_batch, (long)d->asum_batch,
-               d->lda, d->ldb, d->ldc, d->bias_ld, d->ldmask, d->M, d->N, d->K, d->relu};
+               d->lda, d->ldb, d->ldc, d->bias_ld, d->ldmask, d->M, d->N, d->K, d->relu,
+               d->asum_ld > 0 ? d->asum_ld : 1};
   return SCAE_OK;
 }
 

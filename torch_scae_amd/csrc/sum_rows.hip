@@ -48,7 +48,29 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(const float *__restrict__ 
     }
   }
 }
+struct SumJobs {
+  scae_scaled_sum j[8];
+};
+__global__ __launch_bounds__(1024) void scaled_sums_kernel(SumJobs jobs) {
+  __shared__ float red[16];
+  const scae_scaled_sum &job = jobs.j[blockIdx.x];
+  float v[1] = {0.f};
+  for (int64_t i = threadIdx.x; i < job.n; i += 1024) v[0] += job.src[i];
+  scae::block_sum<1, 1024>(v, red);
+  if (threadIdx.x == 0) job.dst[0] = v[0] * job.scale;
+}
 }  // namespace
+
+extern "C" int scae_scaled_sums_f32(const scae_scaled_sum *jobs, int n_jobs, void *stream) {
+  SCAE_REQUIRE(jobs && n_jobs > 0 && n_jobs <= 8);
+  SumJobs sj;
+  for (int i = 0; i < n_jobs; ++i) {
+    sj.j[i] = jobs[i];
+    SCAE_REQUIRE(sj.j[i].src && sj.j[i].dst && sj.j[i].n > 0);
+  }
+  hipLaunchKernelGGL(scaled_sums_kernel, dim3(n_jobs), dim3(1024), 0, (hipStream_t)stream, sj);
+  return scae_launch_status();
+}
 
 extern "C" int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
                                  const scae_sum_segment *segments, int n_segments,

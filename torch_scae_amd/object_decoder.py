@@ -58,7 +58,8 @@ class CapsuleLayer(nn.Module):
         self.cpr_static = nn.Parameter(
             torch.zeros(1, n_caps, n_votes, self.n_transform_params))
 
-    def _votes(self, feature, parent_transform=None, parent_presence=None):
+    def _votes(self, feature, parent_transform=None, parent_presence=None,
+               defer_reg=False):
         if parent_transform is not None or parent_presence is not None:
             raise NotImplementedError(
                 "hierarchical parent_transform / parent_presence are not used "
@@ -78,8 +79,12 @@ class CapsuleLayer(nn.Module):
                 "LogisticNormal noise samples have a trailing dimension of 2 "
                 "(noise_type='logistic' fails the same way in the reference)")
         B = feature.shape[0]
-        raw_caps_param = self.mlps(feature)                      # (B, O, D)
-        all_param = self.caps_mlps(raw_caps_param)               # (B, O, A)
+        # on the HIP path the three stages hand each other gradients w.r.t.
+        # PRE-activations (the ReLU gates ride in the GEMM / K3 epilogues)
+        fused = feature.is_cuda
+        raw_caps_param = self.mlps(feature, grad_pregated=fused)  # (B, O, D)
+        all_param = self.caps_mlps(raw_caps_param, grad_pregated=fused,
+                                   x_is_relu=fused)               # (B, O, A)
         noise_caps = noise_vote = None
         if self.noise_type == 'uniform':
             proto = all_param.new_empty(B, self.n_caps, 1)
@@ -92,13 +97,14 @@ class CapsuleLayer(nn.Module):
             noise_scale=self.noise_scale,
             similarity=self.similarity_transform,
             learn_vote_scale=self.learn_vote_scale,
-            allow_deformations=self.allow_deformations)
+            allow_deformations=self.allow_deformations,
+            param_is_relu=fused, defer_reg=defer_reg)
 
     def forward(self, feature, parent_transform=None, parent_presence=None):
         """feature [B, O, F] -> AttrDict(vote (B,O,V,3,3), scale,
         vote_presence, presence_logit_per_caps, presence_logit_per_vote,
         cpr_dynamic_reg_loss)."""
-        vote6, scale, vote_presence, logit_caps, logit_vote, reg, _ = \
+        vote6, scale, vote_presence, logit_caps, logit_vote, reg, _, _ = \
             self._votes(feature, parent_transform, parent_presence)
         last_row = vote6.new_tensor([0., 0., 1.]).expand(*vote6.shape[:-1], 3)
         vote = torch.cat([vote6, last_row], -1).view(*vote6.shape[:-1], 3, 3)
@@ -118,20 +124,26 @@ class CapsuleLikelihood:
         self.vote_presence = vote_presence    # (B, O, M)
         self.dummy_vote = dummy_vote          # (1, 1, M, P)
 
-    def __call__(self, x, presence=None):     # (B, M, P), (B, M)
+    def __call__(self, x, presence=None, _extra_sums=()):
+        """x (B, M, P), presence (B, M).  ``_extra_sums``: further
+        (src, scale, dst) scalar sums to ride in this call's one
+        scalar-sum launch."""
         batch_size, n_input_points, dim_in = x.shape
         if dim_in != 6 or self.vote.shape[-1] != 6:
             raise ValueError("the capsule likelihood kernel is built for "
                              "6-dim poses")
         (lpp, binary, winner, winner_presence, _widx, is_from_capsule,
          soft_winner, soft_winner_presence, posterior, mixing_log_prob,
-         mixing_logit) = ops.capsule_likelihood(
+         mixing_logit, log_prob) = ops.capsule_likelihood(
             self.vote, self.scale, self.vote_presence, self.dummy_vote, x,
-            presence.float() if presence is not None else None)
+            presence.float() if presence is not None else None,
+            defer_sum=True)
+        ops.scaled_sums([(lpp.detach(), 1.0 / batch_size, log_prob.detach()),
+                         *_extra_sums])
         return AttrDict(
             _log_prob_per_point=lpp,           # inputs of the fused loss tail
             _posterior_full=posterior,
-            log_prob=lpp.sum() / batch_size,
+            log_prob=log_prob,                 # = lpp.sum() / batch_size
             vote_presence_binary=binary,
             winner=winner,
             winner_presence=winner_presence,
@@ -160,7 +172,8 @@ class CapsuleObjectDecoder(nn.Module):
         """obj_encoding [B, O, D], part_pose [B, M, P], part_presence [B, M]
         or None -> AttrDict (object_decoder.py:393-428)."""
         vote, scale, vote_presence, logit_caps, logit_vote, reg, \
-            caps_presence = self.capsule_layer._votes(obj_encoding)
+            caps_presence, reg_partial = self.capsule_layer._votes(
+                obj_encoding, defer_reg=True)
         res = AttrDict(vote=vote,             # (B, O, V, 6): rows 0..1 only
                        scale=scale, vote_presence=vote_presence,
                        presence_logit_per_caps=logit_caps,
@@ -170,7 +183,9 @@ class CapsuleObjectDecoder(nn.Module):
         likelihood = CapsuleLikelihood(vote=res.vote, scale=res.scale,
                                        vote_presence=res.vote_presence,
                                        dummy_vote=self.dummy_vote)
-        res.update(likelihood(part_pose, presence=part_presence))
+        # the two scalar outputs (reg loss, log_prob) in one launch
+        res.update(likelihood(part_pose, presence=part_presence, _extra_sums=[
+            (reg_partial, 0.5 / obj_encoding.shape[0], reg.detach())]))
         return res
 
 

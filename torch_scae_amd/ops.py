@@ -16,7 +16,7 @@ from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_scalar", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "conv_stack", "conv_stack_supported",
-           "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
+           "uniform", "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
 
@@ -63,6 +63,38 @@ def _grad_out(slot, like, shape=None):
         if v is not None:
             return v
     return torch.empty(shape, device=like.device, dtype=like.dtype)
+
+
+def scaled_sums(jobs):
+    """[(src, scale, dst)]: dst[()] = scale * src.sum() for up to 8 tensors in
+    ONE launch (the scalar outputs of the forward pass)."""
+    arr = (_lib.ScaledSum * len(jobs))()
+    for a, (src, scale, dst) in zip(arr, jobs):
+        assert src.is_contiguous() and dst.numel() == 1
+        a.src, a.n, a.scale, a.dst = src.data_ptr(), src.numel(), scale, \
+            dst.data_ptr()
+    _lib.call("scae_scaled_sums_f32", arr, len(jobs), _stream(jobs[0][0]))
+
+
+_NOISE_STATE = {}
+
+
+def uniform(n, ref):
+    """n floats ~ U[0,1) on ``ref``'s device from the device-resident Philox
+    generator (csrc/noise.hip).  Seeded from ``torch.initial_seed()``; the
+    generator state is per (device, stream) and restarts when that seed
+    changes (``torch.manual_seed``) outside a graph capture."""
+    _need_hip(ref)
+    seed = int(torch.initial_seed()) & ((1 << 63) - 1)
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+    state = _NOISE_STATE.get(key)
+    if state is None or (state[0] != seed and
+                         not torch.cuda.is_current_stream_capturing()):
+        state = _NOISE_STATE[key] = (seed, torch.tensor(
+            [seed, 0, 0], dtype=torch.int64).to(ref.device))
+    out = torch.empty(int(n), device=ref.device, dtype=torch.float32)
+    _lib.call("scae_uniform_f32", _p(out), int(n), _p(state[1]), _stream(ref))
+    return out
 
 
 def _sum_rows(partial, shapes, starts=None, period=0, outs=None):
@@ -741,15 +773,15 @@ def colored_templates(template_logits, feature, w1, b1, w2, b2,
 # ----------------------------------------------------------------------------
 def _gemm(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
           bias=None, bias_ld=1, bias_b=0, mask=None, ldmask=0, mask_b=0,
-          relu=False, asum=None, asum_b=0, ref=None):
+          relu=False, asum=None, asum_b=0, asum_ld=1, ref=None):
     _lib.call("scae_gemm_f32", A, B, C, bias, mask, asum, batch, M, N, K,
               int(a_k), lda, a_b, int(b_k), ldb, b_b, ldc, c_b, bias_ld, bias_b,
-              ldmask, mask_b, asum_b, int(relu), _stream(ref))
+              ldmask, mask_b, asum_b, asum_ld, int(relu), _stream(ref))
 
 
 def _gemm_desc(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
                bias=None, bias_ld=1, bias_b=0, mask=None, ldmask=0, mask_b=0,
-               relu=False, asum=None, asum_b=0):
+               relu=False, asum=None, asum_b=0, asum_ld=1):
     """The arguments of ``_gemm`` as a struct scae_gemm_desc (A .. asum are
     ctypes pointers as returned by ``_p`` / ``_off``)."""
     d = _lib.GemmDesc()
@@ -763,6 +795,7 @@ def _gemm_desc(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
     d.bias_ld, d.bias_batch = bias_ld, bias_b
     d.ldmask, d.mask_batch, d.asum_batch, d.relu = ldmask, mask_b, asum_b, \
         int(relu)
+    d.asum_ld = asum_ld
     return d
 
 
@@ -779,10 +812,17 @@ def _off(t, nfloats=0):
 class _GroupedMLP(torch.autograd.Function):
     """relu(.. relu(x W0^T + b0) .. Wn^T + bn) for G independent groups.
     x (B, G, Kin) with unit last stride; W_l (G, N_l, K_l [+1 if ones_input and
-    l == 0]); b_l (G, N_l) or None; returns (B, G, N_last) contiguous."""
+    l == 0]); b_l (G, N_l) or None; returns (B, G, N_last) contiguous.
+
+    Two private contracts let a chain of these MLPs (and the K3 vote kernel
+    behind it) skip the stand-alone ReLU-gate launches of the backward pass:
+    ``grad_pregated``: the consumer hands back the gradient w.r.t. the last
+    PRE-activation (already zeroed where the output is 0); ``x_is_relu``: x is
+    the ReLU output of a producer with ``grad_pregated`` -- the returned input
+    gradient is gated by x > 0 in the epilogue of the data-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, ones_input, n_layers, *wb):
+    def forward(ctx, x, ones_input, n_layers, grad_pregated, x_is_relu, *wb):
         _need_hip(x, *wb)
         if x.stride(2) != 1:
             x = x.contiguous()
@@ -815,20 +855,23 @@ class _GroupedMLP(torch.autograd.Function):
             cur, cur_ld, cur_b, K = out, N, B * N, N
         ctx.save_for_backward(x, *weights, *acts)
         ctx.meta = (bool(ones_input), n_layers,
-                    [b is not None for b in biases])
+                    [b is not None for b in biases], bool(grad_pregated),
+                    bool(x_is_relu))
         ctx.slots = [_slot(t) for t in wb]
         return acts[-1]
 
     @staticmethod
     def backward(ctx, gy):
-        ones_input, L, has_bias = ctx.meta
+        ones_input, L, has_bias, pregated, x_is_relu = ctx.meta
         x = ctx.saved_tensors[0]
         weights = ctx.saved_tensors[1:1 + L]
         acts = ctx.saved_tensors[1 + L:]
         B, G, Kin = x.shape
         dev, dt = x.device, x.dtype
         # gradient w.r.t. the last pre-activation, layout (B, G, N)
-        gpre = torch.ops.aten.threshold_backward(gy.contiguous(), acts[-1], 0.0)
+        gpre = gy.contiguous()
+        if not pregated:
+            gpre = torch.ops.aten.threshold_backward(gpre, acts[-1], 0.0)
         g_ld, g_b = G * gpre.shape[2], gpre.shape[2]
         gws, gbs = [None] * L, [None] * L
         gx = None
@@ -843,17 +886,19 @@ class _GroupedMLP(torch.autograd.Function):
             gw = _grad_out(ctx.slots[l], w)
             # gW[g] (N x K) = gpre^T x : both operands k(=batch)-strided; the
             # bias gradient sum_b gpre is emitted by the same launch
+            asum_ld = 1
             if has_bias[l]:
                 gsum = _grad_out(ctx.slots[L + l], w, (G, N))
                 asum, asum_b = _p(gsum), N
             elif l == 0 and ones_input:
-                gsum = torch.empty(G, N, device=dev, dtype=dt)
-                asum, asum_b = _p(gsum), N
+                # the gradient of the implicit ones column IS that column sum:
+                # written straight into column K of gW
+                gsum, asum, asum_b, asum_ld = None, _off(gw, K), N * ldb, ldb
             else:
                 gsum, asum, asum_b = None, None, 0
             wgrad = _gemm_desc(_p(gpre), _p(xin), _p(gw), G, N, K, B, False,
                                g_ld, g_b, False, x_ld, x_b, ldb, N * ldb,
-                               asum=asum, asum_b=asum_b)
+                               asum=asum, asum_b=asum_b, asum_ld=asum_ld)
             # the data gradient of the layer only waits for gpre as well:
             # both GEMMs go out in one launch
             dgrad = gnext = None
@@ -865,28 +910,32 @@ class _GroupedMLP(torch.autograd.Function):
                                    mask=_p(acts[l - 1]), ldmask=K, mask_b=B * K)
             elif ctx.needs_input_grad[0]:
                 gx = torch.empty(B, G, K, device=dev, dtype=dt)
+                gate = dict(mask=_p(x), ldmask=x.stride(0),
+                            mask_b=x.stride(1)) if x_is_relu else {}
                 dgrad = _gemm_desc(_p(gpre), _p(w), _p(gx), G, B, K, N, True,
-                                   g_ld, g_b, False, ldb, N * ldb, G * K, K)
+                                   g_ld, g_b, False, ldb, N * ldb, G * K, K,
+                                   **gate)
             if dgrad is not None:
                 _gemm_pair(wgrad, dgrad, x)
             else:
                 _gemm(_p(gpre), _p(xin), _p(gw), G, N, K, B, False, g_ld, g_b,
                       False, x_ld, x_b, ldb, N * ldb, asum=asum, asum_b=asum_b,
-                      ref=x)
-            if l == 0 and ones_input:
-                gw[:, :, K] = gsum
+                      asum_ld=asum_ld, ref=x)
             if has_bias[l]:
                 gbs[l] = gsum
             gws[l] = gw
             if l > 0:
                 gpre, g_ld, g_b = gnext, K, B * K
-        return (gx, None, None, *gws, *gbs)
+        return (gx, None, None, None, None, *gws, *gbs)
 
 
-def grouped_mlp(x, weights, biases, ones_input=False):
-    """ReLU MLPs of G independent groups; x (B, G, Kin) -> (B, G, N_last)."""
+def grouped_mlp(x, weights, biases, ones_input=False, grad_pregated=False,
+                x_is_relu=False):
+    """ReLU MLPs of G independent groups; x (B, G, Kin) -> (B, G, N_last).
+    ``grad_pregated`` / ``x_is_relu``: see ``_GroupedMLP``."""
     biases = list(biases) if biases is not None else [None] * len(weights)
-    return _GroupedMLP.apply(x, ones_input, len(weights), *weights, *biases)
+    return _GroupedMLP.apply(x, ones_input, len(weights), grad_pregated,
+                             x_is_relu, *weights, *biases)
 
 
 # ----------------------------------------------------------------------------
@@ -896,7 +945,8 @@ class _CapsuleVotes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, all_param, cpr_static, b_cvr, b_caps, b_vote, b_scale,
                 noise_caps, noise_vote, noise_scale, similarity,
-                learn_vote_scale, allow_deformations):
+                learn_vote_scale, allow_deformations, param_is_relu,
+                defer_reg):
         _need_hip(all_param, cpr_static, b_cvr, b_caps, b_vote, b_scale,
                   noise_caps, noise_vote)
         B, O, A = all_param.shape
@@ -910,6 +960,7 @@ class _CapsuleVotes(torch.autograd.Function):
         lc = torch.empty(B, O, 1, device=dev, dtype=dt)
         lv = torch.empty(B, O, V, device=dev, dtype=dt)
         reg = torch.empty(B, O, device=dev, dtype=dt)
+        reg_loss = torch.empty((), device=dev, dtype=dt)   # l2_loss(.)/B, :170
         caps_presence = torch.empty(B, O, device=dev, dtype=dt)
         caps_arg = torch.empty(B, O, device=dev, dtype=torch.int32)
         flags = (B, O, V, int(similarity), int(learn_vote_scale),
@@ -918,16 +969,19 @@ class _CapsuleVotes(torch.autograd.Function):
                   float(noise_scale), _p(vote), _p(scale), _p(vp), _p(lc),
                   _p(lv), _p(reg), _p(caps_presence), _p(caps_arg), *flags,
                   _stream(all_param))
+        if not defer_reg:   # else the caller folds `reg` into reg_loss later
+            scaled_sums([(reg, 0.5 / B, reg_loss)])
         ctx.save_for_backward(caps_arg, *[t for t in args if t is not None])
         ctx.has_noise = (args[6] is not None, args[7] is not None)
         ctx.noise_scale = float(noise_scale)
         ctx.flags = flags
-        reg_loss = reg.sum() * (0.5 / B)      # l2_loss(.)/B, :170
+        ctx.param_is_relu = bool(param_is_relu)
         ctx.set_materialize_grads(False)
-        return vote, scale, vp, lc, lv, reg_loss, caps_presence
+        ctx.mark_non_differentiable(reg)
+        return vote, scale, vp, lc, lv, reg_loss, caps_presence, reg
 
     @staticmethod
-    def backward(ctx, gvote, gscale, gvp, glc, glv, greg, gcp):
+    def backward(ctx, gvote, gscale, gvp, glc, glv, greg, gcp, _greg_partial):
         saved = list(ctx.saved_tensors)
         caps_arg = saved.pop(0)
         args = saved[:6]
@@ -936,12 +990,17 @@ class _CapsuleVotes(torch.autograd.Function):
         all_param = args[0]
         B, O, V = ctx.flags[:3]
         gall = torch.empty_like(all_param)
+        # all_param = relu(.): hand the producer the gradient w.r.t. its
+        # pre-activation (``grouped_mlp(grad_pregated=True)``); the bias
+        # gradients below still need the ungated one
+        ggated = torch.empty_like(all_param) if ctx.param_is_relu else None
         gin = torch.empty(B, O, V, 6, device=all_param.device,
                           dtype=all_param.dtype)
         grads = [_c(g) for g in (gvote, gscale, gvp, glc, glv, greg, gcp)]
         _lib.call("scae_capsule_votes_bwd_f32", *[_p(t) for t in args],
                   ctx.noise_scale, *[_p(g) for g in grads], _p(caps_arg),
-                  _p(gall), _p(gin), *ctx.flags, _stream(all_param))
+                  _p(gall), _p(gin), _p(ggated), *ctx.flags,
+                  _stream(all_param))
         # bias gradients: batch sums of column blocks of gall (B, O*A); each
         # capsule's block lands in its row of the (.., O, ..) parameter
         A = all_param.shape[2]
@@ -949,21 +1008,27 @@ class _CapsuleVotes(torch.autograd.Function):
         g_cvr, g_caps, g_vote, g_scale = _sum_rows(
             gall.view(B, O * A), [t.shape for t in args[2:6]],
             starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=A)
-        return (gall, g_static, g_cvr, g_caps, g_vote, g_scale, None, None,
-                None, None, None, None)
+        return (gall if ggated is None else ggated, g_static, g_cvr, g_caps,
+                g_vote, g_scale, None, None, None, None, None, None, None, None)
 
 
 def capsule_votes(all_param, cpr_static, bias_cvr, bias_caps, bias_vote,
                   bias_scale, noise_caps=None, noise_vote=None, noise_scale=0.,
                   similarity=False, learn_vote_scale=True,
-                  allow_deformations=True):
+                  allow_deformations=True, param_is_relu=False,
+                  defer_reg=False):
     """-> vote (B,O,V,6), scale, vote_presence, presence_logit_per_caps
     (B,O,1), presence_logit_per_vote (B,O,V), cpr_dynamic_reg_loss (),
-    caps_presence (B,O) = vote_presence.max(-1)."""
+    caps_presence (B,O) = vote_presence.max(-1).  ``param_is_relu``:
+    all_param is the output of ``grouped_mlp(grad_pregated=True)`` and gets
+    the gradient w.r.t. that MLP's last pre-activation.  Also returns the
+    (B,O) partials of the reg loss; with ``defer_reg`` the reg-loss scalar is
+    left for the caller to fill (``scaled_sums([(partial, .5/B, reg_loss)])``,
+    together with other scalars in one launch)."""
     return _CapsuleVotes.apply(all_param, cpr_static, bias_cvr, bias_caps,
                                bias_vote, bias_scale, noise_caps, noise_vote,
                                noise_scale, similarity, learn_vote_scale,
-                               allow_deformations)
+                               allow_deformations, param_is_relu, defer_reg)
 
 
 # ----------------------------------------------------------------------------
@@ -971,7 +1036,7 @@ def capsule_votes(all_param, cpr_static, bias_cvr, bias_caps, bias_vote,
 # ----------------------------------------------------------------------------
 class _CapsuleLikelihood(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, vote, scale, vp, dummy_vote, x, presence):
+    def forward(ctx, vote, scale, vp, dummy_vote, x, presence, defer_sum):
         _need_hip(vote, scale, vp, dummy_vote, x, presence)
         vote, scale, vp, dummy_vote, x, presence = (
             _c(t) for t in (vote, scale, vp, dummy_vote, x, presence))
@@ -984,11 +1049,14 @@ class _CapsuleLikelihood(torch.autograd.Function):
         from_caps = torch.empty(B, M, device=dev, dtype=torch.int64)
         soft, soft_p = f(B, M, 6), f(B, M)
         post, mlp, mlogit = f(B, O + 1, M), f(B, O + 1, M), f(B, O + 1, M)
+        log_prob = torch.empty((), device=dev, dtype=dt)
         _lib.call("scae_capsule_likelihood_fwd_f32", _p(vote), _p(scale),
                   _p(vp), _p(dummy_vote), _p(x), _p(presence), _p(lpp),
                   _p(binary), _p(winner), _p(winner_p), _p(widx),
                   _p(from_caps), _p(soft), _p(soft_p), _p(post), _p(mlp),
                   _p(mlogit), B, O, M, _stream(vote))
+        if not defer_sum:   # else the caller fills log_prob (scaled_sums)
+            scaled_sums([(lpp, 1.0 / B, log_prob)])
         saved = [vote, scale, vp, dummy_vote, x, post, widx]
         if presence is not None:
             saved.append(presence)
@@ -999,15 +1067,18 @@ class _CapsuleLikelihood(torch.autograd.Function):
         ctx.mark_non_differentiable(binary, widx, from_caps)
         ctx.set_materialize_grads(False)
         return (lpp, binary, winner, winner_p, widx, from_caps, soft, soft_p,
-                post, mlp, mlogit)
+                post, mlp, mlogit, log_prob)
 
     @staticmethod
     def backward(ctx, g_lpp, _gb, g_w, g_wp, _gi, _gf, g_s, g_sp, g_post,
-                 g_mlp, g_mlogit):
+                 g_mlp, g_mlogit, g_log_prob):
         saved = ctx.saved_tensors
         vote, scale, vp, dummy_vote, x, post, widx = saved[:7]
         presence = saved[7] if ctx.has_presence else None
         B, O, M = ctx.dims
+        if g_log_prob is not None:     # log_prob = sum(lpp) / B  (op-by-op loss)
+            spread = (g_log_prob / B).expand(B, M)
+            g_lpp = spread if g_lpp is None else g_lpp + spread
         gvote, gscale, gvp = (torch.empty_like(t) for t in (vote, scale, vp))
         gx = torch.empty_like(x)
         gpres = torch.empty(B, M, device=x.device, dtype=x.dtype) \
@@ -1025,16 +1096,18 @@ class _CapsuleLikelihood(torch.autograd.Function):
         g_dummy = None
         if g_w is not None or g_s is not None:
             g_dummy = _sum_rows(gdummy.view(B, -1), [ctx.dummy_shape])[0]
-        return gvote, gscale, gvp, g_dummy, gx, gpres
+        return gvote, gscale, gvp, g_dummy, gx, gpres, None
 
 
 def capsule_likelihood(vote, scale, vote_presence, dummy_vote, x,
-                       presence=None):
+                       presence=None, defer_sum=False):
     """-> (log_prob_per_point (B,M), vote_presence_binary, winner,
     winner_presence, winner_idx, is_from_capsule, soft_winner,
-    soft_winner_presence, posterior (B,O+1,M), mixing_log_prob, mixing_logit)"""
+    soft_winner_presence, posterior (B,O+1,M), mixing_log_prob, mixing_logit,
+    log_prob () = sum(log_prob_per_point) / B -- left for the caller to fill
+    with ``scaled_sums([(lpp, 1/B, log_prob)])`` when ``defer_sum``)"""
     return _CapsuleLikelihood.apply(vote, scale, vote_presence, dummy_vote, x,
-                                    presence)
+                                    presence, defer_sum)
 
 
 # ----------------------------------------------------------------------------

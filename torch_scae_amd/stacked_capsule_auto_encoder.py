@@ -94,7 +94,10 @@ class SCAE(nn.Module):
         if len(shapes) < 2:
             return []                  # nothing to merge: modules draw themselves
         sizes = [int(torch.Size(s).numel()) for s in shapes]
-        flat = torch.rand(sum(sizes), device=image.device, dtype=image.dtype)
+        # device-resident generator: no host-driven seed / offset updates
+        # when the step is replayed from a HIP graph
+        flat = ops.uniform(sum(sizes), image) if image.dtype == torch.float32 \
+            else torch.rand(sum(sizes), device=image.device, dtype=image.dtype)
         return [c.view(s) for c, s in zip(flat.split(sizes), shapes)]
 
     def _forward(self, image):
