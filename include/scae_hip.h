@@ -229,6 +229,7 @@ typedef struct scae_gemm_desc {
   int ldmask;
   int64_t mask_batch, asum_batch;
   int relu, asum_ld;
+  float *c_nomask; /* nullable, layout of C: the values before the mask gate */
 } scae_gemm_desc;
 int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
 
@@ -243,6 +244,9 @@ int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second
  *     scae_conv3x3_first_wgrad_rows(B,Cout) partial rows, each
  *     [dW (Cout,Cin*9) | db (Cout)], for the caller to sum over the rows.
  *   fwd:   out = relu(conv(in, wf) + bias)        Cin, Cout % 64 == 0, s <= 2
+ *          out_post (nullable, NHWC like out) = out + post_bias, post_bias
+ *          (Cout,OH,OW) = img_embedding_bias of part_encoder.py:87 (the sum
+ *          the 1x1 attention convolution reads)
  *   dgrad: din = conv^T(dpre, wd), zeroed where gate <= 0 (gate (B,IH,IW,Cin)
  *          = the producing layer's ReLU output, nullable)
  *   wgrad: dw (Cout,Cin,3,3) = sum_pixels dpre x in and (db nullable) db (Cout)
@@ -264,7 +268,8 @@ int scae_conv3x3_first_wgrad_rows(int B, int Cout);
 int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img, float *partial, int B,
                                  int Cin, int IH, int IW, int Cout, int stride, void *stream);
 int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias, float *out,
-                         int B, int IH, int IW, int Cin, int Cout, int stride, void *stream);
+                         const float *post_bias, float *out_post, int B, int IH, int IW,
+                         int Cin, int Cout, int stride, void *stream);
 int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const float *gate, float *din,
                            int B, int IH, int IW, int Cin, int Cout, int stride, void *stream);
 int scae_conv3x3_wgrad_splits(int B, int OH, int OW, int Cin, int Cout);
@@ -298,15 +303,19 @@ int scae_attention_pool_bwd_f32(const float *y, const float *g, float *dy, int B
  *   absence (B,A) = 1 - presence (nullable; the set-transformer input of
  *   stacked_capsule_auto_encoder.py:113);
  *   pooled (B,A,P-1) is kept for the backward pass, whose incoming gradients
- *   g_pose / g_presence / g_feature may each be NULL (= zeros). */
+ *   g_pose / g_presence / g_feature may each be NULL (= zeros); g_feature2
+ *   (nullable) is added to g_feature -- the feature feeds both the template
+ *   colours and the set transformer (stacked_capsule_auto_encoder.py:103,:119),
+ *   and summing here saves the caller an accumulate launch. */
 int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, float noise_scale,
                               int similarity, float *pooled, float *pose, float *presence,
                               float *feature, float *absence, int B, int HW, int A, int P,
                               void *stream);
 int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *noise_u,
                               float noise_scale, int similarity, const float *g_pose,
-                              const float *g_presence, const float *g_feature, float *dy,
-                              int B, int HW, int A, int P, void *stream);
+                              const float *g_presence, const float *g_feature,
+                              const float *g_feature2, float *dy, int B, int HW, int A, int P,
+                              void *stream);
 
 /* ------------------------------------------------------------------------
  * Optimiser step on the flat parameter buffer
@@ -358,7 +367,10 @@ int scae_template_color_bwd_f32(const float *logits, const float *feature, const
  * 8 contiguous destinations: column j in [begin, end) of segment i goes to
  * segments[i].dst[j - begin]; with period > 0 the window [begin, end) of
  * every period-wide block of columns is gathered instead:
- * dst[(j / period) * (end - begin) + j % period - begin].  Columns in no
+ * dst[(j / period) * (end - begin) + j % period - begin].  period = -W < 0:
+ * the window is an (n x W) matrix whose TRANSPOSE is written,
+ * dst[((j - begin) % W) * n + (j - begin) / W] (an NHWC batch sum landing in
+ * a (C,H,W) parameter).  Columns in no
  * segment are dropped; segments may overlap.  `segments` is a HOST array.  Replaces `partial.sum(0)` + per-parameter slice copies
  * behind the partial-gradient outputs of K1, K2b, K2c, K3, K8, K9 and K10.
  * ---------------------------------------------------------------------- */

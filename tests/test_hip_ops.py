@@ -1141,6 +1141,7 @@ def test_uniform_generator_statistics_and_state():
     from torch_scae_amd import ops
     ref = torch.zeros(1, device="cuda")
     torch.manual_seed(1234)
+    ops.reset_noise()
     a = ops.uniform(79872, ref)
     b = ops.uniform(79872, ref)
     assert a.shape == (79872,) and a.dtype == torch.float32
@@ -1150,8 +1151,10 @@ def test_uniform_generator_statistics_and_state():
     assert not torch.equal(a, b)                 # the state advanced
     # neighbouring draws are uncorrelated
     assert abs(float(((a[:-1] - .5) * (a[1:] - .5)).mean())) < 2e-3
-    torch.manual_seed(1234)                      # re-seeding restarts it
+    ops.reset_noise()                            # restart from the torch seed
     assert torch.equal(ops.uniform(79872, ref), a)
+    torch.manual_seed(4321)                      # a new seed: a new stream
+    assert not torch.equal(ops.uniform(79872, ref), b)
     odd = ops.uniform(5, ref)                    # ragged tail of a group of 4
     assert odd.shape == (5,) and float(odd.max()) < 1.0
 
@@ -1173,3 +1176,75 @@ def test_uniform_generator_advances_under_graph_replay():
     torch.cuda.synchronize()
     assert not torch.equal(first, out)
     assert 0.0 <= float(out.min()) and float(out.max()) < 1.0
+
+
+# --------------------------------------------------------------------------
+# the whole part encoder as one autograd node (part_encoder.py:86-113)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C0,HW,chans,strides,A,F,noisy", [
+    (128, 1, 40, [128, 128, 128, 128], [2, 2, 1, 1], 24, 16, True),   # cfg-2
+    (6, 3, 18, [64, 128], [2, 1], 5, 0, False),
+    (9, 1, 14, [64, 64, 64], [1, 2, 1], 7, 3, True),
+])
+def test_part_encoder_node_vs_fp64_composition(B, C0, HW, chans, strides, A, F,
+                                               noisy):
+    import torch.nn.functional as Fn
+    from torch_scae_amd import ops
+    from torch_scae_amd.nn_ext import multiple_attention_pooling_2d
+    g = torch.Generator().manual_seed(B + 13 * A)
+    P = 6 + 1 + F + 1
+    image = torch.rand(B, C0, HW, HW, generator=g)
+    ws, bs, cin, size = [], [], C0, HW
+    for c, s in zip(chans, strides):
+        ws.append(torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** .5)
+        bs.append(torch.randn(c, generator=g) * 0.1)
+        cin, size = c, (size - 3) // s + 1
+    pb = torch.randn(cin, size, size, generator=g) * 0.5
+    aw = torch.randn(A * P, cin, 1, 1, generator=g) / cin ** 0.5
+    ab = torch.randn(A * P, generator=g)
+    u = torch.rand(B, A, generator=g) if noisy else None
+    gouts = [torch.randn(B, A, 6, generator=g), torch.randn(B, A, generator=g),
+             torch.randn(B, A, F, generator=g), torch.randn(B, A, F, generator=g)]
+    scale = 4.0
+
+    leaves = [t.double().requires_grad_() for t in (pb, aw, ab, *ws, *bs)]
+    rpb, raw, rab = leaves[:3]
+    rws, rbs = leaves[3:3 + len(ws)], leaves[3 + len(ws):]
+    h = image.double()
+    for w, b, s in zip(rws, rbs, strides):
+        h = torch.relu(Fn.conv2d(h, w, b, stride=s))
+    h = multiple_attention_pooling_2d(Fn.conv2d(h + rpb, raw, rab), A) \
+        .view(B, A, P - 1)
+    pose_r = O.geometric_transform(h[..., :6], similarity=False)
+    logit = h[..., 6] + ((u.double() - .5) * scale if noisy else 0.)
+    pres_r, feat_r = torch.sigmoid(logit), h[..., 7:]
+    loss = (pose_r * gouts[0].double()).sum() + (pres_r * gouts[1].double()).sum()
+    if F:   # two consumers of the feature
+        loss = loss + (feat_r * (gouts[2] + gouts[3]).double()).sum()
+    loss.backward()
+
+    dev = [t.cuda().requires_grad_() for t in (pb, aw, ab, *ws, *bs)]
+    pose, pres, feat, twin, absence = ops.part_encoder(
+        image.cuda(), dev[3:3 + len(ws)], dev[3 + len(ws):], strides, dev[0],
+        dev[1], dev[2], A, u.cuda() if noisy else None, scale, False)
+    assert torch.equal(absence, 1. - pres.detach().unsqueeze(-1))
+    assert_close(pose, pose_r.float(), rtol=1e-4, atol=1e-4, what="pose")
+    assert_close(pres, pres_r.float(), rtol=1e-4, atol=1e-4, what="presence")
+    lh = (pose * gouts[0].cuda()).sum() + (pres * gouts[1].cuda()).sum()
+    if F:
+        assert twin is not feat and torch.equal(twin, feat)
+        assert_close(feat, feat_r.float(), rtol=1e-4, atol=1e-4, what="feature")
+        lh = lh + (feat * gouts[2].cuda()).sum() + (twin * gouts[3].cuda()).sum()
+    else:
+        assert feat is None and twin is None
+    lh.backward()
+    names = ["embedding bias", "att weight", "att bias"] + \
+        [f"w{i}" for i in range(len(ws))] + [f"b{i}" for i in range(len(ws))]
+    for name, a, r in zip(names, dev, leaves):
+        # sums over up to ~1e5 ReLU-gated terms: a pre-activation within
+        # round-off of 0 may gate differently in fp32 and fp64
+        scale_r = max(1.0, float(r.grad.abs().max()))
+        bad = ((a.grad.cpu() - r.grad.float()).abs() > 1e-4 * scale_r)
+        assert float(bad.float().mean()) <= 0.02, (name, float(bad.float().mean()))
+        assert_close(a.grad, r.grad.float(), rtol=1e-2, atol=1e-2 * scale_r,
+                     what="grad " + name)

@@ -35,7 +35,7 @@ class GemmDesc(Structure):
                 ("b_batch", c_int64), ("ldc", c_int), ("c_batch", c_int64),
                 ("bias_ld", c_int), ("bias_batch", c_int64), ("ldmask", c_int),
                 ("mask_batch", c_int64), ("asum_batch", c_int64),
-                ("relu", c_int), ("asum_ld", c_int)]
+                ("relu", c_int), ("asum_ld", c_int), ("c_nomask", P)]
 
 
 class SumSegment(Structure):
@@ -108,7 +108,7 @@ SIGNATURES = {
     "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_first_wgrad_rows": [c_int] * 2,
     "scae_conv3x3_first_wgrad_f32": [P] * 3 + [c_int] * 6 + [P],
-    "scae_conv3x3_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
+    "scae_conv3x3_fwd_f32": [P] * 6 + [c_int] * 6 + [P],
     "scae_conv3x3_dgrad_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_wgrad_reduce_batch_f32": [c_int] + [P] * 7,
     "scae_conv3x3_wgrad_splits": [c_int] * 5,
@@ -119,7 +119,7 @@ SIGNATURES = {
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
                               c_float, c_float, c_float, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
-    "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P] + [c_int] * 4 + [P],
+    "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
     "scae_template_color_supported": [c_int] * 4,
     "scae_template_color_partial_rows": [c_int] * 2,
     "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],

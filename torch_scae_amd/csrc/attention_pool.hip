@@ -26,7 +26,7 @@ struct PoolArgs {
   int similarity;
   float *pose, *presence, *feature;                  // forward outputs
   float *absence;                                    // 1 - presence (nullable)
-  const float *pooled, *g_pose, *g_presence, *g_feature;  // backward inputs
+  const float *pooled, *g_pose, *g_presence, *g_feature, *g_feature2;  // backward inputs
 };
 
 __host__ __device__ inline int padded(int AP) { return AP | 1; }
@@ -160,7 +160,8 @@ __global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
     }
     for (int e = threadIdx.x; e < A * F; e += NT) {
       const int a = e / F, f = e - a * F;
-      gs[a * (P - 1) + 7 + f] = k.g_feature ? k.g_feature[cap0 * F + e] : 0.f;
+      gs[a * (P - 1) + 7 + f] = (k.g_feature ? k.g_feature[cap0 * F + e] : 0.f) +
+                                (k.g_feature2 ? k.g_feature2[cap0 * F + e] : 0.f);
     }
   } else {
     for (int e = threadIdx.x; e < A * (P - 1); e += NT) gs[e] = k.g[cap0 * (P - 1) + e];
@@ -252,13 +253,14 @@ extern "C" int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, f
 extern "C" int scae_capsule_head_bwd_f32(const float *y, const float *pooled,
                                          const float *noise_u, float noise_scale, int similarity,
                                          const float *g_pose, const float *g_presence,
-                                         const float *g_feature, float *dy, int B, int HW, int A,
-                                         int P, void *stream) {
+                                         const float *g_feature, const float *g_feature2,
+                                         float *dy, int B, int HW, int A, int P, void *stream) {
   PoolArgs k{};
   k.y = y, k.dy = dy, k.B = B, k.HW = HW, k.A = A, k.P = P;
   k.splits = pool_splits(B, A);
   k.noise_u = noise_u, k.noise_scale = noise_scale, k.similarity = similarity;
   k.pooled = pooled, k.g_pose = g_pose, k.g_presence = g_presence, k.g_feature = g_feature;
+  k.g_feature2 = g_feature2;
   int rc = check(k);
   if (rc) return rc;
   if (P < 8) return SCAE_ERR_UNSUPPORTED;

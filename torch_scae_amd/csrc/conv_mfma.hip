@@ -49,7 +49,9 @@ template <int MODE>
 __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ in,
                                                       const float *__restrict__ wf,
                                                       const float *__restrict__ bias,
-                                                      float *__restrict__ out, ConvGeom g) {
+                                                      float *__restrict__ out,
+                                                      const float *__restrict__ post_bias,
+                                                      float *__restrict__ out_post, ConvGeom g) {
   SCAE_TILE_PROLOGUE_M(MODE)
   constexpr int TB = TL::TB, NQB = TL::NQB;
   const int M = g.B * g.OH * g.OW, K = 9 * g.Cin;
@@ -87,9 +89,15 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ 
     const int m = m0 + row, n = n0 + col;
     if (m >= M) return;
     const float4 b = ld4(bias + n);
-    *reinterpret_cast<float4 *>(out + (size_t)m * g.Cout + n) =
-        make_float4(fmaxf(v.x + b.x, 0.f), fmaxf(v.y + b.y, 0.f), fmaxf(v.z + b.z, 0.f),
-                    fmaxf(v.w + b.w, 0.f));
+    const float4 o = make_float4(fmaxf(v.x + b.x, 0.f), fmaxf(v.y + b.y, 0.f),
+                                 fmaxf(v.z + b.z, 0.f), fmaxf(v.w + b.w, 0.f));
+    *reinterpret_cast<float4 *>(out + (size_t)m * g.Cout + n) = o;
+    if (out_post) {  // + the per-(channel, pixel) embedding bias, (Cout, OH, OW)
+      const int hw = g.OH * g.OW;
+      const float *pb = post_bias + (size_t)n * hw + m % hw;
+      *reinterpret_cast<float4 *>(out_post + (size_t)m * g.Cout + n) =
+          make_float4(o.x + pb[0], o.y + pb[hw], o.z + pb[2 * hw], o.w + pb[3 * hw]);
+    }
   });
 }
 
@@ -605,27 +613,28 @@ extern "C" int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img,
 }
 
 extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias,
-                                    float *out, int B, int IH, int IW, int Cin, int Cout,
-                                    int stride, void *stream) {
+                                    float *out, const float *post_bias, float *out_post, int B,
+                                    int IH, int IW, int Cin, int Cout, int stride,
+                                    void *stream) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, true);
   if (rc) return rc;
-  SCAE_REQUIRE(in && wf && bias && out);
+  SCAE_REQUIRE(in && wf && bias && out && (!out_post || post_bias));
   const int M = B * g.OH * g.OW;
   hipStream_t st = (hipStream_t)stream;
   switch (tile_mode((long)(Cout / 64) * ((M + 63) / 64), (long)(Cout / 64) * ((M + 31) / 32),
                     300)) {
     case 0:
       hipLaunchKernelGGL(conv_fwd_kernel<0>, dim3(Cout / 64, (M + 63) / 64), dim3(NT), 0, st, in,
-                         wf, bias, out, g);
+                         wf, bias, out, post_bias, out_post, g);
       break;
     case 2:
       hipLaunchKernelGGL(conv_fwd_kernel<2>, dim3(Cout / 64, (M + 31) / 32), dim3(NT), 0, st, in,
-                         wf, bias, out, g);
+                         wf, bias, out, post_bias, out_post, g);
       break;
     default:
       hipLaunchKernelGGL(conv_fwd_kernel<1>, dim3(Cout / 32, (M + 31) / 32), dim3(NT), 0, st, in,
-                         wf, bias, out, g);
+                         wf, bias, out, post_bias, out_post, g);
   }
   return scae_launch_status();
 }

@@ -23,7 +23,7 @@ using namespace scae_tile;
 
 struct GemmArgs {
   const float *A, *B, *bias, *mask;
-  float *C, *asum;
+  float *C, *asum, *craw;
   long a_batch, b_batch, c_batch, bias_batch, mask_batch, asum_batch;
   int lda, ldb, ldc, bias_ld, ldmask;
   int M, N, K, relu, asum_ld;
@@ -99,6 +99,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
         }
       });
   float *C = g.C + z * g.c_batch;
+  float *craw = g.craw ? g.craw + z * g.c_batch : nullptr;  // pre-gate copy (layout of C)
   const float *bias = g.bias ? g.bias + z * g.bias_batch : nullptr;
   const float *mask = g.mask ? g.mask + z * g.mask_batch : nullptr;
   const bool cvec = (g.ldc & 3) == 0 && (g.c_batch & 3) == 0 && ((size_t)g.C & 15) == 0;
@@ -112,6 +113,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
       if (e >= cnt) break;
       if (bias) v[e] += bias[(size_t)(n + e) * g.bias_ld];
       if (g.relu) v[e] = fmaxf(v[e], 0.f);
+      if (craw) craw[(size_t)m * g.ldc + n + e] = v[e];
       if (mask && !(mask[(size_t)m * g.ldmask + n + e] > 0.f)) v[e] = 0.f;
     }
     float *dst = C + (size_t)m * g.ldc + n;
@@ -184,7 +186,7 @@ extern "C" int scae_gemm_f32(const float *A, const float *B, float *C, const flo
                              int64_t asum_batch, int asum_ld, int relu, void *stream) {
   SCAE_REQUIRE(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0);
   if (asum && a_kcontig) return SCAE_ERR_UNSUPPORTED;
-  GemmArgs g{A, B, bias, mask, C, asum, (long)a_batch, (long)b_batch, (long)c_batch,
+  GemmArgs g{A, B, bias, mask, C, asum, nullptr, (long)a_batch, (long)b_batch, (long)c_batch,
              (long)bias_batch, (long)mask_batch, (long)asum_batch, lda, ldb, ldc, bias_ld,
              ldmask, M, N, K, relu, asum_ld > 0 ? asum_ld : 1};
   const long tiles64 = (long)((N + 63) / 64) * ((M + 63) / 64) * batch;
@@ -199,7 +201,7 @@ static int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
   if (!d || !d->A || !d->B || !d->C || d->batch <= 0 || d->M <= 0 || d->N <= 0 || d->K <= 0)
     return SCAE_ERR_BAD_ARG;
   if (d->asum && d->a_kcontig) return SCAE_ERR_UNSUPPORTED;
-  g = GemmArgs{d->A, d->B, d->bias, d->mask, d->C, d->asum, (long)d->a_batch, (long)d->b_batch,
+  g = GemmArgs{d->A, d->B, d->bias, d->mask, d->C, d->asum, d->c_nomask, (long)d->a_batch, (long)d->b_batch,
                (long)d->c_batch, (long)d->bias_batch, (long)d->mask_batch, (long)d->asum_batch,
                d->lda, d->ldb, d->ldc, d->bias_ld, d->ldmask, d->M, d->N, d->K, d->relu,
                d->asum_ld > 0 ? d->asum_ld : 1};

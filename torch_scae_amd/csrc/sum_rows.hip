@@ -44,7 +44,12 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(const float *__restrict__ 
       const long blk = j / g.period, c = j - blk * g.period;
       if (c >= g.begin && c < g.end) g.dst[blk * (g.end - g.begin) + c - g.begin] = tot;
     } else if (j >= g.begin && j < g.end) {
-      g.dst[j - g.begin] = tot;
+      if (g.period < 0) {  // the window is an (n x W) matrix: write its transpose
+        const long W = -g.period, l = j - g.begin;
+        g.dst[(l % W) * ((g.end - g.begin) / W) + l / W] = tot;
+      } else {
+        g.dst[j - g.begin] = tot;
+      }
     }
   }
 }
@@ -81,8 +86,9 @@ extern "C" int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
   for (int i = 0; i < n_segments; ++i) {
     segs.s[i] = segments[i];
     SCAE_REQUIRE(segs.s[i].dst && segs.s[i].begin >= 0 && segs.s[i].begin < segs.s[i].end &&
-                 segs.s[i].period >= 0 &&
                  segs.s[i].end <= (segs.s[i].period > 0 ? segs.s[i].period : cols));
+    SCAE_REQUIRE(segs.s[i].period >= 0 ||
+                 (segs.s[i].end - segs.s[i].begin) % -segs.s[i].period == 0);
   }
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 16) {

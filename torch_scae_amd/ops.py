@@ -15,8 +15,8 @@ from . import _lib
 from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_scalar", "loss_tail_supported", "capsule_votes",
-           "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "conv_stack", "conv_stack_supported",
-           "uniform", "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
+           "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "part_encoder", "conv_stack", "conv_stack_supported",
+           "uniform", "reset_noise", "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
 
@@ -79,6 +79,13 @@ def scaled_sums(jobs):
 _NOISE_STATE = {}
 
 
+def reset_noise():
+    """Restart the device noise generators from ``torch.initial_seed()`` (call
+    after ``torch.manual_seed`` to replay a noise sequence; not inside a graph
+    capture)."""
+    _NOISE_STATE.clear()
+
+
 def uniform(n, ref):
     """n floats ~ U[0,1) on ``ref``'s device from the device-resident Philox
     generator (csrc/noise.hip).  Seeded from ``torch.initial_seed()``; the
@@ -97,12 +104,14 @@ def uniform(n, ref):
     return out
 
 
-def _sum_rows(partial, shapes, starts=None, period=0, outs=None):
+def _sum_rows(partial, shapes, starts=None, period=0, outs=None, transpose=0):
     """Column sums of ``partial`` (rows, cols) scattered into fresh contiguous
     tensors of the given shapes; consecutive column ranges unless ``starts``
     gives each one's first column.  With ``period`` the columns form blocks
     of that width and output i gathers columns [starts[i], starts[i] + w_i) of
-    every block (w_i = numel / number of blocks).  One launch."""
+    every block (w_i = numel / number of blocks).  With ``transpose`` = W each
+    output's window is an (n x W) matrix that is written transposed (W x n).
+    One launch."""
     rows, cols = partial.shape
     given, outs, segs = outs, [], (_lib.SumSegment * len(shapes))()
     nblk = cols // period if period else 1
@@ -114,7 +123,7 @@ def _sum_rows(partial, shapes, starts=None, period=0, outs=None):
             pos = starts[i]
         width = o.numel() // nblk
         segs[i].dst, segs[i].begin, segs[i].end = o.data_ptr(), pos, pos + width
-        segs[i].period = period
+        segs[i].period = -transpose if transpose else period
         pos += width
         outs.append(o)
     for k in range(0, len(shapes), 8):
@@ -419,6 +428,90 @@ def conv_stack_supported(in_channels, out_channels, kernel_sizes, strides):
             and all(c <= 1024 for c in chans))
 
 
+def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
+    """-> (acts, wds, x_post): the NHWC ReLU outputs of every layer, the
+    re-laid-out filters the data-gradient kernels read, and (with
+    ``post_bias`` (C,OH,OW), needs >= 2 layers) acts[-1] + post_bias."""
+    L = len(strides)
+    B, C0, H, W = image.shape
+    dev, st = image.device, _stream(image)
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=image.dtype)
+    c1, s = weights[0].shape[0], strides[0]
+    oh, ow = (H - 3) // s + 1, (W - 3) // s + 1
+    act = new(B, oh, ow, c1)
+    _lib.call("scae_conv3x3_first_fwd_f32", _p(image), _p(weights[0]),
+              _p(biases[0]), _p(act), B, C0, H, W, c1, s, st)
+    acts, wds, wfs = [act], [], []
+    for l in range(1, L):
+        co, ci = weights[l].shape[0], weights[l].shape[1]
+        wfs.append(new(co, 9, ci))
+        wds.append(new(ci, 9, co))
+    if L > 1:       # every layer's filter re-layout in one launch
+        n = L - 1
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ints = lambda v: (ctypes.c_int * n)(*v)
+        _lib.call("scae_conv3x3_relayout_batch_f32", n, arr(weights[1:]),
+                  arr(wfs), arr(wds), ints([w.shape[0] for w in weights[1:]]),
+                  ints([w.shape[1] for w in weights[1:]]), st)
+    x_post = None
+    for l in range(1, L):
+        w, s = weights[l], strides[l]
+        co, ci = w.shape[0], w.shape[1]
+        ih, iw = act.shape[1], act.shape[2]
+        out = new(B, (ih - 3) // s + 1, (iw - 3) // s + 1, co)
+        if l == L - 1 and post_bias is not None:
+            x_post = torch.empty_like(out)
+        _lib.call("scae_conv3x3_fwd_f32", _p(act), _p(wfs[l - 1]),
+                  _p(biases[l]), _p(out), _p(post_bias if x_post is not None
+                                             else None), _p(x_post),
+                  B, ih, iw, ci, co, s, st)
+        acts.append(out)
+        act = out
+    return acts, wds, x_post
+
+
+def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout):
+    """Weight / bias gradients of the stack from ``dpre``, the (B,OH,OW,C)
+    gradient w.r.t. the last layer's pre-activation; ``gout(i)`` supplies the
+    buffer of weight i (0..L-1) / bias i (L..2L-1)."""
+    L = len(strides)
+    B, C0, H, W = image.shape
+    dev, dt, st = image.device, image.dtype, _stream(image)
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
+    gws, gbs = [None] * L, [None] * L
+    pending = []       # (partial, gw, gb, co, ci, splits): reduced in one launch
+    for l in range(L - 1, 0, -1):
+        co, ci = wshapes[l][0], wshapes[l][1]
+        xin, s = acts[l - 1], strides[l]
+        ih, iw, oh, ow = xin.shape[1], xin.shape[2], dpre.shape[1], dpre.shape[2]
+        splits = _lib.load().scae_conv3x3_wgrad_splits(B, oh, ow, ci, co)
+        partial = new(splits * (9 * co * ci + co))
+        gw, gb = gout(l), gout(L + l)
+        _lib.call("scae_conv3x3_wgrad_f32", _p(dpre), _p(xin), _p(partial),
+                  None, None, B, ih, iw, ci, co, s, st)
+        pending.append((partial, gw, gb, co, ci, splits))
+        gws[l], gbs[l] = gw, gb
+        din = new(B, ih, iw, ci)
+        _lib.call("scae_conv3x3_dgrad_f32", _p(dpre), _p(wds[l - 1]),
+                  _p(xin), _p(din), B, ih, iw, ci, co, s, st)
+        dpre = din
+    if pending:
+        n = len(pending)
+        arr = lambda k: (ctypes.c_void_p * n)(*[p[k].data_ptr() for p in pending])
+        ints = lambda k: (ctypes.c_int * n)(*[p[k] for p in pending])
+        _lib.call("scae_conv3x3_wgrad_reduce_batch_f32", n, arr(0), arr(1),
+                  arr(2), ints(3), ints(4), ints(5), st)
+    c1 = wshapes[0][0]
+    k1 = C0 * 9 + 1
+    partial = new(_lib.load().scae_conv3x3_first_wgrad_rows(B, c1), c1, k1)
+    _lib.call("scae_conv3x3_first_wgrad_f32", _p(dpre), _p(image),
+              _p(partial), B, C0, H, W, c1, strides[0], st)
+    gws[0], gbs[0] = _sum_rows(partial.view(partial.shape[0], -1),
+                               [(c1, C0, 3, 3), (c1,)],
+                               outs=[gout(0), gout(L)])
+    return gws, gbs
+
+
 class _ConvStack(torch.autograd.Function):
     """relu(conv3x3(.. relu(conv3x3(image)) ..)): image (B, C, H, W) NCHW ->
     (B, C_last, OH, OW) as a channels-last view.  Intermediates are NHWC."""
@@ -430,40 +523,12 @@ class _ConvStack(torch.autograd.Function):
         image = image.contiguous()
         weights = [w.contiguous() for w in wb[:L]]
         biases = [b.contiguous() for b in wb[L:]]
-        B, C0, H, W = image.shape
-        dev, st = image.device, _stream(image)
-        new = lambda *shape: torch.empty(*shape, device=dev, dtype=image.dtype)
-        c1, s = weights[0].shape[0], strides[0]
-        oh, ow = (H - 3) // s + 1, (W - 3) // s + 1
-        act = new(B, oh, ow, c1)
-        _lib.call("scae_conv3x3_first_fwd_f32", _p(image), _p(weights[0]),
-                  _p(biases[0]), _p(act), B, C0, H, W, c1, s, st)
-        acts, wds, wfs = [act], [], []
-        for l in range(1, L):
-            co, ci = weights[l].shape[0], weights[l].shape[1]
-            wfs.append(new(co, 9, ci))
-            wds.append(new(ci, 9, co))
-        if L > 1:       # every layer's filter re-layout in one launch
-            n = L - 1
-            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-            ints = lambda v: (ctypes.c_int * n)(*v)
-            _lib.call("scae_conv3x3_relayout_batch_f32", n, arr(weights[1:]),
-                      arr(wfs), arr(wds), ints([w.shape[0] for w in weights[1:]]),
-                      ints([w.shape[1] for w in weights[1:]]), st)
-        for l in range(1, L):
-            w, s = weights[l], strides[l]
-            co, ci = w.shape[0], w.shape[1]
-            ih, iw = act.shape[1], act.shape[2]
-            out = new(B, (ih - 3) // s + 1, (iw - 3) // s + 1, co)
-            _lib.call("scae_conv3x3_fwd_f32", _p(act), _p(wfs[l - 1]),
-                      _p(biases[l]), _p(out), B, ih, iw, ci, co, s, st)
-            acts.append(out)
-            act = out
+        acts, wds, _ = _conv_stack_fwd(image, strides, weights, biases)
         ctx.save_for_backward(image, *acts, *wds)
         ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights])
         ctx.slots = [_slot(t) for t in wb]
         ctx.refs = [tuple(t.shape) for t in wb]
-        return act.permute(0, 3, 1, 2)
+        return acts[-1].permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
@@ -472,46 +537,11 @@ class _ConvStack(torch.autograd.Function):
         image = ctx.saved_tensors[0]
         acts = ctx.saved_tensors[1:1 + L]
         wds = ctx.saved_tensors[1 + L:]
-        B, C0, H, W = image.shape
-        dev, dt, st = image.device, image.dtype, _stream(image)
-        new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
-
-        def gout(i):     # gradient buffer of weight / bias i (flat slot if any)
-            return _grad_out(ctx.slots[i], image, ctx.refs[i])
-
         dpre = torch.ops.aten.threshold_backward(
             gy.permute(0, 2, 3, 1).contiguous(), acts[-1], 0.0)
-        gws, gbs = [None] * L, [None] * L
-        pending = []       # (partial, gw, gb, co, ci, splits): reduced in one launch
-        for l in range(L - 1, 0, -1):
-            co, ci = wshapes[l][0], wshapes[l][1]
-            xin, s = acts[l - 1], strides[l]
-            ih, iw, oh, ow = xin.shape[1], xin.shape[2], dpre.shape[1], dpre.shape[2]
-            splits = _lib.load().scae_conv3x3_wgrad_splits(B, oh, ow, ci, co)
-            partial = new(splits * (9 * co * ci + co))
-            gw, gb = gout(l), gout(L + l)
-            _lib.call("scae_conv3x3_wgrad_f32", _p(dpre), _p(xin), _p(partial),
-                      None, None, B, ih, iw, ci, co, s, st)
-            pending.append((partial, gw, gb, co, ci, splits))
-            gws[l], gbs[l] = gw, gb
-            din = new(B, ih, iw, ci)
-            _lib.call("scae_conv3x3_dgrad_f32", _p(dpre), _p(wds[l - 1]),
-                      _p(xin), _p(din), B, ih, iw, ci, co, s, st)
-            dpre = din
-        if pending:
-            n = len(pending)
-            arr = lambda k: (ctypes.c_void_p * n)(*[p[k].data_ptr() for p in pending])
-            ints = lambda k: (ctypes.c_int * n)(*[p[k] for p in pending])
-            _lib.call("scae_conv3x3_wgrad_reduce_batch_f32", n, arr(0), arr(1),
-                      arr(2), ints(3), ints(4), ints(5), st)
-        c1 = wshapes[0][0]
-        k1 = C0 * 9 + 1
-        partial = new(_lib.load().scae_conv3x3_first_wgrad_rows(B, c1), c1, k1)
-        _lib.call("scae_conv3x3_first_wgrad_f32", _p(dpre), _p(image),
-                  _p(partial), B, C0, H, W, c1, strides[0], st)
-        gws[0], gbs[0] = _sum_rows(partial.view(partial.shape[0], -1),
-                                   [(c1, C0, 3, 3), (c1,)],
-                                   outs=[gout(0), gout(L)])
+        gws, gbs = _conv_stack_bwd(
+            image, acts, wds, strides, wshapes, dpre,
+            lambda i: _grad_out(ctx.slots[i], image, ctx.refs[i]))
         return (None, None, *gws, *gbs)
 
 
@@ -540,8 +570,11 @@ def _conv1x1_fwd(x, weight, bias):
     return y
 
 
-def _conv1x1_bwd(x, weight, dy):
-    """-> (dx, dweight, dbias) of the 1x1 conv given dy (B, HW, AP)."""
+def _conv1x1_bwd(x, weight, dy, gate=None, outs=None):
+    """-> (dx, dweight, dbias) of the 1x1 conv given dy (B, HW, AP).  With
+    ``gate`` (the ReLU output x was made from, layout of x) -> (dx zeroed
+    where gate <= 0, dweight, dbias, ungated dx).  ``outs``: buffers for
+    (dweight, dbias)."""
     B, HW, C = x.shape
     AP = weight.shape[0]
     # weight / bias gradient: dy^T x split over groups of images (the launch
@@ -551,14 +584,19 @@ def _conv1x1_bwd(x, weight, dy):
     S, kper, slab = B // gsz, HW * gsz, AP * C + AP
     part = torch.empty(S, slab, device=x.device, dtype=x.dtype)
     dx = torch.empty_like(x)
+    dgrad = _gemm_desc(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP,
+                       0, False, C, 0, C, 0)
+    raw = None
+    if gate is not None:
+        raw = torch.empty_like(x)
+        dgrad.mask, dgrad.ldmask, dgrad.c_nomask = gate.data_ptr(), C, \
+            raw.data_ptr()
     _gemm_pair(
         _gemm_desc(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP,
                    kper * AP, False, C, kper * C, C, slab,
-                   asum=_off(part, AP * C), asum_b=slab),
-        _gemm_desc(_p(dy), _p(weight), _p(dx), 1, B * HW, C, AP, True, AP, 0,
-                   False, C, 0, C, 0), x)
-    gw, gb = _sum_rows(part, [(AP, C), (AP,)])
-    return dx, gw, gb
+                   asum=_off(part, AP * C), asum_b=slab), dgrad, x)
+    gw, gb = _sum_rows(part, [tuple(weight.shape), (AP,)], outs=outs)
+    return (dx, gw, gb) if gate is None else (dx, gw, gb, raw)
 
 
 class _AttentionConvPool(torch.autograd.Function):
@@ -635,8 +673,8 @@ class _CapsuleHead(torch.autograd.Function):
         dy = torch.empty_like(y)
         _lib.call("scae_capsule_head_bwd_f32", _p(y), _p(pooled), _p(noise_u),
                   noise_scale, similarity, _p(_c(g_pose)), _p(_c(g_presence)),
-                  _p(_c(g_feature)), _p(dy), B, HW, A, weight.shape[0] // A,
-                  _stream(x))
+                  _p(_c(g_feature)), None, _p(dy), B, HW, A,
+                  weight.shape[0] // A, _stream(x))
         return (*_conv1x1_bwd(x, weight, dy), None, None, None, None)
 
 
@@ -648,6 +686,110 @@ def capsule_head(x, weight, bias, n_caps, noise_u=None, noise_scale=0.,
     pose, presence, feature, absence = _CapsuleHead.apply(
         x, weight, bias, noise_u, n_caps, noise_scale, similarity)
     return pose, presence, (feature if feature.shape[-1] > 0 else None), absence
+
+
+class _PartEncoder(torch.autograd.Function):
+    """The whole CapsuleImageEncoder.forward (part_encoder.py:86-113) as ONE
+    autograd node: conv stack (K8) with the embedding bias in the last
+    layer's epilogue, 1x1 attention conv (K7), capsule head (K9).  As one node
+    the backward needs no stand-alone glue launches: the ReLU gate of the last
+    conv layer rides in the epilogue of the 1x1 conv's data-gradient GEMM
+    (which also keeps the ungated values for the embedding-bias gradient), and
+    the two consumers of ``feature`` get separate outputs whose gradients the
+    head kernel adds."""
+
+    @staticmethod
+    def forward(ctx, image, strides, post_bias, att_w, att_b, noise_u, n_caps,
+                noise_scale, similarity, *wb):
+        _need_hip(image, post_bias, att_w, att_b, noise_u, *wb)
+        L = len(strides)
+        image = image.contiguous()
+        weights = [w.contiguous() for w in wb[:L]]
+        biases = [b.contiguous() for b in wb[L:]]
+        acts, wds, x = _conv_stack_fwd(image, strides, weights, biases,
+                                       post_bias.contiguous())
+        B, OH, OW, C = x.shape
+        HW = OH * OW
+        x = x.view(B, HW, C)
+        att_w2 = att_w.contiguous().view(-1, C)
+        P = att_w2.shape[0] // n_caps
+        F = P - 8
+        noise_u = _c(noise_u)
+        y = _conv1x1_fwd(x, att_w2, att_b.contiguous())
+        new = lambda *shape: torch.empty(*shape, device=x.device, dtype=x.dtype)
+        pooled, pose, presence = new(B, n_caps, P - 1), new(B, n_caps, 6), \
+            new(B, n_caps)
+        feature = new(B, n_caps, F) if F > 0 else None
+        absence = new(B, n_caps, 1)
+        _lib.call("scae_capsule_head_fwd_f32", _p(y), _p(noise_u),
+                  float(noise_scale), int(similarity), _p(pooled), _p(pose),
+                  _p(presence), _p(feature), _p(absence), B, HW, n_caps, P,
+                  _stream(x))
+        ctx.save_for_backward(image, *acts, *wds, x, att_w2, y, pooled,
+                              *([noise_u] if noise_u is not None else []))
+        ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights], n_caps,
+                    float(noise_scale), int(similarity), noise_u is not None,
+                    tuple(post_bias.shape), tuple(att_w.shape))
+        ctx.slots = [_slot(t) for t in (post_bias, att_w, att_b, *wb)]
+        ctx.refs = [tuple(t.shape) for t in wb]
+        ctx.set_materialize_grads(False)
+        if feature is None:
+            feature = new(B, n_caps, 0)
+            ctx.mark_non_differentiable(feature)
+        # the same values as a second tensor object (same memory): one output
+        # per consumer, so autograd never has to add their gradients
+        twin = torch.empty(0, device=x.device, dtype=x.dtype).set_(
+            feature.untyped_storage(), feature.storage_offset(),
+            feature.shape, feature.stride())
+        if F <= 0:
+            ctx.mark_non_differentiable(twin)
+        ctx.mark_non_differentiable(absence)
+        return pose, presence, feature, twin, absence
+
+    @staticmethod
+    def backward(ctx, g_pose, g_presence, g_feature, g_twin, _g_absence):
+        (strides, wshapes, A, noise_scale, similarity, has_noise, pb_shape,
+         attw_shape) = ctx.meta
+        L = len(strides)
+        saved = ctx.saved_tensors
+        image, acts, wds = saved[0], saved[1:1 + L], saved[1 + L:2 * L]
+        x, att_w2, y, pooled = saved[2 * L:2 * L + 4]
+        noise_u = saved[2 * L + 4] if has_noise else None
+        B, HW, C = x.shape
+        dy = torch.empty_like(y)
+        _lib.call("scae_capsule_head_bwd_f32", _p(y), _p(pooled), _p(noise_u),
+                  noise_scale, similarity, _p(_c(g_pose)), _p(_c(g_presence)),
+                  _p(_c(g_feature)), _p(_c(g_twin)), _p(dy), B, HW, A,
+                  att_w2.shape[0] // A, _stream(x))
+        act = acts[-1]
+        g_attw = _grad_out(ctx.slots[1], x, attw_shape)
+        g_attb = _grad_out(ctx.slots[2], x, (att_w2.shape[0],))
+        dpre, _, _, raw = _conv1x1_bwd(x, att_w2, dy, gate=act.view(B, HW, C),
+                                       outs=[g_attw, g_attb])
+        # embedding-bias gradient: batch sum of the ungated dx, (HW, C) -> (C, HW)
+        (g_pb,) = _sum_rows(raw.view(B, HW * C), [pb_shape], transpose=C,
+                            outs=[_grad_out(ctx.slots[0], x, pb_shape)])
+        gws, gbs = _conv_stack_bwd(
+            image, acts, wds, strides, wshapes, dpre.view(act.shape),
+            lambda i: _grad_out(ctx.slots[3 + i], image, ctx.refs[i]))
+        return (None, None, g_pb, g_attw, g_attb, None, None, None, None,
+                *gws, *gbs)
+
+
+def part_encoder(image, weights, biases, strides, post_bias, att_weight,
+                 att_bias, n_caps, noise_u=None, noise_scale=0.,
+                 similarity=False):
+    """CapsuleImageEncoder.forward as one autograd node (``_PartEncoder``):
+    -> (pose (B,A,6), presence (B,A), feature (B,A,F) or None, feature twin
+    (the same values for a second consumer), 1 - presence (B,A,1) detached).
+    Needs a >= 2-layer ``conv_stack_supported`` stack, n_poses == 6 and
+    ``attention_pool_supported`` shapes."""
+    pose, presence, feature, twin, absence = _PartEncoder.apply(
+        image, tuple(int(s) for s in strides), post_bias, att_weight, att_bias,
+        noise_u, n_caps, noise_scale, similarity, *weights, *biases)
+    if feature.shape[-1] == 0:
+        feature = twin = None
+    return pose, presence, feature, twin, absence
 
 
 def attention_conv_pool(x, weight, bias, n_caps):

@@ -70,9 +70,28 @@ class CapsuleImageEncoder(nn.Module):
 
     def forward(self, image):
         batch_size = image.shape[0]
+        noisy = self.training and self.noise_scale > 0.
+        C, H, W = self.encoder.output_shape
+        if image.is_cuda and image.dtype == torch.float32 and \
+                self.n_poses == 6 and \
+                getattr(self.encoder, "_hip_stack", False) and \
+                len(self.encoder.strides) >= 2 and \
+                ops.attention_pool_supported(H * W, self.n_caps,
+                                             self.n_total_caps_dims + 1):
+            # the whole encoder as one autograd node over the HIP kernels
+            convs = [m for m in self.encoder.network
+                     if isinstance(m, nn.Conv2d)]
+            noise = rand_like(image.new_empty(batch_size, self.n_caps)) \
+                if noisy else None
+            pose, presence, feature, twin, absence = ops.part_encoder(
+                image, [c.weight for c in convs], [c.bias for c in convs],
+                self.encoder.strides, self.img_embedding_bias,
+                self.att_conv.weight, self.att_conv.bias, self.n_caps, noise,
+                self.noise_scale, self.similarity_transform)
+            return AttrDict(pose=pose, presence=presence, feature=feature,
+                            _feature_twin=twin, _absence=absence)
         h = self.encoder(image)
         C, H, W = h.shape[1:]
-        noisy = self.training and self.noise_scale > 0.
         if h.is_cuda and h.dtype == torch.float32 and \
                 ops.attention_pool_supported(H * W, self.n_caps,
                                              self.n_total_caps_dims + 1):

@@ -119,7 +119,11 @@ class SCAE(nn.Module):
             "_absence" in parts else 1. - in_presence.unsqueeze(-1)
         segments = [in_pose, absence]
         if parts.feature is not None:
-            segments.append(parts.feature)
+            # (a second tensor with the same values when the fused encoder
+            # provides one: its gradient is summed inside the head kernel)
+            segments.append(parts.get("_feature_twin", parts.feature)
+                            if parts.get("_feature_twin") is not None
+                            else parts.feature)
         segments.append(in_templates.flatten(2))
         if hasattr(self.obj_encoder, "forward_segments"):
             # fused trunk: the concat is never materialised
