@@ -217,11 +217,17 @@ def test_flat_gradient_slots_match_plain_backward():
         flat.gather_grads()
         in_place = sum(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
                        for p, v in zip(flat.params, flat.grad_views()))
-        assert in_place >= 20, in_place      # convs, capsule MLPs, projectors
-        for (name, p), v, q in zip(model.named_parameters(), flat.grad_views(),
-                                   plain.parameters()):
+        # every op writes its parameter gradients in place: nothing is left
+        # for the per-step pack but the two 10-class classifier tensors
+        assert in_place >= len(flat.params) - 4, in_place
+        # (the flat order is not the module order: parameter groups a kernel
+        # reads as one buffer are laid out back to back)
+        names = {id(p): n for n, p in model.named_parameters()}
+        reference = dict(plain.named_parameters())
+        for p, v in zip(flat.params, flat.grad_views()):
+            q = reference[names[id(p)]]
             want = q.grad if q.grad is not None else torch.zeros_like(q)
-            assert torch.equal(v, want), (step, name)
+            assert torch.equal(v, want), (step, names[id(p)])
 
 
 @pytest.mark.gpu

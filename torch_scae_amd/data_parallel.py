@@ -50,6 +50,18 @@ class FlatParameters:
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
             raise ValueError("module has no trainable parameters")
+        # modules may ask for groups of parameters to lie back to back (in
+        # the layout one of their kernels reads): move each group, in order,
+        # to the position of its first member
+        for m in module.modules():
+            for group in getattr(m, "_flat_param_groups", lambda: [])():
+                ids = {id(p) for p in group}
+                if len(ids) != len(group) or \
+                        not ids <= {id(p) for p in params}:
+                    continue
+                first = min(i for i, p in enumerate(params) if id(p) in ids)
+                rest = [p for p in params if id(p) not in ids]
+                params = rest[:first] + list(group) + rest[first:]
         dev, dt = params[0].device, params[0].dtype
         for p in params:
             if p.device != dev or p.dtype != dt:

@@ -16,7 +16,7 @@ from ._lib import DecoderDesc, ScaeHipError
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_scalar", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "part_encoder", "conv_stack", "conv_stack_supported",
-           "uniform", "reset_noise", "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
+           "uniform", "reset_noise", "pack_params", "render_templates", "render_gmm_log_prob", "render_gmm_log_prob_sums",
            "gmm_log_prob", "gmm_mean", "gmm_mode", "ScaeHipError"]
 
 
@@ -253,6 +253,7 @@ class _SetEncoder(torch.autograd.Function):
         ctx.has_presence = presence is not None
         ctx.nseg = len(segs)
         ctx.dims = (B, N, D, Din, Dout, L, int(layer_norm))
+        ctx.slot = _slot(packed)
         return z
 
     @staticmethod
@@ -274,7 +275,13 @@ class _SetEncoder(torch.autograd.Function):
         _lib.call("scae_set_encoder_bwd_f32", len(segs), ptrs, widths, rs, bs,
                   gptrs, _p(presence), _p(packed), _p(hsave), _p(gz),
                   _p(partial), B, N, D, Din, Dout, L, ln, _stream(packed))
-        return (None, _sum_rows(partial, [packed.shape])[0], None, *gsegs)
+        taken_before = ctx.slot is not None and ctx.slot.taken
+        gpacked = _grad_out(ctx.slot, packed)
+        if ctx.slot is not None and not taken_before:
+            for sl in getattr(ctx.slot, "parts", ()):
+                sl.taken = True   # the parts' slots are written through it
+        return (None, _sum_rows(partial, [packed.shape], outs=[gpacked])[0],
+                None, *gsegs)
 
 
 def set_encoder(segments, presence, packed_params, dim_hidden, dim_out,
@@ -286,6 +293,54 @@ def set_encoder(segments, presence, packed_params, dim_hidden, dim_out,
     return _SetEncoder.apply(presence, packed_params,
                              (dim_hidden, dim_out, n_layers, bool(layer_norm)),
                              *segments)
+
+
+class _PackParams(torch.autograd.Function):
+    """Concatenation of flattened parameters.  When they already lie back to
+    back in memory in this order (FlatParameters places a module's
+    ``_flat_param_groups`` that way) the result aliases them -- no copy -- and
+    the gradient is handed back as views of one buffer."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.shapes = [tuple(p.shape) for p in parts]
+        adjacent = all(p.is_contiguous() for p in parts) and all(
+            a.data_ptr() + 4 * a.numel() == b.data_ptr()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            for a, b in zip(parts, parts[1:]))
+        if adjacent:
+            total = sum(p.numel() for p in parts)
+            return torch.empty(0, device=parts[0].device, dtype=parts[0].dtype) \
+                .set_(parts[0].untyped_storage(), parts[0].storage_offset(),
+                      (total,), (1,))
+        return torch.cat([p.reshape(-1) for p in parts])
+
+    @staticmethod
+    def backward(ctx, g):
+        out, off = [], 0
+        for shape in ctx.shapes:
+            n = int(np.prod(shape))
+            out.append(g[off:off + n].view(shape))
+            off += n
+        return tuple(out)
+
+
+def pack_params(parts):
+    """One flat buffer of ``parts`` (see ``_PackParams``).  When the parts also
+    own back-to-back slots of the flat gradient buffer, the result carries a
+    slot covering all of them, so the consumer's backward writes the packed
+    gradient straight into place."""
+    parts = list(parts)
+    packed = _PackParams.apply(*parts)
+    slots = [_slot(p) for p in parts]
+    if packed.data_ptr() == parts[0].data_ptr() and all(
+            sl is not None and not sl.taken for sl in slots) and all(
+            a.flat_grad is b.flat_grad and a.offset + a.numel == b.offset
+            for a, b in zip(slots, slots[1:])):
+        packed._scae_grad_slot = type(slots[0])(
+            slots[0].flat_grad, slots[0].offset, (packed.numel(),))
+        packed._scae_grad_slot.parts = slots
+    return packed
 
 
 # ----------------------------------------------------------------------------
@@ -373,7 +428,7 @@ class _SeedFold(torch.autograd.Function):
         ctx.slots = [_slot(t) for t in inputs]
         inputs = tuple(t.contiguous() for t in inputs)
         seeds, w2 = inputs[0], inputs[9]
-        O, C = seeds.shape
+        O, C = seeds.shape[-2:]           # (O, C) or the parameter's (1, O, C)
         D = w2.shape[1]
         new = lambda *shape: torch.empty(*shape, device=seeds.device,
                                          dtype=seeds.dtype)
@@ -387,7 +442,7 @@ class _SeedFold(torch.autograd.Function):
     def backward(ctx, g_q, g_wkf, g_bkf, g_wvf, g_bvf):
         inputs, outs = ctx.saved_tensors[:11], ctx.saved_tensors[11:]
         seeds, w2 = inputs[0], inputs[9]
-        O, C = seeds.shape
+        O, C = seeds.shape[-2:]
         D = w2.shape[1]
         zeros = lambda ref: torch.zeros_like(ref)
         incoming = [g if g is not None else zeros(o) for g, o in
@@ -875,6 +930,7 @@ class _ColoredTemplates(torch.autograd.Function):
                   _p(color), B, M, C, th * tw, F, H1, tnl, cnl, _stream(logits))
         ctx.save_for_backward(logits, feature, w1, b1, w2, b2, color)
         ctx.codes = (tnl, cnl)
+        ctx.slots = [_slot(t) for t in (logits, w1, b1, w2, b2)]
         ctx.set_materialize_grads(False)
         return raw, templates
 
@@ -887,7 +943,8 @@ class _ColoredTemplates(torch.autograd.Function):
             g_templates = torch.zeros(B, M, C, th, tw, device=logits.device,
                                       dtype=logits.dtype)
         n1, n2, n3 = H1 * F, H1 * F + H1, H1 * F + H1 + C * H1
-        g_logits, g_feature = torch.empty_like(logits), torch.empty_like(feature)
+        g_logits = _grad_out(ctx.slots[0], logits)
+        g_feature = torch.empty_like(feature)
         rows = _lib.load().scae_template_color_partial_rows(B, M)
         partial = torch.empty(rows, n3 + C, device=logits.device,
                               dtype=logits.dtype)
@@ -896,8 +953,10 @@ class _ColoredTemplates(torch.autograd.Function):
                   _p(g_templates.contiguous()), _p(_c(g_raw)), _p(g_logits),
                   _p(g_feature), _p(partial), B, M, C, th * tw, F, H1,
                   *ctx.codes, _stream(logits))
-        gw1, gb1, gw2, gb2 = _sum_rows(partial,
-                                       [(H1, F), (H1,), (C, H1), (C,)])
+        gw1, gb1, gw2, gb2 = _sum_rows(
+            partial, [(H1, F), (H1,), (C, H1), (C,)],
+            outs=[_grad_out(sl, t) for sl, t in zip(ctx.slots[1:],
+                                                    (w1, b1, w2, b2))])
         return g_logits, g_feature, gw1, gb1, gw2, gb2, None, None
 
 
@@ -1118,6 +1177,8 @@ class _CapsuleVotes(torch.autograd.Function):
         ctx.noise_scale = float(noise_scale)
         ctx.flags = flags
         ctx.param_is_relu = bool(param_is_relu)
+        ctx.slots = [_slot(t) for t in (cpr_static, b_cvr, b_caps, b_vote,
+                                        b_scale)]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(reg)
         return vote, scale, vp, lc, lv, reg_loss, caps_presence, reg
@@ -1146,10 +1207,13 @@ class _CapsuleVotes(torch.autograd.Function):
         # bias gradients: batch sums of column blocks of gall (B, O*A); each
         # capsule's block lands in its row of the (.., O, ..) parameter
         A = all_param.shape[2]
-        (g_static,) = _sum_rows(gin.view(B, -1), [args[1].shape])
+        outs = [_grad_out(sl, t) for sl, t in zip(ctx.slots, args[1:6])]
+        (g_static,) = _sum_rows(gin.view(B, -1), [args[1].shape],
+                                outs=outs[:1])
         g_cvr, g_caps, g_vote, g_scale = _sum_rows(
             gall.view(B, O * A), [t.shape for t in args[2:6]],
-            starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=A)
+            starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=A,
+            outs=outs[1:])
         return (gall if ggated is None else ggated, g_static, g_cvr, g_caps,
                 g_vote, g_scale, None, None, None, None, None, None, None, None)
 
@@ -1267,6 +1331,7 @@ class _LossTail(torch.autograd.Function):
     def forward(ctx, lpp, posterior, caps_presence, cls_w, cls_b, label,
                 rec_sums, reg, cfg):
         _need_hip(lpp, posterior, caps_presence, cls_w, cls_b, rec_sums, reg)
+        ctx.slots = (_slot(cls_w), _slot(cls_b))
         lpp, posterior, caps_presence = _c(lpp), _c(posterior), _c(caps_presence)
         cls_w, cls_b, label = _c(cls_w), _c(cls_b), _c(label)
         rec_sums, reg = _c(rec_sums), _c(reg)
@@ -1317,8 +1382,8 @@ class _LossTail(torch.autograd.Function):
             reg = rest[0]
         ints, weights, wc, w_reg = ctx.call
         g_lpp, g_post, g_cp = (torch.empty_like(t) for t in (lpp, posterior, cp))
-        g_w = torch.empty_like(cls_w) if cls_w is not None else None
-        g_b = torch.empty_like(cls_b) if cls_b is not None else None
+        g_w = _grad_out(ctx.slots[0], cls_w) if cls_w is not None else None
+        g_b = _grad_out(ctx.slots[1], cls_b) if cls_b is not None else None
         g_rec = torch.empty_like(rec_sums) if has_rec else None
         g_reg = torch.empty_like(reg) if has_reg else None
         ex = _lib.LossExtras()
@@ -1399,7 +1464,8 @@ def _make_desc(tensors, output_size):
 
 
 def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
-                      g_lp, g_tt, g_ml, g_tile=None):
+                      g_lp, g_tt, g_ml, g_tile=None, slots=None,
+                      alpha_shape=None):
     (templates, alpha, pose, presence, bg_image, bg_value, bg_ml, temp,
      out_scale) = ctx_tensors
     d, (B, M, C, th, tw, H, W) = _make_desc(ctx_tensors, output_size)
@@ -1421,15 +1487,23 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
                   _p(lse_post), _p(lse_prior), _p(g_lp), _p(g_tt), _p(g_ml),
                   _p(g_templates), _p(g_alpha_p), _p(g_pose), _p(g_presence),
                   _p(g_bg_image), _p(g_scal), _stream(templates))
-    gs = g_scal.sum((0, 1))
-    return (g_templates,
-            None if alpha is None else _sum_rows(g_alpha_p.view(B, -1),
-                                                 [alpha.shape])[0],
-            g_pose, g_presence, g_bg_image,
-            None if bg_value is None else gs[0:1].view_as(bg_value),
-            None if bg_ml is None else gs[1:2].view_as(bg_ml),
-            None if temp is None else gs[2:3].view_as(temp),
-            None if out_scale is None else gs[3:4].view_as(out_scale))
+    slots = slots or [None] * 9
+    g_alpha = None
+    if alpha is not None:
+        ashape = tuple(alpha_shape or alpha.shape)
+        g_alpha = _sum_rows(g_alpha_p.view(B, -1), [ashape],
+                            outs=[_grad_out(slots[1], alpha, ashape)])[0]
+    # the four scalar parameters: column sums of the (B*(M+1), 4) partials
+    scal = [(i, t) for i, t in enumerate((bg_value, bg_ml, temp, out_scale))
+            if t is not None]
+    gs = [None] * 4
+    if scal:
+        outs = _sum_rows(g_scal.view(-1, 4), [t.shape for _, t in scal],
+                         starts=[i for i, _ in scal],
+                         outs=[_grad_out(slots[5 + i], t) for i, t in scal])
+        for (i, _), o in zip(scal, outs):
+            gs[i] = o
+    return (g_templates, g_alpha, g_pose, g_presence, g_bg_image, *gs)
 
 
 def _prep_decoder(tensors):
@@ -1457,6 +1531,7 @@ class _RenderTemplates(torch.autograd.Function):
         ctx.present = [x is not None for x in t]
         ctx.output_size = output_size
         ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
+        ctx.slots = [_slot(v) for v in tensors]
         ctx.set_materialize_grads(False)
         return tt, ml
 
@@ -1467,7 +1542,8 @@ class _RenderTemplates(torch.autograd.Function):
         it = iter(ctx.saved_tensors)
         t = [next(it) if p else None for p in ctx.present]
         grads = _decoder_backward(t, ctx.output_size, ctx.needs_input_grad,
-                                  None, None, None, None, _c(g_tt), _c(g_ml))
+                                  None, None, None, None, _c(g_tt), _c(g_ml),
+                                  slots=ctx.slots, alpha_shape=ctx.alpha_shape)
         grads = list(grads)
         if grads[1] is not None:
             grads[1] = grads[1].view(ctx.alpha_shape)
@@ -1495,6 +1571,7 @@ class _RenderGmmLogProb(torch.autograd.Function):
         ctx.present = [v is not None for v in t]
         ctx.output_size = output_size
         ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
+        ctx.slots = [_slot(v) for v in tensors]
         return lp
 
     @staticmethod
@@ -1504,7 +1581,9 @@ class _RenderGmmLogProb(torch.autograd.Function):
         t = [next(it) if p else None for p in ctx.present]
         grads = list(_decoder_backward(t, ctx.output_size, ctx.needs_input_grad,
                                        x, lse_post, lse_prior,
-                                       g_lp.contiguous(), None, None))
+                                       g_lp.contiguous(), None, None,
+                                       slots=ctx.slots,
+                                       alpha_shape=ctx.alpha_shape))
         if grads[1] is not None:
             grads[1] = grads[1].view(ctx.alpha_shape)
         # the reconstruction target gets no gradient on this path (the
@@ -1535,6 +1614,7 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
         ctx.present = [v is not None for v in t]
         ctx.output_size = output_size
         ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
+        ctx.slots = [_slot(v) for v in tensors]
         return sums
 
     @staticmethod
@@ -1544,7 +1624,9 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
         t = [next(it) if p else None for p in ctx.present]
         grads = list(_decoder_backward(t, ctx.output_size, ctx.needs_input_grad,
                                        x, lse_post, lse_prior, None, None, None,
-                                       g_tile=g_sums.contiguous()))
+                                       g_tile=g_sums.contiguous(),
+                                       slots=ctx.slots,
+                                       alpha_shape=ctx.alpha_shape))
         if grads[1] is not None:
             grads[1] = grads[1].view(ctx.alpha_shape)
         return (None, None, *grads)

@@ -159,9 +159,17 @@ class SetTransformer(nn.Module):
             n_items, self.fc1.out_features, self.fc1.in_features,
             self.fc2.out_features, len(self.sabs), int(layer_norm)))
 
+    def _flat_param_groups(self):
+        """Parameters data_parallel.FlatParameters should lay out back to back
+        (then ``_packed_trunk`` is a view, not a copy)."""
+        return [self._trunk_parts(True)]
+
     def _packed_trunk(self, with_fc2=True):
         """All trunk parameters as one flat buffer in the layout the fused
         kernel reads (include/scae_hip.h, K2b)."""
+        return ops.pack_params(self._trunk_parts(with_fc2))
+
+    def _trunk_parts(self, with_fc2):
         parts = [self.fc1.weight, self.fc1.bias]
         for sab in self.sabs:
             m = sab.mab
@@ -175,7 +183,7 @@ class SetTransformer(nn.Module):
                 parts += [m.ln1.weight, m.ln1.bias]
         if with_fc2:
             parts += [self.fc2.weight, self.fc2.bias]
-        return torch.cat([p.reshape(-1) for p in parts])
+        return parts
 
     def encode_segments(self, segments, presence=None):
         """fc1 -> blocks -> fc2 on the set whose features are the column-wise
@@ -216,8 +224,7 @@ class SetTransformer(nn.Module):
             C, D = w2.shape
             if ops.seed_fold_supported(self.seeds.shape[1], C, D):
                 q, wk, bk, wv, bv = ops.seed_fold(
-                    self.seeds.view(self.seeds.shape[1:]),
-                    mha.q_projector.weight,
+                    self.seeds, mha.q_projector.weight,
                     mha.q_projector.bias, mha.k_projector.weight,
                     mha.k_projector.bias, mha.v_projector.weight,
                     mha.v_projector.bias, mha.o_projector.weight,
