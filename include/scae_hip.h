@@ -515,6 +515,9 @@ int scae_class_probs_f32(const float *caps_presence, const float *posterior, con
  *   g_reg receive their gradients in the backward pass.
  *   backward: gout12 (12) -> g_lpp, g_posterior, g_caps_presence, g_cls_w,
  *   g_cls_b (classifier inputs are detached in the reference).
+ *   workspace: scae_loss_tail_workspace_floats(B,O,ncls) floats owned by the
+ *   caller; the forward leaves the per-image / per-column statistics there and
+ *   the backward of the same inputs reads them.
  * ---------------------------------------------------------------------- */
 typedef struct scae_loss_extras {
   const float *rec_sums;
@@ -527,18 +530,20 @@ typedef struct scae_loss_extras {
                            gout12 may then be NULL (= zeros) */
 } scae_loss_extras;
 int scae_loss_tail_supported(int B, int O, int ncls);
+int64_t scae_loss_tail_workspace_floats(int B, int O, int ncls);
 int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                            const float *caps_presence, const float *cls_w,
                            const float *cls_b, const int64_t *label,
-                           const scae_loss_extras *extras, float *out12, int B, int O, int M,
-                           int ncls, int n_classes_cfg, int prior_type, int post_type,
-                           int sparsity_on, const float *weights5, float within_const,
-                           void *stream);
+                           const scae_loss_extras *extras, float *out12, float *workspace,
+                           int B, int O, int M, int ncls, int n_classes_cfg, int prior_type,
+                           int post_type, int sparsity_on, const float *weights5,
+                           float within_const, void *stream);
 int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
                            const float *caps_presence, const float *cls_w,
                            const float *cls_b, const int64_t *label,
-                           const scae_loss_extras *extras, const float *gout12, float *g_lpp,
-                           float *g_posterior, float *g_caps_presence, float *g_cls_w,
+                           const scae_loss_extras *extras, const float *gout12,
+                           const float *workspace, float *g_lpp, float *g_posterior,
+                           float *g_caps_presence, float *g_cls_w,
                            float *g_cls_b, int B, int O, int M, int ncls, int n_classes_cfg,
                            int prior_type, int post_type, int sparsity_on,
                            const float *weights5, float within_const, void *stream);

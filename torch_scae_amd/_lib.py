@@ -135,9 +135,10 @@ SIGNATURES = {
     "scae_capsule_likelihood_fwd_f32": [P] * 17 + [c_int] * 3 + [P],
     "scae_capsule_likelihood_bwd_f32": [P] * 22 + [c_int] * 3 + [P],
     "scae_loss_tail_supported": [c_int] * 3,
-    "scae_loss_tail_fwd_f32": [P] * 6 + [POINTER(LossExtras), P] + [c_int] * 8
+    "scae_loss_tail_workspace_floats": [c_int] * 3,
+    "scae_loss_tail_fwd_f32": [P] * 6 + [POINTER(LossExtras), P, P] + [c_int] * 8
     + [POINTER(c_float), c_float, P],
-    "scae_loss_tail_bwd_f32": [P] * 6 + [POINTER(LossExtras)] + [P] * 6
+    "scae_loss_tail_bwd_f32": [P] * 6 + [POINTER(LossExtras)] + [P] * 7
     + [c_int] * 8 + [POINTER(c_float), c_float, P],
     "scae_template_render_fwd_f32": [POINTER(DecoderDesc), P, P, P],
     "scae_render_gmm_logprob_fwd_f32": [POINTER(DecoderDesc), P, P, P, P, P],
@@ -172,7 +173,8 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = c_char_p if name == "scae_error_string" else c_int
+        fn.restype = c_char_p if name == "scae_error_string" else (
+            c_int64 if name == "scae_loss_tail_workspace_floats" else c_int)
     _lib = lib
     return lib
 

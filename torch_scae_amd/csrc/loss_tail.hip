@@ -5,13 +5,21 @@
 //   caps_presence, posterior sparsity on the capsule mass / n_points, and the
 //   two "cross_entropy over probabilities" classification terms (both through
 //   prior_classifier, as the reference does, :207-212, :281-282).
-// Everything is O(B*O) data: one workgroup per independent group of terms,
-// tensors staged in LDS, block reductions by wave shuffles.  The backward kernel recomputes the forward
-// statistics and writes every gradient once (no atomics).
+// Decomposition: everything except the between-example terms is per image, so
+//   tail_image_kernel   one wave per image: row statistics, within-example
+//                       terms, both classification terms (lanes = classes),
+//                       per-image partials + the capsule mass into a workspace;
+//   tail_combine_kernel one workgroup: batch sums of the partials, column
+//                       (between-example) statistics, the training scalar;
+//   tail_bwd_kernel     one workgroup per image writes that image's gradient
+//                       rows from the saved statistics, a few more workgroups
+//                       reduce the classifier-parameter gradients over the batch.
+// No atomics, every output has one writer, fixed summation orders.
 #include "common.h"
 
 namespace {
-constexpr int NT = 1024;
+constexpr int NTI = 64;    // tail_image_kernel: one wave per image
+constexpr int NT = 256;    // combine / backward workgroups
 constexpr int MAXCLS = 32;
 
 struct TailArgs {
@@ -28,14 +36,25 @@ struct TailArgs {
   float l2_within_const, l2_between_const, l2_within_const_post, l2_between_const_post;
 };
 
-__device__ __forceinline__ float block_total(float v, float *red) {
-  float a[1] = {v};
-  scae::block_sum<1, NT>(a, red);
-  if (threadIdx.x == 0) red[31] = a[0];
-  __syncthreads();
-  const float r = red[31];
-  __syncthreads();
-  return r;
+// workspace (floats): part (B,8) | mass (B,O) | gl (B,2,ncls) | col (2,O)
+//   part[b] = {sum_m lpp, prior within_b, posterior within_b, prior xe_b,
+//              posterior xe_b, row sum of caps_presence, row sum of mass / M, -}
+//   mass[b][o] = sum_m posterior[b,o,m]  (un-normalised)
+//   gl[b][which][c] = d xe_b / d logit_c (which: 0 prior, 1 posterior input)
+//   col[0][o] = sum_b caps_presence, col[1][o] = sum_b mass / M
+struct Ws {
+  float *part, *mass, *gl, *col;
+};
+__host__ __device__ inline Ws carve_ws(float *w, int B, int O, int ncls) {
+  Ws s;
+  s.part = w;
+  s.mass = s.part + (size_t)B * 8;
+  s.gl = s.mass + (size_t)B * O;
+  s.col = s.gl + (size_t)B * 2 * (ncls > 0 ? ncls : 1);
+  return s;
+}
+inline size_t ws_floats(int B, int O, int ncls) {
+  return (size_t)B * 8 + (size_t)B * O + (size_t)B * 2 * (ncls > 0 ? ncls : 1) + 2 * (size_t)O;
 }
 
 // -sum p log_safe(p*k) terms: value and d/dp
@@ -47,171 +66,47 @@ __device__ __forceinline__ float ent_term_grad(float p, float k) {
   return q < scae::kLogSafeEps ? 1e8f : -(logf(q) + 1.f);
 }
 
-// shared statistics of one (B,O) activation matrix x
-struct Stats {
-  float *x;     // [B*O]
-  float *row;   // [B]  sum over o
-  float *col;   // [O]  sum over b
-};
-
-__device__ void row_col_sums(const Stats &s, int B, int O) {
-  for (int b = threadIdx.x; b < B; b += NT) {
-    float t = 0.f;
-    for (int o = 0; o < O; ++o) t += s.x[b * O + o];
-    s.row[b] = t;
-  }
-  // column sums: 16 lanes per column, each takes every 16th row
-  for (int e = threadIdx.x; e < ((O * 16 + NT - 1) / NT) * NT; e += NT) {
-    const int o = e >> 4, l = e & 15;
-    float t = 0.f;
-    if (o < O)
-      for (int b = l; b < B; b += 16) t += s.x[b * O + o];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-    if (o < O && l == 0) s.col[o] = t;
-  }
-  __syncthreads();
+// within-example sparsity term of one image: x[o] in LDS, r = its row sum
+__device__ __forceinline__ float within_term(const float *x, float r, int O, int type,
+                                             float cw, int lane) {
+  if (type == 0) return (r - cw) * (r - cw);
+  const float k = type == 2 ? (float)O : 1.f;
+  float w = 0.f;
+  for (int o = lane; o < O; o += NTI) w += ent_term(x[o] / (r + 1e-8f), k);
+  return scae::wave_sum(w);
 }
 
-// (within, between) of sparsity_loss(type, x); object_decoder.py:433-493
-__device__ void sparsity_fwd(const Stats &s, int B, int O, int type, float cw, float cb,
-                             float *red, float &within, float &between) {
-  float w = 0.f, bt = 0.f;
-  if (type == 0) {
-    for (int b = threadIdx.x; b < B; b += NT) {
-      const float d = s.row[b] - cw;
-      w += d * d;
-    }
-    for (int o = threadIdx.x; o < O; o += NT) {
-      const float d = s.col[o] - cb;
-      bt += d * d;
-    }
-    within = block_total(w, red) / B;
-    between = block_total(bt, red) / O;
-  } else {
-    const float k = type == 2 ? (float)O : 1.f;
-    for (int i = threadIdx.x; i < B * O; i += NT) {
-      const int b = i / O;
-      w += ent_term(s.x[i] / (s.row[b] + 1e-8f), k);
-    }
-    float tot = 0.f;
-    for (int o = 0; o < O; ++o) tot += s.col[o];
-    for (int o = threadIdx.x; o < O; o += NT) bt += ent_term(s.col[o] / (tot + 1e-8f), k);
-    within = block_total(w, red) / B;
-    between = -block_total(bt, red);
+// softmax(prior_classifier(x)) then cross_entropy(probs, label) (:281-282): lanes
+// are classes.  Returns xe (all lanes); gl = d xe / d logit of this lane's class.
+__device__ __forceinline__ float cls_xe(const TailArgs &a, const float *x, int label, int lane,
+                                        float &gl) {
+  const bool on = lane < a.ncls;
+  float z = -INFINITY;
+  if (on) {
+    z = a.cls_b[lane];
+    for (int o = 0; o < a.O; ++o) z = fmaf(x[o], a.cls_w[lane * a.O + o], z);
   }
+  const float mx = scae::wave_max(z);
+  float p = on ? expf(z - mx) : 0.f;
+  p /= scae::wave_sum(p);
+  const float mx2 = scae::wave_max(on ? p : -INFINITY);
+  const float q = on ? expf(p - mx2) : 0.f;
+  const float sum2 = scae::wave_sum(q);
+  const float plabel = scae::wave_sum(lane == label ? p : 0.f);
+  const float dq = on ? q / sum2 - (lane == label ? 1.f : 0.f) : 0.f;  // d xe / d p_c
+  const float dot = scae::wave_sum(p * dq);
+  gl = p * (dq - dot);
+  return mx2 + logf(sum2) - plabel;  // -log_softmax(p)[label]
 }
 
-// g[b,o] += gw * d within/dx + gb * d between/dx
-__device__ void sparsity_bwd(const Stats &s, int B, int O, int type, float cw, float cb,
-                             float gw, float gb, float *g, float *tmp_row /*[B]*/) {
-  if (type == 0) {
-    for (int i = threadIdx.x; i < B * O; i += NT) {
-      const int b = i / O, o = i - b * O;
-      g[i] += gw * 2.f * (s.row[b] - cw) / B + gb * 2.f * (s.col[o] - cb) / O;
-    }
-  } else {
-    const float k = type == 2 ? (float)O : 1.f;
-    float tot = 0.f;
-    for (int o = 0; o < O; ++o) tot += s.col[o];
-    const float tinv = 1.f / (tot + 1e-8f);
-    // between: d(-H(bp))/dx[b,o] = -(sum_j dH/dbp_j dbp_j/dt_o), t_o = col sums
-    float dot_b = 0.f;
-    for (int o = 0; o < O; ++o) dot_b += ent_term_grad(s.col[o] * tinv, k) * s.col[o] * tinv;
-    for (int b = threadIdx.x; b < B; b += NT) {
-      const float rinv = 1.f / (s.row[b] + 1e-8f);
-      float dot_w = 0.f;
-      for (int j = 0; j < O; ++j)
-        dot_w += ent_term_grad(s.x[b * O + j] * rinv, k) * s.x[b * O + j] * rinv;
-      tmp_row[b] = dot_w;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < B * O; i += NT) {
-      const int b = i / O, o = i - b * O;
-      const float rinv = 1.f / (s.row[b] + 1e-8f);
-      const float dot_w = tmp_row[b];
-      const float dw = (ent_term_grad(s.x[i] * rinv, k) - dot_w) * rinv / B;
-      const float db = -(ent_term_grad(s.col[o] * tinv, k) - dot_b) * tinv;
-      g[i] += gw * dw + gb * db;
-    }
-  }
-}
-
-// softmax(prior_classifier(x[b])) then cross_entropy(probs, label): value and
-// gradient w.r.t. the classifier logits (x is detached in the reference)
-__device__ __forceinline__ float cls_xe(const TailArgs &a, const float *xrow, int label,
-                                        float (&glogit)[MAXCLS]) {
-  float z[MAXCLS], p[MAXCLS];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c) {
-    if (c < a.ncls) {
-      float t = a.cls_b[c];
-      for (int o = 0; o < a.O; ++o) t = fmaf(xrow[o], a.cls_w[c * a.O + o], t);
-      z[c] = t;
-      mx = fmaxf(mx, t);
-    }
-  }
-  float sum = 0.f;
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c)
-    if (c < a.ncls) {
-      p[c] = expf(z[c] - mx);
-      sum += p[c];
-    }
-  float mx2 = -INFINITY;
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c)
-    if (c < a.ncls) {
-      p[c] /= sum;
-      mx2 = fmaxf(mx2, p[c]);
-    }
-  float sum2 = 0.f, plabel = 0.f;
-  float q[MAXCLS];
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c)
-    if (c < a.ncls) {
-      q[c] = expf(p[c] - mx2);
-      sum2 += q[c];
-      if (c == label) plabel = p[c];
-    }
-  const float xe = mx2 + logf(sum2) - plabel;  // -log_softmax(p)[label]
-  float dot = 0.f;
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c)
-    if (c < a.ncls) {
-      q[c] = q[c] / sum2 - (c == label ? 1.f : 0.f);  // d xe / d p_c
-      dot = fmaf(p[c], q[c], dot);
-    }
-#pragma unroll
-  for (int c = 0; c < MAXCLS; ++c) glogit[c] = c < a.ncls ? p[c] * (q[c] - dot) : 0.f;
-  return xe;
-}
-
-struct Carve {
-  float *cp, *mass, *row_c, *col_c, *row_m, *col_m, *red, *gl;
-};
-__device__ Carve carve(float *smem, int B, int O, int ncls) {
-  Carve c;
-  c.cp = smem;
-  c.mass = c.cp + B * O;
-  c.row_c = c.mass + B * O;
-  c.col_c = c.row_c + B;
-  c.row_m = c.col_c + O;
-  c.col_m = c.row_m + B;
-  c.red = c.col_m + O;
-  c.gl = c.red + 32;  // [2][B][ncls] classifier logit grads (backward only)
-  return c;
-}
-
-// stages caps_presence and / or the capsule mass with their row / column sums
-__device__ void load_stats(const TailArgs &a, const Carve &c, bool want_cp, bool want_mass,
-                           bool sums = true) {
-  const int B = a.B, O = a.O, M = a.M;
-  for (int i = threadIdx.x; i < B * O; i += NT) {
-    const int b = i / O, o = i - b * O;
-    if (want_cp) c.cp[i] = a.cp[i];
-    if (!want_mass) continue;
+__global__ __launch_bounds__(NTI) void tail_image_kernel(TailArgs a, Ws ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int B = a.B, O = a.O, M = a.M, b = blockIdx.x, lane = threadIdx.x;
+  (void)B;
+  float *s_cp = smem, *s_mass = smem + O, *s_raw = smem + 2 * O;
+  float rc = 0.f, rm = 0.f;
+  for (int o = lane; o < O; o += NTI) {
+    const float xc = a.cp[(size_t)b * O + o];
     const float *pr = a.posterior + ((size_t)b * (O + 1) + o) * M;
     float t = 0.f;
     if ((M & 3) == 0) {
@@ -223,94 +118,139 @@ __device__ void load_stats(const TailArgs &a, const Carve &c, bool want_cp, bool
     } else {
       for (int m = 0; m < M; ++m) t += pr[m];
     }
-    c.mass[i] = t / M;  // mass_explained_by_capsule / n_points (:260-266)
+    s_cp[o] = xc;
+    s_raw[o] = t;       // classifier input (:210-212)
+    s_mass[o] = t / M;  // mass_explained_by_capsule / n_points (:260-266)
+    ws.mass[(size_t)b * O + o] = t;
+    rc += xc;
+    rm += t / M;
   }
+  rc = scae::wave_sum(rc);
+  rm = scae::wave_sum(rm);
+  float lp = 0.f;
+  for (int m = lane; m < M; m += NTI) lp += a.lpp[(size_t)b * M + m];
+  lp = scae::wave_sum(lp);
   __syncthreads();
-  if (!sums) return;
-  if (want_cp) row_col_sums(Stats{c.cp, c.row_c, c.col_c}, B, O);
-  if (want_mass) row_col_sums(Stats{c.mass, c.row_m, c.col_m}, B, O);
-}
-
-// out: [0] tail loss  [1] log_prob  [2] prior_within [3] prior_between
-//      [4] post_within [5] post_between [6] prior_cls_xe [7] posterior_cls_xe
-// The terms are independent until the final weighted sum, so they run as three
-// workgroups (blockIdx.x = role) on three CUs; tail_combine_kernel then forms
-// the scalar.  role 0: capsule log-likelihood, reconstruction term, regulariser;
-// role 1: prior sparsity + prior classification; role 2: the posterior pair.
-__global__ __launch_bounds__(NT) void tail_fwd_kernel(TailArgs a, scae_loss_extras x, float *out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int B = a.B, O = a.O, role = blockIdx.x;
-  const Carve c = carve(smem, B, O, a.ncls);
-  if (role == 0) {
-    float lp = 0.f;
-    for (int i = threadIdx.x; i < B * a.M; i += NT) lp += a.lpp[i];
-    const float log_prob = block_total(lp, c.red) / B;
-    // reconstruction term (stacked_capsule_auto_encoder.py:222-224) from K1's tile
-    // sums, and the dynamic-regularisation scalar
-    float rec = 0.f;
-    if (x.rec_sums) {
-      float t = 0.f;
-      for (int i = threadIdx.x; i < x.n_rec; i += NT) t += x.rec_sums[i];
-      rec = block_total(t, c.red) / B;
-    }
-    if (threadIdx.x == 0) {
-      out[1] = log_prob;
-      out[8] = rec;
-      out[9] = -rec;
-      out[10] = -log_prob;
-      out[11] = x.reg ? x.reg[0] : 0.f;
-    }
-    return;
-  }
-  const bool prior = role == 1;
-  load_stats(a, c, prior, !prior);
-  float within = 0.f, between = 0.f;
+  float wc = 0.f, wm = 0.f;
   if (a.sparsity_on) {
-    if (prior)
-      sparsity_fwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
-                   a.l2_between_const, c.red, within, between);
-    else
-      sparsity_fwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type, a.l2_within_const_post,
-                   a.l2_between_const_post, c.red, within, between);
+    wc = within_term(s_cp, rc, O, a.prior_type, a.l2_within_const, lane);
+    wm = within_term(s_mass, rm, O, a.post_type, a.l2_within_const_post, lane);
   }
-  float xe = 0.f;
+  float xe_c = 0.f, xe_m = 0.f;
   if (a.label) {
-    // posterior classifier input: the un-normalised capsule mass (:210-212)
-    if (!prior) {
-      for (int i = threadIdx.x; i < B * O; i += NT) c.cp[i] = c.mass[i] * a.M;
-      __syncthreads();
+    const int label = (int)a.label[b];
+    float g0, g1;
+    xe_c = cls_xe(a, s_cp, label, lane, g0);
+    xe_m = cls_xe(a, s_raw, label, lane, g1);
+    if (lane < a.ncls) {
+      ws.gl[((size_t)b * 2 + 0) * a.ncls + lane] = g0;
+      ws.gl[((size_t)b * 2 + 1) * a.ncls + lane] = g1;
     }
-    float t = 0.f;
-    float gl[MAXCLS];
-    for (int b = threadIdx.x; b < B; b += NT) t += cls_xe(a, c.cp + b * O, (int)a.label[b], gl);
-    xe = block_total(t, c.red) / B;
   }
-  if (threadIdx.x == 0) {
-    out[prior ? 2 : 4] = within;
-    out[prior ? 3 : 5] = between;
-    out[prior ? 6 : 7] = xe;
+  if (lane == 0) {
+    float *p = ws.part + (size_t)b * 8;
+    p[0] = lp, p[1] = wc, p[2] = wm, p[3] = xe_c, p[4] = xe_m, p[5] = rc, p[6] = rm, p[7] = 0.f;
   }
 }
 
-__global__ void tail_combine_kernel(TailArgs a, scae_loss_extras x, float *out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const float loss = -a.w_ll * out[1] + a.w_pw * out[2] + a.w_pb * out[3] + a.w_qw * out[4] +
-                     a.w_qb * out[5] + out[6] + out[7] - out[8] + x.w_reg * out[11];
+// between-example term from the column sums in LDS (first wave; result in all lanes)
+__device__ __forceinline__ float between_term(const float *col, int O, int type, float cb,
+                                              int lane) {
+  float t = 0.f;
+  if (type == 0) {
+    for (int o = lane; o < O; o += 64) t += (col[o] - cb) * (col[o] - cb);
+    return scae::wave_sum(t) / O;
+  }
+  const float k = type == 2 ? (float)O : 1.f;
+  float tot = 0.f;
+  for (int o = 0; o < O; ++o) tot += col[o];
+  for (int o = lane; o < O; o += 64) t += ent_term(col[o] / (tot + 1e-8f), k);
+  return -scae::wave_sum(t);
+}
+
+// out: [0] loss  [1] log_prob  [2] prior_within [3] prior_between [4] post_within
+//      [5] post_between [6] prior_cls_xe [7] posterior_cls_xe [8] rec_ll [9] -rec_ll
+//      [10] -log_prob [11] reg
+__global__ __launch_bounds__(NT) void tail_combine_kernel(TailArgs a, scae_loss_extras x, Ws ws,
+                                                          float *out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int B = a.B, O = a.O, tid = threadIdx.x;
+  float *col = smem, *red = smem + 2 * O;  // red: 6 * (NT/64) floats
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = tid; b < B; b += NT) {
+    const float *p = ws.part + (size_t)b * 8;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] += p[i];
+  }
+  if (x.rec_sums)
+    for (int i = tid; i < x.n_rec; i += NT) v[5] += x.rec_sums[i];
+  // column sums over the batch: 16 lanes per column, each takes every 16th image
+  for (int e = tid; e < ((2 * O * 16 + NT - 1) / NT) * NT; e += NT) {
+    const int c = e >> 4, l = e & 15, which = c / O, o = c - which * O;
+    float t = 0.f;
+    if (c < 2 * O) {
+      if (which == 0)
+        for (int b = l; b < B; b += 16) t += a.cp[(size_t)b * O + o];
+      else
+        for (int b = l; b < B; b += 16) t += ws.mass[(size_t)b * O + o] / a.M;
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (c < 2 * O && l == 0) col[c] = ws.col[c] = t;
+  }
+  scae::block_sum<6, NT>(v, red);  // (contains the barriers that publish col[])
+  if (tid >= 64) return;
+  float pb = 0.f, qb = 0.f;
+  if (a.sparsity_on) {
+    pb = between_term(col, O, a.prior_type, a.l2_between_const, tid);
+    qb = between_term(col + O, O, a.post_type, a.l2_between_const_post, tid);
+  }
+  if (tid != 0) return;
+  const float log_prob = v[0] / B, pw = v[1] / B, qw = v[2] / B, xe1 = v[3] / B, xe2 = v[4] / B;
+  const float rec = x.rec_sums ? v[5] / B : 0.f, reg = x.reg ? x.reg[0] : 0.f;
+  out[1] = log_prob, out[2] = pw, out[3] = pb, out[4] = qw, out[5] = qb;
+  out[6] = xe1, out[7] = xe2, out[8] = rec, out[9] = -rec, out[10] = -log_prob, out[11] = reg;
+  const float loss = -a.w_ll * log_prob + a.w_pw * pw + a.w_pb * pb + a.w_qw * qw +
+                     a.w_qb * qb + xe1 + xe2 - rec + x.w_reg * reg;
   out[0] = loss;
   if (x.loss) x.loss[0] = loss;
 }
 
-// Backward: four independent workgroups (blockIdx.x = role), disjoint outputs.
-// role 0: g_lpp, g_rec_sums, g_reg; role 1: prior sparsity -> g_caps_presence;
-// role 2: posterior sparsity -> g_posterior; role 3: both classification terms
-// -> g_cls_w, g_cls_b.
-__global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extras x,
+// d(gw * within + gb * between) / d x[b,o] for one image: x[o], col[o] in LDS
+__device__ __forceinline__ void sparsity_grad(const float *x, const float *col, float r, int B,
+                                              int O, int type, float cw, float cb, float gw,
+                                              float gb, float *g, int lane) {
+  if (type == 0) {
+    for (int o = lane; o < O; o += 64)
+      g[o] = gw * 2.f * (r - cw) / B + gb * 2.f * (col[o] - cb) / O;
+    return;
+  }
+  const float k = type == 2 ? (float)O : 1.f;
+  float tot = 0.f;
+  for (int o = 0; o < O; ++o) tot += col[o];
+  const float tinv = 1.f / (tot + 1e-8f), rinv = 1.f / (r + 1e-8f);
+  float dot_b = 0.f, dot_w = 0.f;
+  for (int o = lane; o < O; o += 64) {
+    dot_b += ent_term_grad(col[o] * tinv, k) * col[o] * tinv;
+    dot_w += ent_term_grad(x[o] * rinv, k) * x[o] * rinv;
+  }
+  dot_b = scae::wave_sum(dot_b);
+  dot_w = scae::wave_sum(dot_w);
+  for (int o = lane; o < O; o += 64) {
+    const float dw = (ent_term_grad(x[o] * rinv, k) - dot_w) * rinv / B;
+    const float db = -(ent_term_grad(col[o] * tinv, k) - dot_b) * tinv;
+    g[o] = gw * dw + gb * db;
+  }
+}
+
+// blockIdx.x < B: the gradient rows of image b.  blockIdx.x >= B: 64 outputs each
+// of the classifier-parameter gradients (4 lanes per output, interleaved over b).
+__global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extras x, Ws ws,
                                                       const float *gout /*[12]*/, float *g_lpp,
                                                       float *g_post, float *g_cp, float *g_w,
                                                       float *g_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int B = a.B, O = a.O, M = a.M, role = blockIdx.x;
-  const Carve c = carve(smem, B, O, a.ncls);
+  const int B = a.B, O = a.O, M = a.M, tid = threadIdx.x;
   // d(total)/d(component): the loss plus whatever flowed into the individually
   // exposed log entries; d/d(loss) may arrive on the 12-vector, on the separate
   // scalar, or both
@@ -319,84 +259,22 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
   for (int i = 0; i < 12; ++i) go[i] = gout ? gout[i] : 0.f;
   if (x.g_loss) go[0] += x.g_loss[0];
   const float g0 = go[0];
-  if (role == 0) {
-    const float g_lp = -a.w_ll * g0 + go[1] - go[10];
-    if (x.g_rec_sums) {
-      const float gr = (-g0 + go[8] - go[9]) / B;
-      for (int i = threadIdx.x; i < x.n_rec; i += NT) x.g_rec_sums[i] = gr;
-    }
-    if (x.g_reg && threadIdx.x == 0) x.g_reg[0] = x.w_reg * g0 + go[11];
-    for (int i = threadIdx.x; i < B * M; i += NT) g_lpp[i] = g_lp / B;
-    return;
-  }
-  // reuse LDS: a gradient accumulator over (B,O) and a per-row scratch
-  float *gacc = c.gl + 2 * B * MAXCLS;  // [B*O]
-  float *tmp = gacc + 2 * B * O;        // [B]
-  if (role == 1 || role == 2) {
-    const bool prior = role == 1;
-    load_stats(a, c, prior, !prior);
-    for (int i = threadIdx.x; i < B * O; i += NT) gacc[i] = 0.f;
-    __syncthreads();
-    if (a.sparsity_on) {
-      if (prior)
-        sparsity_bwd(Stats{c.cp, c.row_c, c.col_c}, B, O, a.prior_type, a.l2_within_const,
-                     a.l2_between_const, a.w_pw * g0 + go[2], a.w_pb * g0 + go[3], gacc, tmp);
-      else
-        sparsity_bwd(Stats{c.mass, c.row_m, c.col_m}, B, O, a.post_type,
-                     a.l2_within_const_post, a.l2_between_const_post, a.w_qw * g0 + go[4],
-                     a.w_qb * g0 + go[5], gacc, tmp);
-    }
-    __syncthreads();
-    if (prior) {
-      for (int i = threadIdx.x; i < B * O; i += NT) g_cp[i] = gacc[i];
-    } else {
-      // posterior (B,O+1,M): mass/M = sum_m post / M, i.e. one value per (b, o) row
-      // of M entries; the dummy row gets zero.  One row per thread: no per-element
-      // index divisions, 16-byte stores when M allows
-      for (int bo = threadIdx.x; bo < B * (O + 1); bo += NT) {
-        const int b = bo / (O + 1), o = bo - b * (O + 1);
-        const float v = o < O ? gacc[b * O + o] / M : 0.f;
-        float *row = g_post + (size_t)bo * M;
-        if ((M & 3) == 0) {
-          const float4 v4 = make_float4(v, v, v, v);
-          for (int m = 0; m < M / 4; ++m) reinterpret_cast<float4 *>(row)[m] = v4;
-        } else {
-          for (int m = 0; m < M; ++m) row[m] = v;
-        }
-      }
-    }
-    return;
-  }
-  // role 3: classifier parameter gradients (inputs are detached)
-  if (!(a.label && g_w)) return;
-  const float g_x1 = g0 + go[6], g_x2 = g0 + go[7];
-  load_stats(a, c, true, true, false);
-  float gl[MAXCLS];
-  for (int i = threadIdx.x; i < B * O; i += NT) gacc[i] = c.mass[i] * M;  // second input
-  __syncthreads();
-  for (int e = threadIdx.x; e < 2 * B; e += NT) {
-    const int which = e / B, b = e - which * B;
-    cls_xe(a, (which ? gacc : c.cp) + b * O, (int)a.label[b], gl);
-    const float gx = which ? g_x2 : g_x1;
-#pragma unroll
-    for (int cc = 0; cc < MAXCLS; ++cc)
-      if (cc < a.ncls) c.gl[e * MAXCLS + cc] = gl[cc] * gx / B;
-  }
-  __syncthreads();
-  // g_w[cc][o] = sum_b glogit * input, g_b[cc] = sum_b glogit: few outputs with a
-  // 2B-long sum each -> four lanes per output, interleaved over b, meet by shuffle
-  const int nout = a.ncls * O + a.ncls;
-  for (int e = threadIdx.x; e < ((nout * 4 + NT - 1) / NT) * NT; e += NT) {
-    const int out = e >> 2, part = e & 3;
+  if ((int)blockIdx.x >= B) {  // classifier parameters (their inputs are detached)
+    if (!(a.label && g_w)) return;
+    const float g_x1 = (g0 + go[6]) / B, g_x2 = (g0 + go[7]) / B;
+    const int nout = a.ncls * O + a.ncls;
+    const int out = ((int)blockIdx.x - B) * (NT / 4) + (tid >> 2), part = tid & 3;
     float t = 0.f;
     if (out < a.ncls * O) {
       const int cc = out / O, o = out - cc * O;
       for (int b = part; b < B; b += 4)
-        t += c.gl[b * MAXCLS + cc] * c.cp[b * O + o] +
-             c.gl[(B + b) * MAXCLS + cc] * gacc[b * O + o];
+        t += ws.gl[((size_t)b * 2) * a.ncls + cc] * g_x1 * a.cp[(size_t)b * O + o] +
+             ws.gl[((size_t)b * 2 + 1) * a.ncls + cc] * g_x2 * ws.mass[(size_t)b * O + o];
     } else if (out < nout) {
       const int cc = out - a.ncls * O;
-      for (int b = part; b < B; b += 4) t += c.gl[b * MAXCLS + cc] + c.gl[(B + b) * MAXCLS + cc];
+      for (int b = part; b < B; b += 4)
+        t += ws.gl[((size_t)b * 2) * a.ncls + cc] * g_x1 +
+             ws.gl[((size_t)b * 2 + 1) * a.ncls + cc] * g_x2;
     }
     t += __shfl_xor(t, 1, 64);
     t += __shfl_xor(t, 2, 64);
@@ -406,18 +284,61 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
       else
         g_b[out - a.ncls * O] = t;
     }
+    return;
   }
-}
-
-size_t tail_lds(int B, int O, bool bwd) {
-  size_t f = 2 * (size_t)B * O + 2 * B + 2 * O + 32;
-  if (bwd) f += 2 * (size_t)B * MAXCLS + 2 * (size_t)B * O + B;
-  return f * sizeof(float);
+  const int b = blockIdx.x;
+  const float g_lp = (-a.w_ll * g0 + go[1] - go[10]) / B;
+  for (int m = tid; m < M; m += NT) g_lpp[(size_t)b * M + m] = g_lp;
+  if (x.g_rec_sums) {  // image b fills its share
+    const float gr = (-g0 + go[8] - go[9]) / B;
+    const int per = (x.n_rec + B - 1) / B, i1 = min(x.n_rec, (b + 1) * per);
+    for (int i = b * per + tid; i < i1; i += NT) x.g_rec_sums[i] = gr;
+  }
+  if (x.g_reg && b == 0 && tid == 0) x.g_reg[0] = x.w_reg * g0 + go[11];
+  float *s_cp = smem, *s_mass = s_cp + O, *col = s_mass + O, *gc = col + 2 * O, *gm = gc + O;
+  for (int o = tid; o < O; o += NT) {
+    s_cp[o] = a.cp[(size_t)b * O + o];
+    s_mass[o] = ws.mass[(size_t)b * O + o] / M;
+    col[o] = ws.col[o];
+    col[O + o] = ws.col[O + o];
+    gc[o] = gm[o] = 0.f;
+  }
+  __syncthreads();
+  if (a.sparsity_on && tid < 64) {
+    const float *p = ws.part + (size_t)b * 8;
+    sparsity_grad(s_cp, col, p[5], B, O, a.prior_type, a.l2_within_const, a.l2_between_const,
+                  a.w_pw * g0 + go[2], a.w_pb * g0 + go[3], gc, tid);
+    sparsity_grad(s_mass, col + O, p[6], B, O, a.post_type, a.l2_within_const_post,
+                  a.l2_between_const_post, a.w_qw * g0 + go[4], a.w_qb * g0 + go[5], gm, tid);
+  }
+  __syncthreads();
+  for (int o = tid; o < O; o += NT) g_cp[(size_t)b * O + o] = gc[o];
+  // posterior (O+1, M) rows of image b: mass / M = sum_m post / M, one value per
+  // (b, o) row; the dummy row gets zero
+  float *gp = g_post + (size_t)b * (O + 1) * M;
+  if ((M & 3) == 0) {
+    const int M4 = M / 4;
+    for (int e = tid; e < (O + 1) * M4; e += NT) {
+      const int o = e / M4;
+      const float v = o < O ? gm[o] / M : 0.f;
+      reinterpret_cast<float4 *>(gp)[e] = make_float4(v, v, v, v);
+    }
+  } else {
+    for (int e = tid; e < (O + 1) * M; e += NT) {
+      const int o = e / M;
+      gp[e] = o < O ? gm[o] / M : 0.f;
+    }
+  }
 }
 }  // namespace
 
 extern "C" int scae_loss_tail_supported(int B, int O, int ncls) {
-  return (B > 0 && O > 0 && ncls <= MAXCLS && tail_lds(B, O, true) <= 150 * 1024) ? 1 : 0;
+  return (B > 0 && O > 0 && O <= 4096 && ncls <= MAXCLS) ? 1 : 0;
+}
+
+extern "C" int64_t scae_loss_tail_workspace_floats(int B, int O, int ncls) {
+  if (B <= 0 || O <= 0 || ncls < 0) return 0;
+  return (int64_t)ws_floats(B, O, ncls);
 }
 
 static int fill_tail(TailArgs &a, const float *lpp, const float *posterior, const float *cp,
@@ -445,26 +366,24 @@ static int fill_tail(TailArgs &a, const float *lpp, const float *posterior, cons
 extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                                       const float *caps_presence, const float *cls_w,
                                       const float *cls_b, const int64_t *label,
-                                      const scae_loss_extras *extras, float *out12, int B,
-                                      int O, int M, int ncls, int n_classes_cfg, int prior_type,
-                                      int post_type, int sparsity_on, const float *weights5,
+                                      const scae_loss_extras *extras, float *out12,
+                                      float *workspace, int B, int O, int M, int ncls,
+                                      int n_classes_cfg, int prior_type, int post_type,
+                                      int sparsity_on, const float *weights5,
                                       float within_const, void *stream) {
   TailArgs a;
   int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
                      n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
   if (rc) return rc;
-  SCAE_REQUIRE(out12);
+  SCAE_REQUIRE(out12 && workspace);
   scae_loss_extras x{};
   if (extras) x = *extras;
   if (x.rec_sums && x.n_rec <= 0) return SCAE_ERR_BAD_ARG;
-  const size_t lds = tail_lds(B, O, false);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipLaunchKernelGGL(tail_fwd_kernel, dim3(3), dim3(NT), lds, (hipStream_t)stream, a, x, out12);
-  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, x, out12);
+  const Ws ws = carve_ws(workspace, B, O, ncls);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tail_image_kernel, dim3(B), dim3(NTI), 3 * O * sizeof(float), st, a, ws);
+  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NT),
+                     (2 * O + 6 * (NT / 64)) * sizeof(float), st, a, x, ws, out12);
   return scae_launch_status();
 }
 
@@ -472,7 +391,7 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
                                       const float *caps_presence, const float *cls_w,
                                       const float *cls_b, const int64_t *label,
                                       const scae_loss_extras *extras, const float *gout12,
-                                      float *g_lpp, float *g_posterior,
+                                      const float *workspace, float *g_lpp, float *g_posterior,
                                       float *g_caps_presence, float *g_cls_w, float *g_cls_b,
                                       int B, int O, int M, int ncls, int n_classes_cfg,
                                       int prior_type, int post_type, int sparsity_on,
@@ -481,20 +400,17 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
   int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
                      n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
   if (rc) return rc;
-  SCAE_REQUIRE(g_lpp && g_posterior && g_caps_presence);
+  SCAE_REQUIRE(g_lpp && g_posterior && g_caps_presence && workspace);
   if (!gout12 && !(extras && extras->g_loss)) return SCAE_ERR_BAD_ARG;
   scae_loss_extras x{};
   if (extras) x = *extras;
   if (x.rec_sums && (x.n_rec <= 0 || !x.g_rec_sums)) return SCAE_ERR_BAD_ARG;
   if (x.reg && !x.g_reg) return SCAE_ERR_BAD_ARG;
   if (label) SCAE_REQUIRE(g_cls_w && g_cls_b);
-  const size_t lds = tail_lds(B, O, true);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3(4), dim3(NT), lds, (hipStream_t)stream, a, x, gout12,
-                     g_lpp, g_posterior, g_caps_presence, g_cls_w, g_cls_b);
+  const Ws ws = carve_ws(const_cast<float *>(workspace), B, O, ncls);
+  const int cls_blocks = label ? (ncls * O + ncls + NT / 4 - 1) / (NT / 4) : 0;
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(B + cls_blocks), dim3(NT), 6 * O * sizeof(float),
+                     (hipStream_t)stream, a, x, ws, gout12, g_lpp, g_posterior,
+                     g_caps_presence, g_cls_w, g_cls_b);
   return scae_launch_status();
 }

@@ -1353,10 +1353,13 @@ class _LossTail(torch.autograd.Function):
             ex.reg, ex.w_reg = reg.data_ptr(), float(w_reg)
         loss = torch.empty((), device=lpp.device, dtype=lpp.dtype)
         ex.loss = loss.data_ptr()
+        # per-image / per-column statistics the backward kernel reads back
+        ws = torch.empty(_lib.load().scae_loss_tail_workspace_floats(
+            ints[0], ints[1], ints[3]), device=lpp.device, dtype=lpp.dtype)
         _lib.call("scae_loss_tail_fwd_f32", _p(lpp), _p(posterior),
                   _p(caps_presence), _p(cls_w), _p(cls_b), lab, ctypes.byref(ex),
-                  _p(out), *ints, w5, wc, _stream(lpp))
-        ctx.save_for_backward(lpp, posterior, caps_presence,
+                  _p(out), _p(ws), *ints, w5, wc, _stream(lpp))
+        ctx.save_for_backward(lpp, posterior, caps_presence, ws,
                               *([cls_w, cls_b, label] if label is not None
                                 else []),
                               *([rec_sums] if rec_sums is not None else []),
@@ -1369,8 +1372,8 @@ class _LossTail(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, gout):
         saved = list(ctx.saved_tensors)
-        lpp, posterior, cp = saved[:3]
-        rest = saved[3:]
+        lpp, posterior, cp, ws = saved[:4]
+        rest = saved[4:]
         has_label, has_rec, has_reg = ctx.has
         cls_w = cls_b = label = rec_sums = reg = None
         if has_label:
@@ -1401,7 +1404,7 @@ class _LossTail(torch.autograd.Function):
         lab = None if label is None else ctypes.c_void_p(label.data_ptr())
         _lib.call("scae_loss_tail_bwd_f32", _p(lpp), _p(posterior), _p(cp),
                   _p(cls_w), _p(cls_b), lab, ctypes.byref(ex),
-                  _p(_c(gout)), _p(g_lpp), _p(g_post), _p(g_cp),
+                  _p(_c(gout)), _p(ws), _p(g_lpp), _p(g_post), _p(g_cp),
                   _p(g_w), _p(g_b), *ints, w5, wc, _stream(lpp))
         return g_lpp, g_post, g_cp, g_w, g_b, None, g_rec, g_reg, None
 
