@@ -380,6 +380,16 @@ typedef struct scae_sum_segment {
 } scae_sum_segment;
 int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
                       const scae_sum_segment *segments, int n_segments, void *stream);
+/* Up to 4 such column-sum jobs (different matrices) in ONE launch: a backward
+ * pass usually leaves two or three partial matrices behind at the same time.
+ * `jobs` and the segment arrays it points to are HOST memory. */
+typedef struct scae_sum_job {
+  const float *src;
+  int64_t rows, cols;
+  const scae_sum_segment *segments;
+  int n_segments;
+} scae_sum_job;
+int scae_sum_rows_multi_f32(const scae_sum_job *jobs, int n_jobs, void *stream);
 
 /* Up to 8 scaled full sums in ONE launch: dst[i][0] = scale[i] * sum(src[i][0..n[i]))
  * (one workgroup each, fixed order).  The scalar outputs of the forward pass:

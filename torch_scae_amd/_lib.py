@@ -44,6 +44,12 @@ class SumSegment(Structure):
                 ("period", c_int64)]
 
 
+class SumJob(Structure):
+    """struct scae_sum_job"""
+    _fields_ = [("src", P), ("rows", c_int64), ("cols", c_int64),
+                ("segments", POINTER(SumSegment)), ("n_segments", c_int)]
+
+
 class ScaledSum(Structure):
     """struct scae_scaled_sum"""
     _fields_ = [("src", P), ("n", c_int64), ("scale", c_float), ("dst", P)]
@@ -125,6 +131,7 @@ SIGNATURES = {
     "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],
     "scae_template_color_bwd_f32": [P] * 12 + [c_int] * 8 + [P],
     "scae_sum_rows_f32": [P, c_int64, c_int64, POINTER(SumSegment), c_int, P],
+    "scae_sum_rows_multi_f32": [POINTER(SumJob), c_int, P],
     "scae_scaled_sums_f32": [POINTER(ScaledSum), c_int, P],
     "scae_class_probs_supported": [c_int] * 2,
     "scae_class_probs_f32": [P] * 6 + [c_int] * 4 + [P],

@@ -7,19 +7,31 @@
 
 namespace {
 constexpr int NT = 256;
-struct Segs {
+constexpr int MAXJOBS = 4;
+struct Job {
+  const float *src;
+  long rows, cols;
+  int py;           // row parts per column (1 | 4 | 16 | 64); NT / py columns per workgroup
+  int first_block;  // first workgroup of this job
+  int n;
   scae_sum_segment s[8];
+};
+struct Jobs {
+  Job j[MAXJOBS];
   int n;
 };
 
-// workgroup = (256 / PY columns) x PY row-parts; parts meet in LDS
-template <int PY>
-__global__ __launch_bounds__(NT) void sum_rows_kernel(const float *__restrict__ src, long rows,
-                                                      long cols, Segs segs) {
-  constexpr int CX = NT / PY;
-  __shared__ float red[PY][CX];
+// workgroup = (256 / py columns) x py row-parts; parts meet in LDS
+__global__ __launch_bounds__(NT) void sum_rows_kernel(Jobs jobs) {
+  __shared__ float red[NT];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].first_block) ++ji;
+  const Job &job = jobs.j[ji];
+  const float *__restrict__ src = job.src;
+  const long rows = job.rows, cols = job.cols;
+  const int PY = job.py, CX = NT / PY;
   const int cx = threadIdx.x % CX, py = threadIdx.x / CX;
-  const long j = (long)blockIdx.x * CX + cx;
+  const long j = (long)((int)blockIdx.x - job.first_block) * CX + cx;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < cols) {
     const long per = (rows + PY - 1) / PY, r0 = py * per, r1 = min(rows, r0 + per);
@@ -32,14 +44,13 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(const float *__restrict__ 
     }
     for (; r < r1; ++r) s0 += src[r * cols + j];
   }
-  red[py][cx] = (s0 + s1) + (s2 + s3);
+  red[py * CX + cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (py != 0 || j >= cols) return;
   float tot = 0.f;
-#pragma unroll
-  for (int p = 0; p < PY; ++p) tot += red[p][cx];
-  for (int i = 0; i < segs.n; ++i) {
-    const scae_sum_segment &g = segs.s[i];
+  for (int p = 0; p < PY; ++p) tot += red[p * CX + cx];
+  for (int i = 0; i < job.n; ++i) {
+    const scae_sum_segment &g = job.s[i];
     if (g.period > 0) {  // the same column window of every period-wide block
       const long blk = j / g.period, c = j - blk * g.period;
       if (c >= g.begin && c < g.end) g.dst[blk * (g.end - g.begin) + c - g.begin] = tot;
@@ -77,29 +88,39 @@ extern "C" int scae_scaled_sums_f32(const scae_scaled_sum *jobs, int n_jobs, voi
   return scae_launch_status();
 }
 
+extern "C" int scae_sum_rows_multi_f32(const scae_sum_job *jobs, int n_jobs, void *stream) {
+  SCAE_REQUIRE(jobs && n_jobs > 0 && n_jobs <= MAXJOBS);
+  Jobs js;
+  js.n = n_jobs;
+  int blocks = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    const scae_sum_job &in = jobs[k];
+    SCAE_REQUIRE(in.src && in.segments && in.rows > 0 && in.cols > 0 && in.n_segments > 0 &&
+                 in.n_segments <= 8);
+    Job &job = js.j[k];
+    job.src = in.src, job.rows = (long)in.rows, job.cols = (long)in.cols, job.n = in.n_segments;
+    for (int i = 0; i < in.n_segments; ++i) {
+      job.s[i] = in.segments[i];
+      const scae_sum_segment &g = job.s[i];
+      SCAE_REQUIRE(g.dst && g.begin >= 0 && g.begin < g.end &&
+                   g.end <= (g.period > 0 ? g.period : in.cols));
+      SCAE_REQUIRE(g.period >= 0 || (g.end - g.begin) % -g.period == 0);
+    }
+    // few rows: a thread per column; tall and skinny: many row parts per column
+    job.py = in.rows <= 16 ? 1
+             : (in.cols <= 8 && in.rows > 256) ? 64
+             : (in.rows <= 128 || in.cols >= 16384) ? 4 : 16;
+    const int cx = NT / job.py;
+    job.first_block = blocks;
+    blocks += (int)((in.cols + cx - 1) / cx);
+  }
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, js);
+  return scae_launch_status();
+}
+
 extern "C" int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
                                  const scae_sum_segment *segments, int n_segments,
                                  void *stream) {
-  SCAE_REQUIRE(src && segments && rows > 0 && cols > 0 && n_segments > 0 && n_segments <= 8);
-  Segs segs;
-  segs.n = n_segments;
-  for (int i = 0; i < n_segments; ++i) {
-    segs.s[i] = segments[i];
-    SCAE_REQUIRE(segs.s[i].dst && segs.s[i].begin >= 0 && segs.s[i].begin < segs.s[i].end &&
-                 segs.s[i].end <= (segs.s[i].period > 0 ? segs.s[i].period : cols));
-    SCAE_REQUIRE(segs.s[i].period >= 0 ||
-                 (segs.s[i].end - segs.s[i].begin) % -segs.s[i].period == 0);
-  }
-  hipStream_t st = (hipStream_t)stream;
-  if (rows <= 16) {
-    hipLaunchKernelGGL(sum_rows_kernel<1>, dim3((unsigned)((cols + 255) / 256)), dim3(NT), 0, st,
-                       src, (long)rows, (long)cols, segs);
-  } else if (rows <= 128 || cols >= 16384) {
-    hipLaunchKernelGGL(sum_rows_kernel<4>, dim3((unsigned)((cols + 63) / 64)), dim3(NT), 0, st,
-                       src, (long)rows, (long)cols, segs);
-  } else {
-    hipLaunchKernelGGL(sum_rows_kernel<16>, dim3((unsigned)((cols + 15) / 16)), dim3(NT), 0, st,
-                       src, (long)rows, (long)cols, segs);
-  }
-  return scae_launch_status();
+  const scae_sum_job job{src, rows, cols, segments, n_segments};
+  return scae_sum_rows_multi_f32(&job, 1, stream);
 }

@@ -112,27 +112,50 @@ def _sum_rows(partial, shapes, starts=None, period=0, outs=None, transpose=0):
     every block (w_i = numel / number of blocks).  With ``transpose`` = W each
     output's window is an (n x W) matrix that is written transposed (W x n).
     One launch."""
-    rows, cols = partial.shape
-    given, outs, segs = outs, [], (_lib.SumSegment * len(shapes))()
-    nblk = cols // period if period else 1
-    pos = 0
-    for i, shape in enumerate(shapes):
-        o = given[i] if given is not None and given[i] is not None else \
-            torch.empty(shape, device=partial.device, dtype=partial.dtype)
-        if starts is not None:
-            pos = starts[i]
-        width = o.numel() // nblk
-        segs[i].dst, segs[i].begin, segs[i].end = o.data_ptr(), pos, pos + width
-        segs[i].period = -transpose if transpose else period
-        pos += width
-        outs.append(o)
-    for k in range(0, len(shapes), 8):
-        n = min(8, len(shapes) - k)
-        _lib.call("scae_sum_rows_f32", _p(partial), rows, cols,
-                  ctypes.cast(ctypes.byref(segs, k * ctypes.sizeof(
-                      _lib.SumSegment)), ctypes.POINTER(_lib.SumSegment)), n,
-                  _stream(partial))
-    return outs
+    return _sum_rows_multi([dict(partial=partial, shapes=shapes, starts=starts,
+                                 period=period, outs=outs,
+                                 transpose=transpose)])[0]
+
+
+def _sum_rows_multi(jobs):
+    """Several ``_sum_rows`` jobs (dicts of its arguments, different partial
+    matrices) in as few launches as possible (4 jobs of <= 8 outputs each per
+    launch); returns the list of output lists."""
+    units, results = [], []
+    for job in jobs:
+        partial, shapes = job["partial"], job["shapes"]
+        starts, period = job.get("starts"), job.get("period", 0)
+        given, transpose = job.get("outs"), job.get("transpose", 0)
+        rows, cols = partial.shape
+        assert partial.is_contiguous()
+        nblk = cols // period if period else 1
+        outs, segs = [], (_lib.SumSegment * len(shapes))()
+        pos = 0
+        for i, shape in enumerate(shapes):
+            o = given[i] if given is not None and given[i] is not None else \
+                torch.empty(shape, device=partial.device, dtype=partial.dtype)
+            if starts is not None:
+                pos = starts[i]
+            width = o.numel() // nblk
+            segs[i].dst, segs[i].begin, segs[i].end = o.data_ptr(), pos, \
+                pos + width
+            segs[i].period = -transpose if transpose else period
+            pos += width
+            outs.append(o)
+        results.append(outs)
+        for k in range(0, len(shapes), 8):
+            units.append((partial, rows, cols, ctypes.cast(
+                ctypes.byref(segs, k * ctypes.sizeof(_lib.SumSegment)),
+                ctypes.POINTER(_lib.SumSegment)), min(8, len(shapes) - k), segs))
+    for k in range(0, len(units), 4):
+        chunk = units[k:k + 4]
+        arr = (_lib.SumJob * len(chunk))()
+        for a, (partial, rows, cols, segp, n, _keep) in zip(arr, chunk):
+            a.src, a.rows, a.cols, a.segments, a.n_segments = \
+                partial.data_ptr(), rows, cols, segp, n
+        _lib.call("scae_sum_rows_multi_f32", arr, len(chunk),
+                  _stream(chunk[0][0]))
+    return results
 
 
 # ----------------------------------------------------------------------------
@@ -383,9 +406,13 @@ class _SeedAttention(torch.autograd.Function):
                   _p(wv), _p(bv), _p(presence), _p(gout.contiguous()), _p(gh),
                   _p(partial), B, N, O, D, C, _stream(h))
         # one h-gradient slab per query group
-        gh = gh[0] if S == 1 else _sum_rows(gh.view(S, -1), [(B, N, D)])[0]
-        gq, gwk, gbk, gwv, gbv = _sum_rows(
-            partial, [(O, C), (C, D), (C,), (C, D), (C,)])
+        jobs = [dict(partial=partial,
+                     shapes=[(O, C), (C, D), (C,), (C, D), (C,)])]
+        if S > 1:
+            jobs.append(dict(partial=gh.view(S, -1), shapes=[(B, N, D)]))
+        res = _sum_rows_multi(jobs)
+        gq, gwk, gbk, gwv, gbv = res[0]
+        gh = gh[0] if S == 1 else res[1][0]
         return gh, gq, gwk, gbk, gwv, gbv, None
 
 
@@ -625,11 +652,13 @@ def _conv1x1_fwd(x, weight, bias):
     return y
 
 
-def _conv1x1_bwd(x, weight, dy, gate=None, outs=None):
+def _conv1x1_bwd(x, weight, dy, gate=None, outs=None, raw_sum=None):
     """-> (dx, dweight, dbias) of the 1x1 conv given dy (B, HW, AP).  With
     ``gate`` (the ReLU output x was made from, layout of x) -> (dx zeroed
     where gate <= 0, dweight, dbias, ungated dx).  ``outs``: buffers for
-    (dweight, dbias)."""
+    (dweight, dbias).  ``raw_sum`` = (shape, out): also the batch sum of the
+    ungated dx, written transposed ((HW, C) -> (C, HW)) into ``out``, in the
+    same launch as the weight / bias sums."""
     B, HW, C = x.shape
     AP = weight.shape[0]
     # weight / bias gradient: dy^T x split over groups of images (the launch
@@ -650,7 +679,11 @@ def _conv1x1_bwd(x, weight, dy, gate=None, outs=None):
         _gemm_desc(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP,
                    kper * AP, False, C, kper * C, C, slab,
                    asum=_off(part, AP * C), asum_b=slab), dgrad, x)
-    gw, gb = _sum_rows(part, [tuple(weight.shape), (AP,)], outs=outs)
+    jobs = [dict(partial=part, shapes=[tuple(weight.shape), (AP,)], outs=outs)]
+    if raw_sum is not None:
+        jobs.append(dict(partial=raw.view(B, HW * C), shapes=[raw_sum[0]],
+                         transpose=C, outs=[raw_sum[1]]))
+    gw, gb = _sum_rows_multi(jobs)[0]
     return (dx, gw, gb) if gate is None else (dx, gw, gb, raw)
 
 
@@ -819,11 +852,11 @@ class _PartEncoder(torch.autograd.Function):
         act = acts[-1]
         g_attw = _grad_out(ctx.slots[1], x, attw_shape)
         g_attb = _grad_out(ctx.slots[2], x, (att_w2.shape[0],))
-        dpre, _, _, raw = _conv1x1_bwd(x, att_w2, dy, gate=act.view(B, HW, C),
-                                       outs=[g_attw, g_attb])
         # embedding-bias gradient: batch sum of the ungated dx, (HW, C) -> (C, HW)
-        (g_pb,) = _sum_rows(raw.view(B, HW * C), [pb_shape], transpose=C,
-                            outs=[_grad_out(ctx.slots[0], x, pb_shape)])
+        g_pb = _grad_out(ctx.slots[0], x, pb_shape)
+        dpre, _, _, _ = _conv1x1_bwd(x, att_w2, dy, gate=act.view(B, HW, C),
+                                     outs=[g_attw, g_attb],
+                                     raw_sum=(pb_shape, g_pb))
         gws, gbs = _conv_stack_bwd(
             image, acts, wds, strides, wshapes, dpre.view(act.shape),
             lambda i: _grad_out(ctx.slots[3 + i], image, ctx.refs[i]))
@@ -1208,12 +1241,13 @@ class _CapsuleVotes(torch.autograd.Function):
         # capsule's block lands in its row of the (.., O, ..) parameter
         A = all_param.shape[2]
         outs = [_grad_out(sl, t) for sl, t in zip(ctx.slots, args[1:6])]
-        (g_static,) = _sum_rows(gin.view(B, -1), [args[1].shape],
-                                outs=outs[:1])
-        g_cvr, g_caps, g_vote, g_scale = _sum_rows(
-            gall.view(B, O * A), [t.shape for t in args[2:6]],
-            starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=A,
-            outs=outs[1:])
+        (g_static,), (g_cvr, g_caps, g_vote, g_scale) = _sum_rows_multi([
+            dict(partial=gin.view(B, -1), shapes=[args[1].shape],
+                 outs=outs[:1]),
+            dict(partial=gall.view(B, O * A),
+                 shapes=[t.shape for t in args[2:6]],
+                 starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=A,
+                 outs=outs[1:])])
         return (gall if ggated is None else ggated, g_static, g_cvr, g_caps,
                 g_vote, g_scale, None, None, None, None, None, None, None, None)
 
@@ -1491,20 +1525,25 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
                   _p(g_templates), _p(g_alpha_p), _p(g_pose), _p(g_presence),
                   _p(g_bg_image), _p(g_scal), _stream(templates))
     slots = slots or [None] * 9
-    g_alpha = None
+    # batch sums of the alpha partials and of the four scalar parameters'
+    # (B*(M+1), 4) partials: one launch
+    jobs, g_alpha, gs = [], None, [None] * 4
     if alpha is not None:
         ashape = tuple(alpha_shape or alpha.shape)
-        g_alpha = _sum_rows(g_alpha_p.view(B, -1), [ashape],
-                            outs=[_grad_out(slots[1], alpha, ashape)])[0]
-    # the four scalar parameters: column sums of the (B*(M+1), 4) partials
+        jobs.append(dict(partial=g_alpha_p.view(B, -1), shapes=[ashape],
+                         outs=[_grad_out(slots[1], alpha, ashape)]))
     scal = [(i, t) for i, t in enumerate((bg_value, bg_ml, temp, out_scale))
             if t is not None]
-    gs = [None] * 4
     if scal:
-        outs = _sum_rows(g_scal.view(-1, 4), [t.shape for _, t in scal],
+        jobs.append(dict(partial=g_scal.view(-1, 4),
+                         shapes=[t.shape for _, t in scal],
                          starts=[i for i, _ in scal],
-                         outs=[_grad_out(slots[5 + i], t) for i, t in scal])
-        for (i, _), o in zip(scal, outs):
+                         outs=[_grad_out(slots[5 + i], t) for i, t in scal]))
+    res = _sum_rows_multi(jobs) if jobs else []
+    if alpha is not None:
+        g_alpha = res[0][0]
+    if scal:
+        for (i, _), o in zip(scal, res[-1]):
             gs[i] = o
     return (g_templates, g_alpha, g_pose, g_presence, g_bg_image, *gs)
 
