@@ -206,7 +206,7 @@ def time_k8_kernels(cfg, device, reps=50):
         geo = (I(B), I(IH), I(IH), I(Ci), I(Co), I(s))
         calls = {
             "conv_fwd_kernel": lambda: lib.scae_conv3x3_fwd_f32(
-                p(x), p(wf), p(bias), p(y), *geo, st),
+                p(x), p(wf), p(bias), p(y), None, None, *geo, st),
             "conv_dgrad_kernel": lambda: lib.scae_conv3x3_dgrad_f32(
                 p(dy), p(wd), p(x), p(dx), *geo, st),
             "conv_wgrad_kernel": lambda: lib.scae_conv3x3_wgrad_f32(

@@ -334,6 +334,13 @@ int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg, fl
                           int64_t n, float lr, const float *lr_dev, float alpha, float eps,
                           float momentum, float weight_decay, float grad_scale, void *stream);
 
+/* The batch hand-over of a training step (base_experiment.py:109-112): n_image
+ * floats and n_label int64 labels (device memory) into the step's resident
+ * input buffers, in one launch. */
+int scae_stage_batch(float *dst_image, const float *src_image, int64_t n_image,
+                     int64_t *dst_label, const int64_t *src_label, int64_t n_label,
+                     void *stream);
+
 /* ------------------------------------------------------------------------
  * K10  coloured templates      replaces TemplateGenerator.forward,
  *      part_decoder.py:78-110 (colorize_templates = True):
@@ -496,11 +503,16 @@ int scae_capsule_likelihood_bwd_f32(
  *     with caps_presence (B,O), posterior (B,O+1,M), w (ncls,O), bias (ncls)
  *     = prior_classifier.0 (the reference routes both through it).
  *     Limits: O <= 64, ncls <= 32.
+ *     extra_sums (HOST array, n_extra <= 8, nullable): scaled full sums (see
+ *     scae_scaled_sums_f32) that ride in the same launch -- this is the last
+ *     kernel of SCAE.forward, and the forward's scalar outputs (log_prob,
+ *     cpr_dynamic_reg_loss) are not read before it.
  * ---------------------------------------------------------------------- */
 int scae_class_probs_supported(int O, int ncls);
 int scae_class_probs_f32(const float *caps_presence, const float *posterior, const float *w,
                          const float *bias, float *prior_prob, float *post_prob, int B, int O,
-                         int M, int ncls, void *stream);
+                         int M, int ncls, const scae_scaled_sum *extra_sums, int n_extra,
+                         void *stream);
 
 /* ------------------------------------------------------------------------
  * K6  fused tail of SCAE.loss        replaces stacked_capsule_auto_encoder.py

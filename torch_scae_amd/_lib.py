@@ -122,6 +122,7 @@ SIGNATURES = {
     "scae_attention_pool_supported": [c_int] * 3,
     "scae_attention_pool_fwd_f32": [P, P] + [c_int] * 4 + [P],
     "scae_attention_pool_bwd_f32": [P, P, P] + [c_int] * 4 + [P],
+    "scae_stage_batch": [P, P, c_int64, P, P, c_int64, P],
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
                               c_float, c_float, c_float, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
@@ -134,7 +135,7 @@ SIGNATURES = {
     "scae_sum_rows_multi_f32": [POINTER(SumJob), c_int, P],
     "scae_scaled_sums_f32": [POINTER(ScaledSum), c_int, P],
     "scae_class_probs_supported": [c_int] * 2,
-    "scae_class_probs_f32": [P] * 6 + [c_int] * 4 + [P],
+    "scae_class_probs_f32": [P] * 6 + [c_int] * 4 + [POINTER(ScaledSum), c_int, P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 8
                                   + [c_int] * 6 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 11

@@ -8,13 +8,25 @@
 
 namespace {
 constexpr int MAXCLS = 32;
+struct ExtraSums {
+  scae_scaled_sum j[8];
+  int n;
+};
 
 __global__ __launch_bounds__(64) void class_probs_kernel(
     const float *__restrict__ cp, const float *__restrict__ posterior,
     const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ prior_prob,
-    float *__restrict__ post_prob, int O, int M, int ncls) {
+    float *__restrict__ post_prob, int B, int O, int M, int ncls, ExtraSums extra) {
   __shared__ float s_x[2][64], s_l[2][MAXCLS];
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= B) {  // riders: scaled full sums (the scalar outputs of the forward pass)
+    const scae_scaled_sum &job = extra.j[b - B];
+    float t = 0.f;
+    for (int64_t i = lane; i < job.n; i += 64) t += job.src[i];
+    t = scae::wave_sum(t);
+    if (lane == 0) job.dst[0] = t * job.scale;
+    return;
+  }
   if (lane < O) {  // lane = capsule: the two classifier inputs
     s_x[0][lane] = cp[(size_t)b * O + lane];
     const float *p = posterior + ((size_t)b * (O + 1) + lane) * M;
@@ -47,11 +59,20 @@ extern "C" int scae_class_probs_supported(int O, int ncls) {
 extern "C" int scae_class_probs_f32(const float *caps_presence, const float *posterior,
                                     const float *w, const float *bias, float *prior_prob,
                                     float *post_prob, int B, int O, int M, int ncls,
+                                    const scae_scaled_sum *extra_sums, int n_extra,
                                     void *stream) {
   SCAE_REQUIRE(caps_presence && posterior && w && bias && prior_prob && post_prob && B > 0 &&
                M > 0);
   if (!scae_class_probs_supported(O, ncls)) return SCAE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(class_probs_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream,
-                     caps_presence, posterior, w, bias, prior_prob, post_prob, O, M, ncls);
+  SCAE_REQUIRE(n_extra >= 0 && n_extra <= 8 && (n_extra == 0 || extra_sums));
+  ExtraSums ex;
+  ex.n = n_extra;
+  for (int i = 0; i < n_extra; ++i) {
+    ex.j[i] = extra_sums[i];
+    SCAE_REQUIRE(ex.j[i].src && ex.j[i].dst && ex.j[i].n > 0);
+  }
+  hipLaunchKernelGGL(class_probs_kernel, dim3(B + n_extra), dim3(64), 0, (hipStream_t)stream,
+                     caps_presence, posterior, w, bias, prior_prob, post_prob, B, O, M, ncls,
+                     ex);
   return scae_launch_status();
 }

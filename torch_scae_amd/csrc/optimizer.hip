@@ -62,7 +62,37 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(OptArgs a, int head) {
     if (a.buf) a.buf[i] = b;
   }
 }
+// The batch hand-over of a training step: image floats and int64 labels into the
+// step's resident input buffers, one launch instead of two device copies.
+__global__ __launch_bounds__(256) void stage_batch_kernel(float *__restrict__ dst_image,
+                                                          const float *__restrict__ src_image,
+                                                          long n_image,
+                                                          int64_t *__restrict__ dst_label,
+                                                          const int64_t *__restrict__ src_label,
+                                                          long n_label) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x,
+             stride = (long)gridDim.x * blockDim.x;
+  const bool vec = (((size_t)dst_image | (size_t)src_image) & 15) == 0;
+  const long n4 = vec ? n_image >> 2 : 0;
+  for (long i = tid; i < n4; i += stride)
+    reinterpret_cast<float4 *>(dst_image)[i] = reinterpret_cast<const float4 *>(src_image)[i];
+  for (long i = 4 * n4 + tid; i < n_image; i += stride) dst_image[i] = src_image[i];
+  for (long i = tid; i < n_label; i += stride) dst_label[i] = src_label[i];
+}
 }  // namespace
+
+extern "C" int scae_stage_batch(float *dst_image, const float *src_image, int64_t n_image,
+                                int64_t *dst_label, const int64_t *src_label, int64_t n_label,
+                                void *stream) {
+  SCAE_REQUIRE(dst_image && src_image && n_image > 0 && n_label >= 0 &&
+               (n_label == 0 || (dst_label && src_label)));
+  long blocks = (n_image / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(stage_batch_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, dst_image, src_image, (long)n_image, dst_label,
+                     src_label, (long)n_label);
+  return scae_launch_status();
+}
 
 extern "C" int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg,
                                      float *buf, int64_t n, float lr, const float *lr_dev,

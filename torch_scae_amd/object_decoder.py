@@ -124,10 +124,11 @@ class CapsuleLikelihood:
         self.vote_presence = vote_presence    # (B, O, M)
         self.dummy_vote = dummy_vote          # (1, 1, M, P)
 
-    def __call__(self, x, presence=None, _extra_sums=()):
+    def __call__(self, x, presence=None, _extra_sums=(), _defer_sums=False):
         """x (B, M, P), presence (B, M).  ``_extra_sums``: further
         (src, scale, dst) scalar sums to ride in this call's one
-        scalar-sum launch."""
+        scalar-sum launch; ``_defer_sums``: do not launch it -- the jobs are
+        returned as ``_pending_sums`` for a later kernel to carry."""
         batch_size, n_input_points, dim_in = x.shape
         if dim_in != 6 or self.vote.shape[-1] != 6:
             raise ValueError("the capsule likelihood kernel is built for "
@@ -138,9 +139,12 @@ class CapsuleLikelihood:
             self.vote, self.scale, self.vote_presence, self.dummy_vote, x,
             presence.float() if presence is not None else None,
             defer_sum=True)
-        ops.scaled_sums([(lpp.detach(), 1.0 / batch_size, log_prob.detach()),
-                         *_extra_sums])
+        sums = [(lpp.detach(), 1.0 / batch_size, log_prob.detach()),
+                *_extra_sums]
+        if not _defer_sums:
+            ops.scaled_sums(sums)
         return AttrDict(
+            **(dict(_pending_sums=sums) if _defer_sums else {}),
             _log_prob_per_point=lpp,           # inputs of the fused loss tail
             _posterior_full=posterior,
             log_prob=log_prob,                 # = lpp.sum() / batch_size
@@ -168,9 +172,11 @@ class CapsuleObjectDecoder(nn.Module):
         return self.capsule_layer.n_caps
 
     def forward(self, obj_encoding: torch.Tensor, part_pose: torch.Tensor,
-                part_presence: torch.Tensor = None):
+                part_presence: torch.Tensor = None, _defer_sums=False):
         """obj_encoding [B, O, D], part_pose [B, M, P], part_presence [B, M]
-        or None -> AttrDict (object_decoder.py:393-428)."""
+        or None -> AttrDict (object_decoder.py:393-428).  ``_defer_sums``
+        (SCAE.forward only): the two scalar outputs are filled by a later
+        launch the caller makes (``res._pending_sums``)."""
         vote, scale, vote_presence, logit_caps, logit_vote, reg, \
             caps_presence, reg_partial = self.capsule_layer._votes(
                 obj_encoding, defer_reg=True)
@@ -185,7 +191,8 @@ class CapsuleObjectDecoder(nn.Module):
                                        dummy_vote=self.dummy_vote)
         # the two scalar outputs (reg loss, log_prob) in one launch
         res.update(likelihood(part_pose, presence=part_presence, _extra_sums=[
-            (reg_partial, 0.5 / obj_encoding.shape[0], reg.detach())]))
+            (reg_partial, 0.5 / obj_encoding.shape[0], reg.detach())],
+            _defer_sums=_defer_sums))
         return res
 
 

@@ -65,15 +65,20 @@ def _grad_out(slot, like, shape=None):
     return torch.empty(shape, device=like.device, dtype=like.dtype)
 
 
-def scaled_sums(jobs):
-    """[(src, scale, dst)]: dst[()] = scale * src.sum() for up to 8 tensors in
-    ONE launch (the scalar outputs of the forward pass)."""
-    arr = (_lib.ScaledSum * len(jobs))()
+def _sum_jobs(jobs):
+    arr = (_lib.ScaledSum * max(1, len(jobs)))()
     for a, (src, scale, dst) in zip(arr, jobs):
         assert src.is_contiguous() and dst.numel() == 1
         a.src, a.n, a.scale, a.dst = src.data_ptr(), src.numel(), scale, \
             dst.data_ptr()
-    _lib.call("scae_scaled_sums_f32", arr, len(jobs), _stream(jobs[0][0]))
+    return arr
+
+
+def scaled_sums(jobs):
+    """[(src, scale, dst)]: dst[()] = scale * src.sum() for up to 8 tensors in
+    ONE launch (the scalar outputs of the forward pass)."""
+    _lib.call("scae_scaled_sums_f32", _sum_jobs(jobs), len(jobs),
+              _stream(jobs[0][0]))
 
 
 _NOISE_STATE = {}
@@ -900,7 +905,7 @@ class _ClassProbs(torch.autograd.Function):
     plain ops."""
 
     @staticmethod
-    def forward(ctx, caps_presence, posterior, weight, bias):
+    def forward(ctx, caps_presence, posterior, weight, bias, extra_sums):
         _need_hip(caps_presence, posterior, weight, bias)
         cp, post = caps_presence.detach().contiguous(), \
             posterior.detach().contiguous()
@@ -909,8 +914,10 @@ class _ClassProbs(torch.autograd.Function):
         ncls = weight.shape[0]
         prior = torch.empty(B, ncls, device=cp.device, dtype=cp.dtype)
         posterior_prob = torch.empty_like(prior)
+        extra = list(extra_sums or ())
         _lib.call("scae_class_probs_f32", _p(cp), _p(post), _p(weight), _p(bias),
-                  _p(prior), _p(posterior_prob), B, O1 - 1, M, ncls, _stream(cp))
+                  _p(prior), _p(posterior_prob), B, O1 - 1, M, ncls,
+                  _sum_jobs(extra), len(extra), _stream(cp))
         ctx.save_for_backward(cp, post, weight, bias)
         ctx.set_materialize_grads(False)
         return prior, posterior_prob
@@ -928,11 +935,13 @@ class _ClassProbs(torch.autograd.Function):
                     gs.append(g)
             gw, gb = torch.autograd.grad(outs, (w, b), gs) if outs else (None,
                                                                          None)
-        return None, None, gw, gb
+        return None, None, gw, gb, None
 
 
-def class_probs(caps_presence, posterior, weight, bias):
-    return _ClassProbs.apply(caps_presence, posterior, weight, bias)
+def class_probs(caps_presence, posterior, weight, bias, extra_sums=None):
+    """-> (prior_cls_prob, posterior_cls_prob).  ``extra_sums``: pending
+    ``scaled_sums`` jobs (<= 8) that ride in the same launch."""
+    return _ClassProbs.apply(caps_presence, posterior, weight, bias, extra_sums)
 
 
 # ----------------------------------------------------------------------------

@@ -137,7 +137,11 @@ class SCAE(nn.Module):
         if self.stop_grad_caps_target:
             target_pose = target_pose.detach()
             target_presence = target_presence.detach()
-        res = self.obj_decoder(obj_encoding, target_pose, target_presence)
+        # the forward's scalar outputs ride in its last kernel when there is one
+        fused_probs = self._fused_class_probs(obj_encoding)
+        res = self.obj_decoder(obj_encoding, target_pose, target_presence,
+                               **(dict(_defer_sums=True) if fused_probs else {}))
+        pending = res.pop("_pending_sums", None)
         res.part_presence = parts.presence
 
         dec_pose = {'enc': parts.pose, 'soft': res.soft_winner,
@@ -173,14 +177,11 @@ class SCAE(nn.Module):
             assert self.prior_classifier is not None
             assert self.posterior_classifier is not None
             linear = self.prior_classifier[0]
-            if "_posterior_full" in res and res.caps_presence.is_cuda and \
-                    len(self.prior_classifier) == 2 and \
-                    ops.class_probs_supported(res.caps_presence.shape[1],
-                                              self.n_classes):
+            if fused_probs:
                 # both heads (and the capsule-mass reduction) in one launch
                 res.prior_cls_prob, res.posterior_cls_prob = ops.class_probs(
                     res.caps_presence, res._posterior_full, linear.weight,
-                    linear.bias)
+                    linear.bias, extra_sums=pending)
                 return res
             res.prior_cls_prob = self.prior_classifier(
                 res.caps_presence.detach())
@@ -189,6 +190,15 @@ class SCAE(nn.Module):
             res.posterior_cls_prob = self.prior_classifier(
                 res.posterior_mixing_prob.sum(-1).detach())
         return res
+
+    def _fused_class_probs(self, obj_encoding):
+        from .object_decoder import CapsuleObjectDecoder
+        return (self.n_classes is not None and obj_encoding.is_cuda
+                and type(self.obj_decoder) is CapsuleObjectDecoder
+                and self.prior_classifier is not None
+                and len(self.prior_classifier) == 2
+                and ops.class_probs_supported(self.obj_decoder.n_obj_capsules,
+                                              self.n_classes))
 
     # -- loss ----------------------------------------------------------------
     def loss(self, res, reconstruction_target, label=None):
