@@ -272,6 +272,12 @@ int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias, fl
                          int Cin, int Cout, int stride, void *stream);
 int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const float *gate, float *din,
                            int B, int IH, int IW, int Cin, int Cout, int stride, void *stream);
+/* dgrad (gated by `in`, the layer's input = the producing layer's ReLU output)
+ * and the weight-gradient partials (as scae_conv3x3_wgrad_f32 with dw == NULL)
+ * of one layer in ONE launch: both only wait for dpre. */
+int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, const float *in, float *din,
+                              float *partial, int B, int IH, int IW, int Cin, int Cout,
+                              int stride, void *stream);
 int scae_conv3x3_wgrad_splits(int B, int OH, int OW, int Cin, int Cout);
 int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float *partial, float *dw,
                            float *db, int B, int IH, int IW, int Cin, int Cout, int stride,

@@ -116,6 +116,7 @@ SIGNATURES = {
     "scae_conv3x3_first_wgrad_f32": [P] * 3 + [c_int] * 6 + [P],
     "scae_conv3x3_fwd_f32": [P] * 6 + [c_int] * 6 + [P],
     "scae_conv3x3_dgrad_f32": [P] * 4 + [c_int] * 6 + [P],
+    "scae_conv3x3_bwd_pair_f32": [P] * 5 + [c_int] * 6 + [P],
     "scae_conv3x3_wgrad_reduce_batch_f32": [c_int] + [P] * 7,
     "scae_conv3x3_wgrad_splits": [c_int] * 5,
     "scae_conv3x3_wgrad_f32": [P] * 5 + [c_int] * 6 + [P],

@@ -31,11 +31,11 @@ struct ConvGeom {
   int B, IH, IW, OH, OW, Cin, Cout, stride;
 };
 
-// MODE: workgroup shape of mfma_tile.h (a `bool SK` argument selects 0 / 1)
+// MODE: workgroup shape of mfma_tile.h (a `bool SK` argument selects 0 / 1);
+// `smem` (Tile<MODE>::SMEM floats of LDS) is supplied by the enclosing kernel
 #define SCAE_TILE_PROLOGUE_M(MODE)                                              \
   using TL = Tile<MODE>;                                                        \
   constexpr int T = TL::T, NQ = TL::NQ;                                         \
-  __shared__ __attribute__((aligned(16))) float smem[TL::SMEM];                 \
   float *As = smem, *Bs = smem + TL::OPER;                                      \
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, r = lane & 15,  \
             q = lane >> 4;                                                      \
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const float *__restrict__ 
                                                       float *__restrict__ out,
                                                       const float *__restrict__ post_bias,
                                                       float *__restrict__ out_post, ConvGeom g) {
+  __shared__ __attribute__((aligned(16))) float smem[Tile<MODE>::SMEM];
   SCAE_TILE_PROLOGUE_M(MODE)
   constexpr int TB = TL::TB, NQB = TL::NQB;
   const int M = g.B * g.OH * g.OW, K = 9 * g.Cin;
@@ -151,20 +152,22 @@ inline int dgrad_axis(int I, int O, int stride, unsigned char *mask, short *coun
   return n;
 }
 
+// (bx, by): the tile's position in the (C_in tiles, pixel tiles) grid
 template <int MODE>
-__global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict__ dpre,
-                                                        const float *__restrict__ wd,
-                                                        const float *__restrict__ gate,
-                                                        float *__restrict__ din, ConvGeom g,
-                                                        DgradPlan pl) {
+__device__ __forceinline__ void dgrad_tile(float *smem, int bx, int by,
+                                           const float *__restrict__ dpre,
+                                           const float *__restrict__ wd,
+                                           const float *__restrict__ gate,
+                                           float *__restrict__ din, const ConvGeom &g,
+                                           const DgradPlan &pl) {
   SCAE_TILE_PROLOGUE_M(MODE)
   constexpr int TB = TL::TB, NQB = TL::NQB;
   // class pair of this tile: the number of class starts at or before it
   const int nz = pl.nrc * pl.ncc;
-  const int z = __popcll(__ballot(lane + 1 < nz && (int)blockIdx.y >= pl.tile_start[min(lane + 1, 64)]));
+  const int z = __popcll(__ballot(lane + 1 < nz && by >= pl.tile_start[min(lane + 1, 64)]));
   const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
   const int AH = pl.rcount[rc], AW = pl.ccount[cc], M = g.B * AH * AW, KT = 9 * g.Cout;
-  const int m0 = ((int)blockIdx.y - pl.tile_start[z]) * T, n0 = blockIdx.x * TB;
+  const int m0 = (by - pl.tile_start[z]) * T, n0 = bx * TB;
   const int sh = g.stride - 1;  // stride 1 or 2
   // the class pair's taps: set bits of rmask x cmask
   const int rm = pl.rmask[rc], cm = pl.cmask[cc];
@@ -228,20 +231,31 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
   });
 }
 
+template <int MODE>
+__global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict__ dpre,
+                                                        const float *__restrict__ wd,
+                                                        const float *__restrict__ gate,
+                                                        float *__restrict__ din, ConvGeom g,
+                                                        DgradPlan pl) {
+  __shared__ __attribute__((aligned(16))) float smem[Tile<MODE>::SMEM];
+  dgrad_tile<MODE>(smem, blockIdx.x, blockIdx.y, dpre, wd, gate, din, g, pl);
+}
+
 // ---- weight gradient: grid (Cin/T, Cout/T, 9 taps * S splits) --------------------
 // partial[(split*9 + tap)][co][ci], then bias partials [split][co] after 9*S slabs
 template <bool SK>
-__global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict__ dpre,
-                                                        const float *__restrict__ in,
-                                                        float *__restrict__ partial, ConvGeom g,
-                                                        int splits) {
+__device__ __forceinline__ void wgrad_tile(float *smem, int bx, int by, int bz,
+                                           const float *__restrict__ dpre,
+                                           const float *__restrict__ in,
+                                           float *__restrict__ partial, const ConvGeom &g,
+                                           int splits) {
   SCAE_TILE_PROLOGUE
   const int M = g.B * g.OH * g.OW;
-  const int tap = blockIdx.z % 9, split = blockIdx.z / 9, kh = tap / 3, kw = tap - kh * 3;
+  const int tap = bz % 9, split = bz / 9, kh = tap / 3, kw = tap - kh * 3;
   const int per = ((M + splits - 1) / splits + BK - 1) / BK * BK;
   const int kbeg = split * per, kend = min(M, kbeg + per);
-  const int co0 = blockIdx.y * T, ci0 = blockIdx.x * T;
-  const bool want_bias = tap == 0 && blockIdx.x == 0;  // workgroup-uniform
+  const int co0 = by * T, ci0 = bx * T;
+  const bool want_bias = tap == 0 && bx == 0;  // workgroup-uniform
   float4 bsum = zero4();
   // each thread stages pixel m = kbeg + c*BK + (its k slot) of chunk c; the
   // mainloop fetches chunks in ascending order exactly once, so (n, oh, ow) of
@@ -296,6 +310,38 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict_
       for (int j = 0; j < NT / (T / 4); ++j) sum += smem[4 * (tid / 4 + (T / 4) * j) + (tid & 3)];
       partial[(size_t)splits * 9 * g.Cout * g.Cin + (size_t)split * g.Cout + co0 + tid] = sum;
     }
+  }
+}
+
+template <bool SK>
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict__ dpre,
+                                                        const float *__restrict__ in,
+                                                        float *__restrict__ partial, ConvGeom g,
+                                                        int splits) {
+  __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
+  wgrad_tile<SK>(smem, blockIdx.x, blockIdx.y, blockIdx.z, dpre, in, partial, g, splits);
+}
+
+// Data and weight gradient of one layer in ONE launch: both only wait for dpre, and
+// at this model's sizes neither fills the 256 CUs on its own.  1-D grid: the first
+// nd workgroups are data-gradient tiles (gx per pixel-tile row), the rest walk the
+// weight-gradient grid (wx, wy, 9 * splits).
+struct PairGrid {
+  int nd, gx, wx, wy;
+};
+template <int DMODE, bool WSK>
+__global__ __launch_bounds__(NT) void conv_bwd_pair_kernel(
+    const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
+    float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
+    ConvGeom g, DgradPlan pl, int splits, PairGrid pg) {
+  constexpr int SM = Tile<DMODE>::SMEM > Tile<WSK>::SMEM ? Tile<DMODE>::SMEM : Tile<WSK>::SMEM;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  const int bid = blockIdx.x;
+  if (bid < pg.nd) {  // workgroup-uniform
+    dgrad_tile<DMODE>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
+  } else {
+    const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
+    wgrad_tile<WSK>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
   }
 }
 
@@ -639,6 +685,31 @@ extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const floa
   return scae_launch_status();
 }
 
+// the data-gradient tiling of a layer: class tables, tile shape, grid
+struct DgradLaunch {
+  DgradPlan pl;
+  int mode, gx, ny;
+};
+static DgradLaunch plan_dgrad(const ConvGeom &g) {
+  DgradLaunch d;
+  DgradPlan &pl = d.pl;
+  pl.nrc = dgrad_axis(g.IH, g.OH, g.stride, pl.rmask, pl.rcount, pl.rstart, pl.rlist);
+  pl.ncc = dgrad_axis(g.IW, g.OW, g.stride, pl.cmask, pl.ccount, pl.cstart, pl.clist);
+  auto tiles = [&](int T) {  // fills tile_start for tile size T, returns the total
+    int tot = 0;
+    for (int z = 0; z < pl.nrc * pl.ncc; ++z) {
+      pl.tile_start[z] = tot;
+      tot += (g.B * pl.rcount[z / pl.ncc] * pl.ccount[z % pl.ncc] + T - 1) / T;
+    }
+    pl.tile_start[pl.nrc * pl.ncc] = tot;
+    return tot;
+  };
+  d.mode = tile_mode((long)(g.Cin / 64) * tiles(64), (long)(g.Cin / 64) * tiles(32), 600);
+  d.ny = tiles(d.mode == 0 ? 64 : 32);
+  d.gx = d.mode == 1 ? g.Cin / 32 : g.Cin / 64;
+  return d;
+}
+
 extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const float *gate,
                                       float *din, int B, int IH, int IW, int Cin, int Cout,
                                       int stride, void *stream) {
@@ -647,33 +718,43 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
   if (rc) return rc;
   SCAE_REQUIRE(dpre && wd && din);
   if (IH > DG_MAXDIM || IW > DG_MAXDIM) return SCAE_ERR_UNSUPPORTED;
-  DgradPlan pl;
-  pl.nrc = dgrad_axis(IH, g.OH, stride, pl.rmask, pl.rcount, pl.rstart, pl.rlist);
-  pl.ncc = dgrad_axis(IW, g.OW, stride, pl.cmask, pl.ccount, pl.cstart, pl.clist);
-  auto tiles = [&](int T) {  // fills tile_start for tile size T, returns the total
-    int tot = 0;
-    for (int z = 0; z < pl.nrc * pl.ncc; ++z) {
-      pl.tile_start[z] = tot;
-      tot += (B * pl.rcount[z / pl.ncc] * pl.ccount[z % pl.ncc] + T - 1) / T;
-    }
-    pl.tile_start[pl.nrc * pl.ncc] = tot;
-    return tot;
-  };
+  const DgradLaunch d = plan_dgrad(g);
   hipStream_t st = (hipStream_t)stream;
-  const int mode = tile_mode((long)(Cin / 64) * tiles(64), (long)(Cin / 64) * tiles(32), 600);
-  if (mode == 0) {
-    const int ny = tiles(64);
-    hipLaunchKernelGGL(conv_dgrad_kernel<0>, dim3(Cin / 64, ny), dim3(NT), 0, st, dpre, wd, gate,
-                       din, g, pl);
+  const dim3 grid(d.gx, d.ny);
+  if (d.mode == 0)
+    hipLaunchKernelGGL(conv_dgrad_kernel<0>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+  else if (d.mode == 2)
+    hipLaunchKernelGGL(conv_dgrad_kernel<2>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+  else
+    hipLaunchKernelGGL(conv_dgrad_kernel<1>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+  return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, const float *in,
+                                         float *din, float *partial, int B, int IH, int IW,
+                                         int Cin, int Cout, int stride, void *stream) {
+  ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
+  int rc = check_geom(g, true);
+  if (rc) return rc;
+  SCAE_REQUIRE(dpre && wd && in && din && partial);
+  if (IH > DG_MAXDIM || IW > DG_MAXDIM) return SCAE_ERR_UNSUPPORTED;
+  const DgradLaunch d = plan_dgrad(g);
+  const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
+  const int wt = p.small ? 32 : 64;
+  const PairGrid pg{d.gx * d.ny, d.gx, Cin / wt, Cout / wt};
+  const dim3 grid(pg.nd + pg.wx * pg.wy * 9 * p.splits);
+  hipStream_t st = (hipStream_t)stream;
+#define SCAE_PAIR(DM, WS)                                                                     \
+  hipLaunchKernelGGL((conv_bwd_pair_kernel<DM, WS>), grid, dim3(NT), 0, st, dpre, wd, in, din, \
+                     in, partial, g, d.pl, p.splits, pg)
+  if (d.mode == 0) {
+    if (p.small) SCAE_PAIR(0, true); else SCAE_PAIR(0, false);
+  } else if (d.mode == 2) {
+    if (p.small) SCAE_PAIR(2, true); else SCAE_PAIR(2, false);
   } else {
-    const int ny = tiles(32);
-    if (mode == 2)
-      hipLaunchKernelGGL(conv_dgrad_kernel<2>, dim3(Cin / 64, ny), dim3(NT), 0, st, dpre, wd,
-                         gate, din, g, pl);
-    else
-      hipLaunchKernelGGL(conv_dgrad_kernel<1>, dim3(Cin / 32, ny), dim3(NT), 0, st, dpre, wd,
-                         gate, din, g, pl);
+    if (p.small) SCAE_PAIR(1, true); else SCAE_PAIR(1, false);
   }
+#undef SCAE_PAIR
   return scae_launch_status();
 }
 

@@ -574,13 +574,13 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout):
         splits = _lib.load().scae_conv3x3_wgrad_splits(B, oh, ow, ci, co)
         partial = new(splits * (9 * co * ci + co))
         gw, gb = gout(l), gout(L + l)
-        _lib.call("scae_conv3x3_wgrad_f32", _p(dpre), _p(xin), _p(partial),
-                  None, None, B, ih, iw, ci, co, s, st)
+        din = new(B, ih, iw, ci)
+        # weight-gradient partials and the (ReLU-gated) data gradient both
+        # only wait for dpre: one launch
+        _lib.call("scae_conv3x3_bwd_pair_f32", _p(dpre), _p(wds[l - 1]),
+                  _p(xin), _p(din), _p(partial), B, ih, iw, ci, co, s, st)
         pending.append((partial, gw, gb, co, ci, splits))
         gws[l], gbs[l] = gw, gb
-        din = new(B, ih, iw, ci)
-        _lib.call("scae_conv3x3_dgrad_f32", _p(dpre), _p(wds[l - 1]),
-                  _p(xin), _p(din), B, ih, iw, ci, co, s, st)
         dpre = din
     if pending:
         n = len(pending)
