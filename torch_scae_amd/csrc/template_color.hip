@@ -3,7 +3,8 @@
 // colour from its special features through MLP([F, H1, C]) (ReLU after both
 // layers, nn_ext.py:19-31), colour non-linearity, templates = raw * colour
 // (B,M,C,h,w).  The reference runs ~10 small ATen launches forward and ~15 in
-// the autograd backward; here: one launch forward, two backward.
+// the autograd backward; here: one launch forward, one backward (two kinds of
+// workgroups).
 //   fwd : one workgroup per image (MLP weights in LDS)
 //   bwdA: one workgroup per image: g_colour = <g_templates, raw>, MLP backward
 //         -> g_feature and per-image partial weight gradients
@@ -129,9 +130,8 @@ __global__ __launch_bounds__(NT) void tc_fwd_kernel(TcArgs k) {
   }
 }
 
-__global__ __launch_bounds__(NT) void tc_bwdA_kernel(TcArgs k) {
-  extern __shared__ float lds[];
-  const int M = k.M / k.splits, b = blockIdx.x / k.splits, m0 = (blockIdx.x % k.splits) * M;
+__device__ __forceinline__ void tc_bwdA_body(const TcArgs &k, float *lds, int block) {
+  const int M = k.M / k.splits, b = block / k.splits, m0 = (block % k.splits) * M;
   const Lds l = carve(lds, k, M);
   float *g2 = l.pre2 + M * k.C, *g1 = g2 + M * k.C;
   const int t = threadIdx.x, MC = M * k.C, wave = t >> 6, lane = t & 63;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT) void tc_bwdA_kernel(TcArgs k) {
   }
   // per-workgroup weight-gradient partials: [dW1 | db1 | dW2 | db2]
   const int n1 = k.H1 * k.F, n2 = n1 + k.H1, n3 = n2 + k.C * k.H1, n4 = n3 + k.C;
-  float *part = k.partial + (size_t)blockIdx.x * n4;
+  float *part = k.partial + (size_t)block * n4;
   for (int e = t; e < n4; e += NT) {
     float s = 0.f;
     if (e < n1) {
@@ -182,9 +182,10 @@ __global__ __launch_bounds__(NT) void tc_bwdA_kernel(TcArgs k) {
 }
 
 // workgroup (256 texels, 4 batch parts)
-__global__ __launch_bounds__(1024) void tc_bwdB_kernel(TcArgs k) {
+__device__ __forceinline__ void tc_bwdB_body(const TcArgs &k, int block) {
   __shared__ float red[4][256];
-  const int e = blockIdx.x * 256 + threadIdx.x, part = threadIdx.y, MC = k.M * k.C;
+  const int tx = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int e = block * 256 + tx, MC = k.M * k.C;
   const int n = MC * k.hw;
   float s = 0.f;
   if (e < n) {
@@ -193,14 +194,24 @@ __global__ __launch_bounds__(1024) void tc_bwdB_kernel(TcArgs k) {
     for (int b = b0; b < b1; ++b)
       s = fmaf(k.g_templates[(size_t)b * n + e], k.color[(size_t)b * MC + mc], s);
   }
-  red[part][threadIdx.x] = s;
+  red[part][tx] = s;
   __syncthreads();
   if (part == 0 && e < n) {
-    float tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
-                (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float tot = (red[0][tx] + red[1][tx]) +
+                (red[2][tx] + red[3][tx]);
     if (k.g_raw) tot += k.g_raw[e];
     k.g_logits[e] = tot * nonlin_grad(k.logits[e], k.tnl);
   }
+}
+
+// the two halves are independent (A: per (image, capsule group) colour-MLP backward,
+// B: per texel batch sums for the template logits): one launch, A's workgroups first
+__global__ __launch_bounds__(NT) void tc_bwd_kernel(TcArgs k, int nA) {
+  extern __shared__ float lds[];
+  if ((int)blockIdx.x < nA)  // workgroup-uniform
+    tc_bwdA_body(k, lds, blockIdx.x);
+  else
+    tc_bwdB_body(k, (int)blockIdx.x - nA);
 }
 
 // capsule groups per image: enough workgroups to cover the 256 CUs twice
@@ -269,11 +280,9 @@ extern "C" int scae_template_color_bwd_f32(const float *logits, const float *fea
   SCAE_REQUIRE(logits && feature && w1 && b1 && w2 && b2 && color && g_templates && g_logits &&
                g_feature && partial);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(tc_bwdA_kernel, dim3(B * k.splits), dim3(NT),
-                     lds_floats(M / k.splits, C, F, H1, true) * sizeof(float),
-                     st, k);
-  const int n = M * C * hw;
-  hipLaunchKernelGGL(tc_bwdB_kernel, dim3((n + 255) / 256), dim3(256, 4), 0, st, k);
+  const int n = M * C * hw, nA = B * k.splits;
+  hipLaunchKernelGGL(tc_bwd_kernel, dim3(nA + (n + 255) / 256), dim3(NT),
+                     lds_floats(M / k.splits, C, F, H1, true) * sizeof(float), st, k, nA);
   return scae_launch_status();
 }
 
