@@ -211,9 +211,13 @@ def time_k8_kernels(cfg, device, reps=50):
                 p(dy), p(wd), p(x), p(dx), *geo, st),
             "conv_wgrad_kernel": lambda: lib.scae_conv3x3_wgrad_f32(
                 p(dy), p(x), p(part), p(dw), p(db), *geo, st),
+            # what the step launches: both gradients of a layer together
+            "conv_bwd_pair_kernel": lambda: lib.scae_conv3x3_bwd_pair_f32(
+                p(dy), p(wd), p(x), p(dx), p(part), *geo, st),
         }
-        flops = 2.0 * B * OH * OH * Co * 9 * Ci        # MACs x 2, all 3 passes
+        flops1 = 2.0 * B * OH * OH * Co * 9 * Ci       # MACs x 2 of one pass
         for name, fn in calls.items():
+            flops = flops1 * (2 if name == "conv_bwd_pair_kernel" else 1)
             for _ in range(5):
                 assert fn() == 0
             torch.cuda.synchronize()
@@ -234,16 +238,17 @@ def time_k8_kernels(cfg, device, reps=50):
 
 def roofline(cfg, device):
     """Roofline of the dominant hand-written kernel of the step.  By rocprofv3
-    total time per step that is the implicit-GEMM data-gradient kernel of the
-    CNN encoder (K8, MFMA-bound): achieved = algorithmic FLOPs of its launches
-    (2 x MACs of the convolution, zero-padding work not counted) / their
-    measured duration.  The K1 likelihood kernels (HBM/VALU) and the other K8
-    passes are reported alongside."""
+    total time per step that is the implicit-GEMM backward kernel of the CNN
+    encoder (K8, MFMA-bound; data and weight gradient of a layer in one
+    launch): achieved = algorithmic FLOPs of its launches (2 x MACs of both
+    gradient convolutions, zero-padding work not counted) / their measured
+    duration.  The K1 likelihood kernels (VALU-issue bound, priced against HBM
+    as the brief asks) and the other K8 passes are reported alongside."""
     k1 = time_k1_kernels(cfg, device)
     alg = k1_algorithmic_bytes(cfg)
     B = cfg["batch"]
     k8 = time_k8_kernels(cfg, device)
-    name = "conv_dgrad_kernel"
+    name = "conv_bwd_pair_kernel"
     launches = k8[name]
     secs = sum(l["seconds"] for l in launches)
     flops = sum(l["flops"] for l in launches)

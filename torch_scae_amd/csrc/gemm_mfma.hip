@@ -163,6 +163,12 @@ __global__ __launch_bounds__(NT) void gemm_pair_kernel(GemmPair p) {
   }
 }
 
+// fewer 64 x 64 tiles than this: 32 x 32 split-K tiles (4x the workgroups)
+#ifndef SCAE_GEMM_SK_BELOW
+#define SCAE_GEMM_SK_BELOW 1024
+#endif
+constexpr long kSplitKBelow = SCAE_GEMM_SK_BELOW;
+
 template <bool SK>
 void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
   constexpr int T = Tile<SK>::T;
@@ -190,7 +196,7 @@ extern "C" int scae_gemm_f32(const float *A, const float *B, float *C, const flo
              (long)bias_batch, (long)mask_batch, (long)asum_batch, lda, ldb, ldc, bias_ld,
              ldmask, M, N, K, relu, asum_ld > 0 ? asum_ld : 1};
   const long tiles64 = (long)((N + 63) / 64) * ((M + 63) / 64) * batch;
-  if (tiles64 < 1024)
+  if (tiles64 < kSplitKBelow)
     launch<true>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
   else
     launch<false>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
@@ -223,7 +229,7 @@ extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_d
   const long tiles64 = (long)((first->N + 63) / 64) * ((first->M + 63) / 64) * first->batch +
                        (long)((second->N + 63) / 64) * ((second->M + 63) / 64) * second->batch;
   const int nz = first->batch + second->batch;
-  if (tiles64 < 1024)
+  if (tiles64 < kSplitKBelow)
     hipLaunchKernelGGL(gemm_pair_kernel<true>, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(NT),
                        0, (hipStream_t)stream, p);
   else
