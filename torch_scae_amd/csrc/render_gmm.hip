@@ -105,6 +105,84 @@ __device__ __forceinline__ void tap_value_grad(const float *plane, const Taps &t
   dy = (v10 - v00) * wx0 + (v11 - v01) * wx1;
 }
 
+// ---- zero-padded template planes in LDS ------------------------------------------
+// A (th x tw) plane is staged as (th+4) x (tw+4) with the texels at offset (2, 2) and
+// zeros around them.  With the sampling position clamped to [-2, tw] x [-2, th]
+// every bilinear tap is then an in-range LDS read and an outside tap reads 0 -- the
+// zero padding of grid_sample without per-tap masks, index clamps or compares (the
+// unpadded formulation above spends ~2/3 of its instructions on those).  A
+// position beyond the clamp has all four taps outside either way; NaN clamps to -2.
+__host__ __device__ inline int pad_w(int tw) { return tw + 4; }
+__host__ __device__ inline int pad_elems(int th, int tw) { return (th + 4) * (tw + 4); }
+
+struct PTaps {
+  int base;      // offset of tap (y0, x0) inside a padded plane
+  float fx, fy;  // fractional position
+  float xn, yn;  // normalised output-pixel coordinates
+};
+
+__device__ __forceinline__ void make_ptaps(const float *a, int p, int W, int H, int tw, int th,
+                                           PTaps &t) {
+  const float inv_w = 1.f / (float)W;
+  const int i = (int)(((float)p + 0.5f) * inv_w), j = p - i * W;  // exact for p < 2^22
+  t.xn = norm_coord(j, inv_w);
+  t.yn = norm_coord(i, 1.f / (float)H);
+  float ix, iy;
+  tex_pos(a, t.xn, t.yn, tw, th, ix, iy);
+  ix = fminf(fmaxf(ix, -2.f), (float)tw);  // fmaxf(NaN, -2) = -2
+  iy = fminf(fmaxf(iy, -2.f), (float)th);
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  t.fx = ix - x0f;
+  t.fy = iy - y0f;
+  t.base = ((int)y0f + 2) * pad_w(tw) + (int)x0f + 2;
+}
+
+__device__ __forceinline__ float ptap_value(const float *plane, const PTaps &t, int pw) {
+  const float wx1 = t.fx, wx0 = 1.f - t.fx, wy1 = t.fy, wy0 = 1.f - t.fy;
+  const float *q = plane + t.base;
+  return q[0] * (wx0 * wy0) + q[1] * (wx1 * wy0) + q[pw] * (wx0 * wy1) + q[pw + 1] * (wx1 * wy1);
+}
+
+// value and d/dix, d/diy (grid_sampler_2d_backward's formulas).
+__device__ __forceinline__ void ptap_value_grad(const float *plane, const PTaps &t, int pw,
+                                                float &v, float &dx, float &dy) {
+  const float *q = plane + t.base;
+  const float v00 = q[0], v01 = q[1], v10 = q[pw], v11 = q[pw + 1];
+  const float wx1 = t.fx, wx0 = 1.f - t.fx, wy1 = t.fy, wy0 = 1.f - t.fy;
+  v = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+  dx = (v01 - v00) * wy0 + (v11 - v10) * wy1;
+  dy = (v10 - v00) * wx0 + (v11 - v01) * wx1;
+}
+
+// stage `n` dense (th x tw) planes from global memory as padded planes (NTHREADS
+// threads of the workgroup; the caller synchronises afterwards)
+template <int NTHREADS>
+__device__ __forceinline__ void stage_padded(float *dst, const float *src, int n, int th, int tw) {
+  const int psz = pad_elems(th, tw), pw = pad_w(tw);
+  // zero everything (16-byte stores where dst allows), then one thread per texel
+  // row: a single division per row
+  const int total = n * psz, n4 = (((size_t)dst & 15) == 0) ? total >> 2 : 0;
+  for (int i = threadIdx.x; i < n4; i += NTHREADS)
+    reinterpret_cast<float4 *>(dst)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 4 * n4 + threadIdx.x; i < total; i += NTHREADS) dst[i] = 0.f;
+  __syncthreads();
+  if (!src) return;
+  if (n * th >= NTHREADS) {  // many planes: a thread per texel row (one division per row)
+    for (int row = threadIdx.x; row < n * th; row += NTHREADS) {
+      const int pl = row / th, y = row - pl * th;
+      const float *sp = src + (size_t)row * tw;
+      float *dp = dst + pl * psz + (y + 2) * pw + 2;
+      for (int x = 0; x < tw; ++x) dp[x] = sp[x];
+    }
+  } else {  // few planes: a thread per texel
+    const int tsz = th * tw;
+    for (int i = threadIdx.x; i < n * tsz; i += NTHREADS) {
+      const int pl = i / tsz, e = i - pl * tsz, y = e / tw, x = e - y * tw;
+      dst[pl * psz + (y + 2) * pw + x + 2] = src[i];
+    }
+  }
+}
+
 // template set of image b: consecutive groups of `template_repeat` images share one
 // (stacked_capsule_auto_encoder.py:188-195 decodes every object capsule's votes with the
 // image's templates: B*O virtual images, B template sets)
@@ -158,12 +236,14 @@ __global__ __launch_bounds__(NT) void render_fwd_kernel(scae_decoder_desc d,
     return;
   }
 
-  float *s_tmpl = smem;             // C * tsz
-  float *s_alpha = smem + C * tsz;  // tsz (alpha mode)
+  const int psz = pad_elems(d.th, d.tw), pw = pad_w(d.tw);
+  float *s_tmpl = smem;             // C padded planes
+  float *s_alpha = smem + C * psz;  // one more (alpha mode)
   const float *g_tmpl = d.templates + (size_t)(tb(d, b) * M + k) * C * tsz;
-  for (int i = tid; i < C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
+  // (the alpha plane follows the template planes in LDS: one staging pass each)
+  stage_padded<NT>(s_tmpl, g_tmpl, C, d.th, d.tw);
   if (alpha_mode)
-    for (int i = tid; i < tsz; i += NT) s_alpha[i] = d.templates_alpha[(size_t)k * tsz + i];
+    stage_padded<NT>(s_alpha, d.templates_alpha + (size_t)k * tsz, 1, d.th, d.tw);
   float a[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) a[i] = d.pose[(size_t)(b * M + k) * 6 + i];
@@ -171,14 +251,14 @@ __global__ __launch_bounds__(NT) void render_fwd_kernel(scae_decoder_desc d,
   __syncthreads();
 
   for (int p = tid; p < HW; p += NT) {
-    Taps t;
-    make_taps(a, p, d.W, d.H, d.tw, d.th, t);
+    PTaps t;
+    make_ptaps(a, p, d.W, d.H, d.tw, d.th, t);
     for (int c = 0; c < C; ++c) {
-      const float v = tap_value(s_tmpl + c * tsz, t);
+      const float v = ptap_value(s_tmpl + c * psz, t, pw);
       tt_out[c * HW + p] = v;
       if (!alpha_mode) ml_out[c * HW + p] = v / sc.temperature + lsp;
     }
-    if (alpha_mode) ml_out[p] = tap_value(s_alpha, t) + lsp;
+    if (alpha_mode) ml_out[p] = ptap_value(s_alpha, t, pw) + lsp;
   }
 }
 
@@ -186,7 +266,9 @@ __global__ __launch_bounds__(NT) void render_fwd_kernel(scae_decoder_desc d,
 // fused forward: log_prob(x) straight from the compact inputs.
 // grid (pixel tiles, B).  Lane layout: tid = pixel_local * KSPLIT + kgroup.
 // ---------------------------------------------------------------------------
-template <int C, int KSPLIT>
+// PAD: the templates are staged as zero-padded planes (see above); chosen by the
+// launcher while M * (C + 1) padded planes keep two workgroups per CU.
+template <int C, int KSPLIT, bool PAD>
 __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
     scae_decoder_desc d, const float *__restrict__ x, float *__restrict__ log_prob,
     float *__restrict__ lse_post, float *__restrict__ lse_prior, int pix_per_block,
@@ -200,15 +282,21 @@ __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
   constexpr int CM = C;  // register arrays sized for the per-channel mode
   const Scalars sc = load_scalars(d);
 
-  float *s_tmpl = smem;                                // M*C*tsz
-  float *s_alpha = s_tmpl + M * C * tsz;               // M*tsz (alpha mode)
-  float *s_pose = s_alpha + (alpha_mode ? M * tsz : 0);  // M*6
+  const int psz = PAD ? pad_elems(d.th, d.tw) : tsz, pw = pad_w(d.tw);  // plane stride in LDS
+  float *s_tmpl = smem;                                // M*C planes
+  float *s_alpha = s_tmpl + M * C * psz;               // M planes (alpha mode)
+  float *s_pose = s_alpha + (alpha_mode ? M * psz : 0);  // M*6
   float *s_lsp = s_pose + M * 6;                       // M
   {
     const float *g_tmpl = d.templates + (size_t)tb(d, b) * M * C * tsz;
-    for (int i = tid; i < M * C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
-    if (alpha_mode)
-      for (int i = tid; i < M * tsz; i += NT) s_alpha[i] = d.templates_alpha[i];
+    if (PAD) {
+      stage_padded<NT>(s_tmpl, g_tmpl, M * C, d.th, d.tw);
+      if (alpha_mode) stage_padded<NT>(s_alpha, d.templates_alpha, M, d.th, d.tw);
+    } else {
+      for (int i = tid; i < M * C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
+      if (alpha_mode)
+        for (int i = tid; i < M * tsz; i += NT) s_alpha[i] = d.templates_alpha[i];
+    }
     for (int i = tid; i < M * 6; i += NT) s_pose[i] = d.pose[(size_t)b * M * 6 + i];
     for (int i = tid; i < M; i += NT)
       s_lsp[i] = d.presence ? log_safe(d.presence[b * M + i]) : 0.f;
@@ -236,15 +324,21 @@ __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
     }
     for (int k = kg; k < M; k += KSPLIT) {
       Taps t;
-      make_taps(s_pose + k * 6, pc, d.W, d.H, d.tw, d.th, t);
+      PTaps pt;
+      if (PAD)
+        make_ptaps(s_pose + k * 6, pc, d.W, d.H, d.tw, d.th, pt);
+      else
+        make_taps(s_pose + k * 6, pc, d.W, d.H, d.tw, d.th, t);
       float mlv = 0.f;
       if (alpha_mode) {
-        mlv = tap_value(s_alpha + k * tsz, t) + s_lsp[k];
+        mlv = (PAD ? ptap_value(s_alpha + k * psz, pt, pw) : tap_value(s_alpha + k * psz, t)) +
+              s_lsp[k];
         prior[0].add(mlv);
       }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float v = tap_value(s_tmpl + (k * C + c) * tsz, t);
+        const float v = PAD ? ptap_value(s_tmpl + (k * C + c) * psz, pt, pw)
+                            : tap_value(s_tmpl + (k * C + c) * psz, t);
         if (!alpha_mode) {
           mlv = v / sc.temperature + s_lsp[k];
           prior[c].add(mlv);
@@ -340,9 +434,10 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
   const float inv_w = 1.f / (float)W, inv_h = 1.f / (float)H;
   const int npc = rows_per_chunk * W;  // pixels per chunk (LDS plane stride)
 
-  float *s_tmpl = smem;                        // C*tsz
-  float *s_alpha = s_tmpl + C * tsz;           // tsz
-  float *s_acc = s_alpha + tsz;                // SLICES * (C+1) * tsz
+  const int psz = pad_elems(th, tw), pw = pad_w(tw);
+  float *s_tmpl = smem;                        // C padded planes
+  float *s_alpha = s_tmpl + C * psz;           // one padded plane
+  float *s_acc = s_alpha + psz;                // SLICES * (C+1) * tsz
   float *s_red = s_acc + SLICES * (C + 1) * tsz;  // 11 * (NT/64)
   float *s_g = s_red + 11 * (NT / 64);         // (C+1) * npc: per-pixel grads
 
@@ -351,9 +446,9 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
   float lsp = 0.f;
   if (!is_bg) {
     const float *g_tmpl = d.templates + (size_t)(tb(d, b) * M + k) * C * tsz;
-    for (int i = tid; i < C * tsz; i += NT) s_tmpl[i] = g_tmpl[i];
-    for (int i = tid; i < tsz; i += NT)
-      s_alpha[i] = alpha_mode ? d.templates_alpha[(size_t)k * tsz + i] : 0.f;
+    stage_padded<NT>(s_tmpl, g_tmpl, C, th, tw);
+    stage_padded<NT>(s_alpha, alpha_mode ? d.templates_alpha + (size_t)k * tsz : nullptr, 1, th,
+                     tw);
     for (int i = tid; i < SLICES * (C + 1) * tsz; i += NT) s_acc[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) a[i] = d.pose[(size_t)(b * M + k) * 6 + i];
@@ -389,14 +484,15 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
     // ---- phase 1: pixel-parallel --------------------------------------
     for (int pl = tid; pl < np; pl += NT) {
       const int p = p0 + pl;
-      Taps t;
+      PTaps t;
       float tv[C], tdx[C], tdy[C];
       float av = 0.f, adx = 0.f, ady = 0.f;
       if (!is_bg) {
-        make_taps(a, p, W, H, tw, th, t);
+        make_ptaps(a, p, W, H, tw, th, t);
 #pragma unroll
-        for (int c = 0; c < C; ++c) tap_value_grad(s_tmpl + c * tsz, t, tv[c], tdx[c], tdy[c]);
-        if (alpha_mode) tap_value_grad(s_alpha, t, av, adx, ady);
+        for (int c = 0; c < C; ++c)
+          ptap_value_grad(s_tmpl + c * psz, t, pw, tv[c], tdx[c], tdy[c]);
+        if (alpha_mode) ptap_value_grad(s_alpha, t, pw, av, adx, ady);
       } else {
 #pragma unroll
         for (int c = 0; c < C; ++c)
@@ -795,7 +891,9 @@ extern "C" int scae_template_render_fwd_f32(const scae_decoder_desc *d,
   int rc = check_desc(d);
   if (rc) return rc;
   SCAE_REQUIRE(transformed_templates && mixing_logits);
-  const size_t lds = sizeof(float) * (size_t)(d->C + 1) * d->th * d->tw;
+  const size_t lds = sizeof(float) * (size_t)(d->C + 1) * pad_elems(d->th, d->tw);
+  int rc2 = set_lds(render_fwd_kernel, lds);
+  if (rc2) return rc2;
   hipLaunchKernelGGL(render_fwd_kernel, dim3(d->M + 1, d->B), dim3(NT), lds,
                      (hipStream_t)stream, *d, transformed_templates, mixing_logits);
   return scae_launch_status();
@@ -813,7 +911,10 @@ LpTiling lp_tiling(const scae_decoder_desc *d) {
   const long pixels = (long)d->B * HW;
   LpTiling t;
   t.ksplit = pixels >= 256L * 1024 * 4 ? 1 : (pixels >= 256L * 1024 ? 2 : 4);
-  t.ppb = 4 * NT / t.ksplit;  // four pixel rounds per workgroup amortise the LDS fill
+#ifndef SCAE_LP_ROUNDS
+#define SCAE_LP_ROUNDS 6
+#endif
+  t.ppb = SCAE_LP_ROUNDS * NT / t.ksplit;  // pixel rounds per workgroup amortise the LDS fill
   if (t.ppb > HW) t.ppb = ((HW + (NT / t.ksplit) - 1) / (NT / t.ksplit)) * (NT / t.ksplit);
   t.tiles = (HW + t.ppb - 1) / t.ppb;
   return t;
@@ -822,27 +923,39 @@ LpTiling lp_tiling(const scae_decoder_desc *d) {
 template <int C>
 int launch_logprob_fwd(const scae_decoder_desc *d, const float *x, float *log_prob,
                        float *lse_post, float *lse_prior, float *block_sums, hipStream_t st) {
-  const int tsz = d->th * d->tw;
-  const size_t lds = sizeof(float) * ((size_t)d->M * d->C * tsz +
-                                      (d->templates_alpha ? (size_t)d->M * tsz : 0) +
-                                      (size_t)d->M * 7);
+  const size_t planes = (size_t)d->M * (d->C + (d->templates_alpha ? 1 : 0));
+  // zero-padded planes (no tap masks) while two workgroups still fit a CU's LDS
+  const size_t lds_pad = sizeof(float) * (planes * pad_elems(d->th, d->tw) + (size_t)d->M * 7);
+#ifndef SCAE_LP_PAD_LIMIT_KB
+#define SCAE_LP_PAD_LIMIT_KB 72
+#endif
+  const bool pad = lds_pad <= (size_t)SCAE_LP_PAD_LIMIT_KB * 1024;
+  const size_t lds =
+      pad ? lds_pad : sizeof(float) * (planes * d->th * d->tw + (size_t)d->M * 7);
   const LpTiling t = lp_tiling(d);
   const int ppb = t.ppb;
   const dim3 grid(t.tiles, d->B);
   int rc;
-#define SCAE_LAUNCH_LP(KS)                                                            \
-  rc = set_lds(logprob_fwd_kernel<C, KS>, lds);                                       \
-  if (rc) return rc;                                                                  \
-  hipLaunchKernelGGL((logprob_fwd_kernel<C, KS>), grid, dim3(NT), lds, st, *d, x,     \
+#define SCAE_LAUNCH_LP2(KS, PD)                                                           \
+  rc = set_lds(logprob_fwd_kernel<C, KS, PD>, lds);                                       \
+  if (rc) return rc;                                                                      \
+  hipLaunchKernelGGL((logprob_fwd_kernel<C, KS, PD>), grid, dim3(NT), lds, st, *d, x,     \
                      log_prob, lse_post, lse_prior, ppb, block_sums)
+#define SCAE_LAUNCH_LP(KS)  \
+  if (pad) {                \
+    SCAE_LAUNCH_LP2(KS, true);  \
+  } else {                  \
+    SCAE_LAUNCH_LP2(KS, false); \
+  }
   if (t.ksplit == 1) {
-    SCAE_LAUNCH_LP(1);
+    SCAE_LAUNCH_LP(1)
   } else if (t.ksplit == 2) {
-    SCAE_LAUNCH_LP(2);
+    SCAE_LAUNCH_LP(2)
   } else {
-    SCAE_LAUNCH_LP(4);
+    SCAE_LAUNCH_LP(4)
   }
 #undef SCAE_LAUNCH_LP
+#undef SCAE_LAUNCH_LP2
   return scae_launch_status();
 }
 
@@ -857,7 +970,8 @@ int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post
   // per-pixel gradient planes of one chunk of output rows live in LDS
   int rows = (int)((40 * 1024 / sizeof(float)) / ((size_t)(d->C + 1) * d->W));
   rows = rows < 1 ? 1 : (rows > d->H ? d->H : rows);
-  const size_t lds = sizeof(float) * ((1 + SLICES) * (size_t)(d->C + 1) * tsz + 11 * (NT / 64) +
+  const size_t lds = sizeof(float) * ((size_t)(d->C + 1) * pad_elems(d->th, d->tw) +
+                                      SLICES * (size_t)(d->C + 1) * tsz + 11 * (NT / 64) +
                                       (size_t)(d->C + 1) * rows * d->W);
   const dim3 grid(d->M + 1, d->B);
   const bool fused = (g_tt == nullptr && g_ml == nullptr);
