@@ -84,6 +84,14 @@ int scae_qkv_attention_fwd_f32(const float *q, const float *k, const float *v,
                                int HB, int N, int M, int dk, int dv,
                                float sqrt_dk, void *stream);
 /* gq (HB,N,dk) gk (HB,M,dk) gv (HB,M,dv); gpresence (HB,M) nullable. */
+/* bf16 forward (BASELINE.json configs[2]): q, k, v, out as bf16 bit patterns
+ * (what torch.autocast hands the attention), both contractions on the bf16
+ * matrix cores with fp32 accumulation, mask / scale / softmax in fp32; probs
+ * (HB,N,M) stays fp32 -- the backward pass is scae_qkv_attention_bwd_f32 on
+ * upcast operands. */
+int scae_qkv_attention_fwd_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                const float *presence, uint16_t *out, float *probs, int HB,
+                                int N, int M, int dk, int dv, float sqrt_dk, void *stream);
 int scae_qkv_attention_bwd_f32(const float *q, const float *k, const float *v,
                                const float *probs, const float *gout,
                                float *gq, float *gk, float *gv,

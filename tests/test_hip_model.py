@@ -294,3 +294,69 @@ def test_training_step_trajectory_vs_oracle_and_torch_rmsprop():
     sd = model.state_dict()
     for k, p in P.items():
         assert_close(sd[k].cpu(), p.detach(), 1e-4, 2e-3, "param " + k)
+
+
+@pytest.mark.gpu
+def test_cfg3_bf16_attention_path_vs_fp32_oracle():
+    """BASELINE.json configs[2] (48 part / 64 object capsules, "bf16, MFMA
+    attention path"; SURVEY.md 8d: bf16 autocast for attention / linears, fp32
+    for the mixture): under ``torch.autocast(bfloat16)`` the set transformer
+    runs module by module -- bf16 projections, the bf16 MFMA attention kernel
+    -- and everything behind it stays fp32.  Compared with the fp32 CPU oracle
+    on identical parameters / inputs / noise; the tolerance is bf16's: 2^-7
+    relative on the loss and its log entries, 5 % of the output scale on the
+    object-capsule votes (batch cut to keep the oracle quick)."""
+    from torch_scae_amd import factory, nn_utils
+    cfg = dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=48,
+               n_obj_caps=64, scae_params=dict(reconstruct_alternatives=False))
+    B = 16
+    np.random.seed(1)
+    torch.manual_seed(1)
+    proto = factory.make_scae(cfg)
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for p in proto.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    sd = {k: v.clone() for k, v in proto.state_dict().items()}
+    image = torch.rand(B, 1, 40, 40, generator=g)
+    label = torch.randint(0, 10, (B,), generator=g)
+    noise = [torch.rand(B, 48, generator=g), torch.rand(B, 64, 1, generator=g),
+             torch.rand(B, 64, 48, generator=g)]
+    ocfg = O.prepare_model_params(**cfg)
+    with torch.no_grad():
+        ores = O.scae_forward(sd, ocfg, image, noise, training=True)
+        oloss, olog = O.scae_loss(ocfg, ores, image, label)
+
+    model = factory.make_scae(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    calls = []
+    from torch_scae_amd import ops
+    real = ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    ops._lib.call = spy
+    try:
+        with nn_utils.fixed_noise(noise), \
+                torch.autocast("cuda", dtype=torch.bfloat16):
+            res = model(image.cuda())
+        loss, log = model.loss(res, image.cuda(), label.cuda())
+        loss.backward()
+    finally:
+        ops._lib.call = real
+    # the attention of all 3 SABs and the output attention ran on the bf16 kernel
+    assert calls.count("scae_qkv_attention_fwd_bf16") == 4, calls
+    assert "scae_set_encoder_fwd_f32" not in calls
+    tol = 2.0 ** -7
+    assert_close(loss, oloss, tol * abs(float(oloss)), tol, "loss (bf16 path)")
+    for k in olog:
+        assert_close(log[k], olog[k], tol * max(1.0, abs(float(olog[k]))), 4 * tol,
+                     "log " + k)
+    assert res.vote.dtype == torch.float32
+    assert_close(res.vote, ores.vote, 0.05 * float(ores.vote.abs().max()), 0.05,
+                 "vote")
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all())
+               for p in model.parameters())

@@ -1248,3 +1248,57 @@ def test_part_encoder_node_vs_fp64_composition(B, C0, HW, chans, strides, A, F,
         assert float(bad.float().mean()) <= 0.02, (name, float(bad.float().mean()))
         assert_close(a.grad, r.grad.float(), rtol=1e-2, atol=1e-2 * scale_r,
                      what="grad " + name)
+
+
+# --------------------------------------------------------------------------
+# K2 bf16 forward (BASELINE.json configs[2]: bf16, MFMA attention path)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("HB,N,M,dk,dv,pres", [
+    (64, 64, 48, 256, 256, "mixed"),     # output attention of cfg-3 (O=64, M=48)
+    (64, 48, 48, 16, 16, "mixed"),       # SAB of cfg-3
+    (5, 33, 17, 70, 130, "mixed"),       # ragged, multi-chunk
+    (7, 1, 1, 3, 5, None),               # degenerate
+])
+def test_qkv_attention_bf16_vs_oracle(HB, N, M, dk, dv, pres):
+    """bf16 operands on the bf16 matrix cores, fp32 accumulate / softmax.  The
+    oracle runs in fp32 on the SAME bf16-rounded inputs, so the differences
+    left are the bf16 rounding of P (as the A operand of P V) and of the
+    output: tolerance 2^-7 relative to the output scale, written below; the
+    attention probabilities themselves (fp32) must agree to 1e-4."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(HB * 1000 + N)
+    bf = torch.bfloat16
+    q = torch.randn(HB, N, dk, generator=g).to(bf)
+    k = torch.randn(HB, M, dk, generator=g).to(bf)
+    v = torch.randn(HB, M, dv, generator=g).to(bf)
+    w = torch.randn(HB, N, dv, generator=g)
+    p = None
+    if pres == "mixed":
+        p = torch.ones(HB, M)
+        p[:, ::3] = torch.rand(HB, len(range(0, M, 3)), generator=g)
+        p[0] = 1.0
+    qc, kc, vc = (t.float().requires_grad_(True) for t in (q, k, v))
+    oo = O.qkv_attention(qc, kc, vc, p)
+    (oo * w).sum().backward()
+
+    qg, kg, vg = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    import numpy as np
+    og = ops.qkv_attention(qg, kg, vg, dev(p))
+    assert og.dtype == bf
+    # probabilities (saved for the backward pass): fp32 softmax of exact bf16
+    # products accumulated in fp32
+    ref_p = torch.softmax(
+        (qc @ kc.transpose(1, 2) - ((1. - p[:, None, :]) * 1e32 if p is not None
+                                    else 0.)) / np.float32(np.sqrt(dk)), -1)
+    got_p = og.grad_fn.saved_tensors[3]
+    assert got_p.dtype == torch.float32
+    assert_close(got_p, ref_p.detach(), 1e-4, 1e-4, "probs (fp32)")
+    (og.float() * w.cuda()).sum().backward()
+    scale = max(1.0, float(oo.abs().max()))
+    tol = 2.0 ** -7
+    assert_close(og.float(), oo, tol * scale, tol, "out (bf16)")
+    for name, a, b in (("gq", qg.grad, qc.grad), ("gk", kg.grad, kc.grad),
+                       ("gv", vg.grad, vc.grad)):
+        assert a.dtype == bf
+        assert_close(a.float(), b, tol * max(1.0, float(b.abs().max())), tol,
+                     name + " (bf16)")

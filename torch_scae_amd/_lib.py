@@ -88,6 +88,8 @@ SIGNATURES = {
                                          P],
     "scae_qkv_attention_fwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int,
                                    c_int, c_int, c_float, P],
+    "scae_qkv_attention_fwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_int,
+                                    c_int, c_int, c_float, P],
     "scae_qkv_attention_bwd_f32": [P, P, P, P, P, P, P, P, P, c_int, c_int,
                                    c_int, c_int, c_int, c_float, P],
     "scae_set_encoder_param_count": [c_int] * 5,

@@ -161,6 +161,159 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 forward (BASELINE.json configs[2]: "bf16 ... MFMA attention path"): the same
+// decomposition with both contractions on v_mfma_f32_16x16x16_bf16 (bf16 operands,
+// fp32 accumulate; 4x the K per instruction and half the LDS bytes of the fp32
+// kernel).  q, k, v arrive as bf16 -- what torch.autocast hands the attention after
+// the bf16 q/k/v projections -- the mask / scale / softmax stay fp32 (the 1e32 mask
+// needs the exponent range and the reference order of operations), the
+// probabilities are rounded to bf16 only as the A operand of P V and are kept in
+// fp32 for the backward pass, which runs the fp32 kernel above on upcast operands.
+//
+// MFMA 16x16x16 bf16 lane maps: A[i][k]: lane l holds i = l&15, k = 4*(l>>4) + 0..3
+// (4 consecutive k = 8 bytes); B[k][j]: k = 4*(l>>4) + 0..3, j = l&15; C as above.
+// ---------------------------------------------------------------------------
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDH = DC + 8;  // LDS row stride in bf16 units: 144 B = 4 mod 32 banks... rows
+                             // of a fragment read (8 B per lane) spread over all banks
+
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ bf16x4 ld_bf4(const unsigned short *p) {
+  return *reinterpret_cast<const bf16x4 *>(p);
+}
+
+// rows x DC chunk of a (rows_valid x d) row-major bf16 matrix -> LDS, zero padded;
+// TR: stored transposed, dst[c][n] (the B operand of P V wants 4 consecutive rows)
+template <bool TR>
+__device__ __forceinline__ void stage_bf(unsigned short *dst, const unsigned short *src,
+                                         int rows_pad, int rows_valid, int d, int c0, int dc) {
+  for (int i = threadIdx.x; i < rows_pad * DC; i += NT) {
+    const int n = i / DC, c = i - n * DC;
+    const unsigned short v = (n < rows_valid && c < dc) ? src[(size_t)n * d + c0 + c] : 0;
+    if (TR)
+      dst[c * LDH + n] = v;
+    else
+      dst[n * LDH + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(
+    const unsigned short *__restrict__ q, const unsigned short *__restrict__ k,
+    const unsigned short *__restrict__ v, const float *__restrict__ presence,
+    unsigned short *__restrict__ out, float *__restrict__ probs, int N, int M, int dk, int dv,
+    float sqrt_dk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hb = blockIdx.x, tid = threadIdx.x;
+  const int wid = tid >> 6, lane = tid & 63, r = lane & 15, qd = lane >> 4;
+  const int Npad = (N + 15) & ~15, Mpad = (M + 15) & ~15;
+  const int nrt = Npad / 16, nct = Mpad / 16;
+  unsigned short *Qs = reinterpret_cast<unsigned short *>(smem);  // [Npad][LDH]
+  unsigned short *Ks = Qs + SCAE_ATTN_MAX_SET * LDH;  // [Mpad][LDH] K chunks, then V^T chunks [DC][LDH]
+  unsigned short *Ps = Ks + SCAE_ATTN_MAX_SET * LDH;  // [Npad][LDH] probabilities (bf16)
+  const unsigned short *qb = q + (size_t)hb * N * dk;
+  const unsigned short *kb = k + (size_t)hb * M * dk;
+  const unsigned short *vb = v + (size_t)hb * M * dv;
+
+  // ---- S = Q K^T -------------------------------------------------------
+  f32x4 acc[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < dk; c0 += DC) {
+    const int dc = min(DC, dk - c0), dcp = (dc + 15) & ~15;
+    __syncthreads();
+    stage_bf<false>(Qs, qb, Npad, N, dk, c0, dc);
+    stage_bf<false>(Ks, kb, Mpad, M, dk, c0, dc);
+    __syncthreads();
+    if (wid < nrt) {
+      for (int kk = 0; kk < dcp; kk += 16) {
+        const bf16x4 a = ld_bf4(Qs + (16 * wid + r) * LDH + kk + 4 * qd);
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j)
+          if (j < nct)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                a, ld_bf4(Ks + (16 * j + r) * LDH + kk + 4 * qd), acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- presence mask, scale, softmax (set_transformer.py:42-43), fp32 ---
+  if (wid < nrt) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = 16 * wid + qd * 4 + reg;
+      float sv[MAXT];
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        const int col = 16 * j + r;
+        float s = -INFINITY;
+        if (j < nct && col < M) {
+          s = acc[j][reg];
+          if (presence) s = s - (1.f - presence[(size_t)hb * M + col]) * 1e32f;
+          s = s / sqrt_dk;
+        }
+        sv[j] = s;
+        m = fmaxf(m, s);
+      }
+      m = group16_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        sv[j] = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - m);
+        sum += sv[j];
+      }
+      sum = group16_sum(sum);
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        const int col = 16 * j + r;
+        if (j < nct) {
+          const float p = sv[j] / sum;
+          Ps[row * LDH + col] = f2bf(p);
+          if (row < N && col < M) probs[((size_t)hb * N + row) * M + col] = p;
+        }
+      }
+    }
+  }
+
+  // ---- O = P V ----------------------------------------------------------
+  for (int c0 = 0; c0 < dv; c0 += DC) {
+    const int dc = min(DC, dv - c0);
+    const int nvt = (dc + 15) / 16;
+    __syncthreads();
+    stage_bf<true>(Ks, vb, Mpad, M, dv, c0, dc);  // Ks[d][m]
+    __syncthreads();
+    if (wid < nrt) {
+      f32x4 o[DC / 16];
+#pragma unroll
+      for (int j = 0; j < DC / 16; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < Mpad; kk += 16) {
+        const bf16x4 a = ld_bf4(Ps + (16 * wid + r) * LDH + kk + 4 * qd);
+#pragma unroll
+        for (int j = 0; j < DC / 16; ++j)
+          if (j < nvt)
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                a, ld_bf4(Ks + (16 * j + r) * LDH + kk + 4 * qd), o[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < DC / 16; ++j) {
+        const int col = 16 * j + r;
+        if (j < nvt && col < dc) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * wid + qd * 4 + reg;
+            if (row < N) out[((size_t)hb * N + row) * dv + c0 + col] = f2bf(o[j][reg]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // C[rows x cols tile (ti, tj)] = sum_kk A(ti, kk) * B(kk, tj) with both
 // operands in LDS.  TA: A is read transposed (A[i][k] = As[k][i]).
 template <bool TA>
@@ -319,6 +472,19 @@ extern "C" int scae_qkv_attention_fwd_f32(const float *q, const float *k, const 
   if (rc) return rc;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k, v,
                      presence, out, probs, N, M, dk, dv, sqrt_dk);
+  return scae_launch_status();
+}
+
+extern "C" int scae_qkv_attention_fwd_bf16(const uint16_t *q, const uint16_t *k,
+                                           const uint16_t *v, const float *presence,
+                                           uint16_t *out, float *probs, int HB, int N, int M,
+                                           int dk, int dv, float sqrt_dk, void *stream) {
+  int rc = check_attn(HB, N, M, dk, dv);
+  if (rc) return rc;
+  SCAE_REQUIRE(q && k && v && out && probs && sqrt_dk > 0.f);
+  const size_t lds = sizeof(unsigned short) * 3 * (size_t)SCAE_ATTN_MAX_SET * LDH;
+  hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k,
+                     v, presence, out, probs, N, M, dk, dv, sqrt_dk);
   return scae_launch_status();
 }
 

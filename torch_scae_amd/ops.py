@@ -207,16 +207,30 @@ def geometric_transform(pose, similarity=False, nonlinear=True,
 # K2 qkv_attention (set_transformer.py:24-47)
 # ----------------------------------------------------------------------------
 class _QKVAttention(torch.autograd.Function):
+    """fp32: both passes on the fp32 MFMA kernels.  bf16 (q, k, v all bfloat16,
+    as under ``torch.autocast``): forward on the bf16 MFMA kernel (fp32
+    softmax; output bf16, probabilities kept in fp32), backward on the fp32
+    kernel with upcast operands."""
+
     @staticmethod
     def forward(ctx, q, k, v, presence):
-        _need_hip(q, k, v, presence)
+        bf16 = q.dtype == torch.bfloat16
+        if bf16:
+            if not (k.dtype == v.dtype == torch.bfloat16 and q.is_cuda):
+                raise ScaeHipError("bf16 attention wants q, k and v in bf16 "
+                                   "on a HIP device")
+            presence = None if presence is None else presence.float()
+            _need_hip(presence)
+        else:
+            _need_hip(q, k, v, presence)
         q, k, v, presence = _c(q), _c(k), _c(v), _c(presence)
         HB, N, dk = q.shape
         M, dv = v.shape[1], v.shape[2]
         out = torch.empty(HB, N, dv, device=q.device, dtype=q.dtype)
-        probs = torch.empty(HB, N, M, device=q.device, dtype=q.dtype)
+        probs = torch.empty(HB, N, M, device=q.device, dtype=torch.float32)
         sqrt_dk = float(np.float32(np.sqrt(dk)))
-        _lib.call("scae_qkv_attention_fwd_f32", _p(q), _p(k), _p(v),
+        _lib.call("scae_qkv_attention_fwd_bf16" if bf16 else
+                  "scae_qkv_attention_fwd_f32", _p(q), _p(k), _p(v),
                   _p(presence), _p(out), _p(probs), HB, N, M, dk, dv, sqrt_dk,
                   _stream(q))
         ctx.save_for_backward(q, k, v, probs)
@@ -227,9 +241,12 @@ class _QKVAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         q, k, v, probs = ctx.saved_tensors
+        dtype = q.dtype
+        if dtype != torch.float32:       # bf16 forward: fp32 backward
+            q, k, v = q.float(), k.float(), v.float()
         HB, N, dk = q.shape
         M, dv = v.shape[1], v.shape[2]
-        gout = gout.contiguous()
+        gout = gout.float().contiguous()
         gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         gp = None
         if ctx.has_presence and ctx.needs_input_grad[3]:
@@ -237,6 +254,8 @@ class _QKVAttention(torch.autograd.Function):
         _lib.call("scae_qkv_attention_bwd_f32", _p(q), _p(k), _p(v), _p(probs),
                   _p(gout), _p(gq), _p(gk), _p(gv), _p(gp), HB, N, M, dk, dv,
                   ctx.sqrt_dk, _stream(q))
+        if dtype != torch.float32:
+            gq, gk, gv = gq.to(dtype), gk.to(dtype), gv.to(dtype)
         return gq, gk, gv, gp
 
 

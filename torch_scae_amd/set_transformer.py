@@ -149,6 +149,12 @@ class SetTransformer(nn.Module):
 
     # -- fused trunk ---------------------------------------------------------
     def _fusable(self, n_items, presence):
+        # the fused trunk is fp32 only: under a bf16 autocast the modules run
+        # one by one (bf16 linears, bf16 MFMA attention kernel)
+        if not getattr(self, "fused", True) or (
+                torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") != torch.float32):
+            return False
         if not (all(isinstance(b, SAB) for b in self.sabs)
                 and self.multi_head_attention.n_heads == 1
                 and (presence is None or not presence.requires_grad)):

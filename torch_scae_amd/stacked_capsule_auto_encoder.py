@@ -133,6 +133,11 @@ class SCAE(nn.Module):
             obj_encoding = self.obj_encoder(torch.cat(segments, -1),
                                             in_presence)
 
+        if obj_encoding.dtype != image.dtype:
+            # bf16 autocast covers the object encoder only (SURVEY.md 8d cfg-3:
+            # "bf16 autocast for attention/linears, fp32 accumulators for the
+            # mixture"); everything behind it stays fp32
+            obj_encoding = obj_encoding.to(image.dtype)
         target_pose, target_presence = parts.pose, parts.presence
         if self.stop_grad_caps_target:
             target_pose = target_pose.detach()

@@ -14,7 +14,7 @@ from .data_parallel import (FlatParameters, RMSpropFlat, all_reduce_gradients,
 class TrainStep:
     def __init__(self, model, batch_size, image_shape, lr=3e-5, use_graph=True,
                  optimizer=True, momentum=0.9, weight_decay=0.0,
-                 lr_decay_rate=0.997):
+                 lr_decay_rate=0.997, autocast_dtype=None):
         self.model = model
         self.device = next(model.parameters()).device
         self.flat = FlatParameters(model)
@@ -25,6 +25,9 @@ class TrainStep:
                                weight_decay=weight_decay) \
             if optimizer else None
         self.lr_decay_rate = lr_decay_rate
+        # e.g. torch.bfloat16: the object encoder's linears and attention run
+        # in bf16 (BASELINE.json configs[2]); everything else stays fp32
+        self.autocast_dtype = autocast_dtype
         self.log = None          # device tensors of the last step's log dict
         self.image = torch.zeros(batch_size, *image_shape, device=self.device)
         self.label = torch.zeros(batch_size, dtype=torch.long,
@@ -40,7 +43,9 @@ class TrainStep:
 
     def _fwd_bwd(self):
         self.flat.clear_grads()
-        res = self.model(self.image)
+        with torch.autocast("cuda", dtype=self.autocast_dtype,
+                            enabled=self.autocast_dtype is not None):
+            res = self.model(self.image)
         loss, info = self.model.loss(res, self.image, self.label)
         loss.backward(self._one)     # a resident seed: no ones_like fill per step
         self.flat.gather_grads()
