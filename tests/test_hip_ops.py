@@ -1302,3 +1302,78 @@ def test_qkv_attention_bf16_vs_oracle(HB, N, M, dk, dv, pres):
         assert a.dtype == bf
         assert_close(a.float(), b, tol * max(1.0, float(b.abs().max())), tol,
                      name + " (bf16)")
+
+
+# --------------------------------------------------------------------------
+# launch-merging helpers: multi-matrix / transposed / periodic column sums,
+# scaled scalar sums (alone and riding in the class-probability launch), the
+# one-launch batch hand-over
+# --------------------------------------------------------------------------
+def test_sum_rows_multi_transpose_period_and_tall_skinny():
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(128, 25 * 128, generator=g)      # (B, HW*C) -> (C, HW) transposed
+    b = torch.randn(3200, 4, generator=g)            # tall and skinny (K1 scalars)
+    c = torch.randn(128, 24 * 199, generator=g)      # periodic windows (K3 biases)
+    d = torch.randn(7, 33, generator=g)              # few rows
+    given = torch.full((128, 5, 5), float("nan"), device="cuda")
+    (ta,), (b0, b3), (p0, p1), (dd,) = ops._sum_rows_multi([
+        dict(partial=a.cuda(), shapes=[(128, 5, 5)], transpose=128, outs=[given]),
+        dict(partial=b.cuda(), shapes=[(1,), (1,)], starts=[0, 3]),
+        dict(partial=c.cuda(), shapes=[(1, 24, 1, 6), (1, 24, 24)],
+             starts=[144, 151], period=199),
+        dict(partial=d.cuda(), shapes=[(33,)])])
+    assert ta.data_ptr() == given.data_ptr()
+    want_a = a.double().sum(0).view(25, 128).t().reshape(128, 5, 5)
+    assert_close(ta, want_a.float(), 2e-4, 1e-5, "transposed scatter")
+    sb = b.double().sum(0)
+    assert_close(b0, sb[0:1].float(), 1e-3, 1e-5, "tall-skinny col 0")
+    assert_close(b3, sb[3:4].float(), 1e-3, 1e-5, "tall-skinny col 3")
+    sc = c.double().sum(0).view(24, 199)
+    assert_close(p0, sc[:, 144:150].reshape(1, 24, 1, 6).float(), 2e-4, 1e-5,
+                 "periodic window 0")
+    assert_close(p1, sc[:, 151:175].reshape(1, 24, 24).float(), 2e-4, 1e-5,
+                 "periodic window 1")
+    assert_close(dd, d.double().sum(0).float(), 1e-5, 1e-5, "few rows")
+
+
+def test_scaled_sums_alone_and_riding_in_class_probs():
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(128, 24, generator=g)
+    y = torch.randn(3072, generator=g)
+    jobs = lambda: [(x.cuda(), 1.0 / 128, torch.empty((), device="cuda")),   # noqa: E731
+                    (y.cuda(), 0.5 / 128, torch.empty((), device="cuda"))]
+    alone = jobs()
+    ops.scaled_sums(alone)
+    assert_close(alone[0][2], (x.double().sum() / 128).float(), 1e-5, 1e-5, "x")
+    assert_close(alone[1][2], (y.double().sum() * 0.5 / 128).float(), 1e-5, 1e-5, "y")
+    # the same jobs as riders of the class-probability kernel
+    cp = torch.rand(128, 24, generator=g)
+    post = torch.rand(128, 25, 24, generator=g)
+    w, b = torch.randn(10, 24, generator=g), torch.randn(10, generator=g)
+    riders = jobs()
+    prior, posterior = ops.class_probs(cp.cuda(), post.cuda(), w.cuda(), b.cuda(),
+                                       extra_sums=riders)
+    assert torch.equal(riders[0][2].cpu().reshape(()), alone[0][2].cpu().reshape(())) \
+        or abs(float(riders[0][2]) - float(alone[0][2])) <= 1e-6
+    assert_close(riders[1][2], alone[1][2], 1e-6, 1e-5, "rider y")
+    assert_close(prior, torch.softmax(cp @ w.t() + b, -1), 1e-5, 1e-4, "prior")
+    assert_close(posterior, torch.softmax(post[:, :-1].sum(-1) @ w.t() + b, -1),
+                 1e-5, 1e-4, "posterior")
+
+
+def test_stage_batch_one_launch():
+    import ctypes
+    from torch_scae_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    for shape in ((128, 1, 40, 40), (5, 3, 7, 9)):       # vector and scalar-tail paths
+        image = torch.rand(*shape, generator=g).cuda()
+        label = torch.randint(0, 10, (shape[0],), generator=g).cuda()
+        di = torch.full(shape, float("nan"), device="cuda")
+        dl = torch.full((shape[0],), -1, dtype=torch.long, device="cuda")
+        P = ctypes.c_void_p
+        _lib.call("scae_stage_batch", P(di.data_ptr()), P(image.data_ptr()),
+                  image.numel(), P(dl.data_ptr()), P(label.data_ptr()), label.numel(),
+                  P(torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(di, image) and torch.equal(dl, label)
