@@ -265,13 +265,25 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
     const int nout = a.ncls * O + a.ncls;
     const int out = ((int)blockIdx.x - B) * (NT / 4) + (tid >> 2), part = tid & 3;
     float t = 0.f;
+    // (independent loads kept in flight: the sums are L2-latency bound)
     if (out < a.ncls * O) {
       const int cc = out / O, o = out - cc * O;
-      for (int b = part; b < B; b += 4)
-        t += ws.gl[((size_t)b * 2) * a.ncls + cc] * g_x1 * a.cp[(size_t)b * O + o] +
-             ws.gl[((size_t)b * 2 + 1) * a.ncls + cc] * g_x2 * ws.mass[(size_t)b * O + o];
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      int b = part;
+      for (; b + 12 < B; b += 16) {
+#define SCAE_TERM(bb)                                                                  \
+  (ws.gl[((size_t)(bb) * 2) * a.ncls + cc] * g_x1 * a.cp[(size_t)(bb) * O + o] +      \
+   ws.gl[((size_t)(bb) * 2 + 1) * a.ncls + cc] * g_x2 * ws.mass[(size_t)(bb) * O + o])
+        const float u0 = SCAE_TERM(b), u1 = SCAE_TERM(b + 4), u2 = SCAE_TERM(b + 8),
+                    u3 = SCAE_TERM(b + 12);
+        t0 += u0, t1 += u1, t2 += u2, t3 += u3;
+      }
+      for (; b < B; b += 4) t0 += SCAE_TERM(b);
+#undef SCAE_TERM
+      t = (t0 + t1) + (t2 + t3);
     } else if (out < nout) {
       const int cc = out - a.ncls * O;
+#pragma unroll 4
       for (int b = part; b < B; b += 4)
         t += ws.gl[((size_t)b * 2) * a.ncls + cc] * g_x1 +
              ws.gl[((size_t)b * 2 + 1) * a.ncls + cc] * g_x2;
