@@ -21,8 +21,15 @@ __global__ __launch_bounds__(64) void class_probs_kernel(
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) {  // riders: scaled full sums (the scalar outputs of the forward pass)
     const scae_scaled_sum &job = extra.j[b - B];
-    float t = 0.f;
-    for (int64_t i = lane; i < job.n; i += 64) t += job.src[i];
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f;
+    int64_t i = lane;  // eight loads in flight per lane: the sum is L2-latency bound
+    for (; i + 448 < job.n; i += 512) {
+      const float *p = job.src + i;
+      t0 += p[0], t1 += p[64], t2 += p[128], t3 += p[192];
+      t4 += p[256], t5 += p[320], t6 += p[384], t7 += p[448];
+    }
+    for (; i < job.n; i += 64) t0 += job.src[i];
+    float t = ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
     t = scae::wave_sum(t);
     if (lane == 0) job.dst[0] = t * job.scale;
     return;
@@ -30,9 +37,11 @@ __global__ __launch_bounds__(64) void class_probs_kernel(
   if (lane < O) {  // lane = capsule: the two classifier inputs
     s_x[0][lane] = cp[(size_t)b * O + lane];
     const float *p = posterior + ((size_t)b * (O + 1) + lane) * M;
-    float mass = 0.f;
-    for (int m = 0; m < M; ++m) mass += p[m];
-    s_x[1][lane] = mass;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;  // four loads in flight
+    int m = 0;
+    for (; m + 4 <= M; m += 4) m0 += p[m], m1 += p[m + 1], m2 += p[m + 2], m3 += p[m + 3];
+    for (; m < M; ++m) m0 += p[m];
+    s_x[1][lane] = (m0 + m1) + (m2 + m3);
   }
   __syncthreads();
   if (lane < 2 * ncls) {  // lane = (input, class): one logit each

@@ -178,9 +178,9 @@ __global__ __launch_bounds__(NT) void tail_combine_kernel(TailArgs a, scae_loss_
   float *col = smem, *red = smem + 2 * O;  // red: 6 * (NT/64) floats
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int b = tid; b < B; b += NT) {
-    const float *p = ws.part + (size_t)b * 8;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) v[i] += p[i];
+    const float4 p = *reinterpret_cast<const float4 *>(ws.part + (size_t)b * 8);
+    v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w;
+    v[4] += ws.part[(size_t)b * 8 + 4];
   }
   if (x.rec_sums)
     for (int i = tid; i < x.n_rec; i += NT) v[5] += x.rec_sums[i];
@@ -188,11 +188,18 @@ __global__ __launch_bounds__(NT) void tail_combine_kernel(TailArgs a, scae_loss_
   for (int e = tid; e < ((2 * O * 16 + NT - 1) / NT) * NT; e += NT) {
     const int c = e >> 4, l = e & 15, which = c / O, o = c - which * O;
     float t = 0.f;
-    if (c < 2 * O) {
-      if (which == 0)
-        for (int b = l; b < B; b += 16) t += a.cp[(size_t)b * O + o];
-      else
-        for (int b = l; b < B; b += 16) t += ws.mass[(size_t)b * O + o] / a.M;
+    if (c < 2 * O) {  // (loads kept in flight: four independent partial sums)
+      auto at = [&](int b) {
+        return which == 0 ? a.cp[(size_t)b * O + o] : ws.mass[(size_t)b * O + o] / a.M;
+      };
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      int b = l;
+      for (; b + 48 < B; b += 64) {
+        const float u0 = at(b), u1 = at(b + 16), u2 = at(b + 32), u3 = at(b + 48);
+        t0 += u0, t1 += u1, t2 += u2, t3 += u3;
+      }
+      for (; b < B; b += 16) t0 += at(b);
+      t = (t0 + t1) + (t2 + t3);
     }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
