@@ -144,45 +144,58 @@ __global__ __launch_bounds__(NT) void likelihood_fwd_kernel(
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
     lk_stats(a, s, b);
-    // phase C1: per pair outputs (incl. the dummy row o == O)
+    // phase C1: per pair outputs (incl. the dummy row o == O); the posterior
+    // probability of every real pair replaces its mixing logit in LDS
     for (int e = tid; e < (O + 1) * M; e += NT) {
       const int o = e / M, m = e - o * M;
       const size_t g1 = (size_t)b * (O + 1) * M + e;
       const float ml = o < O ? s.ml[e] : kLog001;
       const float post = o < O ? s.post[e] : kLog001 + kLog001;
+      const float pp = expf(post - s.max_post[m]) / s.sum_post[m];       // :338
       mixing_logit[g1] = ml;
       mixing_log_prob[g1] = ml - s.lse_ml[m];                        // :286
-      posterior[g1] = expf(post - s.max_post[m]) / s.sum_post[m];    // :338
-      if (o < O) binary[(size_t)b * O * M + e] = ml > kLog001 ? 1.f : 0.f;  // :289
-    }
-    // phase C2: winners
-    for (int e = tid; e < M * 6; e += NT) {
-      const int m = e / 6, i = e - m * 6;
-      float sw = 0.f;
-      for (int o = 0; o < O; ++o) {
-        const float pp = expf(s.post[o * M + m] - s.max_post[m]) / s.sum_post[m];
-        sw = fmaf(pp, a.vote[(((size_t)b * O + o) * M + m) * 6 + i], sw);
+      posterior[g1] = pp;
+      if (o < O) {
+        binary[(size_t)b * O * M + e] = ml > kLog001 ? 1.f : 0.f;  // :289
+        s.ml[e] = pp;
       }
-      const float ppd = expf(kLog001 + kLog001 - s.max_post[m]) / s.sum_post[m];
-      sw = fmaf(ppd, a.dummy_vote[m * 6 + i], sw);
-      const int win = (int)s.win[m];
-      soft_winner[((size_t)b * M + m) * 6 + i] = sw;                 // :350
-      winner[((size_t)b * M + m) * 6 + i] =
-          a.vote[(((size_t)b * O + win) * M + m) * 6 + i];           // :324
     }
-    for (int m = tid; m < M; m += NT) {
+    __syncthreads();
+    // phase C2: winners.  Four lanes share the sum over o of one output (loads
+    // of a lane's O/4 votes are in flight together), met by two shuffles
+    for (int t = tid; t < ((M * 7 * 4 + NT - 1) / NT) * NT; t += NT) {
+      const int e = t >> 2, part = t & 3;  // e < M*6: soft_winner[m][i]; else soft presence
+      const bool pose = e < M * 6, live = e < M * 7;
+      const int m = pose ? e / 6 : e - M * 6, i = pose ? e - m * 6 : 0;
+      float acc = 0.f;
+      if (live) {
+        if (pose) {
+#pragma unroll 6
+          for (int o = part; o < O; o += 4)
+            acc = fmaf(s.ml[o * M + m], a.vote[(((size_t)b * O + o) * M + m) * 6 + i], acc);
+        } else {
+#pragma unroll 6
+          for (int o = part; o < O; o += 4)
+            acc = fmaf(s.ml[o * M + m], a.vp[((size_t)b * O + o) * M + m], acc);
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (!live || part != 0) continue;
       const size_t idx = (size_t)b * M + m;
-      float swp = 0.f;
-      for (int o = 0; o < O; ++o)
-        swp = fmaf(expf(s.post[o * M + m] - s.max_post[m]) / s.sum_post[m],
-                   a.vp[((size_t)b * O + o) * M + m], swp);
       const int win = (int)s.win[m];
-      const float lse_post = s.max_post[m] + logf(s.sum_post[m]);
-      lpp[idx] = a.presence ? lse_post * a.presence[idx] : lse_post;  // :296-300
-      soft_winner_presence[idx] = swp;                                // :354
-      winner_presence[idx] = a.vp[((size_t)b * O + win) * M + m];     // :328
-      winner_idx[idx] = win;
-      is_from_capsule[idx] = win / M;                                 // :334 (reference quirk)
+      if (pose) {
+        const float ppd = expf(kLog001 + kLog001 - s.max_post[m]) / s.sum_post[m];
+        soft_winner[idx * 6 + i] = fmaf(ppd, a.dummy_vote[m * 6 + i], acc);   // :350
+        winner[idx * 6 + i] = a.vote[(((size_t)b * O + win) * M + m) * 6 + i];  // :324
+      } else {
+        const float lse_post = s.max_post[m] + logf(s.sum_post[m]);
+        lpp[idx] = a.presence ? lse_post * a.presence[idx] : lse_post;  // :296-300
+        soft_winner_presence[idx] = acc;                                // :354
+        winner_presence[idx] = a.vp[((size_t)b * O + win) * M + m];     // :328
+        winner_idx[idx] = win;
+        is_from_capsule[idx] = win / M;                                 // :334 (reference quirk)
+      }
     }
   }
 }
@@ -222,15 +235,24 @@ __global__ __launch_bounds__(NT) void likelihood_bwd_kernel(
       s_gpp[e] = gpp;
     }
     __syncthreads();
-    for (int m = tid; m < M; m += NT) {
+    // softmax-backward inner product and the column sums of g_mixing_log_prob:
+    // 16 lanes per part capsule m share the sum over the O + 1 components
+    for (int t = tid; t < ((M * 16 + NT - 1) / NT) * NT; t += NT) {
+      const int m = t >> 4, l = t & 15;
       float dot = 0.f, gs = 0.f;
-      for (int o = 0; o <= O; ++o) {
-        const float post = o < O ? s.post[o * M + m] : kLog001 + kLog001;
-        dot = fmaf(expf(post - s.max_post[m]) / s.sum_post[m], s_gpp[o * M + m], dot);
-        if (g_mlp) gs += g_mlp[((size_t)b * (O + 1) + o) * M + m];
+      if (m < M) {
+        for (int o = l; o <= O; o += 16) {
+          const float post = o < O ? s.post[o * M + m] : kLog001 + kLog001;
+          dot = fmaf(expf(post - s.max_post[m]) / s.sum_post[m], s_gpp[o * M + m], dot);
+          if (g_mlp) gs += g_mlp[((size_t)b * (O + 1) + o) * M + m];
+        }
       }
-      s_dot[m] = dot;
-      s_gmlp[m] = gs;
+      dot = group_sum<16>(dot);
+      gs = group_sum<16>(gs);
+      if (m < M && l == 0) {
+        s_dot[m] = dot;
+        s_gmlp[m] = gs;
+      }
     }
     __syncthreads();
     for (int e = tid; e < O * M; e += NT) {  // per pair gradients
@@ -263,18 +285,26 @@ __global__ __launch_bounds__(NT) void likelihood_bwd_kernel(
       }
       gvp[g] = g_pv;
       gscale[g] = gsc;
-      s.ml[e] = gpost;  // reuse: g wrt posterior logit, for the x gradient below
+      s.ml[e] = gpost * inv_var;  // reuse: (g wrt posterior logit) / s^2, for gx below
     }
     __syncthreads();
-    for (int e = tid; e < M * 6; e += NT) {  // gx[m][i] = -sum_o gpost (x - v) / s^2
-      const int m = e / 6, i = e - m * 6;
-      const size_t idx = (size_t)b * M + m;
+    // gx[m][i] = -sum_o gpost (x - v) / s^2: four lanes per output split the sum
+    // over o (their votes are in flight together), met by two shuffles
+    for (int t = tid; t < ((M * 6 * 4 + NT - 1) / NT) * NT; t += NT) {
+      const int e = t >> 2, part = t & 3;
+      const bool live = e < M * 6;
+      const int m = live ? e / 6 : 0, i = live ? e - m * 6 : 0;
       float acc = 0.f;
-      for (int o = 0; o < O; ++o) {
-        const size_t g = ((size_t)b * O + o) * M + m;
-        const float sc = a.scale[g];
-        acc -= s.ml[o * M + m] * (s.x[e] - a.vote[g * 6 + i]) / (sc * sc);
+      if (live) {
+        const float xv = s.x[e];
+#pragma unroll 6
+        for (int o = part; o < O; o += 4)
+          acc -= s.ml[o * M + m] * (xv - a.vote[(((size_t)b * O + o) * M + m) * 6 + i]);
       }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (!live || part != 0) continue;
+      const size_t idx = (size_t)b * M + m;
       gx[idx * 6 + i] = acc;
       const float ppd = expf(kLog001 + kLog001 - s.max_post[m]) / s.sum_post[m];
       gdummy[idx * 6 + i] = g_soft_winner ? g_soft_winner[idx * 6 + i] * ppd : 0.f;
