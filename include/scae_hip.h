@@ -275,6 +275,21 @@ int scae_conv3x3_first_fwd_f32(const float *img, const float *w, const float *bi
 int scae_conv3x3_first_wgrad_rows(int B, int Cout);
 int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img, float *partial, int B,
                                  int Cin, int IH, int IW, int Cout, int stride, void *stream);
+/* first_fwd / first_wgrad with riders: the parameter-only filter re-layouts of the
+ * following n_layers layers (arguments of scae_conv3x3_relayout_batch_f32), resp.
+ * the split reductions of their weight-gradient partials (arguments of
+ * scae_conv3x3_wgrad_reduce_batch_f32), run as extra workgroups of the same
+ * launch -- they are independent of the image layer.  n_layers = 0: no riders. */
+int scae_conv3x3_first_fwd_relayout_f32(const float *img, const float *w, const float *bias,
+                                        float *out, int B, int Cin, int IH, int IW, int Cout,
+                                        int stride, int n_layers, const float *const *rw,
+                                        float *const *rwf, float *const *rwd, const int *rCout,
+                                        const int *rCin, void *stream);
+int scae_conv3x3_first_wgrad_reduce_f32(const float *dpre, const float *img, float *partial,
+                                        int B, int Cin, int IH, int IW, int Cout, int stride,
+                                        int n_layers, const float *const *rpartial,
+                                        float *const *rdw, float *const *rdb, const int *rCout,
+                                        const int *rCin, const int *rsplits, void *stream);
 int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias, float *out,
                          const float *post_bias, float *out_post, int B, int IH, int IW,
                          int Cin, int Cout, int stride, void *stream);

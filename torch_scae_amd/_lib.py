@@ -114,6 +114,8 @@ SIGNATURES = {
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_relayout_batch_f32": [c_int, P, P, P, P, P, P],
     "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
+    "scae_conv3x3_first_fwd_relayout_f32": [P] * 4 + [c_int] * 7 + [P] * 6,
+    "scae_conv3x3_first_wgrad_reduce_f32": [P] * 3 + [c_int] * 7 + [P] * 7,
     "scae_conv3x3_first_wgrad_rows": [c_int] * 2,
     "scae_conv3x3_first_wgrad_f32": [P] * 3 + [c_int] * 6 + [P],
     "scae_conv3x3_fwd_f32": [P] * 6 + [c_int] * 6 + [P],

@@ -363,14 +363,16 @@ struct RelayoutBatch {
   float *wf[8], *wd[8];
   int Cout[8], Cin[8];
 };
-__global__ void relayout_batch_kernel(RelayoutBatch r) {
-  const int l = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void relayout_batch(const RelayoutBatch &r, int l, int e) {
   const int Cout = r.Cout[l], Cin = r.Cin[l];
   if (e >= Cout * Cin * 9) return;
   const int co = e / (Cin * 9), rem = e - co * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
   const float v = r.w[l][e];
   r.wf[l][((size_t)co * 9 + tap) * Cin + ci] = v;
   r.wd[l][((size_t)ci * 9 + tap) * Cout + co] = v;
+}
+__global__ void relayout_batch_kernel(RelayoutBatch r) {
+  relayout_batch(r, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // dW[co][ci][tap] = sum_split partial[(split*9+tap)][co][ci]; db[co] = sum_split bias partials
@@ -429,13 +431,22 @@ __device__ __forceinline__ void stage_image(float *s_img, const float *img, int 
 }
 
 // image NCHW (B,Cin,IH,IW), w [Cout][Cin][3][3] -> out NHWC, ReLU
+// Riders: the filter re-layouts of the following layers (RelayoutBatch, parameter-only,
+// independent of this layer) run as extra workgroups of the same launch: blocks
+// [n_first, n_first + n_layers * rb) with rb workgroups of 256 elements per layer.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__restrict__ img,
                                                              const float *__restrict__ w,
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out,
-                                                             ConvGeom g) {
+                                                             ConvGeom g, RelayoutBatch rl,
+                                                             int n_first, int rb) {
   extern __shared__ float s_img[];
+  if ((int)blockIdx.x >= n_first) {  // workgroup-uniform
+    const int w_ = (int)blockIdx.x - n_first;
+    relayout_batch(rl, w_ / rb, (w_ % rb) * 256 + threadIdx.x);
+    return;
+  }
   const FirstSplit f = first_split(g.B, g.Cout);
   const int n = blockIdx.x / f.slices, slice = blockIdx.x % f.slices;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -469,12 +480,21 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__rest
 
 // weight/bias gradient partials: partial[(n*slices + slice)*parts + part] = one row
 // [dW (Cout, CIN*9) | db (Cout)]; the caller sums the rows.
+// Riders: the split reductions of the other layers' weight-gradient partials
+// (ReduceBatch; they wait for the same kernels as this one) as extra workgroups.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__restrict__ dpre,
                                                                const float *__restrict__ img,
                                                                float *__restrict__ partial,
-                                                               ConvGeom g) {
+                                                               ConvGeom g, ReduceBatch rd,
+                                                               int n_first, int rb) {
   extern __shared__ float s_img[];
+  if ((int)blockIdx.x >= n_first) {  // workgroup-uniform
+    const int w_ = (int)blockIdx.x - n_first, l = w_ / rb;
+    reduce_wgrad(rd.partial[l], rd.dw[l], rd.db[l], rd.Cout[l], rd.Cin[l], rd.splits[l],
+                 (w_ % rb) * 256 + threadIdx.x);
+    return;
+  }
   constexpr int K1 = CIN * 9 + 1;
   const FirstSplit f = first_split(g.B, g.Cout);
   const int n = blockIdx.x / f.slices, slice = blockIdx.x % f.slices;
@@ -587,37 +607,53 @@ extern "C" int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, i
   return scae_launch_status();
 }
 
-extern "C" int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const *w,
-                                               float *const *wf, float *const *wd,
-                                               const int *Cout, const int *Cin, void *stream) {
-  SCAE_REQUIRE(n_layers > 0 && n_layers <= 8 && w && wf && wd && Cout && Cin);
-  RelayoutBatch r{};
+// fills a RelayoutBatch; returns the workgroups (of 256 elements) per layer or < 0
+static int fill_relayout(RelayoutBatch &r, int n_layers, const float *const *w, float *const *wf,
+                         float *const *wd, const int *Cout, const int *Cin) {
+  if (!(n_layers > 0 && n_layers <= 8 && w && wf && wd && Cout && Cin)) return -1;
   int nmax = 0;
   for (int l = 0; l < n_layers; ++l) {
-    SCAE_REQUIRE(w[l] && wf[l] && wd[l] && Cout[l] > 0 && Cin[l] > 0);
+    if (!(w[l] && wf[l] && wd[l] && Cout[l] > 0 && Cin[l] > 0)) return -1;
     r.w[l] = w[l], r.wf[l] = wf[l], r.wd[l] = wd[l], r.Cout[l] = Cout[l], r.Cin[l] = Cin[l];
     nmax = nmax > Cout[l] * Cin[l] * 9 ? nmax : Cout[l] * Cin[l] * 9;
   }
-  hipLaunchKernelGGL(relayout_batch_kernel, dim3((nmax + 255) / 256, n_layers), dim3(256), 0,
+  return (nmax + 255) / 256;
+}
+
+extern "C" int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const *w,
+                                               float *const *wf, float *const *wd,
+                                               const int *Cout, const int *Cin, void *stream) {
+  RelayoutBatch r{};
+  const int rb = fill_relayout(r, n_layers, w, wf, wd, Cout, Cin);
+  SCAE_REQUIRE(rb > 0);
+  hipLaunchKernelGGL(relayout_batch_kernel, dim3(rb, n_layers), dim3(256), 0,
                      (hipStream_t)stream, r);
   return scae_launch_status();
 }
 
-extern "C" int scae_conv3x3_first_fwd_f32(const float *img, const float *w, const float *bias,
-                                          float *out, int B, int Cin, int IH, int IW, int Cout,
-                                          int stride, void *stream) {
+extern "C" int scae_conv3x3_first_fwd_relayout_f32(
+    const float *img, const float *w, const float *bias, float *out, int B, int Cin, int IH,
+    int IW, int Cout, int stride, int n_layers, const float *const *rw, float *const *rwf,
+    float *const *rwd, const int *rCout, const int *rCin, void *stream) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, false);
   if (rc) return rc;
-  SCAE_REQUIRE(img && w && bias && out);
+  SCAE_REQUIRE(img && w && bias && out && n_layers >= 0);
   if (Cout % 64) return SCAE_ERR_UNSUPPORTED;
   const FirstSplit f = first_split(B, Cout);
   const size_t lds = (size_t)Cin * IH * IW * sizeof(float);
   if (lds > 64 * 1024) return SCAE_ERR_UNSUPPORTED;
-#define SCAE_FIRST_FWD(CI)                                                                   \
-  case CI:                                                                                   \
-    hipLaunchKernelGGL(conv_first_fwd_kernel<CI>, dim3(B * f.slices), dim3(256), lds,        \
-                       (hipStream_t)stream, img, w, bias, out, g);                           \
+  RelayoutBatch r{};
+  int rb = 0;
+  if (n_layers > 0) {
+    rb = fill_relayout(r, n_layers, rw, rwf, rwd, rCout, rCin);
+    SCAE_REQUIRE(rb > 0);
+  }
+  const int n_first = B * f.slices;
+#define SCAE_FIRST_FWD(CI)                                                                    \
+  case CI:                                                                                    \
+    hipLaunchKernelGGL(conv_first_fwd_kernel<CI>, dim3(n_first + n_layers * rb), dim3(256),   \
+                       lds, (hipStream_t)stream, img, w, bias, out, g, r, n_first, rb);       \
     break;
   switch (Cin) {
     SCAE_FIRST_FWD(1) SCAE_FIRST_FWD(2) SCAE_FIRST_FWD(3) SCAE_FIRST_FWD(4)
@@ -627,28 +663,59 @@ extern "C" int scae_conv3x3_first_fwd_f32(const float *img, const float *w, cons
   return scae_launch_status();
 }
 
+extern "C" int scae_conv3x3_first_fwd_f32(const float *img, const float *w, const float *bias,
+                                          float *out, int B, int Cin, int IH, int IW, int Cout,
+                                          int stride, void *stream) {
+  return scae_conv3x3_first_fwd_relayout_f32(img, w, bias, out, B, Cin, IH, IW, Cout, stride, 0,
+                                             nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
 extern "C" int scae_conv3x3_first_wgrad_rows(int B, int Cout) {
   if (B <= 0 || Cout <= 0 || Cout % 64) return 0;
   const FirstSplit f = first_split(B, Cout);
   return B * f.slices;
 }
 
-extern "C" int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img, float *partial,
-                                            int B, int Cin, int IH, int IW, int Cout, int stride,
-                                            void *stream) {
+// fills a ReduceBatch; returns the workgroups (of 256 elements) per layer or < 0
+static int fill_reduce(ReduceBatch &r, int n_layers, const float *const *partial,
+                       float *const *dw, float *const *db, const int *Cout, const int *Cin,
+                       const int *splits) {
+  if (!(n_layers > 0 && n_layers <= 8 && partial && dw && db && Cout && Cin && splits)) return -1;
+  int nmax = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!(partial[l] && dw[l] && Cout[l] > 0 && Cin[l] > 0 && splits[l] > 0)) return -1;
+    r.partial[l] = partial[l], r.dw[l] = dw[l], r.db[l] = db[l];
+    r.Cout[l] = Cout[l], r.Cin[l] = Cin[l], r.splits[l] = splits[l];
+    const int n = 9 * Cout[l] * Cin[l] + Cout[l];
+    nmax = nmax > n ? nmax : n;
+  }
+  return (nmax + 255) / 256;
+}
+
+extern "C" int scae_conv3x3_first_wgrad_reduce_f32(
+    const float *dpre, const float *img, float *partial, int B, int Cin, int IH, int IW,
+    int Cout, int stride, int n_layers, const float *const *rpartial, float *const *rdw,
+    float *const *rdb, const int *rCout, const int *rCin, const int *rsplits, void *stream) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, false);
   if (rc) return rc;
-  SCAE_REQUIRE(dpre && img && partial);
+  SCAE_REQUIRE(dpre && img && partial && n_layers >= 0);
   if (Cout % 64) return SCAE_ERR_UNSUPPORTED;
   const FirstSplit f = first_split(B, Cout);
   const size_t lds = ((size_t)Cin * IH * IW +
                       (f.parts > 1 ? (size_t)f.parts * Cout * (Cin * 9 + 1) : 0)) * sizeof(float);
   if (lds > 64 * 1024) return SCAE_ERR_UNSUPPORTED;
-#define SCAE_FIRST_WGRAD(CI)                                                                 \
-  case CI:                                                                                   \
-    hipLaunchKernelGGL(conv_first_wgrad_kernel<CI>, dim3(B * f.slices), dim3(256), lds,      \
-                       (hipStream_t)stream, dpre, img, partial, g);                          \
+  ReduceBatch r{};
+  int rb = 0;
+  if (n_layers > 0) {
+    rb = fill_reduce(r, n_layers, rpartial, rdw, rdb, rCout, rCin, rsplits);
+    SCAE_REQUIRE(rb > 0);
+  }
+  const int n_first = B * f.slices;
+#define SCAE_FIRST_WGRAD(CI)                                                                  \
+  case CI:                                                                                    \
+    hipLaunchKernelGGL(conv_first_wgrad_kernel<CI>, dim3(n_first + n_layers * rb), dim3(256), \
+                       lds, (hipStream_t)stream, dpre, img, partial, g, r, n_first, rb);      \
     break;
   switch (Cin) {
     SCAE_FIRST_WGRAD(1) SCAE_FIRST_WGRAD(2) SCAE_FIRST_WGRAD(3) SCAE_FIRST_WGRAD(4)
@@ -656,6 +723,14 @@ extern "C" int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img,
   }
 #undef SCAE_FIRST_WGRAD
   return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img, float *partial,
+                                            int B, int Cin, int IH, int IW, int Cout, int stride,
+                                            void *stream) {
+  return scae_conv3x3_first_wgrad_reduce_f32(dpre, img, partial, B, Cin, IH, IW, Cout, stride, 0,
+                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                             stream);
 }
 
 extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias,
@@ -789,17 +864,10 @@ extern "C" int scae_conv3x3_wgrad_reduce_batch_f32(int n_layers, const float *co
                                                    float *const *dw, float *const *db,
                                                    const int *Cout, const int *Cin,
                                                    const int *splits, void *stream) {
-  SCAE_REQUIRE(n_layers > 0 && n_layers <= 8 && partial && dw && db && Cout && Cin && splits);
   ReduceBatch r{};
-  int nmax = 0;
-  for (int l = 0; l < n_layers; ++l) {
-    SCAE_REQUIRE(partial[l] && dw[l] && Cout[l] > 0 && Cin[l] > 0 && splits[l] > 0);
-    r.partial[l] = partial[l], r.dw[l] = dw[l], r.db[l] = db[l];
-    r.Cout[l] = Cout[l], r.Cin[l] = Cin[l], r.splits[l] = splits[l];
-    const int n = 9 * Cout[l] * Cin[l] + Cout[l];
-    nmax = nmax > n ? nmax : n;
-  }
-  hipLaunchKernelGGL(reduce_wgrad_batch_kernel, dim3((nmax + 255) / 256, n_layers), dim3(256), 0,
+  const int rb = fill_reduce(r, n_layers, partial, dw, db, Cout, Cin, splits);
+  SCAE_REQUIRE(rb > 0);
+  hipLaunchKernelGGL(reduce_wgrad_batch_kernel, dim3(rb, n_layers), dim3(256), 0,
                      (hipStream_t)stream, r);
   return scae_launch_status();
 }

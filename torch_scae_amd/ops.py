@@ -545,20 +545,20 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
     c1, s = weights[0].shape[0], strides[0]
     oh, ow = (H - 3) // s + 1, (W - 3) // s + 1
     act = new(B, oh, ow, c1)
-    _lib.call("scae_conv3x3_first_fwd_f32", _p(image), _p(weights[0]),
-              _p(biases[0]), _p(act), B, C0, H, W, c1, s, st)
     acts, wds, wfs = [act], [], []
     for l in range(1, L):
         co, ci = weights[l].shape[0], weights[l].shape[1]
         wfs.append(new(co, 9, ci))
         wds.append(new(ci, 9, co))
-    if L > 1:       # every layer's filter re-layout in one launch
-        n = L - 1
-        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-        ints = lambda v: (ctypes.c_int * n)(*v)
-        _lib.call("scae_conv3x3_relayout_batch_f32", n, arr(weights[1:]),
-                  arr(wfs), arr(wds), ints([w.shape[0] for w in weights[1:]]),
-                  ints([w.shape[1] for w in weights[1:]]), st)
+    # the image layer; the (parameter-only) filter re-layouts of the other
+    # layers ride in the same launch
+    n = L - 1
+    arr = lambda ts: (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in ts])
+    ints = lambda v: (ctypes.c_int * max(n, 1))(*v)
+    _lib.call("scae_conv3x3_first_fwd_relayout_f32", _p(image), _p(weights[0]),
+              _p(biases[0]), _p(act), B, C0, H, W, c1, s, n, arr(weights[1:]),
+              arr(wfs), arr(wds), ints([w.shape[0] for w in weights[1:]]),
+              ints([w.shape[1] for w in weights[1:]]), st)
     x_post = None
     for l in range(1, L):
         w, s = weights[l], strides[l]
@@ -601,17 +601,18 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout):
         pending.append((partial, gw, gb, co, ci, splits))
         gws[l], gbs[l] = gw, gb
         dpre = din
-    if pending:
-        n = len(pending)
-        arr = lambda k: (ctypes.c_void_p * n)(*[p[k].data_ptr() for p in pending])
-        ints = lambda k: (ctypes.c_int * n)(*[p[k] for p in pending])
-        _lib.call("scae_conv3x3_wgrad_reduce_batch_f32", n, arr(0), arr(1),
-                  arr(2), ints(3), ints(4), ints(5), st)
     c1 = wshapes[0][0]
     k1 = C0 * 9 + 1
     partial = new(_lib.load().scae_conv3x3_first_wgrad_rows(B, c1), c1, k1)
-    _lib.call("scae_conv3x3_first_wgrad_f32", _p(dpre), _p(image),
-              _p(partial), B, C0, H, W, c1, strides[0], st)
+    # the image layer's weight-gradient partials; the split reductions of the
+    # other layers' partials ride in the same launch
+    n = len(pending)
+    arr = lambda k: (ctypes.c_void_p * max(n, 1))(
+        *[p[k].data_ptr() for p in pending])
+    ints = lambda k: (ctypes.c_int * max(n, 1))(*[p[k] for p in pending])
+    _lib.call("scae_conv3x3_first_wgrad_reduce_f32", _p(dpre), _p(image),
+              _p(partial), B, C0, H, W, c1, strides[0], n, arr(0), arr(1),
+              arr(2), ints(3), ints(4), ints(5), st)
     gws[0], gbs[0] = _sum_rows(partial.view(partial.shape[0], -1),
                                [(c1, C0, 3, 3), (c1,)],
                                outs=[gout(0), gout(L)])
