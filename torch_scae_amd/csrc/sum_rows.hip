@@ -32,19 +32,20 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(Jobs jobs) {
   const int PY = job.py, CX = NT / PY;
   const int cx = threadIdx.x % CX, py = threadIdx.x / CX;
   const long j = (long)((int)blockIdx.x - job.first_block) * CX + cx;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (j < cols) {
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j < cols) {  // eight loads in flight per thread: the kernel is latency bound
     const long per = (rows + PY - 1) / PY, r0 = py * per, r1 = min(rows, r0 + per);
     long r = r0;
-    for (; r + 4 <= r1; r += 4) {
-      s0 += src[r * cols + j];
-      s1 += src[(r + 1) * cols + j];
-      s2 += src[(r + 2) * cols + j];
-      s3 += src[(r + 3) * cols + j];
+    for (; r + 8 <= r1; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(r + u) * cols + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += v[u];
     }
-    for (; r < r1; ++r) s0 += src[r * cols + j];
+    for (; r < r1; ++r) acc[0] += src[r * cols + j];
   }
-  red[py * CX + cx] = (s0 + s1) + (s2 + s3);
+  red[py * CX + cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (py != 0 || j >= cols) return;
   float tot = 0.f;
@@ -107,9 +108,12 @@ extern "C" int scae_sum_rows_multi_f32(const scae_sum_job *jobs, int n_jobs, voi
       SCAE_REQUIRE(g.period >= 0 || (g.end - g.begin) % -g.period == 0);
     }
     // few rows: a thread per column; tall and skinny: many row parts per column
+#ifndef SCAE_SUMROWS_MID
+#define SCAE_SUMROWS_MID 4
+#endif
     job.py = in.rows <= 16 ? 1
              : (in.cols <= 8 && in.rows > 256) ? 64
-             : (in.rows <= 128 || in.cols >= 16384) ? 4 : 16;
+             : (in.rows <= 128 || in.cols >= 16384) ? SCAE_SUMROWS_MID : 16;
     const int cx = NT / job.py;
     job.first_block = blocks;
     blocks += (int)((in.cols + cx - 1) / cx);
