@@ -46,9 +46,16 @@ __global__ __launch_bounds__(64) void class_probs_kernel(
   __syncthreads();
   if (lane < 2 * ncls) {  // lane = (input, class): one logit each
     const int which = lane / ncls, c = lane - which * ncls;
-    float t = bias[c];
-    for (int o = 0; o < O; ++o) t = fmaf(s_x[which][o], w[c * O + o], t);
-    s_l[which][c] = t;
+    const float *wr = w + (size_t)c * O;  // four weight loads in flight
+    float t0 = bias[c], t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int o = 0;
+    for (; o + 4 <= O; o += 4) {
+      const float w0 = wr[o], w1 = wr[o + 1], w2 = wr[o + 2], w3 = wr[o + 3];
+      t0 = fmaf(s_x[which][o], w0, t0), t1 = fmaf(s_x[which][o + 1], w1, t1);
+      t2 = fmaf(s_x[which][o + 2], w2, t2), t3 = fmaf(s_x[which][o + 3], w3, t3);
+    }
+    for (; o < O; ++o) t0 = fmaf(s_x[which][o], wr[o], t0);
+    s_l[which][c] = (t0 + t1) + (t2 + t3);
   }
   __syncthreads();
   if (lane < 2 * ncls) {

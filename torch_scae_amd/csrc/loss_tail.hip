@@ -82,9 +82,17 @@ __device__ __forceinline__ float cls_xe(const TailArgs &a, const float *x, int l
                                         float &gl) {
   const bool on = lane < a.ncls;
   float z = -INFINITY;
-  if (on) {
-    z = a.cls_b[lane];
-    for (int o = 0; o < a.O; ++o) z = fmaf(x[o], a.cls_w[lane * a.O + o], z);
+  if (on) {  // four weight loads in flight (the row sits in L2, not in LDS)
+    const float *wr = a.cls_w + (size_t)lane * a.O;
+    float z0 = a.cls_b[lane], z1 = 0.f, z2 = 0.f, z3 = 0.f;
+    int o = 0;
+    for (; o + 4 <= a.O; o += 4) {
+      const float w0 = wr[o], w1 = wr[o + 1], w2 = wr[o + 2], w3 = wr[o + 3];
+      z0 = fmaf(x[o], w0, z0), z1 = fmaf(x[o + 1], w1, z1);
+      z2 = fmaf(x[o + 2], w2, z2), z3 = fmaf(x[o + 3], w3, z3);
+    }
+    for (; o < a.O; ++o) z0 = fmaf(x[o], wr[o], z0);
+    z = (z0 + z1) + (z2 + z3);
   }
   const float mx = scae::wave_max(z);
   float p = on ? expf(z - mx) : 0.f;
