@@ -582,13 +582,13 @@ struct WgradPlan {
 };
 WgradPlan wgrad_plan(int M, int Cin, int Cout) {
   // 64x64 tiles (half the L2 traffic per flop of the 32x32 shape); the grid is
-  // filled by splitting the pixel (K) dimension instead: >= 512 workgroups of
+  // filled by splitting the pixel (K) dimension instead: >= 768 workgroups of
   // >= 8 K chunks each, measured best on the encoder's 128-channel layers
   WgradPlan p;
   const long tiles64 = (long)(Cin / 64) * (Cout / 64) * 9;
   p.small = false;
 #ifndef SCAE_WGRAD_BLOCKS
-#define SCAE_WGRAD_BLOCKS 512
+#define SCAE_WGRAD_BLOCKS 768
 #endif
   long s = (SCAE_WGRAD_BLOCKS + tiles64 - 1) / tiles64;
   const long cap = (M / BK) / 8;
@@ -765,7 +765,15 @@ struct DgradLaunch {
   DgradPlan pl;
   int mode, gx, ny;
 };
-static DgradLaunch plan_dgrad(const ConvGeom &g) {
+// (pair = true: the launch also carries the weight-gradient tiles, so the data
+// gradient does not have to fill the chip on its own)
+#ifndef SCAE_PAIR_SMALL_TILES
+#define SCAE_PAIR_SMALL_TILES SCAE_SMALL_TILES
+#endif
+#ifndef SCAE_PAIR_WIDE_MIN
+#define SCAE_PAIR_WIDE_MIN 600
+#endif
+static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false) {
   DgradLaunch d;
   DgradPlan &pl = d.pl;
   pl.nrc = dgrad_axis(g.IH, g.OH, g.stride, pl.rmask, pl.rcount, pl.rstart, pl.rlist);
@@ -779,7 +787,9 @@ static DgradLaunch plan_dgrad(const ConvGeom &g) {
     pl.tile_start[pl.nrc * pl.ncc] = tot;
     return tot;
   };
-  d.mode = tile_mode((long)(g.Cin / 64) * tiles(64), (long)(g.Cin / 64) * tiles(32), 600);
+  const long t64 = (long)(g.Cin / 64) * tiles(64), t32 = (long)(g.Cin / 64) * tiles(32);
+  d.mode = pair ? (t64 >= SCAE_PAIR_SMALL_TILES ? 0 : (t32 >= SCAE_PAIR_WIDE_MIN ? 2 : 1))
+                : tile_mode(t64, t32, 600);
   d.ny = tiles(d.mode == 0 ? 64 : 32);
   d.gx = d.mode == 1 ? g.Cin / 32 : g.Cin / 64;
   return d;
@@ -813,7 +823,7 @@ extern "C" int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, con
   if (rc) return rc;
   SCAE_REQUIRE(dpre && wd && in && din && partial);
   if (IH > DG_MAXDIM || IW > DG_MAXDIM) return SCAE_ERR_UNSUPPORTED;
-  const DgradLaunch d = plan_dgrad(g);
+  const DgradLaunch d = plan_dgrad(g, true);
   const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
   const int wt = p.small ? 32 : 64;
   const PairGrid pg{d.gx * d.ny, d.gx, Cin / wt, Cout / wt};
