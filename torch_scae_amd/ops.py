@@ -667,6 +667,10 @@ def attention_pool_supported(HW, A, P):
     return bool(_lib.load().scae_attention_pool_supported(HW, A, P))
 
 
+# longest reduction (pixels) of one weight-gradient group of the 1x1 conv
+_CONV1X1_KMAX = int(__import__("os").environ.get("SCAE_CONV1X1_KMAX", "1024"))
+
+
 def _conv1x1_fwd(x, weight, bias):
     """y (B, HW, AP) = x (B, HW, C) weight^T + bias on the K7 GEMM."""
     B, HW, C = x.shape
@@ -689,7 +693,7 @@ def _conv1x1_bwd(x, weight, dy, gate=None, outs=None, raw_sum=None):
     # weight / bias gradient: dy^T x split over groups of images (the launch
     # also emits the column sums of dy), summed afterwards
     gsz = max(d for d in range(1, B + 1)
-              if B % d == 0 and (d == 1 or HW * d <= 256))
+              if B % d == 0 and (d == 1 or HW * d <= _CONV1X1_KMAX))
     S, kper, slab = B // gsz, HW * gsz, AP * C + AP
     part = torch.empty(S, slab, device=x.device, dtype=x.dtype)
     dx = torch.empty_like(x)
