@@ -468,14 +468,27 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
     }
 
     // ---- SAB blocks, last to first ----------------------------------------
+    // (a block's saved input sits in L2: when one element per thread covers it, the
+    // load for block l - 1 is issued while block l is being processed)
+    const bool one_pass = N * D <= NT;
+    float h_ahead = (one_pass && a.L > 0 && tid < N * D)
+                        ? hs[(size_t)(a.L - 1) * N * D + tid] : 0.f;
     for (int l = a.L - 1; l >= 0; --l) {
       const float *W = t.lw + l * lay.lds_layer_size();
       float *PG = t.pg + l * lay.layer_size();
       const float *hin = hs + (size_t)l * N * D;  // the block's input (global, L2)
-      for (int e = tid; e < N * D; e += NT) {
-        const float h = hin[e];
-        t.H()[(e / D) * TS + (e % D)] = h;
-        t.HIN()[(e / D) * TS + (e % D)] = h;
+      if (one_pass) {
+        if (tid < N * D) {
+          t.H()[(tid / D) * TS + (tid % D)] = h_ahead;
+          t.HIN()[(tid / D) * TS + (tid % D)] = h_ahead;
+          if (l > 0) h_ahead = hs[(size_t)(l - 1) * N * D + tid];
+        }
+      } else {
+        for (int e = tid; e < N * D; e += NT) {
+          const float h = hin[e];
+          t.H()[(e / D) * TS + (e % D)] = h;
+          t.HIN()[(e / D) * TS + (e % D)] = h;
+        }
       }
       __syncthreads();
       sab_forward<D, true>(lay, W, presence_b, N, a.sqrt_d, t);
