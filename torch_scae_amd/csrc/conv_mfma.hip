@@ -743,8 +743,14 @@ extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const floa
   SCAE_REQUIRE(in && wf && bias && out && (!out_post || post_bias));
   const int M = B * g.OH * g.OW;
   hipStream_t st = (hipStream_t)stream;
-  switch (tile_mode((long)(Cout / 64) * ((M + 63) / 64), (long)(Cout / 64) * ((M + 31) / 32),
-                    300)) {
+#ifndef SCAE_FWD_WIDE_MIN
+#define SCAE_FWD_WIDE_MIN 300
+#endif
+#ifndef SCAE_FWD_SMALL_TILES
+#define SCAE_FWD_SMALL_TILES SCAE_SMALL_TILES
+#endif
+  const long f64 = (long)(Cout / 64) * ((M + 63) / 64), f32 = (long)(Cout / 64) * ((M + 31) / 32);
+  switch (f64 >= SCAE_FWD_SMALL_TILES ? 0 : (f32 >= SCAE_FWD_WIDE_MIN ? 2 : 1)) {
     case 0:
       hipLaunchKernelGGL(conv_fwd_kernel<0>, dim3(Cout / 64, (M + 63) / 64), dim3(NT), 0, st, in,
                          wf, bias, out, post_bias, out_post, g);
