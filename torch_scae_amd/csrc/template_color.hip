@@ -47,23 +47,28 @@ __device__ __forceinline__ float nonlin_grad(float x, int kind) {
   return relu1_grad(x);
 }
 
+// w1 rows and h1 rows carry one float of padding: the MLP loops read w1[j][f] with
+// lanes over j and h1[m][j] with lanes over m -- unpadded strides of 16 / 32 floats
+// put all lanes of a wave on one or two LDS banks
 struct Lds {
   float *w1, *b1, *w2, *b2, *feat, *h1, *pre2;
+  int ldw, ldh;  // row strides of w1 (F + 1) and h1 (H1 + 1)
 };
 __device__ __forceinline__ Lds carve(float *base, const TcArgs &k, int M) {
   Lds l;
+  l.ldw = k.F + 1, l.ldh = k.H1 + 1;
   l.w1 = base;
-  l.b1 = l.w1 + k.H1 * k.F;
+  l.b1 = l.w1 + k.H1 * l.ldw;
   l.w2 = l.b1 + k.H1;
   l.b2 = l.w2 + k.C * k.H1;
   l.feat = l.b2 + k.C;
   l.h1 = l.feat + M * k.F;
-  l.pre2 = l.h1 + M * k.H1;
+  l.pre2 = l.h1 + M * l.ldh;
   return l;
 }
 inline size_t lds_floats(int M, int C, int F, int H1, bool bwd) {
-  size_t n = (size_t)H1 * F + H1 + (size_t)C * H1 + C + (size_t)M * F + (size_t)M * H1 +
-             (size_t)M * C;
+  size_t n = (size_t)H1 * (F + 1) + H1 + (size_t)C * H1 + C + (size_t)M * F +
+             (size_t)M * (H1 + 1) + (size_t)M * C;
   if (bwd) n += (size_t)M * C + (size_t)M * H1;  // g_pre2, g_h1
   return n;
 }
@@ -73,7 +78,7 @@ inline size_t lds_floats(int M, int C, int F, int H1, bool bwd) {
 __device__ __forceinline__ void mlp_forward(const Lds &l, const TcArgs &k, const float *feature,
                                             int M) {
   const int t = threadIdx.x;
-  for (int e = t; e < k.H1 * k.F; e += NT) l.w1[e] = k.w1[e];
+  for (int e = t; e < k.H1 * k.F; e += NT) l.w1[(e / k.F) * l.ldw + e % k.F] = k.w1[e];
   for (int e = t; e < k.H1; e += NT) l.b1[e] = k.b1[e];
   for (int e = t; e < k.C * k.H1; e += NT) l.w2[e] = k.w2[e];
   for (int e = t; e < k.C; e += NT) l.b2[e] = k.b2[e];
@@ -82,14 +87,14 @@ __device__ __forceinline__ void mlp_forward(const Lds &l, const TcArgs &k, const
   for (int e = t; e < M * k.H1; e += NT) {
     const int m = e / k.H1, j = e - m * k.H1;
     float s = l.b1[j];
-    for (int f = 0; f < k.F; ++f) s = fmaf(l.feat[m * k.F + f], l.w1[j * k.F + f], s);
-    l.h1[e] = fmaxf(s, 0.f);
+    for (int f = 0; f < k.F; ++f) s = fmaf(l.feat[m * k.F + f], l.w1[j * l.ldw + f], s);
+    l.h1[m * l.ldh + j] = fmaxf(s, 0.f);
   }
   __syncthreads();
   for (int e = t; e < M * k.C; e += NT) {
     const int m = e / k.C, c = e - m * k.C;
     float s = l.b2[c];
-    for (int j = 0; j < k.H1; ++j) s = fmaf(l.h1[m * k.H1 + j], l.w2[c * k.H1 + j], s);
+    for (int j = 0; j < k.H1; ++j) s = fmaf(l.h1[m * l.ldh + j], l.w2[c * k.H1 + j], s);
     l.pre2[e] = s;
   }
   __syncthreads();
@@ -152,13 +157,13 @@ __device__ __forceinline__ void tc_bwdA_body(const TcArgs &k, float *lds, int bl
     const int m = e / k.H1, j = e - m * k.H1;
     float s = 0.f;
     for (int c = 0; c < k.C; ++c) s = fmaf(g2[m * k.C + c], l.w2[c * k.H1 + j], s);
-    g1[e] = l.h1[e] > 0.f ? s : 0.f;
+    g1[e] = l.h1[m * l.ldh + j] > 0.f ? s : 0.f;
   }
   __syncthreads();
   for (int e = t; e < M * k.F; e += NT) {
     const int m = e / k.F, f = e - m * k.F;
     float s = 0.f;
-    for (int j = 0; j < k.H1; ++j) s = fmaf(g1[m * k.H1 + j], l.w1[j * k.F + f], s);
+    for (int j = 0; j < k.H1; ++j) s = fmaf(g1[m * k.H1 + j], l.w1[j * l.ldw + f], s);
     k.g_feature[cap0 * k.F + e] = s;
   }
   // per-workgroup weight-gradient partials: [dW1 | db1 | dW2 | db2]
@@ -173,7 +178,7 @@ __device__ __forceinline__ void tc_bwdA_body(const TcArgs &k, float *lds, int bl
       for (int m = 0; m < M; ++m) s += g1[m * k.H1 + e - n1];
     } else if (e < n3) {
       const int c = (e - n2) / k.H1, j = (e - n2) - c * k.H1;
-      for (int m = 0; m < M; ++m) s = fmaf(g2[m * k.C + c], l.h1[m * k.H1 + j], s);
+      for (int m = 0; m < M; ++m) s = fmaf(g2[m * k.C + c], l.h1[m * l.ldh + j], s);
     } else {
       for (int m = 0; m < M; ++m) s += g2[m * k.C + e - n3];
     }
