@@ -72,6 +72,33 @@ __device__ __forceinline__ float dot4(const float *a, const float *b, int n4) {
   return (a0 + a1) + (a2 + a3);
 }
 
+__device__ __forceinline__ float4 ld4s(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4s(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void fma4(float4 &acc, float s, const float4 &v) {
+  acc.x = fmaf(s, v.x, acc.x), acc.y = fmaf(s, v.y, acc.y);
+  acc.z = fmaf(s, v.z, acc.z), acc.w = fmaf(s, v.w, acc.w);
+}
+// a C-long dot product shared by 4 consecutive lanes, met by shuffles: lane `part`
+// takes the float4s part, part + 4, ... (interleaved, so that the four lanes read
+// consecutive 16-byte units: no bank conflict among them).  Needs C % 16 == 0.
+__device__ __forceinline__ float dot_quarter(const float *a, const float *b, int C, int part) {
+  const float4 *pa = reinterpret_cast<const float4 *>(a) + part;
+  const float4 *pb = reinterpret_cast<const float4 *>(b) + part;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+  for (int j = 0; j < C / 16; ++j) {
+    const float4 x = pa[4 * j], y = pb[4 * j];
+    a0 = fmaf(x.x, y.x, a0);
+    a1 = fmaf(x.y, y.y, a1);
+    a2 = fmaf(x.z, y.z, a2);
+    a3 = fmaf(x.w, y.w, a3);
+  }
+  float s = (a0 + a1) + (a2 + a3);
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  return s;
+}
+
 template <int D>
 struct Carve {
   float *h, *q, *wk, *wv, *bk, *bv, *K, *V, *S, *GO, *GS;
@@ -143,11 +170,24 @@ __device__ __forceinline__ void forward_core(const SaArgs &a, const Carve<D> &c,
   }
   __syncthreads();
   const float *pres = a.presence ? a.presence + (size_t)b * N : nullptr;
-  for (int e = tid; e < O * N; e += NT) {  // routing (set_transformer.py:40-43)
-    const int o = e / N, m = e - o * N;
-    float s = dot4(c.q + o * CS, c.K + m * CS, C / 4);
-    if (pres) s = s - (1.f - pres[m]) * 1e32f;
-    c.S[o * NS + m] = s / a.sqrt_c;
+  if ((C & 15) == 0) {  // routing (set_transformer.py:40-43): 4 lanes per logit
+    for (int t = tid; t < ((O * N * 4 + NT - 1) / NT) * NT; t += NT) {
+      const int e = t >> 2, part = t & 3;
+      const bool ok = e < O * N;
+      const int o = ok ? e / N : 0, m = ok ? e - o * N : 0;
+      float s = dot_quarter(c.q + o * CS, c.K + m * CS, C, part);
+      if (ok && part == 0) {
+        if (pres) s = s - (1.f - pres[m]) * 1e32f;
+        c.S[o * NS + m] = s / a.sqrt_c;
+      }
+    }
+  } else {
+    for (int e = tid; e < O * N; e += NT) {
+      const int o = e / N, m = e - o * N;
+      float s = dot4(c.q + o * CS, c.K + m * CS, C / 4);
+      if (pres) s = s - (1.f - pres[m]) * 1e32f;
+      c.S[o * NS + m] = s / a.sqrt_c;
+    }
   }
   __syncthreads();
   for (int e = tid; e < ((O * 16 + NT - 1) / NT) * NT; e += NT) {  // softmax, 16 lanes / row
@@ -194,16 +234,12 @@ __global__ __launch_bounds__(NT) void sa_fwd_kernel(SaArgs a) {
     if (a.probs)
       for (int e = tid; e < O * N; e += NT)
         a.probs[((size_t)b * a.O + o0) * N + e] = c.S[(e / N) * NS + (e % N)];
-    for (int e = tid; e < O * C; e += NT) {  // out = P V'
-      const int o = e / C, cc = e - o * C;
-      float a0 = 0.f, a1 = 0.f;
-      int m = 0;
-      for (; m + 1 < N; m += 2) {
-        a0 = fmaf(c.S[o * NS + m], c.V[m * CS + cc], a0);
-        a1 = fmaf(c.S[o * NS + m + 1], c.V[(m + 1) * CS + cc], a1);
-      }
-      if (m < N) a0 = fmaf(c.S[o * NS + m], c.V[m * CS + cc], a0);
-      a.out[((size_t)b * a.O + o0 + o) * C + cc] = a0 + a1;
+    const int C4 = C / 4;
+    for (int e = tid; e < O * C4; e += NT) {  // out = P V': four columns per thread
+      const int o = e / C4, c4 = 4 * (e - o * C4);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < N; ++m) fma4(acc, c.S[o * NS + m], ld4s(c.V + m * CS + c4));
+      st4s(a.out + ((size_t)b * a.O + o0 + o) * C + c4, acc);
     }
   }
 }
@@ -234,9 +270,19 @@ __global__ __launch_bounds__(NT) void sa_bwd_kernel(SaArgs a) {
     for (int e = tid; e < O * C; e += NT)
       c.GO[(e / C) * CS + (e % C)] = a.gout[((size_t)b * a.O + o0) * C + e];
     __syncthreads();
-    for (int e = tid; e < O * N; e += NT) {  // dL/dP
-      const int o = e / N, m = e - o * N;
-      c.GS[o * NS + m] = dot4(c.GO + o * CS, c.V + m * CS, C / 4);
+    if ((C & 15) == 0) {  // dL/dP: 4 lanes per entry
+      for (int t = tid; t < ((O * N * 4 + NT - 1) / NT) * NT; t += NT) {
+        const int e = t >> 2, part = t & 3;
+        const bool ok = e < O * N;
+        const int o = ok ? e / N : 0, m = ok ? e - o * N : 0;
+        const float s = dot_quarter(c.GO + o * CS, c.V + m * CS, C, part);
+        if (ok && part == 0) c.GS[o * NS + m] = s;
+      }
+    } else {
+      for (int e = tid; e < O * N; e += NT) {
+        const int o = e / N, m = e - o * N;
+        c.GS[o * NS + m] = dot4(c.GO + o * CS, c.V + m * CS, C / 4);
+      }
     }
     __syncthreads();
     for (int e = tid; e < ((O * 16 + NT - 1) / NT) * NT; e += NT) {  // softmax backward
@@ -259,53 +305,72 @@ __global__ __launch_bounds__(NT) void sa_bwd_kernel(SaArgs a) {
       }
     }
     // (V' is dead once dL/dP is known: its tile now receives dL/dV')
-    for (int e = tid; e < N * C; e += NT) {
-      const int m = e / C, cc = e - m * C;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int o = 0; o < O; ++o) acc = fmaf(c.S[o * NS + m], c.GO[o * CS + cc], acc);
-      c.V[m * CS + cc] = acc;
+    const int C4 = C / 4;  // (N x C) products below: four columns per thread
+    for (int e = tid; e < N * C4; e += NT) {
+      const int m = e / C4, c4 = 4 * (e - m * C4);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = 0; o < O; ++o) fma4(acc, c.S[o * NS + m], ld4s(c.GO + o * CS + c4));
+      st4s(c.V + m * CS + c4, acc);
     }
     __syncthreads();
-    for (int e = tid; e < O * C; e += NT) {  // dq (batch-invariant query): partial sum
-      const int o = e / C, cc = e - o * C;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int m = 0; m < N; ++m) acc = fmaf(c.GS[o * NS + m], c.K[m * CS + cc], acc);
-      p_gq[e] = first ? acc : p_gq[e] + acc;
+    for (int e = tid; e < O * C4; e += NT) {  // dq (batch-invariant query): partial sum
+      const int o = e / C4, c4 = 4 * (e - o * C4);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < N; ++m) fma4(acc, c.GS[o * NS + m], ld4s(c.K + m * CS + c4));
+      float *dst = p_gq + (size_t)o * C + c4;
+      if (!first) {
+        const float4 old = ld4s(dst);
+        acc.x += old.x, acc.y += old.y, acc.z += old.z, acc.w += old.w;
+      }
+      st4s(dst, acc);
     }
     __syncthreads();
-    for (int e = tid; e < N * C; e += NT) {  // dL/dK' into the K' tile
-      const int m = e / C, cc = e - m * C;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int o = 0; o < O; ++o) acc = fmaf(c.GS[o * NS + m], c.q[o * CS + cc], acc);
-      c.K[m * CS + cc] = acc;
+    for (int e = tid; e < N * C4; e += NT) {  // dL/dK' into the K' tile
+      const int m = e / C4, c4 = 4 * (e - m * C4);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = 0; o < O; ++o) fma4(acc, c.GS[o * NS + m], ld4s(c.q + o * CS + c4));
+      st4s(c.K + m * CS + c4, acc);
     }
     __syncthreads();
-    for (int e = tid; e < N * D; e += NT) {  // dh = dK' Wk2 + dV' Wvo
-      const int m = e / D, j = e - m * D;
-      float a0 = 0.f, a1 = 0.f;
+    // dh = dK' Wk2 + dV' Wvo: 8 lanes per entry, each an eighth of the C-long sums
+    for (int t = tid; t < ((N * D * 8 + NT - 1) / NT) * NT; t += NT) {
+      const int e = t >> 3, part = t & 7;
+      const bool ok = e < N * D;
+      const int m = ok ? e / D : 0, j = ok ? e - m * D : 0;
+      float a0 = 0.f, a1 = 0.f;  // lane `part` takes cc = part, part + 8, ... (interleaved)
 #pragma unroll 4
-      for (int cc = 0; cc < C; ++cc) {
+      for (int cc = part; cc < C; cc += 8) {
         a0 = fmaf(c.K[m * CS + cc], c.wk[cc * TS + j], a0);
         a1 = fmaf(c.V[m * CS + cc], c.wv[cc * TS + j], a1);
       }
-      gh[(size_t)b * N * D + e] = a0 + a1;
+      float sum = a0 + a1;
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      if (ok && part == 0) gh[(size_t)b * N * D + e] = sum;
     }
-    for (int e = tid; e < C * D; e += NT) {  // dWk2, dWvo (+ biases)
-      const int cc = e / D, j = e - cc * D;
-      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    constexpr int D4 = D / 4;
+    for (int e = tid; e < C * D4; e += NT) {  // dWk2, dWvo (+ biases): four columns per thread
+      const int cc = e / D4, j4 = 4 * (e - cc * D4);
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+      float b0 = 0.f, b1 = 0.f;
       for (int m = 0; m < N; ++m) {
-        const float gk = c.K[m * CS + cc], gv = c.V[m * CS + cc], hv = c.h[m * TS + j];
-        a0 = fmaf(gk, hv, a0);
-        a1 = fmaf(gv, hv, a1);
+        const float gk = c.K[m * CS + cc], gv = c.V[m * CS + cc];
+        const float4 hv = ld4s(c.h + m * TS + j4);
+        fma4(a0, gk, hv);
+        fma4(a1, gv, hv);
         b0 += gk;
         b1 += gv;
       }
-      p_gwk[e] = first ? a0 : p_gwk[e] + a0;
-      p_gwv[e] = first ? a1 : p_gwv[e] + a1;
-      if (j == 0) {
+      float *dk = p_gwk + (size_t)cc * D + j4, *dv = p_gwv + (size_t)cc * D + j4;
+      if (!first) {
+        const float4 ok_ = ld4s(dk), ov = ld4s(dv);
+        a0.x += ok_.x, a0.y += ok_.y, a0.z += ok_.z, a0.w += ok_.w;
+        a1.x += ov.x, a1.y += ov.y, a1.z += ov.z, a1.w += ov.w;
+      }
+      st4s(dk, a0);
+      st4s(dv, a1);
+      if (j4 == 0) {
         p_gbk[cc] = first ? b0 : p_gbk[cc] + b0;
         p_gbv[cc] = first ? b1 : p_gbv[cc] + b1;
       }
