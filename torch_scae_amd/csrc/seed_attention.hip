@@ -163,10 +163,34 @@ __device__ __forceinline__ void forward_core(const SaArgs &a, const Carve<D> &c,
   for (int e = tid; e < N * D; e += NT)
     c.h[(e / D) * TS + (e % D)] = a.h[(size_t)b * N * D + e];
   __syncthreads();
-  for (int e = tid; e < N * C; e += NT) {  // K' and V'
-    const int m = e / C, cc = e - m * C;
-    c.K[m * CS + cc] = c.bk[cc] + dot4(c.h + m * TS, c.wk + cc * TS, D / 4);
-    c.V[m * CS + cc] = c.bv[cc] + dot4(c.h + m * TS, c.wv + cc * TS, D / 4);
+  if (NT % C == 0) {  // K' and V': a thread keeps its column's two weight rows in registers
+    const int cc = tid % C;
+    float4 wkr[D / 4], wvr[D / 4];
+#pragma unroll
+    for (int j = 0; j < D / 4; ++j) {
+      wkr[j] = ld4s(c.wk + cc * TS + 4 * j);
+      wvr[j] = ld4s(c.wv + cc * TS + 4 * j);
+    }
+    const float bkc = c.bk[cc], bvc = c.bv[cc];
+    for (int m = tid / C; m < N; m += NT / C) {
+      float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < D / 4; ++j) {
+        const float4 hv = ld4s(c.h + m * TS + 4 * j);
+        k0 = fmaf(hv.x, wkr[j].x, k0), k1 = fmaf(hv.y, wkr[j].y, k1);
+        k0 = fmaf(hv.z, wkr[j].z, k0), k1 = fmaf(hv.w, wkr[j].w, k1);
+        v0 = fmaf(hv.x, wvr[j].x, v0), v1 = fmaf(hv.y, wvr[j].y, v1);
+        v0 = fmaf(hv.z, wvr[j].z, v0), v1 = fmaf(hv.w, wvr[j].w, v1);
+      }
+      c.K[m * CS + cc] = bkc + (k0 + k1);
+      c.V[m * CS + cc] = bvc + (v0 + v1);
+    }
+  } else {
+    for (int e = tid; e < N * C; e += NT) {
+      const int m = e / C, cc = e - m * C;
+      c.K[m * CS + cc] = c.bk[cc] + dot4(c.h + m * TS, c.wk + cc * TS, D / 4);
+      c.V[m * CS + cc] = c.bv[cc] + dot4(c.h + m * TS, c.wv + cc * TS, D / 4);
+    }
   }
   __syncthreads();
   const float *pres = a.presence ? a.presence + (size_t)b * N : nullptr;
