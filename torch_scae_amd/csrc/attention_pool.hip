@@ -66,21 +66,32 @@ __device__ __forceinline__ void stage_y(float *ys, const float *y, int HW, int A
   }
 }
 
-// mask[a][pix] = softmax over pixels of the capsule's logit channel
+// mask[a][pix] = softmax over pixels of the capsule's logit channel: 32 lanes per
+// capsule (a group of capsules is only a handful -- one thread each would leave the
+// workgroup waiting on 3 x HW serial LDS round trips)
 __device__ __forceinline__ void softmax_masks(float *mask, const float *ys, int HW, int A, int P,
                                               int APp) {
-  for (int a = threadIdx.x; a < A; a += NT) {
-    const float *col = ys + a * P + P - 1;
+  for (int t = threadIdx.x; t < ((A * 32 + NT - 1) / NT) * NT; t += NT) {
+    const int a = t >> 5, l = t & 31;
+    const bool ok = a < A;
+    const float *col = ys + (ok ? a : 0) * P + P - 1;
     float mx = -INFINITY;
-    for (int pix = 0; pix < HW; ++pix) mx = fmaxf(mx, col[pix * APp]);
+    if (ok)
+      for (int pix = l; pix < HW; pix += 32) mx = fmaxf(mx, col[pix * APp]);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     float s = 0.f;
-    for (int pix = 0; pix < HW; ++pix) {
-      const float e = expf(col[pix * APp] - mx);
-      mask[a * HW + pix] = e;
-      s += e;
-    }
+    if (ok)
+      for (int pix = l; pix < HW; pix += 32) {
+        const float e = expf(col[pix * APp] - mx);
+        mask[a * HW + pix] = e;
+        s += e;
+      }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float inv = 1.f / s;
-    for (int pix = 0; pix < HW; ++pix) mask[a * HW + pix] *= inv;
+    if (ok)
+      for (int pix = l; pix < HW; pix += 32) mask[a * HW + pix] *= inv;  // own elements
   }
 }
 
@@ -176,10 +187,14 @@ __global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
     t[e] = s;
   }
   __syncthreads();
-  for (int a = threadIdx.x; a < A; a += NT) {
+  for (int u = threadIdx.x; u < ((A * 32 + NT - 1) / NT) * NT; u += NT) {  // 32 lanes per capsule
+    const int a = u >> 5, l = u & 31;
     float s = 0.f;
-    for (int pix = 0; pix < HW; ++pix) s = fmaf(mask[a * HW + pix], t[a * HW + pix], s);
-    sa[a] = s;
+    if (a < A)
+      for (int pix = l; pix < HW; pix += 32) s = fmaf(mask[a * HW + pix], t[a * HW + pix], s);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (a < A && l == 0) sa[a] = s;
   }
   __syncthreads();
   float *dy = k.dy + (size_t)b * HW * ldy + a0 * P;
