@@ -38,6 +38,28 @@ def test_launchers_reject_bad_arguments_without_a_gpu():
                                           1, 65, 4, 4, 4, 2.0, None) == -2
     d = _lib.DecoderDesc()
     assert lib.scae_template_render_fwd_f32(d, None, None, None) == -1
+    # the launch-merging entry points: null pointers / empty job lists / bad sizes
+    assert lib.scae_qkv_attention_fwd_bf16(None, None, None, None, None, None,
+                                           1, 4, 4, 4, 4, 2.0, None) == -1
+    assert lib.scae_uniform_f32(None, 16, None, None) == -1
+    assert lib.scae_scaled_sums_f32(None, 1, None) == -1
+    assert lib.scae_sum_rows_multi_f32(None, 1, None) == -1
+    jobs = (_lib.SumJob * 5)()
+    assert lib.scae_sum_rows_multi_f32(jobs, 5, None) == -1          # > 4 jobs
+    assert lib.scae_stage_batch(None, None, 4, None, None, 0, None) == -1
+    assert lib.scae_conv3x3_bwd_pair_f32(None, None, None, None, None, 2, 9, 9,
+                                         64, 64, 1, None) == -1
+    assert lib.scae_conv3x3_first_fwd_relayout_f32(
+        None, None, None, None, 2, 1, 8, 8, 64, 1, 0, None, None, None, None,
+        None, None) == -1
+    assert lib.scae_conv3x3_first_wgrad_reduce_f32(
+        None, None, None, 2, 1, 8, 8, 64, 1, 0, None, None, None, None, None,
+        None, None) == -1
+    assert lib.scae_loss_tail_workspace_floats(128, 24, 10) == \
+        128 * 8 + 128 * 24 + 128 * 2 * 10 + 2 * 24
+    assert lib.scae_loss_tail_workspace_floats(0, 24, 10) == 0
+    assert lib.scae_class_probs_f32(None, None, None, None, None, None, 4, 8, 8,
+                                    4, None, 0, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():
