@@ -604,7 +604,10 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
         if (n < N) a0 = fmaf(gy[n * TS + i], xin[n * TS + j], a0);
         PG[lay.g_w(m) + rc] += a0 + a1;
       }
-      for (int e = tid; e < 5 * D; e += NT) {  // bias grads: column sums
+      // (the column-sum loops below go to the threads with one weight-gradient element
+      // less -- the upper half of the workgroup when 5 D D is not a multiple of NT)
+      for (int e = NT >= 5 * D + 256 ? tid - (NT - 5 * D) : tid; e >= 0 && e < 5 * D;
+           e += NT) {  // bias grads: column sums
         const int m = e / D, i = e - m * D;
         const int gi = m < 3 ? 14 + m : (m == 3 ? 12 : 6);
         const float *gy = t.tiles + gi * t.tile;
@@ -613,8 +616,8 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
         PG[lay.g_b(m) + i] += acc;
       }
       if (lay.ln) {  // LN gamma / beta: column sums of gy * xhat and gy
-        auto lngrad = [&](const float *gy, const float *xh, int off) {
-          for (int e = tid; e < 2 * D; e += NT) {
+        auto lngrad = [&](const float *gy, const float *xh, int off, int t0) {
+          for (int e = tid - t0; e >= 0 && e < 2 * D; e += NT) {
             const int beta = e / D, i = e - beta * D;
             float acc = 0.f;
             for (int n = 0; n < N; ++n)
@@ -622,8 +625,9 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
             PG[off + e] += acc;
           }
         };
-        lngrad(t.GH1(), t.XH0(), lay.g_ln0());
-        lngrad(G, t.XH1(), lay.g_ln1());
+        const int t0 = NT >= 5 * D + 256 ? 256 : 0;  // idle-ish threads, disjoint ranges
+        lngrad(t.GH1(), t.XH0(), lay.g_ln0(), t0);
+        lngrad(G, t.XH1(), lay.g_ln1(), t0 + (t0 ? 2 * D : 0));
       }
       __syncthreads();
       {  // next block's output gradient
