@@ -210,19 +210,42 @@ template <int D>
 __device__ __forceinline__ void stage_weights(const Layout<D> &lay, const float *params, const Tiles<D> &t) {
   constexpr int TS = D + 4;
   const int Din = lay.Din, DinS = lay.DinS();
+  // 16-byte copies when the packed layout allows (every row start a multiple of 4
+  // floats from a 16-byte aligned base): a quarter of the loads and index divisions
+  const bool vec = (Din & 3) == 0 && ((size_t)params & 15) == 0 &&
+                   (lay.off_layer(0) & 3) == 0 && (lay.layer_size() & 3) == 0;
+  if (vec) {
+    const int q = Din / 4, qs = DinS / 4;
+    for (int i = threadIdx.x; i < D * qs; i += NT) {
+      const int r = i / qs, c4 = i - r * qs;
+      reinterpret_cast<float4 *>(t.w1)[i] =
+          c4 < q ? reinterpret_cast<const float4 *>(params)[r * q + c4]
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
 #pragma unroll 4
-  for (int i = threadIdx.x; i < D * DinS; i += NT) {
-    const int r = i / DinS, c = i - r * DinS;
-    t.w1[i] = c < Din ? params[r * Din + c] : 0.f;
+    for (int i = threadIdx.x; i < D * DinS; i += NT) {
+      const int r = i / DinS, c = i - r * DinS;
+      t.w1[i] = c < Din ? params[r * Din + c] : 0.f;
+    }
   }
   for (int i = threadIdx.x; i < D; i += NT) t.b1[i] = params[lay.off_b1() + i];
   for (int l = 0; l < lay.L; ++l) {
     const float *g = params + lay.off_layer(l);
     float *w = t.lw + l * lay.lds_layer_size();
+    if (vec) {
+      constexpr int Q = D / 4;
+      for (int i = threadIdx.x; i < 5 * D * Q; i += NT) {
+        const int m = i / (D * Q), rq = i - m * D * Q, r = rq / Q, c4 = rq - r * Q;
+        *reinterpret_cast<float4 *>(w + lay.l_w(m) + r * TS + 4 * c4) =
+            *reinterpret_cast<const float4 *>(g + lay.g_w(m) + r * D + 4 * c4);
+      }
+    } else {
 #pragma unroll 4
-    for (int i = threadIdx.x; i < 5 * D * D; i += NT) {
-      const int m = i / (D * D), rc = i - m * D * D, r = rc / D, c = rc - r * D;
-      w[lay.l_w(m) + r * TS + c] = g[lay.g_w(m) + rc];
+      for (int i = threadIdx.x; i < 5 * D * D; i += NT) {
+        const int m = i / (D * D), rc = i - m * D * D, r = rc / D, c = rc - r * D;
+        w[lay.l_w(m) + r * TS + c] = g[lay.g_w(m) + rc];
+      }
     }
     for (int i = threadIdx.x; i < 5 * D; i += NT) {
       const int m = i / D, c = i - m * D;

@@ -53,6 +53,7 @@ class FlatParameters:
         # modules may ask for groups of parameters to lie back to back (in
         # the layout one of their kernels reads): move each group, in order,
         # to the position of its first member
+        aligned = set()      # group heads start on a 16-byte boundary
         for m in module.modules():
             for group in getattr(m, "_flat_param_groups", lambda: [])():
                 ids = {id(p) for p in group}
@@ -62,34 +63,37 @@ class FlatParameters:
                 first = min(i for i, p in enumerate(params) if id(p) in ids)
                 rest = [p for p in params if id(p) not in ids]
                 params = rest[:first] + list(group) + rest[first:]
+                aligned.add(id(group[0]))
         dev, dt = params[0].device, params[0].dtype
         for p in params:
             if p.device != dev or p.dtype != dt:
                 raise ValueError("all parameters must share device and dtype")
         self.params = params
-        total = sum(p.numel() for p in params)
-        self.flat_param = torch.empty(total, device=dev, dtype=dt)
+        # offsets (in elements); the few padding elements in front of an
+        # aligned group stay zero in both buffers
+        self.offsets, off = [], 0
+        for p in params:
+            if id(p) in aligned:
+                off = (off + 3) // 4 * 4
+            self.offsets.append(off)
+            off += p.numel()
+        total = off
+        self.flat_param = torch.zeros(total, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(total, device=dev, dtype=dt)
-        off = 0
         with torch.no_grad():
-            for p in params:
+            for p, off in zip(params, self.offsets):
                 n = p.numel()
                 self.flat_param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = None
                 p._scae_grad_slot = GradSlot(self.flat_grad, off, tuple(p.shape))
-                off += n
         self.numel = total
         self._views = None
 
     def grad_views(self):
         if self._views is None:
-            views, off = [], 0
-            for p in self.params:
-                n = p.numel()
-                views.append(self.flat_grad[off:off + n].view(p.shape))
-                off += n
-            self._views = views
+            self._views = [self.flat_grad[off:off + p.numel()].view(p.shape)
+                           for p, off in zip(self.params, self.offsets)]
         return self._views
 
     def clear_grads(self):
@@ -121,15 +125,14 @@ class FlatParameters:
         """[(offset, numel)] of the maximal runs of parameters that received a
         gradient in the last backward (torch optimisers skip ``grad is None``
         parameters altogether -- it matters with weight decay)."""
-        runs, off = [], 0
-        for p in self.params:
+        runs = []
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             if getattr(p, "_flat_was_set", True):
                 if runs and runs[-1][0] + runs[-1][1] == off:
                     runs[-1][1] += n
                 else:
                     runs.append([off, n])
-            off += n
         return [tuple(r) for r in runs]
 
 
