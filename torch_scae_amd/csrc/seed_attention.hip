@@ -138,20 +138,35 @@ template <int D>
 __device__ __forceinline__ void stage_common(const SaArgs &a, const Carve<D> &c, int o0, int Og) {
   constexpr int TS = D + 4;
   const int C = a.C, O = Og, tid = threadIdx.x;
+  const bool vec = (((size_t)a.wk | (size_t)a.wv | (size_t)a.q) & 15) == 0;  // C % 8 == 0
+  if (vec) {  // 16-byte copies: (C x D) dense rows -> TS-strided rows, q rows -> CS-strided
+    constexpr int Q = D / 4;
+    for (int e = tid; e < C * Q; e += NT) {
+      const int r = e / Q, j4 = 4 * (e - r * Q);
+      st4s(c.wk + r * TS + j4, ld4s(a.wk + (size_t)r * D + j4));
+      st4s(c.wv + r * TS + j4, ld4s(a.wv + (size_t)r * D + j4));
+    }
+    const int C4 = C / 4;
+    for (int e = tid; e < O * C4; e += NT) {
+      const int o = e / C4, c4 = 4 * (e - o * C4);
+      st4s(c.q + o * c.CS + c4, ld4s(a.q + ((size_t)o0 + o) * C + c4));
+    }
+  } else {
 #pragma unroll 4
-  for (int e = tid; e < C * D; e += NT) {
-    const int r = e / D, j = e - r * D;
-    c.wk[r * TS + j] = a.wk[e];
-    c.wv[r * TS + j] = a.wv[e];
+    for (int e = tid; e < C * D; e += NT) {
+      const int r = e / D, j = e - r * D;
+      c.wk[r * TS + j] = a.wk[e];
+      c.wv[r * TS + j] = a.wv[e];
+    }
+#pragma unroll 4
+    for (int e = tid; e < O * C; e += NT) {
+      const int o = e / C, cc = e - o * C;
+      c.q[o * c.CS + cc] = a.q[(size_t)o0 * C + e];
+    }
   }
   for (int e = tid; e < C; e += NT) {
     c.bk[e] = a.bk[e];
     c.bv[e] = a.bv[e];
-  }
-#pragma unroll 4
-  for (int e = tid; e < O * C; e += NT) {
-    const int o = e / C, cc = e - o * C;
-    c.q[o * c.CS + cc] = a.q[(size_t)o0 * C + e];
   }
 }
 
@@ -290,9 +305,19 @@ __global__ __launch_bounds__(NT) void sa_bwd_kernel(SaArgs a) {
   for (int b = blockIdx.x / a.splits; b < a.B; b += gridDim.x / a.splits) {
     __syncthreads();
     forward_core<D>(a, c, b, Og);  // recompute K', V', P
+    {
+      const float *go = a.gout + ((size_t)b * a.O + o0) * C;
+      if (((size_t)go & 15) == 0) {
+        const int C4 = C / 4;
+        for (int e = tid; e < O * C4; e += NT) {
+          const int o = e / C4, c4 = 4 * (e - o * C4);
+          st4s(c.GO + o * CS + c4, ld4s(go + (size_t)o * C + c4));
+        }
+      } else {
 #pragma unroll 4
-    for (int e = tid; e < O * C; e += NT)
-      c.GO[(e / C) * CS + (e % C)] = a.gout[((size_t)b * a.O + o0) * C + e];
+        for (int e = tid; e < O * C; e += NT) c.GO[(e / C) * CS + (e % C)] = go[e];
+      }
+    }
     __syncthreads();
     if ((C & 15) == 0) {  // dL/dP: 4 lanes per entry
       for (int t = tid; t < ((O * N * 4 + NT - 1) / NT) * NT; t += NT) {
