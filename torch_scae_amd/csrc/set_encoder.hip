@@ -664,10 +664,25 @@ __global__ __launch_bounds__(NT) void st_bwd_kernel(StArgs a) {
     for (int j0 = 0; j0 < Din; j0 += 128) {  // Din walked in 128-column chunks via LDS
       const int jn = min(128, Din - j0);
       __syncthreads();
+      {  // the chunk's columns segment by segment (no per-element table walk)
+        int c0 = 0;
+#pragma unroll
+        for (int sgi = 0; sgi < MAXSEG; ++sgi) {
+          if (sgi < a.nseg) {
+            const int w = a.seg[sgi].width;
+            const int lo = max(c0, j0), hi = min(c0 + w, j0 + jn), cw = hi - lo;
+            if (cw > 0) {  // workgroup-uniform
+              const float *src = a.seg[sgi].ptr + (size_t)b * a.seg[sgi].bs + (lo - c0);
+              const int rs = a.seg[sgi].rs;
 #pragma unroll 4
-      for (int e = tid; e < N * jn; e += NT) {
-        const int n = e / jn, jj = e - n * jn;
-        t.scr[n * 129 + jj] = load_x(a, b, n, j0 + jj);
+              for (int e = tid; e < N * cw; e += NT) {
+                const int n = e / cw, jj = e - n * cw;
+                t.scr[n * 129 + (lo - j0) + jj] = src[(size_t)n * rs + jj];
+              }
+            }
+            c0 += w;
+          }
+        }
       }
       __syncthreads();
       for (int e = tid; e < D * jn; e += NT) {  // dW1[i][j] = sum_n g[n][i] x[n][j]
