@@ -142,23 +142,6 @@ __device__ __forceinline__ float dot_col(const float *grow, const float *W, int 
   return a0 + a1;
 }
 
-// element (b, n, col) of the segmented input; static walk over the segment
-// table (a runtime-indexed kernel-argument array would be spilled to scratch)
-__device__ __forceinline__ float load_x(const StArgs &a, int b, int n, int col) {
-  float v = 0.f;
-  int c0 = 0;
-#pragma unroll
-  for (int s = 0; s < MAXSEG; ++s) {
-    if (s < a.nseg) {
-      const int w = a.seg[s].width;
-      if (col >= c0 && col < c0 + w)
-        v = a.seg[s].ptr[(size_t)b * a.seg[s].bs + (size_t)n * a.seg[s].rs + (col - c0)];
-      c0 += w;
-    }
-  }
-  return v;
-}
-
 template <int D>
 struct Tiles {  // LDS carve.  The (N x TS) activation tiles are addressed as
                 // base + index * tile so that only one pointer stays live
