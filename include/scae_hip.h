@@ -444,7 +444,9 @@ int scae_scaled_sums_f32(const scae_scaled_sum *jobs, int n_jobs, void *stream);
  *     (+ cv_ops.py:20-76 on OPR/OVR, the batched 3x3 product :189-191)
  *   all_param (B,O,A), A = 6V+6+1+2V, the output of the per-capsule MLPs,
  *     split as [cpr_dynamic 6V | cvr 6 | caps logit 1 | vote logit V |
- *     scale V] (:160-162).
+ *     scale V] (:160-162); consecutive capsule rows are ld_param >= A floats
+ *     apart (0 = A; a multiple of 4 lets the MLP GEMMs on either side use
+ *     16-byte accesses), the gradients of the backward pass likewise.
  *   cpr_static (O,V,6); bias_cvr (O,6); bias_caps (O); bias_vote (O,V);
  *   bias_scale (O,V)  (caps_bias_list, :108-111).
  *   noise_caps (B,O) / noise_vote (B,O,V): U[0,1) draws, nullable (no noise);
@@ -464,7 +466,7 @@ int scae_capsule_votes_fwd_f32(const float *all_param, const float *cpr_static,
                                float *vote_presence, float *logit_caps,
                                float *logit_vote, float *reg_partial,
                                float *caps_presence, int *caps_arg, int B, int O, int V,
-                               int similarity, int learn_vote_scale,
+                               int ld_param, int similarity, int learn_vote_scale,
                                int allow_deformations, void *stream);
 /* incoming grads (all nullable = zero): gvote (B,O,V,6) gscale (B,O,V)
  * gvote_presence (B,O,V) glogit_caps (B,O) glogit_vote (B,O,V);
@@ -485,7 +487,7 @@ int scae_capsule_votes_bwd_f32(const float *all_param, const float *cpr_static,
                                const float *glogit_caps, const float *glogit_vote,
                                const float *greg, const float *gcaps_presence,
                                const int *caps_arg, float *gall_param, float *gcpr_in,
-                               float *gall_param_gated, int B, int O, int V,
+                               float *gall_param_gated, int B, int O, int V, int ld_param,
                                int similarity, int learn_vote_scale,
                                int allow_deformations, void *stream);
 

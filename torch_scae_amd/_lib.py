@@ -142,9 +142,9 @@ SIGNATURES = {
     "scae_class_probs_supported": [c_int] * 2,
     "scae_class_probs_f32": [P] * 6 + [c_int] * 4 + [POINTER(ScaledSum), c_int, P],
     "scae_capsule_votes_fwd_f32": [P] * 8 + [c_float] + [P] * 8
-                                  + [c_int] * 6 + [P],
+                                  + [c_int] * 7 + [P],
     "scae_capsule_votes_bwd_f32": [P] * 8 + [c_float] + [P] * 11
-                                  + [c_int] * 6 + [P],
+                                  + [c_int] * 7 + [P],
     "scae_capsule_likelihood_fwd_f32": [P] * 17 + [c_int] * 3 + [P],
     "scae_capsule_likelihood_bwd_f32": [P] * 22 + [c_int] * 3 + [P],
     "scae_loss_tail_supported": [c_int] * 3,

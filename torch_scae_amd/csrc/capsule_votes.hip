@@ -79,6 +79,7 @@ struct VoteArgs {
   const float *noise_caps, *noise_vote;
   float noise_scale;
   int B, O, V, similarity, learn_vote_scale, allow_deformations;
+  int ldp;  // floats between consecutive capsule rows of all_param (and of its gradients), >= A
 };
 
 __global__ __launch_bounds__(NT) void votes_fwd_kernel(
@@ -87,8 +88,7 @@ __global__ __launch_bounds__(NT) void votes_fwd_kernel(
     float *__restrict__ logit_vote, float *__restrict__ reg_partial,
     float *__restrict__ caps_presence, int *__restrict__ caps_arg) {
   const int bo = blockIdx.x, o = bo % a.O, V = a.V, lane = threadIdx.x;
-  const int A = 8 * V + 7;
-  const float *ap = a.all_param + (size_t)bo * A;
+  const float *ap = a.all_param + (size_t)bo * a.ldp;
 
   // OVR (one per capsule): every lane computes it redundantly from 6 floats
   float cv[6];
@@ -159,12 +159,11 @@ __global__ __launch_bounds__(NT) void votes_bwd_kernel(
     const float *__restrict__ g_caps_presence, const int *__restrict__ caps_arg,
     float *__restrict__ gall_gated) {
   const int bo = blockIdx.x, o = bo % a.O, V = a.V, lane = threadIdx.x;
-  const int A = 8 * V + 7;
-  const float *ap = a.all_param + (size_t)bo * A;
-  float *ga = gall + (size_t)bo * A;
+  const float *ap = a.all_param + (size_t)bo * a.ldp;
+  float *ga = gall + (size_t)bo * a.ldp;
   // optional second copy zeroed where all_param <= 0: all_param is a ReLU
   // output, so this is the gradient w.r.t. the producing layer's pre-activation
-  float *gg = gall_gated ? gall_gated + (size_t)bo * A : nullptr;
+  float *gg = gall_gated ? gall_gated + (size_t)bo * a.ldp : nullptr;
   auto put = [&](int i, float v) {
     ga[i] = v;
     if (gg) gg[i] = ap[i] > 0.f ? v : 0.f;
@@ -251,7 +250,7 @@ int check_votes(const VoteArgs &a) {
   if (!a.all_param || !a.cpr_static || !a.bias_cvr || !a.bias_caps || !a.bias_vote ||
       !a.bias_scale)
     return SCAE_ERR_BAD_ARG;
-  if (a.B <= 0 || a.O <= 0 || a.V <= 0) return SCAE_ERR_BAD_ARG;
+  if (a.B <= 0 || a.O <= 0 || a.V <= 0 || a.ldp < 8 * a.V + 7) return SCAE_ERR_BAD_ARG;
   return SCAE_OK;
 }
 }  // namespace
@@ -262,10 +261,10 @@ extern "C" int scae_capsule_votes_fwd_f32(
     const float *noise_caps, const float *noise_vote, float noise_scale, float *vote,
     float *scale, float *vote_presence, float *logit_caps, float *logit_vote,
     float *reg_partial, float *caps_presence, int *caps_arg, int B, int O, int V,
-    int similarity, int learn_vote_scale, int allow_deformations, void *stream) {
+    int ld_param, int similarity, int learn_vote_scale, int allow_deformations, void *stream) {
   VoteArgs a{all_param, cpr_static, bias_cvr, bias_caps, bias_vote, bias_scale,
              noise_caps, noise_vote, noise_scale, B, O, V, similarity, learn_vote_scale,
-             allow_deformations};
+             allow_deformations, ld_param > 0 ? ld_param : 8 * V + 7};
   int rc = check_votes(a);
   if (rc) return rc;
   SCAE_REQUIRE(vote && scale && vote_presence && logit_caps && logit_vote && reg_partial);
@@ -283,11 +282,11 @@ extern "C" int scae_capsule_votes_bwd_f32(
     const float *gvote, const float *gscale, const float *gvote_presence,
     const float *glogit_caps, const float *glogit_vote, const float *greg,
     const float *gcaps_presence, const int *caps_arg, float *gall_param, float *gcpr_in,
-    float *gall_param_gated, int B, int O, int V, int similarity, int learn_vote_scale,
-    int allow_deformations, void *stream) {
+    float *gall_param_gated, int B, int O, int V, int ld_param, int similarity,
+    int learn_vote_scale, int allow_deformations, void *stream) {
   VoteArgs a{all_param, cpr_static, bias_cvr, bias_caps, bias_vote, bias_scale,
              noise_caps, noise_vote, noise_scale, B, O, V, similarity, learn_vote_scale,
-             allow_deformations};
+             allow_deformations, ld_param > 0 ? ld_param : 8 * V + 7};
   int rc = check_votes(a);
   if (rc) return rc;
   SCAE_REQUIRE(gall_param && gcpr_in && (!gcaps_presence || caps_arg));

@@ -84,7 +84,7 @@ class GroupedMLP(nn.Module):
         return [getattr(self, f"stacked_bias_{j}")
                 for j in range(self.n_layers)]
 
-    def forward(self, x, grad_pregated=False, x_is_relu=False):
+    def forward(self, x, grad_pregated=False, x_is_relu=False, pad_out=False):
         """``grad_pregated`` / ``x_is_relu``: private backward contracts of
         a fused chain (ops._GroupedMLP); HIP path only."""
         if x.is_cuda:      # batched fp32-MFMA GEMMs with fused bias / ReLU (K7)
@@ -92,8 +92,8 @@ class GroupedMLP(nn.Module):
             return ops.grouped_mlp(x, self.weights, self.biases,
                                    ones_input=self.ones_input,
                                    grad_pregated=grad_pregated,
-                                   x_is_relu=x_is_relu)
-        if grad_pregated or x_is_relu:
+                                   x_is_relu=x_is_relu, pad_out=pad_out)
+        if grad_pregated or x_is_relu or pad_out:
             raise ValueError("fused-chain gradient contracts need the HIP path")
         h = x.transpose(0, 1)                                  # (G, B, in)
         for j, w in enumerate(self.weights):

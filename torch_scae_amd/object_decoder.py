@@ -84,7 +84,7 @@ class CapsuleLayer(nn.Module):
         fused = feature.is_cuda
         raw_caps_param = self.mlps(feature, grad_pregated=fused)  # (B, O, D)
         all_param = self.caps_mlps(raw_caps_param, grad_pregated=fused,
-                                   x_is_relu=fused)               # (B, O, A)
+                                   x_is_relu=fused, pad_out=fused)  # (B, O, A)
         noise_caps = noise_vote = None
         if self.noise_type == 'uniform':
             proto = all_param.new_empty(B, self.n_caps, 1)

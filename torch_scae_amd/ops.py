@@ -1089,7 +1089,8 @@ class _GroupedMLP(torch.autograd.Function):
     gradient is gated by x > 0 in the epilogue of the data-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, ones_input, n_layers, grad_pregated, x_is_relu, *wb):
+    def forward(ctx, x, ones_input, n_layers, grad_pregated, x_is_relu,
+                pad_out, *wb):
         _need_hip(x, *wb)
         if x.stride(2) != 1:
             x = x.contiguous()
@@ -1104,8 +1105,12 @@ class _GroupedMLP(torch.autograd.Function):
             N, ldb = w.shape[1], w.shape[2]
             last = l == n_layers - 1
             if last:
-                out = torch.empty(B, G, N, device=x.device, dtype=x.dtype)
-                ldc, c_b = G * N, N
+                # pad_out: group rows padded to a multiple of 4 floats, so that
+                # this GEMM's stores and the consumers' loads are 16-byte wide
+                Np = (N + 3) // 4 * 4 if pad_out else N
+                out = torch.empty(B, G, Np, device=x.device,
+                                  dtype=x.dtype)[:, :, :N]
+                ldc, c_b = G * Np, Np
             else:
                 out = torch.empty(G, B, N, device=x.device, dtype=x.dtype)
                 ldc, c_b = N, B * N
@@ -1135,11 +1140,16 @@ class _GroupedMLP(torch.autograd.Function):
         acts = ctx.saved_tensors[1 + L:]
         B, G, Kin = x.shape
         dev, dt = x.device, x.dtype
-        # gradient w.r.t. the last pre-activation, layout (B, G, N)
-        gpre = gy.contiguous()
+        # gradient w.r.t. the last pre-activation, layout (B, G, N); the group
+        # rows may be padded (stride(1) >= N) when the consumer made them so
+        gpre = gy
         if not pregated:
-            gpre = torch.ops.aten.threshold_backward(gpre, acts[-1], 0.0)
-        g_ld, g_b = G * gpre.shape[2], gpre.shape[2]
+            gpre = torch.ops.aten.threshold_backward(gpre.contiguous(),
+                                                     acts[-1].contiguous(), 0.0)
+        if not (gpre.stride(2) == 1 and gpre.stride(1) >= gpre.shape[2]
+                and gpre.stride(0) == G * gpre.stride(1)):
+            gpre = gpre.contiguous()
+        g_ld, g_b = gpre.stride(0), gpre.stride(1)
         gws, gbs = [None] * L, [None] * L
         gx = None
         for l in range(L - 1, -1, -1):
@@ -1193,16 +1203,18 @@ class _GroupedMLP(torch.autograd.Function):
             gws[l] = gw
             if l > 0:
                 gpre, g_ld, g_b = gnext, K, B * K
-        return (gx, None, None, None, None, *gws, *gbs)
+        return (gx, None, None, None, None, None, *gws, *gbs)
 
 
 def grouped_mlp(x, weights, biases, ones_input=False, grad_pregated=False,
-                x_is_relu=False):
+                x_is_relu=False, pad_out=False):
     """ReLU MLPs of G independent groups; x (B, G, Kin) -> (B, G, N_last).
-    ``grad_pregated`` / ``x_is_relu``: see ``_GroupedMLP``."""
+    ``grad_pregated`` / ``x_is_relu``: see ``_GroupedMLP``.  ``pad_out``: the
+    result's group rows are padded to a multiple of 4 floats (a strided view;
+    for consumers that take a row stride, like ``capsule_votes``)."""
     biases = list(biases) if biases is not None else [None] * len(weights)
     return _GroupedMLP.apply(x, ones_input, len(weights), grad_pregated,
-                             x_is_relu, *weights, *biases)
+                             x_is_relu, pad_out, *weights, *biases)
 
 
 # ----------------------------------------------------------------------------
@@ -1218,8 +1230,14 @@ class _CapsuleVotes(torch.autograd.Function):
                   noise_caps, noise_vote)
         B, O, A = all_param.shape
         V = (A - 7) // 8
-        args = [_c(t) for t in (all_param, cpr_static, b_cvr, b_caps, b_vote,
-                                b_scale, noise_caps, noise_vote)]
+        # all_param may come with padded capsule rows (stride ldp >= A, see
+        # grouped_mlp(pad_out=True)); anything else is made dense
+        ldp = all_param.stride(1)
+        if not (all_param.stride(2) == 1 and ldp >= A
+                and all_param.stride(0) == O * ldp):
+            all_param, ldp = all_param.contiguous(), A
+        args = [all_param] + [_c(t) for t in (cpr_static, b_cvr, b_caps, b_vote,
+                                              b_scale, noise_caps, noise_vote)]
         dev, dt = all_param.device, all_param.dtype
         vote = torch.empty(B, O, V, 6, device=dev, dtype=dt)
         scale = torch.empty(B, O, V, device=dev, dtype=dt)
@@ -1230,7 +1248,7 @@ class _CapsuleVotes(torch.autograd.Function):
         reg_loss = torch.empty((), device=dev, dtype=dt)   # l2_loss(.)/B, :170
         caps_presence = torch.empty(B, O, device=dev, dtype=dt)
         caps_arg = torch.empty(B, O, device=dev, dtype=torch.int32)
-        flags = (B, O, V, int(similarity), int(learn_vote_scale),
+        flags = (B, O, V, ldp, int(similarity), int(learn_vote_scale),
                  int(allow_deformations))
         _lib.call("scae_capsule_votes_fwd_f32", *[_p(t) for t in args],
                   float(noise_scale), _p(vote), _p(scale), _p(vp), _p(lc),
@@ -1257,12 +1275,16 @@ class _CapsuleVotes(torch.autograd.Function):
         args.append(saved.pop(6) if ctx.has_noise[0] else None)
         args.append(saved[6] if ctx.has_noise[1] else None)
         all_param = args[0]
-        B, O, V = ctx.flags[:3]
-        gall = torch.empty_like(all_param)
+        B, O, V, ldp = ctx.flags[:4]
+        A = all_param.shape[2]
+        # gradients with all_param's (possibly padded) capsule rows
+        padded = lambda: torch.empty(B, O, ldp, device=all_param.device,  # noqa: E731
+                                     dtype=all_param.dtype)[:, :, :A]
+        gall = padded()
         # all_param = relu(.): hand the producer the gradient w.r.t. its
         # pre-activation (``grouped_mlp(grad_pregated=True)``); the bias
         # gradients below still need the ungated one
-        ggated = torch.empty_like(all_param) if ctx.param_is_relu else None
+        ggated = padded() if ctx.param_is_relu else None
         gin = torch.empty(B, O, V, 6, device=all_param.device,
                           dtype=all_param.dtype)
         grads = [_c(g) for g in (gvote, gscale, gvp, glc, glv, greg, gcp)]
@@ -1272,14 +1294,14 @@ class _CapsuleVotes(torch.autograd.Function):
                   _stream(all_param))
         # bias gradients: batch sums of column blocks of gall (B, O*A); each
         # capsule's block lands in its row of the (.., O, ..) parameter
-        A = all_param.shape[2]
         outs = [_grad_out(sl, t) for sl, t in zip(ctx.slots, args[1:6])]
+        gall_rows = torch.as_strided(gall, (B, O * ldp), (O * ldp, 1))
         (g_static,), (g_cvr, g_caps, g_vote, g_scale) = _sum_rows_multi([
             dict(partial=gin.view(B, -1), shapes=[args[1].shape],
                  outs=outs[:1]),
-            dict(partial=gall.view(B, O * A),
+            dict(partial=gall_rows,
                  shapes=[t.shape for t in args[2:6]],
-                 starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=A,
+                 starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=ldp,
                  outs=outs[1:])])
         return (gall if ggated is None else ggated, g_static, g_cvr, g_caps,
                 g_vote, g_scale, None, None, None, None, None, None, None, None)
