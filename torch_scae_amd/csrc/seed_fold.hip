@@ -10,8 +10,9 @@
 // library GEMM / GEMV / add launches (and twice as many in the backward pass)
 // they cost more than the attention itself.  Here: two launches forward, two
 // backward.
-//   fwd1: row c of Wk, Wv, Wq (one workgroup per row): [wkf|bkf], wv2e = Wv W2e + [0|bv], q[:,c]
-//   fwd2: row c of Wo: [wvf|bvf] = Wo wv2e + [0|bo]
+//   fwd stage 1: row blocks of Wk, Wv (NT/(D+1) rows per workgroup, W2e in LDS, a thread per
+//         (row, column)): [wkf|bkf], wv2e = Wv W2e + [0|bv]; one workgroup per column c of q
+//   fwd stage 2: row blocks of Wo: [wvf|bvf] = Wo wv2e + [0|bo]
 //   bwdA: column jobs, one workgroup per output column, threads over j:
 //         gv2e = Wo^T [g_wvf|g_bvf],  t1 = Wk^T [g_wkf|g_bkf],  d_seeds = g_q Wq
 //   bwdB: row jobs (outer products, K = O or D+1): d_Wq, d_Wk, d_Wo, d_Wv and
@@ -21,97 +22,90 @@
 namespace {
 constexpr int NT = 256;
 
-// Row job (workgroup = one row c of the C x C matrices, 256 threads over j):
-// sums[v][d] = sum_j rows[v][j] * ext[j][d] for NV rows at once, ext = [mat | col]
-// (C x (D+1)); the D+1 per-thread products are reduced wave-wide, then across
-// the 4 waves through `red` (NV * (D+1) * 4 floats).  Results valid for
-// threads t < NV*(D+1): value index t = v*(D+1) + d.
-template <int D, int NV>
-__device__ __forceinline__ float rows_times_ext(const float *const (&rows)[NV], const float *mat,
-                                                int mat_ld, const float *col, int C, float *red) {
-  constexpr int DP = D + 1;
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  float acc[NV][DP];
-#pragma unroll
-  for (int v = 0; v < NV; ++v)
-#pragma unroll
-    for (int d = 0; d < DP; ++d) acc[v][d] = 0.f;
-  for (int j = t; j < C; j += NT) {
-    float e[DP];
-#pragma unroll
-    for (int d = 0; d < D; ++d) e[d] = mat[(size_t)j * mat_ld + d];
-    e[D] = col ? col[j] : mat[(size_t)j * mat_ld + D];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const float r = rows[v][j];
-#pragma unroll
-      for (int d = 0; d < DP; ++d) acc[v][d] = fmaf(r, e[d], acc[v][d]);
-    }
+// Row-block job: out[r][d] = sum_j W[row0 + r][j] * ext[j][d] for R = NT / (D+1) rows
+// and all D+1 columns at once.  ext (C x (D+1)) and the R rows sit in LDS; thread
+// (r, d) keeps its own sum -- no cross-lane reduction (the earlier one-workgroup-per-
+// row version spent its time wave-reducing 34 partial sums per thread).
+template <int D, class Store>
+__device__ __forceinline__ void rows_block(const float *W, int C, const float *mat, int mat_ld,
+                                           const float *col, int row0, float *lds, Store store) {
+  constexpr int DP = D + 1, R = NT / DP;
+  const int t = threadIdx.x, nrows = min(R, C - row0);
+  float *ext = lds, *rows = lds + C * DP;
+  for (int e = t; e < C * DP; e += NT) {
+    const int jj = e / DP, d = e - jj * DP;
+    ext[e] = d < D ? mat[(size_t)jj * mat_ld + d] : (col ? col[jj] : mat[(size_t)jj * mat_ld + D]);
   }
-#pragma unroll
-  for (int v = 0; v < NV; ++v)
-#pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      const float s = scae::wave_sum(acc[v][d]);
-      if (lane == 0) red[(v * DP + d) * 4 + wave] = s;
-    }
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(W + (size_t)row0 * C);  // C % 64 == 0
+    for (int e = t; e < nrows * C / 4; e += NT) reinterpret_cast<float4 *>(rows)[e] = src[e];
+  }
   __syncthreads();
-  float out = 0.f;
-  if (t < NV * DP) out = (red[t * 4] + red[t * 4 + 1]) + (red[t * 4 + 2] + red[t * 4 + 3]);
-  return out;
+  if (t >= nrows * DP) return;
+  const int r = t / DP, d = t - r * DP;
+  const float *wr = rows + r * C;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int jj = 0; jj < C; jj += 4) {  // C % 64 == 0
+    const float4 w = *reinterpret_cast<const float4 *>(wr + jj);
+    a0 = fmaf(w.x, ext[(jj + 0) * DP + d], a0);
+    a1 = fmaf(w.y, ext[(jj + 1) * DP + d], a1);
+    a2 = fmaf(w.z, ext[(jj + 2) * DP + d], a2);
+    a3 = fmaf(w.w, ext[(jj + 3) * DP + d], a3);
+  }
+  store(row0 + r, d, (a0 + a1) + (a2 + a3));
 }
 
+// stage 1: blocks [0, nb): rows of Wk -> [wkf | bkf]; [nb, 2 nb): rows of Wv -> wv2e
+// (+ [0 | bv]); then one block per column c of q = seeds Wq^T + bq.
+// stage 2: blocks [0, nb): rows of Wo against wv2e -> [wvf | bvf].
 template <int D>
-__global__ __launch_bounds__(NT) void fold_fwd1_kernel(scae_seed_fold_desc a) {
-  constexpr int DP = D + 1;
-  __shared__ float red[2 * DP * 4];
-  const int c = blockIdx.x, t = threadIdx.x, C = a.C;
-  const float *const rows[2] = {a.wk + (size_t)c * C, a.wv + (size_t)c * C};
-  const float s = rows_times_ext<D, 2>(rows, a.w2, D, a.b2, C, red);
-  if (t < 2 * DP) {
-    const int v = t / DP, d = t - v * DP;
-    if (v == 0) {
+__global__ __launch_bounds__(NT) void fold_fwd_kernel(scae_seed_fold_desc a, int stage, int nb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int DP = D + 1, R = NT / DP;
+  const int t = threadIdx.x, C = a.C, blk = blockIdx.x;
+  if (stage == 2) {
+    rows_block<D>(a.wo, C, a.wv2e, DP, nullptr, blk * R, lds, [&](int c, int d, float s) {
+      if (d < D)
+        a.wvf[c * D + d] = s;
+      else
+        a.bvf[c] = s + a.bo[c];
+    });
+    return;
+  }
+  if (blk < nb) {
+    rows_block<D>(a.wk, C, a.w2, D, a.b2, blk * R, lds, [&](int c, int d, float s) {
       if (d < D)
         a.wkf[c * D + d] = s;
       else
         a.bkf[c] = s + a.bk[c];
-    } else {
+    });
+    return;
+  }
+  if (blk < 2 * nb) {
+    rows_block<D>(a.wv, C, a.w2, D, a.b2, (blk - nb) * R, lds, [&](int c, int d, float s) {
       a.wv2e[c * DP + d] = d < D ? s : s + a.bv[c];
-    }
+    });
+    return;
   }
   // q[:, c] = seeds Wq[c, :]^T + bq[c]: 8 lanes per seed o, each an 8-strided
   // slice of j, so that all loads of the dot product are in flight at once
+  const int c = blk - 2 * nb;
   const float *wq = a.wq + (size_t)c * C;
   const int sub = t & 7;
   for (int o = t >> 3; o < a.O; o += NT / 8) {
     const float *sd = a.seeds + (size_t)o * C;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-    for (int j = sub; j < C; j += 32) {  // C % 64 == 0
-      p0 = fmaf(wq[j], sd[j], p0);
-      p1 = fmaf(wq[j + 8], sd[j + 8], p1);
-      p2 = fmaf(wq[j + 16], sd[j + 16], p2);
-      p3 = fmaf(wq[j + 24], sd[j + 24], p3);
+    for (int jj = sub; jj < C; jj += 32) {  // C % 64 == 0
+      p0 = fmaf(wq[jj], sd[jj], p0);
+      p1 = fmaf(wq[jj + 8], sd[jj + 8], p1);
+      p2 = fmaf(wq[jj + 16], sd[jj + 16], p2);
+      p3 = fmaf(wq[jj + 24], sd[jj + 24], p3);
     }
-    float r = (p0 + p1) + (p2 + p3);
-    r += __shfl_xor(r, 1, 64);
-    r += __shfl_xor(r, 2, 64);
-    r += __shfl_xor(r, 4, 64);
-    if (sub == 0) a.q[(size_t)o * C + c] = r + a.bq[c];
-  }
-}
-
-template <int D>
-__global__ __launch_bounds__(NT) void fold_fwd2_kernel(scae_seed_fold_desc a) {
-  constexpr int DP = D + 1;
-  __shared__ float red[DP * 4];
-  const int c = blockIdx.x, t = threadIdx.x, C = a.C;
-  const float *const rows[1] = {a.wo + (size_t)c * C};
-  const float s = rows_times_ext<D, 1>(rows, a.wv2e, DP, nullptr, C, red);
-  if (t < DP) {
-    if (t < D)
-      a.wvf[c * D + t] = s;
-    else
-      a.bvf[c] = s + a.bo[c];
+    float rr = (p0 + p1) + (p2 + p3);
+    rr += __shfl_xor(rr, 1, 64);
+    rr += __shfl_xor(rr, 2, 64);
+    rr += __shfl_xor(rr, 4, 64);
+    if (sub == 0) a.q[(size_t)o * C + c] = rr + a.bq[c];
   }
 }
 
@@ -233,18 +227,30 @@ int check(const scae_seed_fold_desc *a) {
 }  // namespace
 
 extern "C" int scae_seed_fold_supported(int O, int C, int D) {
-  return O > 0 && O <= 64 && C >= 64 && C % 64 == 0 && C <= 1024 && (D == 8 || D == 16 || D == 32);
+  if (!(O > 0 && O <= 64 && C >= 64 && C % 64 == 0 && C <= 1024 && (D == 8 || D == 16 || D == 32)))
+    return 0;
+  // LDS of a forward row block: ext (C x (D+1)) + NT / (D+1) rows of C floats
+  return ((size_t)C * (D + 1) + (size_t)(NT / (D + 1)) * C) * sizeof(float) <= 160 * 1024;
 }
 
 extern "C" int scae_seed_fold_fwd_f32(const scae_seed_fold_desc *desc, void *stream) {
   int rc = check(desc);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-#define SCAE_FOLD_FWD(DD)                                                              \
-  case DD:                                                                             \
-    hipLaunchKernelGGL(fold_fwd1_kernel<DD>, dim3(desc->C), dim3(NT), 0, st, *desc);   \
-    hipLaunchKernelGGL(fold_fwd2_kernel<DD>, dim3(desc->C), dim3(NT), 0, st, *desc);   \
-    break;
+#define SCAE_FOLD_FWD(DD)                                                                  \
+  case DD: {                                                                               \
+    constexpr int R = NT / (DD + 1);                                                       \
+    const int nb = (desc->C + R - 1) / R;                                                  \
+    const size_t lds = ((size_t)desc->C * (DD + 1) + (size_t)R * desc->C) * sizeof(float); \
+    if (lds > 48 * 1024) {                                                                 \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fold_fwd_kernel<DD>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                  \
+    }                                                                                      \
+    hipLaunchKernelGGL(fold_fwd_kernel<DD>, dim3(2 * nb + desc->C), dim3(NT), lds, st, *desc, 1, \
+                       nb);                                                                \
+    hipLaunchKernelGGL(fold_fwd_kernel<DD>, dim3(nb), dim3(NT), lds, st, *desc, 2, nb);    \
+  } break;
   switch (desc->D) {
     SCAE_FOLD_FWD(8) SCAE_FOLD_FWD(16) SCAE_FOLD_FWD(32)
     default: return SCAE_ERR_UNSUPPORTED;
