@@ -636,6 +636,7 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
         // lo / hi are clamped into [j_lo, j_hi] (fmaxf / fminf drop NaNs)
         const int jl = (int)ceilf(lo), jh = (int)floorf(hi);
         const float *g_row = s_g + (i - r0) * W;
+#pragma unroll 4
         for (int j = jl; j <= jh; ++j) {
           const float wx = 1.f - fabsf(fmaf(ax, (float)j, rx));
           const float wy = 1.f - fabsf(fmaf(ay, (float)j, ry));
