@@ -432,14 +432,14 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
   const Scalars sc = load_scalars(d);
   const float inv_T = 1.f / sc.temperature;
   const float inv_w = 1.f / (float)W, inv_h = 1.f / (float)H;
-  const int npc = rows_per_chunk * W;  // pixels per chunk (LDS plane stride)
 
   const int psz = pad_elems(th, tw), pw = pad_w(tw);
   float *s_tmpl = smem;                        // C padded planes
   float *s_alpha = s_tmpl + C * psz;           // one padded plane
   float *s_acc = s_alpha + psz;                // SLICES * (C+1) * tsz
   float *s_red = s_acc + SLICES * (C + 1) * tsz;  // 11 * (NT/64)
-  float *s_g = s_red + 11 * (NT / 64);         // (C+1) * npc: per-pixel grads
+  float *s_g = s_red + 11 * (NT / 64);         // (C+1) * npc: per-pixel grads, [pixel][C+1]
+  const bool g_pair_ok = ((size_t)s_g & 7) == 0;  // 8-byte reads of a pixel's pair (C == 1)
 
   const bool is_bg = (k == M);
   float a[6] = {0, 0, 0, 0, 0, 0};
@@ -562,9 +562,9 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
         for (int c = 0; c < C; ++c) {
           gix += gtt[c] * tdx[c];
           giy += gtt[c] * tdy[c];
-          s_g[c * npc + pl] = gtt[c];
+          s_g[pl * (C + 1) + c] = gtt[c];
         }
-        if (alpha_mode) s_g[C * npc + pl] = gml_alpha;
+        if (alpha_mode) s_g[pl * (C + 1) + C] = gml_alpha;
         gix *= sx;
         giy *= sy;
         acc[0] += gix * t.xn;
@@ -635,15 +635,25 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
         }
         // lo / hi are clamped into [j_lo, j_hi] (fmaxf / fminf drop NaNs)
         const int jl = (int)ceilf(lo), jh = (int)floorf(hi);
-        const float *g_row = s_g + (i - r0) * W;
+        // per-pixel gradients are interleaved ([pixel][C + 1]): one LDS read per pair;
+        // the sample offsets advance by (ax, ay) per pixel instead of being re-derived
+        const float *gp = s_g + ((i - r0) * W + jl) * (C + 1);
+        float px = fmaf(ax, (float)jl, rx), py = fmaf(ay, (float)jl, ry);
 #pragma unroll 4
         for (int j = jl; j <= jh; ++j) {
-          const float wx = 1.f - fabsf(fmaf(ax, (float)j, rx));
-          const float wy = 1.f - fabsf(fmaf(ay, (float)j, ry));
-          const float wgt = fmaxf(wx, 0.f) * fmaxf(wy, 0.f);
+          const float wgt = fmaxf(1.f - fabsf(px), 0.f) * fmaxf(1.f - fabsf(py), 0.f);
+          if (C == 1 && g_pair_ok) {
+            const float2 g2 = *reinterpret_cast<const float2 *>(gp);
+            gsum[0] = fmaf(wgt, g2.x, gsum[0]);
+            if (planes > 1) gsum[1] = fmaf(wgt, g2.y, gsum[1]);
+          } else {
 #pragma unroll
-          for (int c = 0; c <= C; ++c)
-            if (c < planes) gsum[c] = fmaf(wgt, g_row[c * npc + j], gsum[c]);
+            for (int c = 0; c <= C; ++c)
+              if (c < planes) gsum[c] = fmaf(wgt, gp[c], gsum[c]);
+          }
+          gp += C + 1;
+          px += ax;
+          py += ay;
         }
       }
 #pragma unroll
