@@ -5,7 +5,10 @@ MNIST-shaped batches, BASELINE.json's metric / configs[1]:
 MNIST 40x40, 24 part / 24 object capsules, bs=128 per GPU, fp32.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N>1 works both ways: under `python -m torch.distributed.run --nproc-per-node N
+  ... bench.py --gpus N` (RANK/WORLD_SIZE in the environment) and bare
+  (`python bench.py --gpus N`): the bare parent starts N fresh rank processes
+  itself -- before anything touches the GPU -- and relays rank 0's JSON line.
 
 Prints ONE JSON line on rank 0 (contract in the task brief), extended with
   roofline     : the dominant hand-written kernel (K8 conv data gradient) timed
@@ -72,7 +75,65 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--force-spawn", action="store_true",
+                    help="take the rank-launcher + RCCL process-group path even "
+                         "for --gpus 1 (a 1-rank nccl group; proves the N>1 "
+                         "plumbing on a 1-GPU box)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: one all-reduce after the whole backward instead "
+                         "of the bucketed one that overlaps the encoder backward")
     return ap.parse_args()
+
+
+def metric_name(workload):
+    """BASELINE.json's metric, with the workload's own image / batch size."""
+    m = CONFIGS[workload]
+    C, H, W = m["model"]["image_shape"]
+    data = "MNIST" if C == 1 else "CIFAR-10"
+    return (f"images/sec SCAE fwd+bwd, {data} {H}x{W} bs={m['batch']}, "
+            f"1/2/4/8 MI355X")
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes
+    (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) from this
+    process, which has not touched the GPU (no exec of a GPU-initialised
+    process anywhere), relay rank 0's stdout, fail if any rank fails."""
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0):
+                failed = p.returncode
+        time.sleep(0.05)
+    if failed is not None:          # a rank died: the others would wait forever
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out = procs[0].stdout.read().decode()
+    for p in procs:
+        p.wait()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    codes = [p.returncode for p in procs]
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
 
 
 def build_model(cfg, seed):
@@ -342,19 +403,27 @@ def cpu_baseline(cfg, steps):
 # ----------------------------------------------------------------------------
 def main():
     args = parse()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_spawn):
+        return launch_ranks(args)       # nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch "
-                         f"with torch.distributed.run --nproc-per-node "
-                         f"{args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    collective = world > 1 or args.force_spawn
+    rccl_ranks = None
+    if collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device, rank=rank,
+                                world_size=world)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)           # how many ranks RCCL really connects
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world
 
     from torch_scae_amd.train_step import TrainStep
     cfg = CONFIGS[args.workload]
@@ -364,7 +433,8 @@ def main():
                      use_graph=not args.no_graph,
                      optimizer=not args.no_optimizer,
                      autocast_dtype=torch.bfloat16 if args.bf16_attention
-                     else None)
+                     else None, force_collective=args.force_spawn,
+                     overlap=not args.no_overlap)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     n_batches = 8
     images = torch.rand(n_batches, B, *cfg["model"]["image_shape"],
@@ -372,7 +442,7 @@ def main():
     labels = torch.randint(0, 10, (n_batches, B), generator=g).to(device)
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -385,7 +455,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     final_loss = float(step.loss)
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -394,7 +464,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         result = {
-            "metric": "images/sec SCAE fwd+bwd, MNIST 40x40 bs=128, 1/2/4/8 MI355X",
+            "metric": metric_name(args.workload),
             "value": round(B * world * args.steps / elapsed, 1),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -405,11 +475,12 @@ def main():
                 "workload": args.workload, "per_gpu_batch": B,
                 "global_batch": B * world,
                 "step": "forward + SCAE.loss + backward"
-                        + (" + RCCL all-reduce of one flat fp32 grad buffer"
-                           if world > 1 else "")
+                        + (f" + RCCL all-reduce of the flat fp32 gradient "
+                           f"buffer ({step.collective_mode})"
+                           if collective else "")
                         + ("" if args.no_optimizer else " + RMSprop step"),
                 "hip_graph": not args.no_graph,
-                "parallelism": f"dp{world}",
+                "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                 "final_loss": round(final_loss, 3),
             },
         }
@@ -418,7 +489,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

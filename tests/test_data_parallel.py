@@ -108,3 +108,138 @@ def test_two_rank_gradient_all_reduce_equals_global_batch():
     assert torch.allclose(flat.flat_grad, g0, atol=1e-6)
     assert float(g0[:4].abs().sum()) == 0.0        # the unused parameter
     assert float(g0[4:].abs().sum()) > 0.0
+
+
+# -- SCAE's own flat layout (aligned groups, the early-gradient front block,
+#    GradSlot re-arming) through the bucketed two-all-reduce path ------------
+SCAE_CFG = dict(image_shape=(1, 16, 16), n_classes=4, n_part_caps=5,
+                n_obj_caps=4,
+                pcae_cnn_encoder_params=dict(out_channels=[8, 8],
+                                             kernel_sizes=[3, 3],
+                                             strides=[2, 1]),
+                pcae_template_generator_params=dict(template_size=(5, 5)),
+                ocae_encoder_set_transformer_params=dict(dim_hidden=8,
+                                                         dim_out=16,
+                                                         n_layers=2),
+                ocae_decoder_capsule_params=dict(dim_caps=4,
+                                                 hidden_sizes=(8,)),
+                scae_params=dict(reconstruct_alternatives=False))
+
+
+def make_scae():
+    import numpy as np
+    from torch_scae_amd import factory
+    np.random.seed(0)
+    torch.manual_seed(0)
+    return factory.make_scae(SCAE_CFG)
+
+
+def fake_backward(flat, names, seed, step):
+    """What a backward of the HIP ops does to the flat buffers: most
+    parameters get their gradient written straight into their slot (adopted
+    as p.grad), some get a separate tensor from autograd, two get none."""
+    g = torch.Generator().manual_seed(1000 * seed + step)
+    want = {}
+    for i, (n, p) in enumerate(zip(names, flat.params)):
+        if n.endswith("dummy_vote") or n.startswith("posterior_classifier"):
+            continue                               # no gradient at all
+        val = torch.randn(p.shape, generator=g)
+        want[n] = val
+        if i % 3 == 0:
+            p.grad = val.clone()                   # produced by autograd itself
+        else:
+            v = p._scae_grad_slot.take()
+            assert v is not None, n                # slots were re-armed
+            v.copy_(val)
+            p.grad = v
+            assert p._scae_grad_slot.take() is None    # one taker per step
+    return want
+
+
+def _scae_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch_scae_amd.data_parallel import (FlatParameters, RMSpropFlat,
+                                              all_reduce_gradients,
+                                              broadcast_parameters)
+    from torch_scae_amd.train_step import EARLY_PREFIXES
+    model = make_scae()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.25 * rank)
+    flat = FlatParameters(model, front=lambda n: n.startswith(EARLY_PREFIXES))
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    names = [by_id[id(p)] for p in flat.params]
+    broadcast_parameters(flat)
+    opt = RMSpropFlat(flat, lr=1e-2, eps=1e-3)
+    wants = []
+    for step in range(2):
+        flat.clear_grads()
+        want = fake_backward(flat, names, rank, step)
+        # the order TrainStep uses: bucket 0 leaves while "part B" still runs
+        early = {n: v for n, v in want.items() if n.startswith(EARLY_PREFIXES)}
+        flat.gather_grads(0)
+        w0 = all_reduce_gradients(flat, average=False, which=0, async_op=True)
+        flat.gather_grads(1)
+        w1 = all_reduce_gradients(flat, average=False, which=1, async_op=True)
+        w0.wait()
+        w1.wait()
+        assert len(early) > 0
+        wants.append(want)
+        grads = flat.flat_grad.clone()
+        opt.step(grad_scale=1.0 / world)
+    out[rank] = (names, list(flat.offsets), flat.n_front, wants, grads,
+                 flat.flat_param.clone())
+    dist.destroy_process_group()
+
+
+def test_scae_flat_layout_front_block_and_alignment():
+    from torch_scae_amd.data_parallel import FlatParameters
+    from torch_scae_amd.train_step import EARLY_PREFIXES
+    model = make_scae()
+    n_params = sum(p.numel() for p in model.parameters())
+    flat = FlatParameters(model, front=lambda n: n.startswith(EARLY_PREFIXES))
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    names = [by_id[id(p)] for p in flat.params]
+    early = [n.startswith(EARLY_PREFIXES) for n in names]
+    k = sum(early)
+    assert 0 < k < len(names) and all(early[:k]) and not any(early[k:])
+    assert flat.front_count == k and flat.n_front % 4 == 0
+    assert flat.offsets[k] == flat.n_front
+    assert flat.block_grad(0).numel() + flat.block_grad(1).numel() \
+        == flat.numel >= n_params
+    assert flat.block_grad(1).data_ptr() % 16 == flat.flat_grad.data_ptr() % 16
+    # the object encoder's trunk group still lies back to back, 16-byte aligned
+    groups = [g for m in model.modules()
+              for g in getattr(m, "_flat_param_groups", lambda: [])()]
+    assert groups
+    for group in groups:
+        idx = [[id(p) for p in flat.params].index(id(q)) for q in group]
+        assert idx == list(range(idx[0], idx[0] + len(idx)))
+        assert flat.offsets[idx[0]] % 4 == 0
+        for a, b in zip(idx, idx[1:]):
+            assert flat.offsets[b] == flat.offsets[a] + flat.params[a].numel()
+    # without the hint the module order is kept and there is one block
+    plain = FlatParameters(make_scae())
+    assert plain.n_front == plain.numel
+
+
+def test_two_rank_bucketed_all_reduce_on_scae_layout():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_scae_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    names, offsets, n_front, wants0, g0, p0 = out[0]
+    _, _, _, wants1, g1, p1 = out[1]
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)
+    # the last step's reduced gradient: the sum of both ranks' gradients in
+    # every parameter's slot, zeros for the gradient-less parameters and pads
+    expect = torch.zeros_like(g0)
+    for n, off in zip(names, offsets):
+        if n in wants0[-1]:
+            v = wants0[-1][n] + wants1[-1][n]
+            expect[off:off + v.numel()] = v.reshape(-1)
+    assert torch.allclose(g0, expect, atol=1e-6)
+    assert 0 < n_front < g0.numel()

@@ -46,10 +46,22 @@ class FlatParameters:
     fp32 buffers.  ``param.data`` / ``param.grad`` become views, so optimisers,
     autograd and checkpoints keep working unchanged."""
 
-    def __init__(self, module):
-        params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module, front=None):
+        """``front``: optional predicate on parameter names; the parameters it
+        selects are laid out first, as one contiguous block ``[0, n_front)``
+        (the bucket whose gradients are final earliest in backward), the rest
+        starts on a 16-byte boundary behind it."""
+        named = [(n, p) for n, p in module.named_parameters()
+                 if p.requires_grad]
+        params = [p for _, p in named]
         if not params:
             raise ValueError("module has no trainable parameters")
+        first_back = None
+        if front is not None:
+            head = [p for n, p in named if front(n)]
+            back = [p for n, p in named if not front(n)]
+            params = head + back
+            first_back = back[0] if head and back else None
         # modules may ask for groups of parameters to lie back to back (in
         # the layout one of their kernels reads): move each group, in order,
         # to the position of its first member
@@ -64,6 +76,14 @@ class FlatParameters:
                 rest = [p for p in params if id(p) not in ids]
                 params = rest[:first] + list(group) + rest[first:]
                 aligned.add(id(group[0]))
+        if first_back is not None:
+            head_ids = {id(q) for q in head}
+            flags = [id(p) in head_ids for p in params]
+            n_head = sum(flags)
+            if not all(flags[:n_head]):
+                raise ValueError("a parameter group straddles the front block")
+            first_back = params[n_head]
+            aligned.add(id(first_back))
         dev, dt = params[0].device, params[0].dtype
         for p in params:
             if p.device != dev or p.dtype != dt:
@@ -89,6 +109,11 @@ class FlatParameters:
                 p._scae_grad_slot = GradSlot(self.flat_grad, off, tuple(p.shape))
         self.numel = total
         self._views = None
+        # element offset where the second block starts (== numel without one)
+        self.n_front = self.offsets[[id(p) for p in params].index(
+            id(first_back))] if first_back is not None else total
+        self.front_count = sum(1 for p, off in zip(params, self.offsets)
+                               if off < self.n_front)
 
     def grad_views(self):
         if self._views is None:
@@ -103,20 +128,37 @@ class FlatParameters:
             p.grad = None
             p._scae_grad_slot.taken = False
 
+    def block(self, which):
+        """(first, last) parameter index of a block: 0 = the front block,
+        1 = the rest, None = everything."""
+        if which is None:
+            return 0, len(self.params)
+        return (0, self.front_count) if which == 0 else \
+            (self.front_count, len(self.params))
+
+    def block_grad(self, which):
+        """The contiguous slice of the flat gradient buffer of a block."""
+        if which is None:
+            return self.flat_grad
+        return self.flat_grad[:self.n_front] if which == 0 else \
+            self.flat_grad[self.n_front:]
+
     @torch.no_grad()
-    def gather_grads(self):
+    def gather_grads(self, which=None):
         """Pack the gradients backward produced into the flat buffer with one
         multi-tensor copy.  Parameters that received no gradient
         (``obj_decoder.dummy_vote``, ``posterior_classifier.*`` in the default
-        SCAE config) keep zeros in their slice."""
-        views = self.grad_views()
-        pairs = [(v, p.grad) for v, p in zip(views, self.params)
+        SCAE config) keep zeros in their slice.  ``which``: only the
+        parameters of that block (see ``block``)."""
+        lo, hi = self.block(which)
+        views, params = self.grad_views()[lo:hi], self.params[lo:hi]
+        pairs = [(v, p.grad) for v, p in zip(views, params)
                  if p.grad is not None
                  # written in place by the op that produced it (GradSlot)
                  and p.grad.data_ptr() != v.data_ptr()]
         if pairs:
             torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
-        for v, p in zip(views, self.params):
+        for v, p in zip(views, params):
             if p.grad is None and getattr(p, "_flat_was_set", False):
                 v.zero_()
             p._flat_was_set = p.grad is not None
@@ -148,16 +190,19 @@ def broadcast_parameters(flat: FlatParameters, src=0):
         dist.broadcast(flat.flat_param, src=src)
 
 
-def all_reduce_gradients(flat: FlatParameters, async_op=False, average=True):
+def all_reduce_gradients(flat: FlatParameters, async_op=False, average=True,
+                         which=None, force=False):
     """grad <- mean over ranks (``average=False``: the sum, for an optimiser
-    step that folds the 1/world scale in), one all-reduce of the flat buffer."""
+    step that folds the 1/world scale in), one all-reduce of the flat buffer
+    (``which``: of one of its two blocks).  ``force``: issue the collective
+    even in a 1-rank group (tests of the collective path on one GPU)."""
     _, n = world()
-    if n == 1:
+    if n == 1 and not (force and dist.is_initialized()):
         return None
-    if average:
-        flat.flat_grad.div_(n)
-    return dist.all_reduce(flat.flat_grad, op=dist.ReduceOp.SUM,
-                           async_op=async_op)
+    g = flat.block_grad(which)
+    if average and n > 1:
+        g.div_(n)
+    return dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
 class RMSpropFlat:

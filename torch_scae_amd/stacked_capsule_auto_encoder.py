@@ -64,6 +64,10 @@ class SCAE(nn.Module):
         self.part_caps_sparsity_weight = part_caps_sparsity_weight
         self.reconstruct_alternatives = reconstruct_alternatives
         self.fuse_loss_tail = True     # set False for the op-by-op loss
+        # set by train_step.TrainStep: hand the two decoders detached leaves
+        # of their inputs (res._phase_cut) so that backward can run in two
+        # parts with a gradient all-reduce between them
+        self.split_backward = False
 
     # -- forward -------------------------------------------------------------
     def forward(self, image):
@@ -142,16 +146,29 @@ class SCAE(nn.Module):
         if self.stop_grad_caps_target:
             target_pose = target_pose.detach()
             target_presence = target_presence.detach()
+        live_pose, live_presence = parts.pose, parts.presence
+        phase_cut = None
+        if self.split_backward and self.stop_grad_caps_target and \
+                torch.is_grad_enabled() and \
+                self.vote_type == self.presence_type == 'enc':
+            # everything behind this point sees leaves: loss.backward() stops
+            # at them, backward(srcs, [l.grad for l in leaves]) does the rest
+            srcs = [obj_encoding, templates, live_pose, live_presence]
+            leaves = [t.detach().requires_grad_(t.requires_grad) for t in srcs]
+            obj_encoding, templates, live_pose, live_presence = leaves
+            phase_cut = (srcs, leaves)
         # the forward's scalar outputs ride in its last kernel when there is one
         fused_probs = self._fused_class_probs(obj_encoding)
         res = self.obj_decoder(obj_encoding, target_pose, target_presence,
                                **(dict(_defer_sums=True) if fused_probs else {}))
         pending = res.pop("_pending_sums", None)
-        res.part_presence = parts.presence
+        res.part_presence = live_presence
+        if phase_cut is not None:
+            res._phase_cut = phase_cut
 
-        dec_pose = {'enc': parts.pose, 'soft': res.soft_winner,
+        dec_pose = {'enc': live_pose, 'soft': res.soft_winner,
                     'hard': res.winner}[self.vote_type]
-        dec_presence = {'enc': parts.presence,
+        dec_presence = {'enc': live_presence,
                         'soft': res.soft_winner_presence,
                         'hard': res.winner_presence}[self.presence_type]
         res.rec = self.part_decoder(templates=templates, pose=dec_pose,
@@ -175,7 +192,7 @@ class SCAE(nn.Module):
                     presence=td_presence)
 
         res.templates = templates
-        res.template_presence = parts.presence
+        res.template_presence = live_presence
         res.transformed_templates = res.rec.transformed_templates
 
         if self.n_classes is not None:

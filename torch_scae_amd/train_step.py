@@ -5,19 +5,64 @@ removing the per-launch host cost matters more than any single kernel.
 
 Mirrors the semantics of the reference's BaseExperiment.training_step
 (torch_scae_experiments/base_experiment.py:109-126)."""
+import os
+
 import torch
 
 from .data_parallel import (FlatParameters, RMSpropFlat, all_reduce_gradients,
                             broadcast_parameters, world)
 
 
+# parameters whose gradients are final once backward has come down through
+# the two decoders (the object decoder's capsule MLPs alone are 66 % of the
+# model, SURVEY.md Appendix A): the first all-reduce bucket
+EARLY_PREFIXES = ("obj_decoder.", "part_decoder.", "prior_classifier.",
+                  "posterior_classifier.")
+
+
 class TrainStep:
+    """collective modes (world > 1, or ``force_collective`` in a 1-rank group):
+
+    * ``"2 buckets"`` (default when the model exposes the backward cut): the
+      step is captured as TWO HIP graphs sharing one memory pool -- A: forward,
+      loss, backward down to the inputs of the two decoders; B: the backward of
+      the object encoder, template generator and part encoder.  The decoders'
+      gradient block (flat[:n_front]) is all-reduced on RCCL's stream while B
+      replays; the rest after B; then the fused RMSprop.  (Branches INSIDE one
+      replayed graph serialise on this stack, DESIGN.md section 5, hence two
+      graphs with the collective between them.)
+    * ``"1 bucket"``: one graph, one all-reduce of the whole flat buffer after
+      it (``overlap=False``, or a model without the cut).
+    * ``"in graph"`` (env ``SCAE_GRAPH_ALLREDUCE=1``): the all-reduce and the
+      RMSprop step captured inside the one graph.
+    """
+
     def __init__(self, model, batch_size, image_shape, lr=3e-5, use_graph=True,
                  optimizer=True, momentum=0.9, weight_decay=0.0,
-                 lr_decay_rate=0.997, autocast_dtype=None):
+                 lr_decay_rate=0.997, autocast_dtype=None,
+                 force_collective=False, overlap=True):
         self.model = model
         self.device = next(model.parameters()).device
-        self.flat = FlatParameters(model)
+        self.world = world()[1]
+        self.collective = self.world > 1 or (
+            force_collective and torch.distributed.is_initialized())
+        self.in_graph_collective = self.collective and use_graph and \
+            os.environ.get("SCAE_GRAPH_ALLREDUCE", "0") == "1"
+        self.split = bool(self.collective and overlap
+                          and not self.in_graph_collective
+                          and getattr(model, "vote_type", None) == "enc"
+                          and getattr(model, "presence_type", None) == "enc")
+        self.flat = FlatParameters(
+            model, front=(lambda n: n.startswith(EARLY_PREFIXES))
+            if self.split else None)
+        if self.split and self.flat.n_front in (0, self.flat.numel):
+            self.split = False
+        if hasattr(model, "split_backward"):
+            model.split_backward = self.split
+        self.collective_mode = None if not self.collective else \
+            "in graph" if self.in_graph_collective else \
+            "2 buckets, the first overlapping the encoder backward" \
+            if self.split else "1 bucket after the backward"
         broadcast_parameters(self.flat)
         # eps = 1e-2 / bs**2 as in configs/optimizer/rmsprop.yaml
         self.opt = RMSpropFlat(self.flat, lr=lr, momentum=momentum,
@@ -38,17 +83,22 @@ class TrainStep:
         self._capturing = False
         self._stream = None
         self._with_log = False
-        self.graph = None
-        self.world = world()[1]
+        self.graph = None        # the whole step, or its part A when split
+        self.graph_b = None
+        self._cut = None
 
-    def _fwd_bwd(self):
+    # -- the step in two parts ------------------------------------------------
+    def _part_a(self):
+        """forward + loss + backward (split: down to the decoders' inputs)."""
         self.flat.clear_grads()
         with torch.autocast("cuda", dtype=self.autocast_dtype,
                             enabled=self.autocast_dtype is not None):
             res = self.model(self.image)
         loss, info = self.model.loss(res, self.image, self.label)
-        loss.backward(self._one)     # a resident seed: no ones_like fill per step
-        self.flat.gather_grads()
+        # a resident seed: no ones_like fill per step
+        loss.backward(self._one)
+        self._cut = res.get("_phase_cut") if self.split else None
+        self.flat.gather_grads(None if self._cut is None else 0)
         if self._capturing:
             # the captured loss tensor lives in the graph's private pool at a
             # fixed address: expose it instead of copying it out every replay
@@ -68,11 +118,45 @@ class TrainStep:
             for k, v in fresh.items():
                 self.log[k].copy_(v)
 
-    def _finish(self):
+    def _part_b(self):
+        """split only: the backward below the decoders' inputs."""
+        if self._cut is None:
+            return
+        srcs, leaves = self._cut
+        self._cut = None
+        keep = [(t, l.grad) for t, l in zip(srcs, leaves)
+                if l.grad is not None]
+        torch.autograd.backward([t for t, _ in keep], [g for _, g in keep])
+        self.flat.gather_grads(1)
+
+    def _fwd_bwd(self):
+        self._part_a()
+        self._part_b()
+
+    def _reduce(self, which=None, async_op=False):
         # SUM all-reduce; the 1/world scale rides in the optimiser kernel
-        all_reduce_gradients(self.flat, average=self.opt is None)
+        return all_reduce_gradients(self.flat, average=self.opt is None,
+                                    which=which, async_op=async_op,
+                                    force=self.collective)
+
+    def _finish(self):
+        if self.collective:
+            self._reduce()
         if self.opt is not None:
             self.opt.step(grad_scale=1.0 / self.world)
+
+    def _run(self, part_a, part_b):
+        """One step from its two parts (graph replays or eager calls)."""
+        if not self.split:
+            part_a()
+            return
+        part_a()
+        w0 = self._reduce(0, async_op=True)     # overlaps part B
+        part_b()
+        w1 = self._reduce(1, async_op=True)
+        for w in (w0, w1):
+            if w is not None:
+                w.wait()                        # stream-side wait, not a host one
 
     def _capture(self):
         # warm up on a side stream (allocator, lazy init), then capture; the
@@ -89,12 +173,22 @@ class TrainStep:
         # capture on the SAME stream the warm-up ran on: autograd caches each
         # parameter's AccumulateGrad node together with its stream
         self.graph = torch.cuda.CUDAGraph()
+        self._capturing = True
         with torch.cuda.graph(self.graph, stream=s):
-            self._capturing = True
-            self._fwd_bwd()
-            self._capturing = False
-            if self.world == 1:
-                self._finish()
+            self._part_a()
+            if not self.split:
+                self._part_b()
+                if not self.collective or self.in_graph_collective:
+                    self._finish()
+        if self.split:
+            # part B allocates from part A's pool: the tensors A left for it
+            # (saved activations, the cut gradients) are alive across the two
+            # captures, and the graphs are always replayed A, B, A, B, ...
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, stream=s,
+                                  pool=self.graph.pool()):
+                self._part_b()
+        self._capturing = False
 
     def _stage(self, image, label):
         """The batch into the resident input buffers: one launch when both
@@ -122,9 +216,18 @@ class TrainStep:
         if self.use_graph:
             if self.graph is None:
                 self._capture()
-            self.graph.replay()
-            if self.world > 1:
-                self._finish()
+            if self.split:
+                self._run(self.graph.replay, self.graph_b.replay)
+                if self.opt is not None:
+                    self.opt.step(grad_scale=1.0 / self.world)
+            else:
+                self.graph.replay()
+                if self.collective and not self.in_graph_collective:
+                    self._finish()
+        elif self.split:
+            self._run(self._part_a, self._part_b)
+            if self.opt is not None:
+                self.opt.step(grad_scale=1.0 / self.world)
         else:
             self._fwd_bwd()
             self._finish()
@@ -136,7 +239,7 @@ class TrainStep:
         the next call overwrites.  Builds the step with the log outputs on
         first use (costs a few extra small kernels per step)."""
         if not self._with_log:
-            self._with_log, self.graph = True, None
+            self._with_log, self.graph, self.graph_b = True, None, None
         loss = self(image, label)
         return dict(loss=loss, log=self.log)
 
