@@ -320,7 +320,9 @@ def roofline(cfg, device):
     # HBM traffic per launch from the committed rocprofv3 --pmc passes
     # (counters cannot be read from inside this run)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "k8_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02", "k8_pmc.json")
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r01", "k8_pmc.json")
     if os.path.exists(pmc) and cfg is CONFIGS["mnist_24_24_bs128"]:
         k = json.load(open(pmc))["kernels"].get(name)
         if k:
@@ -347,7 +349,7 @@ def roofline(cfg, device):
         "note": "achieved/us_per_launch/algorithmic_flops_per_launch are "
                 "averages over the kernel's launches of one step (one per "
                 "encoder layer); traffic = FETCH_SIZE+WRITE_SIZE per launch "
-                "from profiles/r01/k8_pmc.json (separate rocprofv3 --pmc "
+                "from profiles/r0x/k8_pmc.json (separate rocprofv3 --pmc "
                 "passes); K1 byte figures: DESIGN.md section 4",
     }
 
@@ -363,6 +365,38 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def step_algorithmic(cfg):
+    """(FLOPs, hot-path bytes) per image of one training step, SURVEY.md 8d's
+    conventions: FLOPs = 3 x forward 2*MAC of the CNN encoder, set transformer,
+    capsule MLPs, K1 and the pose products (its table); bytes = compact inputs read once +
+    contract outputs written once for K1 / K2 / K3+K4, forward and backward."""
+    m = cfg["model"]
+    C, H, W = m["image_shape"]
+    M, Oc = m["n_part_caps"], m["n_obj_caps"]
+    K, hw = M + 1, 121
+    e = 4
+    A = 6 * M + 6 + 1 + 2 * M
+    Din = 23 + C * hw
+    k1 = (M * C * hw + 6 * M + M + C * H * W + K * C * H * W + K * H * W) * e \
+        + (2 * (M * C * hw + 6 * M + M) + C * H * W) * e
+    k2 = (M * Din + M + Oc * 256) * e + (2 * M * Din + M + 2 * Oc * 256) * e
+    k3 = 3 * (Oc * A + 6 * Oc * M + 3 * Oc * M + Oc) * e
+    # SURVEY.md 8d's table (fwd 2*MAC x 3), counted on the reference modules
+    flops = {(24, 24, 1): 209e6, (40, 32, 1): 250e6, (48, 64, 1): 313e6,
+             (32, 32, 3): 164e6}[(M, Oc, C)]
+    return flops, k1 + k2 + k3
 
 
 def cpu_baseline(cfg, steps):
@@ -393,11 +427,25 @@ def cpu_baseline(cfg, steps):
         step()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
+    cores = torch.get_num_threads()
+    # the same step on ONE thread (SURVEY.md 8d asks for both), 3 steps
+    torch.set_num_threads(1)
+    step()
+    one = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        one.append(time.perf_counter() - t0)
+    torch.set_num_threads(cores)
+    med1 = float(np.median(one))
     return {"value": round(B / med, 1), "unit": "images/sec",
-            "cores": torch.get_num_threads(), "kind": "port",
+            "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{steps} steps of the same workload (B={B}) after 3 "
                       f"warm-up, median; fwd+loss+bwd, no optimiser",
-            "ms_per_step": round(med * 1e3, 2)}
+            "ms_per_step": round(med * 1e3, 2),
+            "one_thread": {"value": round(B / med1, 1), "unit": "images/sec",
+                           "ms_per_step": round(med1 * 1e3, 2),
+                           "sample": "3 steps after 1 warm-up, median"}}
 
 
 # ----------------------------------------------------------------------------
@@ -486,6 +534,15 @@ def main():
         }
         if not args.no_roofline:
             result["roofline"] = roofline(cfg, device)
+            fl, by = step_algorithmic(cfg)
+            ips = result["value"] / world        # per GPU
+            result["roofline"]["step"] = {
+                "flops_per_image": fl, "hot_bytes_per_image": by,
+                "mfma_frac": round(ips * fl / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
+                "hbm_frac": round(ips * by / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "whole step per GPU: images/s x SURVEY.md 8d's "
+                        "algorithmic FLOPs (bytes) per image / fp32 MFMA "
+                        "(HBM) peak"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
         print(json.dumps(result), flush=True)
