@@ -79,22 +79,28 @@ FULL = {
     "cfg2": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24,
                   n_obj_caps=24,
                   scae_params=dict(reconstruct_alternatives=False)), 128),
-    # configs[4]: CIFAR shape, 32/32, 3-channel templates (batch cut to keep
-    # the CPU oracle quick)
+    # configs[4]: CIFAR shape, 32/32, 3-channel templates, bs=256
     "cfg5": (dict(image_shape=(3, 32, 32), n_classes=10, n_part_caps=32,
                   n_obj_caps=32,
-                  scae_params=dict(reconstruct_alternatives=False)), 32),
+                  scae_params=dict(reconstruct_alternatives=False)), 256),
     # hydra default of the reference: 40 part / 32 object capsules
     "mnist_40_32": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=40,
                          n_obj_caps=32,
                          scae_params=dict(reconstruct_alternatives=False)),
-                    16),
+                    128),
+    # configs[2]'s shape (48 / 64 capsules, bs=1024) on the fp32 path
+    "cfg3_shape": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=48,
+                        n_obj_caps=64,
+                        scae_params=dict(reconstruct_alternatives=False)),
+                   1024),
 }
 
 
-@pytest.mark.parametrize("name", sorted(FULL))
-def test_scae_vs_oracle_full_size(name):
-    from torch_scae_amd import factory, nn_ext
+def full_size_case(name):
+    """Parameters + a gate-screened batch (tests/gate_screen.py) of a FULL
+    configuration at its full batch size."""
+    from tests.gate_screen import screened_scae_batch
+    from torch_scae_amd import factory
     cfg, B = FULL[name]
     np.random.seed(1)
     torch.manual_seed(1)
@@ -105,12 +111,20 @@ def test_scae_vs_oracle_full_size(name):
             if float(p.abs().sum()) == 0.0:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
     sd = {k: v.clone() for k, v in proto.state_dict().items()}
-    M, Oc = cfg["n_part_caps"], cfg["n_obj_caps"]
-    image = torch.rand(B, *cfg["image_shape"], generator=g)
-    label = torch.randint(0, 10, (B,), generator=g)
-    noise = [torch.rand(B, M, generator=g), torch.rand(B, Oc, 1, generator=g),
-             torch.rand(B, Oc, M, generator=g)]
+    image, label, noise = screened_scae_batch(O, cfg, sd, B, g)
+    return cfg, B, sd, image, label, noise
 
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_scae_vs_oracle_full_size(name):
+    """Whole model at BASELINE.json's full sizes against the fp32 oracle on the
+    same parameters / batch / noise.  The north-star bar -- 1e-4, relative to
+    the largest entry of each tensor -- holds for EVERY entry of every output
+    and of every parameter gradient: the batch is screened so that no ReLU gate
+    is within round-off of its kink (gate_screen.py), so there is no
+    "equally valid other gradient" left to allow for."""
+    from torch_scae_amd import nn_ext
+    cfg, B, sd, image, label, noise = full_size_case(name)
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ocfg = O.prepare_model_params(**cfg)
     ores = O.scae_forward(P, ocfg, image, noise, training=True)
@@ -131,35 +145,30 @@ def test_scae_vs_oracle_full_size(name):
     olp = O.gmm_log_prob(ores.rec.transformed_templates, ores.rec.scale,
                          ores.rec.mixing_logits, image)
     assert_close(lp, olp, 1e-4, 1e-4, "rec log_prob")
+    del ores, olp, lp
     grads = nn_ext.named_reference_grads(model)
+    off, n = [], 0
     for k, p in P.items():
         if p.grad is None:
             continue
         ref = p.grad
-        # Parameter gradients are batch sums of per-sample terms gated by
-        # ~1.5 M ReLU units (every reference MLP ends in a ReLU).  A
-        # pre-activation within fp32 round-off of zero leaves the forward
-        # unchanged (checked to 1e-4 above) but flips that unit's gate between
-        # two equally valid fp32 evaluations, moving ONE sample's contribution
-        # to a few weight rows by O(|grad|/B).  So: all but a sliver of the
-        # entries must meet the 1e-4 bar, and no entry may be off by more than
-        # a single-sample share.  The kernels' own gradients are held to 1e-4
-        # everywhere in test_hip_ops.py and on the golden models above.
         got = grads[k].detach().cpu()
-        scale = max(1.0, float(ref.abs().max()))
-        err = (got - ref).abs()
-        bad = err > (1e-4 * scale + 1e-3 * ref.abs())
-        # a flip upstream of a whole layer (one sample's one-hot attention key
-        # or one capsule's hidden unit) moves EVERY entry of a small tensor by
-        # that sample's share, so small tensors are judged on their relative
-        # L2 error against one sample's weight 1/B instead of an entry count
-        rel_l2 = float((got - ref).norm() / (ref.norm() + 1e-12))
-        assert int(bad.sum()) <= max(8, 2e-2 * bad.numel()) or \
-            rel_l2 <= 2.0 / B, \
-            f"grad {k}: {int(bad.sum())}/{bad.numel()} entries off, " \
-            f"rel L2 {rel_l2:.2e}"
-        assert float(err.max()) <= 4.0 / B * scale, \
-            f"grad {k}: max err {float(err.max()):.3e} (scale {scale:.3e})"
+        # every entry within 1e-4 of the tensor's largest entry
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            # (the seeds / query projection at initialisation: the 1e32
+            # presence mask makes the output attention one-hot, its queries
+            # receive exactly no gradient)
+            assert float(got.abs().max()) <= 1e-6, k
+            continue
+        ratio = float((got - ref).abs().max()) / scale
+        off.append((ratio, k))
+        n += 1
+    assert n > 200
+    off.sort(reverse=True)
+    assert off[0][0] <= 1e-4, "gradient entries off by more than 1e-4 of " \
+        "their tensor's largest entry: " + ", ".join(
+            f"{k} {r:.2e}" for r, k in off[:8] if r > 1e-4)
 
 
 def test_scae_forward_is_stochastic_like_the_reference():
@@ -425,3 +434,46 @@ def test_train_step_collective_paths_match_plain_step_bitwise():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_recon_mse_term_sends_gradient_like_the_oracle():
+    """recon_mse_weight > 0 (stacked_capsule_auto_encoder.py:226-230): the MSE
+    term is built from pdf.mode(), whose gradient reaches the templates and
+    the pose through the winning component -- loss, log and every parameter
+    gradient against the oracle."""
+    from torch_scae_amd import nn_ext
+    blob, meta = load("scae_base")
+    cfg = dict(meta["config"])
+    cfg["scae_params"] = dict(cfg.get("scae_params", {}), recon_mse_weight=0.7)
+    noise = sub(blob, "noise/")
+    noise = [noise[k] for k in sorted(noise)]
+    image, label = blob["in/image"], blob["in/label"]
+    sd = sub(blob, "param/")
+    # (with the golden parameters the background wins every pixel's arg-max;
+    # raise the template alphas so that templates win some)
+    sd["part_decoder.templates_alpha"] = \
+        sd["part_decoder.templates_alpha"] + 4.0
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = O.prepare_model_params(**cfg)
+    oloss, olog, ograds = O.train_step(P, ocfg, image, label, noise)
+    assert "mse" in olog and float(olog["mse"]) > 0
+    model, res, loss, log = run_model(cfg, sd, image, label, noise, True)
+    loss.backward()
+    assert_close(loss, oloss, 1e-4, 1e-5, "loss")
+    assert_close(log["mse"], olog["mse"], 1e-4, 1e-5, "mse")
+    grads = nn_ext.named_reference_grads(model)
+    n = 0
+    for k, ref in ograds.items():
+        if ref is None:
+            continue
+        assert_close(grads[k], ref, 1e-4 * max(1.0, float(ref.abs().max())),
+                     1e-4, "grad " + k)
+        n += 1
+    assert n > 20
+    # the term really contributes to the templates' gradient
+    cfg0 = dict(cfg, scae_params=dict(cfg["scae_params"], recon_mse_weight=0))
+    P0 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    _, _, g0 = O.train_step(P0, O.prepare_model_params(**cfg0), image, label,
+                            noise)
+    k = "template_generator.template_logits"
+    assert float((ograds[k] - g0[k]).abs().max()) > 1e-3

@@ -1814,25 +1814,77 @@ def gmm_log_prob(loc, mixing_logits, sigma, x):
     return _GmmLogProb.apply(loc, mixing_logits, sigma.reshape(1), x)
 
 
+class _GmmMean(torch.autograd.Function):
+    """sum_k softmax(logits)_k * loc_k (distributions.py:37-39), differentiable
+    w.r.t. both operands; the backward of this inspection path is composed
+    from device tensor ops."""
+
+    @staticmethod
+    def forward(ctx, loc, ml):
+        loc, ml = _c(loc), _c(ml)
+        B, K, C, Cm, P = _gmm_dims(loc, ml)
+        out = torch.empty(B, *loc.shape[2:], device=loc.device, dtype=loc.dtype)
+        _lib.call("scae_gmm_mean_f32", _p(loc), _p(ml), _p(out), B, K, C, Cm, P,
+                  _stream(loc))
+        ctx.save_for_backward(loc, ml)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, ml = ctx.saved_tensors
+        prob = torch.softmax(ml, 1)
+        g = g.unsqueeze(1)
+        g_loc = prob * g if ctx.needs_input_grad[0] else None
+        g_ml = None
+        if ctx.needs_input_grad[1]:
+            t = g * loc                               # (B,K,C,P)
+            if ml.shape[2] != loc.shape[2]:
+                t = t.sum(2, keepdim=True)
+            g_ml = prob * (t - (prob * t).sum(1, keepdim=True))
+        return g_loc, g_ml
+
+
 def gmm_mean(loc, mixing_logits):
     _need_hip(loc, mixing_logits)
-    loc, ml = _c(loc.detach()), _c(mixing_logits.detach())
-    B, K, C, Cm, P = _gmm_dims(loc, ml)
-    out = torch.empty(B, *loc.shape[2:], device=loc.device, dtype=loc.dtype)
-    _lib.call("scae_gmm_mean_f32", _p(loc), _p(ml), _p(out), B, K, C, Cm, P,
-              _stream(loc))
-    return out
+    return _GmmMean.apply(loc, mixing_logits)
+
+
+class _GmmMode(torch.autograd.Function):
+    """loc of the component with the largest mixing log-prob
+    (distributions.py:50-77 without the straight-through estimator):
+    differentiable w.r.t. loc only -- the incoming gradient goes to the winning
+    component -- exactly like the reference's sum(one_hot * loc)."""
+
+    @staticmethod
+    def forward(ctx, loc, ml, sigma, maximum):
+        loc, ml = _c(loc), _c(ml)
+        B, K, C, Cm, P = _gmm_dims(loc, ml)
+        out = torch.empty(B, *loc.shape[2:], device=loc.device, dtype=loc.dtype)
+        _lib.call("scae_gmm_mode_f32", _p(loc), _p(ml), _p(_c(sigma)),
+                  _p(out), int(maximum), B, K, C, Cm, P, _stream(loc))
+        ctx.save_for_backward(ml)
+        ctx.loc_shape = loc.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ml,) = ctx.saved_tensors
+        # (with `maximum` and a shared scale the added density is the same
+        # for every component: the winner is the arg-max of the logits)
+        idx = ml.argmax(1, keepdim=True)
+        idx = idx.expand(ml.shape[0], 1, *ctx.loc_shape[2:])
+        g_loc = torch.zeros(ctx.loc_shape, device=g.device, dtype=g.dtype)
+        g_loc.scatter_(1, idx, g.unsqueeze(1))
+        return g_loc, None, None, None
 
 
 def gmm_mode(loc, mixing_logits, sigma, maximum=False):
     _need_hip(loc, mixing_logits, sigma)
-    loc, ml = _c(loc.detach()), _c(mixing_logits.detach())
-    B, K, C, Cm, P = _gmm_dims(loc, ml)
+    B, K, C, Cm, P = _gmm_dims(loc, mixing_logits)
     if maximum and Cm == 1 and C > 1:
         # same failure as the reference's in-place broadcast, distributions.py:65
-        raise RuntimeError(f"output with shape {list(ml.shape)} doesn't match "
-                           f"the broadcast shape {list(loc.shape)}")
-    out = torch.empty(B, *loc.shape[2:], device=loc.device, dtype=loc.dtype)
-    _lib.call("scae_gmm_mode_f32", _p(loc), _p(ml), _p(_c(sigma.detach())),
-              _p(out), int(maximum), B, K, C, Cm, P, _stream(loc))
-    return out
+        raise RuntimeError(f"output with shape {list(mixing_logits.shape)} "
+                           f"doesn't match the broadcast shape "
+                           f"{list(loc.shape)}")
+    return _GmmMode.apply(loc, mixing_logits.detach(), sigma.detach(),
+                          bool(maximum))
