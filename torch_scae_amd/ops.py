@@ -323,6 +323,12 @@ class _SetEncoder(torch.autograd.Function):
                   gptrs, _p(presence), _p(packed), _p(hsave), _p(gz),
                   _p(partial), B, N, D, Din, Dout, L, ln, _stream(packed))
         taken_before = ctx.slot is not None and ctx.slot.taken
+        if ctx.slot is not None and not taken_before and \
+                any(sl.taken for sl in getattr(ctx.slot, "parts", ())):
+            # a part's slot already holds another op's gradient (a trunk
+            # parameter shared with a second slot-aware op): writing the packed
+            # block would overwrite it -- leave the slots to autograd's sum
+            ctx.slot.taken = taken_before = True
         gpacked = _grad_out(ctx.slot, packed)
         if ctx.slot is not None and not taken_before:
             for sl in getattr(ctx.slot, "parts", ()):

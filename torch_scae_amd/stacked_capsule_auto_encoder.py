@@ -89,7 +89,9 @@ class SCAE(nn.Module):
         enc, layer = self.part_encoder, self.obj_decoder.capsule_layer
         B = image.shape[0]
         shapes = []
-        if self.training and getattr(enc, "noise_scale", 0.) > 0. \
+        # (keyed on each consumer's own mode: a frozen part encoder in eval()
+        # inside a training SCAE draws nothing, like the reference)
+        if enc.training and getattr(enc, "noise_scale", 0.) > 0. \
                 and hasattr(enc, "n_caps"):
             shapes.append((B, enc.n_caps))
         if getattr(layer, "noise_type", None) == 'uniform' \
