@@ -416,8 +416,10 @@ typedef struct scae_sum_segment {
 } scae_sum_segment;
 int scae_sum_rows_f32(const float *src, int64_t rows, int64_t cols,
                       const scae_sum_segment *segments, int n_segments, void *stream);
-/* Up to 4 such column-sum jobs (different matrices) in ONE launch: a backward
- * pass usually leaves two or three partial matrices behind at the same time.
+/* Up to 16 such column-sum jobs (different matrices) in ONE launch: a backward
+ * pass usually leaves two or three partial matrices behind at the same time,
+ * and the sums that only feed the optimiser (parameter gradients) of a whole
+ * training step can wait for one launch at its end.
  * `jobs` and the segment arrays it points to are HOST memory. */
 typedef struct scae_sum_job {
   const float *src;

@@ -477,3 +477,52 @@ def test_recon_mse_term_sends_gradient_like_the_oracle():
                             noise)
     k = "template_generator.template_logits"
     assert float((ograds[k] - g0[k]).abs().max()) > 1e-3
+
+
+def test_lazy_render_gives_the_same_tensors_and_the_same_step():
+    """part_decoder.lazy_render (the loss-only training step): the rendered
+    tensors appear on first access with the eager values, and a TrainStep
+    with it ends on bit-identical parameters."""
+    from torch_scae_amd import factory, nn_utils, ops
+    from torch_scae_amd.general_utils import LazyAttrDict
+    from torch_scae_amd.train_step import TrainStep
+    cfg, _ = FULL["cfg2"]
+    B = 8
+    g = torch.Generator().manual_seed(11)
+    image = torch.rand(B, 1, 40, 40, generator=g).cuda()
+    label = torch.randint(0, 10, (B,), generator=g).cuda()
+    noise = [torch.rand(B, 24, generator=g), torch.rand(B, 24, 1, generator=g),
+             torch.rand(B, 24, 24, generator=g)]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(cfg).cuda().train()
+    with torch.no_grad(), nn_utils.fixed_noise([n.clone() for n in noise]):
+        eager = model(image)
+    model.part_decoder.lazy_render = True
+    with torch.no_grad(), nn_utils.fixed_noise([n.clone() for n in noise]):
+        lazy = model(image)
+    assert isinstance(lazy, LazyAttrDict) and isinstance(lazy.rec, LazyAttrDict)
+    assert "transformed_templates" not in list(lazy.keys())
+    assert "transformed_templates" in lazy
+    assert lazy.rec.pdf.n_components == 25
+    assert torch.equal(lazy.rec.pdf.log_prob(image), eager.rec.pdf.log_prob(image))
+    assert "mixing_logits" not in list(lazy.rec.keys())        # still not rendered
+    assert torch.equal(lazy.transformed_templates, eager.transformed_templates)
+    assert torch.equal(lazy.rec.mixing_logits, eager.rec.mixing_logits)
+    assert torch.equal(lazy.rec.pdf.mode(), eager.rec.pdf.mode())
+
+    def run(lazy_render):
+        np.random.seed(0)
+        torch.manual_seed(0)
+        ops.reset_noise()
+        m = factory.make_scae(cfg).cuda().train()
+        step = TrainStep(m, B, (1, 40, 40), lr=1e-3, lazy_render=lazy_render)
+        assert m.part_decoder.lazy_render == lazy_render
+        for _ in range(2):
+            step(image, label)
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in m.state_dict().items()}
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -211,3 +211,31 @@ def test_mnist_pad_and_translate():
                           digits.float().flatten(1).sum(1) / 255)
     assert torch.equal(pad_and_translate(digits[:, :, :, :], (28, 28)),
                        digits.float() / 255)
+
+
+def test_lazy_attr_dict_materialises_on_first_access():
+    from torch_scae_amd.general_utils import AttrDict, LazyAttrDict
+    calls = []
+
+    def fill(d):
+        calls.append(1)
+        dict.__setitem__(d, "a", 1)
+        dict.__setitem__(d, "b", 2)
+        d["_lazy"].clear()
+
+    d = LazyAttrDict(pdf=3)
+    d["_lazy"] = dict(a=fill, b=fill)
+    assert "a" in d and "zz" not in d and d.get("zz", 7) == 7
+    assert "a" not in list(d.keys()) and calls == []
+    assert d.b == 2 and d["a"] == 1 and d.get("a") == 1 and calls == [1]
+    assert {"a", "b", "pdf"} <= set(d.keys())
+    with pytest.raises(AttributeError):
+        d.nope
+    with pytest.raises(KeyError):
+        d["nope"]
+    outer = LazyAttrDict(AttrDict(x=1, rec=d))
+    outer["_lazy"] = dict(t=lambda dd: dict.__setitem__(dd, "t",
+                                                        dd["rec"]["a"]))
+    assert outer.t == 1 and outer.x == 1
+    del outer.x                      # attribute deletion still works
+    assert "x" not in outer

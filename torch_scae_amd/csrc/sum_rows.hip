@@ -7,14 +7,18 @@
 
 namespace {
 constexpr int NT = 256;
-constexpr int MAXJOBS = 4;
+constexpr int MAXJOBS = 16;  // 16 x 224 B of kernel arguments
+struct Seg {       // scae_sum_segment with 32-bit columns
+  float *dst;
+  int begin, end, period;
+};
 struct Job {
   const float *src;
-  long rows, cols;
+  int rows, cols;
   int py;           // row parts per column (1 | 4 | 16 | 64); NT / py columns per workgroup
   int first_block;  // first workgroup of this job
   int n;
-  scae_sum_segment s[8];
+  Seg s[8];
 };
 struct Jobs {
   Job j[MAXJOBS];
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(Jobs jobs) {
   float tot = 0.f;
   for (int p = 0; p < PY; ++p) tot += red[p * CX + cx];
   for (int i = 0; i < job.n; ++i) {
-    const scae_sum_segment &g = job.s[i];
+    const Seg &g = job.s[i];
     if (g.period > 0) {  // the same column window of every period-wide block
       const long blk = j / g.period, c = j - blk * g.period;
       if (c >= g.begin && c < g.end) g.dst[blk * (g.end - g.begin) + c - g.begin] = tot;
@@ -97,12 +101,12 @@ extern "C" int scae_sum_rows_multi_f32(const scae_sum_job *jobs, int n_jobs, voi
   for (int k = 0; k < n_jobs; ++k) {
     const scae_sum_job &in = jobs[k];
     SCAE_REQUIRE(in.src && in.segments && in.rows > 0 && in.cols > 0 && in.n_segments > 0 &&
-                 in.n_segments <= 8);
+                 in.n_segments <= 8 && in.rows < (1ll << 31) && in.cols < (1ll << 31));
     Job &job = js.j[k];
-    job.src = in.src, job.rows = (long)in.rows, job.cols = (long)in.cols, job.n = in.n_segments;
+    job.src = in.src, job.rows = (int)in.rows, job.cols = (int)in.cols, job.n = in.n_segments;
     for (int i = 0; i < in.n_segments; ++i) {
-      job.s[i] = in.segments[i];
-      const scae_sum_segment &g = job.s[i];
+      const scae_sum_segment &g = in.segments[i];
+      job.s[i] = Seg{g.dst, (int)g.begin, (int)g.end, (int)g.period};
       SCAE_REQUIRE(g.dst && g.begin >= 0 && g.begin < g.end &&
                    g.end <= (g.period > 0 ? g.period : in.cols));
       SCAE_REQUIRE(g.period >= 0 || (g.end - g.begin) % -g.period == 0);

@@ -20,8 +20,14 @@ class _NormalView:
     (``pdf.dist.loc`` / ``.mean`` / ``.scale``)."""
 
     def __init__(self, loc, scale):
-        self.loc = loc
+        self._loc = loc            # a tensor, or a thunk that renders it
         self.scale = scale
+
+    @property
+    def loc(self):
+        if callable(self._loc):
+            self._loc = self._loc()
+        return self._loc
 
     @property
     def mean(self):
@@ -37,11 +43,19 @@ class GaussianMixture:
           mixing_logits: tensor [B, K, ...] with K the number of components.
         """
         self.dist = normal_dist
-        self.mixing_logits = mixing_logits
+        self._mixing_logits = mixing_logits    # a tensor, or a thunk
         self._decoder_inputs = _decoder_inputs
 
     @property
+    def mixing_logits(self):
+        if callable(self._mixing_logits):
+            self._mixing_logits = self._mixing_logits()
+        return self._mixing_logits
+
+    @property
     def n_components(self):
+        if callable(self._mixing_logits) and self._decoder_inputs is not None:
+            return self._decoder_inputs.templates.shape[1] + 1
         return self.mixing_logits.shape[1]
 
     def _sigma(self):

@@ -109,7 +109,8 @@ def uniform(n, ref):
     return out
 
 
-def _sum_rows(partial, shapes, starts=None, period=0, outs=None, transpose=0):
+def _sum_rows(partial, shapes, starts=None, period=0, outs=None, transpose=0,
+              defer=False):
     """Column sums of ``partial`` (rows, cols) scattered into fresh contiguous
     tensors of the given shapes; consecutive column ranges unless ``starts``
     gives each one's first column.  With ``period`` the columns form blocks
@@ -118,15 +119,64 @@ def _sum_rows(partial, shapes, starts=None, period=0, outs=None, transpose=0):
     output's window is an (n x W) matrix that is written transposed (W x n).
     One launch."""
     return _sum_rows_multi([dict(partial=partial, shapes=shapes, starts=starts,
-                                 period=period, outs=outs,
-                                 transpose=transpose)])[0]
+                                 period=period, outs=outs, transpose=transpose,
+                                 defer=defer)])[0]
+
+
+_SUMS_PER_LAUNCH = 16
+_DEFERRED = None        # list of pending units while deferral is on
+
+
+class deferred_param_sums:
+    """Inside this context the column-sum jobs marked ``defer`` -- those whose
+    outputs are parameter gradients, which nothing but the optimiser / the
+    gradient all-reduce reads -- are queued instead of launched;
+    ``flush_param_sums()`` (and leaving the context) runs everything queued in
+    one launch per 16 jobs.  A training step's backward then ends in ONE
+    column-sum launch instead of one per op."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.outer = _DEFERRED
+        if _DEFERRED is None:
+            _DEFERRED = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        if self.outer is None:
+            if exc[0] is None:
+                flush_param_sums()
+            _DEFERRED = None
+        return False
+
+
+def flush_param_sums():
+    if _DEFERRED:
+        units = list(_DEFERRED)
+        del _DEFERRED[:]
+        _launch_sum_units(units)
+
+
+def _launch_sum_units(units):
+    for k in range(0, len(units), _SUMS_PER_LAUNCH):
+        chunk = units[k:k + _SUMS_PER_LAUNCH]
+        arr = (_lib.SumJob * len(chunk))()
+        for a, (partial, rows, cols, segp, n, _keep) in zip(arr, chunk):
+            a.src, a.rows, a.cols, a.segments, a.n_segments = \
+                partial.data_ptr(), rows, cols, segp, n
+        _lib.call("scae_sum_rows_multi_f32", arr, len(chunk),
+                  _stream(chunk[0][0]))
 
 
 def _sum_rows_multi(jobs):
     """Several ``_sum_rows`` jobs (dicts of its arguments, different partial
-    matrices) in as few launches as possible (4 jobs of <= 8 outputs each per
-    launch); returns the list of output lists."""
-    units, results = [], []
+    matrices) in as few launches as possible (16 jobs of <= 8 outputs each per
+    launch); returns the list of output lists.  Jobs with ``defer=True`` wait
+    for ``flush_param_sums`` while ``deferred_param_sums`` is active (the
+    queue keeps the partial matrix alive but no reference to the outputs:
+    autograd only adopts a gradient tensor nobody else holds)."""
+    units, later, results = [], [], []
     for job in jobs:
         partial, shapes = job["partial"], job["shapes"]
         starts, period = job.get("starts"), job.get("period", 0)
@@ -148,18 +198,15 @@ def _sum_rows_multi(jobs):
             pos += width
             outs.append(o)
         results.append(outs)
+        dst = later if (_DEFERRED is not None and job.get("defer")) else units
         for k in range(0, len(shapes), 8):
-            units.append((partial, rows, cols, ctypes.cast(
+            dst.append((partial, rows, cols, ctypes.cast(
                 ctypes.byref(segs, k * ctypes.sizeof(_lib.SumSegment)),
                 ctypes.POINTER(_lib.SumSegment)), min(8, len(shapes) - k), segs))
-    for k in range(0, len(units), 4):
-        chunk = units[k:k + 4]
-        arr = (_lib.SumJob * len(chunk))()
-        for a, (partial, rows, cols, segp, n, _keep) in zip(arr, chunk):
-            a.src, a.rows, a.cols, a.segments, a.n_segments = \
-                partial.data_ptr(), rows, cols, segp, n
-        _lib.call("scae_sum_rows_multi_f32", arr, len(chunk),
-                  _stream(chunk[0][0]))
+    if later:
+        _DEFERRED.extend(later)
+    if units:
+        _launch_sum_units(units)
     return results
 
 
@@ -333,8 +380,9 @@ class _SetEncoder(torch.autograd.Function):
         if ctx.slot is not None and not taken_before:
             for sl in getattr(ctx.slot, "parts", ()):
                 sl.taken = True   # the parts' slots are written through it
-        return (None, _sum_rows(partial, [packed.shape], outs=[gpacked])[0],
-                None, *gsegs)
+        # (a slot: the packed block is parameters only -- its sum can wait)
+        return (None, _sum_rows(partial, [packed.shape], outs=[gpacked],
+                                defer=ctx.slot is not None)[0], None, *gsegs)
 
 
 def set_encoder(segments, presence, packed_params, dim_hidden, dim_out,
@@ -582,7 +630,8 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
     return acts, wds, x_post
 
 
-def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout):
+def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
+                    defer=False):
     """Weight / bias gradients of the stack from ``dpre``, the (B,OH,OW,C)
     gradient w.r.t. the last layer's pre-activation; ``gout(i)`` supplies the
     buffer of weight i (0..L-1) / bias i (L..2L-1)."""
@@ -621,7 +670,7 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout):
               arr(2), ints(3), ints(4), ints(5), st)
     gws[0], gbs[0] = _sum_rows(partial.view(partial.shape[0], -1),
                                [(c1, C0, 3, 3), (c1,)],
-                               outs=[gout(0), gout(L)])
+                               outs=[gout(0), gout(L)], defer=defer)
     return gws, gbs
 
 
@@ -687,7 +736,8 @@ def _conv1x1_fwd(x, weight, bias):
     return y
 
 
-def _conv1x1_bwd(x, weight, dy, gate=None, outs=None, raw_sum=None):
+def _conv1x1_bwd(x, weight, dy, gate=None, outs=None, raw_sum=None,
+                 defer=False):
     """-> (dx, dweight, dbias) of the 1x1 conv given dy (B, HW, AP).  With
     ``gate`` (the ReLU output x was made from, layout of x) -> (dx zeroed
     where gate <= 0, dweight, dbias, ungated dx).  ``outs``: buffers for
@@ -714,10 +764,11 @@ def _conv1x1_bwd(x, weight, dy, gate=None, outs=None, raw_sum=None):
         _gemm_desc(_p(dy), _p(x), _p(part), S, AP, C, kper, False, AP,
                    kper * AP, False, C, kper * C, C, slab,
                    asum=_off(part, AP * C), asum_b=slab), dgrad, x)
-    jobs = [dict(partial=part, shapes=[tuple(weight.shape), (AP,)], outs=outs)]
+    jobs = [dict(partial=part, shapes=[tuple(weight.shape), (AP,)], outs=outs,
+                 defer=defer)]
     if raw_sum is not None:
         jobs.append(dict(partial=raw.view(B, HW * C), shapes=[raw_sum[0]],
-                         transpose=C, outs=[raw_sum[1]]))
+                         transpose=C, outs=[raw_sum[1]], defer=defer))
     gw, gb = _sum_rows_multi(jobs)[0]
     return (dx, gw, gb) if gate is None else (dx, gw, gb, raw)
 
@@ -889,12 +940,18 @@ class _PartEncoder(torch.autograd.Function):
         g_attb = _grad_out(ctx.slots[2], x, (att_w2.shape[0],))
         # embedding-bias gradient: batch sum of the ungated dx, (HW, C) -> (C, HW)
         g_pb = _grad_out(ctx.slots[0], x, pb_shape)
+        # parameters with a slot in the flat gradient buffer are leaves: the
+        # sums that produce their gradients can wait for the step's one
+        # column-sum launch (ops.deferred_param_sums)
         dpre, _, _, _ = _conv1x1_bwd(x, att_w2, dy, gate=act.view(B, HW, C),
                                      outs=[g_attw, g_attb],
-                                     raw_sum=(pb_shape, g_pb))
+                                     raw_sum=(pb_shape, g_pb),
+                                     defer=all(sl is not None
+                                               for sl in ctx.slots[:3]))
         gws, gbs = _conv_stack_bwd(
             image, acts, wds, strides, wshapes, dpre.view(act.shape),
-            lambda i: _grad_out(ctx.slots[3 + i], image, ctx.refs[i]))
+            lambda i: _grad_out(ctx.slots[3 + i], image, ctx.refs[i]),
+            defer=ctx.slots[3] is not None and ctx.slots[3 + L] is not None)
         return (None, None, g_pb, g_attw, g_attb, None, None, None, None,
                 *gws, *gbs)
 
@@ -1028,7 +1085,8 @@ class _ColoredTemplates(torch.autograd.Function):
         gw1, gb1, gw2, gb2 = _sum_rows(
             partial, [(H1, F), (H1,), (C, H1), (C,)],
             outs=[_grad_out(sl, t) for sl, t in zip(ctx.slots[1:],
-                                                    (w1, b1, w2, b2))])
+                                                    (w1, b1, w2, b2))],
+            defer=all(sl is not None for sl in ctx.slots[1:5]))
         return g_logits, g_feature, gw1, gb1, gw2, gb2, None, None
 
 
@@ -1304,11 +1362,12 @@ class _CapsuleVotes(torch.autograd.Function):
         gall_rows = torch.as_strided(gall, (B, O * ldp), (O * ldp, 1))
         (g_static,), (g_cvr, g_caps, g_vote, g_scale) = _sum_rows_multi([
             dict(partial=gin.view(B, -1), shapes=[args[1].shape],
-                 outs=outs[:1]),
+                 outs=outs[:1], defer=ctx.slots[0] is not None),
             dict(partial=gall_rows,
                  shapes=[t.shape for t in args[2:6]],
                  starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=ldp,
-                 outs=outs[1:])])
+                 outs=outs[1:],
+                 defer=all(sl is not None for sl in ctx.slots[1:5]))])
         return (gall if ggated is None else ggated, g_static, g_cvr, g_caps,
                 g_vote, g_scale, None, None, None, None, None, None, None, None)
 
@@ -1592,14 +1651,17 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
     if alpha is not None:
         ashape = tuple(alpha_shape or alpha.shape)
         jobs.append(dict(partial=g_alpha_p.view(B, -1), shapes=[ashape],
-                         outs=[_grad_out(slots[1], alpha, ashape)]))
+                         outs=[_grad_out(slots[1], alpha, ashape)],
+                         defer=slots[1] is not None))
     scal = [(i, t) for i, t in enumerate((bg_value, bg_ml, temp, out_scale))
             if t is not None]
     if scal:
         jobs.append(dict(partial=g_scal.view(-1, 4),
                          shapes=[t.shape for _, t in scal],
                          starts=[i for i, _ in scal],
-                         outs=[_grad_out(slots[5 + i], t) for i, t in scal]))
+                         outs=[_grad_out(slots[5 + i], t) for i, t in scal],
+                         defer=all(slots[5 + i] is not None
+                                   for i, _ in scal)))
     res = _sum_rows_multi(jobs) if jobs else []
     if alpha is not None:
         g_alpha = res[0][0]

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from . import ops
 from .distributions import GaussianMixture, _NormalView
-from .general_utils import AttrDict, prod
+from .general_utils import AttrDict, LazyAttrDict, prod
 from .nn_ext import MLP, relu1
 from .nn_utils import choose_activation
 
@@ -73,6 +73,18 @@ class TemplateGenerator(nn.Module):
         return AttrDict(raw_templates=raw_templates, templates=templates)
 
 
+class _Rendered:
+    """The two rendered outputs of a decoder call, made on first use."""
+
+    def __init__(self, inputs):
+        self.inputs, self.out = inputs, None
+
+    def get(self, i):
+        if self.out is None:
+            self.out = ops.render_templates(self.inputs)
+        return self.out[i]
+
+
 class TemplateBasedImageDecoder(nn.Module):
     """Affine-warps every template (and its alpha map) into the image frame
     and returns the per-pixel Gaussian mixture over the M templates plus a
@@ -88,6 +100,11 @@ class TemplateBasedImageDecoder(nn.Module):
         self.learn_output_scale = learn_output_scale
         self.use_alpha_channel = use_alpha_channel
         self.background_value = background_value
+        # True: the two (B, M+1, ., H, W) outputs are rendered on first access
+        # instead of in forward() -- a training step only needs
+        # pdf.log_prob(...) of the fused kernel, which never reads them
+        # (SURVEY.md section 7's loss-only path; train_step.TrainStep sets it)
+        self.lazy_render = False
 
         if use_alpha_channel:
             self.templates_alpha = nn.Parameter(
@@ -130,11 +147,24 @@ class TemplateBasedImageDecoder(nn.Module):
             temperature_logit=None if self.use_alpha_channel
             else self.temperature_logit,
             out_scale=self.scale if self.learn_output_scale else None)
-        transformed_templates, mixing_logits = ops.render_templates(inputs)
         if self.learn_output_scale:
             scale = nn.functional.softplus(self.scale) + 1e-4
         else:
             scale = self._unit_scale
+        if self.lazy_render:
+            rendered = _Rendered(inputs)
+
+            def fill(d):
+                dict.__setitem__(d, "transformed_templates", rendered.get(0))
+                dict.__setitem__(d, "mixing_logits", rendered.get(1))
+                d["_lazy"].clear()
+
+            out = LazyAttrDict(pdf=GaussianMixture(
+                _NormalView(lambda: rendered.get(0), scale),
+                lambda: rendered.get(1), _decoder_inputs=inputs))
+            out["_lazy"] = dict(transformed_templates=fill, mixing_logits=fill)
+            return out
+        transformed_templates, mixing_logits = ops.render_templates(inputs)
         pdf = GaussianMixture(_NormalView(transformed_templates, scale),
                               mixing_logits, _decoder_inputs=inputs)
         return AttrDict(transformed_templates=transformed_templates,

@@ -5,6 +5,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import nn_utils, ops
+from .general_utils import LazyAttrDict
 from .object_decoder import sparsity_loss
 
 
@@ -195,7 +196,14 @@ class SCAE(nn.Module):
 
         res.templates = templates
         res.template_presence = live_presence
-        res.transformed_templates = res.rec.transformed_templates
+        if isinstance(res.rec, LazyAttrDict):
+            # part_decoder.lazy_render: the alias must not force the render
+            lazy = LazyAttrDict(res)
+            lazy["_lazy"] = dict(transformed_templates=lambda d: dict.__setitem__(
+                d, "transformed_templates", d["rec"]["transformed_templates"]))
+            res = lazy
+        else:
+            res.transformed_templates = res.rec.transformed_templates
 
         if self.n_classes is not None:
             assert self.prior_classifier is not None

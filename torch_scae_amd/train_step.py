@@ -9,6 +9,7 @@ import os
 
 import torch
 
+from . import ops
 from .data_parallel import (FlatParameters, RMSpropFlat, all_reduce_gradients,
                             broadcast_parameters, world)
 
@@ -40,7 +41,7 @@ class TrainStep:
     def __init__(self, model, batch_size, image_shape, lr=3e-5, use_graph=True,
                  optimizer=True, momentum=0.9, weight_decay=0.0,
                  lr_decay_rate=0.997, autocast_dtype=None,
-                 force_collective=False, overlap=True):
+                 force_collective=False, overlap=True, lazy_render=True):
         self.model = model
         self.device = next(model.parameters()).device
         self.world = world()[1]
@@ -59,6 +60,11 @@ class TrainStep:
             self.split = False
         if hasattr(model, "split_backward"):
             model.split_backward = self.split
+        # loss-only step: the (B, M+1, ., H, W) reconstruction tensors, which
+        # neither SCAE.loss nor its backward read, render on first access
+        dec = getattr(model, "part_decoder", None)
+        if lazy_render and hasattr(dec, "lazy_render"):
+            dec.lazy_render = True
         self.collective_mode = None if not self.collective else \
             "in graph" if self.in_graph_collective else \
             "2 buckets, the first overlapping the encoder backward" \
@@ -95,8 +101,10 @@ class TrainStep:
                             enabled=self.autocast_dtype is not None):
             res = self.model(self.image)
         loss, info = self.model.loss(res, self.image, self.label)
-        # a resident seed: no ones_like fill per step
-        loss.backward(self._one)
+        # a resident seed: no ones_like fill per step; the column sums that
+        # only produce parameter gradients wait for ONE launch at the end
+        with ops.deferred_param_sums():
+            loss.backward(self._one)
         self._cut = res.get("_phase_cut") if self.split else None
         self.flat.gather_grads(None if self._cut is None else 0)
         if self._capturing:
@@ -126,7 +134,9 @@ class TrainStep:
         self._cut = None
         keep = [(t, l.grad) for t, l in zip(srcs, leaves)
                 if l.grad is not None]
-        torch.autograd.backward([t for t, _ in keep], [g for _, g in keep])
+        with ops.deferred_param_sums():
+            torch.autograd.backward([t for t, _ in keep],
+                                    [g for _, g in keep])
         self.flat.gather_grads(1)
 
     def _fwd_bwd(self):
