@@ -22,7 +22,10 @@
 //     without a workgroup, 32 x 32 split-K tiles give 4x as many).
 // Either way the accumulators leave through LDS as float4 rows (coalesced NHWC
 // stores).  The first layer (C_in <= 4: nine-tap dot products) is a direct kernel.
+#include <cstdlib>
+
 #include "mfma_tile.h"
+#include "mfma_pipe.h"
 
 namespace {
 using namespace scae_tile;
@@ -345,6 +348,327 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_kernel(
   }
 }
 
+// =====================================================================================
+// Second-generation tiles (mfma_pipe.h): v_mfma_f32_32x32x2_f32, operands DMA'd global ->
+// LDS into a 3-stage ring, one barrier per 64-wide K chunk.  Same math, same operand
+// layouts (NHWC activations, Wf / Wd filters, per-split weight-gradient partials) and
+// the same tap-class decomposition of the data gradient as above.
+// =====================================================================================
+namespace pipe = scae_pipe;
+
+#define SCAE_PIPE_IDS                                                                  \
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6),        \
+            lane = tid & 63, li = lane & 31, lk = lane >> 5;                           \
+  const int wn = wid % T::WN, ks = wid / T::WN;
+
+// ---- forward ------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void fwd_pipe_tile(float *smem, int bx, int by,
+                                              const float *__restrict__ in,
+                                              const float *__restrict__ wf,
+                                              const float *__restrict__ bias,
+                                              float *__restrict__ out,
+                                              const float *__restrict__ post_bias,
+                                              float *__restrict__ out_post, const ConvGeom &g) {
+  SCAE_PIPE_IDS
+  const int M = g.B * g.OH * g.OW, K = 9 * g.Cin;
+  const int m0 = by * T::TA, n0 = bx * T::TB;
+  const pipe::DmaLane da = pipe::dma_lane<T::TA>(wid, lane), db = pipe::dma_lane<T::TB>(wid, lane);
+  const pipe::rsrc_t ra = pipe::make_rsrc(in, (unsigned)((size_t)g.B * g.IH * g.IW * g.Cin * 4));
+  const pipe::rsrc_t rb = pipe::make_rsrc(wf, (unsigned)((size_t)g.Cout * K * 4));
+  int avo[T::RA], bvo[T::RB];   // per-lane byte offsets of the rows this lane moves
+#pragma unroll
+  for (int j = 0; j < T::RA; ++j) {
+    const int m = min(m0 + da.row0 + pipe::DMA_ROWS * j, M - 1);   // rows past M: any valid line
+    const int n = m / (g.OH * g.OW), rem = m - n * g.OH * g.OW, oh = rem / g.OW,
+              ow = rem - oh * g.OW;
+    avo[j] = ((((n * g.IH + oh * g.stride) * g.IW + ow * g.stride) * g.Cin) + da.koff) * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < T::RB; ++j)
+    bvo[j] = ((n0 + db.row0 + pipe::DMA_ROWS * j) * K + db.koff) * 4;
+  struct Ctx {
+    int soa, sob;
+  };
+  // chunk c covers k = 32 c .. 32 c + 31 = channels ci0 .. of tap (kh, kw): carried
+  int c_ci = 0, c_kw = 0, c_kh = 0, c_k = 0;
+  auto chunk = [&](int) {
+    const Ctx x{((c_kh * g.IW + c_kw) * g.Cin + c_ci) * 4, c_k * 4};
+    c_k += pipe::BK, c_ci += pipe::BK;
+    if (c_ci == g.Cin) {
+      c_ci = 0;
+      if (++c_kw == 3) c_kw = 0, ++c_kh;
+    }
+    return x;
+  };
+  auto issue = [&](const Ctx &x, float *st, int j) {   // j: compile-time after unrolling
+    if (j < T::RA)
+      pipe::dma16(ra, st + da.loff + j * pipe::DMA_ROWS * pipe::BKH, avo[j], x.soa);
+    else
+      pipe::dma16(rb, st + T::TA * pipe::BK + db.loff + (j - T::RA) * pipe::DMA_ROWS * pipe::BKH,
+                  bvo[j - T::RA], x.sob);
+  };
+  pipe::f32x16 acc[T::MI][T::NI];
+  pipe::kk_zero<T>(acc);
+  pipe::kk_mainloop<T>(K / pipe::BK, smem, acc, wn, ks, li, lk, chunk, issue);
+  const int hw = g.OH * g.OW;
+  pipe::kk_epilogue<T>(smem, acc, wid, wn, ks, li, lk, [&](int row, int col, float v) {
+    const int m = m0 + row, n = n0 + col;
+    if (m >= M) return;
+    const float o = fmaxf(v + bias[n], 0.f);
+    out[(size_t)m * g.Cout + n] = o;
+    if (out_post)   // + the per-(channel, pixel) embedding bias, (Cout, OH, OW)
+      out_post[(size_t)m * g.Cout + n] = o + post_bias[(size_t)n * hw + m % hw];
+  });
+}
+
+template <class T>
+__global__ __launch_bounds__(pipe::NT) void conv_fwd_pipe_kernel(
+    const float *__restrict__ in, const float *__restrict__ wf, const float *__restrict__ bias,
+    float *__restrict__ out, const float *__restrict__ post_bias, float *__restrict__ out_post,
+    ConvGeom g) {
+  __shared__ __attribute__((aligned(1024))) float smem[T::SMEM];
+  fwd_pipe_tile<T>(smem, blockIdx.x, blockIdx.y, in, wf, bias, out, post_bias, out_post, g);
+}
+
+// ---- data gradient (tap classes as in dgrad_tile) -----------------------------------
+template <class T>
+__device__ __forceinline__ void dgrad_pipe_tile(float *smem, int bx, int by,
+                                                const float *__restrict__ dpre,
+                                                const float *__restrict__ wd,
+                                                const float *__restrict__ gate,
+                                                float *__restrict__ din, const ConvGeom &g,
+                                                const DgradPlan &pl) {
+  SCAE_PIPE_IDS
+  const int nz = pl.nrc * pl.ncc;
+  const int z = __popcll(__ballot(lane + 1 < nz && by >= pl.tile_start[min(lane + 1, 64)]));
+  const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
+  const int AH = pl.rcount[rc], AW = pl.ccount[cc], M = g.B * AH * AW, KT = 9 * g.Cout;
+  const int m0 = (by - pl.tile_start[z]) * T::TA, n0 = bx * T::TB;
+  const int sh = g.stride - 1;
+  const int rm = pl.rmask[rc], cm = pl.cmask[cc];
+  const int nkh = __popc(rm), nkw = __popc(cm);
+  auto nth_bit = [](int mask, int n) {
+    const int k0 = (mask & 1) ? 0 : ((mask & 2) ? 1 : 2);
+    if (n == 0) return k0;
+    const int rest = mask & ~(1 << k0);
+    return (n == 1 && (rest & 2)) ? 1 : 2;
+  };
+  const int cpt = g.Cout / pipe::BK, nchunk = nkh * nkw * cpt;
+  const pipe::DmaLane da = pipe::dma_lane<T::TA>(wid, lane), db = pipe::dma_lane<T::TB>(wid, lane);
+  const pipe::rsrc_t ra =
+      pipe::make_rsrc(dpre, (unsigned)((size_t)g.B * g.OH * g.OW * g.Cout * 4));
+  const pipe::rsrc_t rb = pipe::make_rsrc(wd, (unsigned)((size_t)g.Cin * KT * 4));
+  int pn[T::RA], pih[T::RA], piw[T::RA], bvo[T::RB];
+#pragma unroll
+  for (int j = 0; j < T::RA; ++j) {
+    const int m = min(m0 + da.row0 + pipe::DMA_ROWS * j, M - 1);
+    const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
+    pn[j] = n * g.OH * g.OW;
+    pih[j] = pl.rlist[pl.rstart[rc] + a], piw[j] = pl.clist[pl.cstart[cc] + b];
+  }
+#pragma unroll
+  for (int j = 0; j < T::RB; ++j)
+    bvo[j] = ((n0 + db.row0 + pipe::DMA_ROWS * j) * KT + db.koff) * 4;
+  struct Ctx {
+    int kh, kw, soa, sob;
+  };
+  int c_co = 0, c_ti = 0, c_tj = 0;   // chunk -> (tap (ti, tj) of the class, channel block)
+  auto chunk = [&](int) {
+    const int kh = nth_bit(rm, c_ti), kw = nth_bit(cm, c_tj);
+    const Ctx x{kh, kw, c_co * 4, ((kh * 3 + kw) * g.Cout + c_co) * 4};
+    c_co += pipe::BK;
+    if (c_co == g.Cout) {
+      c_co = 0;
+      if (++c_tj == nkw) c_tj = 0, ++c_ti;
+    }
+    return x;
+  };
+  auto issue = [&](const Ctx &x, float *st, int j) {
+    if (j < T::RA) {
+      // the range check only ever fails on the merged classes of stride 2: such a
+      // lane reads zeros (an offset outside the descriptor)
+      const int dh = pih[j] - x.kh, dw = piw[j] - x.kw, oh = dh >> sh, ow = dw >> sh;
+      const bool ok = dh >= 0 && dw >= 0 && oh < g.OH && ow < g.OW;
+      const int vo = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout + da.koff) * 4 : pipe::DMA_ZERO;
+      pipe::dma16(ra, st + da.loff + j * pipe::DMA_ROWS * pipe::BKH, vo, x.soa);
+    } else {
+      pipe::dma16(rb, st + T::TA * pipe::BK + db.loff + (j - T::RA) * pipe::DMA_ROWS * pipe::BKH,
+                  bvo[j - T::RA], x.sob);
+    }
+  };
+  pipe::f32x16 acc[T::MI][T::NI];
+  pipe::kk_zero<T>(acc);
+  pipe::kk_mainloop<T>(nchunk, smem, acc, wn, ks, li, lk, chunk, issue);
+  pipe::kk_epilogue<T>(smem, acc, wid, wn, ks, li, lk, [&](int row, int col, float v) {
+    const int m = m0 + row;
+    if (m >= M) return;
+    const int nb = m / (AH * AW), rem = m - nb * AH * AW, a = rem / AW, b = rem - a * AW;
+    const int ih = pl.rlist[pl.rstart[rc] + a], iw = pl.clist[pl.cstart[cc] + b];
+    const size_t o = (((size_t)nb * g.IH + ih) * g.IW + iw) * g.Cin + n0 + col;
+    if (gate) v = gate[o] > 0.f ? v : 0.f;
+    din[o] = v;
+  });
+}
+
+// ---- weight gradient: tile (bx, by) of tap / split bz ------------------------------------
+template <class T>
+__device__ __forceinline__ void wgrad_pipe_tile(float *smem, int bx, int by, int bz,
+                                                const float *__restrict__ dpre,
+                                                const float *__restrict__ in,
+                                                float *__restrict__ partial, const ConvGeom &g,
+                                                int splits) {
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63,
+            li = lane & 31, lk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  const int M = g.B * g.OH * g.OW;
+  const int tap = bz % 9, split = bz / 9, kh = tap / 3, kw = tap - kh * 3;
+  const int per = ((M + splits - 1) / splits + T::BKW - 1) / T::BKW * T::BKW;
+  const int kbeg = split * per, kend = min(M, kbeg + per);
+  const int co0 = by * T::TA, ci0 = bx * T::TB;
+  const bool want_bias = tap == 0 && bx == 0;   // workgroup-uniform
+  // DMA pieces: 256 consecutive floats of the [k][rows] tile; piece p = wid + 4 j of the
+  // A tile, then of the B tile.  Lane l moves floats 4 l .. 4 l + 3 of its piece.
+  constexpr int KA = 256 / T::TA, KB = 256 / T::TB;   // k rows per piece
+  const int ka = (4 * lane) / T::TA, ca = (4 * lane) % T::TA;
+  const int kb = (4 * lane) / T::TB, cb = (4 * lane) % T::TB;
+  // descriptors end at pixel kend: rows past the split's end read zeros
+  const pipe::rsrc_t ra = pipe::make_rsrc(dpre, (unsigned)((size_t)kend * g.Cout * 4));
+  const pipe::rsrc_t rb = pipe::make_rsrc(in, (unsigned)((size_t)g.B * g.IH * g.IW * g.Cin * 4));
+  // the pixel (n, oh, ow) of each B piece is carried from chunk to chunk (every piece is
+  // issued exactly once per chunk, in ascending chunk order) instead of re-divided
+  constexpr int NA = T::PA / 4, NB = T::PB / 4;
+  int avo[NA], pm[NB], pn[NB], poh[NB], pow_[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j)
+    avo[j] = ((kbeg + (wid + 4 * j) * KA + ka) * g.Cout + co0 + ca) * 4;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    pm[j] = kbeg + (wid + 4 * j) * KB + kb;
+    pn[j] = pm[j] / (g.OH * g.OW);
+    const int rem = pm[j] - pn[j] * g.OH * g.OW;
+    poh[j] = rem / g.OW, pow_[j] = rem - poh[j] * g.OW;
+  }
+  const int dq = T::BKW / g.OW, dr = T::BKW - dq * g.OW;
+  const int cstep = T::BKW * g.Cout * 4;
+  auto issue = [&](int c, float *st, int j) {
+    if (j < NA) {
+      // (the chunk offset rides in the per-lane offset: the descriptor's range check,
+      // which makes the rows past kend read zeros, does not see the scalar offset)
+      pipe::dma16(ra, st + (wid + 4 * j) * 256, avo[j] + c * cstep, 0);
+    } else {
+      const int jb = j - NA, p = wid + 4 * jb;
+      const int vo = pm[jb] < kend
+                         ? ((((pn[jb] * g.IH + poh[jb] * g.stride + kh) * g.IW +
+                              pow_[jb] * g.stride + kw) * g.Cin) + ci0 + cb) * 4
+                         : pipe::DMA_ZERO;
+      pipe::dma16(rb, st + T::TA * T::BKW + p * 256, vo, 0);
+      pm[jb] += T::BKW;   // advance by one chunk of pixels
+      pow_[jb] += dr;
+      const int carry = pow_[jb] >= g.OW;
+      pow_[jb] -= carry ? g.OW : 0;
+      poh[jb] += dq + carry;
+      while (poh[jb] >= g.OH) poh[jb] -= g.OH, ++pn[jb];
+    }
+  };
+  const int nchunk = kbeg < kend ? (kend - kbeg + T::BKW - 1) / T::BKW : 0;
+  pipe::f32x16 acc[T::MI][T::NI];
+#pragma unroll
+  for (int a = 0; a < T::MI; ++a)
+#pragma unroll
+    for (int b = 0; b < T::NI; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  float bsum = 0.f;   // column sum of dpre over this split (thread = channel, tid < TA)
+  {
+    constexpr int LA = T::NS - 1;
+#pragma unroll
+    for (int c = 0; c < LA; ++c)
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < T::PPW; ++j) issue(c, smem + c * T::STAGE, j);
+      }
+    int s = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      if (LA == 2 && c + 1 < nchunk)
+        pipe::wait_vm<T::PPW>();
+      else
+        pipe::wait_vm<0>();
+      pipe::wg_barrier();
+      float *s2 = smem + (s >= 1 ? s - 1 : T::NS - 1) * T::STAGE;
+      const float *st = smem + s * T::STAGE;
+      if (want_bias && tid < T::TA) {
+#pragma unroll 16
+        for (int k = 0; k < T::BKW; ++k) bsum += st[k * T::TA + tid];
+      }
+      pipe::ss_compute<T>(st, acc, wm, wn, li, lk, c + LA < nchunk,
+                          [&](int j) { issue(c + LA, s2, j); });
+      s = s + 1 == T::NS ? 0 : s + 1;
+    }
+  }
+  float *dst = partial + (size_t)(split * 9 + tap) * g.Cout * g.Cin;
+#pragma unroll
+  for (int a = 0; a < T::MI; ++a)
+#pragma unroll
+    for (int b = 0; b < T::NI; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (wm * T::MI + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int col = (wn * T::NI + b) * 32 + li;
+        dst[(size_t)(co0 + row) * g.Cin + ci0 + col] = acc[a][b][e];
+      }
+  if (want_bias && tid < T::TA)
+    partial[(size_t)splits * 9 * g.Cout * g.Cin + (size_t)split * g.Cout + co0 + tid] = bsum;
+}
+
+template <class T>
+__global__ __launch_bounds__(pipe::NT) void conv_dgrad_pipe_kernel(
+    const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
+    float *__restrict__ din, ConvGeom g, DgradPlan pl) {
+  __shared__ __attribute__((aligned(1024))) float smem[T::SMEM];
+  dgrad_pipe_tile<T>(smem, blockIdx.x, blockIdx.y, dpre, wd, gate, din, g, pl);
+}
+template <class T>
+__global__ __launch_bounds__(pipe::NT) void conv_wgrad_pipe_kernel(
+    const float *__restrict__ dpre, const float *__restrict__ in, float *__restrict__ partial,
+    ConvGeom g, int splits) {
+  __shared__ __attribute__((aligned(1024))) float smem[T::SMEM];
+  wgrad_pipe_tile<T>(smem, blockIdx.x, blockIdx.y, blockIdx.z, dpre, in, partial, g, splits);
+}
+// data- and weight-gradient tiles of a layer in one launch (see conv_bwd_pair_kernel)
+template <class TD, class TW>
+__global__ __launch_bounds__(pipe::NT) void conv_bwd_pair_pipe_kernel(
+    const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
+    float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
+    ConvGeom g, DgradPlan pl, int splits, PairGrid pg) {
+  constexpr int SM = TD::SMEM > TW::SMEM ? TD::SMEM : TW::SMEM;
+  __shared__ __attribute__((aligned(1024))) float smem[SM];
+  const int bid = blockIdx.x;
+  if (bid < pg.nd) {   // workgroup-uniform
+    dgrad_pipe_tile<TD>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
+  } else {
+    const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
+    wgrad_pipe_tile<TW>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
+  }
+}
+
+// first-generation data-gradient tiles (many small workgroups per CU suit the short K
+// loops of the tap classes) beside second-generation weight-gradient tiles
+template <int DMODE, class TW>
+__global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_kernel(
+    const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
+    float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
+    ConvGeom g, DgradPlan pl, int splits, PairGrid pg) {
+  constexpr int SM = Tile<DMODE>::SMEM > TW::SMEM ? Tile<DMODE>::SMEM : TW::SMEM;
+  __shared__ __attribute__((aligned(1024))) float smem[SM];
+  const int bid = blockIdx.x;
+  if (bid < pg.nd) {   // workgroup-uniform
+    dgrad_tile<DMODE>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
+  } else {
+    const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
+    wgrad_pipe_tile<TW>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
+  }
+}
+
 // ---- small helpers ---------------------------------------------------------------
 // W[co][ci][3][3] -> Wf[co][tap][ci], Wd[ci][tap][co]
 __global__ void relayout_weights_kernel(const float *__restrict__ w, float *__restrict__ wf,
@@ -596,6 +920,37 @@ WgradPlan wgrad_plan(int M, int Cin, int Cout) {
   p.splits = (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
   return p;
 }
+
+// second-generation tile shapes (mfma_pipe.h)
+#ifndef SCAE_PIPE_NS
+#define SCAE_PIPE_NS 3
+#endif
+#ifndef SCAE_PIPE_WBK
+#define SCAE_PIPE_WBK 32
+#endif
+using PipeC0 = pipe::KK<64, 128, 4, SCAE_PIPE_NS>;   // 4 waves x (64 x 32); 24 KiB / stage
+using PipeC1 = pipe::KK<32, 128, 4, SCAE_PIPE_NS>;   // 4 waves x (32 x 32); 20 KiB / stage
+using PipeC2 = pipe::KK<32, 64, 2, SCAE_PIPE_NS>;    // 2 x 2 (columns x k halves); 12 KiB
+using PipeC3 = pipe::KK<64, 64, 2, SCAE_PIPE_NS>;    // 2 x 2, 64 rows; 16 KiB
+// weight gradient: 2 x 2 waves x (32 x 32)
+using PipeW = pipe::SS<64, 64, SCAE_PIPE_WBK, SCAE_PIPE_NS>;
+
+// shape for an (M rows) x (N columns) k-contiguous problem; an environment variable
+// (read per call; tuning aid) overrides: -1 = first-generation kernels
+inline int pipe_cfg(const char *env, long M, int N) {
+  const char *e = getenv(env);
+  if (e && *e) {
+    const int v = atoi(e);
+    if (v < 0) return -1;
+    if (N % 128 == 0 || v >= 2) return v > 3 ? 3 : v;
+  }
+  // measured on the encoder's 128-channel layers at B = 128 and B = 1024: the 32 x 64
+  // shape (4 workgroups per CU, in-workgroup k split) wins or ties everywhere -- with
+  // few tiles because it quantises best over 256 CUs, with many because four
+  // workgroups per CU cover each other's barrier and DMA waits
+  (void)M;
+  return 2;
+}
 }  // namespace
 
 extern "C" int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout,
@@ -743,6 +1098,20 @@ extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const floa
   SCAE_REQUIRE(in && wf && bias && out && (!out_post || post_bias));
   const int M = B * g.OH * g.OW;
   hipStream_t st = (hipStream_t)stream;
+  const int cfg = pipe_cfg("SCAE_K8_FWD", M, Cout);
+  if (cfg >= 0) {
+#define SCAE_FWD_PIPE(TT)                                                                    \
+  hipLaunchKernelGGL(conv_fwd_pipe_kernel<TT>, dim3(Cout / TT::TB, (M + TT::TA - 1) / TT::TA), \
+                     dim3(pipe::NT), 0, st, in, wf, bias, out, post_bias, out_post, g)
+    switch (cfg) {
+      case 0: SCAE_FWD_PIPE(PipeC0); break;
+      case 1: SCAE_FWD_PIPE(PipeC1); break;
+      case 2: SCAE_FWD_PIPE(PipeC2); break;
+      default: SCAE_FWD_PIPE(PipeC3);
+    }
+#undef SCAE_FWD_PIPE
+    return scae_launch_status();
+  }
 #ifndef SCAE_FWD_WIDE_MIN
 #define SCAE_FWD_WIDE_MIN 300
 #endif
@@ -770,6 +1139,7 @@ extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const floa
 struct DgradLaunch {
   DgradPlan pl;
   int mode, gx, ny;
+  int cfg;   // >= 0: second-generation tile shape (mode / gx / ny then refer to it)
 };
 // (pair = true: the launch also carries the weight-gradient tiles, so the data
 // gradient does not have to fill the chip on its own)
@@ -793,6 +1163,19 @@ static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false) {
     pl.tile_start[pl.nrc * pl.ncc] = tot;
     return tot;
   };
+  // rows of the problem: input pixels (class tiles are ragged; close enough to choose)
+  // (default: first-generation data-gradient tiles, see conv_bwd_pair_mixed_kernel)
+  const char *env = getenv(pair ? "SCAE_K8_PAIR" : "SCAE_K8_DG");
+  d.cfg = env && *env ? pipe_cfg(pair ? "SCAE_K8_PAIR" : "SCAE_K8_DG", (long)g.B * g.IH * g.IW,
+                                 g.Cin)
+                      : -1;
+  if (d.cfg >= 0) {
+    const int ta = (d.cfg == 0 || d.cfg == 3) ? 64 : 32, tb = d.cfg <= 1 ? 128 : 64;
+    d.mode = 0;
+    d.ny = tiles(ta);
+    d.gx = g.Cin / tb;
+    return d;
+  }
   const long t64 = (long)(g.Cin / 64) * tiles(64), t32 = (long)(g.Cin / 64) * tiles(32);
   d.mode = pair ? (t64 >= SCAE_PAIR_SMALL_TILES ? 0 : (t32 >= SCAE_PAIR_WIDE_MIN ? 2 : 1))
                 : tile_mode(t64, t32, 600);
@@ -812,6 +1195,19 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
   const DgradLaunch d = plan_dgrad(g);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(d.gx, d.ny);
+  if (d.cfg >= 0) {
+#define SCAE_DG_PIPE(TT)                                                                   \
+  hipLaunchKernelGGL(conv_dgrad_pipe_kernel<TT>, grid, dim3(pipe::NT), 0, st, dpre, wd, gate, \
+                     din, g, d.pl)
+    switch (d.cfg) {
+      case 0: SCAE_DG_PIPE(PipeC0); break;
+      case 1: SCAE_DG_PIPE(PipeC1); break;
+      case 2: SCAE_DG_PIPE(PipeC2); break;
+      default: SCAE_DG_PIPE(PipeC3);
+    }
+#undef SCAE_DG_PIPE
+    return scae_launch_status();
+  }
   if (d.mode == 0)
     hipLaunchKernelGGL(conv_dgrad_kernel<0>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
   else if (d.mode == 2)
@@ -831,10 +1227,36 @@ extern "C" int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, con
   if (IH > DG_MAXDIM || IW > DG_MAXDIM) return SCAE_ERR_UNSUPPORTED;
   const DgradLaunch d = plan_dgrad(g, true);
   const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
-  const int wt = p.small ? 32 : 64;
+  const int wt = p.small && d.cfg < 0 ? 32 : 64;
   const PairGrid pg{d.gx * d.ny, d.gx, Cin / wt, Cout / wt};
   const dim3 grid(pg.nd + pg.wx * pg.wy * 9 * p.splits);
   hipStream_t st = (hipStream_t)stream;
+  if (d.cfg >= 0) {
+#define SCAE_PAIR_PIPE(TT)                                                                  \
+  hipLaunchKernelGGL((conv_bwd_pair_pipe_kernel<TT, PipeW>), grid, dim3(pipe::NT), 0, st,   \
+                     dpre, wd, in, din, in, partial, g, d.pl, p.splits, pg)
+    switch (d.cfg) {
+      case 0: SCAE_PAIR_PIPE(PipeC0); break;
+      case 1: SCAE_PAIR_PIPE(PipeC1); break;
+      case 2: SCAE_PAIR_PIPE(PipeC2); break;
+      default: SCAE_PAIR_PIPE(PipeC3);
+    }
+#undef SCAE_PAIR_PIPE
+    return scae_launch_status();
+  }
+  const char *pe = getenv("SCAE_K8_PAIR");
+  if (!(pe && atoi(pe) < 0)) {   // second-generation weight-gradient tiles (64 x 64)
+    const PairGrid mg{d.gx * d.ny, d.gx, Cin / 64, Cout / 64};
+    const dim3 mgrid(mg.nd + mg.wx * mg.wy * 9 * p.splits);
+#define SCAE_PAIR_MIXED(DM)                                                                  \
+  hipLaunchKernelGGL((conv_bwd_pair_mixed_kernel<DM, PipeW>), mgrid, dim3(NT), 0, st, dpre, wd, \
+                     in, din, in, partial, g, d.pl, p.splits, mg)
+    if (d.mode == 0) SCAE_PAIR_MIXED(0);
+    else if (d.mode == 2) SCAE_PAIR_MIXED(2);
+    else SCAE_PAIR_MIXED(1);
+#undef SCAE_PAIR_MIXED
+    return scae_launch_status();
+  }
 #define SCAE_PAIR(DM, WS)                                                                     \
   hipLaunchKernelGGL((conv_bwd_pair_kernel<DM, WS>), grid, dim3(NT), 0, st, dpre, wd, in, din, \
                      in, partial, g, d.pl, p.splits, pg)
@@ -862,7 +1284,11 @@ extern "C" int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float 
   if (rc) return rc;
   SCAE_REQUIRE(dpre && in && partial);
   const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
-  if (p.small)
+  const char *e = getenv("SCAE_K8_WG");
+  if (!(e && atoi(e) < 0))
+    hipLaunchKernelGGL(conv_wgrad_pipe_kernel<PipeW>, dim3(Cin / 64, Cout / 64, 9 * p.splits),
+                       dim3(pipe::NT), 0, (hipStream_t)stream, dpre, in, partial, g, p.splits);
+  else if (p.small)
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(Cin / 32, Cout / 32, 9 * p.splits), dim3(NT),
                        0, (hipStream_t)stream, dpre, in, partial, g, p.splits);
   else
