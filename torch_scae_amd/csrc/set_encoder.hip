@@ -21,35 +21,19 @@
 // weight-gradient entry has one owning lane; per-workgroup partial sums are
 // reduced by the caller) and is bit-reproducible.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
+#include "set_encoder_args.h"
 
 namespace {
 
 constexpr int NT = 512;  // 8 waves: every (N x D) stage of a 24 x 16 set is one pass
-constexpr int NMAX = 64;   // max set size
-constexpr int MAXSEG = 4;  // input given as up to 4 column segments
-constexpr float kLnEps = 1e-5f;
-
-struct Seg {
-  const float *ptr;  // element (b, n, j) at ptr[b*bs + n*rs + j]
-  float *grad;       // nullable, contiguous (B, N, width)
-  int width, rs;
-  long bs;
-};
-
-struct StArgs {
-  Seg seg[MAXSEG];
-  int nseg;
-  const float *presence;  // (B, N) nullable
-  const float *params;    // packed, layout below
-  float *z;               // (B, N, Dout)
-  float *hsave;           // (B, L+1, N, D): input of every block + trunk output
-  const float *gz;        // bwd: (B, N, Dout)
-  float *pg_partial;      // bwd: (gridDim.x, P) per-workgroup parameter grads
-  int B, N, Din, Dout, L, layer_norm;
-  float sqrt_d;
-};
+using scae_st::kLnEps;
+using scae_st::MAXSEG;
+using scae_st::NMAX;
+using scae_st::Seg;
+using scae_st::StArgs;
 
 // packed GLOBAL parameter layout (floats), D = hidden width:
 //   W1 [D][Din], b1 [D]
@@ -763,6 +747,13 @@ int fill_args(StArgs &a, int nseg, const float *const *seg_ptr, const int *seg_w
   return SCAE_OK;
 }
 
+
+// the wave-per-set MFMA kernels (set_encoder_wave.hip) where they apply; the
+// environment variable SCAE_ST_WAVE=0 keeps the workgroup-per-set kernels (A/B timing)
+bool use_wave(const StArgs &a, int D) {
+  const char *e = getenv("SCAE_ST_WAVE");
+  return !(e && *e == '0') && scae_st::wave_supported(a, D);
+}
 }  // namespace
 
 extern "C" int scae_set_encoder_param_count(int D, int Din, int Dout, int L, int layer_norm) {
@@ -804,6 +795,7 @@ extern "C" int scae_set_encoder_fwd_f32(int nseg, const float *const *seg_ptr,
   a.z = z;
   a.hsave = hsave;
   const int grid = scae_set_encoder_grid(B);
+  if (use_wave(a, D)) return scae_st::wave_launch(a, false, grid, (hipStream_t)stream);
   switch (D) {
     case 8: return launch<8>(a, false, grid, (hipStream_t)stream);
     case 16: return launch<16>(a, false, grid, (hipStream_t)stream);

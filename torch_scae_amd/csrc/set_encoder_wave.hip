@@ -1,0 +1,427 @@
+// K2b on the matrix cores: ONE WAVEFRONT PER SET.
+//
+// The fused set-transformer trunk (fc1 -> L x SAB, set_transformer.py:107-142,:212-219)
+// at the reference's sizes is a chain of ~25 tiny dependent products per set (24 x 16
+// activations, 16 x 16 weights, 24 x 24 attention).  The workgroup-per-set kernels of
+// set_encoder.hip spread each product over 512 threads and pay a workgroup barrier
+// between every two stages: ~1 us per stage, 25 / 58 us per pass.  Here a single wave
+// owns a set: every product is a handful of v_mfma_f32_16x16x4_f32 (exact fp32), the
+// activations stay in registers in the MFMA output layout, and a stage boundary is an
+// LDS round trip of the same wave (no barrier) whenever the next product needs the
+// values as an operand.
+//
+// Layouts (lane l: r = l & 15, q = l >> 4; rows are padded to 32 = two 16-row tiles t):
+//   O layout   : what MFMA leaves: o[t][reg] = M[16 t + 4 q + reg][r]   (all N x 16 /
+//                N x N activations live like this; LayerNorm / softmax reduce over r
+//                with 16-lane xor shuffles, column sums over n are register sums plus
+//                xor 16 / 32);
+//   operand    : v_mfma_f32_16x16x4_f32 takes A[row r][k], B[k][col r] with k picked by q;
+//                which four k an instruction contracts is free as long as A and B
+//                agree, so lane q owns K/4 CONSECUTIVE k and reads them as float4s:
+//                  x W^T (B[k][c] = W[c][k])   : a float4 of W's row c (global, L2);
+//                  g W   (B[k][c] = W[k][c])   : four floats of W's column c;
+//                  products over n or m (K = 32): both operands from LDS tiles written
+//                                                 transposed ([col][row], 16-byte stores).
+//   LDS tiles  : "R" [32 rows][24] row-major (A operands with K = 16; stride 24 floats =
+//                6 x 16 B makes the row-per-lane ds_read_b128 conflict free), "T"
+//                [16][40] / [32][40] transposed or N x N (K = 32).
+// Rows / columns >= N carry finite padding that never reaches a valid entry: padded
+// keys get probability 0, padded rows get presence 0 and a zero output gradient.
+#include "set_encoder_args.h"
+
+namespace scae_st {
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int D = 16;
+constexpr int RS = 24;    // row stride of R tiles
+constexpr int TS = 40;    // row stride of T tiles
+constexpr int SLOT = 32 * TS;   // floats per generic tile slot
+
+struct Lay {   // packed parameter offsets (floats), see set_encoder.hip
+  int Din, L, ln;
+  __device__ int b1() const { return D * Din; }
+  __device__ int layer(int l) const { return D * Din + D + l * (5 * 272 + (ln ? 64 : 0)); }
+  __device__ int w(int m) const { return m < 4 ? m * 272 : 4 * 272 + (ln ? 32 : 0); }
+  __device__ int b(int m) const { return w(m) + 256; }
+  __device__ int ln0() const { return 4 * 272; }
+  __device__ int ln1() const { return b(4) + 16; }
+  __device__ int total() const { return layer(L); }
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
+__device__ __forceinline__ void lds_fence() {
+  // the wave's own LDS writes are visible to its later reads once they have completed
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// acc += A B over K = 16 (a, b: the lane's four consecutive k)
+__device__ __forceinline__ f32x4 mma16(f32x4 acc, float4 a, float4 b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  return acc;
+}
+struct F8 {
+  float4 lo, hi;
+};
+__device__ __forceinline__ f32x4 mma32(f32x4 acc, const F8 &a, const F8 &b) {
+  return mma16(mma16(acc, a.lo, b.lo), a.hi, b.hi);
+}
+// Reductions over the 16 lanes of a row group (= one DPP row): quad butterflies, then the
+// half-row and row mirrors pair every lane with the other quads -- VALU-speed lane
+// exchanges (ds_bpermute shuffles cost an LDS round trip each: a first version of this
+// kernel spent half of its time in them).  All 16 lanes get the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+__device__ __forceinline__ float rsum(float v) {
+  v += dpp<DPP_XOR1>(v);
+  v += dpp<DPP_XOR2>(v);
+  v += dpp<DPP_HALF_MIRROR>(v);
+  v += dpp<DPP_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ float rmax(float v) {
+  v = fmaxf(v, dpp<DPP_XOR1>(v));
+  v = fmaxf(v, dpp<DPP_XOR2>(v));
+  v = fmaxf(v, dpp<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp<DPP_MIRROR>(v));
+  return v;
+}
+// sum over the 16 rows of an O-layout tile (column sum): every lane of column r gets it
+__device__ __forceinline__ float csum(const f32x4 &o) {
+  float v = (o[0] + o[1]) + (o[2] + o[3]);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+struct Wave {
+  int lane, r, q, t;   // t: the 16-row tile this wave owns (= its index in the workgroup)
+  // O layout (own tile) -> R tile (row-major, stride RS)
+  __device__ __forceinline__ void wr_rows(float *tile, const f32x4 &o) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * q + e) * RS + r] = o[e];
+  }
+  // O layout -> T tile, transposed: tile[col r][row]
+  __device__ __forceinline__ void wr_cols(float *tile, const f32x4 &o) const {
+    *reinterpret_cast<float4 *>(tile + r * TS + 16 * t + 4 * q) =
+        make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // own rows of an N x N matrix (column tiles u) -> [32][TS] row-major
+  template <int NT>
+  __device__ __forceinline__ void wr_nn(float *tile, const f32x4 (&o)[NT]) const {
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * q + e) * TS + 16 * u + r] = o[u][e];
+  }
+  // ... and transposed: tile[col][row]
+  template <int NT>
+  __device__ __forceinline__ void wr_nn_t(float *tile, const f32x4 (&o)[NT]) const {
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+      *reinterpret_cast<float4 *>(tile + (16 * u + r) * TS + 16 * t + 4 * q) =
+          make_float4(o[u][0], o[u][1], o[u][2], o[u][3]);
+  }
+  // operand with K = 16 from an R tile: row 16 u + r, k = 4 q ..
+  __device__ __forceinline__ float4 rd16(const float *tile, int u) const {
+    return ld4(tile + (16 * u + r) * RS + 4 * q);
+  }
+  // operand with K = 32 from a T tile: row 16 u + r, k = 8 q ..
+  __device__ __forceinline__ F8 rd32(const float *tile, int u) const {
+    const float *p = tile + (16 * u + r) * TS + 8 * q;
+    return F8{ld4(p), ld4(p + 4)};
+  }
+  // ... K = 16 from a T tile (one key tile only): k = 4 q ..
+  __device__ __forceinline__ float4 rd16t(const float *tile, int u) const {
+    return ld4(tile + (16 * u + r) * TS + 4 * q);
+  }
+  // B operand of x W^T from a 16 x 16 row-major matrix in global memory
+  __device__ __forceinline__ float4 w_rows(const float *W) const { return ld4(W + r * D + 4 * q); }
+  // B operand of g W (column r of W)
+  __device__ __forceinline__ float4 w_cols(const float *W) const {
+    return make_float4(W[(4 * q) * D + r], W[(4 * q + 1) * D + r], W[(4 * q + 2) * D + r],
+                       W[(4 * q + 3) * D + r]);
+  }
+};
+// products over the keys / queries: K = 16 NT
+template <int NT>
+__device__ __forceinline__ f32x4 mma_n(f32x4 acc, const Wave &w, const float *A, int ua,
+                                       const float *B, int ub) {
+  if (NT == 2) return mma32(acc, w.rd32(A, ua), w.rd32(B, ub));
+  return mma16(acc, w.rd16t(A, ua), w.rd16t(B, ub));
+}
+
+// LayerNorm over the 16 features of the rows of an O-layout tile
+template <bool KEEP>
+__device__ __forceinline__ void layer_norm(f32x4 &v, float gamma, float beta, f32x4 &xh,
+                                           f32x4 &rstd) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = v[e];
+    const float mean = rsum(x) * (1.f / D);
+    const float d = x - mean;
+    const float rs = 1.f / sqrtf(rsum(d * d) * (1.f / D) + kLnEps);
+    const float h = d * rs;
+    if (KEEP) xh[e] = h, rstd[e] = rs;
+    v[e] = fmaf(h, gamma, beta);
+  }
+}
+
+// everything a SAB forward leaves behind for the backward pass (own tile)
+template <int NT>
+struct SabState {
+  f32x4 hin;          // block input
+  f32x4 p[NT];        // attention probabilities of the own queries
+  f32x4 h1;           // after LN0 (input of the feed-forward)
+  f32x4 tv;           // feed-forward pre-activation
+  f32x4 xh0, rstd0, xh1, rstd1;
+};
+
+// LDS tile slots (SLOT floats each); rows 16 t .. of a slot belong to wave t unless
+// the slot is marked shared
+enum {
+  S_HS = 0, S_QS, S_AS, S_H1S, S_PS,   // private rows
+  S_KS0, S_KS1, S_VT0, S_VT1,          // shared, double buffered by block parity
+  S_FWD_SLOTS,
+  S_VS0 = S_FWD_SLOTS, S_VS1, S_KT0, S_KT1, S_QT, S_PT, S_GT, S_XT, S_GR, S_DSR, S_DST,
+  S_BWD_SLOTS
+};
+
+// One SAB: h (O layout, own tile) -> h.  NT = number of 16-row tiles (= waves) of the set.
+// `par`: parity of the block counter (selects the K / V buffers).  KEEP: fill `st` and
+// leave V row-major / K transposed / Q transposed behind for the backward pass.
+template <int NT, bool KEEP>
+__device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const float *Wl,
+                                            float *tiles, f32x4 &h, const f32x4 &pres,
+                                            const float (&kmask)[NT], int N, float sqrt_d,
+                                            int par, SabState<NT> *st) {
+  float *Hs = tiles + S_HS * SLOT, *Qs = tiles + S_QS * SLOT, *As = tiles + S_AS * SLOT,
+        *H1s = tiles + S_H1S * SLOT, *Ps = tiles + S_PS * SLOT,
+        *Ks = tiles + (S_KS0 + par) * SLOT, *Vt = tiles + (S_VT0 + par) * SLOT;
+  const int r = w.r, t = w.t;
+  const float inv_sqrt_d = 1.f / sqrt_d;
+  // weights of the block as B operands (issued up front: they come from L2)
+  const float4 wq = w.w_rows(Wl + lay.w(0)), wk = w.w_rows(Wl + lay.w(1)),
+               wv = w.w_rows(Wl + lay.w(2)), wo = w.w_rows(Wl + lay.w(3)),
+               wf = w.w_rows(Wl + lay.w(4));
+  const float bq = Wl[lay.b(0) + r], bk = Wl[lay.b(1) + r], bv = Wl[lay.b(2) + r],
+              bo = Wl[lay.b(3) + r], bf = Wl[lay.b(4) + r];
+  float g0 = 1.f, be0 = 0.f, g1 = 1.f, be1 = 0.f;
+  if (lay.ln) {
+    g0 = Wl[lay.ln0() + r], be0 = Wl[lay.ln0() + D + r];
+    g1 = Wl[lay.ln1() + r], be1 = Wl[lay.ln1() + D + r];
+  }
+  if (KEEP) st->hin = h;
+  // q, k, v projections of the own rows
+  w.wr_rows(Hs, h);
+  lds_fence();
+  f32x4 qo, ko, vo;
+  {
+    const float4 a = w.rd16(Hs, t);
+    qo = mma16(splat(bq), a, wq);
+    ko = mma16(splat(bk), a, wk);
+    vo = mma16(splat(bv), a, wv);
+  }
+  w.wr_rows(Qs, qo);
+  w.wr_rows(Ks, ko);
+  w.wr_cols(Vt, vo);
+  if (KEEP) {
+    w.wr_rows(tiles + (S_VS0 + par) * SLOT, vo);
+    w.wr_cols(tiles + (S_KT0 + par) * SLOT, ko);
+    w.wr_cols(tiles + S_QT * SLOT, qo);
+  }
+  lds_fence();
+  if (NT > 1) __syncthreads();   // the other wave's keys / values
+  // routing logits (q k^T - (1 - presence_m) 1e32) / sqrt(d), softmax over the keys m
+  f32x4 s[NT];
+  {
+    const float4 qa = w.rd16(Qs, t);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) s[u] = mma16(splat(0.f), qa, w.rd16(Ks, u));
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    // (sqrt(16) = 4: the division is an exact multiplication)
+    float v[NT], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      v[u] = 16 * u + r < N ? (s[u][e] - kmask[u]) * inv_sqrt_d : -INFINITY;
+      mx = fmaxf(mx, v[u]);
+    }
+    mx = rmax(mx);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) v[u] = __expf(v[u] - mx), sum += v[u];   // exp(-inf) = 0
+    const float inv = 1.f / rsum(sum);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) s[u][e] = v[u] * inv;
+  }
+  if (KEEP) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) st->p[u] = s[u];
+  }
+  // a = P V
+  w.template wr_nn<NT>(Ps, s);
+  lds_fence();
+  const f32x4 ao = mma_n<NT>(splat(0.f), w, Ps, t, Vt, 0);   // B[k = m][c]: row c of Vt
+  // r = (Wo a + bo + h) presence_n; LN0
+  w.wr_rows(As, ao);
+  lds_fence();
+  f32x4 h1 = mma16(splat(bo), w.rd16(As, t), wo);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h1[e] = (h1[e] + h[e]) * pres[e];
+  f32x4 dummy;
+  if (lay.ln) layer_norm<KEEP>(h1, g0, be0, KEEP ? st->xh0 : dummy, KEEP ? st->rstd0 : dummy);
+  // h2 = h1 + relu(Wf h1 + bf); LN1
+  w.wr_rows(H1s, h1);
+  lds_fence();
+  const f32x4 tv = mma16(splat(bf), w.rd16(H1s, t), wf);
+  if (KEEP) st->tv = tv, st->h1 = h1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h[e] = h1[e] + fmaxf(tv[e], 0.f);
+  if (lay.ln) layer_norm<KEEP>(h, g1, be1, KEEP ? st->xh1 : dummy, KEEP ? st->rstd1 : dummy);
+}
+
+// LDS of a workgroup: X [32][XS], W1s [16][XS], tile slots
+__host__ __device__ inline int xs_of(int Din) { return (Din + 15) / 16 * 16 + 4; }
+__host__ __device__ inline size_t lds_floats(int Din, bool bwd) {
+  return (size_t)48 * xs_of(Din) + (size_t)(bwd ? S_BWD_SLOTS : S_FWD_SLOTS) * SLOT;
+}
+
+// 4 bytes per lane, global -> LDS (lane l lands at lds + 4 l bytes): a row of up to 64
+// floats per instruction, nothing held in registers, one wait for everything
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7ffffffc, 0x00020000);
+}
+__device__ __forceinline__ void dma4(rsrc_t r, float *lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 4,
+                                           voff, soff, 0, 0);
+}
+// rows [n0, n1) x width floats (row stride sstride) -> LDS rows of stride XS, asynchronously
+__device__ __forceinline__ void dma_rows(const float *src, int sstride, int n0, int n1, int width,
+                                         float *dst, int XS, int lane) {
+  const rsrc_t rs = make_rsrc(src);
+  for (int c = 0; c < width; c += 64)
+    if (c + lane < width)
+      for (int n = n0; n < n1; ++n) dma4(rs, dst + n * XS + c, 4 * lane, 4 * (n * sstride + c));
+}
+__device__ __forceinline__ void dma_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// the own rows of the set's input (segments side by side) into X; X's padding stays zero
+__device__ __forceinline__ void stage_input(const StArgs &a, int b, const Wave &w, float *X,
+                                            int XS) {
+  const int n0 = 16 * w.t, n1 = min(a.N, n0 + 16);
+  int col = 0;
+#pragma unroll 1
+  for (int s = 0; s < a.nseg; ++s) {
+    dma_rows(a.seg[s].ptr + (size_t)b * a.seg[s].bs, a.seg[s].rs, n0, n1, a.seg[s].width,
+             X + col, XS, w.lane);
+    col += a.seg[s].width;
+  }
+}
+
+// fc1 of the own tile: x W1^T + b1, two independent accumulation chains
+__device__ __forceinline__ f32x4 fc1_forward(const Wave &w, const float *X, const float *W1s,
+                                             int XS, float bias) {
+  const int kq = (XS - 4) / 4;   // k per lane group (a multiple of 4)
+  const float *xa = X + (16 * w.t + w.r) * XS + kq * w.q, *wb = W1s + w.r * XS + kq * w.q;
+  f32x4 h0 = splat(bias), h1 = splat(0.f);
+  int j = 0;
+  for (; j + 8 <= kq; j += 8) {
+    h0 = mma16(h0, ld4(xa + j), ld4(wb + j));
+    h1 = mma16(h1, ld4(xa + j + 4), ld4(wb + j + 4));
+  }
+  if (j < kq) h0 = mma16(h0, ld4(xa + j), ld4(wb + j));
+  return h0 + h1;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Lay lay{a.Din, a.L, a.layer_norm};
+  const int N = a.N, XS = xs_of(a.Din);
+  Wave w;
+  w.lane = threadIdx.x & 63, w.r = w.lane & 15, w.q = w.lane >> 4;
+  w.t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *X = smem, *W1s = smem + 32 * XS, *tiles = smem + 48 * XS;
+  // zero padding of X / W1s (rows >= N, columns >= Din), then W1, once per workgroup
+  for (int i = threadIdx.x; i < 48 * XS; i += 64 * NT) X[i] = 0.f;   // X, W1s contiguous
+  lds_fence();
+  if (NT > 1) __syncthreads();
+  dma_rows(a.params, a.Din, w.t * (D / NT), (w.t + 1) * (D / NT), a.Din, W1s, XS, w.lane);
+  dma_wait();
+  if (NT > 1) __syncthreads();
+  int blk = 0;   // running SAB counter: parity picks the K / V buffers
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    stage_input(a, b, w, X, XS);
+    f32x4 pres;
+    float kmask[NT];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = 16 * w.t + 4 * w.q + e;
+      pres[e] = n < N ? (a.presence ? a.presence[(size_t)b * N + n] : 1.f) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int m = 16 * u + w.r;
+      kmask[u] = a.presence && m < N ? (1.f - a.presence[(size_t)b * N + m]) * 1e32f : 0.f;
+    }
+    const float bias1 = a.params[lay.b1() + w.r];
+    dma_wait();
+    f32x4 h = fc1_forward(w, X, W1s, XS, bias1);
+    float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
+    const bool quad_ok = 16 * w.t + 4 * w.q + 3 < N;   // the lane's four rows all valid
+    auto save = [&](float *dst) {
+      if (quad_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(16 * w.t + 4 * w.q + e) * D + w.r] = h[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (16 * w.t + 4 * w.q + e < N) dst[(16 * w.t + 4 * w.q + e) * D + w.r] = h[e];
+      }
+    };
+    for (int l = 0; l <= a.L; ++l) {
+      save(hs + (size_t)l * N * D);
+      if (l < a.L) {
+        sab_forward<NT, false>(w, lay, a.params + lay.layer(l), tiles, h, pres, kmask, N,
+                               a.sqrt_d, blk & 1, nullptr);
+        ++blk;
+      }
+    }
+    save(a.z + (size_t)b * N * D);
+  }
+}
+}  // namespace
+
+bool wave_supported(const StArgs &a, int Dh) {
+  return Dh == D && a.N <= 32 && a.Dout == 0 && a.L >= 0 && a.Din >= 1 &&
+         lds_floats(a.Din, true) * sizeof(float) <= 160 * 1024;
+}
+
+int wave_launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
+  const size_t lds = lds_floats(a.Din, bwd) * sizeof(float);
+  if (bwd) return SCAE_ERR_UNSUPPORTED;
+  const bool two = a.N > 16;
+  const void *fn = two ? reinterpret_cast<const void *>(stw_fwd_kernel<2>)
+                       : reinterpret_cast<const void *>(stw_fwd_kernel<1>);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (two)
+    hipLaunchKernelGGL(stw_fwd_kernel<2>, dim3(grid), dim3(128), lds, st, a);
+  else
+    hipLaunchKernelGGL(stw_fwd_kernel<1>, dim3(grid), dim3(64), lds, st, a);
+  return scae_launch_status();
+}
+}  // namespace scae_st
