@@ -819,6 +819,7 @@ extern "C" int scae_set_encoder_bwd_f32(int nseg, const float *const *seg_ptr,
   a.gz = gz;
   a.pg_partial = pg_partial;
   const int grid = scae_set_encoder_grid(B);
+  if (use_wave(a, D)) return scae_st::wave_launch(a, true, grid, (hipStream_t)stream);
   switch (D) {
     case 8: return launch<8>(a, true, grid, (hipStream_t)stream);
     case 16: return launch<16>(a, true, grid, (hipStream_t)stream);

@@ -179,19 +179,36 @@ template <int NT>
 struct SabState {
   f32x4 hin;          // block input
   f32x4 p[NT];        // attention probabilities of the own queries
+  f32x4 ao;           // attention output P V
   f32x4 h1;           // after LN0 (input of the feed-forward)
   f32x4 tv;           // feed-forward pre-activation
   f32x4 xh0, rstd0, xh1, rstd1;
 };
 
-// LDS tile slots (SLOT floats each); rows 16 t .. of a slot belong to wave t unless
-// the slot is marked shared
+// LDS tile slots.  Small slots (SMALL floats: an R tile [32][24] or a transposed
+// [16][40] tile), then large ones (SLOT floats: N x N tiles [32][40]).  Rows 16 t .. of a
+// row-major slot / columns 16 t .. of a transposed one belong to wave t; "shared" slots
+// are read across waves after a workgroup barrier.
+constexpr int SMALL = 32 * RS;   // 768 >= 16 * TS
 enum {
-  S_HS = 0, S_QS, S_AS, S_H1S, S_PS,   // private rows
+  S_HS = 0, S_QS, S_AS, S_H1S,         // private rows
   S_KS0, S_KS1, S_VT0, S_VT1,          // shared, double buffered by block parity
-  S_FWD_SLOTS,
-  S_VS0 = S_FWD_SLOTS, S_VS1, S_KT0, S_KT1, S_QT, S_PT, S_GT, S_XT, S_GR, S_DSR, S_DST,
-  S_BWD_SLOTS
+  S_FWD_SMALL,
+  S_VS0 = S_FWD_SMALL, S_VS1, S_KT0, S_KT1, S_QT, S_GT,   // shared (backward)
+  S_XT1, S_XT2, S_GR,                  // private scratch tiles (backward)
+  S_BWD_SMALL
+};
+enum { L_PS = 0, L_FWD_LARGE, L_PT = L_FWD_LARGE, L_DSR, L_DST, L_SCR0, L_SCR1, L_BWD_LARGE };
+__host__ __device__ inline int tiles_floats(bool bwd) {
+  return (bwd ? S_BWD_SMALL : S_FWD_SMALL) * SMALL + (bwd ? L_BWD_LARGE : L_FWD_LARGE) * SLOT;
+}
+struct Tiles {
+  float *base;
+  bool bwd;
+  __device__ __forceinline__ float *small(int i) const { return base + i * SMALL; }
+  __device__ __forceinline__ float *large(int i) const {
+    return base + (bwd ? S_BWD_SMALL : S_FWD_SMALL) * SMALL + i * SLOT;
+  }
 };
 
 // One SAB: h (O layout, own tile) -> h.  NT = number of 16-row tiles (= waves) of the set.
@@ -199,12 +216,12 @@ enum {
 // leave V row-major / K transposed / Q transposed behind for the backward pass.
 template <int NT, bool KEEP>
 __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const float *Wl,
-                                            float *tiles, f32x4 &h, const f32x4 &pres,
+                                            const Tiles &tl, f32x4 &h, const f32x4 &pres,
                                             const float (&kmask)[NT], int N, float sqrt_d,
                                             int par, SabState<NT> *st) {
-  float *Hs = tiles + S_HS * SLOT, *Qs = tiles + S_QS * SLOT, *As = tiles + S_AS * SLOT,
-        *H1s = tiles + S_H1S * SLOT, *Ps = tiles + S_PS * SLOT,
-        *Ks = tiles + (S_KS0 + par) * SLOT, *Vt = tiles + (S_VT0 + par) * SLOT;
+  float *Hs = tl.small(S_HS), *Qs = tl.small(S_QS), *As = tl.small(S_AS),
+        *H1s = tl.small(S_H1S), *Ps = tl.large(L_PS), *Ks = tl.small(S_KS0 + par),
+        *Vt = tl.small(S_VT0 + par);
   const int r = w.r, t = w.t;
   const float inv_sqrt_d = 1.f / sqrt_d;
   // weights of the block as B operands (issued up front: they come from L2)
@@ -233,9 +250,9 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   w.wr_rows(Ks, ko);
   w.wr_cols(Vt, vo);
   if (KEEP) {
-    w.wr_rows(tiles + (S_VS0 + par) * SLOT, vo);
-    w.wr_cols(tiles + (S_KT0 + par) * SLOT, ko);
-    w.wr_cols(tiles + S_QT * SLOT, qo);
+    w.wr_rows(tl.small(S_VS0 + par), vo);
+    w.wr_cols(tl.small(S_KT0 + par), ko);
+    w.wr_cols(tl.small(S_QT), qo);
   }
   lds_fence();
   if (NT > 1) __syncthreads();   // the other wave's keys / values
@@ -270,6 +287,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   w.template wr_nn<NT>(Ps, s);
   lds_fence();
   const f32x4 ao = mma_n<NT>(splat(0.f), w, Ps, t, Vt, 0);   // B[k = m][c]: row c of Vt
+  if (KEEP) st->ao = ao;
   // r = (Wo a + bo + h) presence_n; LN0
   w.wr_rows(As, ao);
   lds_fence();
@@ -291,7 +309,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
 // LDS of a workgroup: X [32][XS], W1s [16][XS], tile slots
 __host__ __device__ inline int xs_of(int Din) { return (Din + 15) / 16 * 16 + 4; }
 __host__ __device__ inline size_t lds_floats(int Din, bool bwd) {
-  return (size_t)48 * xs_of(Din) + (size_t)(bwd ? S_BWD_SLOTS : S_FWD_SLOTS) * SLOT;
+  return (size_t)48 * xs_of(Din) + tiles_floats(bwd);
 }
 
 // 4 bytes per lane, global -> LDS (lane l lands at lds + 4 l bytes): a row of up to 64
@@ -344,6 +362,268 @@ __device__ __forceinline__ f32x4 fc1_forward(const Wave &w, const float *X, cons
   return h0 + h1;
 }
 
+// ---- backward --------------------------------------------------------------------
+// operand with K = 16 from the wave's own columns of a transposed tile: row r, k = 16 t + 4 q ..
+__device__ __forceinline__ float4 rdT_own(const Wave &w, const float *tile) {
+  return ld4(tile + w.r * TS + 16 * w.t + 4 * w.q);
+}
+// gradient through a LayerNorm (g: w.r.t. the output -> w.r.t. the input) and the
+// own-tile column sums for gamma / beta
+__device__ __forceinline__ void layer_norm_bwd(f32x4 &g, float gamma, const f32x4 &xh,
+                                               const f32x4 &rstd, float &dgamma, float &dbeta) {
+  f32x4 gx;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gx[e] = g[e] * xh[e];
+  dgamma = csum(gx);
+  dbeta = csum(g);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gh = g[e] * gamma;
+    const float s1 = rsum(gh) * (1.f / D), s2 = rsum(gh * xh[e]) * (1.f / D);
+    g[e] = (gh - s1 - xh[e] * s2) * rstd[e];
+  }
+}
+// parameter gradients of one block from the wave's own rows
+struct LayerGrads {
+  f32x4 w[5];    // dWq dWk dWv dWo dWf, O layout: w[m][e] = dW[4 q + e][r]
+  float v[9];    // dbq dbk dbv dbo dbf dgamma0 dbeta0 dgamma1 dbeta1 (column r)
+};
+
+// Backward of one SAB given everything sab_forward<KEEP> left behind; G: gradient w.r.t.
+// the block output on entry, w.r.t. its input on return (own tile).
+template <int NT>
+__device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, const float *Wl,
+                                             const Tiles &tl, f32x4 &G, const f32x4 &pres, int N,
+                                             float sqrt_d, int par, const SabState<NT> &st,
+                                             LayerGrads &lg) {
+  float *XT1 = tl.small(S_XT1), *XT2 = tl.small(S_XT2), *GR = tl.small(S_GR),
+        *GT = tl.small(S_GT), *Vs = tl.small(S_VS0 + par), *Kt = tl.small(S_KT0 + par),
+        *Qt = tl.small(S_QT), *PT = tl.large(L_PT), *DSR = tl.large(L_DSR),
+        *DST = tl.large(L_DST);
+  const int r = w.r, t = w.t;
+  const float inv_sqrt_d = 1.f / sqrt_d;
+  const float4 wqT = w.w_cols(Wl + lay.w(0)), wkT = w.w_cols(Wl + lay.w(1)),
+               wvT = w.w_cols(Wl + lay.w(2)), woT = w.w_cols(Wl + lay.w(3)),
+               wfT = w.w_cols(Wl + lay.w(4));
+#pragma unroll
+  for (int i = 5; i < 9; ++i) lg.v[i] = 0.f;
+  // LN1, ReLU, feed-forward
+  if (lay.ln) layer_norm_bwd(G, Wl[lay.ln1() + r], st.xh1, st.rstd1, lg.v[7], lg.v[8]);
+  f32x4 gt;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gt[e] = st.tv[e] > 0.f ? G[e] : 0.f;
+  w.wr_cols(XT1, gt);
+  w.wr_cols(XT2, st.h1);
+  w.wr_rows(GR, gt);
+  lds_fence();
+  lg.w[4] = mma16(splat(0.f), rdT_own(w, XT1), rdT_own(w, XT2));
+  lg.v[4] = csum(gt);
+  f32x4 g1 = mma16(G, w.rd16(GR, t), wfT);   // g_h2 + g_t Wf
+  // LN0, presence gate, output projection
+  if (lay.ln) layer_norm_bwd(g1, Wl[lay.ln0() + r], st.xh0, st.rstd0, lg.v[5], lg.v[6]);
+  f32x4 go;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) go[e] = g1[e] * pres[e];
+  w.wr_cols(XT1, go);
+  w.wr_cols(XT2, st.ao);
+  w.wr_rows(GR, go);
+  lds_fence();
+  lg.w[3] = mma16(splat(0.f), rdT_own(w, XT1), rdT_own(w, XT2));
+  lg.v[3] = csum(go);
+  const f32x4 ga = mma16(splat(0.f), w.rd16(GR, t), woT);
+  // attention: dP = GA V^T, softmax backward
+  w.wr_rows(GR, ga);
+  w.wr_cols(GT, ga);
+  lds_fence();
+  f32x4 ds[NT];
+  {
+    const float4 gaa = w.rd16(GR, t);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) ds[u] = mma16(splat(0.f), gaa, w.rd16(Vs, u));
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) dot = fmaf(st.p[u][e], ds[u][e], dot);
+    dot = rsum(dot);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) ds[u][e] = st.p[u][e] * (ds[u][e] - dot) * inv_sqrt_d;
+  }
+  w.template wr_nn<NT>(DSR, ds);
+  w.template wr_nn_t<NT>(DST, ds);
+  w.template wr_nn_t<NT>(PT, st.p);
+  lds_fence();
+  if (NT > 1) __syncthreads();   // the other wave's dS^T, P^T, GA^T columns
+  const f32x4 dq = mma_n<NT>(splat(0.f), w, DSR, t, Kt, 0);   // sum_m dS[n][m] K[m][i]
+  const f32x4 dk = mma_n<NT>(splat(0.f), w, DST, t, Qt, 0);   // sum_n dS[n][m] Q[n][i]
+  const f32x4 dv = mma_n<NT>(splat(0.f), w, PT, t, GT, 0);    // sum_n P[n][m] GA[n][i]
+  // projections: weight gradients and the gradient w.r.t. the block input
+  w.wr_cols(XT2, st.hin);
+  f32x4 gin = go;
+  const f32x4 *dd[3] = {&dq, &dk, &dv};
+  const float4 wT[3] = {wqT, wkT, wvT};
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    w.wr_cols(XT1, *dd[m]);
+    w.wr_rows(GR, *dd[m]);
+    lds_fence();
+    lg.w[m] = mma16(splat(0.f), rdT_own(w, XT1), rdT_own(w, XT2));
+    lg.v[m] = csum(*dd[m]);
+    gin = mma16(gin, w.rd16(GR, t), wT[m]);
+  }
+  G = gin;
+}
+
+// own-rows parameter gradients -> the workgroup's row of the partial matrix (wave 0
+// writes; with two waves, wave 1 hands its values over through LDS)
+template <int NT>
+__device__ __forceinline__ void flush_layer(const Wave &w, const Lay &lay, const Tiles &tl,
+                                            const LayerGrads &lg, float *part, bool first) {
+  float *scr = tl.large(L_SCR0);   // [5][256] matrices, then [9][16] vectors (L_SCR1 follows)
+  if (NT > 1) {
+    if (w.t == 1) {
+#pragma unroll
+      for (int m = 0; m < 5; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) scr[m * 256 + (4 * w.q + e) * D + w.r] = lg.w[m][e];
+      if (w.q == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) scr[5 * 256 + i * D + w.r] = lg.v[i];
+      }
+    }
+    lds_fence();
+    __syncthreads();
+    if (w.t == 1) return;
+  }
+  auto put = [&](int idx, float v) { part[idx] = first ? v : part[idx] + v; };
+#pragma unroll
+  for (int m = 0; m < 5; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ij = (4 * w.q + e) * D + w.r;
+      put(lay.w(m) + ij, lg.w[m][e] + (NT > 1 ? scr[m * 256 + ij] : 0.f));
+    }
+  if (w.q == 0) {
+    const int voff[9] = {lay.b(0), lay.b(1), lay.b(2), lay.b(3), lay.b(4), lay.ln0(),
+                         lay.ln0() + D, lay.ln1(), lay.ln1() + D};
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      if (i < 5 || lay.ln)
+        put(voff[i] + w.r, lg.v[i] + (NT > 1 ? scr[5 * 256 + i * D + w.r] : 0.f));
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Lay lay{a.Din, a.L, a.layer_norm};
+  const int N = a.N, XS = xs_of(a.Din), Din = a.Din;
+  Wave w;
+  w.lane = threadIdx.x & 63, w.r = w.lane & 15, w.q = w.lane >> 4;
+  w.t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *X = smem, *W1s = smem + 32 * XS;
+  const Tiles tiles{smem + 48 * XS, true};
+  for (int i = threadIdx.x; i < 48 * XS; i += 64 * NT) X[i] = 0.f;
+  lds_fence();
+  if (NT > 1) __syncthreads();
+  dma_rows(a.params, Din, w.t * (D / NT), (w.t + 1) * (D / NT), Din, W1s, XS, w.lane);
+  dma_wait();
+  if (NT > 1) __syncthreads();
+  float *part = a.pg_partial + (size_t)blockIdx.x * lay.total();
+  bool first = true;
+  int blk = 0;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    stage_input(a, b, w, X, XS);   // needed at the end (fc1 weight gradient); lands meanwhile
+    f32x4 pres, G;
+    float kmask[NT];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = 16 * w.t + 4 * w.q + e;
+      pres[e] = n < N ? (a.presence ? a.presence[(size_t)b * N + n] : 1.f) : 0.f;
+      G[e] = n < N ? a.gz[((size_t)b * N + n) * D + w.r] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int m = 16 * u + w.r;
+      kmask[u] = a.presence && m < N ? (1.f - a.presence[(size_t)b * N + m]) * 1e32f : 0.f;
+    }
+    const float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
+    for (int l = a.L - 1; l >= 0; --l) {
+      f32x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 16 * w.t + 4 * w.q + e;
+        h[e] = n < N ? hs[((size_t)l * N + n) * D + w.r] : 0.f;
+      }
+      SabState<NT> st;
+      const float *Wl = a.params + lay.layer(l);
+      sab_forward<NT, true>(w, lay, Wl, tiles, h, pres, kmask, N, a.sqrt_d, blk & 1, &st);
+      LayerGrads lg;
+      sab_backward<NT>(w, lay, Wl, tiles, G, pres, N, a.sqrt_d, blk & 1, st, lg);
+      flush_layer<NT>(w, lay, tiles, lg, part + lay.layer(l), first);
+      ++blk;
+    }
+    // fc1: db1, dW1 = G^T x (column tiles split between the waves, K over all rows),
+    // input gradients of the segments that want one
+    dma_wait();
+    float *GT = tiles.small(S_GT), *GR = tiles.small(S_GR), *scr = tiles.large(L_SCR0);
+    w.wr_cols(GT, G);
+    w.wr_rows(GR, G);
+    const float db1 = csum(G);
+    // (behind the block-gradient hand-over area, which wave 0 may still be reading)
+    if (NT > 1 && w.t == 1 && w.q == 0) scr[5 * 256 + 9 * D + w.r] = db1;
+    lds_fence();
+    if (NT > 1) __syncthreads();
+    if (w.t == 0 && w.q == 0) {
+      const float v = db1 + (NT > 1 ? scr[5 * 256 + 9 * D + w.r] : 0.f);
+      part[lay.b1() + w.r] = first ? v : part[lay.b1() + w.r] + v;
+    }
+    for (int jt = w.t; jt * 16 < Din; jt += NT) {
+      f32x4 acc = splat(0.f);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const float *xp = X + (16 * u + 4 * w.q) * XS + 16 * jt + w.r;
+        acc = mma16(acc, ld4(GT + w.r * TS + 16 * u + 4 * w.q),
+                    make_float4(xp[0], xp[XS], xp[2 * XS], xp[3 * XS]));
+      }
+      if (16 * jt + w.r < Din) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = (4 * w.q + e) * Din + 16 * jt + w.r;
+          part[idx] = first ? acc[e] : part[idx] + acc[e];
+        }
+      }
+    }
+    {
+      const float4 ga = w.rd16(GR, w.t);
+      int col = 0;
+#pragma unroll 1
+      for (int s = 0; s < a.nseg; ++s) {
+        const int wd = a.seg[s].width;
+        float *gdst = a.seg[s].grad;
+        if (gdst) {
+          for (int j0 = 0; j0 < wd; j0 += 16) {
+            const float *wp = W1s + (4 * w.q) * XS + col + j0 + w.r;
+            const f32x4 o = mma16(splat(0.f), ga,
+                                  make_float4(wp[0], wp[XS], wp[2 * XS], wp[3 * XS]));
+            if (j0 + w.r < wd) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int n = 16 * w.t + 4 * w.q + e;
+                if (n < N) gdst[((size_t)b * N + n) * wd + j0 + w.r] = o[e];
+              }
+            }
+          }
+        }
+        col += wd;
+      }
+    }
+    first = false;
+    if (NT > 1) __syncthreads();   // X / GT / scratch are rewritten by the next set
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -352,7 +632,8 @@ __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
   Wave w;
   w.lane = threadIdx.x & 63, w.r = w.lane & 15, w.q = w.lane >> 4;
   w.t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *X = smem, *W1s = smem + 32 * XS, *tiles = smem + 48 * XS;
+  float *X = smem, *W1s = smem + 32 * XS;
+  const Tiles tiles{smem + 48 * XS, false};
   // zero padding of X / W1s (rows >= N, columns >= Din), then W1, once per workgroup
   for (int i = threadIdx.x; i < 48 * XS; i += 64 * NT) X[i] = 0.f;   // X, W1s contiguous
   lds_fence();
@@ -410,18 +691,27 @@ bool wave_supported(const StArgs &a, int Dh) {
 
 int wave_launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
   const size_t lds = lds_floats(a.Din, bwd) * sizeof(float);
-  if (bwd) return SCAE_ERR_UNSUPPORTED;
   const bool two = a.N > 16;
-  const void *fn = two ? reinterpret_cast<const void *>(stw_fwd_kernel<2>)
-                       : reinterpret_cast<const void *>(stw_fwd_kernel<1>);
+  const void *fn = bwd ? (two ? reinterpret_cast<const void *>(stw_bwd_kernel<2>)
+                              : reinterpret_cast<const void *>(stw_bwd_kernel<1>))
+                       : (two ? reinterpret_cast<const void *>(stw_fwd_kernel<2>)
+                              : reinterpret_cast<const void *>(stw_fwd_kernel<1>));
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (two)
-    hipLaunchKernelGGL(stw_fwd_kernel<2>, dim3(grid), dim3(128), lds, st, a);
-  else
-    hipLaunchKernelGGL(stw_fwd_kernel<1>, dim3(grid), dim3(64), lds, st, a);
+  const dim3 block(two ? 128 : 64);
+  if (bwd) {
+    if (two)
+      hipLaunchKernelGGL(stw_bwd_kernel<2>, dim3(grid), block, lds, st, a);
+    else
+      hipLaunchKernelGGL(stw_bwd_kernel<1>, dim3(grid), block, lds, st, a);
+  } else {
+    if (two)
+      hipLaunchKernelGGL(stw_fwd_kernel<2>, dim3(grid), block, lds, st, a);
+    else
+      hipLaunchKernelGGL(stw_fwd_kernel<1>, dim3(grid), block, lds, st, a);
+  }
   return scae_launch_status();
 }
 }  // namespace scae_st
