@@ -623,6 +623,74 @@ def test_fused_set_encoder_vs_oracle(B, N, widths, D, Dout, L, ln, pres):
                      "grad " + name)
 
 
+@pytest.mark.parametrize("B,N,widths,L,ln,pres", [
+    (128, 24, (6, 1, 16, 121), 3, True, "mixed"),   # cfg-2: two waves per set
+    (40, 32, (7, 16, 363), 3, True, "rand"),        # cfg-5 shape (Din = 386)
+    (700, 24, (6, 1, 16, 40), 2, True, "rand"),     # B > grid: partial rows accumulate
+    (33, 10, (13,), 1, True, "mixed"),              # one wave per set
+    (17, 17, (5, 30), 2, False, None),              # ragged second tile, no LayerNorm
+    (6, 16, (16,), 3, True, "ones"),                # exactly one tile
+    (3, 1, (5, 3), 1, True, "rand"),                # a single element
+])
+def test_trunk_on_matrix_cores_vs_oracle(B, N, widths, L, ln, pres):
+    """K2b without fc2 (the form SetTransformer.forward_segments uses): for
+    D = 16 and N <= 32 this is the wave-per-tile MFMA implementation
+    (set_encoder_wave.hip) -- trunk output, segment gradients and every
+    parameter gradient against the oracle."""
+    from torch_scae_amd import ops
+    from torch_scae_amd.set_transformer import SetTransformer
+    D = 16
+    torch.manual_seed(B + N)
+    Din = sum(widths)
+    st = SetTransformer(dim_in=Din, dim_hidden=D, dim_out=32, n_outputs=4,
+                        n_layers=L, n_heads=1, layer_norm=ln)
+    g = torch.Generator().manual_seed(23)
+    with torch.no_grad():
+        for q in st.parameters():
+            q.add_(torch.randn(q.shape, generator=g) * 0.1)
+    P = {"m." + k: v.clone().requires_grad_(True)
+         for k, v in st.state_dict().items()}
+    wide = torch.randn(B, N, Din + 3, generator=g)
+    p = None
+    if pres == "rand":
+        p = torch.rand(B, N, generator=g)
+    elif pres == "ones":
+        p = torch.ones(B, N)
+    elif pres == "mixed":
+        p = torch.ones(B, N)
+        p[:, ::3] = torch.rand(B, len(range(0, N, 3)), generator=g)
+    w = torch.randn(B, N, D, generator=g)
+    xc = wide[..., 1:1 + Din].clone().requires_grad_(True)
+    h = O._linear(P, "m.fc1", xc)
+    for l in range(L):
+        h = O.sab(P, f"m.sabs.{l}", h, p, 1, ln)
+    (h * w).sum().backward()
+
+    st = st.cuda()
+    wide_g = wide.cuda()
+    segs, col = [], 1
+    for wd in widths:
+        segs.append(wide_g[..., col:col + wd].detach().requires_grad_(True))
+        col += wd
+    hg = ops.set_encoder(segs, dev(p), st._packed_trunk(with_fc2=False), D, 0,
+                         L, ln)
+    (hg * w.cuda()).sum().backward()
+    assert_close(hg, h, 1e-4, 1e-4, "trunk output")
+    gx = torch.cat([s_.grad for s_ in segs], -1)
+    assert_close(gx, xc.grad, 1e-4 * max(1.0, float(xc.grad.abs().max())),
+                 1e-4, "segment gradients")
+    grads = {k: q.grad for k, q in st.named_parameters()}
+    n = 0
+    for k, q in P.items():
+        if q.grad is None:
+            continue
+        ref = q.grad
+        assert_close(grads[k[2:]], ref, 1e-4 * max(1.0, float(ref.abs().max())),
+                     1e-4, "grad " + k[2:])
+        n += 1
+    assert n == 2 + L * (10 + (4 if ln else 0))
+
+
 # ------------------------------------------------------------- K6 loss tail
 @pytest.mark.parametrize("prior,post,use_label,const", [
     ("l2", "entropy", True, None),       # the default SCAE config
