@@ -164,6 +164,31 @@ int scae_seed_attention_bwd_f32(const float *h, const float *q, const float *wk,
                                 float *partial, int B, int N, int O, int D, int C,
                                 void *stream);
 
+/* The same output attention on the matrix cores (seed_attention_wave.hip; D = 16,
+ * N, O <= 32, C a multiple of 64), with two more steps of algebra: the logits contract
+ * over D through qk = q wk (the q bk term is constant along the keys and drops out of
+ * the softmax), and out = (P h) wv^T + bv.  bk is therefore not an input, and its
+ * gradient is the exact zero the softmax's shift invariance implies.
+ *   fwd : out (B,O,C)
+ *   bwd : gh (B,N,16) and, per workgroup, one row of `partial`
+ *         (scae_seed_attention_mfma_rows(B), O*16 + C*16 + C) = [d(qk) | dwv | dbv]
+ *   reduce: the column sums of `partial`, expanded to the gradients of the operands
+ *         of scae_seed_attention_fwd_f32: gq (O,C) = d(qk) wk^T, gwk (C,16) = q^T d(qk),
+ *         gbk (C) = 0, gwv (C,16), gbv (C) -- one launch (it replaces the column-sum
+ *         launch behind scae_seed_attention_bwd_f32). */
+int scae_seed_attention_mfma_supported(int N, int O, int D, int C);
+int scae_seed_attention_mfma_rows(int B);
+int scae_seed_attention_mfma_fwd_f32(const float *h, const float *q, const float *wk,
+                                     const float *wv, const float *bv, const float *presence,
+                                     float *out, int B, int N, int O, int C, void *stream);
+int scae_seed_attention_mfma_bwd_f32(const float *h, const float *q, const float *wk,
+                                     const float *wv, const float *presence, const float *gout,
+                                     float *gh, float *partial, int B, int N, int O, int C,
+                                     void *stream);
+int scae_seed_attention_mfma_reduce_f32(const float *partial, int rows, const float *q,
+                                        const float *wk, float *gq, float *gwk, float *gbk,
+                                        float *gwv, float *gbv, int O, int C, void *stream);
+
 /* ------------------------------------------------------------------------
  * K2d  batch-invariant weight folding feeding K2c
  *      replaces the per-element fc2 / q,k,v,o projector Linear layers of

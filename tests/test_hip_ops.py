@@ -691,6 +691,58 @@ def test_trunk_on_matrix_cores_vs_oracle(B, N, widths, L, ln, pres):
     assert n == 2 + L * (10 + (4 if ln else 0))
 
 
+@pytest.mark.parametrize("B,N,O,C,pres", [
+    (128, 24, 24, 256, "mixed"),    # cfg-2
+    (600, 24, 24, 64, "rand"),      # B > grid: partial rows accumulate
+    (5, 32, 32, 128, "rand"),       # full tiles
+    (7, 17, 9, 64, None),           # ragged keys, one query tile
+    (3, 1, 1, 64, "ones"),
+    (4, 40, 24, 256, "rand"),       # N > 32: the workgroup-per-set kernels
+])
+def test_seed_attention_vs_fp64(B, N, O, C, pres):
+    """K2c, ops.seed_attention(h, q, wk, bk, wv, bv, presence) =
+    softmax((q K'^T - (1 - presence) 1e32) / sqrt(C)) V' with K' = h wk^T + bk,
+    V' = h wv^T + bv (set_transformer.py:24-47 after the folding of
+    seed_attention.hip): output and all gradients against the same formula
+    in fp64.  For N, O <= 32 this is seed_attention_wave.hip."""
+    from torch_scae_amd import ops
+    D = 16
+    g = torch.Generator().manual_seed(B * 7 + N)
+    h = torch.randn(B, N, D, generator=g)
+    q = torch.randn(O, C, generator=g) * 0.3
+    wk, wv = torch.randn(C, D, generator=g) * 0.3, torch.randn(C, D, generator=g) * 0.3
+    bk, bv = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    p = None
+    if pres == "rand":
+        p = torch.rand(B, N, generator=g)
+    elif pres == "ones":
+        p = torch.ones(B, N)
+    elif pres == "mixed":
+        p = torch.ones(B, N)
+        p[:, ::3] = torch.rand(B, len(range(0, N, 3)), generator=g)
+    w = torch.randn(B, O, C, generator=g)
+
+    ins = [t.double().requires_grad_() for t in (h, q, wk, bk, wv, bv)]
+    hd, qd, wkd, bkd, wvd, bvd = ins
+    K = hd @ wkd.T + bkd
+    V = hd @ wvd.T + bvd
+    R = qd @ K.transpose(1, 2)
+    if p is not None:
+        # the reference's fp32 mask arithmetic absorbs R for every key with
+        # presence < 1; in fp64 the same effect needs the mask to dominate
+        R = R - (1. - p.double())[:, None, :] * 1e300
+    ref = torch.softmax(R / (C ** 0.5), -1) @ V
+    (ref * w.double()).sum().backward()
+
+    outs = [leaf(t) for t in (h, q, wk, bk, wv, bv)]
+    out = ops.seed_attention(*outs, dev(p))
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref.float(), 1e-4, 1e-4, "out")
+    for name, got, want in zip(("gh", "gq", "gwk", "gbk", "gwv", "gbv"), outs, ins):
+        scale = max(1.0, float(want.grad.abs().max()))
+        assert_close(got.grad, want.grad.float(), 1e-4 * scale, 1e-4, name)
+
+
 # ------------------------------------------------------------- K6 loss tail
 @pytest.mark.parametrize("prior,post,use_label,const", [
     ("l2", "entropy", True, None),       # the default SCAE config

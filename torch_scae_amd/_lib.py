@@ -103,6 +103,11 @@ SIGNATURES = {
     "scae_seed_attention_supported": [c_int] * 4,
     "scae_seed_attention_fwd_f32": [P] * 9 + [c_int] * 5 + [P],
     "scae_seed_attention_bwd_f32": [P] * 10 + [c_int] * 5 + [P],
+    "scae_seed_attention_mfma_supported": [c_int] * 4,
+    "scae_seed_attention_mfma_rows": [c_int],
+    "scae_seed_attention_mfma_fwd_f32": [P] * 7 + [c_int] * 4 + [P],
+    "scae_seed_attention_mfma_bwd_f32": [P] * 8 + [c_int] * 4 + [P],
+    "scae_seed_attention_mfma_reduce_f32": [P, c_int] + [P] * 7 + [c_int] * 2 + [P],
     "scae_seed_fold_supported": [c_int] * 3,
     "scae_seed_fold_fwd_f32": [POINTER(SeedFoldDesc), P],
     "scae_seed_fold_bwd_f32": [POINTER(SeedFoldDesc), POINTER(SeedFoldGrads), P],

@@ -1,0 +1,459 @@
+// K2c on the matrix cores -- the set transformer's output attention
+//   MultiHeadQKVAttention(seeds, z, z, presence), z = fc2(h)   (set_transformer.py:218-223)
+// with fc2 and the k / v / o projections folded into two (C x 16) maps (seed_attention.hip,
+// seed_fold.hip), taken two steps further.  With h the (N x 16) trunk output of a set:
+//     K' = h wk^T + bk,  V' = h wv^T + bv                       (N x C, C = 256)
+//     S  = q K'^T        = (q wk) h^T + (q bk) 1^T              -- the second term is constant
+//                                                                  along the keys: the softmax
+//                                                                  over the keys drops it
+//     out = P V'         = (P h) wv^T + bv                      -- rows of P sum to one
+// so the per-set work contracts over 16, not 256: qk = q wk (O x 16, once per workgroup),
+// S = qk h^T, T = P h (O x 16), out = T wv^T + bv.  Backward likewise: dT = gout wv,
+// dwv += gout^T T, dP = dT h^T, d(qk) = dS h, dh = P^T dT + dS^T qk; the gradient reaches q
+// and wk only through d(qk) summed over the batch (dq = d(qk) wk^T, dwk = q^T d(qk): two
+// parameter-sized products done once, in the reduce kernel), and bk gets the exact zero the
+// softmax's shift invariance implies (the reference's value is round-off noise around 0).
+//
+// One workgroup of 4 waves per set.  Waves 0 / 1 own the query-row tiles (softmax, P h);
+// all four share the C-wide products.  v_mfma_f32_16x16x4_f32 throughout (exact fp32).
+#include <algorithm>
+
+#include "wave_mfma.h"
+
+using namespace scae_wave;
+
+namespace {
+constexpr int NTH = 256;
+
+struct SwArgs {
+  const float *h;         // (B,N,16)
+  const float *q;         // (O,C)
+  const float *wk;        // (C,16)
+  const float *wv, *bv;   // (C,16), (C)
+  const float *presence;  // (B,N) nullable
+  float *out;             // fwd (B,O,C)
+  const float *gout;      // bwd (B,O,C)
+  float *gh;              // bwd (B,N,16)
+  float *partial;         // bwd (rows, O*16 + C*16 + C): [d(qk) | dwv | dbv]
+  int B, N, O, C;
+  float inv_sqrt_c;
+};
+
+// LDS (floats): small tiles of 32 * RS, large of 32 * TS
+enum { T_QK = 0, T_TS, T_DT, T_QKT, T_TT, T_DTT, T_SMALL };   // R tiles / [16][TS] transposed
+enum { T_PS = 0, T_PT, T_DSR, T_DST, T_SCR, T_SCR2, T_LARGE };   // N x N tiles, scratch (2)
+constexpr int SMALL = 32 * RS;
+constexpr int LDS_FLOATS = T_SMALL * SMALL + T_LARGE * SLOT;
+struct Tl {
+  float *base;
+  __device__ __forceinline__ float *small(int i) const { return base + i * SMALL; }
+  __device__ __forceinline__ float *large(int i) const { return base + T_SMALL * SMALL + i * SLOT; }
+};
+
+struct Lane {
+  int lane, r, q, v;   // v: wave index in the workgroup
+};
+__device__ __forceinline__ Lane make_lane() {
+  Lane l;
+  l.lane = threadIdx.x & 63, l.r = l.lane & 15, l.q = l.lane >> 4;
+  l.v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return l;
+}
+__device__ __forceinline__ void wr_rows(float *tile, int t, const Lane &l, const f32x4 &o) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * l.q + e) * RS + l.r] = o[e];
+}
+__device__ __forceinline__ void wr_cols(float *tile, int t, const Lane &l, const f32x4 &o) {
+  *reinterpret_cast<float4 *>(tile + l.r * TS + 16 * t + 4 * l.q) =
+      make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void wr_nn(float *tile, int t, const Lane &l, const f32x4 (&o)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * l.q + e) * TS + 16 * u + l.r] = o[u][e];
+}
+__device__ __forceinline__ void wr_nn_t(float *tile, int t, const Lane &l, const f32x4 (&o)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    *reinterpret_cast<float4 *>(tile + (16 * u + l.r) * TS + 16 * t + 4 * l.q) =
+        make_float4(o[u][0], o[u][1], o[u][2], o[u][3]);
+}
+__device__ __forceinline__ float4 rd16(const float *tile, int t, const Lane &l) {
+  return ld4(tile + (16 * t + l.r) * RS + 4 * l.q);
+}
+__device__ __forceinline__ F8 rd32(const float *tile, int t, const Lane &l) {
+  const float *p = tile + (16 * t + l.r) * TS + 8 * l.q;
+  return F8{ld4(p), ld4(p + 4)};
+}
+
+// qk = q wk (O x 16) into the R tile QK (and transposed into QKT when given): the C-long
+// contraction is split over the four waves and met in LDS.  Ends with a barrier.
+__device__ __forceinline__ void fold_qk(const SwArgs &a, const Lane &l, const Tl &tl,
+                                        bool transposed) {
+  const int C = a.C, CW = C / 4, run = CW / 4;   // per wave, per lane group
+  float *scr = tl.large(T_SCR);
+  f32x4 acc[2] = {splat(0.f), splat(0.f)};
+  const int k0 = CW * l.v + run * l.q;
+  for (int j = 0; j < run; j += 4) {
+    const float *wp = a.wk + (size_t)(k0 + j) * D + l.r;
+    const float4 b = make_float4(wp[0], wp[D], wp[2 * D], wp[3 * D]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int o = 16 * t + l.r;
+      const float4 av = o < a.O ? ld4(a.q + (size_t)o * C + k0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc[t] = mma16(acc[t], av, b);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      scr[((l.v * 2 + t) * 16 + 4 * l.q + e) * D + l.r] = acc[t][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * D; i += NTH) {
+    const float s = (scr[i] + scr[512 + i]) + (scr[1024 + i] + scr[1536 + i]);
+    const int o = i / D, c = i % D;
+    tl.small(T_QK)[o * RS + c] = s;
+    if (transposed) tl.small(T_QKT)[c * TS + o] = s;
+  }
+  __syncthreads();
+}
+
+// keys of a set as B operands: hB[u] for S / dP (K = 16: row n = 16 u + r, features 4 q ..)
+// and hT for P h / dS h (K = 32 over n = 8 q .., feature r)
+struct Keys {
+  float4 hB[2];
+  F8 hT;
+  float kmask[2];
+};
+__device__ __forceinline__ Keys load_keys(const SwArgs &a, int b, const Lane &l) {
+  Keys k;
+  const float *hb = a.h + (size_t)b * a.N * D;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = 16 * u + l.r;
+    k.hB[u] = n < a.N ? ld4(hb + n * D + 4 * l.q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    k.kmask[u] = a.presence && n < a.N ? (1.f - a.presence[(size_t)b * a.N + n]) * 1e32f : 0.f;
+  }
+  float t[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int n = 8 * l.q + s;
+    t[s] = n < a.N ? hb[n * D + l.r] : 0.f;
+  }
+  k.hT = F8{make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7])};
+  return k;
+}
+
+// attention probabilities of the own query tile t (O layout, key tiles u)
+__device__ __forceinline__ void probabilities(const SwArgs &a, const Lane &l, const Tl &tl, int t,
+                                              const Keys &k, f32x4 (&p)[2]) {
+  const float4 qa = rd16(tl.small(T_QK), t, l);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) p[u] = mma16(splat(0.f), qa, k.hB[u]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v[2], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      v[u] = 16 * u + l.r < a.N ? (p[u][e] - k.kmask[u]) * a.inv_sqrt_c : -INFINITY;
+      mx = fmaxf(mx, v[u]);
+    }
+    mx = rmax(mx);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = __expf(v[u] - mx), sum += v[u];
+    const float inv = 1.f / rsum(sum);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) p[u][e] = v[u] * inv;
+  }
+}
+
+__global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  const Tl tl{smem};
+  const Lane l = make_lane();
+  const int C = a.C, O = a.O;
+  for (int i = threadIdx.x; i < LDS_FLOATS; i += NTH) smem[i] = 0.f;
+  __syncthreads();
+  fold_qk(a, l, tl, false);
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    if (l.v < 2 && 16 * l.v < O) {   // waves 0 / 1: the query tiles
+      const int t = l.v;
+      const Keys k = load_keys(a, b, l);
+      f32x4 p[2];
+      probabilities(a, l, tl, t, k, p);
+      wr_nn(tl.large(T_PS), t, l, p);
+      lds_fence();
+      const f32x4 T = mma32(splat(0.f), rd32(tl.large(T_PS), t, l), k.hT);
+      wr_rows(tl.small(T_TS), t, l, T);
+      lds_fence();
+    }
+    __syncthreads();
+    // out = T wv^T + bv: column tiles of 16 shared out over the waves
+    float *ob = a.out + (size_t)b * O * C;
+    for (int ct = l.v; ct * 16 < C; ct += 4) {
+      const float4 wb = ld4(a.wv + (size_t)(16 * ct + l.r) * D + 4 * l.q);
+      const float bias = a.bv[16 * ct + l.r];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (16 * t >= O) break;
+        const f32x4 o = mma16(splat(bias), rd16(tl.small(T_TS), t, l), wb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * t + 4 * l.q + e;
+          if (row < O) ob[(size_t)row * C + 16 * ct + l.r] = o[e];
+        }
+      }
+    }
+    __syncthreads();   // T is rewritten by the next set
+  }
+}
+
+__global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  const Tl tl{smem};
+  const Lane l = make_lane();
+  const int C = a.C, O = a.O, N = a.N, CW = C / 4, run = CW / 4;
+  const int npar = O * D + C * D + C;
+  float *part = a.partial + (size_t)blockIdx.x * npar;
+  float *scr = tl.large(T_SCR);
+  for (int i = threadIdx.x; i < LDS_FLOATS; i += NTH) smem[i] = 0.f;
+  __syncthreads();
+  fold_qk(a, l, tl, true);
+  bool first = true;
+  auto put = [&](int idx, float v) { part[idx] = first ? v : part[idx] + v; };
+  const int k0 = CW * l.v + run * l.q;   // this lane group's run of C in the dT product
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float *gb = a.gout + (size_t)b * O * C;
+    // dT = gout wv: partial over this wave's quarter of C
+    {
+      f32x4 acc[2] = {splat(0.f), splat(0.f)};
+      for (int j = 0; j < run; j += 4) {
+        const float *wp = a.wv + (size_t)(k0 + j) * D + l.r;
+        const float4 wb = make_float4(wp[0], wp[D], wp[2 * D], wp[3 * D]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int o = 16 * t + l.r;
+          const float4 av =
+              o < O ? ld4(gb + (size_t)o * C + k0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[t] = mma16(acc[t], av, wb);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          scr[((l.v * 2 + t) * 16 + 4 * l.q + e) * D + l.r] = acc[t][e];
+    }
+    // waves 0 / 1: probabilities and T = P h of their query tile
+    Keys k;
+    f32x4 p[2];
+    const bool qwave = l.v < 2 && 16 * l.v < O;
+    if (qwave) {
+      const int t = l.v;
+      k = load_keys(a, b, l);
+      probabilities(a, l, tl, t, k, p);
+      wr_nn(tl.large(T_PS), t, l, p);
+      wr_nn_t(tl.large(T_PT), t, l, p);
+      lds_fence();
+      const f32x4 T = mma32(splat(0.f), rd32(tl.large(T_PS), t, l), k.hT);
+      wr_cols(tl.small(T_TT), t, l, T);
+    }
+    lds_fence();
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * D; i += NTH) {   // dT: the four partials meet
+      const float s = (scr[i] + scr[512 + i]) + (scr[1024 + i] + scr[1536 + i]);
+      const int o = i / D, c = i % D;
+      tl.small(T_DT)[o * RS + c] = s;
+      tl.small(T_DTT)[c * TS + o] = s;
+    }
+    __syncthreads();
+    // dwv[c][i] = sum_o gout[o][c] T[o][i], dbv[c] = sum_o gout[o][c]: column tiles of 16
+    {
+      const F8 tb = rd32(tl.small(T_TT), 0, l);   // B[k = o][col = i]: row i of T^T
+      for (int ct = l.v; ct * 16 < C; ct += 4) {
+        float g[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int o = 8 * l.q + s;
+          g[s] = o < O ? gb[(size_t)o * C + 16 * ct + l.r] : 0.f;
+        }
+        const F8 ga{make_float4(g[0], g[1], g[2], g[3]), make_float4(g[4], g[5], g[6], g[7])};
+        const f32x4 dw = mma32(splat(0.f), ga, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) put(O * D + (16 * ct + 4 * l.q + e) * D + l.r, dw[e]);
+        float cs = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+        cs += __shfl_xor(cs, 16, 64);
+        cs += __shfl_xor(cs, 32, 64);
+        if (l.q == 0) put(O * D + C * D + 16 * ct + l.r, cs);
+      }
+    }
+    // softmax backward, d(qk) = dS h
+    if (qwave) {
+      const int t = l.v;
+      const float4 dta = rd16(tl.small(T_DT), t, l);
+      f32x4 ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) ds[u] = mma16(splat(0.f), dta, k.hB[u]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float dot = fmaf(p[0][e], ds[0][e], p[1][e] * ds[1][e]);
+        dot = rsum(dot);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ds[u][e] = p[u][e] * (ds[u][e] - dot) * a.inv_sqrt_c;
+      }
+      wr_nn(tl.large(T_DSR), t, l, ds);
+      wr_nn_t(tl.large(T_DST), t, l, ds);
+      lds_fence();
+      const f32x4 dqk = mma32(splat(0.f), rd32(tl.large(T_DSR), t, l), k.hT);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int o = 16 * t + 4 * l.q + e;
+        if (o < O) put(o * D + l.r, dqk[e]);
+      }
+    }
+    lds_fence();
+    __syncthreads();
+    // dh[n][i] = sum_o P[o][n] dT[o][i] + dS[o][n] qk[o][i]: waves 0 / 1 own the key tiles
+    if (l.v < 2 && 16 * l.v < N) {
+      const int u = l.v;
+      f32x4 gh = mma32(splat(0.f), rd32(tl.large(T_PT), u, l), rd32(tl.small(T_DTT), 0, l));
+      gh = mma32(gh, rd32(tl.large(T_DST), u, l), rd32(tl.small(T_QKT), 0, l));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 16 * u + 4 * l.q + e;
+        if (n < N) a.gh[((size_t)b * N + n) * D + l.r] = gh[e];
+      }
+    }
+    first = false;
+    __syncthreads();
+  }
+}
+
+// partial (rows, O*16 + C*16 + C) -> gq (O,C), gwk (C,16), gbk (C) = 0, gwv (C,16), gbv (C).
+// 1024 threads = 64 columns x 16 row parts: a column sum is 8-16 independent loads per
+// thread and one LDS meeting.  Blocks [0, nsum): 64 columns of [dwv | dbv] each; the
+// others first sum the O*16 columns of d(qk) (every one of them: 200 KB from L2) and
+// then produce 1024 entries of [gq | gwk].
+constexpr int RTH = 1024;
+__global__ __launch_bounds__(RTH) void saw_reduce_kernel(const float *__restrict__ partial,
+                                                         int rows, const float *__restrict__ q,
+                                                         const float *__restrict__ wk,
+                                                         float *__restrict__ gq,
+                                                         float *__restrict__ gwk,
+                                                         float *__restrict__ gbk,
+                                                         float *__restrict__ gwv,
+                                                         float *__restrict__ gbv, int O, int C,
+                                                         int nsum) {
+  __shared__ float red[16][65];
+  __shared__ float dqk[32 * D];
+  const int npar = O * D + C * D + C;
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  // sum of column `col` over the rows ry, ry + 16, ..; valid in the threads with ry == 0
+  auto colsum = [&](int col, bool ok) {
+    float acc = 0.f;
+    if (ok) {
+      float v[8];
+      int r = ry;
+      for (; r + 7 * 16 < rows; r += 8 * 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + 16 * u) * npar + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; r < rows; r += 16) acc += partial[(size_t)r * npar + col];
+    }
+    red[ry][cx] = acc;
+    __syncthreads();
+    float tot = 0.f;
+    if (ry == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += red[k][cx];
+    }
+    __syncthreads();
+    return tot;
+  };
+  if ((int)blockIdx.x < nsum) {   // gwv, gbv (and the zero bk gradient)
+    const int i = blockIdx.x * 64 + cx;
+    const float tot = colsum(O * D + i, i < C * D + C);
+    if (ry == 0) {
+      if (i < C * D)
+        gwv[i] = tot;
+      else if (i < C * D + C)
+        gbv[i - C * D] = tot;
+      if (i < C) gbk[i] = 0.f;
+    }
+    return;
+  }
+  for (int c0 = 0; c0 < O * D; c0 += 64) {
+    const float tot = colsum(c0 + cx, c0 + cx < O * D);
+    if (ry == 0 && c0 + cx < O * D) dqk[c0 + cx] = tot;
+  }
+  __syncthreads();
+  const int i = ((int)blockIdx.x - nsum) * RTH + threadIdx.x;
+  if (i < O * C) {   // gq[o][c] = sum_i d(qk)[o][i] wk[c][i]
+    const int o = i / C, c = i - o * C;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) acc = fmaf(dqk[o * D + j], wk[(size_t)c * D + j], acc);
+    gq[i] = acc;
+  } else if (i < O * C + C * D) {   // gwk[c][i] = sum_o q[o][c] d(qk)[o][i]
+    const int e = i - O * C, c = e / D, j = e - c * D;
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc = fmaf(q[(size_t)o * C + c], dqk[o * D + j], acc);
+    gwk[e] = acc;
+  }
+}
+
+int check(const SwArgs &a) {
+  if (a.B <= 0 || a.N <= 0 || a.O <= 0 || a.C <= 0) return SCAE_ERR_BAD_ARG;
+  if (a.N > 32 || a.O > 32 || (a.C & 63)) return SCAE_ERR_UNSUPPORTED;
+  return SCAE_OK;
+}
+}  // namespace
+
+extern "C" int scae_seed_attention_mfma_supported(int N, int O, int D_, int C) {
+  return D_ == D && N > 0 && N <= 32 && O > 0 && O <= 32 && C > 0 && (C & 63) == 0 ? 1 : 0;
+}
+extern "C" int scae_seed_attention_mfma_rows(int B) { return B <= 0 ? 0 : (B < 512 ? B : 512); }
+
+extern "C" int scae_seed_attention_mfma_fwd_f32(const float *h, const float *q, const float *wk,
+                                                const float *wv, const float *bv,
+                                                const float *presence, float *out, int B, int N,
+                                                int O, int C, void *stream) {
+  SCAE_REQUIRE(h && q && wk && wv && bv && out);
+  SwArgs a{h, q, wk, wv, bv, presence, out, nullptr, nullptr, nullptr, B, N, O, C,
+           1.f / sqrtf((float)C)};
+  int rc = check(a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(saw_fwd_kernel, dim3(scae_seed_attention_mfma_rows(B)), dim3(NTH), 0,
+                     (hipStream_t)stream, a);
+  return scae_launch_status();
+}
+
+extern "C" int scae_seed_attention_mfma_bwd_f32(const float *h, const float *q, const float *wk,
+                                                const float *wv, const float *presence,
+                                                const float *gout, float *gh, float *partial,
+                                                int B, int N, int O, int C, void *stream) {
+  SCAE_REQUIRE(h && q && wk && wv && gout && gh && partial);
+  SwArgs a{h, q, wk, wv, nullptr, presence, nullptr, gout, gh, partial, B, N, O, C,
+           1.f / sqrtf((float)C)};
+  int rc = check(a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(saw_bwd_kernel, dim3(scae_seed_attention_mfma_rows(B)), dim3(NTH), 0,
+                     (hipStream_t)stream, a);
+  return scae_launch_status();
+}
+
+extern "C" int scae_seed_attention_mfma_reduce_f32(const float *partial, int rows, const float *q,
+                                                   const float *wk, float *gq, float *gwk,
+                                                   float *gbk, float *gwv, float *gbv, int O,
+                                                   int C, void *stream) {
+  SCAE_REQUIRE(partial && q && wk && gq && gwk && gbk && gwv && gbv && rows > 0 && O > 0 &&
+               O <= 32 && C > 0);
+  const int nsum = (C * D + C + 63) / 64, nexp = (O * C + C * D + RTH - 1) / RTH;
+  hipLaunchKernelGGL(saw_reduce_kernel, dim3(nsum + nexp), dim3(RTH), 0, (hipStream_t)stream,
+                     partial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C, nsum);
+  return scae_launch_status();
+}

@@ -28,14 +28,11 @@
 // Rows / columns >= N carry finite padding that never reaches a valid entry: padded
 // keys get probability 0, padded rows get presence 0 and a zero output gradient.
 #include "set_encoder_args.h"
+#include "wave_mfma.h"
 
 namespace scae_st {
 namespace {
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int D = 16;
-constexpr int RS = 24;    // row stride of R tiles
-constexpr int TS = 40;    // row stride of T tiles
-constexpr int SLOT = 32 * TS;   // floats per generic tile slot
+using namespace scae_wave;
 
 struct Lay {   // packed parameter offsets (floats), see set_encoder.hip
   int Din, L, ln;
@@ -47,59 +44,6 @@ struct Lay {   // packed parameter offsets (floats), see set_encoder.hip
   __device__ int ln1() const { return b(4) + 16; }
   __device__ int total() const { return layer(L); }
 };
-
-__device__ __forceinline__ float4 ld4(const float *p) {
-  return *reinterpret_cast<const float4 *>(p);
-}
-__device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
-__device__ __forceinline__ void lds_fence() {
-  // the wave's own LDS writes are visible to its later reads once they have completed
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-// acc += A B over K = 16 (a, b: the lane's four consecutive k)
-__device__ __forceinline__ f32x4 mma16(f32x4 acc, float4 a, float4 b) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-  return acc;
-}
-struct F8 {
-  float4 lo, hi;
-};
-__device__ __forceinline__ f32x4 mma32(f32x4 acc, const F8 &a, const F8 &b) {
-  return mma16(mma16(acc, a.lo, b.lo), a.hi, b.hi);
-}
-// Reductions over the 16 lanes of a row group (= one DPP row): quad butterflies, then the
-// half-row and row mirrors pair every lane with the other quads -- VALU-speed lane
-// exchanges (ds_bpermute shuffles cost an LDS round trip each: a first version of this
-// kernel spent half of its time in them).  All 16 lanes get the result.
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
-__device__ __forceinline__ float rsum(float v) {
-  v += dpp<DPP_XOR1>(v);
-  v += dpp<DPP_XOR2>(v);
-  v += dpp<DPP_HALF_MIRROR>(v);
-  v += dpp<DPP_MIRROR>(v);
-  return v;
-}
-__device__ __forceinline__ float rmax(float v) {
-  v = fmaxf(v, dpp<DPP_XOR1>(v));
-  v = fmaxf(v, dpp<DPP_XOR2>(v));
-  v = fmaxf(v, dpp<DPP_HALF_MIRROR>(v));
-  v = fmaxf(v, dpp<DPP_MIRROR>(v));
-  return v;
-}
-// sum over the 16 rows of an O-layout tile (column sum): every lane of column r gets it
-__device__ __forceinline__ float csum(const f32x4 &o) {
-  float v = (o[0] + o[1]) + (o[2] + o[3]);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
 
 struct Wave {
   int lane, r, q, t;   // t: the 16-row tile this wave owns (= its index in the workgroup)

@@ -460,9 +460,16 @@ class _SeedAttention(torch.autograd.Function):
         B, N, D = h.shape
         O, C = q.shape
         out = torch.empty(B, O, C, device=h.device, dtype=h.dtype)
-        _lib.call("scae_seed_attention_fwd_f32", _p(h), _p(q), _p(wk), _p(bk),
-                  _p(wv), _p(bv), _p(presence), _p(out), None, B, N, O, D, C,
-                  _stream(h))
+        ctx.mfma = bool(_lib.load().scae_seed_attention_mfma_supported(N, O, D,
+                                                                       C))
+        if ctx.mfma:     # wave-per-tile kernels on the matrix cores
+            _lib.call("scae_seed_attention_mfma_fwd_f32", _p(h), _p(q), _p(wk),
+                      _p(wv), _p(bv), _p(presence), _p(out), B, N, O, C,
+                      _stream(h))
+        else:
+            _lib.call("scae_seed_attention_fwd_f32", _p(h), _p(q), _p(wk),
+                      _p(bk), _p(wv), _p(bv), _p(presence), _p(out), None, B, N,
+                      O, D, C, _stream(h))
         ctx.save_for_backward(h, q, wk, bk, wv, bv,
                               *([presence] if presence is not None else []))
         ctx.has_presence = presence is not None
@@ -475,6 +482,21 @@ class _SeedAttention(torch.autograd.Function):
         B, N, D = h.shape
         O, C = q.shape
         lib = _lib.load()
+        if ctx.mfma:
+            rows = lib.scae_seed_attention_mfma_rows(B)
+            new = lambda *shape: torch.empty(*shape, device=h.device,  # noqa: E731
+                                             dtype=h.dtype)
+            partial, gh = new(rows, O * D + C * D + C), new(B, N, D)
+            _lib.call("scae_seed_attention_mfma_bwd_f32", _p(h), _p(q), _p(wk),
+                      _p(wv), _p(presence), _p(gout.contiguous()), _p(gh),
+                      _p(partial), B, N, O, C, _stream(h))
+            # column sums of the partials, expanded to the operands' gradients
+            gq, gwk, gbk, gwv, gbv = new(O, C), new(C, D), new(C), new(C, D), \
+                new(C)
+            _lib.call("scae_seed_attention_mfma_reduce_f32", _p(partial), rows,
+                      _p(q), _p(wk), _p(gq), _p(gwk), _p(gbk), _p(gwv), _p(gbv),
+                      O, C, _stream(h))
+            return gh, gq, gwk, gbk, gwv, gbv, None
         grid, S = lib.scae_seed_attention_grid(B, O), \
             lib.scae_seed_attention_splits(B, O)
         npar = O * C + 2 * C * D + 2 * C
