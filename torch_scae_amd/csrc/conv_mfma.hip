@@ -749,6 +749,11 @@ __host__ __device__ inline FirstSplit first_split(int B, int Cout) {
   return f;
 }
 
+// the lane = (pixel, channel quad) forms of the two image-layer kernels: C_out / 4 lanes
+// per pixel must divide a wave
+__host__ __device__ inline bool first_vec(int Cout) {
+  return Cout == 64 || Cout == 128 || Cout == 256;
+}
 __device__ __forceinline__ void stage_image(float *s_img, const float *img, int n, int count) {
   for (int e = threadIdx.x; e < count; e += 256) s_img[e] = img[(size_t)n * count + e];
   __syncthreads();
@@ -777,6 +782,41 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__rest
   stage_image(s_img, img, n, CIN * g.IH * g.IW);
   const int P = g.OH * g.OW, per = (P + f.slices - 1) / f.slices;
   const int pbeg = slice * per, pend = min(P, pbeg + per);
+  if (first_vec(g.Cout)) {
+    // lane = (pixel of the pass, channel quad): a wave stores 1 KiB of consecutive NHWC
+    // floats per instruction (lane-per-channel dword stores left the kernel at a third of
+    // the write bandwidth)
+    const int QL = g.Cout / 4, PPW = 64 / QL, cq = lane % QL, ps = lane / QL;
+    float wr[4][CIN * 9], b4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int k = 0; k < CIN * 9; ++k) wr[c][k] = w[(size_t)(4 * cq + c) * CIN * 9 + k];
+      b4[c] = bias[4 * cq + c];
+    }
+    const int step = 4 * PPW;
+    int p = pbeg + wave * PPW + ps;
+    int oh = p / g.OW, ow = p - oh * g.OW;
+    float *dst = out + ((size_t)n * P + p) * g.Cout + 4 * cq;
+    for (; p < pend; p += step) {
+      const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
+      float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float x = src[(ci * g.IH + t / 3) * g.IW + t % 3];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = fmaf(x, wr[c][ci * 9 + t], acc[c]);
+        }
+      *reinterpret_cast<float4 *>(dst) = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f),
+                                                     fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+      dst += (size_t)step * g.Cout;
+      ow += step;
+      while (ow >= g.OW) ow -= g.OW, ++oh;
+    }
+    return;
+  }
   for (int wi = wave; wi < f.nchunk * f.parts; wi += 4) {
     const int co = (wi % f.nchunk) * 64 + lane, part = wi / f.nchunk;
     float wr[CIN * 9];
@@ -1057,6 +1097,8 @@ extern "C" int scae_conv3x3_first_wgrad_reduce_f32(
   SCAE_REQUIRE(dpre && img && partial && n_layers >= 0);
   if (Cout % 64) return SCAE_ERR_UNSUPPORTED;
   const FirstSplit f = first_split(B, Cout);
+  // (a lane = (pixel, channel quad) form like the forward's, with 16-byte gradient loads,
+  // measured slower here: 40 accumulators per lane and a cross-lane meeting per entry)
   const size_t lds = ((size_t)Cin * IH * IW +
                       (f.parts > 1 ? (size_t)f.parts * Cout * (Cin * 9 + 1) : 0)) * sizeof(float);
   if (lds > 64 * 1024) return SCAE_ERR_UNSUPPORTED;
