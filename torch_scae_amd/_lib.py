@@ -10,7 +10,9 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64,
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libscae_hip.so")
+# (SCAE_HIP_LIB: another build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get("SCAE_HIP_LIB") or os.path.join(_HERE, "lib",
+                                                        "libscae_hip.so")
 
 P = c_void_p  # device pointer
 

@@ -32,7 +32,10 @@ using scae::sigmoidf_;
 using scae::softplusf_;
 
 constexpr int NT = 256;
-constexpr int SLICES = 8;  // row slices per texel in the backward gather
+#ifndef SCAE_K1_SLICES
+#define SCAE_K1_SLICES 8
+#endif
+constexpr int SLICES = SCAE_K1_SLICES;  // row slices per texel in the backward gather
 
 struct Taps {
   int i00, i01, i10, i11;      // texel offsets inside one th*tw plane (clamped)

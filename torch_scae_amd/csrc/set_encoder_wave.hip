@@ -138,7 +138,7 @@ enum {
   S_HS = 0, S_QS, S_AS, S_H1S,         // private rows
   S_KS0, S_KS1, S_VT0, S_VT1,          // shared, double buffered by block parity
   S_FWD_SMALL,
-  S_VS0 = S_FWD_SMALL, S_VS1, S_KT0, S_KT1, S_QT, S_GT,   // shared (backward)
+  S_VS = S_FWD_SMALL, S_KT, S_QT, S_GT,   // shared (backward; three barriers per block)
   S_XT1, S_XT2, S_GR,                  // private scratch tiles (backward)
   S_BWD_SMALL
 };
@@ -194,8 +194,8 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   w.wr_rows(Ks, ko);
   w.wr_cols(Vt, vo);
   if (KEEP) {
-    w.wr_rows(tl.small(S_VS0 + par), vo);
-    w.wr_cols(tl.small(S_KT0 + par), ko);
+    w.wr_rows(tl.small(S_VS), vo);
+    w.wr_cols(tl.small(S_KT), ko);
     w.wr_cols(tl.small(S_QT), qo);
   }
   lds_fence();
@@ -341,7 +341,7 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
                                              float sqrt_d, int par, const SabState<NT> &st,
                                              LayerGrads &lg) {
   float *XT1 = tl.small(S_XT1), *XT2 = tl.small(S_XT2), *GR = tl.small(S_GR),
-        *GT = tl.small(S_GT), *Vs = tl.small(S_VS0 + par), *Kt = tl.small(S_KT0 + par),
+        *GT = tl.small(S_GT), *Vs = tl.small(S_VS), *Kt = tl.small(S_KT),
         *Qt = tl.small(S_QT), *PT = tl.large(L_PT), *DSR = tl.large(L_DSR),
         *DST = tl.large(L_DST);
   const int r = w.r, t = w.t;

@@ -448,7 +448,9 @@ def pack_params(parts):
 # K2c output attention with folded projections (set_transformer.py:218-223)
 # ----------------------------------------------------------------------------
 def seed_attention_supported(N, O, D, C):
-    return bool(_lib.load().scae_seed_attention_supported(N, O, D, C))
+    lib = _lib.load()
+    return bool(lib.scae_seed_attention_mfma_supported(N, O, D, C)
+                or lib.scae_seed_attention_supported(N, O, D, C))
 
 
 class _SeedAttention(torch.autograd.Function):
