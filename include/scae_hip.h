@@ -165,7 +165,7 @@ int scae_seed_attention_bwd_f32(const float *h, const float *q, const float *wk,
                                 void *stream);
 
 /* The same output attention on the matrix cores (seed_attention_wave.hip; D = 16,
- * N, O <= 32, C a multiple of 64), with two more steps of algebra: the logits contract
+ * N, O <= 64, C a multiple of 64), with two more steps of algebra: the logits contract
  * over D through qk = q wk (the q bk term is constant along the keys and drops out of
  * the softmax), and out = (P h) wv^T + bv.  bk is therefore not an input, and its
  * gradient is the exact zero the softmax's shift invariance implies.

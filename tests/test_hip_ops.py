@@ -697,14 +697,16 @@ def test_trunk_on_matrix_cores_vs_oracle(B, N, widths, L, ln, pres):
     (5, 32, 32, 128, "rand"),       # full tiles
     (7, 17, 9, 64, None),           # ragged keys, one query tile
     (3, 1, 1, 64, "ones"),
-    (4, 40, 24, 256, "rand"),       # N > 32: the workgroup-per-set kernels
+    (4, 40, 24, 256, "rand"),       # three key tiles (the 40 / 32 default)
+    (130, 48, 64, 256, "mixed"),    # configs[2]: 48 keys, 64 queries
+    (3, 64, 33, 64, None),
 ])
 def test_seed_attention_vs_fp64(B, N, O, C, pres):
     """K2c, ops.seed_attention(h, q, wk, bk, wv, bv, presence) =
     softmax((q K'^T - (1 - presence) 1e32) / sqrt(C)) V' with K' = h wk^T + bk,
     V' = h wv^T + bv (set_transformer.py:24-47 after the folding of
     seed_attention.hip): output and all gradients against the same formula
-    in fp64.  For N, O <= 32 this is seed_attention_wave.hip."""
+    in fp64 (seed_attention_wave.hip for N, O <= 64)."""
     from torch_scae_amd import ops
     D = 16
     g = torch.Generator().manual_seed(B * 7 + N)

@@ -14,8 +14,8 @@
 // parameter-sized products done once, in the reduce kernel), and bk gets the exact zero the
 // softmax's shift invariance implies (the reference's value is round-off noise around 0).
 //
-// One workgroup of 4 waves per set.  Waves 0 / 1 own the query-row tiles (softmax, P h);
-// all four share the C-wide products.  v_mfma_f32_16x16x4_f32 throughout (exact fp32).
+// One workgroup of 4 waves per set.  A wave per 16-row query tile (softmax, P h), then per
+// 16-row key tile (dh); all four share the C-wide products.  N, O <= 64.  v_mfma_f32_16x16x4_f32 throughout (exact fp32).
 #include <algorithm>
 
 #include "wave_mfma.h"
@@ -39,15 +39,28 @@ struct SwArgs {
   float inv_sqrt_c;
 };
 
-// LDS (floats): small tiles of 32 * RS, large of 32 * TS
-enum { T_QK = 0, T_TS, T_DT, T_QKT, T_TT, T_DTT, T_SMALL };   // R tiles / [16][TS] transposed
-enum { T_PS = 0, T_PT, T_DSR, T_DST, T_SCR, T_SCR2, T_LARGE };   // N x N tiles, scratch (2)
-constexpr int SMALL = 32 * RS;
-constexpr int LDS_FLOATS = T_SMALL * SMALL + T_LARGE * SLOT;
+// Tiles.  NT = 16-row tiles per side (2: N, O <= 32; 4: N, O <= 64).  R tiles [16 NT][RS]
+// (rows = queries), transposed [16][TSN] and N x N tiles [16 NT][TSN], TSN = 16 NT + 8.
+enum { T_QK = 0, T_TS, T_DT, T_QKT, T_TT, T_DTT, T_SMALL };   // R tiles / transposed
+enum { T_PS = 0, T_PT, T_DSR, T_DST, T_LARGE };                // N x N tiles
+template <int NT>
+struct Geo {
+  static constexpr int ROWS = 16 * NT, TSN = 16 * NT + 8;
+  static constexpr int SMALL = ROWS * RS;   // >= 16 * TSN
+  static constexpr int LARGE = ROWS * TSN;
+  static constexpr int SCR = 4 * NT * 256;  // the four waves' partial (ROWS x 16) products
+  static constexpr int LDS_FLOATS = T_SMALL * SMALL + T_LARGE * LARGE + SCR;
+};
+template <int NT>
 struct Tl {
   float *base;
-  __device__ __forceinline__ float *small(int i) const { return base + i * SMALL; }
-  __device__ __forceinline__ float *large(int i) const { return base + T_SMALL * SMALL + i * SLOT; }
+  __device__ __forceinline__ float *small(int i) const { return base + i * Geo<NT>::SMALL; }
+  __device__ __forceinline__ float *large(int i) const {
+    return base + T_SMALL * Geo<NT>::SMALL + i * Geo<NT>::LARGE;
+  }
+  __device__ __forceinline__ float *scr() const {
+    return base + T_SMALL * Geo<NT>::SMALL + T_LARGE * Geo<NT>::LARGE;
+  }
 };
 
 struct Lane {
@@ -59,133 +72,162 @@ __device__ __forceinline__ Lane make_lane() {
   l.v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   return l;
 }
+// K = 16 NT operands: the lane's 4 NT consecutive k
+template <int NT>
+struct FK {
+  float4 v[NT];
+};
+template <int NT>
+__device__ __forceinline__ f32x4 mmak(f32x4 acc, const FK<NT> &a, const FK<NT> &b) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc = mma16(acc, a.v[j], b.v[j]);
+  return acc;
+}
 __device__ __forceinline__ void wr_rows(float *tile, int t, const Lane &l, const f32x4 &o) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * l.q + e) * RS + l.r] = o[e];
 }
+template <int NT>
 __device__ __forceinline__ void wr_cols(float *tile, int t, const Lane &l, const f32x4 &o) {
-  *reinterpret_cast<float4 *>(tile + l.r * TS + 16 * t + 4 * l.q) =
+  *reinterpret_cast<float4 *>(tile + l.r * Geo<NT>::TSN + 16 * t + 4 * l.q) =
       make_float4(o[0], o[1], o[2], o[3]);
 }
-__device__ __forceinline__ void wr_nn(float *tile, int t, const Lane &l, const f32x4 (&o)[2]) {
+template <int NT>
+__device__ __forceinline__ void wr_nn(float *tile, int t, const Lane &l, const f32x4 (&o)[NT]) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * l.q + e) * TS + 16 * u + l.r] = o[u][e];
+    for (int e = 0; e < 4; ++e)
+      tile[(16 * t + 4 * l.q + e) * Geo<NT>::TSN + 16 * u + l.r] = o[u][e];
 }
-__device__ __forceinline__ void wr_nn_t(float *tile, int t, const Lane &l, const f32x4 (&o)[2]) {
+template <int NT>
+__device__ __forceinline__ void wr_nn_t(float *tile, int t, const Lane &l, const f32x4 (&o)[NT]) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
-    *reinterpret_cast<float4 *>(tile + (16 * u + l.r) * TS + 16 * t + 4 * l.q) =
+  for (int u = 0; u < NT; ++u)
+    *reinterpret_cast<float4 *>(tile + (16 * u + l.r) * Geo<NT>::TSN + 16 * t + 4 * l.q) =
         make_float4(o[u][0], o[u][1], o[u][2], o[u][3]);
 }
 __device__ __forceinline__ float4 rd16(const float *tile, int t, const Lane &l) {
   return ld4(tile + (16 * t + l.r) * RS + 4 * l.q);
 }
-__device__ __forceinline__ F8 rd32(const float *tile, int t, const Lane &l) {
-  const float *p = tile + (16 * t + l.r) * TS + 8 * l.q;
-  return F8{ld4(p), ld4(p + 4)};
+template <int NT>
+__device__ __forceinline__ FK<NT> rdk(const float *tile, int t, const Lane &l) {
+  const float *p = tile + (16 * t + l.r) * Geo<NT>::TSN + 4 * NT * l.q;
+  FK<NT> f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) f.v[j] = ld4(p + 4 * j);
+  return f;
 }
 
 // qk = q wk (O x 16) into the R tile QK (and transposed into QKT when given): the C-long
 // contraction is split over the four waves and met in LDS.  Ends with a barrier.
-__device__ __forceinline__ void fold_qk(const SwArgs &a, const Lane &l, const Tl &tl,
+template <int NT>
+__device__ __forceinline__ void fold_qk(const SwArgs &a, const Lane &l, const Tl<NT> &tl,
                                         bool transposed) {
   const int C = a.C, CW = C / 4, run = CW / 4;   // per wave, per lane group
-  float *scr = tl.large(T_SCR);
-  f32x4 acc[2] = {splat(0.f), splat(0.f)};
+  float *scr = tl.scr();
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = splat(0.f);
   const int k0 = CW * l.v + run * l.q;
   for (int j = 0; j < run; j += 4) {
     const float *wp = a.wk + (size_t)(k0 + j) * D + l.r;
     const float4 b = make_float4(wp[0], wp[D], wp[2 * D], wp[3 * D]);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int o = 16 * t + l.r;
       const float4 av = o < a.O ? ld4(a.q + (size_t)o * C + k0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
       acc[t] = mma16(acc[t], av, b);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      scr[((l.v * 2 + t) * 16 + 4 * l.q + e) * D + l.r] = acc[t][e];
+      scr[((l.v * NT + t) * 16 + 4 * l.q + e) * D + l.r] = acc[t][e];
   __syncthreads();
-  for (int i = threadIdx.x; i < 32 * D; i += NTH) {
-    const float s = (scr[i] + scr[512 + i]) + (scr[1024 + i] + scr[1536 + i]);
+  for (int i = threadIdx.x; i < Geo<NT>::ROWS * D; i += NTH) {
+    const float s = (scr[i] + scr[NT * 256 + i]) + (scr[2 * NT * 256 + i] + scr[3 * NT * 256 + i]);
     const int o = i / D, c = i % D;
     tl.small(T_QK)[o * RS + c] = s;
-    if (transposed) tl.small(T_QKT)[c * TS + o] = s;
+    if (transposed) tl.small(T_QKT)[c * Geo<NT>::TSN + o] = s;
   }
   __syncthreads();
 }
 
 // keys of a set as B operands: hB[u] for S / dP (K = 16: row n = 16 u + r, features 4 q ..)
-// and hT for P h / dS h (K = 32 over n = 8 q .., feature r)
+// and hT for P h / dS h (K = 16 NT over n = 4 NT q .., feature r)
+template <int NT>
 struct Keys {
-  float4 hB[2];
-  F8 hT;
-  float kmask[2];
+  float4 hB[NT];
+  FK<NT> hT;
+  float kmask[NT];
 };
-__device__ __forceinline__ Keys load_keys(const SwArgs &a, int b, const Lane &l) {
-  Keys k;
+template <int NT>
+__device__ __forceinline__ Keys<NT> load_keys(const SwArgs &a, int b, const Lane &l) {
+  Keys<NT> k;
   const float *hb = a.h + (size_t)b * a.N * D;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NT; ++u) {
     const int n = 16 * u + l.r;
     k.hB[u] = n < a.N ? ld4(hb + n * D + 4 * l.q) : make_float4(0.f, 0.f, 0.f, 0.f);
     k.kmask[u] = a.presence && n < a.N ? (1.f - a.presence[(size_t)b * a.N + n]) * 1e32f : 0.f;
   }
-  float t[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int n = 8 * l.q + s;
-    t[s] = n < a.N ? hb[n * D + l.r] : 0.f;
+  for (int j = 0; j < NT; ++j) {
+    float t[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int n = 4 * NT * l.q + 4 * j + s;
+      t[s] = n < a.N ? hb[n * D + l.r] : 0.f;
+    }
+    k.hT.v[j] = make_float4(t[0], t[1], t[2], t[3]);
   }
-  k.hT = F8{make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7])};
   return k;
 }
 
 // attention probabilities of the own query tile t (O layout, key tiles u)
-__device__ __forceinline__ void probabilities(const SwArgs &a, const Lane &l, const Tl &tl, int t,
-                                              const Keys &k, f32x4 (&p)[2]) {
+template <int NT>
+__device__ __forceinline__ void probabilities(const SwArgs &a, const Lane &l, const Tl<NT> &tl,
+                                              int t, const Keys<NT> &k, f32x4 (&p)[NT]) {
   const float4 qa = rd16(tl.small(T_QK), t, l);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) p[u] = mma16(splat(0.f), qa, k.hB[u]);
+  for (int u = 0; u < NT; ++u) p[u] = mma16(splat(0.f), qa, k.hB[u]);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float v[2], mx = -INFINITY, sum = 0.f;
+    float v[NT], mx = -INFINITY, sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NT; ++u) {
       v[u] = 16 * u + l.r < a.N ? (p[u][e] - k.kmask[u]) * a.inv_sqrt_c : -INFINITY;
       mx = fmaxf(mx, v[u]);
     }
     mx = rmax(mx);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) v[u] = __expf(v[u] - mx), sum += v[u];
+    for (int u = 0; u < NT; ++u) v[u] = __expf(v[u] - mx), sum += v[u];
     const float inv = 1.f / rsum(sum);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) p[u][e] = v[u] * inv;
+    for (int u = 0; u < NT; ++u) p[u][e] = v[u] * inv;
   }
 }
 
+template <int NT>
 __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-  const Tl tl{smem};
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Tl<NT> tl{smem};
   const Lane l = make_lane();
   const int C = a.C, O = a.O;
-  for (int i = threadIdx.x; i < LDS_FLOATS; i += NTH) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < Geo<NT>::LDS_FLOATS; i += NTH) smem[i] = 0.f;
   __syncthreads();
-  fold_qk(a, l, tl, false);
+  fold_qk<NT>(a, l, tl, false);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    if (l.v < 2 && 16 * l.v < O) {   // waves 0 / 1: the query tiles
+    if (l.v < NT && 16 * l.v < O) {   // the query tiles
       const int t = l.v;
-      const Keys k = load_keys(a, b, l);
-      f32x4 p[2];
-      probabilities(a, l, tl, t, k, p);
-      wr_nn(tl.large(T_PS), t, l, p);
+      const Keys<NT> k = load_keys<NT>(a, b, l);
+      f32x4 p[NT];
+      probabilities<NT>(a, l, tl, t, k, p);
+      wr_nn<NT>(tl.large(T_PS), t, l, p);
       lds_fence();
-      const f32x4 T = mma32(splat(0.f), rd32(tl.large(T_PS), t, l), k.hT);
+      const f32x4 T = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_PS), t, l), k.hT);
       wr_rows(tl.small(T_TS), t, l, T);
       lds_fence();
     }
@@ -196,7 +238,7 @@ __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
       const float4 wb = ld4(a.wv + (size_t)(16 * ct + l.r) * D + 4 * l.q);
       const float bias = a.bv[16 * ct + l.r];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         if (16 * t >= O) break;
         const f32x4 o = mma16(splat(bias), rd16(tl.small(T_TS), t, l), wb);
 #pragma unroll
@@ -210,17 +252,19 @@ __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
   }
 }
 
+template <int NT>
 __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-  const Tl tl{smem};
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Tl<NT> tl{smem};
   const Lane l = make_lane();
   const int C = a.C, O = a.O, N = a.N, CW = C / 4, run = CW / 4;
+  constexpr int TSN = Geo<NT>::TSN;
   const int npar = O * D + C * D + C;
   float *part = a.partial + (size_t)blockIdx.x * npar;
-  float *scr = tl.large(T_SCR);
-  for (int i = threadIdx.x; i < LDS_FLOATS; i += NTH) smem[i] = 0.f;
+  float *scr = tl.scr();
+  for (int i = threadIdx.x; i < Geo<NT>::LDS_FLOATS; i += NTH) smem[i] = 0.f;
   __syncthreads();
-  fold_qk(a, l, tl, true);
+  fold_qk<NT>(a, l, tl, true);
   bool first = true;
   auto put = [&](int idx, float v) { part[idx] = first ? v : part[idx] + v; };
   const int k0 = CW * l.v + run * l.q;   // this lane group's run of C in the dT product
@@ -228,12 +272,14 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
     const float *gb = a.gout + (size_t)b * O * C;
     // dT = gout wv: partial over this wave's quarter of C
     {
-      f32x4 acc[2] = {splat(0.f), splat(0.f)};
+      f32x4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = splat(0.f);
       for (int j = 0; j < run; j += 4) {
         const float *wp = a.wv + (size_t)(k0 + j) * D + l.r;
         const float4 wb = make_float4(wp[0], wp[D], wp[2 * D], wp[3 * D]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
           const int o = 16 * t + l.r;
           const float4 av =
               o < O ? ld4(gb + (size_t)o * C + k0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -241,49 +287,55 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          scr[((l.v * 2 + t) * 16 + 4 * l.q + e) * D + l.r] = acc[t][e];
+          scr[((l.v * NT + t) * 16 + 4 * l.q + e) * D + l.r] = acc[t][e];
     }
-    // waves 0 / 1: probabilities and T = P h of their query tile
-    Keys k;
-    f32x4 p[2];
-    const bool qwave = l.v < 2 && 16 * l.v < O;
+    // query waves: probabilities and T = P h of their tile
+    Keys<NT> k;
+    f32x4 p[NT];
+    const bool qwave = l.v < NT && 16 * l.v < O;
     if (qwave) {
       const int t = l.v;
-      k = load_keys(a, b, l);
-      probabilities(a, l, tl, t, k, p);
-      wr_nn(tl.large(T_PS), t, l, p);
-      wr_nn_t(tl.large(T_PT), t, l, p);
+      k = load_keys<NT>(a, b, l);
+      probabilities<NT>(a, l, tl, t, k, p);
+      wr_nn<NT>(tl.large(T_PS), t, l, p);
+      wr_nn_t<NT>(tl.large(T_PT), t, l, p);
       lds_fence();
-      const f32x4 T = mma32(splat(0.f), rd32(tl.large(T_PS), t, l), k.hT);
-      wr_cols(tl.small(T_TT), t, l, T);
+      const f32x4 T = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_PS), t, l), k.hT);
+      wr_cols<NT>(tl.small(T_TT), t, l, T);
     }
     lds_fence();
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * D; i += NTH) {   // dT: the four partials meet
-      const float s = (scr[i] + scr[512 + i]) + (scr[1024 + i] + scr[1536 + i]);
+    for (int i = threadIdx.x; i < Geo<NT>::ROWS * D; i += NTH) {   // dT: the four partials meet
+      const float s =
+          (scr[i] + scr[NT * 256 + i]) + (scr[2 * NT * 256 + i] + scr[3 * NT * 256 + i]);
       const int o = i / D, c = i % D;
       tl.small(T_DT)[o * RS + c] = s;
-      tl.small(T_DTT)[c * TS + o] = s;
+      tl.small(T_DTT)[c * TSN + o] = s;
     }
     __syncthreads();
     // dwv[c][i] = sum_o gout[o][c] T[o][i], dbv[c] = sum_o gout[o][c]: column tiles of 16
     {
-      const F8 tb = rd32(tl.small(T_TT), 0, l);   // B[k = o][col = i]: row i of T^T
+      const FK<NT> tb = rdk<NT>(tl.small(T_TT), 0, l);   // B[k = o][col = i]: row i of T^T
       for (int ct = l.v; ct * 16 < C; ct += 4) {
-        float g[8];
+        FK<NT> ga;
+        float cs = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const int o = 8 * l.q + s;
-          g[s] = o < O ? gb[(size_t)o * C + 16 * ct + l.r] : 0.f;
+        for (int j = 0; j < NT; ++j) {
+          float g[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int o = 4 * NT * l.q + 4 * j + s;
+            g[s] = o < O ? gb[(size_t)o * C + 16 * ct + l.r] : 0.f;
+          }
+          ga.v[j] = make_float4(g[0], g[1], g[2], g[3]);
+          cs += (g[0] + g[1]) + (g[2] + g[3]);
         }
-        const F8 ga{make_float4(g[0], g[1], g[2], g[3]), make_float4(g[4], g[5], g[6], g[7])};
-        const f32x4 dw = mma32(splat(0.f), ga, tb);
+        const f32x4 dw = mmak<NT>(splat(0.f), ga, tb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) put(O * D + (16 * ct + 4 * l.q + e) * D + l.r, dw[e]);
-        float cs = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
         cs += __shfl_xor(cs, 16, 64);
         cs += __shfl_xor(cs, 32, 64);
         if (l.q == 0) put(O * D + C * D + 16 * ct + l.r, cs);
@@ -293,20 +345,22 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
     if (qwave) {
       const int t = l.v;
       const float4 dta = rd16(tl.small(T_DT), t, l);
-      f32x4 ds[2];
+      f32x4 ds[NT];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) ds[u] = mma16(splat(0.f), dta, k.hB[u]);
+      for (int u = 0; u < NT; ++u) ds[u] = mma16(splat(0.f), dta, k.hB[u]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float dot = fmaf(p[0][e], ds[0][e], p[1][e] * ds[1][e]);
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) dot = fmaf(p[u][e], ds[u][e], dot);
         dot = rsum(dot);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ds[u][e] = p[u][e] * (ds[u][e] - dot) * a.inv_sqrt_c;
+        for (int u = 0; u < NT; ++u) ds[u][e] = p[u][e] * (ds[u][e] - dot) * a.inv_sqrt_c;
       }
-      wr_nn(tl.large(T_DSR), t, l, ds);
-      wr_nn_t(tl.large(T_DST), t, l, ds);
+      wr_nn<NT>(tl.large(T_DSR), t, l, ds);
+      wr_nn_t<NT>(tl.large(T_DST), t, l, ds);
       lds_fence();
-      const f32x4 dqk = mma32(splat(0.f), rd32(tl.large(T_DSR), t, l), k.hT);
+      const f32x4 dqk = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_DSR), t, l), k.hT);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = 16 * t + 4 * l.q + e;
@@ -315,11 +369,11 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
     }
     lds_fence();
     __syncthreads();
-    // dh[n][i] = sum_o P[o][n] dT[o][i] + dS[o][n] qk[o][i]: waves 0 / 1 own the key tiles
-    if (l.v < 2 && 16 * l.v < N) {
+    // dh[n][i] = sum_o P[o][n] dT[o][i] + dS[o][n] qk[o][i]: one key tile per wave
+    if (l.v < NT && 16 * l.v < N) {
       const int u = l.v;
-      f32x4 gh = mma32(splat(0.f), rd32(tl.large(T_PT), u, l), rd32(tl.small(T_DTT), 0, l));
-      gh = mma32(gh, rd32(tl.large(T_DST), u, l), rd32(tl.small(T_QKT), 0, l));
+      f32x4 gh = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_PT), u, l), rdk<NT>(tl.small(T_DTT), 0, l));
+      gh = mmak<NT>(gh, rdk<NT>(tl.large(T_DST), u, l), rdk<NT>(tl.small(T_QKT), 0, l));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = 16 * u + 4 * l.q + e;
@@ -347,7 +401,7 @@ __global__ __launch_bounds__(RTH) void saw_reduce_kernel(const float *__restrict
                                                          float *__restrict__ gbv, int O, int C,
                                                          int nsum) {
   __shared__ float red[16][65];
-  __shared__ float dqk[32 * D];
+  __shared__ float dqk[64 * D];
   const int npar = O * D + C * D + C;
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   // sum of column `col` over the rows ry, ry + 16, ..; valid in the threads with ry == 0
@@ -408,13 +462,33 @@ __global__ __launch_bounds__(RTH) void saw_reduce_kernel(const float *__restrict
 
 int check(const SwArgs &a) {
   if (a.B <= 0 || a.N <= 0 || a.O <= 0 || a.C <= 0) return SCAE_ERR_BAD_ARG;
-  if (a.N > 32 || a.O > 32 || (a.C & 63)) return SCAE_ERR_UNSUPPORTED;
+  if (a.N > 64 || a.O > 64 || (a.C & 63)) return SCAE_ERR_UNSUPPORTED;
   return SCAE_OK;
+}
+
+template <int NT>
+int launch_nt(const SwArgs &a, bool bwd, hipStream_t st) {
+  const size_t lds = Geo<NT>::LDS_FLOATS * sizeof(float);
+  const void *fn = bwd ? reinterpret_cast<const void *>(saw_bwd_kernel<NT>)
+                       : reinterpret_cast<const void *>(saw_fwd_kernel<NT>);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid(a.B < 512 ? a.B : 512);
+  if (bwd)
+    hipLaunchKernelGGL(saw_bwd_kernel<NT>, grid, dim3(NTH), lds, st, a);
+  else
+    hipLaunchKernelGGL(saw_fwd_kernel<NT>, grid, dim3(NTH), lds, st, a);
+  return scae_launch_status();
+}
+int launch(const SwArgs &a, bool bwd, hipStream_t st) {
+  return a.N <= 32 && a.O <= 32 ? launch_nt<2>(a, bwd, st) : launch_nt<4>(a, bwd, st);
 }
 }  // namespace
 
 extern "C" int scae_seed_attention_mfma_supported(int N, int O, int D_, int C) {
-  return D_ == D && N > 0 && N <= 32 && O > 0 && O <= 32 && C > 0 && (C & 63) == 0 ? 1 : 0;
+  return D_ == D && N > 0 && N <= 64 && O > 0 && O <= 64 && C > 0 && (C & 63) == 0 ? 1 : 0;
 }
 extern "C" int scae_seed_attention_mfma_rows(int B) { return B <= 0 ? 0 : (B < 512 ? B : 512); }
 
@@ -427,9 +501,7 @@ extern "C" int scae_seed_attention_mfma_fwd_f32(const float *h, const float *q, 
            1.f / sqrtf((float)C)};
   int rc = check(a);
   if (rc) return rc;
-  hipLaunchKernelGGL(saw_fwd_kernel, dim3(scae_seed_attention_mfma_rows(B)), dim3(NTH), 0,
-                     (hipStream_t)stream, a);
-  return scae_launch_status();
+  return launch(a, false, (hipStream_t)stream);
 }
 
 extern "C" int scae_seed_attention_mfma_bwd_f32(const float *h, const float *q, const float *wk,
@@ -441,9 +513,7 @@ extern "C" int scae_seed_attention_mfma_bwd_f32(const float *h, const float *q, 
            1.f / sqrtf((float)C)};
   int rc = check(a);
   if (rc) return rc;
-  hipLaunchKernelGGL(saw_bwd_kernel, dim3(scae_seed_attention_mfma_rows(B)), dim3(NTH), 0,
-                     (hipStream_t)stream, a);
-  return scae_launch_status();
+  return launch(a, true, (hipStream_t)stream);
 }
 
 extern "C" int scae_seed_attention_mfma_reduce_f32(const float *partial, int rows, const float *q,
@@ -451,7 +521,7 @@ extern "C" int scae_seed_attention_mfma_reduce_f32(const float *partial, int row
                                                    float *gbk, float *gwv, float *gbv, int O,
                                                    int C, void *stream) {
   SCAE_REQUIRE(partial && q && wk && gq && gwk && gbk && gwv && gbv && rows > 0 && O > 0 &&
-               O <= 32 && C > 0);
+               O <= 64 && C > 0);
   const int nsum = (C * D + C + 63) / 64, nexp = (O * C + C * D + RTH - 1) / RTH;
   hipLaunchKernelGGL(saw_reduce_kernel, dim3(nsum + nexp), dim3(RTH), 0, (hipStream_t)stream,
                      partial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C, nsum);
