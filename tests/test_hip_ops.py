@@ -631,10 +631,14 @@ def test_fused_set_encoder_vs_oracle(B, N, widths, D, Dout, L, ln, pres):
     (17, 17, (5, 30), 2, False, None),              # ragged second tile, no LayerNorm
     (6, 16, (16,), 3, True, "ones"),                # exactly one tile
     (3, 1, (5, 3), 1, True, "rand"),                # a single element
+    (70, 48, (6, 1, 16, 121), 3, True, "mixed"),    # configs[2]: three tiles / waves
+    (9, 40, (6, 1, 16, 121), 3, True, "rand"),      # the 40 / 32 default (ragged third tile)
+    (5, 64, (11,), 2, False, None),                 # four full tiles
+    (4, 57, (23, 9), 1, True, "rand"),              # ragged fourth tile
 ])
 def test_trunk_on_matrix_cores_vs_oracle(B, N, widths, L, ln, pres):
     """K2b without fc2 (the form SetTransformer.forward_segments uses): for
-    D = 16 and N <= 32 this is the wave-per-tile MFMA implementation
+    D = 16 and N <= 64 this is the wave-per-tile MFMA implementation
     (set_encoder_wave.hip) -- trunk output, segment gradients and every
     parameter gradient against the oracle."""
     from torch_scae_amd import ops

@@ -72,17 +72,6 @@ __device__ __forceinline__ Lane make_lane() {
   l.v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   return l;
 }
-// K = 16 NT operands: the lane's 4 NT consecutive k
-template <int NT>
-struct FK {
-  float4 v[NT];
-};
-template <int NT>
-__device__ __forceinline__ f32x4 mmak(f32x4 acc, const FK<NT> &a, const FK<NT> &b) {
-#pragma unroll
-  for (int j = 0; j < NT; ++j) acc = mma16(acc, a.v[j], b.v[j]);
-  return acc;
-}
 __device__ __forceinline__ void wr_rows(float *tile, int t, const Lane &l, const f32x4 &o) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * l.q + e) * RS + l.r] = o[e];

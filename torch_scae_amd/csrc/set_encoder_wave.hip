@@ -22,9 +22,10 @@
 //                  g W   (B[k][c] = W[k][c])   : four floats of W's column c;
 //                  products over n or m (K = 32): both operands from LDS tiles written
 //                                                 transposed ([col][row], 16-byte stores).
-//   LDS tiles  : "R" [32 rows][24] row-major (A operands with K = 16; stride 24 floats =
+//   LDS tiles  : "R" [16 NT rows][24] row-major (A operands with K = 16; stride 24 floats =
 //                6 x 16 B makes the row-per-lane ds_read_b128 conflict free), "T"
-//                [16][40] / [32][40] transposed or N x N (K = 32).
+//                [16][16 NT + 8] transposed / [16 NT][16 NT + 8] N x N (K = 16 NT); NT = number
+//                of 16-row tiles of the set = waves of its workgroup (N <= 64).
 // Rows / columns >= N carry finite padding that never reaches a valid entry: padded
 // keys get probability 0, padded rows get presence 0 and a zero output gradient.
 #include "set_encoder_args.h"
@@ -47,6 +48,7 @@ struct Lay {   // packed parameter offsets (floats), see set_encoder.hip
 
 struct Wave {
   int lane, r, q, t;   // t: the 16-row tile this wave owns (= its index in the workgroup)
+  int ts;              // row stride of T tiles: 16 NT + 8
   // O layout (own tile) -> R tile (row-major, stride RS)
   __device__ __forceinline__ void wr_rows(float *tile, const f32x4 &o) const {
 #pragma unroll
@@ -54,37 +56,37 @@ struct Wave {
   }
   // O layout -> T tile, transposed: tile[col r][row]
   __device__ __forceinline__ void wr_cols(float *tile, const f32x4 &o) const {
-    *reinterpret_cast<float4 *>(tile + r * TS + 16 * t + 4 * q) =
+    *reinterpret_cast<float4 *>(tile + r * ts + 16 * t + 4 * q) =
         make_float4(o[0], o[1], o[2], o[3]);
   }
-  // own rows of an N x N matrix (column tiles u) -> [32][TS] row-major
+  // own rows of an N x N matrix (column tiles u) -> [16 NT][ts] row-major
   template <int NT>
   __device__ __forceinline__ void wr_nn(float *tile, const f32x4 (&o)[NT]) const {
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * q + e) * TS + 16 * u + r] = o[u][e];
+      for (int e = 0; e < 4; ++e) tile[(16 * t + 4 * q + e) * ts + 16 * u + r] = o[u][e];
   }
   // ... and transposed: tile[col][row]
   template <int NT>
   __device__ __forceinline__ void wr_nn_t(float *tile, const f32x4 (&o)[NT]) const {
 #pragma unroll
     for (int u = 0; u < NT; ++u)
-      *reinterpret_cast<float4 *>(tile + (16 * u + r) * TS + 16 * t + 4 * q) =
+      *reinterpret_cast<float4 *>(tile + (16 * u + r) * ts + 16 * t + 4 * q) =
           make_float4(o[u][0], o[u][1], o[u][2], o[u][3]);
   }
   // operand with K = 16 from an R tile: row 16 u + r, k = 4 q ..
   __device__ __forceinline__ float4 rd16(const float *tile, int u) const {
     return ld4(tile + (16 * u + r) * RS + 4 * q);
   }
-  // operand with K = 32 from a T tile: row 16 u + r, k = 8 q ..
-  __device__ __forceinline__ F8 rd32(const float *tile, int u) const {
-    const float *p = tile + (16 * u + r) * TS + 8 * q;
-    return F8{ld4(p), ld4(p + 4)};
-  }
-  // ... K = 16 from a T tile (one key tile only): k = 4 q ..
-  __device__ __forceinline__ float4 rd16t(const float *tile, int u) const {
-    return ld4(tile + (16 * u + r) * TS + 4 * q);
+  // operand with K = 16 NT from a T tile: row 16 u + r, k = 4 NT q ..
+  template <int NT>
+  __device__ __forceinline__ FK<NT> rdk(const float *tile, int u) const {
+    const float *p = tile + (16 * u + r) * ts + 4 * NT * q;
+    FK<NT> f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) f.v[j] = ld4(p + 4 * j);
+    return f;
   }
   // B operand of x W^T from a 16 x 16 row-major matrix in global memory
   __device__ __forceinline__ float4 w_rows(const float *W) const { return ld4(W + r * D + 4 * q); }
@@ -98,8 +100,7 @@ struct Wave {
 template <int NT>
 __device__ __forceinline__ f32x4 mma_n(f32x4 acc, const Wave &w, const float *A, int ua,
                                        const float *B, int ub) {
-  if (NT == 2) return mma32(acc, w.rd32(A, ua), w.rd32(B, ub));
-  return mma16(acc, w.rd16t(A, ua), w.rd16t(B, ub));
+  return mmak<NT>(acc, w.template rdk<NT>(A, ua), w.template rdk<NT>(B, ub));
 }
 
 // LayerNorm over the 16 features of the rows of an O-layout tile
@@ -129,43 +130,53 @@ struct SabState {
   f32x4 xh0, rstd0, xh1, rstd1;
 };
 
-// LDS tile slots.  Small slots (SMALL floats: an R tile [32][24] or a transposed
-// [16][40] tile), then large ones (SLOT floats: N x N tiles [32][40]).  Rows 16 t .. of a
-// row-major slot / columns 16 t .. of a transposed one belong to wave t; "shared" slots
-// are read across waves after a workgroup barrier.
-constexpr int SMALL = 32 * RS;   // 768 >= 16 * TS
+// LDS tile slots.  Small slots (an R tile [16 NT][24] or a transposed [16][16 NT + 8]
+// tile), then large ones (N x N tiles [16 NT][16 NT + 8]).  Rows 16 t .. of a row-major
+// slot / columns 16 t .. of a transposed one belong to wave t; "shared" slots are read
+// across waves after a workgroup barrier.  Slots whose lifetimes do not overlap share
+// storage (Hs / As / the backward's generic R tile; Qs / H1s; Ps / dS); the backward, which
+// has three barriers per block, needs no double buffering of K / V.
+template <int NT>
+struct Geo {
+  static constexpr int TSN = 16 * NT + 8;
+  static constexpr int SMALL = 16 * NT * RS > 16 * TSN ? 16 * NT * RS : 16 * TSN;
+  static constexpr int LARGE = 16 * NT * TSN;
+  static constexpr int SCR = (NT > 1 ? NT - 1 : 1) * (5 * 256 + 10 * D);   // hand-over area
+};
 enum {
-  S_HS = 0, S_QS, S_AS, S_H1S,         // private rows
-  S_KS0, S_KS1, S_VT0, S_VT1,          // shared, double buffered by block parity
-  S_FWD_SMALL,
-  S_VS = S_FWD_SMALL, S_KT, S_QT, S_GT,   // shared (backward; three barriers per block)
-  S_XT1, S_XT2, S_GR,                  // private scratch tiles (backward)
+  S_HS = 0, S_QS,                      // private rows: Hs = As = GR, Qs = H1s
+  S_KS0, S_VT0,                        // shared
+  S_BWD_FIRST,
+  S_KS1 = S_BWD_FIRST, S_VT1, S_FWD_SMALL,   // forward only: second K / V buffers
+  S_VS = S_BWD_FIRST, S_KT, S_QT, S_GT,      // backward only: shared
+  S_XT1, S_XT2,                              //                private transposed scratch
   S_BWD_SMALL
 };
-enum { L_PS = 0, L_FWD_LARGE, L_PT = L_FWD_LARGE, L_DSR, L_DST, L_SCR0, L_SCR1, L_BWD_LARGE };
-__host__ __device__ inline int tiles_floats(bool bwd) {
-  return (bwd ? S_BWD_SMALL : S_FWD_SMALL) * SMALL + (bwd ? L_BWD_LARGE : L_FWD_LARGE) * SLOT;
-}
+constexpr int S_AS = S_HS, S_GR = S_HS, S_H1S = S_QS;
+enum { L_PS = 0, L_FWD_LARGE, L_PT = L_FWD_LARGE, L_DST, L_BWD_LARGE };
+constexpr int L_DSR = L_PS;
+template <int NT>
 struct Tiles {
-  float *base;
-  bool bwd;
-  __device__ __forceinline__ float *small(int i) const { return base + i * SMALL; }
-  __device__ __forceinline__ float *large(int i) const {
-    return base + (bwd ? S_BWD_SMALL : S_FWD_SMALL) * SMALL + i * SLOT;
-  }
+  float *base;    // small slots
+  float *lbase;   // large slots
+  float *scr;     // hand-over area (backward)
+  __device__ __forceinline__ float *small(int i) const { return base + i * Geo<NT>::SMALL; }
+  __device__ __forceinline__ float *large(int i) const { return lbase + i * Geo<NT>::LARGE; }
 };
 
 // One SAB: h (O layout, own tile) -> h.  NT = number of 16-row tiles (= waves) of the set.
-// `par`: parity of the block counter (selects the K / V buffers).  KEEP: fill `st` and
+// `par`: parity of the block counter (the forward's K / V buffers).  KEEP: fill `st` and
 // leave V row-major / K transposed / Q transposed behind for the backward pass.
 template <int NT, bool KEEP>
 __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const float *Wl,
-                                            const Tiles &tl, f32x4 &h, const f32x4 &pres,
+                                            const Tiles<NT> &tl, f32x4 &h, const f32x4 &pres,
                                             const float (&kmask)[NT], int N, float sqrt_d,
                                             int par, SabState<NT> *st) {
+  // (the forward kernel alternates two K / V buffers: it has one barrier per block)
   float *Hs = tl.small(S_HS), *Qs = tl.small(S_QS), *As = tl.small(S_AS),
-        *H1s = tl.small(S_H1S), *Ps = tl.large(L_PS), *Ks = tl.small(S_KS0 + par),
-        *Vt = tl.small(S_VT0 + par);
+        *H1s = tl.small(S_H1S), *Ps = tl.large(L_PS),
+        *Ks = tl.small(!KEEP && par ? S_KS1 : S_KS0),
+        *Vt = tl.small(!KEEP && par ? S_VT1 : S_VT0);
   const int r = w.r, t = w.t;
   const float inv_sqrt_d = 1.f / sqrt_d;
   // weights of the block as B operands (issued up front: they come from L2)
@@ -250,10 +261,20 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   if (lay.ln) layer_norm<KEEP>(h, g1, be1, KEEP ? st->xh1 : dummy, KEEP ? st->rstd1 : dummy);
 }
 
-// LDS of a workgroup: X [32][XS], W1s [16][XS], tile slots
+// LDS of a workgroup (floats).  Forward: X [16 NT][XS] | W1s [16][XS] | small | large.
+// Backward: W1s | small | hand-over area | arena, the arena holding the large tiles during
+// the blocks and X afterwards (the input is only needed for the fc1 weight gradient).
 __host__ __device__ inline int xs_of(int Din) { return (Din + 15) / 16 * 16 + 4; }
+template <int NT>
 __host__ __device__ inline size_t lds_floats(int Din, bool bwd) {
-  return (size_t)48 * xs_of(Din) + tiles_floats(bwd);
+  const size_t xs = xs_of(Din);
+  if (!bwd)
+    return (16 * NT + 16) * xs + (size_t)S_FWD_SMALL * Geo<NT>::SMALL +
+           (size_t)L_FWD_LARGE * Geo<NT>::LARGE;
+  const size_t arena = (size_t)L_BWD_LARGE * Geo<NT>::LARGE > 16 * NT * xs
+                           ? (size_t)L_BWD_LARGE * Geo<NT>::LARGE
+                           : 16 * NT * xs;
+  return 16 * xs + (size_t)S_BWD_SMALL * Geo<NT>::SMALL + Geo<NT>::SCR + arena;
 }
 
 // 4 bytes per lane, global -> LDS (lane l lands at lds + 4 l bytes): a row of up to 64
@@ -268,11 +289,12 @@ __device__ __forceinline__ void dma4(rsrc_t r, float *lds, int voff, int soff) {
 }
 // rows [n0, n1) x width floats (row stride sstride) -> LDS rows of stride XS, asynchronously
 __device__ __forceinline__ void dma_rows(const float *src, int sstride, int n0, int n1, int width,
-                                         float *dst, int XS, int lane) {
+                                         float *dst, int XS, int lane, int nstep = 1) {
   const rsrc_t rs = make_rsrc(src);
   for (int c = 0; c < width; c += 64)
     if (c + lane < width)
-      for (int n = n0; n < n1; ++n) dma4(rs, dst + n * XS + c, 4 * lane, 4 * (n * sstride + c));
+      for (int n = n0; n < n1; n += nstep)
+        dma4(rs, dst + n * XS + c, 4 * lane, 4 * (n * sstride + c));
 }
 __device__ __forceinline__ void dma_wait() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -309,7 +331,7 @@ __device__ __forceinline__ f32x4 fc1_forward(const Wave &w, const float *X, cons
 // ---- backward --------------------------------------------------------------------
 // operand with K = 16 from the wave's own columns of a transposed tile: row r, k = 16 t + 4 q ..
 __device__ __forceinline__ float4 rdT_own(const Wave &w, const float *tile) {
-  return ld4(tile + w.r * TS + 16 * w.t + 4 * w.q);
+  return ld4(tile + w.r * w.ts + 16 * w.t + 4 * w.q);
 }
 // gradient through a LayerNorm (g: w.r.t. the output -> w.r.t. the input) and the
 // own-tile column sums for gamma / beta
@@ -337,8 +359,8 @@ struct LayerGrads {
 // the block output on entry, w.r.t. its input on return (own tile).
 template <int NT>
 __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, const float *Wl,
-                                             const Tiles &tl, f32x4 &G, const f32x4 &pres, int N,
-                                             float sqrt_d, int par, const SabState<NT> &st,
+                                             const Tiles<NT> &tl, f32x4 &G, const f32x4 &pres,
+                                             int N, float sqrt_d, const SabState<NT> &st,
                                              LayerGrads &lg) {
   float *XT1 = tl.small(S_XT1), *XT2 = tl.small(S_XT2), *GR = tl.small(S_GR),
         *GT = tl.small(S_GT), *Vs = tl.small(S_VS), *Kt = tl.small(S_KT),
@@ -420,13 +442,14 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
 }
 
 // own-rows parameter gradients -> the workgroup's row of the partial matrix (wave 0
-// writes; with two waves, wave 1 hands its values over through LDS)
+// writes; the other waves hand their values over through LDS)
 template <int NT>
-__device__ __forceinline__ void flush_layer(const Wave &w, const Lay &lay, const Tiles &tl,
+__device__ __forceinline__ void flush_layer(const Wave &w, const Lay &lay, const Tiles<NT> &tl,
                                             const LayerGrads &lg, float *part, bool first) {
-  float *scr = tl.large(L_SCR0);   // [5][256] matrices, then [9][16] vectors (L_SCR1 follows)
+  constexpr int PW = 5 * 256 + 10 * D;   // hand-over floats per wave: 5 matrices, 9 (+1) vectors
   if (NT > 1) {
-    if (w.t == 1) {
+    if (w.t > 0) {
+      float *scr = tl.scr + (w.t - 1) * PW;
 #pragma unroll
       for (int m = 0; m < 5; ++m)
 #pragma unroll
@@ -438,23 +461,28 @@ __device__ __forceinline__ void flush_layer(const Wave &w, const Lay &lay, const
     }
     lds_fence();
     __syncthreads();
-    if (w.t == 1) return;
+    if (w.t > 0) return;
   }
   auto put = [&](int idx, float v) { part[idx] = first ? v : part[idx] + v; };
+  auto others = [&](int off) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 1; t < NT; ++t) v += tl.scr[(t - 1) * PW + off];
+    return v;
+  };
 #pragma unroll
   for (int m = 0; m < 5; ++m)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ij = (4 * w.q + e) * D + w.r;
-      put(lay.w(m) + ij, lg.w[m][e] + (NT > 1 ? scr[m * 256 + ij] : 0.f));
+      put(lay.w(m) + ij, lg.w[m][e] + others(m * 256 + ij));
     }
   if (w.q == 0) {
     const int voff[9] = {lay.b(0), lay.b(1), lay.b(2), lay.b(3), lay.b(4), lay.ln0(),
                          lay.ln0() + D, lay.ln1(), lay.ln1() + D};
 #pragma unroll
     for (int i = 0; i < 9; ++i)
-      if (i < 5 || lay.ln)
-        put(voff[i] + w.r, lg.v[i] + (NT > 1 ? scr[5 * 256 + i * D + w.r] : 0.f));
+      if (i < 5 || lay.ln) put(voff[i] + w.r, lg.v[i] + others(5 * 256 + i * D + w.r));
   }
 }
 
@@ -466,19 +494,21 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
   Wave w;
   w.lane = threadIdx.x & 63, w.r = w.lane & 15, w.q = w.lane >> 4;
   w.t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *X = smem, *W1s = smem + 32 * XS;
-  const Tiles tiles{smem + 48 * XS, true};
-  for (int i = threadIdx.x; i < 48 * XS; i += 64 * NT) X[i] = 0.f;
+  w.ts = Geo<NT>::TSN;
+  // W1s | small slots | hand-over area | arena (large tiles during the blocks, X after them)
+  float *W1s = smem, *sm = W1s + 16 * XS, *scr = sm + S_BWD_SMALL * Geo<NT>::SMALL,
+        *arena = scr + Geo<NT>::SCR, *X = arena;
+  const Tiles<NT> tiles{sm, arena, scr};
+  const int lds_total = (int)lds_floats<NT>(Din, true);
+  for (int i = threadIdx.x; i < lds_total; i += 64 * NT) smem[i] = 0.f;
   lds_fence();
   if (NT > 1) __syncthreads();
-  dma_rows(a.params, Din, w.t * (D / NT), (w.t + 1) * (D / NT), Din, W1s, XS, w.lane);
+  dma_rows(a.params, Din, w.t, D, Din, W1s, XS, w.lane, NT);
   dma_wait();
   if (NT > 1) __syncthreads();
   float *part = a.pg_partial + (size_t)blockIdx.x * lay.total();
   bool first = true;
-  int blk = 0;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    stage_input(a, b, w, X, XS);   // needed at the end (fc1 weight gradient); lands meanwhile
     f32x4 pres, G;
     float kmask[NT];
 #pragma unroll
@@ -502,40 +532,49 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
       }
       SabState<NT> st;
       const float *Wl = a.params + lay.layer(l);
-      sab_forward<NT, true>(w, lay, Wl, tiles, h, pres, kmask, N, a.sqrt_d, blk & 1, &st);
+      sab_forward<NT, true>(w, lay, Wl, tiles, h, pres, kmask, N, a.sqrt_d, 0, &st);
       LayerGrads lg;
-      sab_backward<NT>(w, lay, Wl, tiles, G, pres, N, a.sqrt_d, blk & 1, st, lg);
+      sab_backward<NT>(w, lay, Wl, tiles, G, pres, N, a.sqrt_d, st, lg);
       flush_layer<NT>(w, lay, tiles, lg, part + lay.layer(l), first);
-      ++blk;
     }
     // fc1: db1, dW1 = G^T x (column tiles split between the waves, K over all rows),
-    // input gradients of the segments that want one
-    dma_wait();
-    float *GT = tiles.small(S_GT), *GR = tiles.small(S_GR), *scr = tiles.large(L_SCR0);
+    // input gradients of the segments that want one.  The arena's N x N tiles are dead
+    // (every wave is past the last block's hand-over barrier): the input rows move in.
+    if (NT > 1) __syncthreads();
+    for (int i = threadIdx.x; i < 16 * NT * XS; i += 64 * NT) X[i] = 0.f;
+    lds_fence();
+    stage_input(a, b, w, X, XS);
+    float *GT = tiles.small(S_GT), *GR = tiles.small(S_GR);
     w.wr_cols(GT, G);
     w.wr_rows(GR, G);
     const float db1 = csum(G);
-    // (behind the block-gradient hand-over area, which wave 0 may still be reading)
-    if (NT > 1 && w.t == 1 && w.q == 0) scr[5 * 256 + 9 * D + w.r] = db1;
+    constexpr int PW = 5 * 256 + 10 * D;
+    if (NT > 1 && w.t > 0 && w.q == 0) scr[(w.t - 1) * PW + 5 * 256 + 9 * D + w.r] = db1;
+    dma_wait();
     lds_fence();
     if (NT > 1) __syncthreads();
     if (w.t == 0 && w.q == 0) {
-      const float v = db1 + (NT > 1 ? scr[5 * 256 + 9 * D + w.r] : 0.f);
+      float v = db1;
+#pragma unroll
+      for (int t = 1; t < NT; ++t) v += scr[(t - 1) * PW + 5 * 256 + 9 * D + w.r];
       part[lay.b1() + w.r] = first ? v : part[lay.b1() + w.r] + v;
     }
-    for (int jt = w.t; jt * 16 < Din; jt += NT) {
-      f32x4 acc = splat(0.f);
+    {
+      const FK<NT> ga = w.template rdk<NT>(GT, 0);   // A[row i][k = n]: row i of G^T
+      for (int jt = w.t; jt * 16 < Din; jt += NT) {
+        FK<NT> xb;   // B[k = n][col]: column 16 jt + r of X
 #pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        const float *xp = X + (16 * u + 4 * w.q) * XS + 16 * jt + w.r;
-        acc = mma16(acc, ld4(GT + w.r * TS + 16 * u + 4 * w.q),
-                    make_float4(xp[0], xp[XS], xp[2 * XS], xp[3 * XS]));
-      }
-      if (16 * jt + w.r < Din) {
+        for (int j = 0; j < NT; ++j) {
+          const float *xp = X + (4 * NT * w.q + 4 * j) * XS + 16 * jt + w.r;
+          xb.v[j] = make_float4(xp[0], xp[XS], xp[2 * XS], xp[3 * XS]);
+        }
+        const f32x4 acc = mmak<NT>(splat(0.f), ga, xb);
+        if (16 * jt + w.r < Din) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int idx = (4 * w.q + e) * Din + 16 * jt + w.r;
-          part[idx] = first ? acc[e] : part[idx] + acc[e];
+          for (int e = 0; e < 4; ++e) {
+            const int idx = (4 * w.q + e) * Din + 16 * jt + w.r;
+            part[idx] = first ? acc[e] : part[idx] + acc[e];
+          }
         }
       }
     }
@@ -564,7 +603,7 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
       }
     }
     first = false;
-    if (NT > 1) __syncthreads();   // X / GT / scratch are rewritten by the next set
+    if (NT > 1) __syncthreads();   // the arena turns back into tiles
   }
 }
 
@@ -576,13 +615,15 @@ __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
   Wave w;
   w.lane = threadIdx.x & 63, w.r = w.lane & 15, w.q = w.lane >> 4;
   w.t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *X = smem, *W1s = smem + 32 * XS;
-  const Tiles tiles{smem + 48 * XS, false};
+  w.ts = Geo<NT>::TSN;
+  // X | W1s | small slots | large slots
+  float *X = smem, *W1s = X + 16 * NT * XS, *sm = W1s + 16 * XS;
+  const Tiles<NT> tiles{sm, sm + S_FWD_SMALL * Geo<NT>::SMALL, nullptr};
   // zero padding of X / W1s (rows >= N, columns >= Din), then W1, once per workgroup
-  for (int i = threadIdx.x; i < 48 * XS; i += 64 * NT) X[i] = 0.f;   // X, W1s contiguous
+  for (int i = threadIdx.x; i < (16 * NT + 16) * XS; i += 64 * NT) X[i] = 0.f;
   lds_fence();
   if (NT > 1) __syncthreads();
-  dma_rows(a.params, a.Din, w.t * (D / NT), (w.t + 1) * (D / NT), a.Din, W1s, XS, w.lane);
+  dma_rows(a.params, a.Din, w.t, D, a.Din, W1s, XS, w.lane, NT);
   dma_wait();
   if (NT > 1) __syncthreads();
   int blk = 0;   // running SAB counter: parity picks the K / V buffers
@@ -628,34 +669,43 @@ __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
 }
 }  // namespace
 
-bool wave_supported(const StArgs &a, int Dh) {
-  return Dh == D && a.N <= 32 && a.Dout == 0 && a.L >= 0 && a.Din >= 1 &&
-         lds_floats(a.Din, true) * sizeof(float) <= 160 * 1024;
+static int tiles_of(int N) { return (N + 15) / 16; }
+static size_t lds_need(int N, int Din, bool bwd) {
+  switch (tiles_of(N)) {
+    case 1: return lds_floats<1>(Din, bwd) * sizeof(float);
+    case 2: return lds_floats<2>(Din, bwd) * sizeof(float);
+    case 3: return lds_floats<3>(Din, bwd) * sizeof(float);
+    default: return lds_floats<4>(Din, bwd) * sizeof(float);
+  }
 }
 
-int wave_launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
-  const size_t lds = lds_floats(a.Din, bwd) * sizeof(float);
-  const bool two = a.N > 16;
-  const void *fn = bwd ? (two ? reinterpret_cast<const void *>(stw_bwd_kernel<2>)
-                              : reinterpret_cast<const void *>(stw_bwd_kernel<1>))
-                       : (two ? reinterpret_cast<const void *>(stw_fwd_kernel<2>)
-                              : reinterpret_cast<const void *>(stw_fwd_kernel<1>));
+bool wave_supported(const StArgs &a, int Dh) {
+  return Dh == D && a.N <= 64 && a.Dout == 0 && a.L >= 0 && a.Din >= 1 &&
+         lds_need(a.N, a.Din, true) <= 160 * 1024 && lds_need(a.N, a.Din, false) <= 160 * 1024;
+}
+
+template <int NT>
+static int launch_nt(const StArgs &a, bool bwd, int grid, hipStream_t st) {
+  const size_t lds = lds_floats<NT>(a.Din, bwd) * sizeof(float);
+  const void *fn = bwd ? reinterpret_cast<const void *>(stw_bwd_kernel<NT>)
+                       : reinterpret_cast<const void *>(stw_fwd_kernel<NT>);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const dim3 block(two ? 128 : 64);
-  if (bwd) {
-    if (two)
-      hipLaunchKernelGGL(stw_bwd_kernel<2>, dim3(grid), block, lds, st, a);
-    else
-      hipLaunchKernelGGL(stw_bwd_kernel<1>, dim3(grid), block, lds, st, a);
-  } else {
-    if (two)
-      hipLaunchKernelGGL(stw_fwd_kernel<2>, dim3(grid), block, lds, st, a);
-    else
-      hipLaunchKernelGGL(stw_fwd_kernel<1>, dim3(grid), block, lds, st, a);
-  }
+  if (bwd)
+    hipLaunchKernelGGL(stw_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), lds, st, a);
+  else
+    hipLaunchKernelGGL(stw_fwd_kernel<NT>, dim3(grid), dim3(64 * NT), lds, st, a);
   return scae_launch_status();
+}
+
+int wave_launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
+  switch (tiles_of(a.N)) {
+    case 1: return launch_nt<1>(a, bwd, grid, st);
+    case 2: return launch_nt<2>(a, bwd, grid, st);
+    case 3: return launch_nt<3>(a, bwd, grid, st);
+    default: return launch_nt<4>(a, bwd, grid, st);
+  }
 }
 }  // namespace scae_st

@@ -67,4 +67,15 @@ __device__ __forceinline__ float csum(const f32x4 &o) {
   return v;
 }
 
+// K = 16 NT operands: the lane's 4 NT consecutive k
+template <int NT>
+struct FK {
+  float4 v[NT];
+};
+template <int NT>
+__device__ __forceinline__ f32x4 mmak(f32x4 acc, const FK<NT> &a, const FK<NT> &b) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc = mma16(acc, a.v[j], b.v[j]);
+  return acc;
+}
 }  // namespace scae_wave
