@@ -69,9 +69,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-optimizer", action="store_true")
-    ap.add_argument("--bf16-attention", action="store_true",
-                    help="bf16 autocast for the object encoder (configs[2]'s "
-                         "precision); not the headline fp32 line")
+    ap.add_argument("--bf16", "--bf16-attention", dest="bf16",
+                    action="store_true",
+                    help="configs[2]'s precision: bf16 operands / fp32 "
+                         "accumulation on the GEMM-shaped kernels (K7, K8); "
+                         "not the headline fp32 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -480,7 +482,7 @@ def main():
     step = TrainStep(model, B, cfg["model"]["image_shape"],
                      use_graph=not args.no_graph,
                      optimizer=not args.no_optimizer,
-                     autocast_dtype=torch.bfloat16 if args.bf16_attention
+                     autocast_dtype=torch.bfloat16 if args.bf16
                      else None, force_collective=args.force_spawn,
                      overlap=not args.no_overlap)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
@@ -517,8 +519,9 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 attention/linears of the object encoder, f32 elsewhere"
-                     if args.bf16_attention else "f32", "data": "synthetic",
+            "dtype": "bf16 operands / f32 accumulate on the GEMM-shaped kernels "
+                     "(K7, K8), f32 elsewhere" if args.bf16 else "f32",
+            "data": "synthetic",
             "config": {
                 "workload": args.workload, "per_gpu_batch": B,
                 "global_batch": B * world,

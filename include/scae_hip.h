@@ -266,6 +266,27 @@ typedef struct scae_gemm_desc {
 } scae_gemm_desc;
 int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
 
+/* bf16-operand forms of the GEMM-shaped launchers (BASELINE.json configs[2], "bs=1024
+ * bf16"): same arguments, same fp32 tensors in memory; the operands are rounded to bf16
+ * (nearest even) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation, in 128 x 128 tiles.  Problems too small for those tiles (a side shorter
+ * than 32; convolutions whose channel counts are not multiples of 128 or that have too few
+ * pixels to fill the device) run the fp32 kernels unchanged.  Epilogues (bias, ReLU,
+ * gates, column sums -- those of the values as they arrive, rounded) are identical. */
+int scae_gemm_bf16(const float *A, const float *B, float *C, const float *bias,
+                   const float *mask, float *asum, int batch, int M, int N, int K,
+                   int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
+                   int64_t b_batch, int ldc, int64_t c_batch, int bias_ld, int64_t bias_batch,
+                   int ldmask, int64_t mask_batch, int64_t asum_batch, int asum_ld, int relu,
+                   void *stream);
+int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
+int scae_conv3x3_fwd_bf16(const float *in, const float *wf, const float *bias, float *out,
+                          const float *post_bias, float *out_post, int B, int IH, int IW, int Cin,
+                          int Cout, int stride, void *stream);
+int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *in, float *din,
+                               float *partial, int B, int IH, int IW, int Cin, int Cout,
+                               int stride, void *stream);
+
 /* ------------------------------------------------------------------------
  * K8  3x3 "valid" convolutions of the CNN encoder as implicit GEMMs on the
  *     fp32 matrix cores      replaces part_encoder.py:26-44 / nn_ext.py:34-59

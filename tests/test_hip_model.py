@@ -526,3 +526,48 @@ def test_lazy_render_gives_the_same_tensors_and_the_same_step():
     a, b = run(True), run(False)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_cfg3_bf16_operands_vs_fp32_oracle_with_gradients():
+    """BASELINE.json configs[2] at full size (48 part / 64 object capsules,
+    bs = 1024) in its precision: bf16 operands with fp32 accumulation on the
+    GEMM-shaped kernels (K8 convolutions, K7 capsule-MLP and 1x1-conv GEMMs,
+    forward and backward; ops.mfma_bf16), fp32 everywhere else.  Against the
+    fp32 oracle on identical parameters / batch / noise, at bf16's bar: 2^-7
+    relative on the loss and every log entry; every parameter gradient within
+    5e-2 relative L2 (an operand carries 8 significant bits; the errors of a
+    dot product average out, those of a chain of layers add up)."""
+    from torch_scae_amd import nn_ext, ops
+    cfg, B, sd, image, label, noise = full_size_case("cfg3_shape")
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = O.prepare_model_params(**cfg)
+    oloss, olog, ograds = O.train_step(P, ocfg, image, label, noise)
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    ops._lib.call = spy
+    try:
+        with ops.mfma_bf16():
+            model, res, loss, log = run_model(cfg, sd, image, label, noise, True)
+            loss.backward()
+    finally:
+        ops._lib.call = real
+    used = {n for n in calls if n.endswith("_bf16")}
+    assert used == {"scae_conv3x3_fwd_bf16", "scae_conv3x3_bwd_pair_bf16",
+                    "scae_gemm_bf16", "scae_gemm_pair_bf16"}, used
+    tol = 2.0 ** -7
+    assert abs(float(loss) - float(oloss)) <= tol * abs(float(oloss))
+    for k, v in olog.items():
+        assert abs(float(log[k]) - float(v)) <= tol * max(1.0, abs(float(v))), k
+    grads = nn_ext.named_reference_grads(model)
+    worst = []
+    for k, ref in ograds.items():
+        if ref is None or float(ref.abs().max()) == 0.0:
+            continue
+        got = grads[k].detach().cpu()
+        worst.append((float((got - ref).norm() / ref.norm()), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-2, worst[:6]

@@ -1544,3 +1544,105 @@ def test_stage_batch_one_launch():
                   image.numel(), P(dl.data_ptr()), P(label.data_ptr()), label.numel(),
                   P(torch.cuda.current_stream().cuda_stream))
         assert torch.equal(di, image) and torch.equal(dl, label)
+
+
+# --------------------------------------------------------------------------
+# configs[2]'s precision: bf16 operands / fp32 accumulation on K7 and K8
+# (ops.mfma_bf16), against fp64 at bf16's bar
+# --------------------------------------------------------------------------
+def _rel_l2(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("B,HW,chans,strides", [
+    (256, 40, [128, 128, 128], [2, 2, 1]),     # 128-channel layers: bf16 tiles
+    (64, 24, [128, 128], [1, 1]),
+])
+def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides):
+    """K8 with bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): outputs
+    and weight / bias gradients against conv2d in fp64.  Bar: every operand is
+    rounded to 8 significant bits (relative 2^-9), a K-long dot product of
+    such terms is off by ~2^-9 / sqrt(K) x its term scale: relative L2 error
+    <= 1e-2 on the outputs, every entry within 2^-6 of the largest; gradients
+    additionally see the ReLU gates that bf16's rounding flips (pre-activations
+    within ~2^-9 of zero, a few tenths of a per cent of the units per layer):
+    <= 8e-2 relative L2 per tensor, the lower layers' being the worst."""
+    import torch.nn.functional as F
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(B + HW)
+    image = torch.rand(B, 1, HW, HW, generator=g)
+    ws, bs, cin = [], [], 1
+    for c in chans:
+        bound = 1.0 / (cin * 9) ** 0.5
+        ws.append((torch.rand(c, cin, 3, 3, generator=g) * 2 - 1) * bound)
+        bs.append((torch.rand(c, generator=g) * 2 - 1) * bound)
+        cin = c
+    w64 = [t.double().requires_grad_() for t in ws]
+    b64 = [t.double().requires_grad_() for t in bs]
+    y_ref = image.double()
+    for wi, bi, s in zip(w64, b64, strides):
+        y_ref = F.relu(F.conv2d(y_ref, wi, bi, stride=s))
+    wg, bg = [leaf(t) for t in ws], [leaf(t) for t in bs]
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    ops._lib.call = spy
+    try:
+        with ops.mfma_bf16():
+            y = ops.conv_stack(image.cuda(), wg, bg, strides)
+            gy = torch.randn(y_ref.shape, generator=g)
+            y.backward(gy.cuda())
+    finally:
+        ops._lib.call = real
+    assert "scae_conv3x3_fwd_bf16" in calls and "scae_conv3x3_bwd_pair_bf16" in calls
+    y_ref.backward(gy.double())
+    assert _rel_l2(y, y_ref) <= 1e-2
+    assert float((y.cpu().double() - y_ref).abs().max()) <= 2 ** -6 * float(y_ref.abs().max())
+    for l in range(len(chans)):
+        for name, got, ref in (("dW", wg[l].grad, w64[l].grad),
+                               ("db", bg[l].grad, b64[l].grad)):
+            assert _rel_l2(got, ref) <= 8e-2, (name, l, _rel_l2(got, ref))
+
+
+def test_grouped_mlp_bf16_operands_vs_fp64():
+    """K7 (the per-capsule MLPs as batched GEMMs) with bf16 operands: forward,
+    input gradient and weight / bias gradients at configs[2]'s layer sizes."""
+    from torch_scae_amd import ops
+    from torch_scae_amd.nn_ext import GroupedMLP
+    G, B = 8, 1024
+    torch.manual_seed(3)
+    mlp = GroupedMLP(G, [256, 128, 32], bias=True).cuda()
+    x = torch.randn(B, G, 256, device="cuda", requires_grad=True)
+    w = torch.randn(B, G, 32, device="cuda")
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    ops._lib.call = spy
+    try:
+        with ops.mfma_bf16():
+            y = mlp(x)
+            (y * w).sum().backward()
+    finally:
+        ops._lib.call = real
+    assert any(n.endswith("_bf16") for n in calls), calls
+    params = [p for p in mlp.parameters()]
+    got = [x.grad.clone()] + [p.grad.clone() for p in params]
+    x.grad = None
+    for p in params:
+        p.grad = None
+    y_ref = mlp(x)            # the fp32 kernels as the yardstick (held to fp64 elsewhere)
+    (y_ref * w).sum().backward()
+    ref = [x.grad] + [p.grad for p in params]
+    assert _rel_l2(y, y_ref) <= 1e-2
+    # (gradients pass two ReLU gates: the ~0.3 % of units whose pre-activation lies
+    # within bf16's rounding of zero flip their gate, which alone moves a gradient
+    # tensor by a few per cent in L2)
+    for a, b in zip(got, ref):
+        assert _rel_l2(a, b) <= 8e-2, _rel_l2(a, b)

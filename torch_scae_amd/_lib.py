@@ -117,7 +117,12 @@ SIGNATURES = {
                                               c_int, c_int64, c_int, c_int64,
                                               c_int, c_int64, c_int64, c_int, c_int,
                                               P],
+    "scae_gemm_bf16": [P] * 6 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
+                                              c_int, c_int64, c_int, c_int64,
+                                              c_int, c_int64, c_int64, c_int, c_int,
+                                              P],
     "scae_gemm_pair_f32": [POINTER(GemmDesc), POINTER(GemmDesc), P],
+    "scae_gemm_pair_bf16": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_relayout_batch_f32": [c_int, P, P, P, P, P, P],
     "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
@@ -126,8 +131,10 @@ SIGNATURES = {
     "scae_conv3x3_first_wgrad_rows": [c_int] * 2,
     "scae_conv3x3_first_wgrad_f32": [P] * 3 + [c_int] * 6 + [P],
     "scae_conv3x3_fwd_f32": [P] * 6 + [c_int] * 6 + [P],
+    "scae_conv3x3_fwd_bf16": [P] * 6 + [c_int] * 6 + [P],
     "scae_conv3x3_dgrad_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_bwd_pair_f32": [P] * 5 + [c_int] * 6 + [P],
+    "scae_conv3x3_bwd_pair_bf16": [P] * 5 + [c_int] * 6 + [P],
     "scae_conv3x3_wgrad_reduce_batch_f32": [c_int] + [P] * 7,
     "scae_conv3x3_wgrad_splits": [c_int] * 5,
     "scae_conv3x3_wgrad_f32": [P] * 5 + [c_int] * 6 + [P],

@@ -42,9 +42,9 @@ struct ConvGeom {
   float *As = smem, *Bs = smem + TL::OPER;                                      \
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, r = lane & 15,  \
             q = lane >> 4;                                                      \
-  f32x4 acc[2][TL::NJ];                                                         \
+  typename TL::Acc acc[2][TL::NJ];                                              \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TL::NJ; ++j) \
-      acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[i][j] = typename TL::Acc{};
 #define SCAE_TILE_PROLOGUE SCAE_TILE_PROLOGUE_M(SK)
 
 // ---- forward: grid (Cout/TB, ceil(M/TA)) -----------------------------------------
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const float *__restrict_
 
 // ---- weight gradient: grid (Cin/T, Cout/T, 9 taps * S splits) --------------------
 // partial[(split*9 + tap)][co][ci], then bias partials [split][co] after 9*S slabs
-template <bool SK>
+template <int SK>   // workgroup shape (mfma_tile.h MODE 0, 1 or 3)
 __device__ __forceinline__ void wgrad_tile(float *smem, int bx, int by, int bz,
                                            const float *__restrict__ dpre,
                                            const float *__restrict__ in,
@@ -266,7 +266,9 @@ __device__ __forceinline__ void wgrad_tile(float *smem, int bx, int by, int bz,
   int pn[NQ], poh[NQ], pow_[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int m = kbeg + (tid + NT * i) / (T / 4);
+    int kq, rq;
+    kstr_pos<SK, T>(tid, i, kq, rq);
+    const int m = kbeg + kq;
     pn[i] = m / (g.OH * g.OW);
     const int rem = m - pn[i] * g.OH * g.OW;
     poh[i] = rem / g.OW, pow_[i] = rem - poh[i] * g.OW;
@@ -276,7 +278,9 @@ __device__ __forceinline__ void wgrad_tile(float *smem, int bx, int by, int bz,
     const int k0 = kbeg + c * BK;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int id = tid + NT * i, m = k0 + id / (T / 4), rq = 4 * (id % (T / 4));
+      int kq, rq;
+      kstr_pos<SK, T>(tid, i, kq, rq);
+      const int m = k0 + kq;
       ra.v[i] = rb.v[i] = zero4();
       if (m < kend) {
         const size_t pix = ((size_t)pn[i] * g.IH + poh[i] * g.stride + kh) * g.IW +
@@ -316,7 +320,7 @@ __device__ __forceinline__ void wgrad_tile(float *smem, int bx, int by, int bz,
   }
 }
 
-template <bool SK>
+template <int SK>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict__ dpre,
                                                         const float *__restrict__ in,
                                                         float *__restrict__ partial, ConvGeom g,
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float *__restrict_
 struct PairGrid {
   int nd, gx, wx, wy;
 };
-template <int DMODE, bool WSK>
+template <int DMODE, int WSK>
 __global__ __launch_bounds__(NT) void conv_bwd_pair_kernel(
     const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
     float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
@@ -1130,16 +1134,26 @@ extern "C" int scae_conv3x3_first_wgrad_f32(const float *dpre, const float *img,
                                              stream);
 }
 
-extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias,
-                                    float *out, const float *post_bias, float *out_post, int B,
-                                    int IH, int IW, int Cin, int Cout, int stride,
-                                    void *stream) {
+// bf16 operands (mfma_tile.h MODE 3: 128 x 128 tiles) need 128-channel multiples and
+// enough output rows for a few tiles per CU; otherwise the fp32 kernels run
+static bool conv_bf16_shape(long rows, int Cin, int Cout) {
+  return Cin % 128 == 0 && Cout % 128 == 0 && rows * (Cout / 128) >= 128 * 128;
+}
+
+static int conv_fwd_impl(const float *in, const float *wf, const float *bias, float *out,
+                         const float *post_bias, float *out_post, int B, int IH, int IW, int Cin,
+                         int Cout, int stride, bool bf16, void *stream) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, true);
   if (rc) return rc;
   SCAE_REQUIRE(in && wf && bias && out && (!out_post || post_bias));
   const int M = B * g.OH * g.OW;
   hipStream_t st = (hipStream_t)stream;
+  if (bf16 && conv_bf16_shape(M, Cin, Cout)) {
+    hipLaunchKernelGGL(conv_fwd_kernel<3>, dim3(Cout / 128, (M + 127) / 128), dim3(NT), 0, st, in,
+                       wf, bias, out, post_bias, out_post, g);
+    return scae_launch_status();
+  }
   const int cfg = pipe_cfg("SCAE_K8_FWD", M, Cout);
   if (cfg >= 0) {
 #define SCAE_FWD_PIPE(TT)                                                                    \
@@ -1177,6 +1191,21 @@ extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const floa
   return scae_launch_status();
 }
 
+extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const float *bias,
+                                    float *out, const float *post_bias, float *out_post, int B,
+                                    int IH, int IW, int Cin, int Cout, int stride,
+                                    void *stream) {
+  return conv_fwd_impl(in, wf, bias, out, post_bias, out_post, B, IH, IW, Cin, Cout, stride,
+                       false, stream);
+}
+extern "C" int scae_conv3x3_fwd_bf16(const float *in, const float *wf, const float *bias,
+                                     float *out, const float *post_bias, float *out_post, int B,
+                                     int IH, int IW, int Cin, int Cout, int stride,
+                                     void *stream) {
+  return conv_fwd_impl(in, wf, bias, out, post_bias, out_post, B, IH, IW, Cin, Cout, stride,
+                       true, stream);
+}
+
 // the data-gradient tiling of a layer: class tables, tile shape, grid
 struct DgradLaunch {
   DgradPlan pl;
@@ -1191,7 +1220,7 @@ struct DgradLaunch {
 #ifndef SCAE_PAIR_WIDE_MIN
 #define SCAE_PAIR_WIDE_MIN 600
 #endif
-static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false) {
+static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false, bool bf16 = false) {
   DgradLaunch d;
   DgradPlan &pl = d.pl;
   pl.nrc = dgrad_axis(g.IH, g.OH, g.stride, pl.rmask, pl.rcount, pl.rstart, pl.rlist);
@@ -1206,6 +1235,13 @@ static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false) {
     return tot;
   };
   // rows of the problem: input pixels (class tiles are ragged; close enough to choose)
+  if (bf16) {   // mfma_tile.h MODE 3: 128 input pixels x 128 channels
+    d.cfg = -1;
+    d.mode = 3;
+    d.ny = tiles(128);
+    d.gx = g.Cin / 128;
+    return d;
+  }
   // (default: first-generation data-gradient tiles, see conv_bwd_pair_mixed_kernel)
   const char *env = getenv(pair ? "SCAE_K8_PAIR" : "SCAE_K8_DG");
   d.cfg = env && *env ? pipe_cfg(pair ? "SCAE_K8_PAIR" : "SCAE_K8_DG", (long)g.B * g.IH * g.IW,
@@ -1259,16 +1295,24 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
   return scae_launch_status();
 }
 
-extern "C" int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, const float *in,
-                                         float *din, float *partial, int B, int IH, int IW,
-                                         int Cin, int Cout, int stride, void *stream) {
+static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *in, float *din,
+                              float *partial, int B, int IH, int IW, int Cin, int Cout,
+                              int stride, bool bf16, void *stream) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, true);
   if (rc) return rc;
   SCAE_REQUIRE(dpre && wd && in && din && partial);
   if (IH > DG_MAXDIM || IW > DG_MAXDIM) return SCAE_ERR_UNSUPPORTED;
-  const DgradLaunch d = plan_dgrad(g, true);
+  bf16 = bf16 && conv_bf16_shape((long)B * IH * IW, Cin, Cout);
+  const DgradLaunch d = plan_dgrad(g, true, bf16);
   const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
+  if (bf16) {   // both gradients on bf16 operands, 128 x 128 tiles
+    const PairGrid bg{d.gx * d.ny, d.gx, Cin / 128, Cout / 128};
+    hipLaunchKernelGGL((conv_bwd_pair_kernel<3, 3>), dim3(bg.nd + bg.wx * bg.wy * 9 * p.splits),
+                       dim3(NT), 0, (hipStream_t)stream, dpre, wd, in, din, in, partial, g, d.pl,
+                       p.splits, bg);
+    return scae_launch_status();
+  }
   const int wt = p.small && d.cfg < 0 ? 32 : 64;
   const PairGrid pg{d.gx * d.ny, d.gx, Cin / wt, Cout / wt};
   const dim3 grid(pg.nd + pg.wx * pg.wy * 9 * p.splits);
@@ -1311,6 +1355,19 @@ extern "C" int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, con
   }
 #undef SCAE_PAIR
   return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, const float *in,
+                                         float *din, float *partial, int B, int IH, int IW,
+                                         int Cin, int Cout, int stride, void *stream) {
+  return conv_bwd_pair_impl(dpre, wd, in, din, partial, B, IH, IW, Cin, Cout, stride, false,
+                            stream);
+}
+extern "C" int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *in,
+                                          float *din, float *partial, int B, int IH, int IW,
+                                          int Cin, int Cout, int stride, void *stream) {
+  return conv_bwd_pair_impl(dpre, wd, in, din, partial, B, IH, IW, Cin, Cout, stride, true,
+                            stream);
 }
 
 extern "C" int scae_conv3x3_wgrad_splits(int B, int OH, int OW, int Cin, int Cout) {

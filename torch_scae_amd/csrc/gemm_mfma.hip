@@ -34,7 +34,7 @@ struct GemmArgs {
 // X[row*ld + k] (quads along k); else X(row, k) = X[k*ld + row] (quads along
 // row).  `vec`: 16-byte global loads are legal (ld % 4 == 0 and an aligned
 // base); otherwise 4-byte loads.
-template <bool SK, bool KC>
+template <int SK, bool KC>
 __device__ __forceinline__ void fetch(Quads<Tile<SK>::NQ> &q, const float *X, int ld, int row0,
                                       int rows, int k0, int K, bool vec) {
   constexpr int T = Tile<SK>::T;
@@ -46,8 +46,10 @@ __device__ __forceinline__ void fetch(Quads<Tile<SK>::NQ> &q, const float *X, in
       row = row0 + id / QPR;
       k = k0 + 4 * (id % QPR);
     } else {
-      k = k0 + id / (T / 4);
-      row = row0 + 4 * (id % (T / 4));
+      int kq, rq;
+      kstr_pos<SK, T>(threadIdx.x, i, kq, rq);
+      k = k0 + kq;
+      row = row0 + rq;
     }
     float4 v = zero4();
     const size_t base = KC ? (size_t)row * ld + k : (size_t)k * ld + row;
@@ -66,7 +68,7 @@ __device__ __forceinline__ void fetch(Quads<Tile<SK>::NQ> &q, const float *X, in
 }
 
 // one output tile of problem `g`, batch element z (workgroup-uniform arguments)
-template <bool SK, bool AK, bool BKC>
+template <int SK, bool AK, bool BKC>
 __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z) {
   using TL = Tile<SK>;
   constexpr int T = TL::T, NQ = TL::NQ;
@@ -79,11 +81,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
   const bool bvec = (g.ldb & 3) == 0 && (g.b_batch & 3) == 0 && ((size_t)g.B & 15) == 0;
   const bool want_asum = !AK && g.asum && blockIdx.x == 0;  // workgroup-uniform
   float4 asum = zero4();
-  f32x4 acc[2][2];
+  typename TL::Acc acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) acc[i][j] = typename TL::Acc{};
 
   tile_mainloop<STAGES, SK, AK, BKC>(
       (g.K + BK - 1) / BK, As, Bs, acc, wid, r, q,
@@ -137,7 +139,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
   }
 }
 
-template <bool SK, bool AK, bool BKC>
+template <int SK, bool AK, bool BKC>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
   gemm_tile<SK, AK, BKC>(g, smem, blockIdx.z);
@@ -150,7 +152,7 @@ struct GemmPair {
   GemmArgs g[2];
   int nz0, layout[2];  // layout = 2*a_kcontig + b_kcontig
 };
-template <bool SK>
+template <int SK>
 __global__ __launch_bounds__(NT) void gemm_pair_kernel(GemmPair p) {
   __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
   const int which = (int)blockIdx.z >= p.nz0, z = blockIdx.z - (which ? p.nz0 : 0);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(NT) void gemm_pair_kernel(GemmPair p) {
 #endif
 constexpr long kSplitKBelow = SCAE_GEMM_SK_BELOW;
 
-template <bool SK>
+template <int SK>
 void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
   constexpr int T = Tile<SK>::T;
   const dim3 grid((g.N + T - 1) / T, (g.M + T - 1) / T, batch);
@@ -184,23 +186,55 @@ void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
 }
 }  // namespace
 
-extern "C" int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
-                             const float *mask, float *asum, int batch, int M, int N, int K,
-                             int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
-                             int64_t b_batch, int ldc, int64_t c_batch, int bias_ld,
-                             int64_t bias_batch, int ldmask, int64_t mask_batch,
-                             int64_t asum_batch, int asum_ld, int relu, void *stream) {
+// bf16 operands (MODE 3, 128 x 128 tiles) unless a side is so short that most of a tile
+// would be padding (rows / columns past the problem are not loaded, only multiplied)
+#ifndef SCAE_BF16_MIN_SIDE
+#define SCAE_BF16_MIN_SIDE 32
+#endif
+static bool bf16_shape(int M, int N) {
+  return M >= SCAE_BF16_MIN_SIDE && N >= SCAE_BF16_MIN_SIDE;
+}
+
+static int gemm_impl(const float *A, const float *B, float *C, const float *bias,
+                     const float *mask, float *asum, int batch, int M, int N, int K,
+                     int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
+                     int64_t b_batch, int ldc, int64_t c_batch, int bias_ld, int64_t bias_batch,
+                     int ldmask, int64_t mask_batch, int64_t asum_batch, int asum_ld, int relu,
+                     bool bf16, void *stream) {
   SCAE_REQUIRE(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0);
   if (asum && a_kcontig) return SCAE_ERR_UNSUPPORTED;
   GemmArgs g{A, B, bias, mask, C, asum, nullptr, (long)a_batch, (long)b_batch, (long)c_batch,
              (long)bias_batch, (long)mask_batch, (long)asum_batch, lda, ldb, ldc, bias_ld,
              ldmask, M, N, K, relu, asum_ld > 0 ? asum_ld : 1};
   const long tiles64 = (long)((N + 63) / 64) * ((M + 63) / 64) * batch;
-  if (tiles64 < kSplitKBelow)
-    launch<true>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
+  if (bf16 && bf16_shape(M, N))
+    launch<3>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
+  else if (tiles64 < kSplitKBelow)
+    launch<1>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
   else
-    launch<false>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
+    launch<0>(g, batch, a_kcontig, b_kcontig, (hipStream_t)stream);
   return scae_launch_status();
+}
+
+extern "C" int scae_gemm_f32(const float *A, const float *B, float *C, const float *bias,
+                             const float *mask, float *asum, int batch, int M, int N, int K,
+                             int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
+                             int64_t b_batch, int ldc, int64_t c_batch, int bias_ld,
+                             int64_t bias_batch, int ldmask, int64_t mask_batch,
+                             int64_t asum_batch, int asum_ld, int relu, void *stream) {
+  return gemm_impl(A, B, C, bias, mask, asum, batch, M, N, K, a_kcontig, lda, a_batch, b_kcontig,
+                   ldb, b_batch, ldc, c_batch, bias_ld, bias_batch, ldmask, mask_batch,
+                   asum_batch, asum_ld, relu, false, stream);
+}
+extern "C" int scae_gemm_bf16(const float *A, const float *B, float *C, const float *bias,
+                              const float *mask, float *asum, int batch, int M, int N, int K,
+                              int a_kcontig, int lda, int64_t a_batch, int b_kcontig, int ldb,
+                              int64_t b_batch, int ldc, int64_t c_batch, int bias_ld,
+                              int64_t bias_batch, int ldmask, int64_t mask_batch,
+                              int64_t asum_batch, int asum_ld, int relu, void *stream) {
+  return gemm_impl(A, B, C, bias, mask, asum, batch, M, N, K, a_kcontig, lda, a_batch, b_kcontig,
+                   ldb, b_batch, ldc, c_batch, bias_ld, bias_batch, ldmask, mask_batch,
+                   asum_batch, asum_ld, relu, true, stream);
 }
 
 static int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
@@ -214,8 +248,8 @@ static int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
   return SCAE_OK;
 }
 
-extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second,
-                                  void *stream) {
+static int gemm_pair_impl(const scae_gemm_desc *first, const scae_gemm_desc *second, bool bf16,
+                          void *stream) {
   GemmPair p;
   int rc = fill_args(p.g[0], first);
   if (rc) return rc;
@@ -229,11 +263,23 @@ extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_d
   const long tiles64 = (long)((first->N + 63) / 64) * ((first->M + 63) / 64) * first->batch +
                        (long)((second->N + 63) / 64) * ((second->M + 63) / 64) * second->batch;
   const int nz = first->batch + second->batch;
-  if (tiles64 < kSplitKBelow)
-    hipLaunchKernelGGL(gemm_pair_kernel<true>, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(NT),
+  if (bf16 && bf16_shape(first->M, first->N) && bf16_shape(second->M, second->N))
+    hipLaunchKernelGGL(gemm_pair_kernel<3>, dim3((N + 127) / 128, (M + 127) / 128, nz), dim3(NT),
+                       0, (hipStream_t)stream, p);
+  else if (tiles64 < kSplitKBelow)
+    hipLaunchKernelGGL(gemm_pair_kernel<1>, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(NT),
                        0, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL(gemm_pair_kernel<false>, dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(NT),
+    hipLaunchKernelGGL(gemm_pair_kernel<0>, dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(NT),
                        0, (hipStream_t)stream, p);
   return scae_launch_status();
+}
+
+extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second,
+                                  void *stream) {
+  return gemm_pair_impl(first, second, false, stream);
+}
+extern "C" int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_desc *second,
+                                   void *stream) {
+  return gemm_pair_impl(first, second, true, stream);
 }

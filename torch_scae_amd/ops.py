@@ -83,6 +83,33 @@ def scaled_sums(jobs):
 
 _NOISE_STATE = {}
 
+# BASELINE.json configs[2] ("bs=1024 bf16"): inside ``mfma_bf16()`` the GEMM-shaped kernels
+# (K7 batched GEMMs, K8 convolutions) round their fp32 operands to bf16 on the way into LDS
+# and multiply on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 results) wherever the
+# problem is large enough for the 128 x 128 tiles; everything else stays fp32.  The
+# context has to cover the backward pass as well (train_step.TrainStep does that).
+_MFMA_BF16 = False
+
+
+class mfma_bf16:
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _MFMA_BF16
+        self.prev, _MFMA_BF16 = _MFMA_BF16, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _MFMA_BF16
+        _MFMA_BF16 = self.prev
+        return False
+
+
+def _prec(name):
+    """C entry point of a GEMM-shaped launcher for the current precision."""
+    return name.replace("_f32", "_bf16") if _MFMA_BF16 else name
+
 
 def reset_noise():
     """Restart the device noise generators from ``torch.initial_seed()`` (call
@@ -645,7 +672,7 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
         out = new(B, (ih - 3) // s + 1, (iw - 3) // s + 1, co)
         if l == L - 1 and post_bias is not None:
             x_post = torch.empty_like(out)
-        _lib.call("scae_conv3x3_fwd_f32", _p(act), _p(wfs[l - 1]),
+        _lib.call(_prec("scae_conv3x3_fwd_f32"), _p(act), _p(wfs[l - 1]),
                   _p(biases[l]), _p(out), _p(post_bias if x_post is not None
                                              else None), _p(x_post),
                   B, ih, iw, ci, co, s, st)
@@ -675,7 +702,7 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
         din = new(B, ih, iw, ci)
         # weight-gradient partials and the (ReLU-gated) data gradient both
         # only wait for dpre: one launch
-        _lib.call("scae_conv3x3_bwd_pair_f32", _p(dpre), _p(wds[l - 1]),
+        _lib.call(_prec("scae_conv3x3_bwd_pair_f32"), _p(dpre), _p(wds[l - 1]),
                   _p(xin), _p(din), _p(partial), B, ih, iw, ci, co, s, st)
         pending.append((partial, gw, gb, co, ci, splits))
         gws[l], gbs[l] = gw, gb
@@ -1129,7 +1156,7 @@ def colored_templates(template_logits, feature, w1, b1, w2, b2,
 def _gemm(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
           bias=None, bias_ld=1, bias_b=0, mask=None, ldmask=0, mask_b=0,
           relu=False, asum=None, asum_b=0, asum_ld=1, ref=None):
-    _lib.call("scae_gemm_f32", A, B, C, bias, mask, asum, batch, M, N, K,
+    _lib.call(_prec("scae_gemm_f32"), A, B, C, bias, mask, asum, batch, M, N, K,
               int(a_k), lda, a_b, int(b_k), ldb, b_b, ldc, c_b, bias_ld, bias_b,
               ldmask, mask_b, asum_b, asum_ld, int(relu), _stream(ref))
 
@@ -1156,7 +1183,7 @@ def _gemm_desc(A, B, C, batch, M, N, K, a_k, lda, a_b, b_k, ldb, b_b, ldc, c_b,
 
 def _gemm_pair(first, second, ref):
     """Two independent GEMMs (``_gemm_desc``) in one launch."""
-    _lib.call("scae_gemm_pair_f32", ctypes.byref(first), ctypes.byref(second),
+    _lib.call(_prec("scae_gemm_pair_f32"), ctypes.byref(first), ctypes.byref(second),
               _stream(ref))
 
 

@@ -76,8 +76,13 @@ class TrainStep:
                                weight_decay=weight_decay) \
             if optimizer else None
         self.lr_decay_rate = lr_decay_rate
-        # e.g. torch.bfloat16: the object encoder's linears and attention run
-        # in bf16 (BASELINE.json configs[2]); everything else stays fp32
+        # torch.bfloat16 (BASELINE.json configs[2]): the GEMM-shaped kernels --
+        # K8 convolutions, K7 capsule-MLP / 1x1-conv GEMMs, forward and backward
+        # -- take bf16 operands with fp32 accumulation (ops.mfma_bf16); the
+        # mixture likelihood, the capsule likelihood, the fused object encoder
+        # and all reductions stay fp32
+        if autocast_dtype not in (None, torch.bfloat16):
+            raise ValueError("autocast_dtype must be None or torch.bfloat16")
         self.autocast_dtype = autocast_dtype
         self.log = None          # device tensors of the last step's log dict
         self.image = torch.zeros(batch_size, *image_shape, device=self.device)
@@ -97,14 +102,13 @@ class TrainStep:
     def _part_a(self):
         """forward + loss + backward (split: down to the decoders' inputs)."""
         self.flat.clear_grads()
-        with torch.autocast("cuda", dtype=self.autocast_dtype,
-                            enabled=self.autocast_dtype is not None):
+        with ops.mfma_bf16(self.autocast_dtype is not None):
             res = self.model(self.image)
-        loss, info = self.model.loss(res, self.image, self.label)
-        # a resident seed: no ones_like fill per step; the column sums that
-        # only produce parameter gradients wait for ONE launch at the end
-        with ops.deferred_param_sums():
-            loss.backward(self._one)
+            loss, info = self.model.loss(res, self.image, self.label)
+            # a resident seed: no ones_like fill per step; the column sums that
+            # only produce parameter gradients wait for ONE launch at the end
+            with ops.deferred_param_sums():
+                loss.backward(self._one)
         self._cut = res.get("_phase_cut") if self.split else None
         self.flat.gather_grads(None if self._cut is None else 0)
         if self._capturing:
@@ -134,7 +138,8 @@ class TrainStep:
         self._cut = None
         keep = [(t, l.grad) for t, l in zip(srcs, leaves)
                 if l.grad is not None]
-        with ops.deferred_param_sums():
+        with ops.mfma_bf16(self.autocast_dtype is not None), \
+                ops.deferred_param_sums():
             torch.autograd.backward([t for t, _ in keep],
                                     [g for _, g in keep])
         self.flat.gather_grads(1)
