@@ -19,7 +19,9 @@
 
 namespace {
 constexpr int NTI = 64;    // tail_image_kernel: one wave per image
-constexpr int NT = 256;    // combine / backward workgroups
+constexpr int NT = 256;    // backward workgroups
+constexpr int NTC = 1024;  // the one combine workgroup: its batch / column sums are
+                           // chains of L2 loads, 16 waves keep four times as many in flight
 constexpr int MAXCLS = 32;
 
 struct TailArgs {
@@ -179,21 +181,21 @@ __device__ __forceinline__ float between_term(const float *col, int O, int type,
 // out: [0] loss  [1] log_prob  [2] prior_within [3] prior_between [4] post_within
 //      [5] post_between [6] prior_cls_xe [7] posterior_cls_xe [8] rec_ll [9] -rec_ll
 //      [10] -log_prob [11] reg
-__global__ __launch_bounds__(NT) void tail_combine_kernel(TailArgs a, scae_loss_extras x, Ws ws,
+__global__ __launch_bounds__(NTC) void tail_combine_kernel(TailArgs a, scae_loss_extras x, Ws ws,
                                                           float *out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int B = a.B, O = a.O, tid = threadIdx.x;
-  float *col = smem, *red = smem + 2 * O;  // red: 6 * (NT/64) floats
+  float *col = smem, *red = smem + 2 * O;  // red: 6 * (NTC/64) floats
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int b = tid; b < B; b += NT) {
+  for (int b = tid; b < B; b += NTC) {
     const float4 p = *reinterpret_cast<const float4 *>(ws.part + (size_t)b * 8);
     v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w;
     v[4] += ws.part[(size_t)b * 8 + 4];
   }
   if (x.rec_sums)
-    for (int i = tid; i < x.n_rec; i += NT) v[5] += x.rec_sums[i];
+    for (int i = tid; i < x.n_rec; i += NTC) v[5] += x.rec_sums[i];
   // column sums over the batch: 16 lanes per column, each takes every 16th image
-  for (int e = tid; e < ((2 * O * 16 + NT - 1) / NT) * NT; e += NT) {
+  for (int e = tid; e < ((2 * O * 16 + NTC - 1) / NTC) * NTC; e += NTC) {
     const int c = e >> 4, l = e & 15, which = c / O, o = c - which * O;
     float t = 0.f;
     if (c < 2 * O) {  // (loads kept in flight: four independent partial sums)
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(NT) void tail_combine_kernel(TailArgs a, scae_loss_
     for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
     if (c < 2 * O && l == 0) col[c] = ws.col[c] = t;
   }
-  scae::block_sum<6, NT>(v, red);  // (contains the barriers that publish col[])
+  scae::block_sum<6, NTC>(v, red);  // (contains the barriers that publish col[])
   if (tid >= 64) return;
   float pb = 0.f, qb = 0.f;
   if (a.sparsity_on) {
@@ -409,8 +411,8 @@ extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
   const Ws ws = carve_ws(workspace, B, O, ncls);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(tail_image_kernel, dim3(B), dim3(NTI), 3 * O * sizeof(float), st, a, ws);
-  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NT),
-                     (2 * O + 6 * (NT / 64)) * sizeof(float), st, a, x, ws, out12);
+  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NTC),
+                     (2 * O + 6 * (NTC / 64)) * sizeof(float), st, a, x, ws, out12);
   return scae_launch_status();
 }
 
