@@ -416,6 +416,20 @@ int scae_stage_batch(float *dst_image, const float *src_image, int64_t n_image,
                      int64_t *dst_label, const int64_t *src_label, int64_t n_label,
                      void *stream);
 
+/* Prologue of a training step: the three jobs that depend on nothing but the
+ * previous step's parameter update, as block ranges of ONE launch ahead of the
+ * (replayed) step --
+ *   the batch hand-over of scae_stage_batch (base_experiment.py:109-112),
+ *   the presence-noise draws of scae_uniform_f32 (part_encoder.py:106,
+ *   object_decoder.py:201: n_noise floats, same generator state, same values),
+ *   the parameter-only folding products of scae_seed_fold_fwd_f32
+ *   (set_transformer.py:218-223; `fold` as there).
+ * A part is left out with n_image == 0 / n_noise == 0 / fold == NULL. */
+int scae_step_prologue_f32(float *dst_image, const float *src_image, int64_t n_image,
+                           int64_t *dst_label, const int64_t *src_label, int64_t n_label,
+                           float *noise, int64_t n_noise, uint64_t *noise_state,
+                           const scae_seed_fold_desc *fold, void *stream);
+
 /* ------------------------------------------------------------------------
  * K10  coloured templates      replaces TemplateGenerator.forward,
  *      part_decoder.py:78-110 (colorize_templates = True):

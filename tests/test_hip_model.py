@@ -436,6 +436,64 @@ def test_train_step_collective_paths_match_plain_step_bitwise():
             dist.destroy_process_group()
 
 
+def test_step_prologue_gives_the_same_step():
+    """TrainStep(prologue=True): batch hand-over, noise draws and the folding
+    products of the output attention in ONE launch ahead of the step.  Without
+    presence noise the step is deterministic: losses and parameters after three
+    steps are bit-identical to the prologue-free step, eager and replayed; with
+    noise every step sees a fresh draw from the prologue launch."""
+    from torch_scae_amd import factory, ops
+    from torch_scae_amd.train_step import TrainStep
+    cfg = dict(image_shape=(1, 16, 16), n_classes=4, n_part_caps=5,
+               n_obj_caps=4,
+               pcae_cnn_encoder_params=dict(out_channels=[64, 64],
+                                            kernel_sizes=[3, 3],
+                                            strides=[2, 1]),
+               pcae_template_generator_params=dict(template_size=(5, 5)),
+               ocae_encoder_set_transformer_params=dict(dim_hidden=8,
+                                                        dim_out=64, n_layers=2),
+               ocae_decoder_capsule_params=dict(dim_caps=4, hidden_sizes=(8,)),
+               scae_params=dict(reconstruct_alternatives=False))
+    B = 8
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand(4, B, 1, 16, 16, generator=g).cuda()
+    labels = torch.randint(0, 4, (4, B), generator=g).cuda()
+
+    def run(use_graph, prologue, noise):
+        np.random.seed(0)
+        torch.manual_seed(0)
+        ops.reset_noise()
+        model = factory.make_scae(cfg).cuda().train()
+        if not noise:
+            model.part_encoder.noise_scale = 0.
+            model.obj_decoder.capsule_layer.noise_type = None
+        step = TrainStep(model, B, (1, 16, 16), lr=1e-3, use_graph=use_graph,
+                         prologue=prologue)
+        losses, draws = [], []
+        for i in range(4):
+            losses.append(float(step(images[i], labels[i])))
+            if step._pro is not None and step._pro.noise is not None:
+                draws.append(step._pro.noise.clone())
+        torch.cuda.synchronize()
+        return step, losses, draws, {k: v.clone()
+                                     for k, v in model.state_dict().items()}
+
+    for use_graph in (False, True):
+        s1, l1, _, sd1 = run(use_graph, True, False)
+        s0, l0, _, sd0 = run(use_graph, False, False)
+        assert s1._pro is not None and s1._pro.fold_outs is not None
+        assert s1._pro.noise is None and s0._pro is None
+        assert l0 == l1, (use_graph, l0, l1)
+        for k in sd0:
+            assert torch.equal(sd0[k], sd1[k]), (use_graph, k)
+        s2, l2, draws, _ = run(use_graph, True, True)
+        assert s2._pro.noise is not None and all(np.isfinite(l2))
+        assert len(draws) == 4
+        for a, b in zip(draws, draws[1:]):
+            assert not torch.equal(a, b)
+        assert 0.0 <= float(draws[-1].min()) and float(draws[-1].max()) < 1.0
+
+
 def test_recon_mse_term_sends_gradient_like_the_oracle():
     """recon_mse_weight > 0 (stacked_capsule_auto_encoder.py:226-230): the MSE
     term is built from pdf.mode(), whose gradient reaches the templates and

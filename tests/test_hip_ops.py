@@ -1546,6 +1546,67 @@ def test_stage_batch_one_launch():
         assert torch.equal(di, image) and torch.equal(dl, label)
 
 
+def test_step_prologue_matches_the_three_launches():
+    """scae_step_prologue_f32 = scae_stage_batch + scae_uniform_f32 +
+    scae_seed_fold_fwd_f32 in one launch: bit-identical outputs, and the noise
+    generator advances exactly as a scae_uniform_f32 launch advances it."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(11)
+    O, C, D = 24, 256, 16
+    shapes = [(O, C), (C, C), (C,), (C, C), (C,), (C, C), (C,), (C, C), (C,),
+              (C, D), (C,)]
+    vals = [(torch.randn(*s, generator=g) / (s[-1] ** 0.5)).cuda() for s in shapes]
+    image = torch.rand(128, 1, 40, 40, generator=g).cuda()
+    label = torch.randint(0, 10, (128,), generator=g).cuda()
+    n = 128 * 24 + 128 * 24 + 128 * 24 * 24
+    torch.manual_seed(1234)
+    ops.reset_noise()
+    ref_noise = [ops.uniform(n, image).clone() for _ in range(3)]
+    ref_fold = ops.seed_fold(*vals)
+
+    torch.manual_seed(1234)
+    ops.reset_noise()
+    pro = ops.StepPrologue()
+    di, dl = torch.zeros_like(image), torch.zeros_like(label)
+    with ops.step_prologue(pro):
+        first = ops.uniform(n, image)            # establishes the buffer, launches itself
+        assert torch.equal(first, ref_noise[0])
+        fold0 = ops.seed_fold(*vals)             # likewise
+        for a, b in zip(fold0, ref_fold):
+            assert torch.equal(a, b)
+        for a in pro.fold_outs:
+            a.fill_(float("nan"))
+        pro.launch(di, image, dl, label)
+        assert torch.equal(di, image) and torch.equal(dl, label)
+        second = ops.uniform(n, image)           # no launch: the prologue's draw
+        assert second.data_ptr() == pro.noise.data_ptr()
+        assert torch.equal(second, ref_noise[1])
+        fold1 = ops.seed_fold(*vals)
+        for a, b in zip(fold1, ref_fold):
+            assert torch.equal(a, b)
+        third = ops.uniform(n, image)            # consumed: launches again
+        assert torch.equal(third, ref_noise[2])
+        # gradients flow through the prologue-filled outputs as usual
+        vin = [v.clone().requires_grad_() for v in vals]
+        pro2 = ops.StepPrologue()
+        with ops.step_prologue(pro2):
+            ops.seed_fold(*vin)
+            pro2.launch()
+            outs = ops.seed_fold(*vin)
+        ref_in = [v.clone().requires_grad_() for v in vals]
+        ref_outs = ops.seed_fold(*ref_in)
+        gouts = [torch.randn(o.shape, generator=g).cuda() for o in outs]
+        torch.autograd.backward(outs, gouts)
+        torch.autograd.backward(ref_outs, gouts)
+        for a, b in zip(vin, ref_in):
+            assert torch.equal(a.grad, b.grad)
+    # parts can be left out
+    pro3 = ops.StepPrologue()
+    pro3.launch()                                # nothing to do: no launch, no error
+    pro3.launch(di.zero_(), image, dl.zero_(), label)
+    assert torch.equal(di, image) and torch.equal(dl, label)
+
+
 # --------------------------------------------------------------------------
 # configs[2]'s precision: bf16 operands / fp32 accumulation on K7 and K8
 # (ops.mfma_bf16), against fp64 at bf16's bar

@@ -47,6 +47,10 @@ def test_launchers_reject_bad_arguments_without_a_gpu():
     jobs = (_lib.SumJob * 5)()
     assert lib.scae_sum_rows_multi_f32(jobs, 5, None) == -1          # > 4 jobs
     assert lib.scae_stage_batch(None, None, 4, None, None, 0, None) == -1
+    assert lib.scae_step_prologue_f32(None, None, 4, None, None, 0, None, 0,
+                                      None, None, None) == -1
+    assert lib.scae_step_prologue_f32(None, None, 0, None, None, 0, None, 0,
+                                      None, None, None) == -1   # nothing to do
     assert lib.scae_conv3x3_bwd_pair_f32(None, None, None, None, None, 2, 9, 9,
                                          64, 64, 1, None) == -1
     assert lib.scae_conv3x3_first_fwd_relayout_f32(

@@ -1,4 +1,4 @@
-"""Aggregate FETCH_SIZE / WRITE_SIZE (KiB) per K8 kernel launch into profiles/r01/k8_pmc.json."""
+"""usage: pmc_k8.py <out.json> -- aggregate FETCH_SIZE / WRITE_SIZE (KiB) per K8 kernel launch."""
 import csv, json, collections, sys
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -8,9 +8,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != c:
             continue
         n = r["Kernel_Name"]
-        for key in ("conv_fwd_kernel", "conv_dgrad_kernel", "conv_wgrad_kernel",
-                    "conv_bwd_pair_kernel"):
-            if key in n:
+        for key, pats in (("conv_fwd_kernel", ("conv_fwd_kernel", "conv_fwd_pipe_kernel")),
+                          ("conv_dgrad_kernel", ("conv_dgrad_kernel", "conv_dgrad_pipe_kernel")),
+                          ("conv_wgrad_kernel", ("conv_wgrad_kernel", "conv_wgrad_pipe_kernel")),
+                          ("conv_bwd_pair_kernel", ("conv_bwd_pair_kernel", "conv_bwd_pair_pipe_kernel",
+                                                    "conv_bwd_pair_mixed_kernel"))):
+            if any(p + "<" in n or p + "(" in n for p in pats):
                 agg[key].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res[k][c + "_KB_per_launch"] = round(sum(v) / len(v), 1)
@@ -25,5 +28,5 @@ for k, d in res.items():
     d["hbm_bytes_per_launch_raw"] = int(f + w)
     d["hbm_bytes_per_launch_fetch_x2"] = int(2 * f + w)
     out["kernels"][k] = d
-json.dump(out, open("profiles/r01/k8_pmc.json", "w"), indent=1)
+json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-idx = [i for i, n in enumerate(names) if 'stage_batch_kernel' in n]
+idx = [i for i, n in enumerate(names) if 'stage_batch_kernel' in n or 'step_prologue_kernel' in n]
 pairs = [(a, b) for a, b in zip(idx, idx[1:]) if b - a > 20]
 a, b = pairs[-3]
 step = rows[a:b]

@@ -142,6 +142,8 @@ SIGNATURES = {
     "scae_attention_pool_fwd_f32": [P, P] + [c_int] * 4 + [P],
     "scae_attention_pool_bwd_f32": [P, P, P] + [c_int] * 4 + [P],
     "scae_stage_batch": [P, P, c_int64, P, P, c_int64, P],
+    "scae_step_prologue_f32": [P, P, c_int64, P, P, c_int64, P, c_int64, P,
+                               POINTER(SeedFoldDesc), P],
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
                               c_float, c_float, c_float, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],

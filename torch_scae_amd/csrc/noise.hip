@@ -4,63 +4,18 @@
 // kernel itself: a captured HIP graph replays fresh draws without the two
 // host-driven seed/offset fill launches torch's generator adds to every replay.
 #include "common.h"
+#include "noise_dev.h"
 
 namespace {
-constexpr int NT = 256;
-
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-  c[0] = hi1 ^ c[1] ^ k0;
-  c[1] = lo1;
-  c[2] = hi0 ^ c[3] ^ k1;
-  c[3] = lo0;
-}
-
-// state[0] = seed, state[1] = launches so far, low word of state[2] = arrival count.
-// The workgroup that arrives last advances state[1].  The arrival counter only
-// orders "every workgroup has READ state[1]" before that write -- no data is
-// handed between workgroups, so relaxed device-scope atomics suffice (a fenced
-// "last workgroup" protocol costs ~35 ns per workgroup on the 8-XCD part; a
-// second launch would cost ~4.5 us inside a graph).
-__global__ __launch_bounds__(NT) void uniform_kernel(float *__restrict__ out, int64_t n,
-                                                     uint64_t *__restrict__ state) {
-  const uint64_t seed = state[0], launch = state[1];
-  const int64_t groups = (n + 3) / 4;
-  for (int64_t g = (int64_t)blockIdx.x * NT + threadIdx.x; g < groups;
-       g += (int64_t)gridDim.x * NT) {
-    uint32_t c[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)launch,
-                     (uint32_t)(launch >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      philox_round(c, k0, k1);
-      k0 += 0x9E3779B9u;
-      k1 += 0xBB67AE85u;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)  // 24 random bits -> [0, 1)
-      if (4 * g + e < n) out[4 * g + e] = (float)(c[e] >> 8) * (1.0f / 16777216.0f);
-  }
-  __syncthreads();  // every wave of this workgroup holds its copy of state[1]
-  if (threadIdx.x == 0) {
-    unsigned *count = reinterpret_cast<unsigned *>(state + 2);
-    // (launch & 0) keeps the atomic behind the load of state[1] in issue order
-    const unsigned t = __hip_atomic_fetch_add(count, 1u + (unsigned)(launch & 0), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {
-      __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      state[1] = launch + 1;
-    }
-  }
+__global__ __launch_bounds__(scae_noise::NT) void uniform_kernel(float *__restrict__ out, int64_t n,
+                                                                 uint64_t *__restrict__ state) {
+  scae_noise::uniform_block(out, n, state, blockIdx.x, gridDim.x);
 }
 }  // namespace
 
 extern "C" int scae_uniform_f32(float *out, int64_t n, uint64_t *state, void *stream) {
   SCAE_REQUIRE(out && state && n > 0);
-  const int64_t blocks = ((n + 3) / 4 + NT - 1) / NT;
-  hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(NT), 0,
+  hipLaunchKernelGGL(uniform_kernel, dim3(scae_noise::blocks_for(n)), dim3(scae_noise::NT), 0,
                      (hipStream_t)stream, out, n, state);
   return scae_launch_status();
 }

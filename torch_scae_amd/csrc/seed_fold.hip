@@ -8,105 +8,25 @@
 // which only depend on parameters.  With W2e = [W2 | b2] (C x (D+1)) these are
 // three "C x C times C x (D+1)" products, a few MFLOP -- but as a chain of
 // library GEMM / GEMV / add launches (and twice as many in the backward pass)
-// they cost more than the attention itself.  Here: two launches forward, two
-// backward.
-//   fwd stage 1: row blocks of Wk, Wv (NT/(D+1) rows per workgroup, W2e in LDS, a thread per
-//         (row, column)): [wkf|bkf], wv2e = Wv W2e + [0|bv]; one workgroup per column c of q
-//   fwd stage 2: row blocks of Wo: [wvf|bvf] = Wo wv2e + [0|bo]
+// they cost more than the attention itself.  Here: one launch forward (seed_fold_dev.h; the
+// same jobs can ride in the training step's prologue launch, step_prologue.hip), two backward.
+//   fwd: row blocks of Wk, Wv (NT/(D+1) rows per workgroup, W2e in LDS, a thread per
+//         (row, column)): [wkf|bkf], wv2e = Wv W2e + [0|bv]; row blocks of Wo:
+//         [wvf|bvf] = (Wo Wv) W2e + [0 | Wo bv + bo]; column blocks of q
 //   bwdA: column jobs, one workgroup per output column, threads over j:
 //         gv2e = Wo^T [g_wvf|g_bvf],  t1 = Wk^T [g_wkf|g_bkf],  d_seeds = g_q Wq
 //   bwdB: row jobs (outer products, K = O or D+1): d_Wq, d_Wk, d_Wo, d_Wv and
 //         the four bias gradients; column jobs: [d_W2|d_b2] = t1 + Wv^T gv2e
 #include "common.h"
+#include "seed_fold_dev.h"
 
 namespace {
 constexpr int NT = 256;
 
-// Row-block job: out[r][d] = sum_j W[row0 + r][j] * ext[j][d] for R = NT / (D+1) rows
-// and all D+1 columns at once.  ext (C x (D+1)) and the R rows sit in LDS; thread
-// (r, d) keeps its own sum -- no cross-lane reduction (the earlier one-workgroup-per-
-// row version spent its time wave-reducing 34 partial sums per thread).
-template <int D, class Store>
-__device__ __forceinline__ void rows_block(const float *W, int C, const float *mat, int mat_ld,
-                                           const float *col, int row0, float *lds, Store store) {
-  constexpr int DP = D + 1, R = NT / DP;
-  const int t = threadIdx.x, nrows = min(R, C - row0);
-  float *ext = lds, *rows = lds + C * DP;
-  for (int e = t; e < C * DP; e += NT) {
-    const int jj = e / DP, d = e - jj * DP;
-    ext[e] = d < D ? mat[(size_t)jj * mat_ld + d] : (col ? col[jj] : mat[(size_t)jj * mat_ld + D]);
-  }
-  {
-    const float4 *src = reinterpret_cast<const float4 *>(W + (size_t)row0 * C);  // C % 64 == 0
-    for (int e = t; e < nrows * C / 4; e += NT) reinterpret_cast<float4 *>(rows)[e] = src[e];
-  }
-  __syncthreads();
-  if (t >= nrows * DP) return;
-  const int r = t / DP, d = t - r * DP;
-  const float *wr = rows + r * C;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int jj = 0; jj < C; jj += 4) {  // C % 64 == 0
-    const float4 w = *reinterpret_cast<const float4 *>(wr + jj);
-    a0 = fmaf(w.x, ext[(jj + 0) * DP + d], a0);
-    a1 = fmaf(w.y, ext[(jj + 1) * DP + d], a1);
-    a2 = fmaf(w.z, ext[(jj + 2) * DP + d], a2);
-    a3 = fmaf(w.w, ext[(jj + 3) * DP + d], a3);
-  }
-  store(row0 + r, d, (a0 + a1) + (a2 + a3));
-}
-
-// stage 1: blocks [0, nb): rows of Wk -> [wkf | bkf]; [nb, 2 nb): rows of Wv -> wv2e
-// (+ [0 | bv]); then one block per column c of q = seeds Wq^T + bq.
-// stage 2: blocks [0, nb): rows of Wo against wv2e -> [wvf | bvf].
 template <int D>
-__global__ __launch_bounds__(NT) void fold_fwd_kernel(scae_seed_fold_desc a, int stage, int nb) {
+__global__ __launch_bounds__(NT) void fold_fwd_kernel(scae_seed_fold_desc a, scae_fold::Plan pl) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int DP = D + 1, R = NT / DP;
-  const int t = threadIdx.x, C = a.C, blk = blockIdx.x;
-  if (stage == 2) {
-    rows_block<D>(a.wo, C, a.wv2e, DP, nullptr, blk * R, lds, [&](int c, int d, float s) {
-      if (d < D)
-        a.wvf[c * D + d] = s;
-      else
-        a.bvf[c] = s + a.bo[c];
-    });
-    return;
-  }
-  if (blk < nb) {
-    rows_block<D>(a.wk, C, a.w2, D, a.b2, blk * R, lds, [&](int c, int d, float s) {
-      if (d < D)
-        a.wkf[c * D + d] = s;
-      else
-        a.bkf[c] = s + a.bk[c];
-    });
-    return;
-  }
-  if (blk < 2 * nb) {
-    rows_block<D>(a.wv, C, a.w2, D, a.b2, (blk - nb) * R, lds, [&](int c, int d, float s) {
-      a.wv2e[c * DP + d] = d < D ? s : s + a.bv[c];
-    });
-    return;
-  }
-  // q[:, c] = seeds Wq[c, :]^T + bq[c]: 8 lanes per seed o, each an 8-strided
-  // slice of j, so that all loads of the dot product are in flight at once
-  const int c = blk - 2 * nb;
-  const float *wq = a.wq + (size_t)c * C;
-  const int sub = t & 7;
-  for (int o = t >> 3; o < a.O; o += NT / 8) {
-    const float *sd = a.seeds + (size_t)o * C;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-    for (int jj = sub; jj < C; jj += 32) {  // C % 64 == 0
-      p0 = fmaf(wq[jj], sd[jj], p0);
-      p1 = fmaf(wq[jj + 8], sd[jj + 8], p1);
-      p2 = fmaf(wq[jj + 16], sd[jj + 16], p2);
-      p3 = fmaf(wq[jj + 24], sd[jj + 24], p3);
-    }
-    float rr = (p0 + p1) + (p2 + p3);
-    rr += __shfl_xor(rr, 1, 64);
-    rr += __shfl_xor(rr, 2, 64);
-    rr += __shfl_xor(rr, 4, 64);
-    if (sub == 0) a.q[(size_t)o * C + c] = rr + a.bq[c];
-  }
+  scae_fold::forward_block<D>(a, pl, blockIdx.x, lds);
 }
 
 // Column job: out[j] = sum_c W[c][j] * g(c).  Workgroup (C, parts): thread
@@ -229,27 +149,23 @@ int check(const scae_seed_fold_desc *a) {
 extern "C" int scae_seed_fold_supported(int O, int C, int D) {
   if (!(O > 0 && O <= 64 && C >= 64 && C % 64 == 0 && C <= 1024 && (D == 8 || D == 16 || D == 32)))
     return 0;
-  // LDS of a forward row block: ext (C x (D+1)) + NT / (D+1) rows of C floats
-  return ((size_t)C * (D + 1) + (size_t)(NT / (D + 1)) * C) * sizeof(float) <= 160 * 1024;
+  return scae_fold::lds_bytes(C, D) <= 160 * 1024;
 }
 
 extern "C" int scae_seed_fold_fwd_f32(const scae_seed_fold_desc *desc, void *stream) {
   int rc = check(desc);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const scae_fold::Plan pl = scae_fold::plan(desc->C, desc->D);
+  const size_t lds = scae_fold::lds_bytes(desc->C, desc->D);
 #define SCAE_FOLD_FWD(DD)                                                                  \
   case DD: {                                                                               \
-    constexpr int R = NT / (DD + 1);                                                       \
-    const int nb = (desc->C + R - 1) / R;                                                  \
-    const size_t lds = ((size_t)desc->C * (DD + 1) + (size_t)R * desc->C) * sizeof(float); \
     if (lds > 48 * 1024) {                                                                 \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fold_fwd_kernel<DD>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                  \
     }                                                                                      \
-    hipLaunchKernelGGL(fold_fwd_kernel<DD>, dim3(2 * nb + desc->C), dim3(NT), lds, st, *desc, 1, \
-                       nb);                                                                \
-    hipLaunchKernelGGL(fold_fwd_kernel<DD>, dim3(nb), dim3(NT), lds, st, *desc, 2, nb);    \
+    hipLaunchKernelGGL(fold_fwd_kernel<DD>, dim3(pl.blocks()), dim3(NT), lds, st, *desc, pl); \
   } break;
   switch (desc->D) {
     SCAE_FOLD_FWD(8) SCAE_FOLD_FWD(16) SCAE_FOLD_FWD(32)

@@ -111,6 +111,71 @@ def _prec(name):
     return name.replace("_f32", "_bf16") if _MFMA_BF16 else name
 
 
+class StepPrologue:
+    """Buffers of a training step's prologue launch (csrc/step_prologue.hip):
+    the step's noise draws and the folded output-attention weights live in
+    persistent tensors that ONE launch ahead of the step fills -- together with
+    the batch hand-over -- instead of a launch each inside it.
+
+    Inside ``with step_prologue(pro):`` the first ``uniform`` / ``seed_fold``
+    call allocates its persistent outputs and launches as usual; from then on
+    ``pro.launch(...)`` refreshes them and the calls return the buffers without
+    launching (until they have been consumed once: a second forward without a
+    new ``launch`` computes its own)."""
+
+    def __init__(self):
+        self.noise = self.noise_state = None
+        self.fold_inputs = self.fold_outs = self.fold_dims = None
+        self.noise_fresh = self.fold_fresh = False
+
+    def launch(self, dst_image=None, src_image=None, dst_label=None,
+               src_label=None, stream_ref=None):
+        """One launch: batch hand-over (when the four tensors are given) +
+        whatever of noise / folding this prologue has buffers for."""
+        stage = dst_image is not None
+        n_noise = 0 if self.noise is None else self.noise.numel()
+        if not (stage or n_noise or self.fold_outs is not None):
+            return
+        ref = dst_image if stage else (
+            self.noise if n_noise else self.fold_outs[0])
+        _need_hip(ref)
+        P = ctypes.c_void_p
+        desc = None
+        if self.fold_outs is not None:
+            desc = ctypes.byref(_fold_desc(self.fold_inputs, self.fold_outs,
+                                           *self.fold_dims))
+        _lib.call("scae_step_prologue_f32",
+                  _p(dst_image), _p(src_image),
+                  dst_image.numel() if stage else 0,
+                  P(dst_label.data_ptr()) if stage else None,
+                  P(src_label.data_ptr()) if stage else None,
+                  dst_label.numel() if stage else 0,
+                  _p(self.noise), n_noise, _p(self.noise_state), desc,
+                  _stream(ref))
+        self.noise_fresh = self.noise is not None
+        self.fold_fresh = self.fold_outs is not None
+
+
+_PROLOGUE = None
+
+
+class step_prologue:
+    """``with step_prologue(pro):`` -- see ``StepPrologue`` (``pro`` None: no-op)."""
+
+    def __init__(self, pro):
+        self.pro = pro
+
+    def __enter__(self):
+        global _PROLOGUE
+        self.prev, _PROLOGUE = _PROLOGUE, self.pro
+        return self.pro
+
+    def __exit__(self, *exc):
+        global _PROLOGUE
+        _PROLOGUE = self.prev
+        return False
+
+
 def reset_noise():
     """Restart the device noise generators from ``torch.initial_seed()`` (call
     after ``torch.manual_seed`` to replay a noise sequence; not inside a graph
@@ -131,7 +196,18 @@ def uniform(n, ref):
                          not torch.cuda.is_current_stream_capturing()):
         state = _NOISE_STATE[key] = (seed, torch.tensor(
             [seed, 0, 0], dtype=torch.int64).to(ref.device))
-    out = torch.empty(int(n), device=ref.device, dtype=torch.float32)
+    pro = _PROLOGUE
+    if pro is not None:
+        if pro.noise is not None and pro.noise.numel() == int(n) \
+                and pro.noise_state is state[1] and pro.noise_fresh:
+            pro.noise_fresh = False     # drawn by the step's prologue launch
+            return pro.noise
+        # (re-)establish the persistent buffer; this draw is launched here
+        pro.noise = torch.empty(int(n), device=ref.device, dtype=torch.float32)
+        pro.noise_state, pro.noise_fresh = state[1], False
+        out = pro.noise
+    else:
+        out = torch.empty(int(n), device=ref.device, dtype=torch.float32)
     _lib.call("scae_uniform_f32", _p(out), int(n), _p(state[1]), _stream(ref))
     return out
 
@@ -588,11 +664,30 @@ class _SeedFold(torch.autograd.Function):
         D = w2.shape[1]
         new = lambda *shape: torch.empty(*shape, device=seeds.device,
                                          dtype=seeds.dtype)
-        outs = (new(O, C), new(C, D), new(C), new(C, D), new(C), new(C, D + 1))
-        desc = _fold_desc(inputs, outs, O, C, D)
-        _lib.call("scae_seed_fold_fwd_f32", ctypes.byref(desc), _stream(seeds))
+        pro, launch = _PROLOGUE, True
+        if pro is not None:
+            ptrs = [t.data_ptr() for t in inputs]
+            if pro.fold_outs is not None and pro.fold_dims == (O, C, D) and \
+                    [t.data_ptr() for t in pro.fold_inputs] == ptrs:
+                # persistent outputs: filled by the step's prologue launch
+                # (fresh), else by the launch below
+                outs, launch = pro.fold_outs, not pro.fold_fresh
+            else:
+                outs = (new(O, C), new(C, D), new(C), new(C, D), new(C),
+                        new(C, D + 1))
+                pro.fold_inputs, pro.fold_outs, pro.fold_dims = \
+                    inputs, outs, (O, C, D)
+            pro.fold_fresh = False
+        else:
+            outs = (new(O, C), new(C, D), new(C), new(C, D), new(C),
+                    new(C, D + 1))
+        if launch:
+            desc = _fold_desc(inputs, outs, O, C, D)
+            _lib.call("scae_seed_fold_fwd_f32", ctypes.byref(desc),
+                      _stream(seeds))
         ctx.save_for_backward(*inputs, *outs)
-        return outs[:5]
+        return tuple(t.view_as(t) for t in outs[:5]) if pro is not None \
+            else outs[:5]
 
     @staticmethod
     def backward(ctx, g_q, g_wkf, g_bkf, g_wvf, g_bvf):

@@ -41,7 +41,8 @@ class TrainStep:
     def __init__(self, model, batch_size, image_shape, lr=3e-5, use_graph=True,
                  optimizer=True, momentum=0.9, weight_decay=0.0,
                  lr_decay_rate=0.997, autocast_dtype=None,
-                 force_collective=False, overlap=True, lazy_render=True):
+                 force_collective=False, overlap=True, lazy_render=True,
+                 prologue=True):
         self.model = model
         self.device = next(model.parameters()).device
         self.world = world()[1]
@@ -65,6 +66,10 @@ class TrainStep:
         dec = getattr(model, "part_decoder", None)
         if lazy_render and hasattr(dec, "lazy_render"):
             dec.lazy_render = True
+        # the step's noise draws and parameter-only folding products ride with
+        # the batch hand-over in ONE launch ahead of the step (ops.StepPrologue)
+        self._pro = ops.StepPrologue() if prologue and \
+            self.device.type == "cuda" else None
         self.collective_mode = None if not self.collective else \
             "in graph" if self.in_graph_collective else \
             "2 buckets, the first overlapping the encoder backward" \
@@ -102,7 +107,8 @@ class TrainStep:
     def _part_a(self):
         """forward + loss + backward (split: down to the decoders' inputs)."""
         self.flat.clear_grads()
-        with ops.mfma_bf16(self.autocast_dtype is not None):
+        with ops.mfma_bf16(self.autocast_dtype is not None), \
+                ops.step_prologue(self._pro):
             res = self.model(self.image)
             loss, info = self.model.loss(res, self.image, self.label)
             # a resident seed: no ones_like fill per step; the column sums that
@@ -183,7 +189,9 @@ class TrainStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(3):
+                self._refresh_prologue()
                 self._fwd_bwd()
+            self._refresh_prologue()    # what the capture below consumes
         torch.cuda.current_stream().wait_stream(s)
         # capture on the SAME stream the warm-up ran on: autograd caches each
         # parameter's AccumulateGrad node together with its stream
@@ -205,9 +213,29 @@ class TrainStep:
                 self._part_b()
         self._capturing = False
 
+    def _refresh_prologue(self):
+        """Noise + folding products for the next forward (no batch)."""
+        if self._pro is not None:
+            self._pro.launch(stream_ref=self.image)
+
     def _stage(self, image, label):
         """The batch into the resident input buffers: one launch when both
-        tensors already live on the device in the buffers' layout."""
+        tensors already live on the device in the buffers' layout -- the
+        step's prologue launch when there is one."""
+        direct = image.is_cuda and label.is_cuda \
+            and image.dtype == self.image.dtype \
+            and label.dtype == self.label.dtype and image.is_contiguous() \
+            and label.is_contiguous() and image.shape == self.image.shape \
+            and label.shape == self.label.shape \
+            and image.device == self.device == label.device
+        if self._pro is not None:
+            if direct:
+                self._pro.launch(self.image, image, self.label, label)
+            else:
+                self.image.copy_(image, non_blocking=True)
+                self.label.copy_(label, non_blocking=True)
+                self._refresh_prologue()
+            return
         if image.is_cuda and label.is_cuda and image.dtype == self.image.dtype \
                 and label.dtype == self.label.dtype and image.is_contiguous() \
                 and label.is_contiguous() and image.shape == self.image.shape \
@@ -231,6 +259,7 @@ class TrainStep:
         if self.use_graph:
             if self.graph is None:
                 self._capture()
+                self._refresh_prologue()   # the capture consumed the last one
             if self.split:
                 self._run(self.graph.replay, self.graph_b.replay)
                 if self.opt is not None:
