@@ -265,6 +265,52 @@ typedef struct scae_gemm_desc {
   float *c_nomask; /* nullable, layout of C: the values before the mask gate */
 } scae_gemm_desc;
 int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
+/* Up to 4 independent GEMMs of that kind in ONE launch (the four weight-gradient
+ * GEMMs of a capsule's MLP chain once the data-gradient chain has run). */
+int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *stream);
+
+/* ------------------------------------------------------------------------
+ * K7b a chain of up to 4 per-group layers in ONE launch -- the two ReLU MLPs
+ *     CapsuleLayer runs back to back per object capsule (object_decoder.py:
+ *     86-107 `mlps`, :137-158 `caps_mlps`, the `cat([.., caps_exist])` of :149
+ *     between them as an implicit ones column), forward and the data-gradient
+ *     half of their backward.  A workgroup carries 16 batch rows of one group
+ *     through all layers (activations in LDS, weights as MFMA fragments from L2).
+ *     in: element (b, g, k) at in[g*in_gs + b*in_bs + k], k < in_dim.
+ *   fwd: layer i: y = x W_i^T (W_i rows = N outputs, K = width of x, row
+ *     stride ldw, group stride w_gs) + bias[g*bias_gs + n*bias_ld] (nullable),
+ *     ReLU if relu; stored (nullable except for the last layer) at
+ *     out[g*out_gs + b*out_bs + n].
+ *   bwd: layer i: y = x W_i (W_i rows = the K contraction entries, N columns
+ *     used), zeroed where gate[g*gate_gs + b*gate_bs + n] <= 0 (nullable);
+ *     out as above.  Pass the layers in backward order; x of the first = the
+ *     gradient w.r.t. the last pre-activation.
+ *     Each layer's K must equal its predecessor's N (in_dim for the first);
+ *     widths <= scae_mlp_chain_max_width().
+ * ---------------------------------------------------------------------- */
+typedef struct scae_mlp_chain_layer {
+  const float *w;
+  int64_t w_gs;
+  int ldw, K, N;
+  const float *bias;
+  int64_t bias_gs;
+  int bias_ld;
+  const float *gate;
+  int64_t gate_gs, gate_bs;
+  float *out;
+  int64_t out_gs, out_bs;
+  int relu;
+} scae_mlp_chain_layer;
+typedef struct scae_mlp_chain_desc {
+  scae_mlp_chain_layer layer[4];
+  int n_layers;
+  const float *in;
+  int64_t in_gs, in_bs;
+  int in_dim, B, G;
+} scae_mlp_chain_desc;
+int scae_mlp_chain_max_width(void);
+int scae_mlp_chain_fwd_f32(const scae_mlp_chain_desc *desc, void *stream);
+int scae_mlp_chain_bwd_f32(const scae_mlp_chain_desc *desc, void *stream);
 
 /* bf16-operand forms of the GEMM-shaped launchers (BASELINE.json configs[2], "bs=1024
  * bf16"): same arguments, same fp32 tensors in memory; the operands are rounded to bf16

@@ -1546,6 +1546,85 @@ def test_stage_batch_one_launch():
         assert torch.equal(di, image) and torch.equal(dl, label)
 
 
+@pytest.mark.parametrize("B,G,Kin,dims,ones_at", [
+    (128, 24, 256, [128, 32, 128, 199], 2),    # cfg-2's capsule MLPs
+    (37, 3, 50, [37, 12, 29, 45], 2),          # ragged everything, scalar weight loads
+    (16, 2, 64, [8, 4, 8, 31], 2),             # the smoke model's widths
+    (70, 5, 96, [64, 40], None),               # a two-layer chain, no ones column
+])
+def test_mlp_chain_vs_fp64(B, G, Kin, dims, ones_at):
+    """K7b (object_decoder.py:86-107, :137-158, the cat with caps_exist of
+    :149): all layers of the per-capsule MLP chain in one launch, and its
+    backward (data-gradient chain + one weight-gradient launch), against fp64
+    algebra; bar 1e-4 relative to each tensor's largest entry."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(B + G + Kin)
+    layers, K = [], Kin
+    for l, N in enumerate(dims):
+        ones = ones_at is not None and l == ones_at
+        w = torch.randn(G, N, K + (1 if ones else 0), generator=g) / K ** 0.5
+        b = None if (ones_at is not None and l >= ones_at) \
+            else torch.randn(G, N, generator=g) * 0.1
+        layers.append((w, b, ones))
+        K = N
+    x = torch.randn(B, G, Kin, generator=g)
+    R = torch.randn(B, G, dims[-1], generator=g)
+
+    def ref(x, layers):
+        h, near = x.transpose(0, 1), None                  # (G, B, K)
+        for w, b, ones in layers:
+            if ones:
+                h = torch.cat([h, torch.ones_like(h[..., :1])], -1)
+            h = torch.bmm(h, w.transpose(1, 2))
+            if b is not None:
+                h = h + b.unsqueeze(1)
+            # ReLU gates within fp32 round-off of zero: their (b, g) rows are
+            # taken out of the gradient comparison (either gate is a valid fp32
+            # evaluation)
+            n = (h.detach().abs() < 1e-5 * float(h.detach().abs().max())).any(-1)
+            near = n if near is None else near | n
+            h = torch.relu(h)
+        return h.transpose(0, 1), near.transpose(0, 1)
+
+    xr = x.double().requires_grad_()
+    lr = [(w.double().requires_grad_(),
+           None if b is None else b.double().requires_grad_(), o)
+          for w, b, o in layers]
+    yr, near = ref(xr, lr)
+    assert float(near.float().mean()) < 0.2
+    R = R * (~near).unsqueeze(-1)
+    (yr * R.double()).sum().backward()
+
+    xh = x.cuda().requires_grad_()
+    lh = [(w.cuda().requires_grad_(),
+           None if b is None else b.cuda().requires_grad_(), o)
+          for w, b, o in layers]
+    assert ops.mlp_chain_supported(xh, lh)
+    yh = ops.mlp_chain(xh, lh)
+    assert yh.shape == (B, G, dims[-1])
+    assert_close(yh, yr.float(), rtol=1e-4,
+                 atol=1e-4 * float(yr.abs().max()), what="y")
+    # the consumer's contract: gradient w.r.t. the last PRE-activation
+    yh.backward(R.cuda() * (yh.detach() > 0))
+    assert_close(xh.grad, xr.grad.float(), rtol=1e-4,
+                 atol=1e-4 * float(xr.grad.abs().max()), what="gx")
+    for l, ((wh, bh, _), (wr, br, _)) in enumerate(zip(lh, lr)):
+        assert_close(wh.grad, wr.grad.float(), rtol=1e-4,
+                     atol=1e-4 * float(wr.grad.abs().max()), what=f"gw{l}")
+        if bh is not None:
+            assert_close(bh.grad, br.grad.float(), rtol=1e-4,
+                         atol=1e-4 * float(br.grad.abs().max()), what=f"gb{l}")
+    # and it is the same function as the layer-by-layer GEMM path
+    if ones_at == 2 and len(dims) == 4:
+        x2 = x.cuda()
+        h = ops.grouped_mlp(x2, [w.cuda() for w, _, _ in layers[:2]],
+                            [b.cuda() for _, b, _ in layers[:2]])
+        y2 = ops.grouped_mlp(h, [w.cuda() for w, _, _ in layers[2:]], None,
+                             ones_input=True)
+        assert_close(yh, y2, rtol=1e-5, atol=1e-5 * float(yr.abs().max()),
+                     what="vs K7")
+
+
 def test_step_prologue_matches_the_three_launches():
     """scae_step_prologue_f32 = scae_stage_batch + scae_uniform_f32 +
     scae_seed_fold_fwd_f32 in one launch: bit-identical outputs, and the noise

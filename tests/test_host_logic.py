@@ -51,6 +51,13 @@ def test_launchers_reject_bad_arguments_without_a_gpu():
                                       None, None, None) == -1
     assert lib.scae_step_prologue_f32(None, None, 0, None, None, 0, None, 0,
                                       None, None, None) == -1   # nothing to do
+    assert lib.scae_gemm_multi_f32(None, 2, None) == -1
+    assert lib.scae_gemm_multi_f32((_lib.GemmDesc * 5)(), 5, None) == -1   # > 4
+    chain = _lib.MlpChainDesc()
+    assert lib.scae_mlp_chain_fwd_f32(None, None) == -1
+    assert lib.scae_mlp_chain_fwd_f32(chain, None) == -1          # no input, no layers
+    assert lib.scae_mlp_chain_bwd_f32(chain, None) == -1
+    assert lib.scae_mlp_chain_max_width() >= 512
     assert lib.scae_conv3x3_bwd_pair_f32(None, None, None, None, None, 2, 9, 9,
                                          64, 64, 1, None) == -1
     assert lib.scae_conv3x3_first_fwd_relayout_f32(

@@ -40,6 +40,22 @@ class GemmDesc(Structure):
                 ("relu", c_int), ("asum_ld", c_int), ("c_nomask", P)]
 
 
+class MlpChainLayer(Structure):
+    """struct scae_mlp_chain_layer"""
+    _fields_ = [("w", P), ("w_gs", c_int64), ("ldw", c_int), ("K", c_int),
+                ("N", c_int), ("bias", P), ("bias_gs", c_int64),
+                ("bias_ld", c_int), ("gate", P), ("gate_gs", c_int64),
+                ("gate_bs", c_int64), ("out", P), ("out_gs", c_int64),
+                ("out_bs", c_int64), ("relu", c_int)]
+
+
+class MlpChainDesc(Structure):
+    """struct scae_mlp_chain_desc"""
+    _fields_ = [("layer", MlpChainLayer * 4), ("n_layers", c_int), ("in_", P),
+                ("in_gs", c_int64), ("in_bs", c_int64), ("in_dim", c_int),
+                ("B", c_int), ("G", c_int)]
+
+
 class SumSegment(Structure):
     """struct scae_sum_segment"""
     _fields_ = [("dst", P), ("begin", c_int64), ("end", c_int64),
@@ -122,6 +138,10 @@ SIGNATURES = {
                                               c_int, c_int64, c_int64, c_int, c_int,
                                               P],
     "scae_gemm_pair_f32": [POINTER(GemmDesc), POINTER(GemmDesc), P],
+    "scae_gemm_multi_f32": [POINTER(GemmDesc), c_int, P],
+    "scae_mlp_chain_max_width": [],
+    "scae_mlp_chain_fwd_f32": [POINTER(MlpChainDesc), P],
+    "scae_mlp_chain_bwd_f32": [POINTER(MlpChainDesc), P],
     "scae_gemm_pair_bf16": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_relayout_batch_f32": [c_int, P, P, P, P, P, P],

@@ -165,6 +165,26 @@ __global__ __launch_bounds__(NT) void gemm_pair_kernel(GemmPair p) {
   }
 }
 
+// Up to four independent problems in one launch (blockIdx.z picks the problem).
+struct GemmMulti {
+  GemmArgs g[4];
+  int zend[4], layout[4], n;   // zend: exclusive prefix sums of the batch counts
+};
+template <int SK>
+__global__ __launch_bounds__(NT) void gemm_multi_kernel(GemmMulti p) {
+  __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
+  int which = 0;
+  while (which + 1 < p.n && (int)blockIdx.z >= p.zend[which]) ++which;
+  const int z = blockIdx.z - (which ? p.zend[which - 1] : 0);
+  const GemmArgs &g = p.g[which];
+  switch (p.layout[which]) {  // workgroup-uniform
+    case 3: gemm_tile<SK, true, true>(g, smem, z); break;
+    case 2: gemm_tile<SK, true, false>(g, smem, z); break;
+    case 1: gemm_tile<SK, false, true>(g, smem, z); break;
+    default: gemm_tile<SK, false, false>(g, smem, z); break;
+  }
+}
+
 // fewer 64 x 64 tiles than this: 32 x 32 split-K tiles (4x the workgroups)
 #ifndef SCAE_GEMM_SK_BELOW
 #define SCAE_GEMM_SK_BELOW 1024
@@ -282,4 +302,29 @@ extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_d
 extern "C" int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_desc *second,
                                    void *stream) {
   return gemm_pair_impl(first, second, true, stream);
+}
+
+extern "C" int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *stream) {
+  SCAE_REQUIRE(descs && n >= 1 && n <= 4);
+  GemmMulti p{};
+  p.n = n;
+  int M = 0, N = 0, nz = 0;
+  long tiles64 = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = fill_args(p.g[i], descs + i);
+    if (rc) return rc;
+    p.layout[i] = 2 * (descs[i].a_kcontig != 0) + (descs[i].b_kcontig != 0);
+    nz += descs[i].batch;
+    p.zend[i] = nz;
+    M = M > descs[i].M ? M : descs[i].M;
+    N = N > descs[i].N ? N : descs[i].N;
+    tiles64 += (long)((descs[i].N + 63) / 64) * ((descs[i].M + 63) / 64) * descs[i].batch;
+  }
+  if (tiles64 < kSplitKBelow)
+    hipLaunchKernelGGL(gemm_multi_kernel<1>, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(NT), 0,
+                       (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(gemm_multi_kernel<0>, dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(NT), 0,
+                       (hipStream_t)stream, p);
+  return scae_launch_status();
 }

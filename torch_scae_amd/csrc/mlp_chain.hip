@@ -1,0 +1,303 @@
+// K7b -- a chain of per-group MLP layers in ONE launch, gfx950.
+//
+// CapsuleLayer (object_decoder.py:86-107, :137-158) runs, per object capsule, two small
+// ReLU MLPs back to back (feature -> hidden -> capsule parameters -> hidden -> vote
+// parameters; the reference: a Python loop of 4*O nn.Linear calls).  As four batched
+// GEMM launches (K7, gemm_mfma.hip) the chain costs four dependent-dispatch floors and
+// three round trips of the hidden activations through L2 for ~0.4 GFLOP; here a
+// workgroup carries 16 batch rows of ONE group through all the layers:
+//   * the 16 x K activation block lives in LDS (two ping-pong buffers); each weight element
+//     is used exactly once per workgroup: it is loaded coalesced, parked in registers, and
+//     passes through a wave-private LDS tile on its way to the MFMA fragment;
+//   * v_mfma_f32_16x16x4_f32 (exact fp32 products): wave w (of 8) owns the 16-column output
+//     tiles w, w + 8, ...; lane (r, q) reads A[r][k0 + 4q .. + 3] as one ds_read_b128 and the
+//     matching four k of its weight row / column -- which four k an instruction contracts
+//     is free as long as A and B agree;
+//   * the weights of the next (tile, 128-wide k-chunk) item are in flight while the current
+//     one is multiplied, across layer boundaries too, and 8 waves per workgroup cover each
+//     other's waits;
+//   * every layer's output is written once to global memory (the backward pass needs the
+//     ReLU outputs; the data-gradient form needs the pre-activation gradients for the
+//     weight-gradient GEMMs) and kept in LDS for the next layer.
+// The same kernel runs the data-gradient chain of the backward pass: layer l then
+// contracts over the rows of W_l (g_prev = gate(g W_l)), the gate being the ReLU output
+// saved by the forward pass.
+#include "common.h"
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NW = 8, NT = 64 * NW, RB = 16, MAXL = 4, CH = 8;
+constexpr int WLD = 128 + 4;   // row stride of a wave's weight tile: (WLD / 4) odd
+
+struct Layer {
+  const float *w;
+  long w_gs;
+  int ldw, K, N;   // K: contraction length, N: output columns
+  const float *bias;
+  long bias_gs;
+  int bias_ld;
+  const float *gate;
+  long gate_gs, gate_bs;
+  float *out;
+  long out_gs, out_bs;
+  int relu, vec;   // vec: 16-byte weight loads are legal (forward form)
+};
+struct Chain {
+  Layer l[MAXL];
+  const float *in;
+  long in_gs, in_bs;
+  int n, in_dim, B, G, stride;   // stride: floats per LDS activation row
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ f32x4 mma16(f32x4 acc, float4 a, float4 b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  return acc;
+}
+
+// guarded element: an unconditional load from a clamped address, zero when out of range
+// (no divergent branch around the load)
+__device__ __forceinline__ float ldg(const float *base, size_t idx, bool ok) {
+  const float v = base[ok ? idx : 0];
+  return ok ? v : 0.f;
+}
+
+// Weights + epilogue operands of the item (tile, chunk) of layer L: global -> registers,
+// piece i of an item is ONE coalesced wave instruction --
+//   forward:        lane = (row 2i + (lane >> 5), k quad lane & 31)    [2 rows x 512 B]
+//   data gradient:  lane = (k 16i + (lane >> 2), column quad lane & 3)  [16 rows x 64 B]
+// (row-per-lane fragment loads straight from global memory cost the vector L1 one access
+// per lane: 57 per instruction, measured).  No element guards: the loads go through a
+// buffer descriptor that covers the group's weight matrix -- a lane past its end reads
+// zeros -- and what a ragged tile picks up INSIDE the matrix (the next row's head behind a
+// short row, columns past N) only ever multiplies the zero padding of the activation
+// block or lands in output columns the epilogue masks.  With the tile's last chunk come
+// its bias (forward) / its four gate values (data gradient).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bload4(rsrc_t rs, int byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                     __uint_as_float(v.w));
+}
+template <bool BWD>
+__device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g, int b0, int B,
+                                           int tile, int ch, int nch, int lane, float4 (&buf)[CH],
+                                           float4 &epi) {
+  const int n0 = 16 * tile, k0 = 128 * ch, ldw = L.ldw, LN = L.N;
+  // rows of the matrix: N (forward) / K (data gradient)
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(W), 0, (BWD ? L.K : L.N) * ldw * 4, 0x00020000);
+  if (!BWD) {
+    const int o = ((n0 + (lane >> 5)) * ldw + k0 + 4 * (lane & 31)) * 4;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) buf[i] = bload4(rs, o + 2 * i * ldw * 4);
+  } else {
+    const int o = ((k0 + (lane >> 2)) * ldw + n0 + 4 * (lane & 3)) * 4;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) buf[i] = bload4(rs, o + 16 * i * ldw * 4);
+  }
+  if (ch == nch - 1) {
+    const int r = lane & 15, q = lane >> 4, col = n0 + r;
+    const bool cok = col < LN;
+    if (!BWD) {
+      epi.x = L.bias ? ldg(L.bias + (size_t)g * L.bias_gs, (size_t)col * L.bias_ld, cok) : 0.f;
+    } else {
+      epi = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (L.gate) {
+        const float *gp = L.gate + (size_t)g * L.gate_gs;
+        const int b = b0 + 4 * q;
+        epi.x = ldg(gp, (size_t)b * L.gate_bs + col, cok && b < B);
+        epi.y = ldg(gp, (size_t)(b + 1) * L.gate_bs + col, cok && b + 1 < B);
+        epi.z = ldg(gp, (size_t)(b + 2) * L.gate_bs + col, cok && b + 2 < B);
+        epi.w = ldg(gp, (size_t)(b + 3) * L.gate_bs + col, cok && b + 3 < B);
+      }
+    }
+  }
+}
+
+// BWD = false: out[b][n] = epi(sum_k in[b][k] W[n][k])      (W rows = outputs)
+// BWD = true:  out[b][n] = gate(sum_k in[b][k] W[k][n])     (W rows = contraction)
+//
+// The layer loop is unrolled (MAXL = 4 copies with the layer's fields in scalar registers
+// -- an earlier form that walked a run-time (layer, item) cursor spent ~500 instructions of
+// selects and divisions per 32-MFMA item).  A wave's items of a layer are its tiles x
+// 128-wide k-chunks; the weights of the next item -- the first item of the next layer at
+// the end of a layer: weights do not depend on activations -- are in flight while the
+// current one is multiplied, and pass through a wave-private LDS tile [16][128 + 4] on
+// their way to the MFMA fragments (transposed on the way in for the data-gradient form).
+// One workgroup barrier per layer boundary separates the writes of a layer's output from
+// its reads.
+template <bool BWD>
+__global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63,
+            r = lane & 15, q = lane >> 4;
+  const int g = blockIdx.x % c.G, b0 = (blockIdx.x / c.G) * RB;
+  float *wtile = smem + 2 * RB * c.stride + wid * (16 * WLD);   // this wave's weight tile
+  // registers -> the wave's LDS tile [16 columns][128 k (+4)]
+  auto park = [&](const float4 (&buf)[CH]) {
+    if (!BWD) {
+      float *d = wtile + (lane >> 5) * WLD + 4 * (lane & 31);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) *reinterpret_cast<float4 *>(d + 2 * i * WLD) = buf[i];
+    } else {   // transposed: (k, 4 columns) -> [column][k]; banks 16 cq + 4 j + k: distinct
+      float *d = wtile + 4 * (lane & 3) * WLD + (lane >> 2);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        d[16 * i] = buf[i].x;
+        d[WLD + 16 * i] = buf[i].y;
+        d[2 * WLD + 16 * i] = buf[i].z;
+        d[3 * WLD + 16 * i] = buf[i].w;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own tile
+  };
+  auto ntiles_of = [&](int li) { return (c.l[li].N + 15) >> 4; };
+  auto nch_of = [&](int li) { return (((c.l[li].K + 15) >> 4) + CH - 1) / CH; };
+
+  float4 f[CH], fe = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the first weights go out before the input block is staged
+  if (wid < ntiles_of(0))
+    fetch_item<BWD>(c.l[0], c.l[0].w + (size_t)g * c.l[0].w_gs, g, b0, c.B, wid, 0, nch_of(0), lane,
+                    f, fe);
+  {  // the block's input rows, zero padded to a multiple of 16 columns / to 16 rows; eight
+     // independent loads per thread in flight (a load-store loop pays a memory round trip
+     // per iteration)
+    const int k16 = (c.in_dim + 15) & ~15, total = RB * k16;
+    const float *src = c.in + (size_t)g * c.in_gs;
+    for (int e0 = tid; e0 < total; e0 += 8 * NT) {
+      float v[8];
+      int at[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * NT, row = e / k16, k = e - row * k16, b = b0 + row;
+        at[j] = row * c.stride + k;
+        v[j] = ldg(src, (size_t)b * c.in_bs + k, e < total && b < c.B && k < c.in_dim);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (e0 + j * NT < total) smem[at[j]] = v[j];
+    }
+  }
+#pragma unroll
+  for (int li = 0; li < MAXL; ++li) {
+    if (li < c.n) {   // (uniform; li is a compile-time constant in each copy)
+      const Layer &L = c.l[li];
+      const float *W = L.w + (size_t)g * L.w_gs;
+      const int nch = nch_of(li), ntiles = ntiles_of(li), nsteps = (L.K + 15) >> 4;
+      const bool last = li + 1 == c.n;
+      const float *cur = smem + (li & 1) * RB * c.stride;
+      float *nxt = smem + ((li + 1) & 1) * RB * c.stride;
+      float *out = L.out ? L.out + (size_t)g * L.out_gs : nullptr;
+      __syncthreads();   // the layer's input block is complete
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int tile = wid; tile < ntiles; tile += NW) {
+        for (int ch = 0; ch < nch; ++ch) {
+          park(f);   // (waits for the item's loads)
+          const float4 epi = fe;
+          // the next item's loads fly while this one is multiplied
+          if (ch + 1 < nch) {
+            fetch_item<BWD>(L, W, g, b0, c.B, tile, ch + 1, nch, lane, f, fe);
+          } else if (tile + NW < ntiles) {
+            fetch_item<BWD>(L, W, g, b0, c.B, tile + NW, 0, nch, lane, f, fe);
+          } else if (li + 1 < MAXL && li + 1 < c.n) {
+            const Layer &Ln = c.l[li + 1 < MAXL ? li + 1 : li];
+            if (wid < ntiles_of(li + 1 < MAXL ? li + 1 : li))
+              fetch_item<BWD>(Ln, Ln.w + (size_t)g * Ln.w_gs, g, b0, c.B, wid, 0,
+                              nch_of(li + 1 < MAXL ? li + 1 : li), lane, f, fe);
+          }
+          if (ch == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const float *arow = cur + r * c.stride + 128 * ch + 4 * q;
+          const float *brow = wtile + r * WLD + 4 * q;
+#pragma unroll
+          for (int s = 0; s < CH; ++s)
+            if (ch * CH + s < nsteps) acc = mma16(acc, ld4(arow + 16 * s), ld4(brow + 16 * s));   // uniform
+          if (ch != nch - 1) continue;
+          const int col = 16 * tile + r;
+          const bool cok = col < L.N;
+          const float bias = BWD ? 0.f : epi.x;
+          const float gt[4] = {BWD ? epi.x : 1.f, BWD ? epi.y : 1.f, BWD ? epi.z : 1.f,
+                               BWD ? epi.w : 1.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = 4 * q + e, b = b0 + row;
+            float v = acc[e] + bias;
+            if (L.relu) v = fmaxf(v, 0.f);
+            v = cok && gt[e] > 0.f ? v : 0.f;   // (also the zero padding of the next contraction)
+            if (!last) nxt[row * c.stride + col] = v;
+            if (out && cok && b < c.B) out[(size_t)b * L.out_bs + col] = v;
+          }
+        }
+      }
+      // a wave without a tile in this layer still owes the next layer its first fetch
+      if (wid >= ntiles && li + 1 < MAXL && li + 1 < c.n) {
+        const Layer &Ln = c.l[li + 1 < MAXL ? li + 1 : li];
+        if (wid < ntiles_of(li + 1 < MAXL ? li + 1 : li))
+          fetch_item<BWD>(Ln, Ln.w + (size_t)g * Ln.w_gs, g, b0, c.B, wid, 0,
+                          nch_of(li + 1 < MAXL ? li + 1 : li), lane, f, fe);
+      }
+    }
+  }
+}
+
+int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd) {
+  if (!d || !d->in || d->n_layers < 1 || d->n_layers > MAXL || d->B <= 0 || d->G <= 0 ||
+      d->in_dim <= 0)
+    return SCAE_ERR_BAD_ARG;
+  int maxdim = d->in_dim, prev = d->in_dim;
+  for (int i = 0; i < d->n_layers; ++i) {
+    const scae_mlp_chain_layer &s = d->layer[i];
+    if (!s.w || s.K <= 0 || s.N <= 0 || s.ldw <= 0) return SCAE_ERR_BAD_ARG;
+    if (s.K != prev) return SCAE_ERR_BAD_ARG;   // a layer contracts over its predecessor's width
+    if (bwd ? s.ldw < s.N : s.ldw < s.K) return SCAE_ERR_BAD_ARG;
+    if (i + 1 == d->n_layers && !s.out) return SCAE_ERR_BAD_ARG;
+    Layer &L = c.l[i];
+    L.w = s.w, L.w_gs = (long)s.w_gs, L.ldw = s.ldw, L.K = s.K, L.N = s.N;
+    L.bias = bwd ? nullptr : s.bias, L.bias_gs = (long)s.bias_gs, L.bias_ld = s.bias_ld > 0 ? s.bias_ld : 1;
+    L.gate = bwd ? s.gate : nullptr, L.gate_gs = (long)s.gate_gs, L.gate_bs = (long)s.gate_bs;
+    L.out = s.out, L.out_gs = (long)s.out_gs, L.out_bs = (long)s.out_bs;
+    L.relu = bwd ? 0 : s.relu;
+    // 16-byte weight loads: forward rows of K floats, data-gradient rows of N floats
+    L.vec = (s.ldw & 3) == 0 && (s.w_gs & 3) == 0 && ((size_t)s.w & 15) == 0;
+    maxdim = maxdim > s.N ? maxdim : s.N;
+    prev = s.N;
+  }
+  if (maxdim > scae_mlp_chain_max_width()) return SCAE_ERR_UNSUPPORTED;
+  c.in = d->in, c.in_gs = (long)d->in_gs, c.in_bs = (long)d->in_bs;
+  c.n = d->n_layers, c.in_dim = d->in_dim, c.B = d->B, c.G = d->G;
+  c.stride = ((maxdim + 15) & ~15) + 4;   // (stride / 4) odd: conflict-free b128 row reads
+  return SCAE_OK;
+}
+
+template <bool BWD>
+int launch(const scae_mlp_chain_desc *d, void *stream) {
+  Chain c{};
+  int rc = fill(c, d, BWD);
+  if (rc) return rc;
+  const size_t lds = ((size_t)2 * RB * c.stride + (size_t)NW * 16 * WLD) * sizeof(float);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<BWD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int blocks = c.G * ((c.B + RB - 1) / RB);
+  hipLaunchKernelGGL(chain_kernel<BWD>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, c);
+  return scae_launch_status();
+}
+}  // namespace
+
+// LDS: two 16-row activation blocks of the widest layer + the eight weight tiles <= 160 KiB
+extern "C" int scae_mlp_chain_max_width(void) { return 704; }
+
+extern "C" int scae_mlp_chain_fwd_f32(const scae_mlp_chain_desc *desc, void *stream) {
+  return launch<false>(desc, stream);
+}
+extern "C" int scae_mlp_chain_bwd_f32(const scae_mlp_chain_desc *desc, void *stream) {
+  return launch<true>(desc, stream);
+}

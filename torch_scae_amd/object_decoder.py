@@ -82,9 +82,16 @@ class CapsuleLayer(nn.Module):
         # on the HIP path the three stages hand each other gradients w.r.t.
         # PRE-activations (the ReLU gates ride in the GEMM / K3 epilogues)
         fused = feature.is_cuda
-        raw_caps_param = self.mlps(feature, grad_pregated=fused)  # (B, O, D)
-        all_param = self.caps_mlps(raw_caps_param, grad_pregated=fused,
-                                   x_is_relu=fused, pad_out=fused)  # (B, O, A)
+        chain = [(w, b, False) for w, b in zip(self.mlps.weights,
+                                               self.mlps.biases)] + \
+            [(w, None, j == 0) for j, w in enumerate(self.caps_mlps.weights)]
+        if fused and ops.mlp_chain_supported(feature, chain):
+            # both MLPs -- all four layers -- in one launch (K7b)
+            all_param = ops.mlp_chain(feature, chain)              # (B, O, A)
+        else:
+            raw_caps_param = self.mlps(feature, grad_pregated=fused)  # (B, O, D)
+            all_param = self.caps_mlps(raw_caps_param, grad_pregated=fused,
+                                       x_is_relu=fused, pad_out=fused)
         noise_caps = noise_vote = None
         if self.noise_type == 'uniform':
             proto = all_param.new_empty(B, self.n_caps, 1)

@@ -1416,6 +1416,159 @@ class _GroupedMLP(torch.autograd.Function):
         return (gx, None, None, None, None, None, *gws, *gbs)
 
 
+def mlp_chain_supported(x, layers):
+    """The one-launch chain (csrc/mlp_chain.hip) covers fp32, <= 4 layers,
+    widths <= scae_mlp_chain_max_width()."""
+    if _MFMA_BF16 or not x.is_cuda or x.dtype != torch.float32 or \
+            not 1 <= len(layers) <= 4:
+        return False
+    wmax = _lib.load().scae_mlp_chain_max_width()
+    return x.shape[2] <= wmax and all(
+        w.shape[1] <= wmax and w.shape[2] <= wmax + 1 and
+        not (ones and b is not None) for w, b, ones in layers)
+
+
+class _MLPChain(torch.autograd.Function):
+    """relu(W_n .. relu(W_0 x + b_0) .. + b_n) for G groups, all layers in ONE
+    launch (K7b); a layer with ``ones`` sees its input extended by a constant
+    1.0 column (object_decoder.py:149).  x (B, G, Kin); W_l (G, N_l, K_l [+1]);
+    returns (B, G, N_last) -- group rows padded to a multiple of 4 floats.
+    The consumer hands back the gradient w.r.t. the last PRE-activation
+    (``_GroupedMLP``'s ``grad_pregated`` contract); backward = one launch for
+    the data-gradient chain + one for all weight-gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, ones_flags, x_is_relu, *wb):
+        L = len(ones_flags)
+        _need_hip(x, *wb)
+        if x.stride(2) != 1:
+            x = x.contiguous()
+        weights = [w.contiguous() for w in wb[:L]]
+        biases = [None if b is None else b.contiguous() for b in wb[L:]]
+        B, G, Kin = x.shape
+        d = _lib.MlpChainDesc()
+        d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
+            L, x.data_ptr(), x.stride(1), x.stride(0), Kin, B, G
+        acts, K = [], Kin
+        for l, (w, b) in enumerate(zip(weights, biases)):
+            N, ldw = w.shape[1], w.shape[2]
+            assert ldw == K + (1 if ones_flags[l] else 0)
+            last = l == L - 1
+            if last:
+                Np = (N + 3) // 4 * 4
+                out = torch.empty(B, G, Np, device=x.device,
+                                  dtype=x.dtype)[:, :, :N]
+                out_gs, out_bs = Np, G * Np
+            else:
+                out = torch.empty(G, B, N, device=x.device, dtype=x.dtype)
+                out_gs, out_bs = B * N, N
+            y = d.layer[l]
+            y.w, y.w_gs, y.ldw, y.K, y.N = w.data_ptr(), N * ldw, ldw, K, N
+            if ones_flags[l]:          # implicit trailing 1.0 input column
+                y.bias, y.bias_gs, y.bias_ld = w.data_ptr() + 4 * K, N * ldw, ldw
+            elif b is not None:
+                y.bias, y.bias_gs, y.bias_ld = b.data_ptr(), N, 1
+            y.out, y.out_gs, y.out_bs, y.relu = out.data_ptr(), out_gs, out_bs, 1
+            acts.append(out)
+            K = N
+        _lib.call("scae_mlp_chain_fwd_f32", ctypes.byref(d), _stream(x))
+        ctx.save_for_backward(x, *weights, *acts)
+        ctx.meta = (tuple(ones_flags), [b is not None for b in biases],
+                    bool(x_is_relu))
+        ctx.slots = [_slot(t) for t in wb]
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        ones_flags, has_bias, x_is_relu = ctx.meta
+        L = len(ones_flags)
+        x = ctx.saved_tensors[0]
+        weights = ctx.saved_tensors[1:1 + L]
+        acts = ctx.saved_tensors[1 + L:]
+        B, G, Kin = x.shape
+        dev, dt = x.device, x.dtype
+        gpre = gy
+        if not (gpre.stride(2) == 1 and gpre.stride(1) >= gpre.shape[2]
+                and gpre.stride(0) == G * gpre.stride(1)):
+            gpre = gpre.contiguous()
+        # 1. data-gradient chain: g_{l-1} = gate_{l-1}(g_l W_l), last layer first
+        d = _lib.MlpChainDesc()
+        d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
+            L, gpre.data_ptr(), gpre.stride(1), gpre.stride(0), \
+            gpre.shape[2], B, G
+        need_gx = ctx.needs_input_grad[0]
+        gx = torch.empty(B, G, Kin, device=dev, dtype=dt) if need_gx else None
+        gs = [None] * L          # gradient w.r.t. every pre-activation
+        gs[L - 1] = gpre
+        n_chain = 0
+        for i, l in enumerate(range(L - 1, -1, -1)):
+            w = weights[l]
+            N, ldw = w.shape[1], w.shape[2]
+            K = ldw - (1 if ones_flags[l] else 0)
+            if l == 0 and not need_gx:
+                break
+            y = d.layer[i]
+            y.w, y.w_gs, y.ldw, y.K, y.N = w.data_ptr(), N * ldw, ldw, N, K
+            if l > 0:
+                gs[l - 1] = torch.empty(G, B, K, device=dev, dtype=dt)
+                y.gate, y.gate_gs, y.gate_bs = acts[l - 1].data_ptr(), B * K, K
+                y.out, y.out_gs, y.out_bs = gs[l - 1].data_ptr(), B * K, K
+            else:
+                if x_is_relu:
+                    y.gate, y.gate_gs, y.gate_bs = x.data_ptr(), x.stride(1), \
+                        x.stride(0)
+                y.out, y.out_gs, y.out_bs = gx.data_ptr(), K, G * K
+            n_chain += 1
+        if n_chain:
+            d.n_layers = n_chain
+            _lib.call("scae_mlp_chain_bwd_f32", ctypes.byref(d), _stream(x))
+        # 2. all weight gradients gW_l[g] (N x K) = g_l^T act_{l-1} in one launch
+        descs = (_lib.GemmDesc * L)()
+        gws, gbs = [None] * L, [None] * L
+        for l in range(L):
+            w = weights[l]
+            N, ldw = w.shape[1], w.shape[2]
+            K = ldw - (1 if ones_flags[l] else 0)
+            if l == 0:
+                xin, x_ld, x_b = x, x.stride(0), x.stride(1)
+            else:
+                xin, x_ld, x_b = acts[l - 1], K, B * K
+            g = gs[l]
+            if l == L - 1:
+                g_ld, g_b = g.stride(0), g.stride(1)
+            else:
+                g_ld, g_b = N, B * N
+            gw = _grad_out(ctx.slots[l], w)
+            asum_ld = 1
+            if has_bias[l]:
+                gsum = _grad_out(ctx.slots[L + l], w, (G, N))
+                asum, asum_b = _p(gsum), N
+                gbs[l] = gsum
+            elif ones_flags[l]:
+                asum, asum_b, asum_ld = _off(gw, K), N * ldw, ldw
+            else:
+                asum, asum_b = None, 0
+            descs[l] = _gemm_desc(_p(g), _p(xin), _p(gw), G, N, K, B, False,
+                                  g_ld, g_b, False, x_ld, x_b, ldw, N * ldw,
+                                  asum=asum, asum_b=asum_b, asum_ld=asum_ld)
+            gws[l] = gw
+        _lib.call("scae_gemm_multi_f32", descs, L, _stream(x))
+        return (gx, None, None, *gws, *gbs)
+
+
+def mlp_chain(x, layers, x_is_relu=False):
+    """``layers``: [(weight (G,N,K[+1]), bias (G,N) or None, ones_input)] -- up
+    to 4 ReLU layers of G independent groups evaluated in one launch; x
+    (B, G, Kin) -> (B, G, N_last) (a view of rows padded to a multiple of 4
+    floats).  The returned tensor's gradient must be the gradient w.r.t. the
+    last PRE-activation (zero where the output is zero), as ``capsule_votes(
+    param_is_relu=True)`` provides it."""
+    ws = [w for w, _, _ in layers]
+    bs = [b for _, b, _ in layers]
+    return _MLPChain.apply(x, tuple(bool(o) for _, _, o in layers),
+                           bool(x_is_relu), *ws, *bs)
+
+
 def grouped_mlp(x, weights, biases, ones_input=False, grad_pregated=False,
                 x_is_relu=False, pad_out=False):
     """ReLU MLPs of G independent groups; x (B, G, Kin) -> (B, G, N_last).
