@@ -312,6 +312,38 @@ int scae_mlp_chain_max_width(void);
 int scae_mlp_chain_fwd_f32(const scae_mlp_chain_desc *desc, void *stream);
 int scae_mlp_chain_bwd_f32(const scae_mlp_chain_desc *desc, void *stream);
 
+/* The chain with the vote kernel (K3, scae_capsule_votes_*_f32 below) riding in
+ * the same launch: CapsuleLayer.forward (object_decoder.py:120-236) from the
+ * object encoding to the votes as ONE launch, and the first half of its backward
+ * (vote gradients -> parameter-row gradients -> the data-gradient chain) as one.
+ *   fwd: the last layer's output rows (B, G, ld_param), N = 8V+7, are the vote
+ *     kernel's all_param; outputs as scae_capsule_votes_fwd_f32.
+ *   bwd: desc->in is ignored -- the chain's input block is the vote kernel's
+ *     gall_param_gated (or gall_param when that is NULL), computed in the launch
+ *     from the vote gradients and also written out (the weight-gradient GEMM of
+ *     the last layer and the bias sums read them); all_param = the saved rows.
+ * Fields as the arguments of scae_capsule_votes_fwd/bwd_f32; B and O are the
+ * chain's B and G. */
+typedef struct scae_votes_desc {
+  const float *all_param; /* bwd only */
+  const float *cpr_static, *bias_cvr, *bias_caps, *bias_vote, *bias_scale;
+  const float *noise_caps, *noise_vote; /* nullable */
+  float noise_scale;
+  int V, ld_param, similarity, learn_vote_scale, allow_deformations;
+  /* forward outputs */
+  float *vote, *scale, *vote_presence, *logit_caps, *logit_vote, *reg_partial;
+  float *caps_presence; /* nullable together with caps_arg */
+  int *caps_arg;
+  /* backward: incoming gradients (nullable), outputs */
+  const float *gvote, *gscale, *gvote_presence, *glogit_caps, *glogit_vote, *greg;
+  const float *gcaps_presence;
+  float *gall_param, *gcpr_in, *gall_param_gated;
+} scae_votes_desc;
+int scae_mlp_chain_votes_fwd_f32(const scae_mlp_chain_desc *desc, const scae_votes_desc *votes,
+                                 void *stream);
+int scae_mlp_chain_votes_bwd_f32(const scae_mlp_chain_desc *desc, const scae_votes_desc *votes,
+                                 void *stream);
+
 /* bf16-operand forms of the GEMM-shaped launchers (BASELINE.json configs[2], "bs=1024
  * bf16"): same arguments, same fp32 tensors in memory; the operands are rounded to bf16
  * (nearest even) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32

@@ -1625,6 +1625,66 @@ def test_mlp_chain_vs_fp64(B, G, Kin, dims, ones_at):
                      what="vs K7")
 
 
+@pytest.mark.parametrize("B,O,V,noise,sim", [(128, 24, 24, True, True),
+                                              (37, 5, 7, False, False),
+                                              (16, 4, 5, True, True)])
+def test_chain_votes_matches_chain_then_votes(B, O, V, noise, sim):
+    """K7b + K3 in one launch (forward) / K3-backward + data-gradient chain in one
+    launch (backward) against the same two ops launched separately: every
+    output and every gradient, 1e-5 relative to the tensor's largest entry
+    (the only difference is the order of two small sums)."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(B * O + V)
+    Kin, H, Dc, A = 64, 48, 12, 8 * V + 7
+    dims = [(H, Kin, True, False), (Dc, H, True, False), (H, Dc + 1, False, True),
+            (A, H, False, False)]
+    vals = dict(
+        x=torch.randn(B, O, Kin, generator=g),
+        cpr=torch.randn(1, O, V, 6, generator=g) * 0.3,
+        b_cvr=torch.randn(1, O, 1, 6, generator=g) * 0.3,
+        b_caps=torch.randn(1, O, 1, generator=g),
+        b_vote=torch.randn(1, O, V, generator=g),
+        b_scale=torch.randn(1, O, V, generator=g))
+    ws = [torch.randn(O, n, k, generator=g) / k ** 0.5 for n, k, _, _ in dims]
+    bs = [torch.randn(O, n, generator=g) * 0.1 if hb else None
+          for n, _, hb, _ in dims]
+    nz = [torch.rand(B, O, 1, generator=g).cuda(),
+          torch.rand(B, O, V, generator=g).cuda()] if noise else [None, None]
+    gouts = [torch.randn(B, O, V, 6, generator=g), torch.randn(B, O, V, generator=g),
+             torch.randn(B, O, V, generator=g), torch.randn(B, O, 1, generator=g),
+             torch.randn(B, O, V, generator=g), torch.randn((), generator=g),
+             torch.randn(B, O, generator=g)]
+
+    def run(fused):
+        t = {k: v.cuda().requires_grad_() for k, v in vals.items()}
+        w = [x.cuda().requires_grad_() for x in ws]
+        b = [None if x is None else x.cuda().requires_grad_() for x in bs]
+        layers = [(w[i], b[i], dims[i][3]) for i in range(4)]
+        kw = dict(noise_caps=nz[0], noise_vote=nz[1], noise_scale=4.0,
+                  similarity=sim, learn_vote_scale=True, allow_deformations=True)
+        if fused:
+            outs = ops.chain_votes(t["x"], layers, t["cpr"], t["b_cvr"],
+                                   t["b_caps"], t["b_vote"], t["b_scale"], **kw)
+        else:
+            ap = ops.mlp_chain(t["x"], layers)
+            outs = ops.capsule_votes(ap, t["cpr"], t["b_cvr"], t["b_caps"],
+                                     t["b_vote"], t["b_scale"],
+                                     param_is_relu=True, **kw)
+        torch.autograd.backward(list(outs[:7]), [go.cuda() for go in gouts])
+        grads = [t[k].grad for k in vals] + [x.grad for x in w] + \
+            [x.grad for x in b if x is not None]
+        return [o.detach() for o in outs], grads
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    for i, (a, b_) in enumerate(zip(o1, o0)):
+        assert_close(a, b_, rtol=1e-5, atol=1e-5 * float(b_.abs().max()) + 1e-7,
+                     what=f"out{i}")
+    for i, (a, b_) in enumerate(zip(g1, g0)):
+        assert_close(a, b_, rtol=1e-5, atol=1e-5 * float(b_.abs().max()) + 1e-7,
+                     what=f"grad{i}")
+
+
 def test_step_prologue_matches_the_three_launches():
     """scae_step_prologue_f32 = scae_stage_batch + scae_uniform_f32 +
     scae_seed_fold_fwd_f32 in one launch: bit-identical outputs, and the noise

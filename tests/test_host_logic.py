@@ -58,6 +58,8 @@ def test_launchers_reject_bad_arguments_without_a_gpu():
     assert lib.scae_mlp_chain_fwd_f32(chain, None) == -1          # no input, no layers
     assert lib.scae_mlp_chain_bwd_f32(chain, None) == -1
     assert lib.scae_mlp_chain_max_width() >= 512
+    assert lib.scae_mlp_chain_votes_fwd_f32(chain, None, None) == -1
+    assert lib.scae_mlp_chain_votes_bwd_f32(chain, _lib.VotesDesc(), None) == -1
     assert lib.scae_conv3x3_bwd_pair_f32(None, None, None, None, None, 2, 9, 9,
                                          64, 64, 1, None) == -1
     assert lib.scae_conv3x3_first_fwd_relayout_f32(

@@ -56,6 +56,21 @@ class MlpChainDesc(Structure):
                 ("B", c_int), ("G", c_int)]
 
 
+class VotesDesc(Structure):
+    """struct scae_votes_desc"""
+    _fields_ = [(n, P) for n in ("all_param", "cpr_static", "bias_cvr",
+                                 "bias_caps", "bias_vote", "bias_scale",
+                                 "noise_caps", "noise_vote")] + \
+        [("noise_scale", c_float), ("V", c_int), ("ld_param", c_int),
+         ("similarity", c_int), ("learn_vote_scale", c_int),
+         ("allow_deformations", c_int)] + \
+        [(n, P) for n in ("vote", "scale", "vote_presence", "logit_caps",
+                          "logit_vote", "reg_partial", "caps_presence",
+                          "caps_arg", "gvote", "gscale", "gvote_presence",
+                          "glogit_caps", "glogit_vote", "greg", "gcaps_presence",
+                          "gall_param", "gcpr_in", "gall_param_gated")]
+
+
 class SumSegment(Structure):
     """struct scae_sum_segment"""
     _fields_ = [("dst", P), ("begin", c_int64), ("end", c_int64),
@@ -142,6 +157,8 @@ SIGNATURES = {
     "scae_mlp_chain_max_width": [],
     "scae_mlp_chain_fwd_f32": [POINTER(MlpChainDesc), P],
     "scae_mlp_chain_bwd_f32": [POINTER(MlpChainDesc), P],
+    "scae_mlp_chain_votes_fwd_f32": [POINTER(MlpChainDesc), POINTER(VotesDesc), P],
+    "scae_mlp_chain_votes_bwd_f32": [POINTER(MlpChainDesc), POINTER(VotesDesc), P],
     "scae_gemm_pair_bf16": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_relayout_batch_f32": [c_int, P, P, P, P, P, P],

@@ -9,78 +9,11 @@
 // to the V vote lanes.  Elementwise + one small reduction: HBM bound.
 #include "common.h"
 
+#include "capsule_votes_dev.h"
+
 namespace {
+using namespace scae_votes;
 constexpr int NT = 64;  // one wave per capsule; lanes stride over votes
-constexpr float kTwoPi = 6.283185307179586f;
-
-struct Xf {  // a transformed pose and the local derivatives of its 6 outputs
-  float sx, sy, sh, c, s, tx, ty;
-  float dsx, dsy, dsh, dtx, dty;
-  float o[6];
-};
-
-__device__ __forceinline__ void xf_eval(const float *p, int similarity, Xf &g) {
-  const float ex = scae::sigmoidf_(p[0]), ey = scae::sigmoidf_(p[1]);
-  g.sx = ex + 1e-2f;
-  g.sy = ey + 1e-2f;
-  g.dsx = ex * (1.f - ex);
-  g.dsy = ey * (1.f - ey);
-  g.sh = tanhf(p[3] * 5.f);
-  g.tx = tanhf(p[4] * 5.f);
-  g.ty = tanhf(p[5] * 5.f);
-  g.dsh = 5.f * (1.f - g.sh * g.sh);
-  g.dtx = 5.f * (1.f - g.tx * g.tx);
-  g.dty = 5.f * (1.f - g.ty * g.ty);
-  const float th = p[2] * kTwoPi;
-  g.c = cosf(th);
-  g.s = sinf(th);
-  if (similarity) {
-    g.o[0] = g.sx * g.c;
-    g.o[1] = -g.sx * g.s;
-    g.o[2] = g.tx;
-    g.o[3] = g.sx * g.s;
-    g.o[4] = g.sx * g.c;
-    g.o[5] = g.ty;
-  } else {
-    g.o[0] = g.sx * g.c + g.sh * g.sy * g.s;
-    g.o[1] = -g.sx * g.s + g.sh * g.sy * g.c;
-    g.o[2] = g.tx;
-    g.o[3] = g.sy * g.s;
-    g.o[4] = g.sy * g.c;
-    g.o[5] = g.ty;
-  }
-}
-
-__device__ __forceinline__ void xf_backward(const Xf &g, int similarity, const float *go,
-                                            float *gp) {
-  float gsx, gsy, gsh, gth;
-  if (similarity) {
-    gsx = go[0] * g.c - go[1] * g.s + go[3] * g.s + go[4] * g.c;
-    gsy = 0.f;
-    gsh = 0.f;
-    gth = g.sx * (-go[0] * g.s - go[1] * g.c + go[3] * g.c - go[4] * g.s);
-  } else {
-    gsx = go[0] * g.c - go[1] * g.s;
-    gsy = go[0] * g.sh * g.s + go[1] * g.sh * g.c + go[3] * g.s + go[4] * g.c;
-    gsh = go[0] * g.sy * g.s + go[1] * g.sy * g.c;
-    gth = go[0] * (-g.sx * g.s + g.sh * g.sy * g.c) +
-          go[1] * (-g.sx * g.c - g.sh * g.sy * g.s) + go[3] * g.sy * g.c - go[4] * g.sy * g.s;
-  }
-  gp[0] = gsx * g.dsx;
-  gp[1] = gsy * g.dsy;
-  gp[2] = gth * kTwoPi;
-  gp[3] = gsh * g.dsh;
-  gp[4] = go[2] * g.dtx;
-  gp[5] = go[5] * g.dty;
-}
-
-struct VoteArgs {
-  const float *all_param, *cpr_static, *bias_cvr, *bias_caps, *bias_vote, *bias_scale;
-  const float *noise_caps, *noise_vote;
-  float noise_scale;
-  int B, O, V, similarity, learn_vote_scale, allow_deformations;
-  int ldp;  // floats between consecutive capsule rows of all_param (and of its gradients), >= A
-};
 
 __global__ __launch_bounds__(NT) void votes_fwd_kernel(
     VoteArgs a, float *__restrict__ vote, float *__restrict__ scale,

@@ -23,6 +23,7 @@
 // contracts over the rows of W_l (g_prev = gate(g W_l)), the gate being the ReLU output
 // saved by the forward pass.
 #include "common.h"
+#include "capsule_votes_dev.h"
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -47,6 +48,12 @@ struct Chain {
   const float *in;
   long in_gs, in_bs;
   int n, in_dim, B, G, stride;   // stride: floats per LDS activation row
+  // the capsule votes (K3) at the end of the forward chain / at the head of the
+  // data-gradient chain
+  int votes;
+  scae_votes::VoteArgs va;
+  scae_votes::VoteOut vo;
+  scae_votes::VoteGrads vg;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) {
@@ -166,6 +173,12 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
   if (wid < ntiles_of(0))
     fetch_item<BWD>(c.l[0], c.l[0].w + (size_t)g * c.l[0].w_gs, g, b0, c.B, wid, 0, nch_of(0), lane,
                     f, fe);
+  if (BWD && c.votes) {
+    // the chain's input block = the vote kernel's gradient rows, made here (K3 backward
+    // for the block's 16 capsules; also written to global memory for the weight-gradient
+    // GEMM and the bias sums)
+    scae_votes::bwd_block<NT>(c.va, c.vg, smem, c.stride, smem + RB * c.stride, b0, g);
+  } else
   {  // the block's input rows, zero padded to a multiple of 16 columns / to 16 rows; eight
      // independent loads per thread in flight (a load-store loop pays a memory round trip
      // per iteration)
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
             float v = acc[e] + bias;
             if (L.relu) v = fmaxf(v, 0.f);
             v = cok && gt[e] > 0.f ? v : 0.f;   // (also the zero padding of the next contraction)
-            if (!last) nxt[row * c.stride + col] = v;
+            if (!last || (!BWD && c.votes)) nxt[row * c.stride + col] = v;
             if (out && cok && b < c.B) out[(size_t)b * L.out_bs + col] = v;
           }
         }
@@ -244,10 +257,16 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
       }
     }
   }
+  if (!BWD && c.votes) {
+    // K3 forward for the block's 16 capsules from their parameter rows in LDS
+    __syncthreads();
+    scae_votes::fwd_block<NT>(c.va, c.vo, smem + (c.n & 1) * RB * c.stride, c.stride,
+                              smem + ((c.n + 1) & 1) * RB * c.stride, b0, g);
+  }
 }
 
-int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd) {
-  if (!d || !d->in || d->n_layers < 1 || d->n_layers > MAXL || d->B <= 0 || d->G <= 0 ||
+int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd, const scae_votes_desc *v = nullptr) {
+  if (!d || (!d->in && !(bwd && v)) || d->n_layers < 1 || d->n_layers > MAXL || d->B <= 0 || d->G <= 0 ||
       d->in_dim <= 0)
     return SCAE_ERR_BAD_ARG;
   int maxdim = d->in_dim, prev = d->in_dim;
@@ -272,13 +291,44 @@ int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd) {
   c.in = d->in, c.in_gs = (long)d->in_gs, c.in_bs = (long)d->in_bs;
   c.n = d->n_layers, c.in_dim = d->in_dim, c.B = d->B, c.G = d->G;
   c.stride = ((maxdim + 15) & ~15) + 4;   // (stride / 4) odd: conflict-free b128 row reads
+  c.votes = 0;
+  if (v) {
+    const int V = v->V, A = 8 * V + 7;
+    if (V <= 0 || !v->cpr_static || !v->bias_cvr || !v->bias_caps || !v->bias_vote ||
+        !v->bias_scale || v->ld_param < A)
+      return SCAE_ERR_BAD_ARG;
+    const scae_mlp_chain_layer &e = d->layer[bwd ? 0 : d->n_layers - 1];
+    // the chain's (B, G, ld) parameter rows are the vote kernel's all_param
+    if ((bwd ? d->in_dim : e.N) != A) return SCAE_ERR_BAD_ARG;
+    c.votes = 1;
+    c.va = scae_votes::VoteArgs{v->all_param, v->cpr_static, v->bias_cvr, v->bias_caps,
+                                v->bias_vote, v->bias_scale, v->noise_caps, v->noise_vote,
+                                v->noise_scale, d->B, d->G, V, v->similarity,
+                                v->learn_vote_scale, v->allow_deformations, v->ld_param};
+    if (!bwd) {
+      if (!(v->vote && v->scale && v->vote_presence && v->logit_caps && v->logit_vote &&
+            v->reg_partial) || !v->caps_presence != !v->caps_arg)
+        return SCAE_ERR_BAD_ARG;
+      if (e.out_gs != v->ld_param || e.out_bs != (int64_t)d->G * v->ld_param)
+        return SCAE_ERR_BAD_ARG;
+      c.vo = scae_votes::VoteOut{v->vote, v->scale, v->vote_presence, v->logit_caps,
+                                 v->logit_vote, v->reg_partial, v->caps_presence, v->caps_arg};
+    } else {
+      if (!(v->all_param && v->gall_param && v->gcpr_in) ||
+          (v->gcaps_presence && !v->caps_arg))
+        return SCAE_ERR_BAD_ARG;
+      c.vg = scae_votes::VoteGrads{v->gvote, v->gscale, v->gvote_presence, v->glogit_caps,
+                                   v->glogit_vote, v->greg, v->gcaps_presence, v->caps_arg,
+                                   v->gall_param, v->gcpr_in, v->gall_param_gated};
+    }
+  }
   return SCAE_OK;
 }
 
 template <bool BWD>
-int launch(const scae_mlp_chain_desc *d, void *stream) {
+int launch(const scae_mlp_chain_desc *d, const scae_votes_desc *v, void *stream) {
   Chain c{};
-  int rc = fill(c, d, BWD);
+  int rc = fill(c, d, BWD, v);
   if (rc) return rc;
   const size_t lds = ((size_t)2 * RB * c.stride + (size_t)NW * 16 * WLD) * sizeof(float);
   if (lds > 48 * 1024) {
@@ -296,8 +346,18 @@ int launch(const scae_mlp_chain_desc *d, void *stream) {
 extern "C" int scae_mlp_chain_max_width(void) { return 704; }
 
 extern "C" int scae_mlp_chain_fwd_f32(const scae_mlp_chain_desc *desc, void *stream) {
-  return launch<false>(desc, stream);
+  return launch<false>(desc, nullptr, stream);
 }
 extern "C" int scae_mlp_chain_bwd_f32(const scae_mlp_chain_desc *desc, void *stream) {
-  return launch<true>(desc, stream);
+  return launch<true>(desc, nullptr, stream);
+}
+extern "C" int scae_mlp_chain_votes_fwd_f32(const scae_mlp_chain_desc *desc,
+                                            const scae_votes_desc *votes, void *stream) {
+  SCAE_REQUIRE(votes);
+  return launch<false>(desc, votes, stream);
+}
+extern "C" int scae_mlp_chain_votes_bwd_f32(const scae_mlp_chain_desc *desc,
+                                            const scae_votes_desc *votes, void *stream) {
+  SCAE_REQUIRE(votes);
+  return launch<true>(desc, votes, stream);
 }

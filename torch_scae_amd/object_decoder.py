@@ -85,19 +85,27 @@ class CapsuleLayer(nn.Module):
         chain = [(w, b, False) for w, b in zip(self.mlps.weights,
                                                self.mlps.biases)] + \
             [(w, None, j == 0) for j, w in enumerate(self.caps_mlps.weights)]
-        if fused and ops.mlp_chain_supported(feature, chain):
-            # both MLPs -- all four layers -- in one launch (K7b)
-            all_param = ops.mlp_chain(feature, chain)              # (B, O, A)
-        else:
-            raw_caps_param = self.mlps(feature, grad_pregated=fused)  # (B, O, D)
-            all_param = self.caps_mlps(raw_caps_param, grad_pregated=fused,
-                                       x_is_relu=fused, pad_out=fused)
+        chained = fused and ops.mlp_chain_supported(feature, chain)
         noise_caps = noise_vote = None
         if self.noise_type == 'uniform':
-            proto = all_param.new_empty(B, self.n_caps, 1)
+            proto = feature.new_empty(B, self.n_caps, 1)
             noise_caps = rand_like(proto)
-            noise_vote = rand_like(all_param.new_empty(B, self.n_caps,
-                                                       self.n_votes))
+            noise_vote = rand_like(feature.new_empty(B, self.n_caps,
+                                                     self.n_votes))
+        if chained:
+            # both MLPs -- all four layers -- and the vote kernel in one launch
+            # (K7b + K3)
+            return ops.chain_votes(
+                feature, chain, self.cpr_static, *self.caps_bias_list,
+                noise_caps=noise_caps, noise_vote=noise_vote,
+                noise_scale=self.noise_scale,
+                similarity=self.similarity_transform,
+                learn_vote_scale=self.learn_vote_scale,
+                allow_deformations=self.allow_deformations,
+                defer_reg=defer_reg)
+        raw_caps_param = self.mlps(feature, grad_pregated=fused)  # (B, O, D)
+        all_param = self.caps_mlps(raw_caps_param, grad_pregated=fused,
+                                   x_is_relu=fused, pad_out=fused)  # (B, O, A)
         return ops.capsule_votes(
             all_param, self.cpr_static, *self.caps_bias_list,
             noise_caps=noise_caps, noise_vote=noise_vote,

@@ -1428,6 +1428,115 @@ def mlp_chain_supported(x, layers):
         not (ones and b is not None) for w, b, ones in layers)
 
 
+def _chain_forward_desc(x, ones_flags, weights, biases):
+    """-> (struct scae_mlp_chain_desc of the forward chain, [layer outputs]);
+    hidden outputs (G, B, N), the last one (B, G, N) with rows padded to a
+    multiple of 4 floats."""
+    L = len(ones_flags)
+    B, G, Kin = x.shape
+    d = _lib.MlpChainDesc()
+    d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
+        L, x.data_ptr(), x.stride(1), x.stride(0), Kin, B, G
+    acts, K = [], Kin
+    for l, (w, b) in enumerate(zip(weights, biases)):
+        N, ldw = w.shape[1], w.shape[2]
+        assert ldw == K + (1 if ones_flags[l] else 0)
+        if l == L - 1:
+            Np = (N + 3) // 4 * 4
+            out = torch.empty(B, G, Np, device=x.device,
+                              dtype=x.dtype)[:, :, :N]
+            out_gs, out_bs = Np, G * Np
+        else:
+            out = torch.empty(G, B, N, device=x.device, dtype=x.dtype)
+            out_gs, out_bs = B * N, N
+        y = d.layer[l]
+        y.w, y.w_gs, y.ldw, y.K, y.N = w.data_ptr(), N * ldw, ldw, K, N
+        if ones_flags[l]:          # implicit trailing 1.0 input column
+            y.bias, y.bias_gs, y.bias_ld = w.data_ptr() + 4 * K, N * ldw, ldw
+        elif b is not None:
+            y.bias, y.bias_gs, y.bias_ld = b.data_ptr(), N, 1
+        y.out, y.out_gs, y.out_bs, y.relu = out.data_ptr(), out_gs, out_bs, 1
+        acts.append(out)
+        K = N
+    return d, acts
+
+
+def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
+                    need_gx, gpre=None, votes=None):
+    """The backward of the chain: the data-gradient chain (one launch; with
+    ``votes`` -- a struct scae_votes_desc whose gall_param(_gated) rows are
+    ``gpre`` -- the vote kernel's backward rides at its head), then every
+    weight gradient in one launch.  -> (gx, gws, gbs)."""
+    L = len(ones_flags)
+    B, G, Kin = x.shape
+    dev, dt = x.device, x.dtype
+    # 1. data-gradient chain: g_{l-1} = gate_{l-1}(g_l W_l), last layer first
+    d = _lib.MlpChainDesc()
+    d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
+        L, gpre.data_ptr(), gpre.stride(1), gpre.stride(0), gpre.shape[2], B, G
+    gx = torch.empty(B, G, Kin, device=dev, dtype=dt) if need_gx else None
+    gs = [None] * L          # gradient w.r.t. every pre-activation
+    gs[L - 1] = gpre
+    n_chain = 0
+    for i, l in enumerate(range(L - 1, -1, -1)):
+        w = weights[l]
+        N, ldw = w.shape[1], w.shape[2]
+        K = ldw - (1 if ones_flags[l] else 0)
+        if l == 0 and not need_gx:
+            break
+        y = d.layer[i]
+        y.w, y.w_gs, y.ldw, y.K, y.N = w.data_ptr(), N * ldw, ldw, N, K
+        if l > 0:
+            gs[l - 1] = torch.empty(G, B, K, device=dev, dtype=dt)
+            y.gate, y.gate_gs, y.gate_bs = acts[l - 1].data_ptr(), B * K, K
+            y.out, y.out_gs, y.out_bs = gs[l - 1].data_ptr(), B * K, K
+        else:
+            if x_is_relu:
+                y.gate, y.gate_gs, y.gate_bs = x.data_ptr(), x.stride(1), \
+                    x.stride(0)
+            y.out, y.out_gs, y.out_bs = gx.data_ptr(), K, G * K
+        n_chain += 1
+    d.n_layers = n_chain
+    if votes is not None:
+        assert n_chain >= 1
+        _lib.call("scae_mlp_chain_votes_bwd_f32", ctypes.byref(d),
+                  ctypes.byref(votes), _stream(x))
+    elif n_chain:
+        _lib.call("scae_mlp_chain_bwd_f32", ctypes.byref(d), _stream(x))
+    # 2. all weight gradients gW_l[g] (N x K) = g_l^T act_{l-1} in one launch
+    descs = (_lib.GemmDesc * L)()
+    gws, gbs = [None] * L, [None] * L
+    for l in range(L):
+        w = weights[l]
+        N, ldw = w.shape[1], w.shape[2]
+        K = ldw - (1 if ones_flags[l] else 0)
+        if l == 0:
+            xin, x_ld, x_b = x, x.stride(0), x.stride(1)
+        else:
+            xin, x_ld, x_b = acts[l - 1], K, B * K
+        g = gs[l]
+        if l == L - 1:
+            g_ld, g_b = g.stride(0), g.stride(1)
+        else:
+            g_ld, g_b = N, B * N
+        gw = _grad_out(slots[l], w)
+        asum_ld = 1
+        if has_bias[l]:
+            gsum = _grad_out(slots[L + l], w, (G, N))
+            asum, asum_b = _p(gsum), N
+            gbs[l] = gsum
+        elif ones_flags[l]:
+            asum, asum_b, asum_ld = _off(gw, K), N * ldw, ldw
+        else:
+            asum, asum_b = None, 0
+        descs[l] = _gemm_desc(_p(g), _p(xin), _p(gw), G, N, K, B, False,
+                              g_ld, g_b, False, x_ld, x_b, ldw, N * ldw,
+                              asum=asum, asum_b=asum_b, asum_ld=asum_ld)
+        gws[l] = gw
+    _lib.call("scae_gemm_multi_f32", descs, L, _stream(x))
+    return gx, gws, gbs
+
+
 class _MLPChain(torch.autograd.Function):
     """relu(W_n .. relu(W_0 x + b_0) .. + b_n) for G groups, all layers in ONE
     launch (K7b); a layer with ``ones`` sees its input extended by a constant
@@ -1445,32 +1554,7 @@ class _MLPChain(torch.autograd.Function):
             x = x.contiguous()
         weights = [w.contiguous() for w in wb[:L]]
         biases = [None if b is None else b.contiguous() for b in wb[L:]]
-        B, G, Kin = x.shape
-        d = _lib.MlpChainDesc()
-        d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
-            L, x.data_ptr(), x.stride(1), x.stride(0), Kin, B, G
-        acts, K = [], Kin
-        for l, (w, b) in enumerate(zip(weights, biases)):
-            N, ldw = w.shape[1], w.shape[2]
-            assert ldw == K + (1 if ones_flags[l] else 0)
-            last = l == L - 1
-            if last:
-                Np = (N + 3) // 4 * 4
-                out = torch.empty(B, G, Np, device=x.device,
-                                  dtype=x.dtype)[:, :, :N]
-                out_gs, out_bs = Np, G * Np
-            else:
-                out = torch.empty(G, B, N, device=x.device, dtype=x.dtype)
-                out_gs, out_bs = B * N, N
-            y = d.layer[l]
-            y.w, y.w_gs, y.ldw, y.K, y.N = w.data_ptr(), N * ldw, ldw, K, N
-            if ones_flags[l]:          # implicit trailing 1.0 input column
-                y.bias, y.bias_gs, y.bias_ld = w.data_ptr() + 4 * K, N * ldw, ldw
-            elif b is not None:
-                y.bias, y.bias_gs, y.bias_ld = b.data_ptr(), N, 1
-            y.out, y.out_gs, y.out_bs, y.relu = out.data_ptr(), out_gs, out_bs, 1
-            acts.append(out)
-            K = N
+        d, acts = _chain_forward_desc(x, ones_flags, weights, biases)
         _lib.call("scae_mlp_chain_fwd_f32", ctypes.byref(d), _stream(x))
         ctx.save_for_backward(x, *weights, *acts)
         ctx.meta = (tuple(ones_flags), [b is not None for b in biases],
@@ -1485,75 +1569,146 @@ class _MLPChain(torch.autograd.Function):
         x = ctx.saved_tensors[0]
         weights = ctx.saved_tensors[1:1 + L]
         acts = ctx.saved_tensors[1 + L:]
-        B, G, Kin = x.shape
-        dev, dt = x.device, x.dtype
+        G = x.shape[1]
         gpre = gy
         if not (gpre.stride(2) == 1 and gpre.stride(1) >= gpre.shape[2]
                 and gpre.stride(0) == G * gpre.stride(1)):
             gpre = gpre.contiguous()
-        # 1. data-gradient chain: g_{l-1} = gate_{l-1}(g_l W_l), last layer first
-        d = _lib.MlpChainDesc()
-        d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
-            L, gpre.data_ptr(), gpre.stride(1), gpre.stride(0), \
-            gpre.shape[2], B, G
-        need_gx = ctx.needs_input_grad[0]
-        gx = torch.empty(B, G, Kin, device=dev, dtype=dt) if need_gx else None
-        gs = [None] * L          # gradient w.r.t. every pre-activation
-        gs[L - 1] = gpre
-        n_chain = 0
-        for i, l in enumerate(range(L - 1, -1, -1)):
-            w = weights[l]
-            N, ldw = w.shape[1], w.shape[2]
-            K = ldw - (1 if ones_flags[l] else 0)
-            if l == 0 and not need_gx:
-                break
-            y = d.layer[i]
-            y.w, y.w_gs, y.ldw, y.K, y.N = w.data_ptr(), N * ldw, ldw, N, K
-            if l > 0:
-                gs[l - 1] = torch.empty(G, B, K, device=dev, dtype=dt)
-                y.gate, y.gate_gs, y.gate_bs = acts[l - 1].data_ptr(), B * K, K
-                y.out, y.out_gs, y.out_bs = gs[l - 1].data_ptr(), B * K, K
-            else:
-                if x_is_relu:
-                    y.gate, y.gate_gs, y.gate_bs = x.data_ptr(), x.stride(1), \
-                        x.stride(0)
-                y.out, y.out_gs, y.out_bs = gx.data_ptr(), K, G * K
-            n_chain += 1
-        if n_chain:
-            d.n_layers = n_chain
-            _lib.call("scae_mlp_chain_bwd_f32", ctypes.byref(d), _stream(x))
-        # 2. all weight gradients gW_l[g] (N x K) = g_l^T act_{l-1} in one launch
-        descs = (_lib.GemmDesc * L)()
-        gws, gbs = [None] * L, [None] * L
-        for l in range(L):
-            w = weights[l]
-            N, ldw = w.shape[1], w.shape[2]
-            K = ldw - (1 if ones_flags[l] else 0)
-            if l == 0:
-                xin, x_ld, x_b = x, x.stride(0), x.stride(1)
-            else:
-                xin, x_ld, x_b = acts[l - 1], K, B * K
-            g = gs[l]
-            if l == L - 1:
-                g_ld, g_b = g.stride(0), g.stride(1)
-            else:
-                g_ld, g_b = N, B * N
-            gw = _grad_out(ctx.slots[l], w)
-            asum_ld = 1
-            if has_bias[l]:
-                gsum = _grad_out(ctx.slots[L + l], w, (G, N))
-                asum, asum_b = _p(gsum), N
-                gbs[l] = gsum
-            elif ones_flags[l]:
-                asum, asum_b, asum_ld = _off(gw, K), N * ldw, ldw
-            else:
-                asum, asum_b = None, 0
-            descs[l] = _gemm_desc(_p(g), _p(xin), _p(gw), G, N, K, B, False,
-                                  g_ld, g_b, False, x_ld, x_b, ldw, N * ldw,
-                                  asum=asum, asum_b=asum_b, asum_ld=asum_ld)
-            gws[l] = gw
-        _lib.call("scae_gemm_multi_f32", descs, L, _stream(x))
+        gx, gws, gbs = _chain_backward(x, weights, acts, ones_flags, has_bias,
+                                       x_is_relu, ctx.slots,
+                                       ctx.needs_input_grad[0], gpre=gpre)
         return (gx, None, None, *gws, *gbs)
+
+
+class _ChainVotes(torch.autograd.Function):
+    """CapsuleLayer.forward (object_decoder.py:120-236) from the object
+    encoding to the votes in ONE launch: the MLP chain of ``_MLPChain`` with the
+    vote kernel of ``_CapsuleVotes`` at its end; backward: the vote kernel's
+    backward at the head of the data-gradient chain (one launch), all weight
+    gradients (one launch), the bias column sums (deferred).  Outputs as
+    ``capsule_votes``."""
+
+    @staticmethod
+    def forward(ctx, x, ones_flags, vflags, noise_scale, cpr_static, b_cvr,
+                b_caps, b_vote, b_scale, noise_caps, noise_vote, *wb):
+        L = len(ones_flags)
+        similarity, learn_vote_scale, allow_deformations, defer_reg = vflags
+        _need_hip(x, cpr_static, b_cvr, b_caps, b_vote, b_scale, noise_caps,
+                  noise_vote, *wb)
+        if x.stride(2) != 1:
+            x = x.contiguous()
+        weights = [w.contiguous() for w in wb[:L]]
+        biases = [None if b is None else b.contiguous() for b in wb[L:]]
+        vargs = [_c(t) for t in (cpr_static, b_cvr, b_caps, b_vote, b_scale,
+                                 noise_caps, noise_vote)]
+        d, acts = _chain_forward_desc(x, ones_flags, weights, biases)
+        all_param = acts[-1]
+        B, O, A = all_param.shape
+        V, ldp = (A - 7) // 8, all_param.stride(1)
+        assert A == 8 * V + 7
+        dev, dt = x.device, x.dtype
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)  # noqa: E731
+        vote, scale, vp = new(B, O, V, 6), new(B, O, V), new(B, O, V)
+        lc, lv, reg = new(B, O, 1), new(B, O, V), new(B, O)
+        reg_loss = torch.empty((), device=dev, dtype=dt)   # l2_loss(.)/B, :170
+        caps_presence = new(B, O)
+        caps_arg = torch.empty(B, O, device=dev, dtype=torch.int32)
+        v = _lib.VotesDesc()
+        for name, t in zip(("cpr_static", "bias_cvr", "bias_caps", "bias_vote",
+                            "bias_scale", "noise_caps", "noise_vote"), vargs):
+            setattr(v, name, None if t is None else t.data_ptr())
+        v.noise_scale, v.V, v.ld_param = float(noise_scale), V, ldp
+        v.similarity, v.learn_vote_scale, v.allow_deformations = \
+            int(similarity), int(learn_vote_scale), int(allow_deformations)
+        for name, t in (("vote", vote), ("scale", scale), ("vote_presence", vp),
+                        ("logit_caps", lc), ("logit_vote", lv),
+                        ("reg_partial", reg), ("caps_presence", caps_presence),
+                        ("caps_arg", caps_arg)):
+            setattr(v, name, t.data_ptr())
+        _lib.call("scae_mlp_chain_votes_fwd_f32", ctypes.byref(d),
+                  ctypes.byref(v), _stream(x))
+        if not defer_reg:
+            scaled_sums([(reg, 0.5 / B, reg_loss)])
+        ctx.save_for_backward(x, caps_arg, *weights, *acts,
+                              *[t for t in vargs if t is not None])
+        ctx.has_noise = (vargs[5] is not None, vargs[6] is not None)
+        ctx.meta = (tuple(ones_flags), [b is not None for b in biases],
+                    float(noise_scale), (V, ldp, int(similarity),
+                                         int(learn_vote_scale),
+                                         int(allow_deformations)))
+        ctx.slots = [_slot(t) for t in wb]
+        ctx.vslots = [_slot(t) for t in (cpr_static, b_cvr, b_caps, b_vote,
+                                         b_scale)]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(reg)
+        return vote, scale, vp, lc, lv, reg_loss, caps_presence, reg
+
+    @staticmethod
+    def backward(ctx, gvote, gscale, gvp, glc, glv, greg, gcp, _greg_partial):
+        ones_flags, has_bias, noise_scale, (V, ldp, sim, lvs, adef) = ctx.meta
+        L = len(ones_flags)
+        saved = list(ctx.saved_tensors)
+        x, caps_arg = saved[0], saved[1]
+        weights = saved[2:2 + L]
+        acts = saved[2 + L:2 + 2 * L]
+        rest = saved[2 + 2 * L:]
+        vargs = rest[:5]
+        rest = rest[5:]
+        noise_caps = rest.pop(0) if ctx.has_noise[0] else None
+        noise_vote = rest.pop(0) if ctx.has_noise[1] else None
+        all_param = acts[-1]
+        B, O, A = all_param.shape
+        dev, dt = x.device, x.dtype
+        padded = lambda: torch.empty(B, O, ldp, device=dev,   # noqa: E731
+                                     dtype=dt)[:, :, :A]
+        gall, ggated = padded(), padded()
+        gin = torch.empty(B, O, V, 6, device=dev, dtype=dt)
+        grads = [_c(g) for g in (gvote, gscale, gvp, glc, glv, greg, gcp)]
+        v = _lib.VotesDesc()
+        for name, t in zip(("all_param", "cpr_static", "bias_cvr", "bias_caps",
+                            "bias_vote", "bias_scale", "noise_caps",
+                            "noise_vote"),
+                           [all_param, *vargs, noise_caps, noise_vote]):
+            setattr(v, name, None if t is None else t.data_ptr())
+        v.noise_scale, v.V, v.ld_param = noise_scale, V, ldp
+        v.similarity, v.learn_vote_scale, v.allow_deformations = sim, lvs, adef
+        for name, t in zip(("gvote", "gscale", "gvote_presence", "glogit_caps",
+                            "glogit_vote", "greg", "gcaps_presence"), grads):
+            setattr(v, name, None if t is None else t.data_ptr())
+        v.caps_arg = caps_arg.data_ptr()
+        v.gall_param, v.gcpr_in, v.gall_param_gated = \
+            gall.data_ptr(), gin.data_ptr(), ggated.data_ptr()
+        gx, gws, gbs = _chain_backward(x, weights, acts, ones_flags, has_bias,
+                                       False, ctx.slots, True, gpre=ggated,
+                                       votes=v)
+        # bias gradients: batch sums of column blocks of gall (B, O*A)
+        outs = [_grad_out(sl, t) for sl, t in zip(ctx.vslots, vargs)]
+        gall_rows = torch.as_strided(gall, (B, O * ldp), (O * ldp, 1))
+        (g_static,), (g_cvr, g_caps, g_vote, g_scale) = _sum_rows_multi([
+            dict(partial=gin.view(B, -1), shapes=[vargs[0].shape],
+                 outs=outs[:1], defer=ctx.vslots[0] is not None),
+            dict(partial=gall_rows, shapes=[t.shape for t in vargs[1:5]],
+                 starts=[6 * V, 6 * V + 6, 6 * V + 7, 7 * V + 7], period=ldp,
+                 outs=outs[1:],
+                 defer=all(sl is not None for sl in ctx.vslots[1:5]))])
+        return (gx, None, None, None, g_static, g_cvr, g_caps, g_vote, g_scale,
+                None, None, *gws, *gbs)
+
+
+def chain_votes(x, layers, cpr_static, bias_cvr, bias_caps, bias_vote,
+                bias_scale, noise_caps=None, noise_vote=None, noise_scale=0.,
+                similarity=False, learn_vote_scale=True,
+                allow_deformations=True, defer_reg=False):
+    """``capsule_votes(mlp_chain(x, layers), ...)`` as one launch forward and
+    one launch for the vote + data-gradient half of the backward; returns what
+    ``capsule_votes`` returns."""
+    ws = [w for w, _, _ in layers]
+    bs = [b for _, b, _ in layers]
+    return _ChainVotes.apply(
+        x, tuple(bool(o) for _, _, o in layers),
+        (bool(similarity), bool(learn_vote_scale), bool(allow_deformations),
+         bool(defer_reg)), float(noise_scale), cpr_static, bias_cvr, bias_caps,
+        bias_vote, bias_scale, noise_caps, noise_vote, *ws, *bs)
 
 
 def mlp_chain(x, layers, x_is_relu=False):
