@@ -36,8 +36,22 @@ struct GemmArgs {
 // base); otherwise 4-byte loads.
 template <int SK, bool KC>
 __device__ __forceinline__ void fetch(Quads<Tile<SK>::NQ> &q, const float *X, int ld, int row0,
-                                      int rows, int k0, int K, bool vec) {
+                                      int rows, int k0, int K, bool vec, bool inside) {
   constexpr int T = Tile<SK>::T;
+  if (inside) {   // workgroup-uniform: the whole tile chunk is in range and 16-byte loadable
+#pragma unroll
+    for (int i = 0; i < Tile<SK>::NQ; ++i) {
+      const int id = threadIdx.x + NT * i;
+      if (KC) {
+        q.v[i] = ld4(X + (size_t)(row0 + id / QPR) * ld + k0 + 4 * (id % QPR));
+      } else {
+        int kq, rq;
+        kstr_pos<SK, T>(threadIdx.x, i, kq, rq);
+        q.v[i] = ld4(X + (size_t)(k0 + kq) * ld + row0 + rq);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < Tile<SK>::NQ; ++i) {
     const int id = threadIdx.x + NT * i;
@@ -79,6 +93,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
   const float *A = g.A + z * g.a_batch, *B = g.B + z * g.b_batch;
   const bool avec = (g.lda & 3) == 0 && (g.a_batch & 3) == 0 && ((size_t)g.A & 15) == 0;
   const bool bvec = (g.ldb & 3) == 0 && (g.b_batch & 3) == 0 && ((size_t)g.B & 15) == 0;
+  // tiles whose rows and k chunks all lie inside the operands load without per-quad guards
+  const bool ain = avec && m0 + T <= g.M && g.K % BK == 0;
+  const bool bin = bvec && n0 + T <= g.N && g.K % BK == 0;
   const bool want_asum = !AK && g.asum && blockIdx.x == 0;  // workgroup-uniform
   float4 asum = zero4();
   typename TL::Acc acc[2][2];
@@ -90,8 +107,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
   tile_mainloop<STAGES, SK, AK, BKC>(
       (g.K + BK - 1) / BK, As, Bs, acc, wid, r, q,
       [&](int c, Quads<NQ> &ra, Quads<NQ> &rb) {
-        fetch<SK, AK>(ra, A, g.lda, m0, g.M, c * BK, g.K, avec);
-        fetch<SK, BKC>(rb, B, g.ldb, n0, g.N, c * BK, g.K, bvec);
+        fetch<SK, AK>(ra, A, g.lda, m0, g.M, c * BK, g.K, avec, ain);
+        fetch<SK, BKC>(rb, B, g.ldb, n0, g.N, c * BK, g.K, bvec, bin);
       },
       [&](const Quads<NQ> &ra) {
         if (want_asum) {
