@@ -18,7 +18,6 @@ def run(tag, **env):
         out[name] = [round(l["seconds"] * 1e6, 1) for l in ls] + \
             [round(sum(l["flops"] for l in ls) / sum(l["seconds"] for l in ls) / 1e12, 1)]
     print(tag, json.dumps(out), flush=True)
-run("old", SCAE_K8_FWD=-1, SCAE_K8_DG=-1, SCAE_K8_PAIR=-1, SCAE_K8_WG=-1)
 run("auto")
-for c in (2,):
-    run(f"cfg{c}", SCAE_K8_FWD=c, SCAE_K8_DG=c, SCAE_K8_PAIR=c)
+for c in (int(a) for a in sys.argv[2:]):
+    run(f"fwd cfg{c}", SCAE_K8_FWD=c)

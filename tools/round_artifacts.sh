@@ -17,3 +17,14 @@ timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 python3 $R/tools/step_timeline.py $O/step_kernel_trace.csv > $O/step_sequence.txt 2>&1
 rm -f $O/*_kernel_trace.csv $O/*agent_info.csv
 cat $O/pytest_gpu.txt; head -c 300 $O/bench.json; echo; head -3 $O/step_sequence.txt
+# other workloads: bench line + per-kernel stats of one step (cfg-5, cfg-3 fp32 / bf16)
+for spec in "cifar_32_32_bs256:" "mnist_48_64_bs1024:" "mnist_48_64_bs1024:--bf16"; do
+  WL=${spec%%:*}; EX=${spec#*:}; TAG=$WL${EX:+_bf16}
+  timeout 600 python bench.py $EX --workload $WL --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_$TAG.json 2> /dev/null
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o $TAG -- python3 $R/bench.py $EX --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1)
+  rm -f $O/${TAG}_kernel_trace.csv $O/${TAG}_agent_info.csv $O/${TAG}_domain_stats.csv
+done
+# the rank-launcher + RCCL path on one GPU (1-rank nccl group)
+timeout 600 python bench.py --gpus 1 --force-spawn --steps 100 --no-cpu-baseline --no-roofline 2> /dev/null | grep '^{' > $O/bench_force_spawn.json
+rm -f $O/*_domain_stats.csv
+ls $O
