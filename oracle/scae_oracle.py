@@ -409,8 +409,10 @@ def gmm_mode(loc, scale, mixing_logits, straight_through_gradient=False,
 # ----------------------------------------------------------------------------
 # object_decoder.py
 # ----------------------------------------------------------------------------
-def capsule_layer(P, prefix, feature, cfg, noise_caps=None, noise_vote=None):
-    """CapsuleLayer.forward, object_decoder.py:120-236.
+def capsule_layer(P, prefix, feature, cfg, noise_caps=None, noise_vote=None,
+                  parent_transform=None, parent_presence=None):
+    """CapsuleLayer.forward, object_decoder.py:120-236 (``parent_transform`` /
+    ``parent_presence``: the hierarchical form, :184-187, :214-215).
 
     ``noise_caps`` (B,O,1) / ``noise_vote`` (B,O,V): the two U[0,1) draws of
     object_decoder.py:201 (made at :211 and :212) when noise_type='uniform'.
@@ -440,7 +442,10 @@ def capsule_layer(P, prefix, feature, cfg, noise_caps=None, noise_vote=None):
     cvr, logit_caps, logit_vote, scale = [
         t + P[f'{prefix}.caps_bias_list.{j}']
         for j, t in enumerate(parts[1:])]                   # :176-179
-    cvr = geometric_transform(cvr, sim, nonlinear=True, as_matrix=True)
+    if parent_transform is None:                            # :184-187
+        cvr = geometric_transform(cvr, sim, nonlinear=True, as_matrix=True)
+    else:
+        cvr = parent_transform
     vote = torch.matmul(cvr.repeat(1, 1, V, 1, 1), cpr)     # :189-191
 
     ntype = cfg.get('noise_type', None)
@@ -452,7 +457,9 @@ def capsule_layer(P, prefix, feature, cfg, noise_caps=None, noise_vote=None):
         raise NotImplementedError("oracle: LogisticNormal noise not restated")
     elif ntype:
         raise ValueError(f'Invalid noise type: {ntype}')
-    vote_presence = torch.sigmoid(logit_caps) * torch.sigmoid(logit_vote)
+    presence_per_caps = parent_presence if parent_presence is not None \
+        else torch.sigmoid(logit_caps)                      # :214-217
+    vote_presence = presence_per_caps * torch.sigmoid(logit_vote)
     if cfg.get('learn_vote_scale', False):
         scale = F.softplus(scale + .5) + 1e-2               # :225
     else:

@@ -705,9 +705,58 @@ def op_sparsity():
     save("op_sparsity", blob)
 
 
+def op_capsule_layer_hier():
+    """The hierarchical form of CapsuleLayer.forward: parent_transform replaces
+    the capsule's own OVR (object_decoder.py:184-187), parent_presence its own
+    presence (:214-215).  A file of its own (added in round 2; the other
+    fixtures are unchanged)."""
+    from torch_scae.object_decoder import CapsuleLayer
+    g = torch.Generator().manual_seed(53)
+    blob = {}
+    torch.manual_seed(54)
+    B, O, F, V, D = 3, 4, 10, 5, 6
+    layer = CapsuleLayer(n_caps=O, dim_feature=F, n_votes=V, dim_caps=D,
+                         hidden_sizes=(7,), learn_vote_scale=True,
+                         allow_deformations=True, noise_type="uniform",
+                         noise_scale=4., similarity_transform=False)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    feat = torch.randn(B, O, F, generator=g, requires_grad=True)
+    pt = torch.randn(B, O, 1, 3, 3, generator=g, requires_grad=True)
+    pp = torch.rand(B, O, 1, generator=g, requires_grad=True)
+    grab_params(layer, blob, "layer_param/")
+    with NoiseTap() as tap:
+        res = layer(feat, parent_transform=pt, parent_presence=pp)
+    for i, d in enumerate(tap.draws):
+        blob[f"noise/{i}"] = d
+    tot = res.cpr_dynamic_reg_loss * 0.9
+    for kk in ("vote", "scale", "vote_presence", "presence_logit_per_caps",
+               "presence_logit_per_vote"):
+        w = torch.randn(res[kk].shape, generator=g)
+        blob[f"w/{kk}"] = w
+        tot = tot + (res[kk] * w).sum()
+        blob[f"out/{kk}"] = res[kk]
+    blob["out/cpr_dynamic_reg_loss"] = res.cpr_dynamic_reg_loss
+    tot.backward()
+    for kk, t in (("feature", feat), ("parent_transform", pt),
+                  ("parent_presence", pp)):
+        blob[f"in/{kk}"] = t
+        blob[f"grad/{kk}"] = t.grad
+    for k, p in layer.named_parameters():
+        if p.grad is not None:
+            blob[f"grad/{k}"] = p.grad
+    save("op_capsule_layer_hier", blob)
+
+
 def main():
     ref_gt, gt_oop = import_reference()
     from torch_scae import cv_ops
+    if sys.argv[1:] == ["hier"]:             # only the round-2 fixture
+        cv_ops.geometric_transform = gt_oop
+        op_capsule_layer_hier()
+        return
     op_geometric_transform(ref_gt)          # untouched reference function
     cv_ops.geometric_transform = gt_oop      # needed for every backward below
     op_geometric_transform_grad(gt_oop)
@@ -720,6 +769,7 @@ def main():
     op_sparsity()
     for i, (name, (cfg, batch, train)) in enumerate(MODEL_CASES.items()):
         model_golden(name, cfg, batch, train, seed=100 + i)
+    op_capsule_layer_hier()
 
 
 if __name__ == "__main__":

@@ -293,6 +293,39 @@ def test_capsule_layer_and_decoder_vs_golden(name):
         assert_close(r2[k], ref, ATOL, RTOL, "dec_out " + k)
 
 
+def test_capsule_layer_hierarchical_vs_golden():
+    """CapsuleLayer.forward(feature, parent_transform, parent_presence)
+    (object_decoder.py:184-187, :214-215) against reference-captured vectors."""
+    from torch_scae_amd import nn_ext, nn_utils
+    from torch_scae_amd.object_decoder import CapsuleLayer
+    blob, _ = load("op_capsule_layer_hier")
+    layer = CapsuleLayer(n_caps=4, dim_feature=10, n_votes=5, dim_caps=6,
+                         hidden_sizes=(7,), **CAPS_VARIANTS["default"])
+    layer.load_state_dict(sub(blob, "layer_param/"))
+    layer = layer.cuda()
+    ins = {k: leaf(blob["in/" + k])
+           for k in ("feature", "parent_transform", "parent_presence")}
+    noise = sub(blob, "noise/")
+    with nn_utils.fixed_noise([noise[k] for k in sorted(noise)]):
+        res = layer(ins["feature"], parent_transform=ins["parent_transform"],
+                    parent_presence=ins["parent_presence"])
+    tot = res.cpr_dynamic_reg_loss * 0.9
+    for k, w in sub(blob, "w/").items():
+        tot = tot + (res[k] * w.cuda()).sum()
+    tot.backward()
+    for k, ref in sub(blob, "out/").items():
+        assert_close(res[k], ref, ATOL, RTOL, "out " + k)
+    grads = nn_ext.named_reference_grads(layer)
+    for k, g in sub(blob, "grad/").items():
+        got = ins[k].grad if k in ins else grads[k]
+        assert_close(got, g, GATOL, 2e-4, "grad " + k)
+    # each argument on its own works too
+    with nn_utils.fixed_noise([noise[k] for k in sorted(noise)]):
+        r1 = layer(ins["feature"], parent_presence=ins["parent_presence"])
+    assert_close(r1.vote_presence, blob["out/vote_presence"], ATOL, RTOL,
+                 "presence only")
+
+
 def test_capsule_layer_error_behaviour():
     from torch_scae_amd.object_decoder import CapsuleLayer, sparsity_loss
     x = torch.zeros(2, 3, 4, device="cuda")

@@ -155,6 +155,30 @@ def test_capsule_layer(name):
         assert_close(r2[k], ref, 1e-5, 1e-5, "dec_out " + k)
 
 
+def test_capsule_layer_hierarchical():
+    """parent_transform / parent_presence (object_decoder.py:184-187, :214-215)."""
+    blob, _ = load("op_capsule_layer_hier")
+    cfg = dict(n_caps=4, dim_feature=10, n_votes=5, dim_caps=6,
+               hidden_sizes=(7,), **CAPS_VARIANTS["default"])
+    P = leafify({"L." + k: v for k, v in sub(blob, "layer_param/").items()})
+    ins = {k: blob["in/" + k].clone().requires_grad_(True)
+           for k in ("feature", "parent_transform", "parent_presence")}
+    noise = sub(blob, "noise/")
+    res = O.capsule_layer(P, "L", ins["feature"], cfg, noise.get("0"),
+                          noise.get("1"),
+                          parent_transform=ins["parent_transform"],
+                          parent_presence=ins["parent_presence"])
+    tot = res.cpr_dynamic_reg_loss * 0.9
+    for k, w in sub(blob, "w/").items():
+        tot = tot + (res[k] * w).sum()
+    tot.backward()
+    for k, ref in sub(blob, "out/").items():
+        assert_close(res[k], ref, 1e-5, 1e-5, "out " + k)
+    for k, g in sub(blob, "grad/").items():
+        got = ins[k].grad if k in ins else P["L." + k].grad
+        assert_close(got, g, 1e-5, 1e-4, "grad " + k)
+
+
 def decoder_cases():
     _, meta = load("op_image_decoder")
     return sorted(k for k in meta if not k.startswith("tg_"))

@@ -58,12 +58,7 @@ class CapsuleLayer(nn.Module):
         self.cpr_static = nn.Parameter(
             torch.zeros(1, n_caps, n_votes, self.n_transform_params))
 
-    def _votes(self, feature, parent_transform=None, parent_presence=None,
-               defer_reg=False):
-        if parent_transform is not None or parent_presence is not None:
-            raise NotImplementedError(
-                "hierarchical parent_transform / parent_presence are not used "
-                "by SCAE and not built")
+    def _check_config(self):
         if self.caps_dropout_rate != 0.0:
             # the reference deletes `caps_exist` (:152) before reading it (:196)
             raise NameError("free variable 'caps_exist' referenced before "
@@ -78,6 +73,9 @@ class CapsuleLayer(nn.Module):
                 "The size of tensor a must match the size of tensor b: "
                 "LogisticNormal noise samples have a trailing dimension of 2 "
                 "(noise_type='logistic' fails the same way in the reference)")
+
+    def _votes(self, feature, defer_reg=False):
+        self._check_config()
         B = feature.shape[0]
         # on the HIP path the three stages hand each other gradients w.r.t.
         # PRE-activations (the ReLU gates ride in the GEMM / K3 epilogues)
@@ -119,10 +117,59 @@ class CapsuleLayer(nn.Module):
         """feature [B, O, F] -> AttrDict(vote (B,O,V,3,3), scale,
         vote_presence, presence_logit_per_caps, presence_logit_per_vote,
         cpr_dynamic_reg_loss)."""
+        if parent_transform is not None or parent_presence is not None:
+            return self._forward_hierarchical(feature, parent_transform,
+                                              parent_presence)
         vote6, scale, vote_presence, logit_caps, logit_vote, reg, _, _ = \
-            self._votes(feature, parent_transform, parent_presence)
+            self._votes(feature)
         last_row = vote6.new_tensor([0., 0., 1.]).expand(*vote6.shape[:-1], 3)
         vote = torch.cat([vote6, last_row], -1).view(*vote6.shape[:-1], 3, 3)
+        return AttrDict(vote=vote, scale=scale, vote_presence=vote_presence,
+                        presence_logit_per_caps=logit_caps,
+                        presence_logit_per_vote=logit_vote,
+                        cpr_dynamic_reg_loss=reg)
+
+
+    def _forward_hierarchical(self, feature, parent_transform,
+                              parent_presence):
+        """object_decoder.py:184-187, :214-215: a parent capsule's transform
+        (B,O,1,3,3) stands in for the capsule's own OVR and / or its presence
+        (B,O,1) for the capsule's own.  Not on SCAE's path: the per-capsule
+        MLPs on K7, the pose transform on K5, the 3x3 products on the library."""
+        self._check_config()
+        B = feature.shape[0]
+        raw_caps_param = self.mlps(feature)                       # (B, O, D)
+        all_param = self.caps_mlps(raw_caps_param)                # (B, O, A)
+        parts = [t.reshape(B, self.n_caps, *shape) for t, shape in
+                 zip(torch.split(all_param, self.splits, -1),
+                     self.output_shapes)]
+        cpr_dynamic = parts[0]
+        if not self.allow_deformations:
+            cpr_dynamic = torch.zeros_like(cpr_dynamic)
+        reg = math_ops.l2_loss(cpr_dynamic) / B
+        cpr = ops.geometric_transform(cpr_dynamic + self.cpr_static,
+                                      self.similarity_transform,
+                                      nonlinear=True, as_matrix=True)
+        cvr, logit_caps, logit_vote, scale = [
+            t + bias for t, bias in zip(parts[1:], self.caps_bias_list)]
+        if parent_transform is None:
+            cvr = ops.geometric_transform(cvr, self.similarity_transform,
+                                          nonlinear=True, as_matrix=True)
+        else:
+            cvr = parent_transform
+        vote = torch.matmul(cvr.repeat(1, 1, self.n_votes, 1, 1), cpr)
+        if self.noise_type == 'uniform':
+            logit_caps = logit_caps + (rand_like(logit_caps) - 0.5) \
+                * self.noise_scale
+            logit_vote = logit_vote + (rand_like(logit_vote) - 0.5) \
+                * self.noise_scale
+        presence_per_caps = parent_presence if parent_presence is not None \
+            else torch.sigmoid(logit_caps)
+        vote_presence = presence_per_caps * torch.sigmoid(logit_vote)
+        if self.learn_vote_scale:
+            scale = torch.nn.functional.softplus(scale + .5) + 1e-2
+        else:
+            scale = torch.ones_like(scale)
         return AttrDict(vote=vote, scale=scale, vote_presence=vote_presence,
                         presence_logit_per_caps=logit_caps,
                         presence_logit_per_vote=logit_vote,
