@@ -252,3 +252,20 @@ def test_lazy_attr_dict_materialises_on_first_access():
     assert outer.t == 1 and outer.x == 1
     del outer.x                      # attribute deletion still works
     assert "x" not in outer
+
+
+def test_factory_rejects_configurations_outside_the_kernel_limits():
+    """shape limits of the kernels surface when the model is
+    assembled, with a message, not as SCAE_ERR_UNSUPPORTED at the first forward."""
+    from torch_scae_amd import factory
+    base = dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24,
+                n_obj_caps=24)
+    factory.check_kernel_limits(factory.prepare_model_params(**base))
+    for bad, needle in ((dict(n_part_caps=65), "n_part_caps"),
+                        (dict(n_obj_caps=80), "n_obj_caps"),
+                        (dict(image_shape=(5, 40, 40)), "channels"),
+                        (dict(n_classes=40), "n_classes"),
+                        (dict(pcae_template_generator_params=dict(
+                            template_size=(64, 64))), "th*tw")):
+        with pytest.raises(ValueError, match=needle.replace("*", r"\*")):
+            factory.make_scae(dict(base, **bad))

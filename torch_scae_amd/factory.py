@@ -81,9 +81,51 @@ def prepare_model_params(image_shape, n_classes, n_part_caps, n_obj_caps,
                 scae=scae)
 
 
+# Hard shape limits of the HIP kernels behind the module surface (there is no
+# eager fallback): checked when the model is assembled, not at the first forward.
+KERNEL_LIMITS = dict(
+    n_part_caps=64,         # K2 attention sets, K4 lane groups
+    n_obj_caps=64,          # K4 (O <= 64), K2c seeds
+    n_channels=4,           # K1 template planes
+    template_texels=4096,   # K1: (C + 1) * th * tw floats of LDS per template
+    n_classes=32,           # classifier heads in class_probs / the loss tail
+)
+
+
+def check_kernel_limits(params: dict):
+    """Raise ValueError for a configuration the kernels are not built for
+    (``params``: the output of ``prepare_model_params``)."""
+    lim = KERNEL_LIMITS
+    n_part, n_obj = params["n_part_caps"], params["n_obj_caps"]
+    C = params["image_shape"][0]
+    th, tw = params["pcae_template_generator"]["template_size"]
+    problems = []
+    if n_part > lim["n_part_caps"]:
+        problems.append(f"n_part_caps={n_part} > {lim['n_part_caps']} "
+                        "(attention set size / capsule-likelihood groups)")
+    if n_obj > lim["n_obj_caps"]:
+        problems.append(f"n_obj_caps={n_obj} > {lim['n_obj_caps']} "
+                        "(capsule likelihood, output attention seeds)")
+    if C > lim["n_channels"]:
+        problems.append(f"{C} image channels > {lim['n_channels']} "
+                        "(template render / mixture likelihood)")
+    if (C + 1) * th * tw > lim["template_texels"]:
+        problems.append(f"(C+1)*th*tw = {(C + 1) * th * tw} > "
+                        f"{lim['template_texels']} (template planes in LDS)")
+    ncls = params["n_classes"]
+    if ncls is not None and ncls > lim["n_classes"]:
+        problems.append(f"n_classes={ncls} > {lim['n_classes']} "
+                        "(classifier heads of class_probs / the loss tail)")
+    if problems:
+        raise ValueError("torch_scae_amd's HIP kernels do not cover this "
+                         "configuration: " + "; ".join(problems))
+
+
 def make_scae(model_params: dict):
     """config dict -> wired SCAE (factory.py:152-178)."""
-    cfg = Namespace(**prepare_model_params(**model_params))
+    params = prepare_model_params(**model_params)
+    check_kernel_limits(params)
+    cfg = Namespace(**params)
     part_encoder = CapsuleImageEncoder(
         encoder=CNNEncoder(**cfg.pcae_cnn_encoder), **cfg.pcae_encoder)
     obj_decoder = CapsuleObjectDecoder(CapsuleLayer(**cfg.ocae_decoder_capsule))
