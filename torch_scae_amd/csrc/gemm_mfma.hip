@@ -122,6 +122,29 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
   const float *bias = g.bias ? g.bias + z * g.bias_batch : nullptr;
   const float *mask = g.mask ? g.mask + z * g.mask_batch : nullptr;
   const bool cvec = (g.ldc & 3) == 0 && (g.c_batch & 3) == 0 && ((size_t)g.C & 15) == 0;
+  // (workgroup-uniform) the tile lies inside C and its rows take 16-byte accesses: straight-line
+  // vector epilogue; otherwise the per-element form with its guards
+  const bool cin = cvec && m0 + T <= g.M && n0 + T <= g.N &&
+                   (!mask || ((g.ldmask & 3) == 0 && (g.mask_batch & 3) == 0 &&
+                              ((size_t)g.mask & 15) == 0));
+  if (cin) {
+    tile_epilogue<SK>(smem, acc, wid, r, q, [&](int row, int col, float4 v) {
+      const int m = m0 + row, n = n0 + col;
+      if (bias) {
+        const float *bp = bias + (size_t)n * g.bias_ld;
+        v.x += bp[0], v.y += bp[g.bias_ld], v.z += bp[2 * (size_t)g.bias_ld],
+            v.w += bp[3 * (size_t)g.bias_ld];
+      }
+      if (g.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (craw) *reinterpret_cast<float4 *>(craw + (size_t)m * g.ldc + n) = v;
+      if (mask) {
+        const float4 mk = ld4(mask + (size_t)m * g.ldmask + n);
+        v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
+                        mk.w > 0.f ? v.w : 0.f);
+      }
+      *reinterpret_cast<float4 *>(C + (size_t)m * g.ldc + n) = v;
+    });
+  } else {
   tile_epilogue<SK>(smem, acc, wid, r, q, [&](int row, int col, float4 v4) {
     const int m = m0 + row, n = n0 + col;
     if (m >= g.M || n >= g.N) return;
@@ -144,6 +167,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z)
         if (e < cnt) dst[e] = v[e];
     }
   });
+  }
   if (want_asum) {  // threads tid % (T/4) stage the same 4 rows of A
     __syncthreads();
     reinterpret_cast<float4 *>(smem)[tid] = asum;
