@@ -13,16 +13,19 @@
 //   * forward: one lane owns (pixel, component-subset); the mixture
 //     log-sum-exp is an online (max,sum) pair per lane, merged across the
 //     KSPLIT lanes of a pixel with wavefront xor-shuffles;
-//   * backward: one workgroup per (image, component), two phases per chunk
-//     of output rows.  Phase 1 is pixel-parallel: recompute the component's
-//     responsibility, park d/d(sample) per pixel in LDS, and reduce the 6 pose
-//     gradients / presence gradient with wave shuffles.  Phase 2 is
-//     texel-parallel: each lane owns one template texel and GATHERS the
-//     bilinear-weighted pixel gradients inside the texel's footprint (the
-//     inverse affine image of its +-1 texel support).  No atomics anywhere
-//     (LDS float atomics serialise on the few texels a wave's neighbouring
-//     pixels share: measured 190 us of a 230 us kernel), every output has one
-//     writer and the summation order is fixed, so gradients are bit-reproducible.
+//   * backward: one workgroup per (image, component), pixel-parallel: a lane
+//     recomputes its pixel's responsibility and d/d(sample); the 6 pose
+//     gradients / presence gradient are reduced with wave shuffles; the texel
+//     gradients by a SEGMENTED SCATTER -- the pixels of an image row cross each
+//     texel cell in one contiguous run, so a segmented suffix sum (DPP, within
+//     16-lane rows) leaves each run's weighted sums in its first lane, which
+//     adds them to padded accumulator planes private to its 16-lane row.  When
+//     those planes do not fit LDS (C > 1) the round-1 form runs instead: pixel
+//     gradients parked in LDS, then every (texel, row slice) GATHERS the pixels
+//     of its inverse-affine footprint.  No atomics in either (LDS float adds
+//     cost ~160 cycles per instruction under load, measured twice: 190 us of a
+//     230 us kernel with one add per pixel, 63 of 99 us with one per run),
+//     one writer per address, fixed summation order: bit-reproducible.
 #include "common.h"
 
 namespace {
@@ -32,10 +35,6 @@ using scae::sigmoidf_;
 using scae::softplusf_;
 
 constexpr int NT = 256;
-#ifndef SCAE_K1_SLICES
-#define SCAE_K1_SLICES 8
-#endif
-constexpr int SLICES = SCAE_K1_SLICES;  // row slices per texel in the backward gather
 
 struct Taps {
   int i00, i01, i10, i11;      // texel offsets inside one th*tw plane (clamped)
@@ -417,8 +416,18 @@ __device__ __forceinline__ void clip_range(float centre, float half, int n, int 
   hi = hi_f >= (float)(n - 1) ? n - 1 : (hi_f < 0.f ? -1 : (int)hi_f);
 }
 
+#ifndef SCAE_K1_SLICES
+#define SCAE_K1_SLICES 8
+#endif
+constexpr int SLICES = SCAE_K1_SLICES;  // row slices per texel in the backward gather
+
+// The texel-gather form of the backward (round 1): phase 1 parks d/d(sample) per pixel in
+// LDS, phase 2 gives every (texel, row slice) a lane that collects the bilinear-weighted
+// pixel gradients inside the texel's inverse-affine footprint.  Still the faster form when
+// the per-lane-group accumulator planes of the scatter form below do not fit LDS beside
+// enough workgroups (C > 1: CIFAR 202 vs 309 us).
 template <int C, bool FUSED>
-__global__ __launch_bounds__(NT) void render_bwd_kernel(
+__global__ __launch_bounds__(NT) void render_bwd_gather_kernel(
     scae_decoder_desc d, const float *__restrict__ x, const float *__restrict__ lse_post,
     const float *__restrict__ lse_prior, const float *__restrict__ g_logprob,
     const float *__restrict__ G_tt, const float *__restrict__ G_ml,
@@ -684,6 +693,269 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
         float acc = 0.f;
 #pragma unroll
         for (int sl = 0; sl < SLICES; ++sl) acc += s_acc[(sl * (C + 1) + C) * tsz + e];
+        o_a[e] = acc;
+      }
+    }
+  }
+  if (tid == 0) {
+    float *sp = g_scalar_partial + (size_t)(b * K + k) * 4;
+    sp[0] = sp[1] = sp[2] = sp[3] = 0.f;
+    if (!is_bg) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g_pose[(size_t)(b * M + k) * 6 + i] = acc[i];
+      if (g_presence && d.presence)
+        g_presence[b * M + k] = acc[6] * scae::log_safe_grad(d.presence[b * M + k]);
+    } else {
+      if (!d.bg_image) {
+        const float s = sc.bg_val;
+        sp[0] = acc[7] * s * (1.f - s);
+      }
+      if (alpha_mode) sp[1] = acc[8] * scae::softplus_grad(d.bg_mixing_logit[0]);
+    }
+    if (!alpha_mode) sp[2] = acc[9] * scae::softplus_grad(d.temperature_logit[0] + .5f);
+    if (FUSED && d.out_scale) sp[3] = acc[10] * scae::softplus_grad(d.out_scale[0]);
+  }
+}
+
+
+template <int C, bool FUSED>
+__global__ __launch_bounds__(NT) void render_bwd_kernel(
+    scae_decoder_desc d, const float *__restrict__ x, const float *__restrict__ lse_post,
+    const float *__restrict__ lse_prior, const float *__restrict__ g_logprob,
+    const float *__restrict__ G_tt, const float *__restrict__ G_ml,
+    float *__restrict__ g_templates, float *__restrict__ g_alpha_partial,
+    float *__restrict__ g_pose, float *__restrict__ g_presence,
+    float *__restrict__ g_bg_image, float *__restrict__ g_scalar_partial,
+    int rows_per_chunk, const float *__restrict__ g_tile, int lp_tiles, int lp_ppb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int M = d.M, K = M + 1, W = d.W, H = d.H, HW = H * W, tw = d.tw, th = d.th;
+  const int tsz = th * tw;
+  const bool alpha_mode = d.templates_alpha != nullptr;
+  const int planes = C + (alpha_mode ? 1 : 0);  // gradient planes gathered per texel
+  const Scalars sc = load_scalars(d);
+  const float inv_T = 1.f / sc.temperature;
+  const int psz = pad_elems(th, tw), pw = pad_w(tw);
+  constexpr int NWV = NT / 16;   // accumulator plane sets: one per 16-lane DPP row
+  float *s_tmpl = smem;                        // C padded planes
+  float *s_alpha = s_tmpl + C * psz;           // one padded plane
+  float *s_acc = s_alpha + psz;                // NWV * (C+1) padded planes: per-wave sums
+  float *s_red = s_acc + NWV * (C + 1) * psz;  // 11 * (NT/64)
+
+  const bool is_bg = (k == M);
+  float a[6] = {0, 0, 0, 0, 0, 0};
+  float lsp = 0.f;
+  if (!is_bg) {
+    const float *g_tmpl = d.templates + (size_t)(tb(d, b) * M + k) * C * tsz;
+    stage_padded<NT>(s_tmpl, g_tmpl, C, th, tw);
+    stage_padded<NT>(s_alpha, alpha_mode ? d.templates_alpha + (size_t)k * tsz : nullptr, 1, th,
+                     tw);
+    for (int i = tid; i < NWV * (C + 1) * psz; i += NT) s_acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = d.pose[(size_t)(b * M + k) * 6 + i];
+    lsp = d.presence ? log_safe(d.presence[b * M + k]) : 0.f;
+  }
+  __syncthreads();
+  const float sx = 0.5f * tw, sy = 0.5f * th;
+  const int lane = tid & 63;
+  float *wacc = s_acc + (tid >> 4) * (C + 1) * psz;   // this lane group's planes
+
+  // accumulators: 6 pose grads, d/d log_safe(presence), bg_value, bg_ml,
+  // temperature, sigma
+  float acc[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) acc[i] = 0.f;
+  (void)rows_per_chunk;
+
+  for (int pl0 = 0; pl0 < HW; pl0 += NT) {   // (workgroup-uniform trip count: DPP inside)
+    const int p = pl0 + tid;
+    const bool live = p < HW;
+    PTaps t;
+    t.base = 0, t.fx = t.fy = t.xn = t.yn = 0.f;
+    float gtt[C];
+    float gml_alpha = 0.f;  // alpha mode: grad wrt the (single-channel) logit
+#pragma unroll
+    for (int c = 0; c < C; ++c) gtt[c] = 0.f;
+    if (live) {
+      float tv[C], tdx[C], tdy[C];
+      float av = 0.f, adx = 0.f, ady = 0.f;
+      if (!is_bg) {
+        make_ptaps(a, p, W, H, tw, th, t);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          ptap_value_grad(s_tmpl + c * psz, t, pw, tv[c], tdx[c], tdy[c]);
+        if (alpha_mode) ptap_value_grad(s_alpha, t, pw, av, adx, ady);
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          tv[c] = d.bg_image ? d.bg_image[(size_t)(b * C + c) * HW + p] : sc.bg_val;
+      }
+      if (FUSED) {
+        float mlv = 0.f, sp = 0.f;
+        if (alpha_mode) {
+          mlv = (is_bg ? sc.bg_ml : av + lsp);
+          sp = __expf(mlv - lse_prior[(size_t)b * HW + p]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const size_t o = (size_t)(b * C + c) * HW + p;
+          // per-pixel gradient, or the gradient of the log-prob tile sum the pixel is in
+          const float gc = g_tile ? g_tile[b * lp_tiles + p / lp_ppb] : g_logprob[o];
+          if (!alpha_mode) {
+            mlv = tv[c] / sc.temperature + lsp;
+            sp = __expf(mlv - lse_prior[o]);
+          }
+          const float diff = x[o] - tv[c];
+          const float lp =
+              -(diff * diff) * (0.5f * sc.inv_var) - sc.log_sigma - scae::kHalfLog2Pi;
+          const float w = __expf(lp + mlv - lse_post[o]);
+          gtt[c] = gc * w * diff * sc.inv_var;
+          const float gml = gc * (w - sp);
+          acc[10] += gc * w * (diff * diff * sc.inv_var - 1.f) / sc.sigma;
+          if (alpha_mode) {
+            gml_alpha += gml;
+          } else {
+            gtt[c] += gml * inv_T;
+            acc[9] += -gml * tv[c] * inv_T * inv_T;
+            acc[6] += gml;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          gtt[c] = G_tt ? G_tt[((size_t)(b * K + k) * C + c) * HW + p] : 0.f;
+          if (!alpha_mode && G_ml) {
+            const float gml = G_ml[((size_t)(b * K + k) * C + c) * HW + p];
+            gtt[c] += gml * inv_T;
+            acc[9] += -gml * tv[c] * inv_T * inv_T;
+            acc[6] += gml;
+          }
+        }
+        if (alpha_mode && G_ml) gml_alpha = G_ml[(size_t)(b * K + k) * HW + p];
+      }
+      if (alpha_mode) acc[6] += gml_alpha;
+
+      if (is_bg) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          if (d.bg_image) {
+            if (g_bg_image) g_bg_image[(size_t)(b * C + c) * HW + p] = gtt[c];
+          } else {
+            acc[7] += gtt[c];
+          }
+        }
+        acc[8] += gml_alpha;
+      } else {
+        float gix = gml_alpha * adx, giy = gml_alpha * ady;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          gix += gtt[c] * tdx[c];
+          giy += gtt[c] * tdy[c];
+        }
+        gix *= sx;
+        giy *= sy;
+        acc[0] += gix * t.xn;
+        acc[1] += gix * t.yn;
+        acc[2] += gix;
+        acc[3] += giy * t.xn;
+        acc[4] += giy * t.yn;
+        acc[5] += giy;
+      }
+    }
+    if (is_bg) continue;  // workgroup-uniform: the background has no texels
+
+    // ---- texel gradients: segmented scatter ---------------------------------------
+    // The pixels of an image row cross every texel cell in one contiguous run, so the
+    // lanes (consecutive pixels) that share a cell -- and with it their four bilinear
+    // taps -- are neighbours.  Within each 16-lane DPP row a segmented suffix sum over the
+    // (image row, cell) runs (row_shl 1, 2, 4, 8: VALU-speed lane exchanges) leaves a
+    // run's weighted gradient sums in its first lane, which adds them to padded
+    // accumulator planes private to its lane group (out-of-template taps land in the
+    // padding, like the reads); the groups' planes are summed in a fixed order at the end:
+    // no atomics, one writer per address, bit-reproducible.  (The gather this replaces -- every texel
+    // collecting the pixels of its inverse-affine footprint -- spent ~200 instructions of
+    // interval set-up per (texel, row-slice) item: 46 of the kernel's 82 us.)
+    const int key = live ? ((p / W) << 16) | t.base : -1 - lane;   // (planes: < 2^16 floats)
+    const float wx1 = t.fx, wx0 = 1.f - t.fx, wy1 = t.fy, wy0 = 1.f - t.fy;
+    const float wt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+    float val[4 * (C + 1)];
+#pragma unroll
+    for (int c = 0; c <= C; ++c) {
+      const float gc = c < C ? gtt[c < C ? c : 0] : gml_alpha;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) val[4 * c + q] = gc * wt[q];
+    }
+#define SCAE_SEG_STEP(N)                                                                   \
+  {                                                                                        \
+    const int okey = __builtin_amdgcn_update_dpp(0, key, 0x100 + N, 0xf, 0xf, true);       \
+    const bool same = okey == key;                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4 * (C + 1); ++i) {                              \
+      const float ov = __int_as_float(                                                     \
+          __builtin_amdgcn_update_dpp(0, __float_as_int(val[i]), 0x100 + N, 0xf, 0xf, true)); \
+      val[i] += same ? ov : 0.f;                                                           \
+    }                                                                                      \
+  }
+    SCAE_SEG_STEP(1) SCAE_SEG_STEP(2)
+    // (runs are ~W / tw pixels long: the wider steps only when some run of the wave needs them)
+    if (__any(__builtin_amdgcn_update_dpp(0, key, 0x104, 0xf, 0xf, true) == key)) {
+      SCAE_SEG_STEP(4)
+      if (__any(__builtin_amdgcn_update_dpp(0, key, 0x108, 0xf, 0xf, true) == key)) SCAE_SEG_STEP(8)
+    }
+#undef SCAE_SEG_STEP
+    const int pkey = __builtin_amdgcn_update_dpp(0, key, 0x111, 0xf, 0xf, true);   // row_shr:1
+    const bool leader = live && ((lane & 15) == 0 || pkey != key);
+    {
+      // every 16-lane row has accumulator planes of its own: the leaders of one image
+      // row sit in distinct cells, so a plain read-add-write per tap has one writer per
+      // address; a row of lanes that straddles two image rows (W is not a multiple of 16)
+      // takes them in turn.  The compiler must not fuse the taps of neighbouring
+      // addresses into one 8-byte access (another leader's tap lies in between).
+      const int grow = (pl0 + (tid & ~15)) / W;
+      const bool second = leader && p / W != grow;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !__any(second)) break;   // (wave-uniform) no row of lanes straddles
+        const bool on = pass == 0 ? leader && !second : second;
+        // tap by tap -- neighbouring leaders' taps alias across taps, never within one;
+        // the planes are independent, so their read-add-write chains run side by side
+        const int offs[4] = {0, 1, pw, pw + 1};
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          if (on) {
+            float old[C + 1];
+#pragma unroll
+            for (int c = 0; c <= C; ++c)
+              if (c < planes) old[c] = wacc[c * psz + t.base + offs[q4]];
+#pragma unroll
+            for (int c = 0; c <= C; ++c)
+              if (c < planes) wacc[c * psz + t.base + offs[q4]] = old[c] + val[4 * c + q4];
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  scae::block_sum<11, NT>(acc, s_red);  // ends with __syncthreads()
+
+  if (!is_bg) {   // the waves' padded planes, summed in wave order
+    float *o_t = g_templates + (size_t)(b * M + k) * C * tsz;
+    for (int i = tid; i < C * tsz; i += NT) {
+      const int c = i / tsz, e = i - c * tsz, y = e / tw, xx = e - y * tw;
+      const int at = c * psz + (y + 2) * pw + xx + 2;
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) acc += s_acc[w * (C + 1) * psz + at];
+      o_t[i] = acc;
+    }
+    if (alpha_mode) {
+      float *o_a = g_alpha_partial + (size_t)(b * M + k) * tsz;
+      for (int e = tid; e < tsz; e += NT) {
+        const int y = e / tw, xx = e - y * tw, at = C * psz + (y + 2) * pw + xx + 2;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) acc += s_acc[w * (C + 1) * psz + at];
         o_a[e] = acc;
       }
     }
@@ -981,30 +1253,41 @@ int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post
                float *g_scalar_partial, const float *g_tile, hipStream_t st) {
   const int tsz = d->th * d->tw;
   const LpTiling lt = lp_tiling(d);
-  // per-pixel gradient planes of one chunk of output rows live in LDS
+  // the scatter form needs a set of accumulator planes per 16-lane row beside >= 4
+  // workgroups per CU, and a 16-lane row that spans at most two image rows; else the gather
+  const size_t plane = (size_t)(d->C + 1) * pad_elems(d->th, d->tw);
+  const bool scatter = d->W >= 16 &&
+                       sizeof(float) * ((1 + NT / 16) * plane + 11 * (NT / 64)) <= 40 * 1024;
   int rows = (int)((40 * 1024 / sizeof(float)) / ((size_t)(d->C + 1) * d->W));
   rows = rows < 1 ? 1 : (rows > d->H ? d->H : rows);
-  const size_t lds = sizeof(float) * ((size_t)(d->C + 1) * pad_elems(d->th, d->tw) +
-                                      SLICES * (size_t)(d->C + 1) * tsz + 11 * (NT / 64) +
-                                      (size_t)(d->C + 1) * rows * d->W);
+  const size_t lds =
+      scatter ? sizeof(float) * ((1 + NT / 16) * plane + 11 * (NT / 64))
+              : sizeof(float) * ((size_t)(d->C + 1) * pad_elems(d->th, d->tw) +
+                                 SLICES * (size_t)(d->C + 1) * tsz + 11 * (NT / 64) +
+                                 (size_t)(d->C + 1) * rows * d->W);
   const dim3 grid(d->M + 1, d->B);
   const bool fused = (g_tt == nullptr && g_ml == nullptr);
   int rc;
-  if (fused) {
-    rc = set_lds(render_bwd_kernel<C, true>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((render_bwd_kernel<C, true>), grid, dim3(NT), lds, st, *d, x,
-                       lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,
-                       g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,
-                       rows, g_tile, lt.tiles, lt.ppb);
+#define SCAE_LAUNCH_BWD(KERNEL, FU)                                                          \
+  rc = set_lds(KERNEL<C, FU>, lds);                                                          \
+  if (rc) return rc;                                                                         \
+  hipLaunchKernelGGL((KERNEL<C, FU>), grid, dim3(NT), lds, st, *d, x, lse_post, lse_prior,  \
+                     g_logprob, g_tt, g_ml, g_templates, g_alpha_partial, g_pose, g_presence, \
+                     g_bg_image, g_scalar_partial, rows, g_tile, lt.tiles, lt.ppb)
+  if (scatter) {
+    if (fused) {
+      SCAE_LAUNCH_BWD(render_bwd_kernel, true);
+    } else {
+      SCAE_LAUNCH_BWD(render_bwd_kernel, false);
+    }
   } else {
-    rc = set_lds(render_bwd_kernel<C, false>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((render_bwd_kernel<C, false>), grid, dim3(NT), lds, st, *d, x,
-                       lse_post, lse_prior, g_logprob, g_tt, g_ml, g_templates,
-                       g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,
-                       rows, g_tile, lt.tiles, lt.ppb);
+    if (fused) {
+      SCAE_LAUNCH_BWD(render_bwd_gather_kernel, true);
+    } else {
+      SCAE_LAUNCH_BWD(render_bwd_gather_kernel, false);
+    }
   }
+#undef SCAE_LAUNCH_BWD
   return scae_launch_status();
 }
 }  // namespace
