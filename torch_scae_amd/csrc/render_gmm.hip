@@ -757,6 +757,10 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
   }
   __syncthreads();
   const float sx = 0.5f * tw, sy = 0.5f * th;
+  // integer quotients by run-time divisors through the reciprocal (an integer division
+  // is ~25 instructions; the kernel is VALU-issue bound)
+  const float inv_wf = 1.f / (float)W, inv_ppb = 1.f / (float)lp_ppb;
+  auto fdiv = [](int n, float inv) { return (int)(((float)n + 0.5f) * inv); };
   const int lane = tid & 63;
   float *wacc = s_acc + (tid >> 4) * (C + 1) * psz;   // this lane group's planes
 
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
         for (int c = 0; c < C; ++c) {
           const size_t o = (size_t)(b * C + c) * HW + p;
           // per-pixel gradient, or the gradient of the log-prob tile sum the pixel is in
-          const float gc = g_tile ? g_tile[b * lp_tiles + p / lp_ppb] : g_logprob[o];
+          const float gc = g_tile ? g_tile[b * lp_tiles + fdiv(p, inv_ppb)] : g_logprob[o];
           if (!alpha_mode) {
             mlv = tv[c] / sc.temperature + lsp;
             sp = __expf(mlv - lse_prior[o]);
@@ -875,7 +879,8 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
     // no atomics, one writer per address, bit-reproducible.  (The gather this replaces -- every texel
     // collecting the pixels of its inverse-affine footprint -- spent ~200 instructions of
     // interval set-up per (texel, row-slice) item: 46 of the kernel's 82 us.)
-    const int key = live ? ((p / W) << 16) | t.base : -1 - lane;   // (planes: < 2^16 floats)
+    const int prow = fdiv(p, inv_wf);   // (exact for p < 2^22)
+    const int key = live ? (prow << 16) | t.base : -1 - lane;   // (planes: < 2^16 floats)
     const float wx1 = t.fx, wx0 = 1.f - t.fx, wy1 = t.fy, wy0 = 1.f - t.fy;
     const float wt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
     float val[4 * (C + 1)];
@@ -910,8 +915,8 @@ __global__ __launch_bounds__(NT) void render_bwd_kernel(
       // address; a row of lanes that straddles two image rows (W is not a multiple of 16)
       // takes them in turn.  The compiler must not fuse the taps of neighbouring
       // addresses into one 8-byte access (another leader's tap lies in between).
-      const int grow = (pl0 + (tid & ~15)) / W;
-      const bool second = leader && p / W != grow;
+      const int grow = fdiv(pl0 + (tid & ~15), inv_wf);
+      const bool second = leader && prow != grow;
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1 && !__any(second)) break;   // (wave-uniform) no row of lanes straddles
