@@ -31,15 +31,13 @@ __device__ __forceinline__ float vote_lp(const float *vt, const float *xv, float
 
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  static_assert(G == 16, "one DPP row");
+  return scae::row_sum16(v);
 }
 template <int G>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  static_assert(G == 16, "one DPP row");
+  return scae::row_max16(v);
 }
 template <int G>
 __device__ __forceinline__ int group_min_int(int v) {

@@ -43,15 +43,39 @@ __device__ __forceinline__ float softplus_grad(float x) {
   return x > 20.f ? 1.f : sigmoidf_(x);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// Wave / 16-lane-row reductions without LDS round trips: quad butterflies and the
+// half-row / row mirrors are DPP operand modifiers (VALU speed; a __shfl_xor is a
+// ds_bpermute, ~100 cycles of dependent latency each), the four row sums of a wave meet
+// through v_readlane.  Every lane gets the result; fixed summation order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  v += dpp_f<0x140>(v);   // row_mirror
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
   return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum16(v);
+  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row_max16(v);
+  return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)),
+               fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // Sum `N` per-thread values over a block of NT threads (NT multiple of 64).
