@@ -78,8 +78,8 @@ __device__ __forceinline__ void softmax_masks(float *mask, const float *ys, int 
     float mx = -INFINITY;
     if (ok)
       for (int pix = l; pix < HW; pix += 32) mx = fmaxf(mx, col[pix * APp]);
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = scae::row_max16(mx);   // 32 lanes: two DPP rows + one exchange
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     float s = 0.f;
     if (ok)
       for (int pix = l; pix < HW; pix += 32) {
@@ -87,8 +87,8 @@ __device__ __forceinline__ void softmax_masks(float *mask, const float *ys, int 
         mask[a * HW + pix] = e;
         s += e;
       }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s = scae::row_sum16(s);
+    s += __shfl_xor(s, 16, 64);
     const float inv = 1.f / s;
     if (ok)
       for (int pix = l; pix < HW; pix += 32) mask[a * HW + pix] *= inv;  // own elements
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
     float s = 0.f;
     if (a < A)
       for (int pix = l; pix < HW; pix += 32) s = fmaf(mask[a * HW + pix], t[a * HW + pix], s);
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s = scae::row_sum16(s);
+    s += __shfl_xor(s, 16, 64);
     if (a < A && l == 0) sa[a] = s;
   }
   __syncthreads();

@@ -41,9 +41,8 @@ __device__ __forceinline__ float group_max(float v) {
 }
 template <int G>
 __device__ __forceinline__ int group_min_int(int v) {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
+  static_assert(G == 16, "one DPP row");
+  return scae::row_min16(v);
 }
 
 struct LkArgs {
@@ -177,8 +176,8 @@ __global__ __launch_bounds__(NT) void likelihood_fwd_kernel(
             acc = fmaf(s.ml[o * M + m], a.vp[((size_t)b * O + o) * M + m], acc);
         }
       }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
+      acc += scae::xor1_f(acc);
+      acc += scae::xor2_f(acc);
       if (!live || part != 0) continue;
       const size_t idx = (size_t)b * M + m;
       const int win = (int)s.win[m];
@@ -299,8 +298,8 @@ __global__ __launch_bounds__(NT) void likelihood_bwd_kernel(
         for (int o = part; o < O; o += 4)
           acc -= s.ml[o * M + m] * (xv - a.vote[(((size_t)b * O + o) * M + m) * 6 + i]);
       }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
+      acc += scae::xor1_f(acc);
+      acc += scae::xor2_f(acc);
       if (!live || part != 0) continue;
       const size_t idx = (size_t)b * M + m;
       gx[idx * 6 + i] = acc;

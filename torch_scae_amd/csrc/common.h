@@ -51,6 +51,16 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+// lane ^ 1 / lane ^ 2 within a quad (what __shfl_xor(v, 1 | 2) returns, without the LDS trip)
+__device__ __forceinline__ float xor1_f(float v) { return dpp_f<0xB1>(v); }
+__device__ __forceinline__ float xor2_f(float v) { return dpp_f<0x4E>(v); }
+__device__ __forceinline__ int row_min16(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
+  return v;
+}
 __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]

@@ -211,8 +211,7 @@ __global__ __launch_bounds__(NTC) void tail_combine_kernel(TailArgs a, scae_loss
       for (; b < B; b += 16) t0 += at(b);
       t = (t0 + t1) + (t2 + t3);
     }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    t = scae::row_sum16(t);
     if (c < 2 * O && l == 0) col[c] = ws.col[c] = t;
   }
   scae::block_sum<6, NTC>(v, red);  // (contains the barriers that publish col[])
@@ -305,8 +304,8 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
         t += ws.gl[((size_t)b * 2) * a.ncls + cc] * g_x1 +
              ws.gl[((size_t)b * 2 + 1) * a.ncls + cc] * g_x2;
     }
-    t += __shfl_xor(t, 1, 64);
-    t += __shfl_xor(t, 2, 64);
+    t += scae::xor1_f(t);
+    t += scae::xor2_f(t);
     if (part == 0 && out < nout) {
       if (out < a.ncls * O)
         g_w[out] = t;

@@ -365,14 +365,20 @@ __global__ __launch_bounds__(NT) void logprob_fwd_kernel(
         post[c].add(lp + mlv);
       }
     }
-    // merge the KSPLIT partial (max,sum) pairs of this pixel: wave shuffles
+    // merge the KSPLIT (<= 4) partial (max,sum) pairs of this pixel: the lanes of a pixel
+    // are one quad, so the exchanges are DPP quad permutes (no LDS round trip)
+    static_assert(KSPLIT == 1 || KSPLIT == 2 || KSPLIT == 4, "KSPLIT lanes within a quad");
 #pragma unroll
     for (int off = 1; off < KSPLIT; off <<= 1) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        post[c].merge(__shfl_xor(post[c].m, off, 64), __shfl_xor(post[c].s, off, 64));
-        if (c == 0 || !alpha_mode)
-          prior[c].merge(__shfl_xor(prior[c].m, off, 64), __shfl_xor(prior[c].s, off, 64));
+        if (off == 1) {
+          post[c].merge(scae::xor1_f(post[c].m), scae::xor1_f(post[c].s));
+          if (c == 0 || !alpha_mode) prior[c].merge(scae::xor1_f(prior[c].m), scae::xor1_f(prior[c].s));
+        } else {
+          post[c].merge(scae::xor2_f(post[c].m), scae::xor2_f(post[c].s));
+          if (c == 0 || !alpha_mode) prior[c].merge(scae::xor2_f(prior[c].m), scae::xor2_f(prior[c].s));
+        }
       }
     }
     if (live && kg == 0) {
