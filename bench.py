@@ -57,6 +57,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (MI355X_MICROARCH.md; not the 2:1-sparse figure)
 
 
 def parse():
@@ -249,7 +250,7 @@ def conv_layers(cfg):
     return out
 
 
-def time_k8_kernels(cfg, device, reps=50):
+def time_k8_kernels(cfg, device, reps=50, bf16=False):
     """Average duration of every K8 implicit-GEMM launch of one step (forward,
     data gradient, weight gradient of each encoder layer), timed like the K1
     kernels: raw C-ABI launches on torch's current stream between HIP events."""
@@ -271,14 +272,16 @@ def time_k8_kernels(cfg, device, reps=50):
         part = f(splits * (9 * Co * Ci + Co))
         geo = (I(B), I(IH), I(IH), I(Ci), I(Co), I(s))
         calls = {
-            "conv_fwd_kernel": lambda: lib.scae_conv3x3_fwd_f32(
+            "conv_fwd_kernel": lambda: (lib.scae_conv3x3_fwd_bf16 if bf16
+                                        else lib.scae_conv3x3_fwd_f32)(
                 p(x), p(wf), p(bias), p(y), None, None, *geo, st),
             "conv_dgrad_kernel": lambda: lib.scae_conv3x3_dgrad_f32(
                 p(dy), p(wd), p(x), p(dx), *geo, st),
             "conv_wgrad_kernel": lambda: lib.scae_conv3x3_wgrad_f32(
                 p(dy), p(x), p(part), p(dw), p(db), *geo, st),
             # what the step launches: both gradients of a layer together
-            "conv_bwd_pair_kernel": lambda: lib.scae_conv3x3_bwd_pair_f32(
+            "conv_bwd_pair_kernel": lambda: (lib.scae_conv3x3_bwd_pair_bf16 if bf16
+                                             else lib.scae_conv3x3_bwd_pair_f32)(
                 p(dy), p(wd), p(x), p(dx), p(part), *geo, st),
         }
         flops1 = 2.0 * B * OH * OH * Co * 9 * Ci       # MACs x 2 of one pass
@@ -302,7 +305,7 @@ def time_k8_kernels(cfg, device, reps=50):
     return out
 
 
-def roofline(cfg, device):
+def roofline(cfg, device, bf16=False):
     """Roofline of the dominant hand-written kernel of the step.  By rocprofv3
     total time per step that is the implicit-GEMM backward kernel of the CNN
     encoder (K8, MFMA-bound; data and weight gradient of a layer in one
@@ -313,7 +316,11 @@ def roofline(cfg, device):
     k1 = time_k1_kernels(cfg, device)
     alg = k1_algorithmic_bytes(cfg)
     B = cfg["batch"]
-    k8 = time_k8_kernels(cfg, device)
+    k8 = time_k8_kernels(cfg, device, bf16=bf16)
+    # --bf16: the forward / pair launchers round their operands to bf16 and run on
+    # v_mfma_f32_32x32x16_bf16 -- priced against the dense bf16 peak; the separate dgrad /
+    # wgrad launchers have no bf16 form and stay fp32
+    peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_FP32_PEAK_TFLOPS
     name = "conv_bwd_pair_kernel"
     launches = k8[name]
     secs = sum(l["seconds"] for l in launches)
@@ -325,7 +332,7 @@ def roofline(cfg, device):
     pmc = os.path.join(ROOT, "profiles", "r02", "k8_pmc.json")
     if not os.path.exists(pmc):
         pmc = os.path.join(ROOT, "profiles", "r01", "k8_pmc.json")
-    if os.path.exists(pmc) and cfg is CONFIGS["mnist_24_24_bs128"]:
+    if os.path.exists(pmc) and cfg is CONFIGS["mnist_24_24_bs128"] and not bf16:
         k = json.load(open(pmc))["kernels"].get(name)
         if k:
             traffic = k["hbm_bytes_per_launch_raw"]
@@ -336,13 +343,15 @@ def roofline(cfg, device):
             "bytes_per_image": alg[k]} for k, v in k1.items()}
     for k, ls in k8.items():
         t, fl = sum(l["seconds"] for l in ls), sum(l["flops"] for l in ls)
+        pk = peak if k in ("conv_fwd_kernel", "conv_bwd_pair_kernel") \
+            else MFMA_FP32_PEAK_TFLOPS
         others[k] = {"us_per_step": round(t * 1e6, 2), "launches": len(ls),
                      "bound": "mfma", "TFLOPs": round(fl / t / 1e12, 1),
-                     "frac": round(fl / t / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4)}
+                     "peak": pk, "frac": round(fl / t / 1e12 / pk, 4)}
     return {
         "kernel": name, "bound": "mfma", "achieved": round(achieved, 1),
-        "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / MFMA_FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+        "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic,
         "us_per_launch": round(secs / len(launches) * 1e6, 2),
         "launches_per_step": len(launches),
         "algorithmic_flops_per_launch": flops / len(launches),
@@ -536,12 +545,13 @@ def main():
             },
         }
         if not args.no_roofline:
-            result["roofline"] = roofline(cfg, device)
+            result["roofline"] = roofline(cfg, device, bf16=args.bf16)
             fl, by = step_algorithmic(cfg)
             ips = result["value"] / world        # per GPU
             result["roofline"]["step"] = {
                 "flops_per_image": fl, "hot_bytes_per_image": by,
                 "mfma_frac": round(ips * fl / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
+                "mfma_peak": MFMA_FP32_PEAK_TFLOPS,
                 "hbm_frac": round(ips * by / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "whole step per GPU: images/s x SURVEY.md 8d's "
                         "algorithmic FLOPs (bytes) per image / fp32 MFMA "
