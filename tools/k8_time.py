@@ -19,5 +19,6 @@ def run(tag, **env):
             [round(sum(l["flops"] for l in ls) / sum(l["seconds"] for l in ls) / 1e12, 1)]
     print(tag, json.dumps(out), flush=True)
 run("auto")
-for c in (int(a) for a in sys.argv[2:]):
-    run(f"fwd cfg{c}", SCAE_K8_FWD=c)
+for a in sys.argv[2:]:
+    kind, c = a.split("=")
+    run(a, **{dict(fwd="SCAE_K8_FWD", dg="SCAE_K8_DG", pair="SCAE_K8_PAIR", wg="SCAE_K8_WG")[kind]: int(c)})
