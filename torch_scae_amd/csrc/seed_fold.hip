@@ -36,16 +36,24 @@ template <class G>
 __device__ __forceinline__ float col_dot(const float *W, int C, float *red, G g) {
   const int j = threadIdx.x, part = threadIdx.y, parts = blockDim.y;
   const int per = (C + parts - 1) / parts, cb = part * per, ce = min(C, cb + per);
-  float s[8];
+  // 16 independent (coalesced) row loads in flight per thread: the dot product is a chain of
+  // L2 round trips otherwise
+  constexpr int U = 16;
+  float s[U];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  for (int u = 0; u < U; ++u) s[u] = 0.f;
   int c = cb;
-  for (; c + 8 <= ce; c += 8) {
+  for (; c + U <= ce; c += U) {
+    float w[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] = fmaf(W[(size_t)(c + u) * C + j], g(c + u), s[u]);
+    for (int u = 0; u < U; ++u) w[u] = W[(size_t)(c + u) * C + j];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = fmaf(w[u], g(c + u), s[u]);
   }
   for (; c < ce; ++c) s[0] = fmaf(W[(size_t)c * C + j], g(c), s[0]);
-  const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  float tot = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) tot += s[u];
   red[part * C + j] = tot;
   __syncthreads();
   float out = 0.f;
