@@ -1718,6 +1718,37 @@ def test_chain_votes_matches_chain_then_votes(B, O, V, noise, sim):
                      what=f"grad{i}")
 
 
+@pytest.mark.parametrize("shape,N,bias", [((7, 24, 16), 48, True), ((128, 24, 256), 256, True),
+                                          ((5, 3, 50), 17, False)])
+def test_hip_linear_vs_fp64(shape, N, bias):
+    """ops.HipLinear (the projections / feed-forward layers of the module-by-module
+    set-transformer blocks, set_transformer.py:56-133) on K7 against fp64."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + N)
+    K = shape[-1]
+    lin = ops.HipLinear(K, N, bias=bias)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(N, K, generator=g) / K ** 0.5)
+        if bias:
+            lin.bias.copy_(torch.randn(N, generator=g))
+    x = torch.randn(*shape, generator=g)
+    gy = torch.randn(*shape[:-1], N, generator=g)
+    xr = x.double().requires_grad_()
+    wr = lin.weight.detach().double().requires_grad_()
+    br = lin.bias.detach().double().requires_grad_() if bias else None
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(gy.double())
+    lin = lin.cuda()
+    xh = x.cuda().requires_grad_()
+    yh = lin(xh)
+    yh.backward(gy.cuda())
+    assert_close(yh, yr.float(), 1e-4, 1e-4 * float(yr.abs().max()), "y")
+    assert_close(xh.grad, xr.grad.float(), 1e-4, 1e-4 * float(xr.grad.abs().max()), "gx")
+    assert_close(lin.weight.grad, wr.grad.float(), 1e-4, 1e-4 * float(wr.grad.abs().max()), "gw")
+    if bias:
+        assert_close(lin.bias.grad, br.grad.float(), 1e-4, 1e-4 * float(br.grad.abs().max()), "gb")
+
+
 def test_step_prologue_matches_the_three_launches():
     """scae_step_prologue_f32 = scae_stage_batch + scae_uniform_f32 +
     scae_seed_fold_fwd_f32 in one launch: bit-identical outputs, and the noise

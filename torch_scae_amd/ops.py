@@ -1416,6 +1416,75 @@ class _GroupedMLP(torch.autograd.Function):
         return (gx, None, None, None, None, None, *gws, *gbs)
 
 
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on K7 (fp32 MFMA): the projections / feed-forward layers of
+    the set-transformer blocks that run module by module (multi-head, ISAB,
+    PMA; set_transformer.py:56-104, :107-133).  Forward one launch (bias in the
+    epilogue), backward one (weight + bias gradient and data gradient as a
+    pair)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_hip(x, weight, bias)
+        N, K = weight.shape
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) != K:
+            x2 = x2.contiguous()
+        weight = weight.contiguous()
+        M = x2.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=x.dtype)
+        _gemm(_p(x2), _p(weight), _p(y), 1, M, N, K, True, K, 0, True, K, 0, N,
+              0, bias=_p(_c(bias)), bias_ld=1, bias_b=0, ref=x)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        M = x2.shape[0]
+        gy2 = gy.reshape(M, N)
+        if gy2.stride(1) != 1 or gy2.stride(0) != N:
+            gy2 = gy2.contiguous()
+        gw = _grad_out(ctx.slots[0], weight)
+        gb = _grad_out(ctx.slots[1], weight, (N,)) if ctx.has_bias else None
+        # gW (N x K) = gy^T x: both operands strided along the contraction (rows);
+        # the bias gradient is A's column sum, emitted by the same tiles
+        wgrad = _gemm_desc(_p(gy2), _p(x2), _p(gw), 1, N, K, M, False, N, 0,
+                           False, K, 0, K, 0, asum=_p(gb), asum_b=0, asum_ld=1)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, device=x2.device, dtype=x2.dtype)
+            dgrad = _gemm_desc(_p(gy2), _p(weight), _p(gx), 1, M, K, N, True, N,
+                               0, False, K, 0, K, 0)
+            _gemm_pair(wgrad, dgrad, x2)
+            gx = gx.view(ctx.x_shape)
+        else:
+            gx = None
+            _lib.call("scae_gemm_multi_f32", (_lib.GemmDesc * 1)(wgrad), 1,
+                      _stream(x2))
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """``F.linear`` on the batched MFMA GEMM (K7)."""
+    return _Linear.apply(x, weight, bias)
+
+
+class HipLinear(torch.nn.Linear):
+    """``nn.Linear`` (same parameters, same state_dict keys) whose fp32 CUDA
+    forward / backward run on K7 instead of the BLAS library."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and \
+                self.weight.dtype == torch.float32 and not _MFMA_BF16 and \
+                not torch.is_autocast_enabled("cuda"):
+            return linear(x, self.weight, self.bias)
+        return torch.nn.functional.linear(x, self.weight, self.bias)
+
+
 def mlp_chain_supported(x, layers):
     """The one-launch chain (csrc/mlp_chain.hip) covers fp32, <= 4 layers,
     widths <= scae_mlp_chain_max_width()."""

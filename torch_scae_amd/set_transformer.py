@@ -1,7 +1,8 @@
-"""Set-transformer object encoder on the HIP attention kernel K2 (reference:
-torch_scae/set_transformer.py).  Projections, LayerNorm and the feed-forward
-layer are library ops; the masked softmax(QK^T)V core is ``ops.qkv_attention``
-(fp32 MFMA)."""
+"""Set-transformer object encoder (reference: torch_scae/set_transformer.py).
+Module by module (multi-head, ISAB, PMA -- the default single-head SAB stack
+runs fused, see ``SetTransformer``): projections and the feed-forward layer on
+the batched MFMA GEMM K7 (``ops.HipLinear``), the masked softmax(QK^T)V core
+on ``ops.qkv_attention`` (fp32 MFMA), LayerNorm on the library."""
 import math
 
 import torch
@@ -35,10 +36,10 @@ class MultiHeadQKVAttention(nn.Module):
         self.n_heads = n_heads
         d_k_p = int(math.ceil(d_k / n_heads)) * n_heads
         d_v_p = int(math.ceil(d_v / n_heads)) * n_heads
-        self.q_projector = nn.Linear(d_k, d_k_p)
-        self.k_projector = nn.Linear(d_k, d_k_p)
-        self.v_projector = nn.Linear(d_v, d_v_p)
-        self.o_projector = nn.Linear(d_v_p, d_v)
+        self.q_projector = ops.HipLinear(d_k, d_k_p)
+        self.k_projector = ops.HipLinear(d_k, d_k_p)
+        self.v_projector = ops.HipLinear(d_v, d_v_p)
+        self.o_projector = ops.HipLinear(d_v_p, d_v)
 
     def forward(self, queries, keys, values, presence=None):
         assert queries.shape[2] == keys.shape[2]
@@ -74,7 +75,7 @@ class MAB(nn.Module):
         if layer_norm:
             self.ln0 = nn.LayerNorm(d)
             self.ln1 = nn.LayerNorm(d)
-        self.fc = nn.Linear(d, d)
+        self.fc = ops.HipLinear(d, d)
 
     def forward(self, queries, keys, presence=None):
         h = self.mqkv(queries, keys, keys, presence) + queries
@@ -131,7 +132,7 @@ class SetTransformer(nn.Module):
     def __init__(self, dim_in, dim_hidden, dim_out, n_outputs, n_layers,
                  n_heads, layer_norm=False, n_inducing_points: int = None):
         super().__init__()
-        self.fc1 = nn.Linear(dim_in, dim_hidden)
+        self.fc1 = ops.HipLinear(dim_in, dim_hidden)
         if n_inducing_points is None:
             blocks = [SAB(d=dim_hidden, n_heads=n_heads, layer_norm=layer_norm)
                       for _ in range(n_layers)]
@@ -140,7 +141,7 @@ class SetTransformer(nn.Module):
                            n_inducing_points=n_inducing_points,
                            layer_norm=layer_norm) for _ in range(n_layers)]
         self.sabs = nn.ModuleList(blocks)
-        self.fc2 = nn.Linear(dim_hidden, dim_out)
+        self.fc2 = ops.HipLinear(dim_hidden, dim_out)
         self.seeds = nn.Parameter(torch.zeros(1, n_outputs, dim_out))
         with torch.no_grad():
             nn.init.xavier_uniform_(self.seeds)
