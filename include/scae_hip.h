@@ -221,6 +221,22 @@ int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc, const scae_seed_fold
                            void *stream);
 
 /* ------------------------------------------------------------------------
+ * LayerNorm over the last dimension      replaces nn.LayerNorm(d) of MAB
+ *     (set_transformer.py:114-131) where the blocks run module by module.
+ *     x, y, gy, gx: (rows, d); weight / bias (d) nullable; mean, rstd (rows)
+ *     saved for the backward; d <= 1024.  bwd: gx (nullable) and, when
+ *     `partial` is given, scae_layer_norm_rows(rows) partial rows [gw (d) |
+ *     gb (d)] for the caller to sum (scae_sum_rows_f32).
+ * ---------------------------------------------------------------------- */
+int scae_layer_norm_rows(int64_t rows);
+int scae_layer_norm_fwd_f32(const float *x, const float *weight, const float *bias, float *y,
+                            float *mean, float *rstd, int64_t rows, int d, float eps,
+                            void *stream);
+int scae_layer_norm_bwd_f32(const float *x, const float *weight, const float *mean,
+                            const float *rstd, const float *gy, float *gx, float *partial,
+                            int64_t rows, int d, void *stream);
+
+/* ------------------------------------------------------------------------
  * K7  batched fp32 MFMA GEMM with fused epilogue -- the per-capsule MLPs of
  *     CapsuleLayer (object_decoder.py:86-107, :137-158: a Python loop of 4*O
  *     tiny GEMMs in the reference), forward and backward:

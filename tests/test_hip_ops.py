@@ -1749,6 +1749,39 @@ def test_hip_linear_vs_fp64(shape, N, bias):
         assert_close(lin.bias.grad, br.grad.float(), 1e-4, 1e-4 * float(br.grad.abs().max()), "gb")
 
 
+@pytest.mark.parametrize("shape,affine", [((7, 24, 16), True), ((128, 24, 256), True),
+                                          ((3, 5, 70), True), ((2, 1000), False)])
+def test_hip_layer_norm_vs_fp64(shape, affine):
+    """ops.HipLayerNorm (nn.LayerNorm(d) of MAB, set_transformer.py:114-131)
+    against fp64, outputs and all three gradients."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    d = shape[-1]
+    ln = ops.HipLayerNorm(d, elementwise_affine=affine)
+    if affine:
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(d, generator=g))
+            ln.bias.copy_(torch.randn(d, generator=g))
+    x = torch.randn(*shape, generator=g) * 3 + 1
+    gy = torch.randn(*shape, generator=g)
+    xr = x.double().requires_grad_()
+    wr = ln.weight.detach().double().requires_grad_() if affine else None
+    br = ln.bias.detach().double().requires_grad_() if affine else None
+    yr = torch.nn.functional.layer_norm(xr, (d,), wr, br, ln.eps)
+    yr.backward(gy.double())
+    ln = ln.cuda()
+    xh = x.cuda().requires_grad_()
+    yh = ln(xh)
+    yh.backward(gy.cuda())
+    assert_close(yh, yr.float(), 1e-4, 1e-4 * float(yr.abs().max()), "y")
+    assert_close(xh.grad, xr.grad.float(), 1e-4, 1e-4 * float(xr.grad.abs().max()), "gx")
+    if affine:
+        assert_close(ln.weight.grad, wr.grad.float(), 1e-4,
+                     1e-4 * float(wr.grad.abs().max()), "gw")
+        assert_close(ln.bias.grad, br.grad.float(), 1e-4,
+                     1e-4 * float(br.grad.abs().max()), "gb")
+
+
 def test_step_prologue_matches_the_three_launches():
     """scae_step_prologue_f32 = scae_stage_batch + scae_uniform_f32 +
     scae_seed_fold_fwd_f32 in one launch: bit-identical outputs, and the noise

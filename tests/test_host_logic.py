@@ -52,6 +52,9 @@ def test_launchers_reject_bad_arguments_without_a_gpu():
     assert lib.scae_step_prologue_f32(None, None, 0, None, None, 0, None, 0,
                                       None, None, None) == -1   # nothing to do
     assert lib.scae_gemm_multi_f32(None, 2, None) == -1
+    assert lib.scae_layer_norm_fwd_f32(None, None, None, None, None, None, 4, 16, 1e-5, None) == -1
+    assert lib.scae_layer_norm_bwd_f32(None, None, None, None, None, None, None, 4, 16, None) == -1
+    assert lib.scae_layer_norm_rows(0) == 0 and lib.scae_layer_norm_rows(1000) == 250
     assert lib.scae_gemm_multi_f32((_lib.GemmDesc * 5)(), 5, None) == -1   # > 4
     chain = _lib.MlpChainDesc()
     assert lib.scae_mlp_chain_fwd_f32(None, None) == -1

@@ -144,6 +144,9 @@ SIGNATURES = {
     "scae_seed_fold_supported": [c_int] * 3,
     "scae_seed_fold_fwd_f32": [POINTER(SeedFoldDesc), P],
     "scae_seed_fold_bwd_f32": [POINTER(SeedFoldDesc), POINTER(SeedFoldGrads), P],
+    "scae_layer_norm_rows": [c_int64],
+    "scae_layer_norm_fwd_f32": [P] * 6 + [c_int64, c_int, c_float, P],
+    "scae_layer_norm_bwd_f32": [P] * 7 + [c_int64, c_int, P],
     "scae_gemm_f32": [P] * 6 + [c_int] * 6 + [c_int64, c_int, c_int, c_int64,
                                               c_int, c_int64, c_int, c_int64,
                                               c_int, c_int64, c_int64, c_int, c_int,

@@ -1485,6 +1485,69 @@ class HipLinear(torch.nn.Linear):
         return torch.nn.functional.linear(x, self.weight, self.bias)
 
 
+class _LayerNorm(torch.autograd.Function):
+    """nn.LayerNorm(d) of the module-by-module set-transformer blocks
+    (set_transformer.py:114-131): one wave per row; the weight / bias gradients
+    leave as per-workgroup partial rows summed by ``_sum_rows``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _need_hip(x, weight, bias)
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d).contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=x.dtype)
+        rstd = torch.empty_like(mean)
+        _lib.call("scae_layer_norm_fwd_f32", _p(x2), _p(_c(weight)),
+                  _p(_c(bias)), _p(y), _p(mean), _p(rstd), rows, d, float(eps),
+                  _stream(x))
+        ctx.save_for_backward(x2, mean, rstd, *([weight] if weight is not None
+                                                else []))
+        ctx.has = (weight is not None, bias is not None)
+        ctx.x_shape = x.shape
+        ctx.slots = (_slot(weight) if weight is not None else None,
+                     _slot(bias) if bias is not None else None)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, mean, rstd = ctx.saved_tensors[:3]
+        weight = ctx.saved_tensors[3] if ctx.has[0] else None
+        rows, d = x2.shape
+        gy2 = gy.reshape(rows, d).contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        want_p = ctx.has[0] or ctx.has[1]
+        partial = torch.empty(_lib.load().scae_layer_norm_rows(rows), 2 * d,
+                              device=x2.device, dtype=x2.dtype) \
+            if want_p else None
+        _lib.call("scae_layer_norm_bwd_f32", _p(x2), _p(_c(weight)), _p(mean),
+                  _p(rstd), _p(gy2), _p(gx), _p(partial), rows, d, _stream(x2))
+        gw = gb = None
+        if want_p:
+            outs = [_grad_out(ctx.slots[0], x2, (d,)) if ctx.has[0] else
+                    torch.empty(d, device=x2.device, dtype=x2.dtype),
+                    _grad_out(ctx.slots[1], x2, (d,)) if ctx.has[1] else
+                    torch.empty(d, device=x2.device, dtype=x2.dtype)]
+            gw, gb = _sum_rows(partial, [(d,), (d,)], outs=outs)
+            gw = gw if ctx.has[0] else None
+            gb = gb if ctx.has[1] else None
+        return (None if gx is None else gx.view(ctx.x_shape)), gw, gb, None
+
+
+class HipLayerNorm(torch.nn.LayerNorm):
+    """``nn.LayerNorm`` over the last dimension (same parameters / state_dict
+    keys) on the HIP kernel for fp32 CUDA inputs."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and \
+                len(self.normalized_shape) == 1 and \
+                self.normalized_shape[0] <= 1024 and \
+                not torch.is_autocast_enabled("cuda"):
+            return _LayerNorm.apply(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
 def mlp_chain_supported(x, layers):
     """The one-launch chain (csrc/mlp_chain.hip) covers fp32, <= 4 layers,
     widths <= scae_mlp_chain_max_width()."""

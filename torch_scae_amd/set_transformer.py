@@ -2,7 +2,7 @@
 Module by module (multi-head, ISAB, PMA -- the default single-head SAB stack
 runs fused, see ``SetTransformer``): projections and the feed-forward layer on
 the batched MFMA GEMM K7 (``ops.HipLinear``), the masked softmax(QK^T)V core
-on ``ops.qkv_attention`` (fp32 MFMA), LayerNorm on the library."""
+on ``ops.qkv_attention`` (fp32 MFMA), LayerNorm on ``ops.HipLayerNorm``."""
 import math
 
 import torch
@@ -73,8 +73,8 @@ class MAB(nn.Module):
         self.layer_norm = layer_norm
         self.mqkv = MultiHeadQKVAttention(d_k=d, d_v=d, n_heads=n_heads)
         if layer_norm:
-            self.ln0 = nn.LayerNorm(d)
-            self.ln1 = nn.LayerNorm(d)
+            self.ln0 = ops.HipLayerNorm(d)
+            self.ln1 = ops.HipLayerNorm(d)
         self.fc = ops.HipLinear(d, d)
 
     def forward(self, queries, keys, presence=None):
