@@ -1584,6 +1584,8 @@ def test_stage_batch_one_launch():
     (37, 3, 50, [37, 12, 29, 45], 2),          # ragged everything, scalar weight loads
     (16, 2, 64, [8, 4, 8, 31], 2),             # the smoke model's widths
     (70, 5, 96, [64, 40], None),               # a two-layer chain, no ones column
+    (40, 2, 300, [200, 70, 33, 391], 2),       # 3 k-chunks, several tiles per wave, cfg-3's width
+    (20, 3, 704, [130, 7], None),              # the widest input the kernel takes
 ])
 def test_mlp_chain_vs_fp64(B, G, Kin, dims, ones_at):
     """K7b (object_decoder.py:86-107, :137-158, the cat with caps_exist of
