@@ -492,6 +492,11 @@ def test_step_prologue_gives_the_same_step():
         for a, b in zip(draws, draws[1:]):
             assert not torch.equal(a, b)
         assert 0.0 <= float(draws[-1].min()) and float(draws[-1].max()) < 1.0
+        # the logging form re-captures the step; the prologue keeps feeding it
+        out = s2.training_step(images[0], labels[0])
+        out = s2.training_step(images[1], labels[1])
+        assert np.isfinite(float(out["loss"])) and "accuracy" in out["log"]
+        assert all(np.isfinite(float(v)) for v in out["log"].values())
 
 
 def test_recon_mse_term_sends_gradient_like_the_oracle():
