@@ -140,7 +140,11 @@ inline int dgrad_axis(int I, int O, int stride, unsigned char *mask, short *coun
     return m;
   };
   int n = 0, pos = 0;
-  for (int want = 0; want < (stride == 1 ? 8 : stride); ++want) {
+  // classes in order of decreasing tap count: the tiles with the longest K loops (the
+  // interior, 3 x 3 taps) are dispatched first, the one-tap corners fill the tail
+  static const int by_taps[8] = {7, 3, 5, 6, 1, 2, 4, 0};
+  for (int wi = 0; wi < (stride == 1 ? 8 : stride); ++wi) {
+    const int want = stride == 1 ? by_taps[wi] : wi;
     int cnt = 0, m = 0;
     for (int i = 0; i < I; ++i)
       if ((stride == 1 ? taps(i) : i % stride) == want) {
