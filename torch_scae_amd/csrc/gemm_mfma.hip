@@ -314,43 +314,7 @@ static int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
   return SCAE_OK;
 }
 
-static int gemm_pair_impl(const scae_gemm_desc *first, const scae_gemm_desc *second, bool bf16,
-                          void *stream) {
-  GemmPair p;
-  int rc = fill_args(p.g[0], first);
-  if (rc) return rc;
-  rc = fill_args(p.g[1], second);
-  if (rc) return rc;
-  p.nz0 = first->batch;
-  p.layout[0] = 2 * (first->a_kcontig != 0) + (first->b_kcontig != 0);
-  p.layout[1] = 2 * (second->a_kcontig != 0) + (second->b_kcontig != 0);
-  const int M = first->M > second->M ? first->M : second->M;
-  const int N = first->N > second->N ? first->N : second->N;
-  const long tiles64 = (long)((first->N + 63) / 64) * ((first->M + 63) / 64) * first->batch +
-                       (long)((second->N + 63) / 64) * ((second->M + 63) / 64) * second->batch;
-  const int nz = first->batch + second->batch;
-  if (bf16 && bf16_shape(first->M, first->N) && bf16_shape(second->M, second->N))
-    hipLaunchKernelGGL(gemm_pair_kernel<3>, dim3((N + 127) / 128, (M + 127) / 128, nz), dim3(NT),
-                       0, (hipStream_t)stream, p);
-  else if (tiles64 < kSplitKBelow)
-    hipLaunchKernelGGL(gemm_pair_kernel<1>, dim3((N + 31) / 32, (M + 31) / 32, nz), dim3(NT),
-                       0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(gemm_pair_kernel<0>, dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(NT),
-                       0, (hipStream_t)stream, p);
-  return scae_launch_status();
-}
-
-extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second,
-                                  void *stream) {
-  return gemm_pair_impl(first, second, false, stream);
-}
-extern "C" int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_desc *second,
-                                   void *stream) {
-  return gemm_pair_impl(first, second, true, stream);
-}
-
-extern "C" int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *stream) {
+static int gemm_multi_impl(const scae_gemm_desc *descs, int n, void *stream) {
   SCAE_REQUIRE(descs && n >= 1 && n <= 4);
   GemmMulti p{};
   p.n = n;
@@ -371,4 +335,40 @@ extern "C" int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *str
   else
     hipLaunchKernelGGL(gemm_multi_kernel<0>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
   return scae_launch_status();
+}
+
+static int gemm_pair_impl(const scae_gemm_desc *first, const scae_gemm_desc *second, bool bf16,
+                          void *stream) {
+  SCAE_REQUIRE(first && second);
+  if (!(bf16 && bf16_shape(first->M, first->N) && bf16_shape(second->M, second->N))) {
+    const scae_gemm_desc both[2] = {*first, *second};
+    return gemm_multi_impl(both, 2, stream);   // exactly the tiles that exist
+  }
+  GemmPair p;
+  int rc = fill_args(p.g[0], first);
+  if (rc) return rc;
+  rc = fill_args(p.g[1], second);
+  if (rc) return rc;
+  p.nz0 = first->batch;
+  p.layout[0] = 2 * (first->a_kcontig != 0) + (first->b_kcontig != 0);
+  p.layout[1] = 2 * (second->a_kcontig != 0) + (second->b_kcontig != 0);
+  const int M = first->M > second->M ? first->M : second->M;
+  const int N = first->N > second->N ? first->N : second->N;
+  hipLaunchKernelGGL(gemm_pair_kernel<3>, dim3((N + 127) / 128, (M + 127) / 128,
+                                               first->batch + second->batch),
+                     dim3(NT), 0, (hipStream_t)stream, p);
+  return scae_launch_status();
+}
+
+extern "C" int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second,
+                                  void *stream) {
+  return gemm_pair_impl(first, second, false, stream);
+}
+extern "C" int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_desc *second,
+                                   void *stream) {
+  return gemm_pair_impl(first, second, true, stream);
+}
+
+extern "C" int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *stream) {
+  return gemm_multi_impl(descs, n, stream);
 }
