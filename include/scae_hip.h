@@ -524,6 +524,29 @@ int scae_step_prologue_f32(float *dst_image, const float *src_image, int64_t n_i
                            float *noise, int64_t n_noise, uint64_t *noise_state,
                            const scae_seed_fold_desc *fold, void *stream);
 
+/* ... with a fourth job: the image layer of the CNN encoder and the filter re-layouts
+ * of its other layers (the arguments of scae_conv3x3_first_fwd_relayout_f32;
+ * part_encoder.py:26-44).  `img` is the batch wherever the caller holds it (the
+ * hand-over's source or its destination: the layer does not wait for the copy).
+ * first == NULL: scae_step_prologue_f32. */
+typedef struct scae_first_layer_desc {
+  const float *img;   /* (B, Cin, IH, IW) */
+  const float *w;     /* (Cout, Cin, 3, 3) */
+  const float *bias;  /* (Cout) */
+  float *out;         /* (B, OH, OW, Cout) NHWC, ReLU applied */
+  int B, Cin, IH, IW, Cout, stride;
+  int n_layers;       /* re-layouts riding along (0..8) */
+  const float *rw[8]; /* (rCout, rCin, 3, 3) each */
+  float *rwf[8];      /* (rCout, 9, rCin) */
+  float *rwd[8];      /* (rCin, 9, rCout) */
+  int rCout[8], rCin[8];
+} scae_first_layer_desc;
+int scae_step_prologue_first_f32(float *dst_image, const float *src_image, int64_t n_image,
+                                 int64_t *dst_label, const int64_t *src_label,
+                                 int64_t n_label, float *noise, int64_t n_noise,
+                                 uint64_t *noise_state, const scae_seed_fold_desc *fold,
+                                 const scae_first_layer_desc *first, void *stream);
+
 /* ------------------------------------------------------------------------
  * K10  coloured templates      replaces TemplateGenerator.forward,
  *      part_decoder.py:78-110 (colorize_templates = True):

@@ -1845,6 +1845,67 @@ def test_step_prologue_matches_the_three_launches():
     assert torch.equal(di, image) and torch.equal(dl, label)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C0", [1, 3])
+def test_step_prologue_runs_the_image_layer(C0):
+    """The encoder's image layer + filter re-layouts as a fourth job of the
+    prologue launch (scae_step_prologue_first_f32): the conv stack then finds its
+    first activation and the re-laid filters already there -- bit-identical to
+    the stack's own launch -- reads the batch at the hand-over's SOURCE, and
+    gradients are unchanged."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H = 16, 20
+    chans, strides = [C0, 64, 128, 64], (2, 1, 1)
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
+          for ci, co in zip(chans[:-1], chans[1:])]
+    bs = [(0.1 * torch.randn(co, generator=g)).cuda() for co in chans[1:]]
+    batches = [torch.rand(B, C0, H, H, generator=g).cuda() for _ in range(3)]
+    label = torch.zeros(B, dtype=torch.int64).cuda()
+    resident, rl = torch.zeros_like(batches[0]), torch.zeros_like(label)
+
+    def run(image, wlist, blist):
+        return ops.conv_stack(image, wlist, blist, strides)
+
+    refs = [run(x, ws, bs).clone() for x in batches]
+    pro = ops.StepPrologue()
+    with ops.step_prologue(pro):
+        resident.copy_(batches[0])
+        y0 = run(resident, ws, bs)            # registers the layer, launches itself
+        assert torch.equal(y0, refs[0]) and pro.first_outs is not None
+        for t in (pro.first_outs[0], *pro.first_outs[1], *pro.first_outs[2]):
+            t.fill_(float("nan"))
+        pro.launch(resident, batches[1], rl, label)   # hand-over + image layer
+        assert torch.equal(resident, batches[1]) and pro.first_fresh
+        y1 = run(resident, ws, bs)            # no image-layer launch of its own
+        assert not pro.first_fresh and torch.equal(y1, refs[1])
+        resident.copy_(batches[2])
+        y2 = run(resident, ws, bs)            # consumed: launches again
+        assert torch.equal(y2, refs[2])
+        pro.launch()                          # refresh without a batch: the resident image
+        assert pro.first_fresh
+        assert torch.equal(run(resident, ws, bs), refs[2])
+        # another image tensor: not the registered layer, its own launch
+        pro.launch()
+        assert torch.equal(run(batches[0], ws, bs), refs[0])
+        # gradients through the prologue-filled activation
+        win = [w.clone().requires_grad_() for w in ws]
+        bin_ = [b.clone().requires_grad_() for b in bs]
+        pro2 = ops.StepPrologue()
+        with ops.step_prologue(pro2):
+            run(resident, win, bin_)
+            pro2.launch()
+            y = run(resident, win, bin_)
+        wref = [w.clone().requires_grad_() for w in ws]
+        bref = [b.clone().requires_grad_() for b in bs]
+        yr = run(resident, wref, bref)
+        gy = torch.randn(y.shape, generator=g).cuda()
+        y.backward(gy)
+        yr.backward(gy)
+        for a, b in zip(win + bin_, wref + bref):
+            assert torch.equal(a.grad, b.grad)
+
+
 # --------------------------------------------------------------------------
 # configs[2]'s precision: bf16 operands / fp32 accumulation on K7 and K8
 # (ops.mfma_bf16), against fp64 at bf16's bar

@@ -51,6 +51,9 @@ def test_launchers_reject_bad_arguments_without_a_gpu():
                                       None, None, None) == -1
     assert lib.scae_step_prologue_f32(None, None, 0, None, None, 0, None, 0,
                                       None, None, None) == -1   # nothing to do
+    first = _lib.FirstLayerDesc()                                # null image / filters
+    assert lib.scae_step_prologue_first_f32(None, None, 0, None, None, 0, None, 0,
+                                            None, None, first, None) == -1
     assert lib.scae_gemm_multi_f32(None, 2, None) == -1
     assert lib.scae_layer_norm_fwd_f32(None, None, None, None, None, None, 4, 16, 1e-5, None) == -1
     assert lib.scae_layer_norm_bwd_f32(None, None, None, None, None, None, None, 4, 16, None) == -1

@@ -103,6 +103,15 @@ class SeedFoldDesc(Structure):
         [("O", c_int), ("C", c_int), ("D", c_int)]
 
 
+class FirstLayerDesc(Structure):
+    """struct scae_first_layer_desc"""
+    _fields_ = [("img", P), ("w", P), ("bias", P), ("out", P)] + \
+        [(n, c_int) for n in ("B", "Cin", "IH", "IW", "Cout", "stride",
+                              "n_layers")] + \
+        [("rw", P * 8), ("rwf", P * 8), ("rwd", P * 8),
+         ("rCout", c_int * 8), ("rCin", c_int * 8)]
+
+
 class SeedFoldGrads(Structure):
     """struct scae_seed_fold_grads"""
     _fields_ = [(n, P) for n in (
@@ -184,6 +193,9 @@ SIGNATURES = {
     "scae_stage_batch": [P, P, c_int64, P, P, c_int64, P],
     "scae_step_prologue_f32": [P, P, c_int64, P, P, c_int64, P, c_int64, P,
                                POINTER(SeedFoldDesc), P],
+    "scae_step_prologue_first_f32": [P, P, c_int64, P, P, c_int64, P, c_int64,
+                                     P, POINTER(SeedFoldDesc),
+                                     POINTER(FirstLayerDesc), P],
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
                               c_float, c_float, c_float, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],

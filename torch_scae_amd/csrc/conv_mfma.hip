@@ -26,13 +26,12 @@
 
 #include "mfma_tile.h"
 #include "mfma_pipe.h"
+#include "conv_first_dev.h"
 
 namespace {
 using namespace scae_tile;
 
-struct ConvGeom {
-  int B, IH, IW, OH, OW, Cin, Cout, stride;
-};
+using scae_first::ConvGeom;
 
 // MODE: workgroup shape of mfma_tile.h (a `bool SK` argument selects 0 / 1);
 // `smem` (Tile<MODE>::SMEM floats of LDS) is supplied by the enclosing kernel
@@ -689,20 +688,9 @@ __global__ void relayout_weights_kernel(const float *__restrict__ w, float *__re
   wd[((size_t)ci * 9 + tap) * Cout + co] = v;
 }
 
-// the same for up to 8 layers in one launch (blockIdx.y = layer)
-struct RelayoutBatch {
-  const float *w[8];
-  float *wf[8], *wd[8];
-  int Cout[8], Cin[8];
-};
-__device__ __forceinline__ void relayout_batch(const RelayoutBatch &r, int l, int e) {
-  const int Cout = r.Cout[l], Cin = r.Cin[l];
-  if (e >= Cout * Cin * 9) return;
-  const int co = e / (Cin * 9), rem = e - co * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
-  const float v = r.w[l][e];
-  r.wf[l][((size_t)co * 9 + tap) * Cin + ci] = v;
-  r.wd[l][((size_t)ci * 9 + tap) * Cout + co] = v;
-}
+// (RelayoutBatch / relayout_batch: conv_first_dev.h)
+using scae_first::RelayoutBatch;
+using scae_first::relayout_batch;
 __global__ void relayout_batch_kernel(RelayoutBatch r) {
   relayout_batch(r, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -745,27 +733,10 @@ __global__ void reduce_wgrad_batch_kernel(ReduceBatch r) {
 // One workgroup per (image, pixel slice): the image is staged in LDS, each wave
 // owns 64 output channels (lane = channel: NHWC stores / loads are 256-byte
 // coalesced rows) and, when C_out < 256, a share of the slice's pixels.
-struct FirstSplit {
-  int nchunk, parts, slices;
-};
-__host__ __device__ inline FirstSplit first_split(int B, int Cout) {
-  FirstSplit f;
-  f.nchunk = Cout / 64;
-  f.parts = (f.nchunk <= 4 && 4 % f.nchunk == 0) ? 4 / f.nchunk : 1;
-  int s = (512 + B - 1) / B;  // >= 512 workgroups
-  f.slices = s < 1 ? 1 : (s > 8 ? 8 : s);
-  return f;
-}
-
-// the lane = (pixel, channel quad) forms of the two image-layer kernels: C_out / 4 lanes
-// per pixel must divide a wave
-__host__ __device__ inline bool first_vec(int Cout) {
-  return Cout == 64 || Cout == 128 || Cout == 256;
-}
-__device__ __forceinline__ void stage_image(float *s_img, const float *img, int n, int count) {
-  for (int e = threadIdx.x; e < count; e += 256) s_img[e] = img[(size_t)n * count + e];
-  __syncthreads();
-}
+using scae_first::FirstSplit;
+using scae_first::first_split;
+using scae_first::first_vec;
+using scae_first::stage_image;
 
 // image NCHW (B,Cin,IH,IW), w [Cout][Cin][3][3] -> out NHWC, ReLU
 // Riders: the filter re-layouts of the following layers (RelayoutBatch, parameter-only,
@@ -784,70 +755,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__rest
     relayout_batch(rl, w_ / rb, (w_ % rb) * 256 + threadIdx.x);
     return;
   }
-  const FirstSplit f = first_split(g.B, g.Cout);
-  const int n = blockIdx.x / f.slices, slice = blockIdx.x % f.slices;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  stage_image(s_img, img, n, CIN * g.IH * g.IW);
-  const int P = g.OH * g.OW, per = (P + f.slices - 1) / f.slices;
-  const int pbeg = slice * per, pend = min(P, pbeg + per);
-  if (first_vec(g.Cout)) {
-    // lane = (pixel of the pass, channel quad): a wave stores 1 KiB of consecutive NHWC
-    // floats per instruction (lane-per-channel dword stores left the kernel at a third of
-    // the write bandwidth)
-    const int QL = g.Cout / 4, PPW = 64 / QL, cq = lane % QL, ps = lane / QL;
-    float wr[4][CIN * 9], b4[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-      for (int k = 0; k < CIN * 9; ++k) wr[c][k] = w[(size_t)(4 * cq + c) * CIN * 9 + k];
-      b4[c] = bias[4 * cq + c];
-    }
-    const int step = 4 * PPW;
-    int p = pbeg + wave * PPW + ps;
-    int oh = p / g.OW, ow = p - oh * g.OW;
-    float *dst = out + ((size_t)n * P + p) * g.Cout + 4 * cq;
-    for (; p < pend; p += step) {
-      const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
-      float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
-#pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const float x = src[(ci * g.IH + t / 3) * g.IW + t % 3];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = fmaf(x, wr[c][ci * 9 + t], acc[c]);
-        }
-      *reinterpret_cast<float4 *>(dst) = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f),
-                                                     fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-      dst += (size_t)step * g.Cout;
-      ow += step;
-      while (ow >= g.OW) ow -= g.OW, ++oh;
-    }
-    return;
-  }
-  for (int wi = wave; wi < f.nchunk * f.parts; wi += 4) {
-    const int co = (wi % f.nchunk) * 64 + lane, part = wi / f.nchunk;
-    float wr[CIN * 9];
-#pragma unroll
-    for (int k = 0; k < CIN * 9; ++k) wr[k] = w[(size_t)co * CIN * 9 + k];
-    const float b = bias[co];
-    // (oh, ow) of pixel p carried along instead of divided out per pixel
-    int oh = (pbeg + part) / g.OW, ow = (pbeg + part) - oh * g.OW;
-    float *dst = out + ((size_t)n * P + pbeg + part) * g.Cout + co;
-    for (int p = pbeg + part; p < pend; p += f.parts) {
-      const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
-      float acc = b;
-#pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-          acc = fmaf(src[(ci * g.IH + t / 3) * g.IW + t % 3], wr[ci * 9 + t], acc);
-      *dst = fmaxf(acc, 0.f);
-      dst += (size_t)f.parts * g.Cout;
-      ow += f.parts;
-      while (ow >= g.OW) ow -= g.OW, ++oh;
-    }
-  }
+  scae_first::fwd_block<CIN>(img, w, bias, out, g, blockIdx.x, s_img);
 }
 
 // weight/bias gradient partials: partial[(n*slices + slice)*parts + part] = one row
@@ -1010,18 +918,7 @@ extern "C" int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, i
   return scae_launch_status();
 }
 
-// fills a RelayoutBatch; returns the workgroups (of 256 elements) per layer or < 0
-static int fill_relayout(RelayoutBatch &r, int n_layers, const float *const *w, float *const *wf,
-                         float *const *wd, const int *Cout, const int *Cin) {
-  if (!(n_layers > 0 && n_layers <= 8 && w && wf && wd && Cout && Cin)) return -1;
-  int nmax = 0;
-  for (int l = 0; l < n_layers; ++l) {
-    if (!(w[l] && wf[l] && wd[l] && Cout[l] > 0 && Cin[l] > 0)) return -1;
-    r.w[l] = w[l], r.wf[l] = wf[l], r.wd[l] = wd[l], r.Cout[l] = Cout[l], r.Cin[l] = Cin[l];
-    nmax = nmax > Cout[l] * Cin[l] * 9 ? nmax : Cout[l] * Cin[l] * 9;
-  }
-  return (nmax + 255) / 256;
-}
+using scae_first::fill_relayout;
 
 extern "C" int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const *w,
                                                float *const *wf, float *const *wd,

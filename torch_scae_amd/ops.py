@@ -126,7 +126,25 @@ class StepPrologue:
     def __init__(self):
         self.noise = self.noise_state = None
         self.fold_inputs = self.fold_outs = self.fold_dims = None
-        self.noise_fresh = self.fold_fresh = False
+        # the encoder's image layer: (image, weights, biases, strides) it was
+        # last computed from, its persistent outputs (act, wfs, wds)
+        self.first_inputs = self.first_outs = None
+        self.noise_fresh = self.fold_fresh = self.first_fresh = False
+
+    def _first_desc(self, image):
+        """scae_first_layer_desc of the registered image layer over ``image``."""
+        _, weights, biases, strides = self.first_inputs
+        act, wfs, wds = self.first_outs
+        d = _lib.FirstLayerDesc()
+        d.img, d.w, d.bias, d.out = image.data_ptr(), weights[0].data_ptr(), \
+            biases[0].data_ptr(), act.data_ptr()
+        d.B, d.Cin, d.IH, d.IW = image.shape
+        d.Cout, d.stride, d.n_layers = weights[0].shape[0], strides[0], len(wfs)
+        for i, (w, wf, wd) in enumerate(zip(weights[1:], wfs, wds)):
+            d.rw[i], d.rwf[i], d.rwd[i] = w.data_ptr(), wf.data_ptr(), \
+                wd.data_ptr()
+            d.rCout[i], d.rCin[i] = w.shape[0], w.shape[1]
+        return d
 
     def launch(self, dst_image=None, src_image=None, dst_label=None,
                src_label=None, stream_ref=None):
@@ -134,26 +152,36 @@ class StepPrologue:
         whatever of noise / folding this prologue has buffers for."""
         stage = dst_image is not None
         n_noise = 0 if self.noise is None else self.noise.numel()
-        if not (stage or n_noise or self.fold_outs is not None):
+        # the image layer runs here when the batch it will be asked for is the
+        # one at hand: the hand-over's destination, read at its source
+        first = self.first_outs is not None and (
+            not stage or (dst_image.data_ptr() == self.first_inputs[0].data_ptr()
+                          and dst_image.shape == self.first_inputs[0].shape))
+        if not (stage or n_noise or self.fold_outs is not None or first):
             return
         ref = dst_image if stage else (
-            self.noise if n_noise else self.fold_outs[0])
+            self.noise if n_noise else (self.fold_outs[0] if self.fold_outs
+                                        is not None else self.first_outs[0]))
         _need_hip(ref)
         P = ctypes.c_void_p
-        desc = None
+        desc = fdesc = None
         if self.fold_outs is not None:
             desc = ctypes.byref(_fold_desc(self.fold_inputs, self.fold_outs,
                                            *self.fold_dims))
-        _lib.call("scae_step_prologue_f32",
+        if first:
+            fdesc = ctypes.byref(self._first_desc(
+                src_image if stage else self.first_inputs[0]))
+        _lib.call("scae_step_prologue_first_f32",
                   _p(dst_image), _p(src_image),
                   dst_image.numel() if stage else 0,
                   P(dst_label.data_ptr()) if stage else None,
                   P(src_label.data_ptr()) if stage else None,
                   dst_label.numel() if stage else 0,
-                  _p(self.noise), n_noise, _p(self.noise_state), desc,
+                  _p(self.noise), n_noise, _p(self.noise_state), desc, fdesc,
                   _stream(ref))
         self.noise_fresh = self.noise is not None
         self.fold_fresh = self.fold_outs is not None
+        self.first_fresh = first
 
 
 _PROLOGUE = None
@@ -744,21 +772,43 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=image.dtype)
     c1, s = weights[0].shape[0], strides[0]
     oh, ow = (H - 3) // s + 1, (W - 3) // s + 1
-    act = new(B, oh, ow, c1)
-    acts, wds, wfs = [act], [], []
-    for l in range(1, L):
-        co, ci = weights[l].shape[0], weights[l].shape[1]
-        wfs.append(new(co, 9, ci))
-        wds.append(new(ci, 9, co))
+    pro, launch = _PROLOGUE, True
+    key = lambda ts: [(t.data_ptr(), tuple(t.shape)) for t in ts]
+    if pro is not None and pro.first_outs is not None and \
+            key([image, *weights, *biases]) == key(
+                [pro.first_inputs[0], *pro.first_inputs[1],
+                 *pro.first_inputs[2]]) and \
+            tuple(strides) == pro.first_inputs[3]:
+        # persistent outputs: filled by the step's prologue launch (fresh),
+        # else by the launch below
+        act, wfs, wds = pro.first_outs
+        launch = not pro.first_fresh
+    else:
+        act = new(B, oh, ow, c1)
+        wds, wfs = [], []
+        for l in range(1, L):
+            co, ci = weights[l].shape[0], weights[l].shape[1]
+            wfs.append(new(co, 9, ci))
+            wds.append(new(ci, 9, co))
+        if pro is not None:
+            pro.first_inputs = (image, list(weights), list(biases),
+                                tuple(strides))
+            pro.first_outs = (act, wfs, wds)
+    if pro is not None:
+        pro.first_fresh = False
+    acts = [act]
     # the image layer; the (parameter-only) filter re-layouts of the other
     # layers ride in the same launch
     n = L - 1
-    arr = lambda ts: (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in ts])
-    ints = lambda v: (ctypes.c_int * max(n, 1))(*v)
-    _lib.call("scae_conv3x3_first_fwd_relayout_f32", _p(image), _p(weights[0]),
-              _p(biases[0]), _p(act), B, C0, H, W, c1, s, n, arr(weights[1:]),
-              arr(wfs), arr(wds), ints([w.shape[0] for w in weights[1:]]),
-              ints([w.shape[1] for w in weights[1:]]), st)
+    if launch:
+        arr = lambda ts: (ctypes.c_void_p * max(n, 1))(
+            *[t.data_ptr() for t in ts])
+        ints = lambda v: (ctypes.c_int * max(n, 1))(*v)
+        _lib.call("scae_conv3x3_first_fwd_relayout_f32", _p(image),
+                  _p(weights[0]), _p(biases[0]), _p(act), B, C0, H, W, c1, s, n,
+                  arr(weights[1:]), arr(wfs), arr(wds),
+                  ints([w.shape[0] for w in weights[1:]]),
+                  ints([w.shape[1] for w in weights[1:]]), st)
     x_post = None
     for l in range(1, L):
         w, s = weights[l], strides[l]
