@@ -196,9 +196,11 @@ int scae_seed_attention_mfma_reduce_f32(const float *partial, int rows, const fl
  *        q   = seeds Wq^T + bq                   (O,C)
  *        wkf = Wk W2,       bkf = Wk b2 + bk     (C,D), (C)
  *        wvf = Wo Wv W2,    bvf = Wo (Wv b2 + bv) + bo
- *      wv2e (C,D+1) = [Wv W2 | Wv b2 + bv] is kept for the backward pass.
+ *      wv2e (C,D+1) = [Wv W2 | Wv b2 + bv] and wowv (C,C) = Wo Wv are kept for the
+ *      backward pass.
  *      backward: gradients of (q, wkf, bkf, wvf, bvf) -> gradients of all
- *      eleven parameters; gv2e, t1: (C,D+1) workspaces.
+ *      eleven parameters; gv2e, t1: unused (the workspaces of an earlier two-launch
+ *      form; may be NULL).
  *      Limits: C % 64 == 0, C <= 1024, D in {8,16,32}, O <= 64
  *      (scae_seed_fold_supported).
  * ---------------------------------------------------------------------- */
@@ -208,12 +210,14 @@ typedef struct scae_seed_fold_desc {
   const float *w2, *b2;                 /* fc2: (C,D), (C) */
   float *q, *wkf, *bkf, *wvf, *bvf;     /* outputs */
   float *wv2e;                          /* (C,D+1) output kept for backward */
+  float *wowv;                          /* (C,C) Wo Wv, kept for backward (NULL: not kept;
+                                           scae_seed_fold_bwd_f32 needs it) */
   int O, C, D;
 } scae_seed_fold_desc;
 typedef struct scae_seed_fold_grads {
   const float *g_q, *g_wkf, *g_bkf, *g_wvf, *g_bvf; /* incoming gradients */
   float *d_seeds, *d_wq, *d_bq, *d_wk, *d_bk, *d_wv, *d_bv, *d_wo, *d_bo, *d_w2, *d_b2;
-  float *gv2e, *t1;                     /* (C,D+1) workspaces */
+  float *gv2e, *t1;                     /* unused, may be NULL */
 } scae_seed_fold_grads;
 int scae_seed_fold_supported(int O, int C, int D);
 int scae_seed_fold_fwd_f32(const scae_seed_fold_desc *desc, void *stream);

@@ -99,7 +99,7 @@ class SeedFoldDesc(Structure):
     """struct scae_seed_fold_desc"""
     _fields_ = [(n, P) for n in (
         "seeds", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "w2", "b2",
-        "q", "wkf", "bkf", "wvf", "bvf", "wv2e")] + \
+        "q", "wkf", "bkf", "wvf", "bvf", "wv2e", "wowv")] + \
         [("O", c_int), ("C", c_int), ("D", c_int)]
 
 

@@ -9,14 +9,13 @@
 // three "C x C times C x (D+1)" products, a few MFLOP -- but as a chain of
 // library GEMM / GEMV / add launches (and twice as many in the backward pass)
 // they cost more than the attention itself.  Here: one launch forward (seed_fold_dev.h; the
-// same jobs can ride in the training step's prologue launch, step_prologue.hip), two backward.
+// same jobs can ride in the training step's prologue launch, step_prologue.hip), one backward.
 //   fwd: row blocks of Wk, Wv (NT/(D+1) rows per workgroup, W2e in LDS, a thread per
 //         (row, column)): [wkf|bkf], wv2e = Wv W2e + [0|bv]; row blocks of Wo:
 //         [wvf|bvf] = (Wo Wv) W2e + [0 | Wo bv + bo]; column blocks of q
-//   bwdA: column jobs, one workgroup per output column, threads over j:
-//         gv2e = Wo^T [g_wvf|g_bvf],  t1 = Wk^T [g_wkf|g_bkf],  d_seeds = g_q Wq
-//   bwdB: row jobs (outer products, K = O or D+1): d_Wq, d_Wk, d_Wo, d_Wv and
-//         the four bias gradients; column jobs: [d_W2|d_b2] = t1 + Wv^T gv2e
+//   bwd: column-block jobs: [d_W2|d_b2] (with (Wo Wv), which the forward keeps),
+//         d_seeds = g_q Wq; row jobs (outer products, K = O or D+1): d_Wq, d_Wk, d_Wo, d_Wv
+//         and the four bias gradients -- see fold_bwd_kernel
 #include "common.h"
 #include "seed_fold_dev.h"
 
@@ -29,88 +28,117 @@ __global__ __launch_bounds__(NT) void fold_fwd_kernel(scae_seed_fold_desc a, sca
   scae_fold::forward_block<D>(a, pl, blockIdx.x, lds);
 }
 
-// Column job: out[j] = sum_c W[c][j] * g(c).  Workgroup (C, parts): thread
-// (j, part) walks a quarter of the rows (coalesced W rows, 8 loads in flight),
-// the parts are summed through LDS.  Result valid for threadIdx.y == 0.
-template <class G>
-__device__ __forceinline__ float col_dot(const float *W, int C, float *red, G g) {
-  const int j = threadIdx.x, part = threadIdx.y, parts = blockDim.y;
-  const int per = (C + parts - 1) / parts, cb = part * per, ce = min(C, cb + per);
-  // 16 independent (coalesced) row loads in flight per thread: the dot product is a chain of
-  // L2 round trips otherwise
-  constexpr int U = 16;
-  float s[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) s[u] = 0.f;
-  int c = cb;
-  for (; c + U <= ce; c += U) {
-    float w[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = W[(size_t)(c + u) * C + j];
-#pragma unroll
-    for (int u = 0; u < U; ++u) s[u] = fmaf(w[u], g(c + u), s[u]);
-  }
-  for (; c < ce; ++c) s[0] = fmaf(W[(size_t)c * C + j], g(c), s[0]);
-  float tot = 0.f;
-#pragma unroll
-  for (int u = 0; u < U; ++u) tot += s[u];
-  red[part * C + j] = tot;
-  __syncthreads();
-  float out = 0.f;
-  if (part == 0)
-    for (int p = 0; p < parts; ++p) out += red[p * C + j];
-  return out;
-}
-
 // [g_w | g_b](c, d)
 __device__ __forceinline__ float ext_at(const float *gw, const float *gb, int D, int c, int d) {
   return d < D ? gw[c * D + d] : gb[c];
 }
 
-// grid: 2*(D+1) + O workgroups of (C, parts) threads; LDS parts*C floats
-__global__ void fold_bwdA_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g) {
-  extern __shared__ float red[];
-  const int C = a.C, D = a.D, DP = D + 1, j = threadIdx.x;
-  const bool lead = threadIdx.y == 0;
-  int job = blockIdx.x;
-  if (job < DP) {  // gv2e[:, d] = Wo^T [g_wvf | g_bvf][:, d]
-    const int d = job;
-    const float s =
-        col_dot(a.wo, C, red, [&](int c) { return ext_at(g.g_wvf, g.g_bvf, D, c, d); });
-    if (lead) g.gv2e[j * DP + d] = s;
-    return;
+// ---- backward -------------------------------------------------------------------------
+// Column jobs out[j][d] = sum_c W[c][j] G(c, d) (W: C x C, G: C x (D+1) or C x O -- a few
+// MFLOP) run on the matrix cores, one 16 x 16 output tile per wave, operands straight from
+// global memory: lane (r, q) of v_mfma_f32_16x16x4_f32 supplies W[4 s + q][j0 + r] and
+// G(4 s + q, n0 + r) -- 64-byte row segments, 16 k-steps of independent loads in flight.
+// (The VALU forms tried first were bound by one CU's path to L2 -- a workgroup per output
+// column d reads all of W per dot product, ~5 us each -- or by LDS issue: G broadcast from
+// LDS to a column-per-lane layout costs 96 ds_read_b128 per lane.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// k-steps [0, steps) of the wave's K slice starting at row kb
+template <int STEPS, class GP>
+__device__ __forceinline__ void mfma_cols(f32x4 &acc, const float *W, int C, int kb, int j0, int n,
+                                          int r, int q, GP gp) {
+  float av[STEPS], bv[STEPS];
+#pragma unroll
+  for (int s_ = 0; s_ < STEPS; ++s_) {
+    const int c = kb + 4 * s_ + q;
+    av[s_] = W[(size_t)c * C + j0 + r];
+    bv[s_] = *gp(c, n);
   }
-  job -= DP;
-  if (job < DP) {  // t1[:, d] = Wk^T [g_wkf | g_bkf][:, d]
-    const int d = job;
-    const float s =
-        col_dot(a.wk, C, red, [&](int c) { return ext_at(g.g_wkf, g.g_bkf, D, c, d); });
-    if (lead) g.t1[j * DP + d] = s;
-    return;
-  }
-  const int o = job - DP;  // d_seeds[o, :] = g_q[o, :] Wq
-  const float s = col_dot(a.wq, C, red, [&](int c) { return g.g_q[(size_t)o * C + c]; });
-  if (lead) g.d_seeds[(size_t)o * C + j] = s;
+#pragma unroll
+  for (int s_ = 0; s_ < STEPS; ++s_)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], bv[s_], acc, 0, 0, 0);
+}
+// &[g_w | g_b](c, d): one load whichever side (a select on the address, no branch)
+__device__ __forceinline__ const float *ext_ptr(const float *gw, const float *gb, int D, int c,
+                                                int d) {
+  return d < D ? gw + c * D + d : gb + c;
 }
 
-// grid: C row workgroups + (D+1) column workgroups, (C, parts) threads each.
-// Row c: the four outer-product rows d_Wq, d_Wk, d_Wv, d_Wo[c, :] are shared
-// out over the parts.
-__global__ void fold_bwdB_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g) {
-  extern __shared__ float red[];
+// ONE launch of (C, parts)-thread workgroups:
+//   column workgroups, one per 16 x 16 output tile, the waves splitting K; the partial tiles
+//   meet in LDS:
+//       [d_W2 | d_b2] = Wk^T [g_wkf|g_bkf] + (Wo Wv)^T [g_wvf|g_bvf]   ((Wo Wv) from the forward)
+//       d_seeds = g_q Wq
+//   C row workgroups: the outer-product rows d_Wq, d_Wk, d_Wv, d_Wo[c, :] (shared out over the
+//       parts) and the four bias gradients; row c of gv2e = Wo^T [g_wvf|g_bvf], which d_Wv
+//       needs, is recomputed by the workgroup (D+1 dot products down column c of Wo).
+// No job waits for another workgroup.  (Before: a first kernel produced gv2e and Wk^T g, a
+// second one consumed them.)
+struct BwdPlan {
+  int jt;          // 16-column tiles: C / 16
+  int nt_w2, nt_seed;   // 16-output tiles: ceil((D+1) / 16), ceil(O / 16)
+  int ncol;        // column workgroups (tiles)
+};
+template <int STEPS>   // 4-k steps per wave: (C / waves) / 4 = 16 / parts
+__global__ void fold_bwd_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g, BwdPlan pl) {
+  extern __shared__ float lds[];
   const int C = a.C, D = a.D, DP = D + 1, j = threadIdx.x;
-  if ((int)blockIdx.x >= C) {  // [d_W2 | d_b2][:, d] = t1[:, d] + Wv^T gv2e[:, d]
-    const int d = blockIdx.x - C;
-    const float s = col_dot(a.wv, C, red, [&](int c) { return g.gv2e[c * DP + d]; });
-    if (threadIdx.y == 0) {
-      if (d < D)
-        g.d_w2[j * D + d] = s + g.t1[j * DP + d];
-      else
-        g.d_b2[j] = s + g.t1[j * DP + d];
+  if ((int)blockIdx.x < pl.ncol) {
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nw = (blockDim.x * blockDim.y) >> 6;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int kb = wave * 4 * STEPS;
+    int tile = blockIdx.x;
+    const bool w2 = tile < pl.jt * pl.nt_w2;   // workgroup-uniform
+    if (!w2) tile -= pl.jt * pl.nt_w2;
+    const int j0 = (tile % pl.jt) * 16, n0 = (tile / pl.jt) * 16, nout = w2 ? DP : a.O;
+    const int n = min(n0 + r, nout - 1);   // lanes past the last output repeat it (dropped below)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (w2) {
+      mfma_cols<STEPS>(acc, a.wk, C, kb, j0, n, r, q,
+                       [&](int c, int d) { return ext_ptr(g.g_wkf, g.g_bkf, D, c, d); });
+      mfma_cols<STEPS>(acc, a.wowv, C, kb, j0, n, r, q,
+                       [&](int c, int d) { return ext_ptr(g.g_wvf, g.g_bvf, D, c, d); });
+    } else {
+      mfma_cols<STEPS>(acc, a.wq, C, kb, j0, n, r, q,
+                       [&](int c, int o) { return g.g_q + (size_t)o * C + c; });
+    }
+    // partial tiles [wave][row 4 q + e][col r] meet
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lds[(wave * 16 + 4 * q + e) * 16 + r] = acc[e];
+    __syncthreads();
+    if (tid < 256) {
+      const int row = tid >> 4, col = tid & 15;   // row: column jj of W, col: output
+      float sum = 0.f;
+      for (int w = 0; w < nw; ++w) sum += lds[(w * 16 + row) * 16 + col];
+      const int jj = j0 + row, nn = n0 + col;
+      if (nn < nout) {
+        if (!w2)
+          g.d_seeds[(size_t)nn * C + jj] = sum;
+        else if (nn < D)
+          g.d_w2[jj * D + nn] = sum;
+        else
+          g.d_b2[jj] = sum;
+      }
     }
     return;
   }
-  const int c = blockIdx.x;
+  const int c = blockIdx.x - pl.ncol;
+  float *vec = lds + 64 * 16;   // D + 1 floats behind the wave partials
+  {  // gv2e[c, d] = sum_i Wo[i][c] [g_wvf|g_bvf][i, d]: thread (i = j, part) takes d = part, part + parts, ..
+    const float wo = a.wo[(size_t)j * C + c];
+    const int nw = C >> 6, wave = j >> 6;
+    for (int d = threadIdx.y; d < DP; d += blockDim.y) {
+      const float v = scae::wave_sum(wo * ext_at(g.g_wvf, g.g_bvf, D, j, d));
+      if ((j & 63) == 0) lds[d * nw + wave] = v;
+    }
+    __syncthreads();
+    const int t = threadIdx.y * C + j;
+    if (t < DP) {
+      float v = 0.f;
+      for (int w = 0; w < nw; ++w) v += lds[t * nw + w];
+      vec[t] = v;
+    }
+    __syncthreads();
+  }
   const size_t e = (size_t)c * C + j;
   for (int which = threadIdx.y; which < 4; which += blockDim.y) {
     float acc = 0.f;
@@ -131,9 +159,9 @@ __global__ void fold_bwdB_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g) 
       if (j == 0) g.d_bk[c] = g.g_bkf[c];
     } else if (which == 2) {
 #pragma unroll 8
-      for (int d = 0; d < D; ++d) acc = fmaf(g.gv2e[c * DP + d], a.w2[j * D + d], acc);
-      g.d_wv[e] = fmaf(g.gv2e[c * DP + D], a.b2[j], acc);
-      if (j == 0) g.d_bv[c] = g.gv2e[c * DP + D];
+      for (int d = 0; d < D; ++d) acc = fmaf(vec[d], a.w2[j * D + d], acc);
+      g.d_wv[e] = fmaf(vec[D], a.b2[j], acc);
+      if (j == 0) g.d_bv[c] = vec[D];
     } else {
 #pragma unroll 8
       for (int d = 0; d < D; ++d) acc = fmaf(g.g_wvf[c * D + d], a.wv2e[j * DP + d], acc);
@@ -190,13 +218,21 @@ extern "C" int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc,
   const scae_seed_fold_grads *g = grads;
   SCAE_REQUIRE(g && g->g_q && g->g_wkf && g->g_bkf && g->g_wvf && g->g_bvf && g->d_seeds &&
                g->d_wq && g->d_bq && g->d_wk && g->d_bk && g->d_wv && g->d_bv && g->d_wo &&
-               g->d_bo && g->d_w2 && g->d_b2 && g->gv2e && g->t1);
+               g->d_bo && g->d_w2 && g->d_b2);
+  SCAE_REQUIRE(desc->wowv);
   const int DP = desc->D + 1, C = desc->C;
   const int parts = 1024 / C >= 4 ? 4 : (1024 / C >= 2 ? 2 : 1);
-  const size_t lds = (size_t)parts * C * sizeof(float);
-  hipLaunchKernelGGL(fold_bwdA_kernel, dim3(2 * DP + desc->O), dim3(C, parts), lds,
-                     (hipStream_t)stream, *desc, *g);
-  hipLaunchKernelGGL(fold_bwdB_kernel, dim3(C + DP), dim3(C, parts), lds, (hipStream_t)stream,
-                     *desc, *g);
+  BwdPlan pl{C / 16, (DP + 15) / 16, (desc->O + 15) / 16, 0};
+  pl.ncol = pl.jt * (pl.nt_w2 + pl.nt_seed);
+  // column jobs: waves x 16 x 16 partial tiles; row jobs: wave partials + a gv2e row
+  const size_t lds = (size_t)(C * parts / 64) * 256 * sizeof(float) + 8192;
+  const dim3 grid(pl.ncol + C), block(C, parts);
+  hipStream_t st = (hipStream_t)stream;
+  if (parts == 4)
+    hipLaunchKernelGGL(fold_bwd_kernel<4>, grid, block, lds, st, *desc, *g, pl);
+  else if (parts == 2)
+    hipLaunchKernelGGL(fold_bwd_kernel<8>, grid, block, lds, st, *desc, *g, pl);
+  else
+    hipLaunchKernelGGL(fold_bwd_kernel<16>, grid, block, lds, st, *desc, *g, pl);
   return scae_launch_status();
 }

@@ -121,8 +121,11 @@ __device__ __forceinline__ void wo_block(const scae_seed_fold_desc &a, int row0,
     }
   }
   __syncthreads();  // partial sums complete; every read of the Wo rows is done: u takes their place
-  for (int e = t; e < RO * C; e += NT)
-    rows[e] = (part[e] + part[RO * C + e]) + (part[2 * RO * C + e] + part[3 * RO * C + e]);
+  for (int e = t; e < RO * C; e += NT) {
+    const float u = (part[e] + part[RO * C + e]) + (part[2 * RO * C + e] + part[3 * RO * C + e]);
+    rows[e] = u;
+    if (a.wowv) a.wowv[(size_t)row0 * C + e] = u;   // (Wo Wv), kept for the backward pass
+  }
   __syncthreads();
   if (t >= RO * DP) return;
   const int r = t / DP, d = t - r * DP;

@@ -672,7 +672,8 @@ def _fold_desc(inputs, outputs, O, C, D):
     d = _lib.SeedFoldDesc()
     for name, t in zip(_FOLD_INPUTS, inputs):
         setattr(d, name, t.data_ptr())
-    for name, t in zip(("q", "wkf", "bkf", "wvf", "bvf", "wv2e"), outputs):
+    for name, t in zip(("q", "wkf", "bkf", "wvf", "bvf", "wv2e", "wowv"),
+                       outputs):
         setattr(d, name, t.data_ptr())
     d.O, d.C, d.D = O, C, D
     return d
@@ -702,13 +703,13 @@ class _SeedFold(torch.autograd.Function):
                 outs, launch = pro.fold_outs, not pro.fold_fresh
             else:
                 outs = (new(O, C), new(C, D), new(C), new(C, D), new(C),
-                        new(C, D + 1))
+                        new(C, D + 1), new(C, C))
                 pro.fold_inputs, pro.fold_outs, pro.fold_dims = \
                     inputs, outs, (O, C, D)
             pro.fold_fresh = False
         else:
             outs = (new(O, C), new(C, D), new(C), new(C, D), new(C),
-                    new(C, D + 1))
+                    new(C, D + 1), new(C, C))
         if launch:
             desc = _fold_desc(inputs, outs, O, C, D)
             _lib.call("scae_seed_fold_fwd_f32", ctypes.byref(desc),
@@ -728,7 +729,6 @@ class _SeedFold(torch.autograd.Function):
                     zip((g_q, g_wkf, g_bkf, g_wvf, g_bvf), outs)]
         incoming = [g.contiguous() for g in incoming]
         grads = [_grad_out(sl, t) for sl, t in zip(ctx.slots, inputs)]
-        work = torch.empty(2, C, D + 1, device=seeds.device, dtype=seeds.dtype)
         desc = _fold_desc(inputs, outs, O, C, D)
         g = _lib.SeedFoldGrads()
         for name, t in zip(("g_q", "g_wkf", "g_bkf", "g_wvf", "g_bvf"),
@@ -736,7 +736,6 @@ class _SeedFold(torch.autograd.Function):
             setattr(g, name, t.data_ptr())
         for name, t in zip(_FOLD_INPUTS, grads):
             setattr(g, "d_" + name, t.data_ptr())
-        g.gv2e, g.t1 = work[0].data_ptr(), work[1].data_ptr()
         _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(desc), ctypes.byref(g),
                   _stream(seeds))
         return tuple(grads)
