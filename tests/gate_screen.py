@@ -5,37 +5,71 @@ whose pre-activation lies within fp32 round-off of a kink has two equally
 valid fp32 gradients (gate open / closed), which would move single entries of
 a weight gradient by one sample's share -- far above the 1e-4 bar -- without
 either side being wrong.  Instead of loosening the bar, the full-size parity
-tests draw their batch from candidates screened with the oracle in fp64: a
-sample is kept only if EVERY piecewise-linear unit it drives (conv / MLP ReLUs,
-relu1 colours) sits at least `margin` x (largest pre-activation of that layer)
-away from its kinks.  On such a batch the HIP path and the fp32 oracle
-evaluate the same smooth function, and every gradient entry is held to 1e-4.
+tests draw their batch from candidates screened with the oracle: a sample is
+kept only if EVERY piecewise-linear unit it drives (conv / MLP ReLUs, relu1
+colours) sits clear of its kinks.  On such a batch the HIP path and the fp32
+oracle evaluate the same smooth function, and every gradient entry is held to
+1e-4.
+
+"Clear" is calibrated per layer, not a global constant: the oracle runs twice
+on the candidates, in fp32 and in fp64, and a layer's margin is ``SAFETY`` x
+the largest fp32-vs-fp64 deviation any of its pre-activations shows (relative
+to the layer's largest pre-activation), at least ``FLOOR``.  A 9-tap image
+layer (round-off ~1e-7) then rejects a tenth of what a 1152-term layer does,
+and the screen rejects what round-off could flip and nothing else.  The kept /
+drawn ratio of every screening call is printed, recorded in ``LAST_STATS`` and
+asserted >= ``MIN_KEPT_RATIO``: a screen that rejected most of what it drew
+would be choosing the batch, not cleaning it.
 """
 import contextlib
 
 import torch
 import torch.nn.functional as F
 
+SAFETY = 4.0          # margin = SAFETY x observed fp32 round-off of the layer
+FLOOR = 2e-7          # ... but at least this (relative to the layer's max)
+MIN_KEPT_RATIO = 0.5
+LAST_STATS = []       # [(what, kept, drawn)] of the most recent calls
+
 
 class _Shim:
-    """Stands in for ``torch.nn.functional`` inside the oracle module while
-    screening: records, per sample, the smallest relative distance of any
-    pre-activation to a kink of relu / relu6."""
+    """Stands in for ``torch.nn.functional`` inside the oracle module.
 
-    def __init__(self, B):
+    ``reference`` None: the fp32 pass -- keeps every relu / relu6 input.
+    ``reference`` = that list: the fp64 pass -- per call, the layer's margin
+    from its fp32 round-off, and per sample the smallest (distance to a kink /
+    margin) over all units; a sample is clean iff that ratio is >= 1."""
+
+    def __init__(self, B, reference=None, margin=None):
         self.B = B
-        self.margin = torch.full((B,), float("inf"), dtype=torch.float64)
-        self.shared = float("inf")     # units driven by parameters alone
+        self.reference = reference
+        self.fixed_margin = margin
+        self.calls = []
+        self.k = 0
+        self.ratio = torch.full((B,), float("inf"), dtype=torch.float64)
+        self.margins = []
 
     def _record(self, x, kinks):
+        if self.reference is None and self.fixed_margin is None:
+            self.calls.append(x.detach().clone())
+            return
         z = x.detach().double()
         scale = float(z.abs().max().clamp_min(1e-30))
+        if self.fixed_margin is not None:
+            margin = self.fixed_margin
+        else:
+            ref = self.reference[self.k]
+            self.k += 1
+            assert ref.shape == z.shape, "fp32 / fp64 passes out of step"
+            dev = float((z - ref.double()).abs().max()) / scale
+            margin = max(SAFETY * dev, FLOOR)
+        self.margins.append(margin)
         d = torch.stack([(z - k).abs() for k in kinks]).amin(0) / scale
         if z.dim() > 0 and z.shape[0] >= self.B and z.shape[0] % self.B == 0:
-            self.margin = torch.minimum(self.margin,
-                                        d.reshape(self.B, -1).amin(1))
-        else:
-            self.shared = min(self.shared, float(d.min()))
+            self.ratio = torch.minimum(self.ratio,
+                                       d.reshape(self.B, -1).amin(1) / margin)
+        # (units driven by parameters alone are the same for every candidate:
+        # nothing to screen)
 
     def relu(self, x):
         self._record(x, (0.0,))
@@ -50,8 +84,7 @@ class _Shim:
 
 
 @contextlib.contextmanager
-def record_gates(oracle_module, B):
-    shim = _Shim(B)
+def _shimmed(oracle_module, shim):
     saved = oracle_module.F
     oracle_module.F = shim
     try:
@@ -60,35 +93,91 @@ def record_gates(oracle_module, B):
         oracle_module.F = saved
 
 
-def screened_scae_batch(O, cfg, sd, B, gen, margin=4e-6, n_classes=10,
-                        max_rounds=40):
+def clean_mask(O, ocfg, P32, P64, image, noise):
+    """bool (B,): samples of (image, noise) whose every gate is clear of its
+    kinks by the calibrated margin (two oracle forwards: fp32, fp64)."""
+    B = image.shape[0]
+    with torch.no_grad():
+        with _shimmed(O, _Shim(B)) as rec32:
+            O.scae_forward(P32, ocfg, image, noise, training=True)
+        with _shimmed(O, _Shim(B, reference=rec32.calls)) as rec64:
+            O.scae_forward(P64, ocfg, image.double(),
+                           [n.double() for n in noise], training=True)
+    assert rec64.k == len(rec32.calls)
+    return rec64.ratio >= 1.0, rec64.margins
+
+
+def _note(what, kept, drawn, margins):
+    LAST_STATS.append((what, kept, drawn))
+    del LAST_STATS[:-64]
+    ratio = kept / max(1, drawn)
+    print(f"[gate screen] {what}: kept {kept} of {drawn} drawn ({ratio:.3f}); "
+          f"layer margins {min(margins):.1e} .. {max(margins):.1e}")
+    assert ratio >= MIN_KEPT_RATIO, \
+        f"gate screen {what}: kept only {kept} of {drawn} candidates"
+    return ratio
+
+
+def _params(sd):
+    P32 = {k: v.detach().float() for k, v in sd.items()}
+    return P32, {k: v.double() for k, v in P32.items()}
+
+
+def screened_scae_batch(O, cfg, sd, B, gen, n_classes=10, max_rounds=40):
     """(image, label, noise) of B samples for the SCAE config ``cfg`` with
-    parameters ``sd``, every sample clean by the criterion above (oracle
-    forward in fp64 on candidate chunks of B samples)."""
+    parameters ``sd``, every sample clean by the criterion above (candidate
+    chunks of B samples)."""
     M, Oc = cfg["n_part_caps"], cfg["n_obj_caps"]
-    P64 = {k: v.double() for k, v in sd.items()}
+    P32, P64 = _params(sd)
     ocfg = O.prepare_model_params(**cfg)
     keep = [[], [], [], [], []]
-    have = 0
+    have = drawn = kept = 0
     for _ in range(max_rounds):
         image = torch.rand(B, *cfg["image_shape"], generator=gen)
         label = torch.randint(0, n_classes, (B,), generator=gen)
         noise = [torch.rand(B, M, generator=gen),
                  torch.rand(B, Oc, 1, generator=gen),
                  torch.rand(B, Oc, M, generator=gen)]
-        with torch.no_grad(), record_gates(O, B) as rec:
-            O.scae_forward(P64, ocfg, image.double(),
-                           [n.double() for n in noise], training=True)
-        ok = rec.margin >= margin
+        ok, margins = clean_mask(O, ocfg, P32, P64, image, noise)
         for dst, src in zip(keep, [image, label] + noise):
             dst.append(src[ok])
+        drawn += B
+        kept += int(ok.sum())
         have += int(ok.sum())
         if have >= B:
             break
     else:
         raise RuntimeError(f"only {have} of {B} clean samples found")
+    _note(f"batch of {B} ({M}/{Oc} capsules)", kept, drawn, margins)
     image, label, n0, n1, n2 = [torch.cat(k)[:B] for k in keep]
     return image, label, [n0, n1, n2]
+
+
+def screened_batch_for_noise(O, cfg, sd, noise, gen, n_classes=10,
+                             max_rounds=40):
+    """(image, label) for GIVEN noise draws (the device generator's: a
+    replayed training step draws its own): sample slot b keeps noise[.][b] and
+    gets candidate images until one is clean with it.  Gates of a sample
+    depend on that sample alone (no batch statistics anywhere in the forward),
+    so slots are screened independently."""
+    B = noise[0].shape[0]
+    P32, P64 = _params(sd)
+    ocfg = O.prepare_model_params(**cfg)
+    noise = [n.detach().float().cpu() for n in noise]
+    image = torch.rand(B, *cfg["image_shape"], generator=gen)
+    label = torch.randint(0, n_classes, (B,), generator=gen)
+    drawn = B
+    for _ in range(max_rounds):
+        ok, margins = clean_mask(O, ocfg, P32, P64, image, noise)
+        n_bad = int((~ok).sum())
+        if n_bad == 0:
+            break
+        image[~ok] = torch.rand(n_bad, *cfg["image_shape"], generator=gen)
+        drawn += n_bad
+    else:
+        raise RuntimeError(f"{n_bad} of {B} slots still not clean")
+    _note(f"images for {B} fixed noise rows", B, drawn, margins)
+    return image, label
 
 
 def conv_margins(image, ws, bs, strides):

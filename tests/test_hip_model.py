@@ -96,10 +96,10 @@ FULL = {
 }
 
 
-def full_size_case(name):
-    """Parameters + a gate-screened batch (tests/gate_screen.py) of a FULL
-    configuration at its full batch size."""
-    from tests.gate_screen import screened_scae_batch
+def full_size_params(name):
+    """(cfg, B, state_dict, generator) of a FULL configuration: the factory's
+    initialisation with the all-zero parameters (alpha logits, biases) filled
+    so that every term of the model carries a gradient."""
     from torch_scae_amd import factory
     cfg, B = FULL[name]
     np.random.seed(1)
@@ -111,6 +111,14 @@ def full_size_case(name):
             if float(p.abs().sum()) == 0.0:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
     sd = {k: v.clone() for k, v in proto.state_dict().items()}
+    return cfg, B, sd, g
+
+
+def full_size_case(name):
+    """Parameters + a gate-screened batch (tests/gate_screen.py) of a FULL
+    configuration at its full batch size."""
+    from tests.gate_screen import screened_scae_batch
+    cfg, B, sd, g = full_size_params(name)
     image, label, noise = screened_scae_batch(O, cfg, sd, B, g)
     return cfg, B, sd, image, label, noise
 
@@ -564,6 +572,7 @@ def test_lazy_render_gives_the_same_tensors_and_the_same_step():
     model.part_decoder.lazy_render = True
     with torch.no_grad(), nn_utils.fixed_noise([n.clone() for n in noise]):
         lazy = model(image)
+    model.part_decoder.lazy_render = False
     assert isinstance(lazy, LazyAttrDict) and isinstance(lazy.rec, LazyAttrDict)
     assert "transformed_templates" not in list(lazy.keys())
     assert "transformed_templates" in lazy
@@ -580,10 +589,14 @@ def test_lazy_render_gives_the_same_tensors_and_the_same_step():
         ops.reset_noise()
         m = factory.make_scae(cfg).cuda().train()
         step = TrainStep(m, B, (1, 40, 40), lr=1e-3, lazy_render=lazy_render)
-        assert m.part_decoder.lazy_render == lazy_render
         for _ in range(2):
             step(image, label)
         torch.cuda.synchronize()
+        # the flag is scoped to the step's own forward: the
+        # user's model still returns plain, fully rendered AttrDicts
+        assert m.part_decoder.lazy_render is False
+        with torch.no_grad():
+            assert not isinstance(m(image), LazyAttrDict)
         return {k: v.clone() for k, v in m.state_dict().items()}
 
     a, b = run(True), run(False)

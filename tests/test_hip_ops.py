@@ -2006,3 +2006,57 @@ def test_grouped_mlp_bf16_operands_vs_fp64():
     # tensor by a few per cent in L2)
     for a, b in zip(got, ref):
         assert _rel_l2(a, b) <= 8e-2, _rel_l2(a, b)
+
+
+def test_deferred_sums_with_a_parameter_used_twice():
+    """under ``deferred_param_sums`` a column sum may only wait when
+    its output is the parameter's own slot AND nobody else contributes to that
+    parameter.  A module applied twice in one forward (shared parameters; both
+    uses slot-aware) must therefore get its gradients by autograd's
+    accumulation of two launched sums -- compared with a plain backward of the
+    same graph, and with the once-used module, whose sums do wait."""
+    import copy
+    from torch_scae_amd import ops
+    from torch_scae_amd.data_parallel import FlatParameters
+    from torch_scae_amd.part_decoder import TemplateGenerator
+    torch.manual_seed(3)
+    B, M, C, F, ts = 8, 6, 1, 16, 11
+    tg = TemplateGenerator(M, C, (ts, ts), dim_feature=F,
+                           colorize_templates=True).cuda()
+    plain = copy.deepcopy(tg)
+    f1, f2 = torch.randn(2, B, M, F, device="cuda").unbind(0)
+    w1, w2 = torch.randn(2, B, M, C, ts, ts, device="cuda").unbind(0)
+
+    def loss_of(m, twice):
+        a = (m(feature=f1).templates * w1).sum()
+        return a + (m(feature=f2).templates * w2).sum() if twice else a
+
+    flat = FlatParameters(tg)
+    for twice in (True, False, True):
+        plain.zero_grad(set_to_none=True)
+        loss_of(plain, twice).backward()
+        flat.clear_grads()
+        launched = []
+        real = ops._launch_sum_units
+
+        def spy(units):
+            launched.append((len(units), ops._DEFERRED is not None
+                             and len(ops._DEFERRED)))
+            return real(units)
+        ops._launch_sum_units = spy
+        try:
+            with ops.deferred_param_sums():
+                loss_of(tg, twice).backward()
+                waiting = len(ops._DEFERRED)
+        finally:
+            ops._launch_sum_units = real
+        flat.gather_grads()
+        torch.cuda.synchronize()
+        uses = [p._scae_grad_slot.uses for p in flat.params]
+        assert uses == [2 if twice else 1] * len(uses), uses
+        # once: every sum waits for the flush; twice: none does
+        assert (waiting > 0) == (not twice), (twice, waiting, launched)
+        ref = dict(plain.named_parameters())
+        names = {id(p): n for n, p in tg.named_parameters()}
+        for p, v in zip(flat.params, flat.grad_views()):
+            assert torch.equal(v, ref[names[id(p)]].grad), (twice, names[id(p)])

@@ -270,8 +270,35 @@ def test_factory_rejects_configurations_outside_the_kernel_limits():
     for bad, needle in ((dict(n_part_caps=65), "n_part_caps"),
                         (dict(n_obj_caps=80), "n_obj_caps"),
                         (dict(image_shape=(5, 40, 40)), "channels"),
-                        (dict(n_classes=40), "n_classes"),
                         (dict(pcae_template_generator_params=dict(
                             template_size=(64, 64))), "th*tw")):
         with pytest.raises(ValueError, match=needle.replace("*", r"\*")):
             factory.make_scae(dict(base, **bad))
+    # more classes than the fused classifier heads take is NOT a limit: SCAE
+    # falls back to nn.Linear heads + the op-by-op loss
+    assert factory.make_scae(dict(base, n_classes=40)).n_classes == 40
+
+
+def test_grad_slot_is_only_handed_to_a_single_consumer():
+    """data_parallel.GradSlot: one taker per step, and none at all when the
+    forward counted more than one slot-aware use of the parameter (the second
+    gradient must be accumulated by autograd, not written over the first)."""
+    import torch
+    from torch_scae_amd import ops
+    from torch_scae_amd.data_parallel import FlatParameters
+    lin = torch.nn.Linear(3, 2)
+    flat = FlatParameters(lin)
+    slot = lin.weight._scae_grad_slot
+    assert slot.uses == 0 and ops._slot(lin.weight) is slot and slot.uses == 1
+    v = ops._grad_out(slot, lin.weight)
+    assert ops._in_slot(v) and v.data_ptr() == flat.grad_views()[0].data_ptr()
+    w = ops._grad_out(slot, lin.weight)          # second taker: fresh buffer
+    assert not ops._in_slot(w) and w.data_ptr() != v.data_ptr()
+    flat.clear_grads()
+    assert slot.uses == 0 and not slot.taken
+    ops._slot(lin.weight), ops._slot(lin.weight)
+    assert slot.uses == 2
+    assert not ops._in_slot(ops._grad_out(slot, lin.weight))
+    with torch.no_grad():                        # not differentiated: no count
+        flat.clear_grads()
+        assert ops._slot(lin.weight) is None and slot.uses == 0

@@ -1,0 +1,252 @@
+"""Parity of the path ``bench.py`` times: ``TrainStep`` with its defaults --
+the step captured as a HIP graph and REPLAYED, batch hand-over + Philox noise
+draws + folded attention weights + the encoder's image layer in the prologue
+launch, lazy render, flat gradient slots with deferred column sums, fused
+RMSprop -- at BASELINE.json's full batch sizes.
+
+The reference's step is ``BaseExperiment.training_step`` + RMSprop
+(torch_scae_experiments/base_experiment.py:44-77, :109-126).  Here each
+replayed step is checked against the CPU oracle + stock ``torch.optim.RMSprop``
+on the same parameters-before, the same batch and the step's OWN noise draws:
+the device generator is counter based, so the draw of the next prologue launch
+is predicted from its state, the batch is gate-screened against exactly that
+noise (tests/gate_screen.py), and after the replay the step's noise buffer
+must equal the prediction bit for bit.
+"""
+import ctypes
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scae_oracle as O
+from tests.golden_util import assert_close
+from tests.test_hip_model import FULL, full_size_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise_shapes(cfg, B):
+    M, Oc = cfg["n_part_caps"], cfg["n_obj_caps"]
+    return [(B, M), (B, Oc, 1), (B, Oc, M)]
+
+
+def predict_noise(step):
+    """What the step's next prologue launch will draw (flat device tensor):
+    the same Philox kernel on a COPY of the generator state."""
+    from torch_scae_amd import ops
+    pro = step._pro
+    assert pro is not None and pro.noise is not None
+    state = pro.noise_state.clone()
+    out = torch.empty_like(pro.noise)
+    P = ctypes.c_void_p
+    ops._lib.call("scae_uniform_f32", P(out.data_ptr()), out.numel(),
+                  P(state.data_ptr()),
+                  P(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return out
+
+
+def split_noise(flat, cfg, B):
+    shapes = _noise_shapes(cfg, B)
+    sizes = [int(np.prod(s)) for s in shapes]
+    assert flat.numel() == sum(sizes)
+    return [c.view(s).cpu() for c, s in zip(flat.split(sizes), shapes)]
+
+
+def flat_grads(step):
+    """{reference key: gradient} read from the step's flat gradient buffer
+    (after a replay ``p.grad`` is whatever the capture left behind)."""
+    from torch_scae_amd import nn_ext
+    views = {id(p): v for p, v in zip(step.flat.params,
+                                      step.flat.grad_views())}
+    return nn_ext.named_reference_grads(step.model,
+                                        grad_of=lambda p: views.get(id(p)))
+
+
+def build_step(cfg, B, sd, **kw):
+    from torch_scae_amd import factory, ops
+    from torch_scae_amd.train_step import TrainStep
+    np.random.seed(0)
+    torch.manual_seed(1234)
+    ops.reset_noise()
+    model = factory.make_scae(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    return model, TrainStep(model, B, cfg["image_shape"], **kw)
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg5", "mnist_40_32"])
+def test_replayed_train_step_vs_oracle(name):
+    cfg, B, sd, g = full_size_params(name)
+    model, step = build_step(cfg, B, sd)      # bench.py's defaults
+    assert step.use_graph and step._pro is not None and step.opt is not None
+    assert step._lazy_dec is not None and not step.collective
+    step.capture()
+    assert step.graph is not None and step._pro.noise is not None
+    assert step._pro.fold_outs is not None and step._pro.first_outs is not None
+
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = O.prepare_model_params(**cfg)
+    lr = 3e-5
+    ropt = torch.optim.RMSprop(list(P.values()), lr=lr, alpha=0.99,
+                               momentum=0.9, eps=1e-2 / B ** 2)
+    from tests.gate_screen import screened_batch_for_noise
+    for it in range(3):
+        flat_noise = predict_noise(step)
+        noise = split_noise(flat_noise, cfg, B)
+        image, label = screened_batch_for_noise(
+            O, cfg, {k: p.detach() for k, p in P.items()}, noise, g)
+        ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label, noise)
+        ref_before = {k: p.detach().clone() for k, p in P.items()}
+        ropt.zero_grad(set_to_none=True)
+        for k, p in P.items():
+            p.grad = ref_grads[k]
+        ropt.step()
+
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        loss = step(image.cuda(), label.cuda())
+        torch.cuda.synchronize()
+        # the replay consumed exactly the predicted draws
+        assert torch.equal(step._pro.noise, flat_noise), it
+        assert abs(float(loss) - float(ref_loss)) <= \
+            1e-4 * abs(float(ref_loss)), (it, float(loss), float(ref_loss))
+        # every entry of every parameter gradient within 1e-4 of its tensor's
+        # largest entry (the screened batch has no borderline gate)
+        grads, off, n = flat_grads(step), [], 0
+        for k, ref in ref_grads.items():
+            if ref is None:
+                continue
+            scale = float(ref.abs().max())
+            got = grads[k].detach().cpu()
+            if scale == 0.0:
+                assert float(got.abs().max()) <= 1e-6, (it, k)
+                continue
+            off.append((float((got - ref).abs().max()) / scale, k))
+            n += 1
+        assert n > 200
+        off.sort(reverse=True)
+        assert off[0][0] <= 1e-4, (it, off[:6])
+        # the fused RMSprop moved every tensor like torch.optim.RMSprop did:
+        # a step is ~10 lr sign(g) for |g| >> eps, so the few entries with a
+        # gradient at round-off level differ; 5 % relative L2 per tensor
+        # (a wrong gradient or optimiser state gives O(1))
+        after = model.state_dict()
+        for k in ref_before:
+            d_ref = P[k].detach() - ref_before[k]
+            d_hip = (after[k] - before[k]).cpu()
+            nr = float(d_ref.norm())
+            if nr == 0.0:
+                assert float(d_hip.abs().max()) == 0.0, (it, k)
+                continue
+            assert float((d_hip - d_ref).norm()) <= 5e-2 * nr, \
+                (it, k, float((d_hip - d_ref).norm()), nr)
+    final = model.state_dict()
+    for k, p in P.items():
+        assert_close(final[k].cpu(), p.detach(), 1e-4, 2e-3, "param " + k)
+        # ... and tighter, against what three such steps can move at all
+        assert float((final[k].cpu() - p.detach()).abs().max()) <= \
+            0.05 * 3 * 10 * lr, k
+
+
+def _set_counter(step, value):
+    """Put the step's device generator at launch ``value`` (arrivals 0)."""
+    st = step._pro.noise_state
+    st[1:] = torch.tensor([value, 0], dtype=st.dtype, device=st.device)
+    step._pro.noise_fresh = False
+
+
+def _three_steps(step, images, labels):
+    losses, draws = [], []
+    for i in range(3):
+        losses.append(float(step(images[i], labels[i])))
+        draws.append(step._pro.noise.clone())
+    torch.cuda.synchronize()
+    # per parameter NAME: the flat order depends on the layout (front block)
+    names = {id(p): n for n, p in step.model.named_parameters()}
+    state = {}
+    for p, off in zip(step.flat.params, step.flat.offsets):
+        for what, buf in (("param", step.flat.flat_param),
+                          ("grad", step.flat.flat_grad),
+                          ("square_avg", step.opt.square_avg),
+                          ("buf", step.opt.buf)):
+            state[what + "/" + names[id(p)]] = \
+                buf[off:off + p.numel()].clone()
+    return losses, draws, state
+
+
+def test_replayed_step_equals_eager_step_bitwise():
+    """graph == eager at cfg-2, B = 128, WITH the prologue's Philox noise: both
+    runs start their generator at the same launch counter, take three steps on
+    the same batches and must agree bit for bit in noise, loss, parameters,
+    gradients and optimiser state."""
+    cfg, B, sd, g = full_size_params("cfg2")
+    images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
+    labels = torch.randint(0, 10, (3, B), generator=g).cuda()
+    out = {}
+    for use_graph in (False, True):
+        model, step = build_step(cfg, B, sd, use_graph=use_graph)
+        if use_graph:
+            step.capture()
+        else:
+            step._fwd_bwd()       # establishes the prologue's buffers
+        assert step._pro.noise is not None
+        _set_counter(step, 1000)
+        out[use_graph] = _three_steps(step, images, labels)
+    (l0, d0, s0), (l1, d1, s1) = out[False], out[True]
+    for a, b in zip(d0, d1):
+        assert torch.equal(a, b)
+    assert not torch.equal(d0[0], d0[1])
+    assert l0 == l1, (l0, l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
+def test_two_graph_collective_step_equals_plain_step_bitwise_cfg2():
+    """BASELINE.json configs[3]'s step shape on one GPU: a 1-rank RCCL group
+    drives TrainStep's two-graph mode (bucket 1 all-reduced between the
+    graphs) at cfg-2, B = 128, with Philox noise; it must end on exactly the
+    state of the collective-free replayed step."""
+    import torch.distributed as dist
+    cfg, B, sd, g = full_size_params("cfg2")
+    images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
+    labels = torch.randint(0, 10, (3, B), generator=g).cuda()
+    created = False
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}",
+                                rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        out = {}
+        for mode, kw in (("plain", {}),
+                         ("2 buckets", dict(force_collective=True)),
+                         ("1 bucket", dict(force_collective=True,
+                                           overlap=False))):
+            model, step = build_step(cfg, B, sd, **kw)
+            step.capture()
+            if mode == "plain":
+                assert step.collective_mode is None and step.graph_b is None
+            elif mode == "2 buckets":
+                assert step.split and step.graph_b is not None
+                assert 0 < step.flat.n_front < step.flat.numel
+            else:
+                assert step.collective and not step.split
+            _set_counter(step, 1000)
+            out[mode] = _three_steps(step, images, labels)
+        l0, d0, s0 = out["plain"]
+        for mode in ("2 buckets", "1 bucket"):
+            l, d, s = out[mode]
+            assert all(torch.equal(a, b) for a, b in zip(d0, d)), mode
+            assert l == l0, (mode, l, l0)
+            assert set(s) == set(s0)
+            for k in s0:
+                assert torch.equal(s0[k], s[k]), (mode, k)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -121,7 +121,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z,
   float *craw = g.craw ? g.craw + z * g.c_batch : nullptr;  // pre-gate copy (layout of C)
   const float *bias = g.bias ? g.bias + z * g.bias_batch : nullptr;
   const float *mask = g.mask ? g.mask + z * g.mask_batch : nullptr;
-  const bool cvec = (g.ldc & 3) == 0 && (g.c_batch & 3) == 0 && ((size_t)g.C & 15) == 0;
+  const bool cvec = (g.ldc & 3) == 0 && (g.c_batch & 3) == 0 && ((size_t)g.C & 15) == 0 &&
+                    (!g.craw || ((size_t)g.craw & 15) == 0);  // craw shares C's ldc / batch stride
   // (workgroup-uniform) the tile lies inside C and its rows take 16-byte accesses: straight-line
   // vector epilogue; otherwise the per-element form with its guards
   const bool cin = cvec && m0 + T <= g.M && n0 + T <= g.N &&

@@ -21,8 +21,9 @@ class GradSlot:
     backward passes ask for it (``ops._grad_out``) and write the gradient
     there directly; autograd then adopts that view as ``p.grad`` and the
     per-step pack has nothing to copy for this parameter.  One taker per
-    step: a second gradient of the same parameter is accumulated by autograd
-    as usual."""
+    step, and only when the parameter has ONE slot-aware consumer in the
+    forward (``uses``, counted by ``ops._slot``): with several, each backward
+    gets a fresh buffer and autograd accumulates them as usual."""
 
     def __init__(self, flat_grad, offset, shape):
         self.flat_grad, self.offset, self.shape = flat_grad, offset, shape
@@ -30,9 +31,10 @@ class GradSlot:
         for d in shape:
             self.numel *= d
         self.taken = False
+        self.uses = 0       # differentiated forward uses since clear_grads()
 
     def take(self):
-        if self.taken:
+        if self.taken or self.uses > 1:
             return None
         self.taken = True
         # a fresh tensor object every time: autograd only adopts a gradient
@@ -127,6 +129,7 @@ class FlatParameters:
         for p in self.params:
             p.grad = None
             p._scae_grad_slot.taken = False
+            p._scae_grad_slot.uses = 0
 
     def block(self, which):
         """(first, last) parameter index of a block: 0 = the front block,

@@ -88,7 +88,6 @@ KERNEL_LIMITS = dict(
     n_obj_caps=64,          # K4 (O <= 64), K2c seeds
     n_channels=4,           # K1 template planes
     template_texels=4096,   # K1: (C + 1) * th * tw floats of LDS per template
-    n_classes=32,           # classifier heads in class_probs / the loss tail
 )
 
 
@@ -112,10 +111,9 @@ def check_kernel_limits(params: dict):
     if (C + 1) * th * tw > lim["template_texels"]:
         problems.append(f"(C+1)*th*tw = {(C + 1) * th * tw} > "
                         f"{lim['template_texels']} (template planes in LDS)")
-    ncls = params["n_classes"]
-    if ncls is not None and ncls > lim["n_classes"]:
-        problems.append(f"n_classes={ncls} > {lim['n_classes']} "
-                        "(classifier heads of class_probs / the loss tail)")
+    # (n_classes above the fused heads' limit is not a problem: SCAE then runs
+    # the nn.Linear classifiers and the op-by-op loss,
+    # SCAE._fused_class_probs / _fused_tail_ok)
     if problems:
         raise ValueError("torch_scae_amd's HIP kernels do not cover this "
                          "configuration: " + "; ".join(problems))

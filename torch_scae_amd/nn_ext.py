@@ -183,10 +183,14 @@ def relu1(x):
     return F.relu6(x * 6.) / 6.
 
 
-def named_reference_grads(model):
+def named_reference_grads(model, grad_of=None):
     """{reference state_dict key: gradient} for every parameter of ``model``,
     un-stacking ``GroupedMLP`` parameters into the per-capsule keys (None for
-    parameters that received no gradient)."""
+    parameters that received no gradient).  ``grad_of``: parameter -> its
+    gradient (default ``p.grad``; e.g. a lookup into the flat gradient buffer
+    of ``data_parallel.FlatParameters`` after a replayed step)."""
+    if grad_of is None:
+        grad_of = lambda p: p.grad      # noqa: E731
     out = {}
     for mod_name, mod in model.named_modules():
         prefix = mod_name + "." if mod_name else ""
@@ -197,10 +201,11 @@ def named_reference_grads(model):
                                        else None)):
                     if stacked is None:
                         continue
+                    grad = grad_of(stacked)
                     for g in range(mod.n_groups):
                         out[f"{prefix}{g}.{2 * j}.{kind}"] = \
-                            None if stacked.grad is None else stacked.grad[g]
+                            None if grad is None else grad[g]
         else:
             for pname, p in mod.named_parameters(recurse=False):
-                out[prefix + pname] = p.grad
+                out[prefix + pname] = grad_of(p)
     return out

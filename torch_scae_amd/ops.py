@@ -48,9 +48,20 @@ def _detached(t):
     return None if t is None else t.detach()
 
 
-def _slot(t):
-    """The flat-gradient slot of a parameter (data_parallel.GradSlot) or None."""
-    return getattr(t, "_scae_grad_slot", None) if t is not None else None
+def _slot(t, ctx=None):
+    """The flat-gradient slot of a parameter (data_parallel.GradSlot) or None.
+    Called once per use of the parameter in a forward that will be
+    differentiated (``ctx``: the autograd node under construction; None: ask
+    the grad mode), and counted: a parameter with more than one such consumer
+    gets its gradient by autograd's accumulation, not through the slot."""
+    s = getattr(t, "_scae_grad_slot", None) if t is not None else None
+    if s is not None:
+        live = torch.is_grad_enabled() if ctx is None else \
+            any(ctx.needs_input_grad)
+        if not live:
+            return None
+        s.uses += 1
+    return s
 
 
 def _grad_out(slot, like, shape=None):
@@ -61,8 +72,16 @@ def _grad_out(slot, like, shape=None):
     if slot is not None and tuple(slot.shape) == shape:
         v = slot.take()
         if v is not None:
+            # this call owns the slot: nothing else writes or accumulates
+            # into it this step, so a column sum into it may be deferred
+            v._scae_in_slot = True
             return v
     return torch.empty(shape, device=like.device, dtype=like.dtype)
+
+
+def _in_slot(t):
+    """True for a gradient buffer ``_grad_out`` took from a parameter's slot."""
+    return t is not None and getattr(t, "_scae_in_slot", False)
 
 
 def _sum_jobs(jobs):
@@ -306,7 +325,11 @@ def _sum_rows_multi(jobs):
     launch); returns the list of output lists.  Jobs with ``defer=True`` wait
     for ``flush_param_sums`` while ``deferred_param_sums`` is active (the
     queue keeps the partial matrix alive but no reference to the outputs:
-    autograd only adopts a gradient tensor nobody else holds)."""
+    autograd only adopts a gradient tensor nobody else holds) -- but only when
+    EVERY output is a slot view this backward took itself (``_grad_out``): a
+    fresh buffer (the slot was already taken: shared parameter, second use in
+    one backward) is accumulated by autograd as soon as the node returns, so
+    its sum must have been launched by then."""
     units, later, results = [], [], []
     for job in jobs:
         partial, shapes = job["partial"], job["shapes"]
@@ -329,7 +352,8 @@ def _sum_rows_multi(jobs):
             pos += width
             outs.append(o)
         results.append(outs)
-        dst = later if (_DEFERRED is not None and job.get("defer")) else units
+        dst = later if (_DEFERRED is not None and job.get("defer")
+                        and all(_in_slot(o) for o in outs)) else units
         for k in range(0, len(shapes), 8):
             dst.append((partial, rows, cols, ctypes.cast(
                 ctypes.byref(segs, k * ctypes.sizeof(_lib.SumSegment)),
@@ -478,7 +502,7 @@ class _SetEncoder(torch.autograd.Function):
         ctx.has_presence = presence is not None
         ctx.nseg = len(segs)
         ctx.dims = (B, N, D, Din, Dout, L, int(layer_norm))
-        ctx.slot = _slot(packed)
+        ctx.slot = _slot(packed, ctx)
         return z
 
     @staticmethod
@@ -502,7 +526,8 @@ class _SetEncoder(torch.autograd.Function):
                   _p(partial), B, N, D, Din, Dout, L, ln, _stream(packed))
         taken_before = ctx.slot is not None and ctx.slot.taken
         if ctx.slot is not None and not taken_before and \
-                any(sl.taken for sl in getattr(ctx.slot, "parts", ())):
+                any(sl.taken or sl.uses > 1
+                    for sl in getattr(ctx.slot, "parts", ())):
             # a part's slot already holds another op's gradient (a trunk
             # parameter shared with a second slot-aware op): writing the packed
             # block would overwrite it -- leave the slots to autograd's sum
@@ -511,9 +536,9 @@ class _SetEncoder(torch.autograd.Function):
         if ctx.slot is not None and not taken_before:
             for sl in getattr(ctx.slot, "parts", ()):
                 sl.taken = True   # the parts' slots are written through it
-        # (a slot: the packed block is parameters only -- its sum can wait)
+        # (in its slot the packed block is parameters only: its sum can wait)
         return (None, _sum_rows(partial, [packed.shape], outs=[gpacked],
-                                defer=ctx.slot is not None)[0], None, *gsegs)
+                                defer=True)[0], None, *gsegs)
 
 
 def set_encoder(segments, presence, packed_params, dim_hidden, dim_out,
@@ -686,7 +711,7 @@ class _SeedFold(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *inputs):
         _need_hip(*inputs)
-        ctx.slots = [_slot(t) for t in inputs]
+        ctx.slots = [_slot(t, ctx) for t in inputs]
         inputs = tuple(t.contiguous() for t in inputs)
         seeds, w2 = inputs[0], inputs[9]
         O, C = seeds.shape[-2:]           # (O, C) or the parameter's (1, O, C)
@@ -883,7 +908,7 @@ class _ConvStack(torch.autograd.Function):
         acts, wds, _ = _conv_stack_fwd(image, strides, weights, biases)
         ctx.save_for_backward(image, *acts, *wds)
         ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights])
-        ctx.slots = [_slot(t) for t in wb]
+        ctx.slots = [_slot(t, ctx) for t in wb]
         ctx.refs = [tuple(t.shape) for t in wb]
         return acts[-1].permute(0, 3, 1, 2)
 
@@ -1099,7 +1124,7 @@ class _PartEncoder(torch.autograd.Function):
         ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights], n_caps,
                     float(noise_scale), int(similarity), noise_u is not None,
                     tuple(post_bias.shape), tuple(att_w.shape))
-        ctx.slots = [_slot(t) for t in (post_bias, att_w, att_b, *wb)]
+        ctx.slots = [_slot(t, ctx) for t in (post_bias, att_w, att_b, *wb)]
         ctx.refs = [tuple(t.shape) for t in wb]
         ctx.set_materialize_grads(False)
         if feature is None:
@@ -1254,7 +1279,7 @@ class _ColoredTemplates(torch.autograd.Function):
                   _p(color), B, M, C, th * tw, F, H1, tnl, cnl, _stream(logits))
         ctx.save_for_backward(logits, feature, w1, b1, w2, b2, color)
         ctx.codes = (tnl, cnl)
-        ctx.slots = [_slot(t) for t in (logits, w1, b1, w2, b2)]
+        ctx.slots = [_slot(t, ctx) for t in (logits, w1, b1, w2, b2)]
         ctx.set_materialize_grads(False)
         return raw, templates
 
@@ -1388,7 +1413,7 @@ class _GroupedMLP(torch.autograd.Function):
         ctx.meta = (bool(ones_input), n_layers,
                     [b is not None for b in biases], bool(grad_pregated),
                     bool(x_is_relu))
-        ctx.slots = [_slot(t) for t in wb]
+        ctx.slots = [_slot(t, ctx) for t in wb]
         return acts[-1]
 
     @staticmethod
@@ -1487,7 +1512,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
-        ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
+        ctx.slots = (_slot(weight, ctx), _slot(bias, ctx) if bias is not None else None)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -1555,8 +1580,8 @@ class _LayerNorm(torch.autograd.Function):
                                                 else []))
         ctx.has = (weight is not None, bias is not None)
         ctx.x_shape = x.shape
-        ctx.slots = (_slot(weight) if weight is not None else None,
-                     _slot(bias) if bias is not None else None)
+        ctx.slots = (_slot(weight, ctx) if weight is not None else None,
+                     _slot(bias, ctx) if bias is not None else None)
         return y.view(x.shape)
 
     @staticmethod
@@ -1740,7 +1765,7 @@ class _MLPChain(torch.autograd.Function):
         ctx.save_for_backward(x, *weights, *acts)
         ctx.meta = (tuple(ones_flags), [b is not None for b in biases],
                     bool(x_is_relu))
-        ctx.slots = [_slot(t) for t in wb]
+        ctx.slots = [_slot(t, ctx) for t in wb]
         return acts[-1]
 
     @staticmethod
@@ -1817,8 +1842,8 @@ class _ChainVotes(torch.autograd.Function):
                     float(noise_scale), (V, ldp, int(similarity),
                                          int(learn_vote_scale),
                                          int(allow_deformations)))
-        ctx.slots = [_slot(t) for t in wb]
-        ctx.vslots = [_slot(t) for t in (cpr_static, b_cvr, b_caps, b_vote,
+        ctx.slots = [_slot(t, ctx) for t in wb]
+        ctx.vslots = [_slot(t, ctx) for t in (cpr_static, b_cvr, b_caps, b_vote,
                                          b_scale)]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(reg)
@@ -1960,7 +1985,7 @@ class _CapsuleVotes(torch.autograd.Function):
         ctx.noise_scale = float(noise_scale)
         ctx.flags = flags
         ctx.param_is_relu = bool(param_is_relu)
-        ctx.slots = [_slot(t) for t in (cpr_static, b_cvr, b_caps, b_vote,
+        ctx.slots = [_slot(t, ctx) for t in (cpr_static, b_cvr, b_caps, b_vote,
                                         b_scale)]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(reg)
@@ -2120,7 +2145,7 @@ class _LossTail(torch.autograd.Function):
     def forward(ctx, lpp, posterior, caps_presence, cls_w, cls_b, label,
                 rec_sums, reg, cfg):
         _need_hip(lpp, posterior, caps_presence, cls_w, cls_b, rec_sums, reg)
-        ctx.slots = (_slot(cls_w), _slot(cls_b))
+        ctx.slots = (_slot(cls_w, ctx), _slot(cls_b, ctx))
         lpp, posterior, caps_presence = _c(lpp), _c(posterior), _c(caps_presence)
         cls_w, cls_b, label = _c(cls_w), _c(cls_b), _c(label)
         rec_sums, reg = _c(rec_sums), _c(reg)
@@ -2331,7 +2356,7 @@ class _RenderTemplates(torch.autograd.Function):
         ctx.present = [x is not None for x in t]
         ctx.output_size = output_size
         ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
-        ctx.slots = [_slot(v) for v in tensors]
+        ctx.slots = [_slot(v, ctx) for v in tensors]
         ctx.set_materialize_grads(False)
         return tt, ml
 
@@ -2371,7 +2396,7 @@ class _RenderGmmLogProb(torch.autograd.Function):
         ctx.present = [v is not None for v in t]
         ctx.output_size = output_size
         ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
-        ctx.slots = [_slot(v) for v in tensors]
+        ctx.slots = [_slot(v, ctx) for v in tensors]
         return lp
 
     @staticmethod
@@ -2414,7 +2439,7 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
         ctx.present = [v is not None for v in t]
         ctx.output_size = output_size
         ctx.alpha_shape = None if tensors[1] is None else tensors[1].shape
-        ctx.slots = [_slot(v) for v in tensors]
+        ctx.slots = [_slot(v, ctx) for v in tensors]
         return sums
 
     @staticmethod

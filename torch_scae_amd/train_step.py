@@ -5,6 +5,7 @@ removing the per-launch host cost matters more than any single kernel.
 
 Mirrors the semantics of the reference's BaseExperiment.training_step
 (torch_scae_experiments/base_experiment.py:109-126)."""
+import contextlib
 import os
 
 import torch
@@ -52,6 +53,9 @@ class TrainStep:
             os.environ.get("SCAE_GRAPH_ALLREDUCE", "0") == "1"
         self.split = bool(self.collective and overlap
                           and not self.in_graph_collective
+                          # the conditions under which SCAE._forward cuts
+                          # the backward in two (res._phase_cut)
+                          and getattr(model, "stop_grad_caps_target", False)
                           and getattr(model, "vote_type", None) == "enc"
                           and getattr(model, "presence_type", None) == "enc")
         self.flat = FlatParameters(
@@ -62,10 +66,12 @@ class TrainStep:
         if hasattr(model, "split_backward"):
             model.split_backward = self.split
         # loss-only step: the (B, M+1, ., H, W) reconstruction tensors, which
-        # neither SCAE.loss nor its backward read, render on first access
+        # neither SCAE.loss nor its backward read, render on first access.
+        # Scoped to the step's own forward (_lazy): the user's model keeps
+        # returning plain AttrDicts outside it
         dec = getattr(model, "part_decoder", None)
-        if lazy_render and hasattr(dec, "lazy_render"):
-            dec.lazy_render = True
+        self._lazy_dec = dec if lazy_render and hasattr(dec, "lazy_render") \
+            else None
         # the step's noise draws and parameter-only folding products ride with
         # the batch hand-over in ONE launch ahead of the step (ops.StepPrologue)
         self._pro = ops.StepPrologue() if prologue and \
@@ -103,12 +109,24 @@ class TrainStep:
         self.graph_b = None
         self._cut = None
 
+    @contextlib.contextmanager
+    def _lazy(self):
+        dec = self._lazy_dec
+        if dec is None:
+            yield
+            return
+        prev, dec.lazy_render = dec.lazy_render, True
+        try:
+            yield
+        finally:
+            dec.lazy_render = prev
+
     # -- the step in two parts ------------------------------------------------
     def _part_a(self):
         """forward + loss + backward (split: down to the decoders' inputs)."""
         self.flat.clear_grads()
         with ops.mfma_bf16(self.autocast_dtype is not None), \
-                ops.step_prologue(self._pro):
+                ops.step_prologue(self._pro), self._lazy():
             res = self.model(self.image)
             loss, info = self.model.loss(res, self.image, self.label)
             # a resident seed: no ones_like fill per step; the column sums that
@@ -213,6 +231,15 @@ class TrainStep:
                 self._part_b()
         self._capturing = False
 
+    def capture(self):
+        """Build the step's HIP graph(s) now instead of at the first call
+        (no-op without ``use_graph`` or when already built).  Runs the
+        forward / backward warm-ups on whatever the resident input buffers
+        hold; parameters and optimiser state are not touched."""
+        if self.use_graph and self.graph is None:
+            self._capture()
+            self._refresh_prologue()   # the capture consumed the last one
+
     def _refresh_prologue(self):
         """Noise + folding products for the next forward (no batch)."""
         if self._pro is not None:
@@ -257,9 +284,7 @@ class TrainStep:
         """image / label may be device tensors; copied into the static inputs."""
         self._stage(image, label)
         if self.use_graph:
-            if self.graph is None:
-                self._capture()
-                self._refresh_prologue()   # the capture consumed the last one
+            self.capture()
             if self.split:
                 self._run(self.graph.replay, self.graph_b.replay)
                 if self.opt is not None:
