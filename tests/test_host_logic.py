@@ -279,26 +279,21 @@ def test_factory_rejects_configurations_outside_the_kernel_limits():
     assert factory.make_scae(dict(base, n_classes=40)).n_classes == 40
 
 
-def test_grad_slot_is_only_handed_to_a_single_consumer():
-    """data_parallel.GradSlot: one taker per step, and none at all when the
-    forward counted more than one slot-aware use of the parameter (the second
-    gradient must be accumulated by autograd, not written over the first)."""
+def test_grad_slot_has_one_taker_per_step():
+    """data_parallel.GradSlot: the first gradient of a parameter in a backward
+    is written into its slot of the flat buffer (and only such a buffer may
+    have its column sum deferred); a second one gets a fresh buffer that
+    autograd accumulates."""
     import torch
     from torch_scae_amd import ops
     from torch_scae_amd.data_parallel import FlatParameters
     lin = torch.nn.Linear(3, 2)
     flat = FlatParameters(lin)
-    slot = lin.weight._scae_grad_slot
-    assert slot.uses == 0 and ops._slot(lin.weight) is slot and slot.uses == 1
+    slot = ops._slot(lin.weight)
+    assert slot is lin.weight._scae_grad_slot and not slot.taken
     v = ops._grad_out(slot, lin.weight)
     assert ops._in_slot(v) and v.data_ptr() == flat.grad_views()[0].data_ptr()
     w = ops._grad_out(slot, lin.weight)          # second taker: fresh buffer
     assert not ops._in_slot(w) and w.data_ptr() != v.data_ptr()
     flat.clear_grads()
-    assert slot.uses == 0 and not slot.taken
-    ops._slot(lin.weight), ops._slot(lin.weight)
-    assert slot.uses == 2
-    assert not ops._in_slot(ops._grad_out(slot, lin.weight))
-    with torch.no_grad():                        # not differentiated: no count
-        flat.clear_grads()
-        assert ops._slot(lin.weight) is None and slot.uses == 0
+    assert not slot.taken and ops._in_slot(ops._grad_out(slot, lin.weight))

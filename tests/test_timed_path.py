@@ -55,14 +55,19 @@ def split_noise(flat, cfg, B):
     return [c.view(s).cpu() for c, s in zip(flat.split(sizes), shapes)]
 
 
-def flat_grads(step):
-    """{reference key: gradient} read from the step's flat gradient buffer
-    (after a replay ``p.grad`` is whatever the capture left behind)."""
+def flat_named(step, buf):
+    """{reference state_dict key: that parameter's slice of the flat buffer
+    ``buf``} (gradients: after a replay ``p.grad`` is whatever the capture
+    left behind, the flat buffer is what the optimiser reads)."""
     from torch_scae_amd import nn_ext
-    views = {id(p): v for p, v in zip(step.flat.params,
-                                      step.flat.grad_views())}
+    views = {id(p): buf[off:off + p.numel()].view(p.shape)
+             for p, off in zip(step.flat.params, step.flat.offsets)}
     return nn_ext.named_reference_grads(step.model,
                                         grad_of=lambda p: views.get(id(p)))
+
+
+def flat_grads(step):
+    return flat_named(step, step.flat.flat_grad)
 
 
 def build_step(cfg, B, sd, **kw):
@@ -94,6 +99,21 @@ def test_replayed_train_step_vs_oracle(name):
                                momentum=0.9, eps=1e-2 / B ** 2)
     from tests.gate_screen import screened_batch_for_noise
     for it in range(3):
+        # the SAME state-before on both sides, every step: RMSprop's update is
+        # ~10 lr sign(g) wherever |g| >> eps, so an entry whose gradient is at
+        # round-off level may move 1e-4 apart in ONE step without either side
+        # being wrong -- left alone, step 2 would compare gradients taken at
+        # different parameters
+        if it > 0:
+            now = model.state_dict()
+            sq = flat_named(step, step.opt.square_avg)
+            mom = flat_named(step, step.opt.buf)
+            with torch.no_grad():
+                for k, p in P.items():
+                    p.copy_(now[k])
+                    if p in ropt.state:
+                        ropt.state[p]["square_avg"].copy_(sq[k])
+                        ropt.state[p]["momentum_buffer"].copy_(mom[k])
         flat_noise = predict_noise(step)
         noise = split_noise(flat_noise, cfg, B)
         image, label = screened_batch_for_noise(

@@ -21,9 +21,9 @@ class GradSlot:
     backward passes ask for it (``ops._grad_out``) and write the gradient
     there directly; autograd then adopts that view as ``p.grad`` and the
     per-step pack has nothing to copy for this parameter.  One taker per
-    step, and only when the parameter has ONE slot-aware consumer in the
-    forward (``uses``, counted by ``ops._slot``): with several, each backward
-    gets a fresh buffer and autograd accumulates them as usual."""
+    step: a second gradient of the same parameter gets a fresh buffer
+    (``ops._grad_out`` first flushes any column sum still waiting to be
+    written into the slot) and autograd accumulates it as usual."""
 
     def __init__(self, flat_grad, offset, shape):
         self.flat_grad, self.offset, self.shape = flat_grad, offset, shape
@@ -31,10 +31,9 @@ class GradSlot:
         for d in shape:
             self.numel *= d
         self.taken = False
-        self.uses = 0       # differentiated forward uses since clear_grads()
 
     def take(self):
-        if self.taken or self.uses > 1:
+        if self.taken:
             return None
         self.taken = True
         # a fresh tensor object every time: autograd only adopts a gradient
@@ -129,7 +128,6 @@ class FlatParameters:
         for p in self.params:
             p.grad = None
             p._scae_grad_slot.taken = False
-            p._scae_grad_slot.uses = 0
 
     def block(self, which):
         """(first, last) parameter index of a block: 0 = the front block,

@@ -49,19 +49,9 @@ def _detached(t):
 
 
 def _slot(t, ctx=None):
-    """The flat-gradient slot of a parameter (data_parallel.GradSlot) or None.
-    Called once per use of the parameter in a forward that will be
-    differentiated (``ctx``: the autograd node under construction; None: ask
-    the grad mode), and counted: a parameter with more than one such consumer
-    gets its gradient by autograd's accumulation, not through the slot."""
-    s = getattr(t, "_scae_grad_slot", None) if t is not None else None
-    if s is not None:
-        live = torch.is_grad_enabled() if ctx is None else \
-            any(ctx.needs_input_grad)
-        if not live:
-            return None
-        s.uses += 1
-    return s
+    """The flat-gradient slot of a parameter (data_parallel.GradSlot) or None
+    (``ctx``: the autograd node asking, unused)."""
+    return getattr(t, "_scae_grad_slot", None) if t is not None else None
 
 
 def _grad_out(slot, like, shape=None):
@@ -72,10 +62,14 @@ def _grad_out(slot, like, shape=None):
     if slot is not None and tuple(slot.shape) == shape:
         v = slot.take()
         if v is not None:
-            # this call owns the slot: nothing else writes or accumulates
-            # into it this step, so a column sum into it may be deferred
+            # first gradient of this parameter in this backward: a column sum
+            # into the slot may be deferred (``_in_slot``)
             v._scae_in_slot = True
             return v
+        # a SECOND gradient of the parameter (shared parameter, module applied
+        # twice): autograd is about to add this buffer to the slot's contents,
+        # so whatever sum into the slot is still waiting has to run first
+        flush_param_sums()
     return torch.empty(shape, device=like.device, dtype=like.dtype)
 
 
@@ -329,7 +323,10 @@ def _sum_rows_multi(jobs):
     EVERY output is a slot view this backward took itself (``_grad_out``): a
     fresh buffer (the slot was already taken: shared parameter, second use in
     one backward) is accumulated by autograd as soon as the node returns, so
-    its sum must have been launched by then."""
+    its sum must have been launched by then -- and ``_grad_out`` flushes the
+    queue before it hands out such a buffer, so the slot's own sum has run
+    too.  (Not covered: a parameter that ALSO feeds an op outside this
+    package; the models of this package have none.)"""
     units, later, results = [], [], []
     for job in jobs:
         partial, shapes = job["partial"], job["shapes"]
@@ -526,8 +523,7 @@ class _SetEncoder(torch.autograd.Function):
                   _p(partial), B, N, D, Din, Dout, L, ln, _stream(packed))
         taken_before = ctx.slot is not None and ctx.slot.taken
         if ctx.slot is not None and not taken_before and \
-                any(sl.taken or sl.uses > 1
-                    for sl in getattr(ctx.slot, "parts", ())):
+                any(sl.taken for sl in getattr(ctx.slot, "parts", ())):
             # a part's slot already holds another op's gradient (a trunk
             # parameter shared with a second slot-aware op): writing the packed
             # block would overwrite it -- leave the slots to autograd's sum
