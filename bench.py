@@ -82,6 +82,21 @@ def parse():
                     help="take the rank-launcher + RCCL process-group path even "
                          "for --gpus 1 (a 1-rank nccl group; proves the N>1 "
                          "plumbing on a 1-GPU box)")
+    ap.add_argument("--blocks", type=int, default=21,
+                    help="the K-step timed region is repeated this many times "
+                         "back to back (each bracketed by barrier + "
+                         "synchronize); ms_per_step is the median block")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra_workloads legs (other BASELINE "
+                         "configs, bf16, materialising / alternatives steps)")
+    ap.add_argument("--eager-render", action="store_true",
+                    help="materialise transformed_templates / mixing_logits "
+                         "in every step (SCAE.forward's full contract) "
+                         "instead of rendering them lazily on access")
+    ap.add_argument("--alternatives", action="store_true",
+                    help="reconstruct_alternatives=True (the SCAE ctor "
+                         "default): three more no-grad reconstructions per "
+                         "forward, one of them over B x n_obj_caps images")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: one all-reduce after the whole backward instead "
                          "of the bucketed one that overlaps the encoder backward")
@@ -305,7 +320,7 @@ def time_k8_kernels(cfg, device, reps=50, bf16=False):
     return out
 
 
-def roofline(cfg, device, bf16=False):
+def roofline(cfg, device, bf16=False, light=False):
     """Roofline of the dominant hand-written kernel of the step.  By rocprofv3
     total time per step that is the implicit-GEMM backward kernel of the CNN
     encoder (K8, MFMA-bound; data and weight gradient of a layer in one
@@ -313,10 +328,10 @@ def roofline(cfg, device, bf16=False):
     gradient convolutions, zero-padding work not counted) / their measured
     duration.  The K1 likelihood kernels (VALU-issue bound, priced against HBM
     as the brief asks) and the other K8 passes are reported alongside."""
-    k1 = time_k1_kernels(cfg, device)
+    k1 = time_k1_kernels(cfg, device, reps=40 if light else 200)
     alg = k1_algorithmic_bytes(cfg)
     B = cfg["batch"]
-    k8 = time_k8_kernels(cfg, device, bf16=bf16)
+    k8 = time_k8_kernels(cfg, device, reps=15 if light else 50, bf16=bf16)
     # --bf16: the forward / pair launchers round their operands to bf16 and run on
     # v_mfma_f32_32x32x16_bf16 -- priced against the dense bf16 peak; the separate dgrad /
     # wgrad launchers have no bf16 form and stay fp32
@@ -329,9 +344,9 @@ def roofline(cfg, device, bf16=False):
     # HBM traffic per launch from the committed rocprofv3 --pmc passes
     # (counters cannot be read from inside this run)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02", "k8_pmc.json")
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r01", "k8_pmc.json")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", r, "k8_pmc.json")
+                            for r in ("r03", "r02", "r01"))
+                if os.path.exists(q)), "")
     if os.path.exists(pmc) and cfg is CONFIGS["mnist_24_24_bs128"] and not bf16:
         k = json.load(open(pmc))["kernels"].get(name)
         if k:
@@ -460,6 +475,179 @@ def cpu_baseline(cfg, steps):
 
 
 # ----------------------------------------------------------------------------
+def make_step(cfg, device, seed=0, alternatives=False, **kw):
+    from torch_scae_amd.train_step import TrainStep
+    if alternatives:
+        cfg = dict(cfg, model=dict(cfg["model"], scae_params=dict(
+            cfg["model"]["scae_params"], reconstruct_alternatives=True)))
+    model = build_model(cfg, seed=seed).to(device).train()
+    return TrainStep(model, cfg["batch"], cfg["model"]["image_shape"], **kw)
+
+
+def synthetic_batches(cfg, device, seed, n_batches=8):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    B = cfg["batch"]
+    images = torch.rand(n_batches, B, *cfg["model"]["image_shape"],
+                        generator=g).to(device)
+    labels = torch.randint(0, 10, (n_batches, B), generator=g).to(device)
+    return images, labels
+
+
+def timed_blocks(step, images, labels, steps, warmup, blocks, barrier,
+                 reduce_max=None):
+    """`warmup` untimed steps, then `blocks` back-to-back timed regions of
+    EXACTLY `steps` steps each, every one bracketed by barrier() (a
+    dist.barrier when there are ranks + torch.cuda.synchronize) on both sides;
+    per block the MAX over ranks.  -> list of block seconds."""
+    n = images.shape[0]
+    for i in range(warmup):
+        step(images[i % n], labels[i % n])
+    out = []
+    for _ in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(images[i % n], labels[i % n])
+        barrier()
+        out.append(time.perf_counter() - t0)
+    if reduce_max is not None:
+        out = reduce_max(out)
+    return out
+
+
+def timing_summary(block_s, steps):
+    ms = sorted(1e3 * t / steps for t in block_s)
+    return {"blocks": len(ms), "steps_per_block": steps,
+            "median_ms": round(float(np.median(ms)), 4),
+            "min_ms": round(ms[0], 4), "max_ms": round(ms[-1], 4),
+            "p10_ms": round(ms[len(ms) // 10], 4),
+            "p90_ms": round(ms[-1 - len(ms) // 10], 4)}
+
+
+def extra_workloads(device, budget_s=25.0):
+    """The other BASELINE.json configurations and step variants, one short
+    measurement each on this GPU (same timing procedure, 5 blocks of 20 steps
+    after 5 warm-ups): ms/step, images/s, the dominant hand-written kernel of
+    that workload and its roofline fraction.  Bounded: a leg is skipped once
+    the budget is spent."""
+    legs = [
+        ("mnist_24_24_bs128 eager render (SCAE.forward's full contract: "
+         "transformed_templates + mixing_logits materialised every step)",
+         "mnist_24_24_bs128", dict(lazy_render=False), {}),
+        ("mnist_24_24_bs128 reconstruct_alternatives=True (SCAE ctor default; "
+         "3 more no-grad reconstructions incl. B x n_obj_caps images, eager "
+         "render)", "mnist_24_24_bs128", dict(lazy_render=False),
+         dict(alternatives=True)),
+        ("mnist_40_32_bs128 (the reference's hydra default)",
+         "mnist_40_32_bs128", {}, {}),
+        ("cifar_32_32_bs256 (BASELINE configs[4])", "cifar_32_32_bs256", {},
+         {}),
+        ("mnist_48_64_bs1024 fp32 (BASELINE configs[2]'s shape)",
+         "mnist_48_64_bs1024", {}, {}),
+        ("mnist_48_64_bs1024 bf16 (BASELINE configs[2])",
+         "mnist_48_64_bs1024", dict(autocast_dtype=torch.bfloat16), {}),
+    ]
+    out, t_start = [], time.perf_counter()
+    for label, wl, step_kw, model_kw in legs:
+        if time.perf_counter() - t_start > budget_s:
+            out.append({"workload": label, "skipped": "time budget"})
+            continue
+        cfg = CONFIGS[wl]
+        bf16 = "autocast_dtype" in step_kw
+        step = make_step(cfg, device, **model_kw, **step_kw)
+        images, labels = synthetic_batches(cfg, device, 2000, n_batches=2)
+        blocks = timed_blocks(step, images, labels, 20, 5, 5,
+                              torch.cuda.synchronize)
+        t = timing_summary(blocks, 20)
+        leg = {"workload": label, "ms_per_step": t["median_ms"],
+               "images_per_sec": round(cfg["batch"] / t["median_ms"] * 1e3, 1),
+               "timing": t, "final_loss": round(float(step.loss), 3)}
+        del step
+        r = roofline(cfg, device, bf16=bf16, light=True)
+        leg["dominant_kernel"] = {
+            "kernel": r["kernel"], "bound": r["bound"],
+            "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+            "frac": r["frac"], "us_per_step": round(
+                r["us_per_launch"] * r["launches_per_step"], 1)}
+        leg["k1"] = {k: {"us": v["us"], "frac": v["frac"]}
+                     for k, v in r["other_kernels"].items() if "us" in v}
+        out.append(leg)
+        torch.cuda.empty_cache()
+    return out
+
+
+def comm_diagnostics(step, images, labels, steps, barrier, device, world):
+    """N > 1 (or --force-spawn): where the step's time goes around the
+    collective, from HIP events on this rank's streams.  allreduce_us: the
+    flat-gradient all-reduce(s) alone (mean of 20, back to back, nothing to
+    overlap); step_no_comm_ms: the same replayed step with the collective
+    switched off (identical kernels, no RCCL call); exposed_us = step with
+    collective - step without = what the overlap did not hide."""
+    n = images.shape[0]
+
+    def run(k):
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), \
+            torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(k):
+            step(images[i % n], labels[i % n])
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k        # ms per step on this rank
+
+    with_comm = run(steps)
+    step.skip_collective = True
+    try:
+        run(3)
+        without = run(steps)
+    finally:
+        step.skip_collective = False
+    buckets = [0, 1] if step.split else [None]
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), \
+        torch.cuda.Event(enable_timing=True)
+    reps = 20
+    for _ in range(3):
+        for b in buckets:
+            step._reduce(b)
+    torch.cuda.synchronize()
+    barrier()
+    e0.record()
+    for _ in range(reps):
+        for b in buckets:
+            step._reduce(b)
+    e1.record()
+    torch.cuda.synchronize()
+    allreduce_us = e0.elapsed_time(e1) / reps * 1e3
+    mine = torch.tensor([with_comm, without, allreduce_us], device=device,
+                        dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    every = torch.stack(every).cpu()
+    nbytes = step.flat.numel * 4
+    return {
+        "mode": step.collective_mode,
+        "gradient_bytes": nbytes,
+        "bucket_bytes": [step.flat.n_front * 4,
+                         (step.flat.numel - step.flat.n_front) * 4]
+        if step.split else [nbytes],
+        "allreduce_us": round(float(every[:, 2].max()), 1),
+        "allreduce_busbw_GBps": round(
+            2 * (world - 1) / max(1, world) * nbytes
+            / (float(every[:, 2].max()) * 1e-6) / 1e9, 1),
+        "step_ms": round(float(every[:, 0].max()), 4),
+        "step_no_comm_ms": round(float(every[:, 1].max()), 4),
+        "exposed_us": round(float(every[:, 0].max() - every[:, 1].max())
+                            * 1e3, 1),
+        "per_rank_ms": [round(float(v), 4) for v in every[:, 0]],
+        "per_rank_no_comm_ms": [round(float(v), 4) for v in every[:, 1]],
+        "per_rank_allreduce_us": [round(float(v), 1) for v in every[:, 2]],
+        "note": "HIP-event times per rank over %d steps; busbw = 2(N-1)/N x "
+                "bytes / allreduce time (ring convention)" % steps,
+    }
+
+
 def main():
     args = parse()
     if "RANK" not in os.environ and (args.gpus > 1 or args.force_spawn):
@@ -484,53 +672,54 @@ def main():
         rccl_ranks = int(ones.item())
         assert rccl_ranks == dist.get_world_size() == world
 
-    from torch_scae_amd.train_step import TrainStep
     cfg = CONFIGS[args.workload]
     B = cfg["batch"]
-    model = build_model(cfg, seed=0).to(device).train()
-    step = TrainStep(model, B, cfg["model"]["image_shape"],
+    lazy = not args.eager_render
+    step = make_step(cfg, device, alternatives=args.alternatives,
                      use_graph=not args.no_graph,
                      optimizer=not args.no_optimizer,
-                     autocast_dtype=torch.bfloat16 if args.bf16
-                     else None, force_collective=args.force_spawn,
-                     overlap=not args.no_overlap)
-    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    n_batches = 8
-    images = torch.rand(n_batches, B, *cfg["model"]["image_shape"],
-                        generator=g).to(device)
-    labels = torch.randint(0, 10, (n_batches, B), generator=g).to(device)
+                     autocast_dtype=torch.bfloat16 if args.bf16 else None,
+                     force_collective=args.force_spawn,
+                     overlap=not args.no_overlap, lazy_render=lazy)
+    images, labels = synthetic_batches(cfg, device, 1000 + rank)
 
     def barrier():
         if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(images[i % n_batches], labels[i % n_batches])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(images[i % n_batches], labels[i % n_batches])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    final_loss = float(step.loss)
-    if collective:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    def reduce_max(block_s):
+        if not collective:
+            return block_s
+        t = torch.tensor(block_s, device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        return [float(v) for v in t]
+
+    # the timed region of the contract -- W warm-ups, then EXACTLY K steps
+    # between barrier + synchronize, MAX over ranks -- repeated `blocks` times
+    # back to back; the reported step time is the MEDIAN block
+    blocks = timed_blocks(step, images, labels, args.steps, args.warmup,
+                          max(1, args.blocks), barrier, reduce_max)
+    timing = timing_summary(blocks, args.steps)
+    final_loss = float(step.loss)
+    comm = None
+    if collective:
+        comm = comm_diagnostics(step, images, labels, max(10, args.steps),
+                                barrier, device, world)
 
     result = None
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
+        ms = timing["median_ms"]
         result = {
             "metric": metric_name(args.workload),
-            "value": round(B * world * args.steps / elapsed, 1),
+            "value": round(B * world / ms * 1e3, 1),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 operands / f32 accumulate on the GEMM-shaped kernels "
                      "(K7, K8), f32 elsewhere" if args.bf16 else "f32",
             "data": "synthetic",
+            "timing": timing,
             "config": {
                 "workload": args.workload, "per_gpu_batch": B,
                 "global_batch": B * world,
@@ -540,10 +729,19 @@ def main():
                            if collective else "")
                         + ("" if args.no_optimizer else " + RMSprop step"),
                 "hip_graph": not args.no_graph,
+                # the step computes the loss from the fused likelihood kernel;
+                # the (B, M+1, C, H, W) transformed_templates / mixing_logits
+                # of SCAE.forward's result are rendered on first access (bit
+                # identical), not in every step -- extra_workloads has the
+                # step that materialises them
+                "lazy_render": lazy,
+                "reconstruct_alternatives": bool(args.alternatives),
                 "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                 "final_loss": round(final_loss, 3),
             },
         }
+        if comm is not None:
+            result["comm"] = comm
         if not args.no_roofline:
             result["roofline"] = roofline(cfg, device, bf16=args.bf16)
             fl, by = step_algorithmic(cfg)
@@ -556,6 +754,13 @@ def main():
                 "note": "whole step per GPU: images/s x SURVEY.md 8d's "
                         "algorithmic FLOPs (bytes) per image / fp32 MFMA "
                         "(HBM) peak"}
+        if world == 1 and not args.force_spawn and not args.no_extra \
+                and args.workload == "mnist_24_24_bs128" and not args.bf16 \
+                and not args.no_graph and not args.no_optimizer \
+                and lazy and not args.alternatives:
+            del step
+            torch.cuda.empty_cache()
+            result["extra_workloads"] = extra_workloads(device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
         print(json.dumps(result), flush=True)

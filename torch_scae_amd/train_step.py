@@ -102,6 +102,7 @@ class TrainStep:
         self.loss = torch.zeros((), device=self.device)
         self._one = torch.ones((), device=self.device)   # d loss / d loss
         self.use_graph = use_graph
+        self.skip_collective = False
         self._capturing = False
         self._stream = None
         self._with_log = False
@@ -174,6 +175,8 @@ class TrainStep:
 
     def _reduce(self, which=None, async_op=False):
         # SUM all-reduce; the 1/world scale rides in the optimiser kernel
+        if self.skip_collective:      # measurement only (bench.py's comm leg)
+            return None
         return all_reduce_gradients(self.flat, average=self.opt is None,
                                     which=which, async_op=async_op,
                                     force=self.collective)
