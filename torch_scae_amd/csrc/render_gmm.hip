@@ -27,12 +27,11 @@
 //     230 us kernel with one add per pixel, 63 of 99 us with one per run),
 //     one writer per address, fixed summation order: bit-reproducible.
 #include "common.h"
+#include "render_gmm_dev.h"
 
 namespace {
 
-using scae::log_safe;
-using scae::sigmoidf_;
-using scae::softplusf_;
+using namespace scae_k1;
 
 constexpr int NT = 256;
 
@@ -107,16 +106,6 @@ __device__ __forceinline__ void tap_value_grad(const float *plane, const Taps &t
   dy = (v10 - v00) * wx0 + (v11 - v01) * wx1;
 }
 
-// ---- zero-padded template planes in LDS ------------------------------------------
-// A (th x tw) plane is staged as (th+4) x (tw+4) with the texels at offset (2, 2) and
-// zeros around them.  With the sampling position clamped to [-2, tw] x [-2, th]
-// every bilinear tap is then an in-range LDS read and an outside tap reads 0 -- the
-// zero padding of grid_sample without per-tap masks, index clamps or compares (the
-// unpadded formulation above spends ~2/3 of its instructions on those).  A
-// position beyond the clamp has all four taps outside either way; NaN clamps to -2.
-__host__ __device__ inline int pad_w(int tw) { return tw + 4; }
-__host__ __device__ inline int pad_elems(int th, int tw) { return (th + 4) * (tw + 4); }
-
 struct PTaps {
   int base;      // offset of tap (y0, x0) inside a padded plane
   float fx, fy;  // fractional position
@@ -183,32 +172,6 @@ __device__ __forceinline__ void stage_padded(float *dst, const float *src, int n
       dst[pl * psz + (y + 2) * pw + x + 2] = src[i];
     }
   }
-}
-
-// template set of image b: consecutive groups of `template_repeat` images share one
-// (stacked_capsule_auto_encoder.py:188-195 decodes every object capsule's votes with the
-// image's templates: B*O virtual images, B template sets)
-__device__ __forceinline__ int tb(const scae_decoder_desc &d, int b) {
-  return d.template_repeat > 1 ? b / d.template_repeat : b;
-}
-
-struct Scalars {
-  float sigma, inv_var, log_sigma;  // Normal scale of every component
-  float temperature;                // temperature mode only
-  float bg_ml;                      // alpha mode: softplus(bg_mixing_logit)
-  float bg_val;                     // sigmoid(bg_value) when no bg_image
-};
-
-__device__ __forceinline__ Scalars load_scalars(const scae_decoder_desc &d) {
-  Scalars s;
-  s.sigma = d.out_scale ? softplusf_(d.out_scale[0]) + 1e-4f : 1.f;  // :220-223
-  s.inv_var = 1.f / (s.sigma * s.sigma);
-  s.log_sigma = logf(s.sigma);
-  s.temperature = d.templates_alpha ? 1.f
-                                    : softplusf_(d.temperature_logit[0] + .5f) + 1e-4f;
-  s.bg_ml = d.templates_alpha ? softplusf_(d.bg_mixing_logit[0]) : 0.f;
-  s.bg_val = d.bg_image ? 0.f : sigmoidf_(d.bg_value[0]);
-  return s;
 }
 
 // ---------------------------------------------------------------------------
@@ -1196,17 +1159,32 @@ extern "C" int scae_template_render_fwd_f32(const scae_decoder_desc *d,
   return scae_launch_status();
 }
 
-namespace {
 // pixel tiling of the log-prob kernel: lanes per pixel, pixels per workgroup
-struct LpTiling {
-  int ksplit, ppb, tiles;
-};
+namespace scae_k1 {
 LpTiling lp_tiling(const scae_decoder_desc *d) {
   const int HW = d->H * d->W;
+  LpTiling t;
+  t.wave = false;
+#ifndef SCAE_K1_NO_WAVE
+  if (logprob_wave_lds(d)) {
+    // wave form: a workgroup = up to 16 waves of 64 consecutive pixels of one image, all M
+    // components per lane; enough tiles per image for >= 2 workgroups per CU
+    const int waves = (HW + 63) / 64;
+    int tiles = (waves + 15) / 16;
+    const int want = (512 + d->B - 1) / d->B;
+    if (tiles < want) tiles = want;
+    if (tiles > waves) tiles = waves;
+    const int wpt = (waves + tiles - 1) / tiles;
+    t.wave = true;
+    t.ksplit = 1;
+    t.ppb = wpt * 64;
+    t.tiles = (HW + t.ppb - 1) / t.ppb;
+    return t;
+  }
+#endif
   // component split across lanes: more lanes per pixel when the batch alone
   // cannot fill 256 CUs
   const long pixels = (long)d->B * HW;
-  LpTiling t;
   t.ksplit = pixels >= 256L * 1024 * 4 ? 1 : (pixels >= 256L * 1024 ? 2 : 4);
 #ifndef SCAE_LP_ROUNDS
 #define SCAE_LP_ROUNDS 6
@@ -1216,7 +1194,9 @@ LpTiling lp_tiling(const scae_decoder_desc *d) {
   t.tiles = (HW + t.ppb - 1) / t.ppb;
   return t;
 }
+}  // namespace scae_k1
 
+namespace {
 template <int C>
 int launch_logprob_fwd(const scae_decoder_desc *d, const float *x, float *log_prob,
                        float *lse_post, float *lse_prior, float *block_sums, hipStream_t st) {
@@ -1230,6 +1210,7 @@ int launch_logprob_fwd(const scae_decoder_desc *d, const float *x, float *log_pr
   const size_t lds =
       pad ? lds_pad : sizeof(float) * (planes * d->th * d->tw + (size_t)d->M * 7);
   const LpTiling t = lp_tiling(d);
+  if (t.wave) return launch_logprob_wave(d, t, x, log_prob, lse_post, lse_prior, block_sums, st);
   const int ppb = t.ppb;
   const dim3 grid(t.tiles, d->B);
   int rc;
