@@ -49,15 +49,6 @@ struct Taps {
 __device__ __forceinline__ float norm_coord(int j, float inv_n) {
   return (float)(2 * j + 1) * inv_n - 1.f;
 }
-// template-space sampling position of normalised output position (xn, yn)
-__device__ __forceinline__ void tex_pos(const float *a, float xn, float yn, int tw, int th,
-                                        float &ix, float &iy) {
-  const float gx = a[0] * xn + a[1] * yn + a[2];
-  const float gy = a[3] * xn + a[4] * yn + a[5];
-  ix = ((gx + 1.f) * tw - 1.f) * 0.5f;
-  iy = ((gy + 1.f) * th - 1.f) * 0.5f;
-}
-
 __device__ __forceinline__ void make_taps(const float *a, int p, int W, int H,
                                           int tw, int th, Taps &t) {
   const float inv_w = 1.f / (float)W;
@@ -1259,6 +1250,12 @@ int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post
                                  (size_t)(d->C + 1) * rows * d->W);
   const dim3 grid(d->M + 1, d->B);
   const bool fused = (g_tt == nullptr && g_ml == nullptr);
+#ifndef SCAE_K1_NO_CELL
+  if (fused && bwd_cell_lds(d))
+    return launch_bwd_cell(d, x, lse_post, lse_prior, g_logprob, g_tile, lt.tiles, lt.ppb,
+                           g_templates, g_alpha_partial, g_pose, g_presence, g_bg_image,
+                           g_scalar_partial, st);
+#endif
   int rc;
 #define SCAE_LAUNCH_BWD(KERNEL, FU)                                                          \
   rc = set_lds(KERNEL<C, FU>, lds);                                                          \

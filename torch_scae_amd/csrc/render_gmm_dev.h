@@ -8,6 +8,16 @@ using scae::log_safe;
 using scae::sigmoidf_;
 using scae::softplusf_;
 
+// affine_grid (align_corners=False) + grid_sample's un-normalisation in the reference's
+// operation order: g = theta [x, y, 1];  ix = ((gx + 1) w - 1) / 2
+__device__ __forceinline__ void tex_pos(const float *a, float xn, float yn, int tw, int th,
+                                        float &ix, float &iy) {
+  const float gx = a[0] * xn + a[1] * yn + a[2];
+  const float gy = a[3] * xn + a[4] * yn + a[5];
+  ix = ((gx + 1.f) * tw - 1.f) * 0.5f;
+  iy = ((gy + 1.f) * th - 1.f) * 0.5f;
+}
+
 // ---- zero-padded template planes in LDS ------------------------------------------
 // A (th x tw) plane is staged as (th+4) x (tw+4) with the texels at offset (2, 2) and
 // zeros around them.  With the sampling position clamped to [-2, tw] x [-2, th]
@@ -59,4 +69,14 @@ int launch_logprob_wave(const scae_decoder_desc *d, const LpTiling &t, const flo
                         hipStream_t st);
 // LDS bytes the wave form needs for this shape (0: shape not covered)
 size_t logprob_wave_lds(const scae_decoder_desc *d);
+
+// render_gmm_wave.hip: the fused backward in its cell-gather form (alpha-channel mode,
+// gradient of the per-pixel log-prob or of its tile sums).  bwd_cell_lds: LDS bytes, 0 when
+// the shape is not covered (the caller falls back to render_gmm.hip's kernels).
+size_t bwd_cell_lds(const scae_decoder_desc *d);
+int launch_bwd_cell(const scae_decoder_desc *d, const float *x, const float *lse_post,
+                    const float *lse_prior, const float *g_logprob, const float *g_tile,
+                    int lp_tiles, int lp_ppb, float *g_templates, float *g_alpha_partial,
+                    float *g_pose, float *g_presence, float *g_bg_image,
+                    float *g_scalar_partial, hipStream_t st);
 }  // namespace scae_k1
