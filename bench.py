@@ -179,7 +179,7 @@ def k1_algorithmic_bytes(cfg):
     }
 
 
-def time_k1_kernels(cfg, device, reps=200):
+def time_k1_kernels(cfg, device, reps=200, pose_regime="unit"):
     """Average duration of each K1 kernel: `reps` back-to-back launches through
     the C ABI on torch's current HIP stream, bracketed by HIP events recorded
     on that same stream (torch.cuda.Event records on the current stream).
@@ -195,9 +195,17 @@ def time_k1_kernels(cfg, device, reps=200):
     f = lambda *s: torch.empty(*s, device=device)   # noqa: E731
     templates = torch.rand(B, M, C, 11, 11, generator=g).to(device)
     alpha = (torch.randn(M, 11, 11, generator=g) * 0.5).to(device)
-    pose = torch.randn(B, M, 6, generator=g) * 0.3
-    pose[:, :, 0] += 1.0
-    pose[:, :, 4] += 1.0
+    # two pose regimes: "unit" -- templates about the size of the image, any shear (cells of
+    # ~3.6 pixels); "init" -- what a freshly initialised part encoder emits (scale ~0.48:
+    # the template covers twice the image, cells of ~7.6 pixels, rotations of +-20 degrees)
+    if pose_regime == "init":
+        pose = torch.randn(B, M, 6, generator=g) * torch.tensor(
+            [0.06, 0.2, 0.25, 0.16, 0.02, 0.26]) + torch.tensor(
+            [0.48, -0.04, 0.0, 0.0, 0.48, 0.0])
+    else:
+        pose = torch.randn(B, M, 6, generator=g) * 0.3
+        pose[:, :, 0] += 1.0
+        pose[:, :, 4] += 1.0
     pose = pose.to(device)
     presence = torch.rand(B, M, generator=g).to(device)
     x = torch.rand(B, C, H, W, generator=g).to(device)

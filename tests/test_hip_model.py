@@ -379,13 +379,11 @@ def test_cfg3_bf16_attention_path_vs_fp32_oracle():
                for p in model.parameters())
 
 
-def test_train_step_collective_paths_match_plain_step_bitwise():
+def test_train_step_collective_paths_match_plain_step_bitwise(nccl_group):
     """SURVEY.md 8e on one GPU: TrainStep driven through a 1-rank RCCL group
     (force_collective) -- two graphs with the bucketed all-reduce between
     them, and one graph with one all-reduce behind it -- ends on exactly the
     parameters of the collective-free step (same seeds, three steps)."""
-    import socket
-    import torch.distributed as dist
     from torch_scae_amd import factory, ops
     from torch_scae_amd.train_step import TrainStep
     cfg = dict(image_shape=(1, 16, 16), n_classes=4, n_part_caps=5,
@@ -415,33 +413,19 @@ def test_train_step_collective_paths_match_plain_step_bitwise():
         return step, losses, {k: v.clone()
                               for k, v in model.state_dict().items()}
 
-    created = False
-    if not dist.is_initialized():
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}",
-                                rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
-        created = True
-    try:
-        for use_graph in (False, True):
-            plain, l0, sd0 = run(use_graph)
-            assert plain.collective_mode is None and plain.graph_b is None
-            two, l2, sd2 = run(use_graph, force_collective=True)
-            assert two.split and two.collective_mode.startswith("2 buckets")
-            assert 0 < two.flat.n_front < two.flat.numel
-            assert (two.graph_b is not None) == use_graph
-            one, l1, sd1 = run(use_graph, force_collective=True, overlap=False)
-            assert not one.split and one.collective_mode.startswith("1 bucket")
-            assert l0 == l1 == l2, (l0, l1, l2)
-            for k in sd0:
-                assert torch.equal(sd0[k], sd1[k]), (use_graph, "1 bucket", k)
-                assert torch.equal(sd0[k], sd2[k]), (use_graph, "2 buckets", k)
-    finally:
-        if created:
-            dist.destroy_process_group()
+    for use_graph in (False, True):
+        plain, l0, sd0 = run(use_graph)
+        assert plain.collective_mode is None and plain.graph_b is None
+        two, l2, sd2 = run(use_graph, force_collective=True)
+        assert two.split and two.collective_mode.startswith("2 buckets")
+        assert 0 < two.flat.n_front < two.flat.numel
+        assert (two.graph_b is not None) == use_graph
+        one, l1, sd1 = run(use_graph, force_collective=True, overlap=False)
+        assert not one.split and one.collective_mode.startswith("1 bucket")
+        assert l0 == l1 == l2, (l0, l1, l2)
+        for k in sd0:
+            assert torch.equal(sd0[k], sd1[k]), (use_graph, "1 bucket", k)
+            assert torch.equal(sd0[k], sd2[k]), (use_graph, "2 buckets", k)
 
 
 def test_step_prologue_gives_the_same_step():

@@ -14,7 +14,6 @@ noise (tests/gate_screen.py), and after the replay the step's noise buffer
 must equal the prediction bit for bit.
 """
 import ctypes
-import socket
 
 import numpy as np
 import pytest
@@ -223,50 +222,35 @@ def test_replayed_step_equals_eager_step_bitwise():
         assert torch.equal(s0[k], s1[k]), k
 
 
-def test_two_graph_collective_step_equals_plain_step_bitwise_cfg2():
+def test_two_graph_collective_step_equals_plain_step_bitwise_cfg2(nccl_group):
     """BASELINE.json configs[3]'s step shape on one GPU: a 1-rank RCCL group
     drives TrainStep's two-graph mode (bucket 1 all-reduced between the
     graphs) at cfg-2, B = 128, with Philox noise; it must end on exactly the
     state of the collective-free replayed step."""
-    import torch.distributed as dist
     cfg, B, sd, g = full_size_params("cfg2")
     images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
     labels = torch.randint(0, 10, (3, B), generator=g).cuda()
-    created = False
-    if not dist.is_initialized():
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}",
-                                rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
-        created = True
-    try:
-        out = {}
-        for mode, kw in (("plain", {}),
-                         ("2 buckets", dict(force_collective=True)),
-                         ("1 bucket", dict(force_collective=True,
-                                           overlap=False))):
-            model, step = build_step(cfg, B, sd, **kw)
-            step.capture()
-            if mode == "plain":
-                assert step.collective_mode is None and step.graph_b is None
-            elif mode == "2 buckets":
-                assert step.split and step.graph_b is not None
-                assert 0 < step.flat.n_front < step.flat.numel
-            else:
-                assert step.collective and not step.split
-            _set_counter(step, 1000)
-            out[mode] = _three_steps(step, images, labels)
-        l0, d0, s0 = out["plain"]
-        for mode in ("2 buckets", "1 bucket"):
-            l, d, s = out[mode]
-            assert all(torch.equal(a, b) for a, b in zip(d0, d)), mode
-            assert l == l0, (mode, l, l0)
-            assert set(s) == set(s0)
-            for k in s0:
-                assert torch.equal(s0[k], s[k]), (mode, k)
-    finally:
-        if created:
-            dist.destroy_process_group()
+    out = {}
+    for mode, kw in (("plain", {}),
+                     ("2 buckets", dict(force_collective=True)),
+                     ("1 bucket", dict(force_collective=True,
+                                       overlap=False))):
+        model, step = build_step(cfg, B, sd, **kw)
+        step.capture()
+        if mode == "plain":
+            assert step.collective_mode is None and step.graph_b is None
+        elif mode == "2 buckets":
+            assert step.split and step.graph_b is not None
+            assert 0 < step.flat.n_front < step.flat.numel
+        else:
+            assert step.collective and not step.split
+        _set_counter(step, 1000)
+        out[mode] = _three_steps(step, images, labels)
+    l0, d0, s0 = out["plain"]
+    for mode in ("2 buckets", "1 bucket"):
+        l, d, s = out[mode]
+        assert all(torch.equal(a, b) for a, b in zip(d0, d)), mode
+        assert l == l0, (mode, l, l0)
+        assert set(s) == set(s0)
+        for k in s0:
+            assert torch.equal(s0[k], s[k]), (mode, k)

@@ -5,5 +5,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "mnist_24_24_bs128"
-k1 = bench.time_k1_kernels(bench.CONFIGS[wl], torch.device("cuda", 0), reps=50)
+regime = sys.argv[2] if len(sys.argv) > 2 else "unit"
+k1 = bench.time_k1_kernels(bench.CONFIGS[wl], torch.device("cuda", 0), reps=50, pose_regime=regime)
 print(os.environ.get("SCAE_HIP_LIB", "in-tree"), {k: round(v * 1e6, 1) for k, v in k1.items()}, flush=True)

@@ -261,8 +261,11 @@ int launch_c(const scae_decoder_desc *d, const LpTiling &t, const float *x, floa
 #ifndef SCAE_CELL_NT320
 #define SCAE_CELL_NT320 0
 #endif
+#ifndef SCAE_CELL_REC_KB
+#define SCAE_CELL_REC_KB 16   // LDS budget of a chunk's parked pixel records
+#endif
 #ifndef SCAE_CELL_ITEMS
-#define SCAE_CELL_ITEMS 512
+#define SCAE_CELL_ITEMS 256
 #endif
 template <int C> struct RecOf { static constexpr int RS = C == 1 ? 4 : ((C + 4) & ~1); };
 
@@ -466,21 +469,33 @@ __global__ __launch_bounds__(NTB) void bwd_cell_kernel(
       ncx = max(cxhi - cxlo + 1, 0), ncy = max(cyhi - cylo + 1, 0);
     }
     const int ncells = ncx * ncy;   // (workgroup-uniform)
-    int S = 1;
+    // A cell's pixels are split over P = S x G lanes: S row slices (rows i = ilo + s, step S)
+    // times G segments of each row's interval -- as many as the item budget allows, so that
+    // a pose that puts the whole image into a few cells (a collapsed scale: one cell, 1600
+    // pixels) still spreads over the workgroup instead of serialising on a handful of lanes.
+    int S = 1, G = 1;
     if (ncells > 0) {
-      // row slices per cell: ~2 rounds of items balance the lanes better than one
-      S = item_budget / ncells;
-      S = S < 1 ? 1 : (S > 8 ? 8 : S);
-      const int nitems = ncells * S;
+      const int L = max(item_budget / ncells, 1);
+      const int rows_cell = det_ok ? min(r1 - r0, (int)fminf(fabsf(dix) + fabsf(diy), 1e4f) + 2)
+                                   : r1 - r0;
+      S = min(min(L, rows_cell), 64);
+      const float run = fminf(ax_ok ? fabsf(inv_ax) : 1e4f, ay_ok ? fabsf(inv_ay) : 1e4f);
+      const int jspan = min(W, (int)fminf(run, 1e4f) + 2);   // pixels of a row inside one cell
+      G = max(1, min(L / S, jspan >> 2));
+      const int nparts = S * G, nitems = ncells * nparts;
       const float inv_nc = __builtin_amdgcn_rcpf((float)ncells), inv_ncx = __builtin_amdgcn_rcpf((float)ncx);
+      const float inv_G = __builtin_amdgcn_rcpf((float)G);
       for (int item = tid; item < nitems; item += NTB) {
-        const int sl = fdiv(item, inv_nc), cell = item - sl * ncells;
+        const int part = fdiv(item, inv_nc), cell = item - part * ncells;
+        // (segments fastest: neighbouring lanes read neighbouring records of one row; with
+        // rows fastest their records sit W * 16 bytes apart -- the same LDS banks)
+        const int sl = fdiv(part, inv_G), seg = part - sl * G;
         const int cyi = fdiv(cell, inv_ncx), cxi = cell - cyi * ncx;
         const float cxf = (float)(cxlo + cxi), cyf = (float)(cylo + cyi);
         const int myid = (int)fmaf(cyf, pwf, cxf);
         const float ux = cxf - c0x, uy = cyf - c0y;
         int ilo = r0, ihi = r1 - 1;
-        if (det_ok) {   // rows that cross the cell's parallelogram (+-1 of slack)
+        if (det_ok) {   // rows that cross the cell's parallelogram
           const float i00 = (ax * uy - ay * ux) * inv_det;
           const float imin = i00 + fminf(dix, 0.f) + fminf(diy, 0.f);
           const float imax = i00 + fmaxf(dix, 0.f) + fmaxf(diy, 0.f);
@@ -506,7 +521,13 @@ __global__ __launch_bounds__(NTB) void bwd_cell_kernel(
             hi = fminf(hi, floorf(fmaxf(t0, t1) + kSlack));
           }
           if (!(lo <= hi)) continue;
-          const int jl = (int)lo, jh = (int)hi, base = (i - r0) * W;
+          int jl = (int)lo, jh = (int)hi;
+          if (G > 1) {   // this lane's segment of the interval
+            const int len = fdiv(jh - jl + G, inv_G);
+            jl += seg * len;
+            jh = min(jh, jl + len - 1);
+          }
+          const int base = (i - r0) * W;
 #if SCAE_CELL_ABL == 2
           if (jl > 10000)
 #endif
@@ -532,13 +553,32 @@ __global__ __launch_bounds__(NTB) void bwd_cell_kernel(
             }
           }
         }
-        float *mp = s_part + (size_t)item * NM;
+        float *mp = s_part + (size_t)item * NM;   // [part][cell][NM]
 #pragma unroll
         for (int q = 0; q < NM; q += 4)
           *reinterpret_cast<float4 *>(mp + q) = make_float4(m[q], m[q + 1], m[q + 2], m[q + 3]);
       }
     }
     __syncthreads();
+    // many parts per cell (few, large cells): fold the parts four to one until a texel's
+    // corner sums are short again (fixed order)
+    int P = S * G;
+    while (P > 32) {   // (workgroup-uniform)
+      const int q = (P + 3) >> 2, stride = q * ncells * (NM / 4);   // parts [j q, j q + q), j = 0..3
+      float4 *dst = reinterpret_cast<float4 *>(s_part);
+      for (int t = tid; t < stride; t += NTB) {
+        float4 a4 = dst[t];
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+          if (t + j * stride < P * ncells * (NM / 4)) {
+            const float4 b4 = dst[t + j * stride];
+            a4 = make_float4(a4.x + b4.x, a4.y + b4.y, a4.z + b4.z, a4.w + b4.w);
+          }
+        dst[t] = a4;
+      }
+      __syncthreads();
+      P = q;
+    }
 
     // ---- phase 3: lane = texel: the corner terms of its four cells ----------------------
     if (ncells > 0) {
@@ -554,7 +594,7 @@ __global__ __launch_bounds__(NTB) void bwd_cell_kernel(
           const int cxi = tx - dx - cxlo, cyi = ty - dy - cylo;
           if (cxi < 0 || cxi >= ncx || cyi < 0 || cyi >= ncy) continue;
           const int cell = cyi * ncx + cxi;
-          for (int sl = 0; sl < S; ++sl) {
+          for (int sl = 0; sl < P; ++sl) {
             const float *mp = s_part + (size_t)(sl * ncells + cell) * NM;
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
@@ -602,13 +642,15 @@ CellGeom cell_geom(const scae_decoder_desc *d) {
   const int C = d->C, TX = C == 1 ? 2 : (C <= 3 ? 4 : 8), NV = C + 1;
   const int RS = C == 1 ? 4 : ((C + 4) & ~1);
   // the parked records of a chunk of rows stay below ~32 KB
-  int rows = (32 * 1024 / 4) / ((RS + 1) * d->W);
+  // (C = 1: 16 KB of records -- two chunks of rows at 40 x 40 -- keep five workgroups on a CU;
+  // wider records take 32 KB: splitting a 32 x 32 image costs more than the occupancy returns)
+  int rows = ((NV <= 2 ? SCAE_CELL_REC_KB : 2 * SCAE_CELL_REC_KB) * 1024 / 4) / ((RS + 1) * d->W);
   rows = rows < 1 ? 1 : (rows > d->H ? d->H : rows);
   const int cells = (d->tw + 1) * (d->th + 1);
   g.chunk_rows = rows;
   // (cell, row slice) items per workgroup: ~2 rounds of lanes when their moment partials
   // (16 B per plane and item) stay small beside the records
-  g.item_budget = NV <= 2 ? SCAE_CELL_ITEMS : SCAE_CELL_ITEMS / 2;
+  g.item_budget = SCAE_CELL_ITEMS;
   g.max_items = cells > g.item_budget ? cells : g.item_budget;   // >= ncells * S
   const size_t chunk_px = (size_t)rows * d->W, tsz = (size_t)d->th * d->tw;
   const size_t floats = ((pad_elems(d->th, d->tw) * TX + 3) & ~3) + ((chunk_px * RS + 3) & ~(size_t)3) +
