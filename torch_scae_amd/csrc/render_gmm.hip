@@ -1142,6 +1142,11 @@ extern "C" int scae_template_render_fwd_f32(const scae_decoder_desc *d,
   int rc = check_desc(d);
   if (rc) return rc;
   SCAE_REQUIRE(transformed_templates && mixing_logits);
+#ifndef SCAE_K1_NO_WAVE
+  if (render_wave_lds(d) && (((size_t)transformed_templates | (size_t)mixing_logits) & 15) == 0 &&
+      (!d->bg_image || ((size_t)d->bg_image & 15) == 0))
+    return launch_render_wave(d, transformed_templates, mixing_logits, (hipStream_t)stream);
+#endif
   const size_t lds = sizeof(float) * (size_t)(d->C + 1) * pad_elems(d->th, d->tw);
   int rc2 = set_lds(render_fwd_kernel, lds);
   if (rc2) return rc2;

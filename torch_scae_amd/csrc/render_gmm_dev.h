@@ -70,6 +70,11 @@ int launch_logprob_wave(const scae_decoder_desc *d, const LpTiling &t, const flo
 // LDS bytes the wave form needs for this shape (0: shape not covered)
 size_t logprob_wave_lds(const scae_decoder_desc *d);
 
+// render_gmm_wave.hip: the materialising forward with 16-byte quad stores (alpha-channel
+// mode, H W a multiple of 4); render_wave_lds: LDS bytes, 0 when the shape is not covered.
+size_t render_wave_lds(const scae_decoder_desc *d);
+int launch_render_wave(const scae_decoder_desc *d, float *tt, float *ml, hipStream_t st);
+
 // render_gmm_wave.hip: the fused backward in its cell-gather form (alpha-channel mode,
 // gradient of the per-pixel log-prob or of its tile sums).  bwd_cell_lds: LDS bytes, 0 when
 // the shape is not covered (the caller falls back to render_gmm.hip's kernels).

@@ -32,6 +32,45 @@ template <int C> struct TexelOf { static constexpr int TX = C == 1 ? 2 : (C <= 3
 __device__ __forceinline__ float ex2(float v) { return __builtin_amdgcn_exp2f(v); }
 __device__ __forceinline__ float lg2(float v) { return __builtin_amdgcn_logf(v); }
 
+// Components [k0, k0 + nk) of image b as padded planes of interleaved TX-float texels
+// {channel 0 .. C - 1, alpha * alpha_scale, 0 ..}: one padded texel ROW per thread (one
+// division per row); the caller synchronises.
+template <int C>
+__device__ __forceinline__ void stage_planes(float *s_pl, const scae_decoder_desc &d, int b, int k0,
+                                             int nk, float alpha_scale, int tid, int nthr) {
+  constexpr int TX = TexelOf<C>::TX;
+  const int M = d.M, th = d.th, tw = d.tw, tsz = th * tw;
+  const int psz = pad_elems(th, tw), pw = pad_w(tw), prow = th + 4;
+  const float *g_tmpl = d.templates + (size_t)tb(d, b) * M * C * tsz;
+  const float inv_prow = 1.f / (float)prow;
+  for (int r = tid; r < nk * prow; r += nthr) {
+    const int kl = (int)(((float)r + 0.5f) * inv_prow), yp = r - kl * prow, y = yp - 2, k = k0 + kl;
+    float *dst = s_pl + ((size_t)kl * psz + yp * pw) * TX;
+    const bool in = y >= 0 && y < th;
+    const float *ts = g_tmpl + (size_t)k * C * tsz + y * tw;
+    const float *as = d.templates_alpha + (size_t)k * tsz + y * tw;
+    for (int xp = 0; xp < pw; ++xp) {
+      const int xx = xp - 2;
+      float v[TX];
+#pragma unroll
+      for (int c = 0; c < TX; ++c) v[c] = 0.f;
+      if (in && xx >= 0 && xx < tw) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = ts[c * tsz + xx];
+        v[C] = as[xx] * alpha_scale;
+      }
+      if (TX == 2) {
+        *reinterpret_cast<float2 *>(dst + xp * 2) = make_float2(v[0], v[1]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < TX; c += 4)
+          *reinterpret_cast<float4 *>(dst + xp * TX + c) =
+              make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+      }
+    }
+  }
+}
+
 template <int C>
 __global__ __launch_bounds__(1024) void logprob_wave_kernel(
     scae_decoder_desc d, const float *__restrict__ x, float *__restrict__ log_prob,
@@ -40,8 +79,8 @@ __global__ __launch_bounds__(1024) void logprob_wave_kernel(
   constexpr int TX = TexelOf<C>::TX;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
-  const int M = d.M, W = d.W, HW = d.H * d.W, th = d.th, tw = d.tw, tsz = th * tw;
-  const int psz = pad_elems(th, tw), pw = pad_w(tw), prow = th + 4;
+  const int M = d.M, W = d.W, HW = d.H * d.W, th = d.th, tw = d.tw;
+  const int psz = pad_elems(th, tw), pw = pad_w(tw);
   const Scalars sc = load_scalars(d);
   float *s_pl = smem;                              // M padded planes of TX-float texels
   float *s_coef = s_pl + (size_t)M * psz * TX;     // (M + KC) x 8: texel-space map, presence
@@ -49,34 +88,7 @@ __global__ __launch_bounds__(1024) void logprob_wave_kernel(
 
   // ---- stage: one padded texel row per thread ---------------------------------------
   {
-    const float *g_tmpl = d.templates + (size_t)tb(d, b) * M * C * tsz;
-    const float inv_prow = 1.f / (float)prow;
-    for (int r = tid; r < M * prow; r += nthr) {
-      const int k = (int)(((float)r + 0.5f) * inv_prow), yp = r - k * prow, y = yp - 2;
-      float *dst = s_pl + ((size_t)k * psz + yp * pw) * TX;
-      const bool in = y >= 0 && y < th;
-      const float *ts = g_tmpl + (size_t)k * C * tsz + y * tw;
-      const float *as = d.templates_alpha + (size_t)k * tsz + y * tw;
-      for (int xp = 0; xp < pw; ++xp) {
-        const int xx = xp - 2;
-        float v[TX];
-#pragma unroll
-        for (int c = 0; c < TX; ++c) v[c] = 0.f;
-        if (in && xx >= 0 && xx < tw) {
-#pragma unroll
-          for (int c = 0; c < C; ++c) v[c] = ts[c * tsz + xx];
-          v[C] = as[xx] * kLog2e;
-        }
-        if (TX == 2) {
-          *reinterpret_cast<float2 *>(dst + xp * 2) = make_float2(v[0], v[1]);
-        } else {
-#pragma unroll
-          for (int c = 0; c < TX; c += 4)
-            *reinterpret_cast<float4 *>(dst + xp * TX + c) =
-                make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
-        }
-      }
-    }
+    stage_planes<C>(s_pl, d, b, 0, M, kLog2e, tid, nthr);
     // texel position of normalised (xn, yn):  ix = ((a0 xn + a1 yn + a2 + 1) tw - 1) / 2
     for (int k = tid; k < M + KC; k += nthr) {
       float co[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, kMasked, 0.f};   // k >= M: masked out
@@ -233,6 +245,130 @@ int launch_c(const scae_decoder_desc *d, const LpTiling &t, const float *x, floa
   }
   hipLaunchKernelGGL((logprob_wave_kernel<C>), dim3(t.tiles, d->B), dim3(t.ppb), lds, st, *d, x,
                      log_prob, lse_post, lse_prior, t.ppb, block_sums);
+  return scae_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Materialising forward (transformed_templates, mixing_logits: part_decoder.py:174-231) in
+// the same lane layout.  The tensors are a pure write stream (41 MB at cfg-2, x O more for
+// the per-object-capsule reconstructions of reconstruct_alternatives), so the kernel is
+// built around the stores: a lane owns FOUR consecutive pixels and every store is a full
+// 16-byte quad of one (b, k, c) plane row (1 KiB contiguous per wave instruction); a
+// workgroup = all pixel quads of one image x a group of KG components, whose planes it
+// stages once -- the per-workgroup set-up of render_gmm.hip's one-component workgroups
+// (scalars, staging, 6 pixels per thread) is shared by KG x 4 pixels per thread.
+template <int C>
+__global__ __launch_bounds__(1024) void render_wave_kernel(scae_decoder_desc d,
+                                                           float *__restrict__ tt,
+                                                           float *__restrict__ ml, int KG) {
+  constexpr int TX = TexelOf<C>::TX;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const int M = d.M, K = M + 1, W = d.W, HW = d.H * d.W, th = d.th, tw = d.tw;
+  const int psz = pad_elems(th, tw), pw = pad_w(tw);
+  const int k0 = blockIdx.x * KG, k1 = min(K, k0 + KG), nk = min(M, k1) - k0;   // nk templates
+  float *s_pl = smem;                                  // nk padded planes
+  float *s_pose = s_pl + (size_t)KG * psz * TX;        // KG x 8: pose (6), log presence
+  if (nk > 0) stage_planes<C>(s_pl, d, b, k0, nk, 1.f, tid, nthr);
+  for (int kl = tid; kl < nk; kl += nthr) {
+    const float *a = d.pose + ((size_t)b * M + k0 + kl) * 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s_pose[kl * 8 + i] = a[i];
+    s_pose[kl * 8 + 6] = d.presence ? log_safe(d.presence[b * M + k0 + kl]) : 0.f;   // :225-231
+  }
+  __syncthreads();
+
+  const int p0 = 4 * tid;
+  if (p0 >= HW) return;
+  const float inv_w = 1.f / (float)W, inv_h = 1.f / (float)d.H;
+  float xn[4], yn[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int p = p0 + e, pi = (int)(((float)p + 0.5f) * inv_w), pj = p - pi * W;
+    xn[e] = (float)(2 * pj + 1) * inv_w - 1.f;
+    yn[e] = (float)(2 * pi + 1) * inv_h - 1.f;
+  }
+  const float txf = (float)tw, tyf = (float)th, pwf = (float)pw;
+  const float *s_tap = s_pl + (size_t)(2 * pw + 2) * TX;
+  for (int kl = 0; kl < nk; ++kl) {
+    const float *a = s_pose + kl * 8;
+    const float lsp = a[6];
+    float v[TX][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ix, iy;
+      tex_pos(a, xn[e], yn[e], tw, th, ix, iy);
+      ix = fminf(fmaxf(ix, -2.f), txf);
+      iy = fminf(fmaxf(iy, -2.f), tyf);
+      const float x0f = floorf(ix), y0f = floorf(iy), fx = ix - x0f, fy = iy - y0f;
+      const float *q0 = s_tap + ((size_t)kl * psz + (int)fmaf(y0f, pwf, x0f)) * TX;
+      const float *q1 = q0 + pw * TX;
+#pragma unroll
+      for (int c = 0; c <= C; ++c) {
+        const float v00 = q0[c], v01 = q0[TX + c], v10 = q1[c], v11 = q1[TX + c];
+        const float t0 = fmaf(fx, v01 - v00, v00), t1 = fmaf(fx, v11 - v10, v10);
+        v[c][e] = fmaf(fy, t1 - t0, t0);
+      }
+    }
+    const size_t kb = (size_t)b * K + k0 + kl;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      *reinterpret_cast<float4 *>(tt + (kb * C + c) * HW + p0) =
+          make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+    *reinterpret_cast<float4 *>(ml + kb * HW + p0) =
+        make_float4(v[C][0] + lsp, v[C][1] + lsp, v[C][2] + lsp, v[C][3] + lsp);
+  }
+  if (k1 == K) {   // this group ends with the background component, :189-195, :210-213
+    const float bg_ml = softplusf_(d.bg_mixing_logit[0]);
+    const float bg_val = d.bg_image ? 0.f : sigmoidf_(d.bg_value[0]);
+    const size_t kb = (size_t)b * K + M;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      *reinterpret_cast<float4 *>(tt + (kb * C + c) * HW + p0) =
+          d.bg_image ? *reinterpret_cast<const float4 *>(d.bg_image + ((size_t)b * C + c) * HW + p0)
+                     : make_float4(bg_val, bg_val, bg_val, bg_val);
+    *reinterpret_cast<float4 *>(ml + kb * HW + p0) = make_float4(bg_ml, bg_ml, bg_ml, bg_ml);
+  }
+}
+
+#ifndef SCAE_RENDER_WGS
+#define SCAE_RENDER_WGS 512
+#endif
+#ifndef SCAE_RENDER_MINK
+#define SCAE_RENDER_MINK 4
+#endif
+struct RenderGeom {
+  int groups, KG, threads;
+  size_t lds;
+};
+RenderGeom render_geom(const scae_decoder_desc *d) {
+  RenderGeom g = {0, 0, 0, 0};
+  const int HW = d->H * d->W, K = d->M + 1;
+  // alpha-channel mode, whole pixel quads, one thread per quad of the image
+  if (!d->templates_alpha || d->C < 1 || d->C > 4 || HW % 4 || HW / 4 > 1024) return g;
+  const int TX = d->C == 1 ? 2 : (d->C <= 3 ? 4 : 8);
+  // component groups: >= 2 workgroups per CU when the batch allows, >= 4 components each
+  int groups = (SCAE_RENDER_WGS + d->B - 1) / d->B;
+  if (groups > (K + SCAE_RENDER_MINK - 1) / SCAE_RENDER_MINK) groups = (K + SCAE_RENDER_MINK - 1) / SCAE_RENDER_MINK;
+  if (groups < 1) groups = 1;
+  g.KG = (K + groups - 1) / groups;
+  g.groups = (K + g.KG - 1) / g.KG;
+  g.threads = ((HW / 4 + 63) / 64) * 64;
+  const size_t bytes = sizeof(float) * ((size_t)g.KG * pad_elems(d->th, d->tw) * TX + (size_t)g.KG * 8);
+  g.lds = bytes <= 64 * 1024 ? bytes : 0;
+  return g;
+}
+
+template <int C>
+int launch_render_c(const scae_decoder_desc *d, const RenderGeom &g, float *tt, float *ml,
+                    hipStream_t st) {
+  if (g.lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(render_wave_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL((render_wave_kernel<C>), dim3(g.groups, d->B), dim3(g.threads), g.lds, st, *d,
+                     tt, ml, g.KG);
   return scae_launch_status();
 }
 
@@ -695,6 +831,20 @@ int launch_logprob_wave(const scae_decoder_desc *d, const LpTiling &t, const flo
     case 2: return launch_c<2>(d, t, x, log_prob, lse_post, lse_prior, block_sums, st);
     case 3: return launch_c<3>(d, t, x, log_prob, lse_post, lse_prior, block_sums, st);
     case 4: return launch_c<4>(d, t, x, log_prob, lse_post, lse_prior, block_sums, st);
+    default: return SCAE_ERR_UNSUPPORTED;
+  }
+}
+
+size_t render_wave_lds(const scae_decoder_desc *d) { return render_geom(d).lds; }
+
+int launch_render_wave(const scae_decoder_desc *d, float *tt, float *ml, hipStream_t st) {
+  const RenderGeom g = render_geom(d);
+  if (!g.lds) return SCAE_ERR_UNSUPPORTED;
+  switch (d->C) {
+    case 1: return launch_render_c<1>(d, g, tt, ml, st);
+    case 2: return launch_render_c<2>(d, g, tt, ml, st);
+    case 3: return launch_render_c<3>(d, g, tt, ml, st);
+    case 4: return launch_render_c<4>(d, g, tt, ml, st);
     default: return SCAE_ERR_UNSUPPORTED;
   }
 }
