@@ -134,6 +134,24 @@ int scae_set_encoder_bwd_f32(int nseg, const float *const *seg_ptr, const int *s
                              const float *params, const float *hsave, const float *gz,
                              float *pg_partial, int B, int N, int D, int Din, int Dout,
                              int L, int layer_norm, void *stream);
+/* BASELINE.json configs[2] ("bf16 ... MFMA attention path"): the same two passes with the
+ * attention products of every block -- Q K^T, P V (set_transformer.py:24-47) and, in the
+ * backward, dO V^T, dS K, dS^T Q, P^T dO -- on v_mfma_f32_16x16x16_bf16 (operands rounded
+ * to bf16, fp32 accumulate); mask / scale / softmax, projections, LayerNorm and the saved
+ * activations stay fp32.  scae_set_encoder_bf16_supported: the shapes the matrix-core
+ * (one wave per 16-row tile) kernels cover; others return SCAE_ERR_UNSUPPORTED. */
+int scae_set_encoder_bf16_supported(int N, int D, int Din, int Dout, int L, int layer_norm);
+int scae_set_encoder_fwd_bf16(int nseg, const float *const *seg_ptr, const int *seg_width,
+                              const int *seg_row_stride, const int64_t *seg_batch_stride,
+                              const float *presence, const float *params, float *z,
+                              float *hsave, int B, int N, int D, int Din, int Dout, int L,
+                              int layer_norm, void *stream);
+int scae_set_encoder_bwd_bf16(int nseg, const float *const *seg_ptr, const int *seg_width,
+                              const int *seg_row_stride, const int64_t *seg_batch_stride,
+                              float *const *seg_grad, const float *presence,
+                              const float *params, const float *hsave, const float *gz,
+                              float *pg_partial, int B, int N, int D, int Din, int Dout,
+                              int L, int layer_norm, void *stream);
 
 /* ------------------------------------------------------------------------
  * K2c  output attention with folded projections

@@ -592,7 +592,8 @@ def test_cfg3_bf16_operands_vs_fp32_oracle_with_gradients():
     """BASELINE.json configs[2] at full size (48 part / 64 object capsules,
     bs = 1024) in its precision: bf16 operands with fp32 accumulation on the
     GEMM-shaped kernels (K8 convolutions, K7 capsule-MLP and 1x1-conv GEMMs,
-    forward and backward; ops.mfma_bf16), fp32 everywhere else.  Against the
+    the attention products of the object encoder's fused trunk -- forward and
+    backward; ops.mfma_bf16), fp32 everywhere else.  Against the
     fp32 oracle on identical parameters / batch / noise, at bf16's bar: 2^-7
     relative on the loss and every log entry; every parameter gradient within
     5e-2 relative L2 (an operand carries 8 significant bits; the errors of a
@@ -617,7 +618,10 @@ def test_cfg3_bf16_operands_vs_fp32_oracle_with_gradients():
         ops._lib.call = real
     used = {n for n in calls if n.endswith("_bf16")}
     assert used == {"scae_conv3x3_fwd_bf16", "scae_conv3x3_bwd_pair_bf16",
-                    "scae_gemm_bf16", "scae_gemm_pair_bf16"}, used
+                    "scae_gemm_bf16", "scae_gemm_pair_bf16",
+                    # the attention products of the fused object-encoder trunk
+                    "scae_set_encoder_fwd_bf16", "scae_set_encoder_bwd_bf16"}, \
+        used
     tol = 2.0 ** -7
     assert abs(float(loss) - float(oloss)) <= tol * abs(float(oloss))
     for k, v in olog.items():

@@ -728,6 +728,98 @@ def test_trunk_on_matrix_cores_vs_oracle(B, N, widths, L, ln, pres):
     assert n == 2 + L * (10 + (4 if ln else 0))
 
 
+@pytest.mark.parametrize("B,N,widths,L,ln,pres", [
+    (128, 24, (6, 1, 16, 121), 3, True, "mixed"),   # cfg-2
+    (70, 48, (6, 1, 16, 121), 3, True, "mixed"),    # configs[2]: 48 part capsules
+    (9, 40, (6, 1, 16, 121), 3, True, "rand"),      # ragged third tile
+    (5, 64, (11,), 2, False, None),                 # four full tiles, no LayerNorm
+])
+def test_trunk_bf16_attention_vs_fp32_oracle(B, N, widths, L, ln, pres):
+    """BASELINE.json configs[2] ("bf16 ... MFMA attention path") inside the fused
+    trunk: under ``ops.mfma_bf16()`` the attention products of every block --
+    Q K^T, P V and the four products of their backward -- take bf16 operands on
+    v_mfma_f32_16x16x16_bf16 (fp32 accumulate); everything else stays fp32.
+    Against the fp32 oracle at bf16's bar, written here: 2^-7 of the largest
+    entry on the output; 5e-2 relative L2 on the segment gradients and on
+    every parameter gradient (an operand carries 8 significant bits; the
+    errors of L chained blocks and of the softmax backward's cancellation add
+    up), plus 2e-3 of the largest parameter-gradient norm for the gradients
+    that are zero by symmetry (the key bias: the softmax ignores a shift of
+    all keys).  The fp32 entry on the same inputs stays at 1e-4, so the
+    difference is the operand rounding and nothing else."""
+    from torch_scae_amd import ops
+    from torch_scae_amd.set_transformer import SetTransformer
+    D = 16
+    torch.manual_seed(B + N)
+    Din = sum(widths)
+    st = SetTransformer(dim_in=Din, dim_hidden=D, dim_out=32, n_outputs=4,
+                        n_layers=L, n_heads=1, layer_norm=ln)
+    g = torch.Generator().manual_seed(23)
+    with torch.no_grad():
+        for q in st.parameters():
+            q.add_(torch.randn(q.shape, generator=g) * 0.1)
+    P = {"m." + k: v.clone().requires_grad_(True)
+         for k, v in st.state_dict().items()}
+    wide = torch.randn(B, N, Din + 3, generator=g)
+    p = None
+    if pres == "rand":
+        p = torch.rand(B, N, generator=g)
+    elif pres == "mixed":
+        p = torch.ones(B, N)
+        p[:, ::3] = torch.rand(B, len(range(0, N, 3)), generator=g)
+    w = torch.randn(B, N, D, generator=g)
+    xc = wide[..., 1:1 + Din].clone().requires_grad_(True)
+    h = O._linear(P, "m.fc1", xc)
+    for l in range(L):
+        h = O.sab(P, f"m.sabs.{l}", h, p, 1, ln)
+    (h * w).sum().backward()
+
+    st = st.cuda()
+    wide_g = wide.cuda()
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    def run(bf16):
+        segs, col = [], 1
+        for wd in widths:
+            segs.append(wide_g[..., col:col + wd].detach().requires_grad_(True))
+            col += wd
+        st.zero_grad(set_to_none=True)
+        with ops.mfma_bf16(bf16):
+            hg = ops.set_encoder(segs, dev(p), st._packed_trunk(with_fc2=False),
+                                 D, 0, L, ln)
+            (hg * w.cuda()).sum().backward()
+        return hg, torch.cat([s_.grad for s_ in segs], -1), \
+            {k: q.grad.clone() for k, q in st.named_parameters()
+             if q.grad is not None}
+
+    ops._lib.call = spy
+    try:
+        hb, gxb, gb = run(True)
+    finally:
+        ops._lib.call = real
+    assert calls[:2] == ["scae_set_encoder_fwd_bf16",
+                         "scae_set_encoder_bwd_bf16"], calls
+    hf, gxf, gf = run(False)
+    assert_close(hf, h, 1e-4, 1e-4, "fp32 trunk output")
+    tol = 2.0 ** -7
+    assert not torch.equal(hb, hf)          # the bf16 kernels really ran
+    assert_close(hb, h, tol * float(h.abs().max()), 0, "bf16 trunk output")
+    rel = float((gxb.cpu() - xc.grad).norm() / xc.grad.norm())
+    assert rel <= 5e-2, ("bf16 segment gradients", rel)
+    refs = {k: q.grad for k, q in P.items()
+            if q.grad is not None and k[2:] in gb}
+    floor = 2e-3 * max(float(v.norm()) for v in refs.values())
+    worst = sorted(((float((gb[k[2:]].cpu() - v).norm())
+                     / (5e-2 * float(v.norm()) + floor), k)
+                    for k, v in refs.items()), reverse=True)
+    assert len(worst) >= 2 + L * 10 and worst[0][0] <= 1.0, worst[:5]
+
+
 @pytest.mark.parametrize("B,N,O,C,pres", [
     (128, 24, 24, 256, "mixed"),    # cfg-2
     (600, 24, 24, 64, "rand"),      # B > grid: partial rows accumulate

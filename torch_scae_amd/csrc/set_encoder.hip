@@ -781,12 +781,19 @@ extern "C" int scae_set_encoder_supported(int N, int D, int Din, int Dout, int L
   return need <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int scae_set_encoder_fwd_f32(int nseg, const float *const *seg_ptr,
-                                        const int *seg_width, const int *seg_row_stride,
-                                        const int64_t *seg_batch_stride, const float *presence,
-                                        const float *params, float *z, float *hsave, int B,
-                                        int N, int D, int Din, int Dout, int L, int layer_norm,
-                                        void *stream) {
+extern "C" int scae_set_encoder_bf16_supported(int N, int D, int Din, int Dout, int L,
+                                               int layer_norm) {
+  if (N <= 0 || N > NMAX || Din <= 0 || Dout < 0 || L < 0) return 0;
+  StArgs a{};
+  a.N = N, a.Din = Din, a.Dout = Dout, a.L = L, a.layer_norm = layer_norm;
+  return use_wave(a, D) ? 1 : 0;
+}
+
+namespace {
+int encoder_fwd(bool bf16, int nseg, const float *const *seg_ptr, const int *seg_width,
+                const int *seg_row_stride, const int64_t *seg_batch_stride,
+                const float *presence, const float *params, float *z, float *hsave, int B, int N,
+                int D, int Din, int Dout, int L, int layer_norm, void *stream) {
   StArgs a{};
   int rc = fill_args(a, nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride, nullptr,
                      presence, params, B, N, D, Din, Dout, L, layer_norm);
@@ -794,8 +801,10 @@ extern "C" int scae_set_encoder_fwd_f32(int nseg, const float *const *seg_ptr,
   SCAE_REQUIRE(z && hsave);
   a.z = z;
   a.hsave = hsave;
+  a.bf16_attention = bf16;
   const int grid = scae_set_encoder_grid(B);
   if (use_wave(a, D)) return scae_st::wave_launch(a, false, grid, (hipStream_t)stream);
+  if (bf16) return SCAE_ERR_UNSUPPORTED;   // only the matrix-core kernels have the bf16 form
   switch (D) {
     case 8: return launch<8>(a, false, grid, (hipStream_t)stream);
     case 16: return launch<16>(a, false, grid, (hipStream_t)stream);
@@ -803,13 +812,11 @@ extern "C" int scae_set_encoder_fwd_f32(int nseg, const float *const *seg_ptr,
   }
 }
 
-extern "C" int scae_set_encoder_bwd_f32(int nseg, const float *const *seg_ptr,
-                                        const int *seg_width, const int *seg_row_stride,
-                                        const int64_t *seg_batch_stride,
-                                        float *const *seg_grad, const float *presence,
-                                        const float *params, const float *hsave,
-                                        const float *gz, float *pg_partial, int B, int N, int D,
-                                        int Din, int Dout, int L, int layer_norm, void *stream) {
+int encoder_bwd(bool bf16, int nseg, const float *const *seg_ptr, const int *seg_width,
+                const int *seg_row_stride, const int64_t *seg_batch_stride,
+                float *const *seg_grad, const float *presence, const float *params,
+                const float *hsave, const float *gz, float *pg_partial, int B, int N, int D,
+                int Din, int Dout, int L, int layer_norm, void *stream) {
   StArgs a{};
   int rc = fill_args(a, nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride, seg_grad,
                      presence, params, B, N, D, Din, Dout, L, layer_norm);
@@ -818,11 +825,39 @@ extern "C" int scae_set_encoder_bwd_f32(int nseg, const float *const *seg_ptr,
   a.hsave = const_cast<float *>(hsave);
   a.gz = gz;
   a.pg_partial = pg_partial;
+  a.bf16_attention = bf16;
   const int grid = scae_set_encoder_grid(B);
   if (use_wave(a, D)) return scae_st::wave_launch(a, true, grid, (hipStream_t)stream);
+  if (bf16) return SCAE_ERR_UNSUPPORTED;
   switch (D) {
     case 8: return launch<8>(a, true, grid, (hipStream_t)stream);
     case 16: return launch<16>(a, true, grid, (hipStream_t)stream);
     default: return launch<32>(a, true, grid, (hipStream_t)stream);
   }
 }
+}  // namespace
+
+#define SCAE_ENCODER_ENTRY(SUFFIX, BF)                                                          \
+  extern "C" int scae_set_encoder_fwd_##SUFFIX(                                                 \
+      int nseg, const float *const *seg_ptr, const int *seg_width, const int *seg_row_stride,   \
+      const int64_t *seg_batch_stride, const float *presence, const float *params, float *z,    \
+      float *hsave, int B, int N, int D, int Din, int Dout, int L, int layer_norm,              \
+      void *stream) {                                                                           \
+    return encoder_fwd(BF, nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride,          \
+                       presence, params, z, hsave, B, N, D, Din, Dout, L, layer_norm, stream);  \
+  }                                                                                             \
+  extern "C" int scae_set_encoder_bwd_##SUFFIX(                                                 \
+      int nseg, const float *const *seg_ptr, const int *seg_width, const int *seg_row_stride,   \
+      const int64_t *seg_batch_stride, float *const *seg_grad, const float *presence,           \
+      const float *params, const float *hsave, const float *gz, float *pg_partial, int B,       \
+      int N, int D, int Din, int Dout, int L, int layer_norm, void *stream) {                    \
+    return encoder_bwd(BF, nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride,          \
+                       seg_grad, presence, params, hsave, gz, pg_partial, B, N, D, Din, Dout,   \
+                       L, layer_norm, stream);                                                  \
+  }
+SCAE_ENCODER_ENTRY(f32, false)
+// bf16 operands / fp32 accumulation for the attention products of every block
+// (BASELINE.json configs[2]); projections, LayerNorm, softmax and the saved activations stay
+// fp32.  SCAE_ERR_UNSUPPORTED where only the workgroup-per-set kernels apply.
+SCAE_ENCODER_ENTRY(bf16, true)
+#undef SCAE_ENCODER_ENTRY

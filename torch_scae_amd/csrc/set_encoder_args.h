@@ -27,6 +27,7 @@ struct StArgs {
   float *pg_partial;      // bwd: (gridDim.x, P) per-workgroup parameter grads
   int B, N, Din, Dout, L, layer_norm;
   float sqrt_d;
+  int bf16_attention;     // wave kernels only: bf16 operands for the attention products
 };
 
 // set_encoder_wave.hip: whether it covers the problem, and its launches (grid rows of

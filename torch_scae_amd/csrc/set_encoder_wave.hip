@@ -102,6 +102,12 @@ __device__ __forceinline__ f32x4 mma_n(f32x4 acc, const Wave &w, const float *A,
                                        const float *B, int ub) {
   return mmak<NT>(acc, w.template rdk<NT>(A, ua), w.template rdk<NT>(B, ub));
 }
+// ... in the attention's precision (BF: bf16 operands, fp32 accumulate)
+template <int NT, bool BF>
+__device__ __forceinline__ f32x4 mma_np(f32x4 acc, const Wave &w, const float *A, int ua,
+                                        const float *B, int ub) {
+  return mmakp<NT, BF>(acc, w.template rdk<NT>(A, ua), w.template rdk<NT>(B, ub));
+}
 
 // LayerNorm over the 16 features of the rows of an O-layout tile
 template <bool KEEP>
@@ -167,7 +173,7 @@ struct Tiles {
 // One SAB: h (O layout, own tile) -> h.  NT = number of 16-row tiles (= waves) of the set.
 // `par`: parity of the block counter (the forward's K / V buffers).  KEEP: fill `st` and
 // leave V row-major / K transposed / Q transposed behind for the backward pass.
-template <int NT, bool KEEP>
+template <int NT, bool KEEP, bool BF>
 __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const float *Wl,
                                             const Tiles<NT> &tl, f32x4 &h, const f32x4 &pres,
                                             const float (&kmask)[NT], int N, float sqrt_d,
@@ -216,7 +222,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   {
     const float4 qa = w.rd16(Qs, t);
 #pragma unroll
-    for (int u = 0; u < NT; ++u) s[u] = mma16(splat(0.f), qa, w.rd16(Ks, u));
+    for (int u = 0; u < NT; ++u) s[u] = mma16p<BF>(splat(0.f), qa, w.rd16(Ks, u));
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -241,7 +247,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   // a = P V
   w.template wr_nn<NT>(Ps, s);
   lds_fence();
-  const f32x4 ao = mma_n<NT>(splat(0.f), w, Ps, t, Vt, 0);   // B[k = m][c]: row c of Vt
+  const f32x4 ao = mma_np<NT, BF>(splat(0.f), w, Ps, t, Vt, 0);   // B[k = m][c]: row c of Vt
   if (KEEP) st->ao = ao;
   // r = (Wo a + bo + h) presence_n; LN0
   w.wr_rows(As, ao);
@@ -357,7 +363,7 @@ struct LayerGrads {
 
 // Backward of one SAB given everything sab_forward<KEEP> left behind; G: gradient w.r.t.
 // the block output on entry, w.r.t. its input on return (own tile).
-template <int NT>
+template <int NT, bool BF>
 __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, const float *Wl,
                                              const Tiles<NT> &tl, f32x4 &G, const f32x4 &pres,
                                              int N, float sqrt_d, const SabState<NT> &st,
@@ -405,7 +411,7 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
   {
     const float4 gaa = w.rd16(GR, t);
 #pragma unroll
-    for (int u = 0; u < NT; ++u) ds[u] = mma16(splat(0.f), gaa, w.rd16(Vs, u));
+    for (int u = 0; u < NT; ++u) ds[u] = mma16p<BF>(splat(0.f), gaa, w.rd16(Vs, u));
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -421,9 +427,9 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
   w.template wr_nn_t<NT>(PT, st.p);
   lds_fence();
   if (NT > 1) __syncthreads();   // the other wave's dS^T, P^T, GA^T columns
-  const f32x4 dq = mma_n<NT>(splat(0.f), w, DSR, t, Kt, 0);   // sum_m dS[n][m] K[m][i]
-  const f32x4 dk = mma_n<NT>(splat(0.f), w, DST, t, Qt, 0);   // sum_n dS[n][m] Q[n][i]
-  const f32x4 dv = mma_n<NT>(splat(0.f), w, PT, t, GT, 0);    // sum_n P[n][m] GA[n][i]
+  const f32x4 dq = mma_np<NT, BF>(splat(0.f), w, DSR, t, Kt, 0);   // sum_m dS[n][m] K[m][i]
+  const f32x4 dk = mma_np<NT, BF>(splat(0.f), w, DST, t, Qt, 0);   // sum_n dS[n][m] Q[n][i]
+  const f32x4 dv = mma_np<NT, BF>(splat(0.f), w, PT, t, GT, 0);    // sum_n P[n][m] GA[n][i]
   // projections: weight gradients and the gradient w.r.t. the block input
   w.wr_cols(XT2, st.hin);
   f32x4 gin = go;
@@ -486,7 +492,7 @@ __device__ __forceinline__ void flush_layer(const Wave &w, const Lay &lay, const
   }
 }
 
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Lay lay{a.Din, a.L, a.layer_norm};
@@ -532,9 +538,9 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
       }
       SabState<NT> st;
       const float *Wl = a.params + lay.layer(l);
-      sab_forward<NT, true>(w, lay, Wl, tiles, h, pres, kmask, N, a.sqrt_d, 0, &st);
+      sab_forward<NT, true, BF>(w, lay, Wl, tiles, h, pres, kmask, N, a.sqrt_d, 0, &st);
       LayerGrads lg;
-      sab_backward<NT>(w, lay, Wl, tiles, G, pres, N, a.sqrt_d, st, lg);
+      sab_backward<NT, BF>(w, lay, Wl, tiles, G, pres, N, a.sqrt_d, st, lg);
       flush_layer<NT>(w, lay, tiles, lg, part + lay.layer(l), first);
     }
     // fc1: db1, dW1 = G^T x (column tiles split between the waves, K over all rows),
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
   }
 }
 
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Lay lay{a.Din, a.L, a.layer_norm};
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
     for (int l = 0; l <= a.L; ++l) {
       save(hs + (size_t)l * N * D);
       if (l < a.L) {
-        sab_forward<NT, false>(w, lay, a.params + lay.layer(l), tiles, h, pres, kmask, N,
+        sab_forward<NT, false, BF>(w, lay, a.params + lay.layer(l), tiles, h, pres, kmask, N,
                                a.sqrt_d, blk & 1, nullptr);
         ++blk;
       }
@@ -684,28 +690,33 @@ bool wave_supported(const StArgs &a, int Dh) {
          lds_need(a.N, a.Din, true) <= 160 * 1024 && lds_need(a.N, a.Din, false) <= 160 * 1024;
 }
 
-template <int NT>
+template <int NT, bool BF>
 static int launch_nt(const StArgs &a, bool bwd, int grid, hipStream_t st) {
   const size_t lds = lds_floats<NT>(a.Din, bwd) * sizeof(float);
-  const void *fn = bwd ? reinterpret_cast<const void *>(stw_bwd_kernel<NT>)
-                       : reinterpret_cast<const void *>(stw_fwd_kernel<NT>);
+  const void *fn = bwd ? reinterpret_cast<const void *>(stw_bwd_kernel<NT, BF>)
+                       : reinterpret_cast<const void *>(stw_fwd_kernel<NT, BF>);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   if (bwd)
-    hipLaunchKernelGGL(stw_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), lds, st, a);
+    hipLaunchKernelGGL((stw_bwd_kernel<NT, BF>), dim3(grid), dim3(64 * NT), lds, st, a);
   else
-    hipLaunchKernelGGL(stw_fwd_kernel<NT>, dim3(grid), dim3(64 * NT), lds, st, a);
+    hipLaunchKernelGGL((stw_fwd_kernel<NT, BF>), dim3(grid), dim3(64 * NT), lds, st, a);
   return scae_launch_status();
 }
 
+// a.bf16_attention: the attention products of every block (Q K^T, P V; dO V^T, dS K, dS^T Q,
+// P^T dO in the backward) take bf16 operands on v_mfma_f32_16x16x16_bf16
 int wave_launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
+#define SCAE_STW(NTV) \
+  return a.bf16_attention ? launch_nt<NTV, true>(a, bwd, grid, st) : launch_nt<NTV, false>(a, bwd, grid, st)
   switch (tiles_of(a.N)) {
-    case 1: return launch_nt<1>(a, bwd, grid, st);
-    case 2: return launch_nt<2>(a, bwd, grid, st);
-    case 3: return launch_nt<3>(a, bwd, grid, st);
-    default: return launch_nt<4>(a, bwd, grid, st);
+    case 1: SCAE_STW(1);
+    case 2: SCAE_STW(2);
+    case 3: SCAE_STW(3);
+    default: SCAE_STW(4);
   }
+#undef SCAE_STW
 }
 }  // namespace scae_st

@@ -30,6 +30,23 @@ __device__ __forceinline__ f32x4 mma16(f32x4 acc, float4 a, float4 b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
   return acc;
 }
+// The same K = 16 product with bf16 operands (BASELINE.json configs[2], "bf16 ... MFMA
+// attention path"): the lane's four consecutive k are rounded to bf16 (nearest even) and
+// contracted by ONE v_mfma_f32_16x16x16_bf16, fp32 accumulate.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
+  // (a compiler-visible conversion, not inline asm: the result feeds an MFMA directly and
+  // the hazard recogniser must see the VALU write to place the wait states)
+  const f32x4 f = {v.x, v.y, v.z, v.w};
+  const bf16x4v h = __builtin_convertvector(f, bf16x4v);
+  return __builtin_bit_cast(bf16x4, h);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 mma16p(f32x4 acc, float4 a, float4 b) {
+  if (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(a), to_bf16x4(b), acc, 0, 0, 0);
+  return mma16(acc, a, b);
+}
 struct F8 {
   float4 lo, hi;
 };
@@ -76,6 +93,12 @@ template <int NT>
 __device__ __forceinline__ f32x4 mmak(f32x4 acc, const FK<NT> &a, const FK<NT> &b) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc = mma16(acc, a.v[j], b.v[j]);
+  return acc;
+}
+template <int NT, bool BF>
+__device__ __forceinline__ f32x4 mmakp(f32x4 acc, const FK<NT> &a, const FK<NT> &b) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc = mma16p<BF>(acc, a.v[j], b.v[j]);
   return acc;
 }
 }  // namespace scae_wave

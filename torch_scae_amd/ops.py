@@ -491,7 +491,12 @@ class _SetEncoder(torch.autograd.Function):
         hsave = torch.empty(B, L + 1, N, D, device=packed.device,
                             dtype=packed.dtype)
         ptrs, widths, rs, bs = _seg_arrays(segs)
-        _lib.call("scae_set_encoder_fwd_f32", len(segs), ptrs, widths, rs, bs,
+        # configs[2]'s precision (inside ``mfma_bf16()``): bf16 operands for the
+        # attention products of every block, forward and backward
+        ctx.bf16 = bool(_MFMA_BF16 and lib.scae_set_encoder_bf16_supported(
+            N, D, Din, Dout, L, int(layer_norm)))
+        _lib.call("scae_set_encoder_fwd_bf16" if ctx.bf16 else
+                  "scae_set_encoder_fwd_f32", len(segs), ptrs, widths, rs, bs,
                   _p(presence), _p(packed), _p(z), _p(hsave), B, N, D, Din,
                   Dout, L, int(layer_norm), _stream(packed))
         ctx.save_for_backward(packed, hsave, *segs,
@@ -518,7 +523,8 @@ class _SetEncoder(torch.autograd.Function):
         ptrs, widths, rs, bs = _seg_arrays(segs)
         gptrs = (ctypes.c_void_p * len(segs))(
             *[None if g is None else g.data_ptr() for g in gsegs])
-        _lib.call("scae_set_encoder_bwd_f32", len(segs), ptrs, widths, rs, bs,
+        _lib.call("scae_set_encoder_bwd_bf16" if ctx.bf16 else
+                  "scae_set_encoder_bwd_f32", len(segs), ptrs, widths, rs, bs,
                   gptrs, _p(presence), _p(packed), _p(hsave), _p(gz),
                   _p(partial), B, N, D, Din, Dout, L, ln, _stream(packed))
         taken_before = ctx.slot is not None and ctx.slot.taken
