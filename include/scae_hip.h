@@ -203,6 +203,16 @@ int scae_seed_attention_mfma_bwd_f32(const float *h, const float *q, const float
                                      const float *wv, const float *presence, const float *gout,
                                      float *gh, float *partial, int B, int N, int O, int C,
                                      void *stream);
+/* BASELINE.json configs[2]: the attention products of the output attention (logits q.wkf h^T,
+ * P h; backward dT h^T, dS h, P^T dT + dS^T qk) on v_mfma_f32_16x16x16_bf16, everything else
+ * (folded projections, softmax, the C-wide output product) fp32.  Same arguments. */
+int scae_seed_attention_mfma_fwd_bf16(const float *h, const float *q, const float *wk,
+                                      const float *wv, const float *bv, const float *presence,
+                                      float *out, int B, int N, int O, int C, void *stream);
+int scae_seed_attention_mfma_bwd_bf16(const float *h, const float *q, const float *wk,
+                                      const float *wv, const float *presence,
+                                      const float *gout, float *gh, float *partial, int B,
+                                      int N, int O, int C, void *stream);
 int scae_seed_attention_mfma_reduce_f32(const float *partial, int rows, const float *q,
                                         const float *wk, float *gq, float *gwk, float *gbk,
                                         float *gwv, float *gbv, int O, int C, void *stream);

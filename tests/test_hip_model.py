@@ -620,8 +620,10 @@ def test_cfg3_bf16_operands_vs_fp32_oracle_with_gradients():
     assert used == {"scae_conv3x3_fwd_bf16", "scae_conv3x3_bwd_pair_bf16",
                     "scae_gemm_bf16", "scae_gemm_pair_bf16",
                     # the attention products of the fused object-encoder trunk
-                    "scae_set_encoder_fwd_bf16", "scae_set_encoder_bwd_bf16"}, \
-        used
+                    "scae_set_encoder_fwd_bf16", "scae_set_encoder_bwd_bf16",
+                    # ... and of its output attention
+                    "scae_seed_attention_mfma_fwd_bf16",
+                    "scae_seed_attention_mfma_bwd_bf16"}, used
     tol = 2.0 ** -7
     assert abs(float(loss) - float(oloss)) <= tol * abs(float(oloss))
     for k, v in olog.items():

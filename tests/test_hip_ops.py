@@ -874,6 +874,61 @@ def test_seed_attention_vs_fp64(B, N, O, C, pres):
         assert_close(got.grad, want.grad.float(), 1e-4 * scale, 1e-4, name)
 
 
+@pytest.mark.parametrize("B,N,O,C,pres", [
+    (128, 24, 24, 256, "mixed"),    # cfg-2
+    (130, 48, 64, 256, "mixed"),    # configs[2]: 48 keys, 64 queries
+    (4, 40, 24, 256, "rand"),
+])
+def test_seed_attention_bf16_vs_fp32(B, N, O, C, pres):
+    """configs[2]'s precision in the output attention: inside ``ops.mfma_bf16()``
+    the logits, P h and the three products of their backward take bf16
+    operands (scae_seed_attention_mfma_fwd/bwd_bf16).  Against the fp32 kernels
+    on the same inputs (themselves held to 1e-4 of fp64 above) at bf16's bar:
+    2^-7 of the largest entry on the output, 5e-2 relative L2 on every
+    gradient (plus 2e-3 of the largest gradient norm for those that are zero
+    by the softmax's shift symmetry)."""
+    from torch_scae_amd import ops
+    D = 16
+    g = torch.Generator().manual_seed(B * 7 + N)
+    h = torch.randn(B, N, D, generator=g)
+    q = torch.randn(O, C, generator=g) * 0.3
+    wk, wv = torch.randn(C, D, generator=g) * 0.3, torch.randn(C, D, generator=g) * 0.3
+    bk, bv = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    p = torch.rand(B, N, generator=g)
+    if pres == "mixed":
+        p = torch.ones(B, N)
+        p[:, ::3] = torch.rand(B, len(range(0, N, 3)), generator=g)
+    w = torch.randn(B, O, C, generator=g).cuda()
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    def run(bf16):
+        ins = [leaf(t) for t in (h, q, wk, bk, wv, bv)]
+        with ops.mfma_bf16(bf16):
+            out = ops.seed_attention(*ins, dev(p))
+            (out * w).sum().backward()
+        return out.detach(), [t.grad for t in ins]
+
+    ops._lib.call = spy
+    try:
+        ob, gb = run(True)
+    finally:
+        ops._lib.call = real
+    assert calls[:2] == ["scae_seed_attention_mfma_fwd_bf16",
+                         "scae_seed_attention_mfma_bwd_bf16"], calls
+    of, gf = run(False)
+    assert not torch.equal(ob, of)
+    assert float((ob - of).abs().max()) <= 2.0 ** -7 * float(of.abs().max())
+    floor = 2e-3 * max(float(v.norm()) for v in gf)
+    for name, a, b in zip(("gh", "gq", "gwk", "gbk", "gwv", "gbv"), gb, gf):
+        assert float((a - b).norm()) <= 5e-2 * float(b.norm()) + floor, \
+            (name, float((a - b).norm()), float(b.norm()))
+
+
 # ------------------------------------------------------------- K6 loss tail
 @pytest.mark.parametrize("prior,post,use_label,const", [
     ("l2", "entropy", True, None),       # the default SCAE config

@@ -153,6 +153,8 @@ SIGNATURES = {
     "scae_seed_attention_mfma_rows": [c_int],
     "scae_seed_attention_mfma_fwd_f32": [P] * 7 + [c_int] * 4 + [P],
     "scae_seed_attention_mfma_bwd_f32": [P] * 8 + [c_int] * 4 + [P],
+    "scae_seed_attention_mfma_fwd_bf16": [P] * 7 + [c_int] * 4 + [P],
+    "scae_seed_attention_mfma_bwd_bf16": [P] * 8 + [c_int] * 4 + [P],
     "scae_seed_attention_mfma_reduce_f32": [P, c_int] + [P] * 7 + [c_int] * 2 + [P],
     "scae_seed_fold_supported": [c_int] * 3,
     "scae_seed_fold_fwd_f32": [POINTER(SeedFoldDesc), P],

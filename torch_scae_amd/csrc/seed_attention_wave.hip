@@ -37,6 +37,7 @@ struct SwArgs {
   float *partial;         // bwd (rows, O*16 + C*16 + C): [d(qk) | dwv | dbv]
   int B, N, O, C;
   float inv_sqrt_c;
+  int bf16;               // the attention products (logits, P h, and their backward) in bf16
 };
 
 // Tiles.  NT = 16-row tiles per side (2: N, O <= 32; 4: N, O <= 64).  R tiles [16 NT][RS]
@@ -176,12 +177,12 @@ __device__ __forceinline__ Keys<NT> load_keys(const SwArgs &a, int b, const Lane
 }
 
 // attention probabilities of the own query tile t (O layout, key tiles u)
-template <int NT>
+template <int NT, bool BF>
 __device__ __forceinline__ void probabilities(const SwArgs &a, const Lane &l, const Tl<NT> &tl,
                                               int t, const Keys<NT> &k, f32x4 (&p)[NT]) {
   const float4 qa = rd16(tl.small(T_QK), t, l);
 #pragma unroll
-  for (int u = 0; u < NT; ++u) p[u] = mma16(splat(0.f), qa, k.hB[u]);
+  for (int u = 0; u < NT; ++u) p[u] = mma16p<BF>(splat(0.f), qa, k.hB[u]);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float v[NT], mx = -INFINITY, sum = 0.f;
@@ -199,7 +200,7 @@ __device__ __forceinline__ void probabilities(const SwArgs &a, const Lane &l, co
   }
 }
 
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Tl<NT> tl{smem};
@@ -213,10 +214,10 @@ __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
       const int t = l.v;
       const Keys<NT> k = load_keys<NT>(a, b, l);
       f32x4 p[NT];
-      probabilities<NT>(a, l, tl, t, k, p);
+      probabilities<NT, BF>(a, l, tl, t, k, p);
       wr_nn<NT>(tl.large(T_PS), t, l, p);
       lds_fence();
-      const f32x4 T = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_PS), t, l), k.hT);
+      const f32x4 T = mmakp<NT, BF>(splat(0.f), rdk<NT>(tl.large(T_PS), t, l), k.hT);
       wr_rows(tl.small(T_TS), t, l, T);
       lds_fence();
     }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
   }
 }
 
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Tl<NT> tl{smem};
@@ -288,11 +289,11 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
     if (qwave) {
       const int t = l.v;
       k = load_keys<NT>(a, b, l);
-      probabilities<NT>(a, l, tl, t, k, p);
+      probabilities<NT, BF>(a, l, tl, t, k, p);
       wr_nn<NT>(tl.large(T_PS), t, l, p);
       wr_nn_t<NT>(tl.large(T_PT), t, l, p);
       lds_fence();
-      const f32x4 T = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_PS), t, l), k.hT);
+      const f32x4 T = mmakp<NT, BF>(splat(0.f), rdk<NT>(tl.large(T_PS), t, l), k.hT);
       wr_cols<NT>(tl.small(T_TT), t, l, T);
     }
     lds_fence();
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
       const float4 dta = rd16(tl.small(T_DT), t, l);
       f32x4 ds[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) ds[u] = mma16(splat(0.f), dta, k.hB[u]);
+      for (int u = 0; u < NT; ++u) ds[u] = mma16p<BF>(splat(0.f), dta, k.hB[u]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float dot = 0.f;
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
       wr_nn<NT>(tl.large(T_DSR), t, l, ds);
       wr_nn_t<NT>(tl.large(T_DST), t, l, ds);
       lds_fence();
-      const f32x4 dqk = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_DSR), t, l), k.hT);
+      const f32x4 dqk = mmakp<NT, BF>(splat(0.f), rdk<NT>(tl.large(T_DSR), t, l), k.hT);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = 16 * t + 4 * l.q + e;
@@ -361,8 +362,8 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
     // dh[n][i] = sum_o P[o][n] dT[o][i] + dS[o][n] qk[o][i]: one key tile per wave
     if (l.v < NT && 16 * l.v < N) {
       const int u = l.v;
-      f32x4 gh = mmak<NT>(splat(0.f), rdk<NT>(tl.large(T_PT), u, l), rdk<NT>(tl.small(T_DTT), 0, l));
-      gh = mmak<NT>(gh, rdk<NT>(tl.large(T_DST), u, l), rdk<NT>(tl.small(T_QKT), 0, l));
+      f32x4 gh = mmakp<NT, BF>(splat(0.f), rdk<NT>(tl.large(T_PT), u, l), rdk<NT>(tl.small(T_DTT), 0, l));
+      gh = mmakp<NT, BF>(gh, rdk<NT>(tl.large(T_DST), u, l), rdk<NT>(tl.small(T_QKT), 0, l));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = 16 * u + 4 * l.q + e;
@@ -455,24 +456,26 @@ int check(const SwArgs &a) {
   return SCAE_OK;
 }
 
-template <int NT>
+template <int NT, bool BF>
 int launch_nt(const SwArgs &a, bool bwd, hipStream_t st) {
   const size_t lds = Geo<NT>::LDS_FLOATS * sizeof(float);
-  const void *fn = bwd ? reinterpret_cast<const void *>(saw_bwd_kernel<NT>)
-                       : reinterpret_cast<const void *>(saw_fwd_kernel<NT>);
+  const void *fn = bwd ? reinterpret_cast<const void *>(saw_bwd_kernel<NT, BF>)
+                       : reinterpret_cast<const void *>(saw_fwd_kernel<NT, BF>);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid(a.B < 512 ? a.B : 512);
   if (bwd)
-    hipLaunchKernelGGL(saw_bwd_kernel<NT>, grid, dim3(NTH), lds, st, a);
+    hipLaunchKernelGGL((saw_bwd_kernel<NT, BF>), grid, dim3(NTH), lds, st, a);
   else
-    hipLaunchKernelGGL(saw_fwd_kernel<NT>, grid, dim3(NTH), lds, st, a);
+    hipLaunchKernelGGL((saw_fwd_kernel<NT, BF>), grid, dim3(NTH), lds, st, a);
   return scae_launch_status();
 }
 int launch(const SwArgs &a, bool bwd, hipStream_t st) {
-  return a.N <= 32 && a.O <= 32 ? launch_nt<2>(a, bwd, st) : launch_nt<4>(a, bwd, st);
+  if (a.N <= 32 && a.O <= 32)
+    return a.bf16 ? launch_nt<2, true>(a, bwd, st) : launch_nt<2, false>(a, bwd, st);
+  return a.bf16 ? launch_nt<4, true>(a, bwd, st) : launch_nt<4, false>(a, bwd, st);
 }
 }  // namespace
 
@@ -481,29 +484,32 @@ extern "C" int scae_seed_attention_mfma_supported(int N, int O, int D_, int C) {
 }
 extern "C" int scae_seed_attention_mfma_rows(int B) { return B <= 0 ? 0 : (B < 512 ? B : 512); }
 
-extern "C" int scae_seed_attention_mfma_fwd_f32(const float *h, const float *q, const float *wk,
-                                                const float *wv, const float *bv,
-                                                const float *presence, float *out, int B, int N,
-                                                int O, int C, void *stream) {
-  SCAE_REQUIRE(h && q && wk && wv && bv && out);
-  SwArgs a{h, q, wk, wv, bv, presence, out, nullptr, nullptr, nullptr, B, N, O, C,
-           1.f / sqrtf((float)C)};
-  int rc = check(a);
-  if (rc) return rc;
-  return launch(a, false, (hipStream_t)stream);
-}
-
-extern "C" int scae_seed_attention_mfma_bwd_f32(const float *h, const float *q, const float *wk,
-                                                const float *wv, const float *presence,
-                                                const float *gout, float *gh, float *partial,
-                                                int B, int N, int O, int C, void *stream) {
-  SCAE_REQUIRE(h && q && wk && wv && gout && gh && partial);
-  SwArgs a{h, q, wk, wv, nullptr, presence, nullptr, gout, gh, partial, B, N, O, C,
-           1.f / sqrtf((float)C)};
-  int rc = check(a);
-  if (rc) return rc;
-  return launch(a, true, (hipStream_t)stream);
-}
+#define SCAE_SAW_ENTRY(SUFFIX, BF)                                                             \
+  extern "C" int scae_seed_attention_mfma_fwd_##SUFFIX(                                        \
+      const float *h, const float *q, const float *wk, const float *wv, const float *bv,       \
+      const float *presence, float *out, int B, int N, int O, int C, void *stream) {           \
+    SCAE_REQUIRE(h && q && wk && wv && bv && out);                                             \
+    SwArgs a{h,       q,       wk, wv, bv, presence, out, nullptr,                             \
+             nullptr, nullptr, B,  N,  O,  C,        1.f / sqrtf((float)C), BF};               \
+    int rc = check(a);                                                                         \
+    if (rc) return rc;                                                                         \
+    return launch(a, false, (hipStream_t)stream);                                              \
+  }                                                                                            \
+  extern "C" int scae_seed_attention_mfma_bwd_##SUFFIX(                                        \
+      const float *h, const float *q, const float *wk, const float *wv, const float *presence, \
+      const float *gout, float *gh, float *partial, int B, int N, int O, int C,                \
+      void *stream) {                                                                          \
+    SCAE_REQUIRE(h && q && wk && wv && gout && gh && partial);                                 \
+    SwArgs a{h,  q,       wk, wv, nullptr, presence, nullptr, gout,                            \
+             gh, partial, B,  N,  O,       C,        1.f / sqrtf((float)C), BF};               \
+    int rc = check(a);                                                                         \
+    if (rc) return rc;                                                                         \
+    return launch(a, true, (hipStream_t)stream);                                               \
+  }
+SCAE_SAW_ENTRY(f32, 0)
+// configs[2]: logits, P h and the three products of their backward with bf16 operands
+SCAE_SAW_ENTRY(bf16, 1)
+#undef SCAE_SAW_ENTRY
 
 extern "C" int scae_seed_attention_mfma_reduce_f32(const float *partial, int rows, const float *q,
                                                    const float *wk, float *gq, float *gwk,

@@ -623,7 +623,7 @@ class _SeedAttention(torch.autograd.Function):
         ctx.mfma = bool(_lib.load().scae_seed_attention_mfma_supported(N, O, D,
                                                                        C))
         if ctx.mfma:     # wave-per-tile kernels on the matrix cores
-            _lib.call("scae_seed_attention_mfma_fwd_f32", _p(h), _p(q), _p(wk),
+            _lib.call(_prec("scae_seed_attention_mfma_fwd_f32"), _p(h), _p(q), _p(wk),
                       _p(wv), _p(bv), _p(presence), _p(out), B, N, O, C,
                       _stream(h))
         else:
@@ -647,7 +647,7 @@ class _SeedAttention(torch.autograd.Function):
             new = lambda *shape: torch.empty(*shape, device=h.device,  # noqa: E731
                                              dtype=h.dtype)
             partial, gh = new(rows, O * D + C * D + C), new(B, N, D)
-            _lib.call("scae_seed_attention_mfma_bwd_f32", _p(h), _p(q), _p(wk),
+            _lib.call(_prec("scae_seed_attention_mfma_bwd_f32"), _p(h), _p(q), _p(wk),
                       _p(wv), _p(presence), _p(gout.contiguous()), _p(gh),
                       _p(partial), B, N, O, C, _stream(h))
             # column sums of the partials, expanded to the operands' gradients
