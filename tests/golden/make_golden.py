@@ -171,6 +171,13 @@ MODEL_CASES = {
                                          learn_vote_scale=False)), 2, True),
     "scae_alternatives": (merged(
         TINY_BASE, scae_params=dict(reconstruct_alternatives=True)), 2, False),
+    # round 3: more capsules than the matrix-core kernels' 64-element tiles
+    # (70 part / 66 object capsules: the general attention kernels, the
+    # two-pass capsule likelihood, the unfused object encoder)
+    "scae_big": (merged(
+        TINY_BASE, n_part_caps=70, n_obj_caps=66,
+        ocae_decoder_capsule_params=dict(dim_caps=4, hidden_sizes=(4,))),
+        2, True),
 }
 
 
@@ -750,12 +757,26 @@ def op_capsule_layer_hier():
     save("op_capsule_layer_hier", blob)
 
 
+# seeds that differ from 100 + position: with seed 109 one of scae_big's 36 k (pixel,
+# template) samples lies within round-off of a texel boundary, where the bilinear
+# derivative has two valid one-sided values (the op fixtures avoid that with
+# "irrational" poses; a whole model's poses come out of its encoder)
+SEEDS = {"scae_big": 1234}
+
+
 def main():
     ref_gt, gt_oop = import_reference()
     from torch_scae import cv_ops
     if sys.argv[1:] == ["hier"]:             # only the round-2 fixture
         cv_ops.geometric_transform = gt_oop
         op_capsule_layer_hier()
+        return
+    if len(sys.argv) == 2 and sys.argv[1] in MODEL_CASES:   # one model fixture
+        cv_ops.geometric_transform = gt_oop
+        name = sys.argv[1]
+        cfg, batch, train = MODEL_CASES[name]
+        model_golden(name, cfg, batch, train, seed=SEEDS.get(
+            name, 100 + list(MODEL_CASES).index(name)))
         return
     op_geometric_transform(ref_gt)          # untouched reference function
     cv_ops.geometric_transform = gt_oop      # needed for every backward below
@@ -768,7 +789,7 @@ def main():
     op_part_encoder()
     op_sparsity()
     for i, (name, (cfg, batch, train)) in enumerate(MODEL_CASES.items()):
-        model_golden(name, cfg, batch, train, seed=100 + i)
+        model_golden(name, cfg, batch, train, seed=SEEDS.get(name, 100 + i))
     op_capsule_layer_hier()
 
 

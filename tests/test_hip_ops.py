@@ -86,6 +86,11 @@ def test_qkv_attention_vs_golden(case):
     (7, 1, 1, 3, 5, None),               # degenerate
     (5, 33, 17, 70, 130, "mixed"),       # ragged, multi-chunk
     (6, 10, 20, 6, 6, "rand"),           # heads-of-3 shape, one-hot regime
+    # beyond the 64-element tiles of the matrix-core kernels: the general
+    # kernels of set_attention_big.hip (round 3)
+    (9, 80, 80, 16, 16, "mixed"),        # SAB over 80 part capsules
+    (5, 72, 80, 256, 256, "mixed"),      # output attention, 72 seeds x 80 keys
+    (3, 65, 200, 7, 33, "rand"),         # ragged
 ])
 def test_qkv_attention_vs_oracle(HB, N, M, dk, dv, pres):
     from torch_scae_amd.set_transformer import qkv_attention
@@ -215,10 +220,14 @@ def test_capsule_likelihood_no_presence_vs_golden():
         assert_close(res[k], ref, ATOL, RTOL, "out " + k)
 
 
-def test_capsule_likelihood_vs_oracle_cfg2():
+@pytest.mark.parametrize("B,Oc,M", [
+    (128, 24, 24),    # cfg-2
+    (6, 72, 80),      # more than 64 object capsules: the two-pass statistics
+    (3, 130, 100),    # the largest capsule product the factory admits
+])
+def test_capsule_likelihood_vs_oracle_cfg2(B, Oc, M):
     from torch_scae_amd.object_decoder import CapsuleLikelihood
     g = torch.Generator().manual_seed(77)
-    B, Oc, M = 128, 24, 24
     ins = dict(vote=torch.randn(B, Oc, M, 6, generator=g),
                scale=torch.rand(B, Oc, M, generator=g) + 0.1,
                vote_presence=torch.rand(B, Oc, M, generator=g),

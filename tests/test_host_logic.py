@@ -34,8 +34,12 @@ def test_launchers_reject_bad_arguments_without_a_gpu():
     lib = _lib.load()
     assert lib.scae_geometric_transform_fwd_f32(None, None, 4, 0, 1, 0,
                                                 None) == -1
+    # sets beyond the matrix-core tiles: the general kernels take them (fp32);
+    # the bf16 forward keeps the tile limit
     assert lib.scae_qkv_attention_fwd_f32(None, None, None, None, None, None,
-                                          1, 65, 4, 4, 4, 2.0, None) == -2
+                                          1, 65, 4, 4, 4, 2.0, None) == -1
+    assert lib.scae_qkv_attention_fwd_bf16(None, None, None, None, None, None,
+                                           1, 65, 4, 4, 4, 2.0, None) == -2
     d = _lib.DecoderDesc()
     assert lib.scae_template_render_fwd_f32(d, None, None, None) == -1
     # the launch-merging entry points: null pointers / empty job lists / bad sizes
@@ -267,8 +271,13 @@ def test_factory_rejects_configurations_outside_the_kernel_limits():
     base = dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24,
                 n_obj_caps=24)
     factory.check_kernel_limits(factory.prepare_model_params(**base))
-    for bad, needle in ((dict(n_part_caps=65), "n_part_caps"),
-                        (dict(n_obj_caps=80), "n_obj_caps"),
+    # (80 part / 72 object capsules -- beyond the 64-element tiles of the
+    # matrix-core kernels -- are inside the limits since round 3)
+    factory.check_kernel_limits(factory.prepare_model_params(
+        **dict(base, n_part_caps=80, n_obj_caps=72)))
+    for bad, needle in ((dict(n_part_caps=201), "n_part_caps"),
+                        (dict(n_obj_caps=201, n_part_caps=10), "n_obj_caps"),
+                        (dict(n_obj_caps=150, n_part_caps=100), "n_obj_caps * n_part_caps"),
                         (dict(image_shape=(5, 40, 40)), "channels"),
                         (dict(pcae_template_generator_params=dict(
                             template_size=(64, 64))), "th*tw")):

@@ -14,7 +14,7 @@
 
 namespace {
 constexpr int NT = 1024;
-constexpr int OMAX = 64;  // capsules per lane group: 16 lanes x 4
+constexpr int OMAX = 64;  // the register form of phase B: 16 lanes x 4 capsules (more: the LDS two-pass form)
 constexpr float kLog001 = -4.605170185988091f;  // np.log(0.01), object_decoder.py:274
 
 // sum over the 6 pose dims of Normal(vote, scale).log_prob(x)   (:263-269)
@@ -70,6 +70,10 @@ __device__ __forceinline__ LkSmem lk_carve(float *s, int O, int M) {
 }
 
 // phases A + B for image b: fills the LDS statistics.  Ends with a barrier.
+// BIG: more than OMAX object capsules -- a lane group walks its ceil(O / 16) capsules per lane
+// twice through LDS (maxima / arg-max, then the exponential sums) instead of holding them in
+// registers; same order of operations, any O the LDS holds.
+template <bool BIG>
 __device__ __forceinline__ void lk_stats(const LkArgs &a, const LkSmem &s, int b) {
   const int O = a.O, M = a.M, tid = threadIdx.x;
   for (int i = tid; i < M * 6; i += NT) s.x[i] = a.x[(size_t)b * M * 6 + i];
@@ -87,22 +91,36 @@ __device__ __forceinline__ void lk_stats(const LkArgs &a, const LkSmem &s, int b
   __syncthreads();
   for (int e = tid; e < ((M * 16 + NT - 1) / NT) * NT; e += NT) {  // phase B
     const int m = e >> 4, l = e & 15;
-    float vml[OMAX / 16], vpo[OMAX / 16];
+    constexpr int KR = BIG ? 1 : OMAX / 16;
+    const int kpl = BIG ? (O + 15) >> 4 : OMAX / 16;
+    float vml[KR], vpo[KR];
     float mx_ml = l == 0 ? kLog001 : -INFINITY;            // lane 0 owns the dummy
     float mx_po = l == 0 ? kLog001 + kLog001 : -INFINITY;
     float best = -INFINITY;
     int best_o = 1 << 30;
+    if (BIG) {
+      for (int k = 0; k < kpl; ++k) {
+        const int o = l + 16 * k;
+        if (m < M && o < O) {
+          const float pm = s.ml[o * M + m], pp = s.post[o * M + m];
+          mx_ml = fmaxf(mx_ml, pm);
+          mx_po = fmaxf(mx_po, pp);
+          if (pp > best) best = pp, best_o = o;   // ascending o within the lane: first maximum
+        }
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < OMAX / 16; ++k) {
-      const int o = l + 16 * k;
-      const bool in = m < M && o < O;
-      vml[k] = in ? s.ml[o * M + m] : -INFINITY;
-      vpo[k] = in ? s.post[o * M + m] : -INFINITY;
-      mx_ml = fmaxf(mx_ml, vml[k]);
-      mx_po = fmaxf(mx_po, vpo[k]);
-      if (in && vpo[k] > best) {  // ascending o within the lane: first maximum
-        best = vpo[k];
-        best_o = o;
+      for (int k = 0; k < KR; ++k) {
+        const int o = l + 16 * k;
+        const bool in = m < M && o < O;
+        vml[k] = in ? s.ml[o * M + m] : -INFINITY;
+        vpo[k] = in ? s.post[o * M + m] : -INFINITY;
+        mx_ml = fmaxf(mx_ml, vml[k]);
+        mx_po = fmaxf(mx_po, vpo[k]);
+        if (in && vpo[k] > best) {  // ascending o within the lane: first maximum
+          best = vpo[k];
+          best_o = o;
+        }
       }
     }
     mx_ml = group_max<16>(mx_ml);
@@ -111,10 +129,21 @@ __device__ __forceinline__ void lk_stats(const LkArgs &a, const LkSmem &s, int b
     const int win = group_min_int<16>(best == gbest ? best_o : (1 << 30));  // torch.argmax: first
     float sm = l == 0 ? expf(kLog001 - mx_ml) : 0.f;
     float sp = l == 0 ? expf(kLog001 + kLog001 - mx_po) : 0.f;
+    if (BIG) {
+      for (int k = 0; k < kpl; ++k) {
+        const int o = l + 16 * k;
+        if (m < M && o < O) {
+          const float pm = s.ml[o * M + m], pp = s.post[o * M + m];
+          if (pm != -INFINITY) sm += expf(pm - mx_ml);
+          if (pp != -INFINITY) sp += expf(pp - mx_po);
+        }
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < OMAX / 16; ++k) {
-      if (vml[k] != -INFINITY) sm += expf(vml[k] - mx_ml);
-      if (vpo[k] != -INFINITY) sp += expf(vpo[k] - mx_po);
+      for (int k = 0; k < KR; ++k) {
+        if (vml[k] != -INFINITY) sm += expf(vml[k] - mx_ml);
+        if (vpo[k] != -INFINITY) sp += expf(vpo[k] - mx_po);
+      }
     }
     sm = group_sum<16>(sm);
     sp = group_sum<16>(sp);
@@ -129,6 +158,7 @@ __device__ __forceinline__ void lk_stats(const LkArgs &a, const LkSmem &s, int b
   __syncthreads();
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(NT) void likelihood_fwd_kernel(
     LkArgs a, float *__restrict__ lpp, float *__restrict__ binary, float *__restrict__ winner,
     float *__restrict__ winner_presence, int64_t *__restrict__ winner_idx,
@@ -140,7 +170,7 @@ __global__ __launch_bounds__(NT) void likelihood_fwd_kernel(
   const LkSmem s = lk_carve(smem, O, M);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
-    lk_stats(a, s, b);
+    lk_stats<BIG>(a, s, b);
     // phase C1: per pair outputs (incl. the dummy row o == O); the posterior
     // probability of every real pair replaces its mixing logit in LDS
     for (int e = tid; e < (O + 1) * M; e += NT) {
@@ -197,6 +227,7 @@ __global__ __launch_bounds__(NT) void likelihood_fwd_kernel(
   }
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(NT) void likelihood_bwd_kernel(
     LkArgs a, const int64_t *__restrict__ winner_idx, const float *__restrict__ g_lpp,
     const float *__restrict__ g_winner, const float *__restrict__ g_winner_presence,
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(NT) void likelihood_bwd_kernel(
   float *s_gmlp = s_dot + M;            // [M] column sums of g_mixing_log_prob
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
-    lk_stats(a, s, b);
+    lk_stats<BIG>(a, s, b);
     // incoming gradient on every posterior probability (dummy row included)
     for (int e = tid; e < (O + 1) * M; e += NT) {
       const int o = e / M, m = e - o * M;
@@ -323,7 +354,7 @@ size_t lk_lds(int O, int M, bool bwd) {
 }
 int lk_check(int B, int O, int M) {
   if (B <= 0 || O <= 0 || M <= 0) return SCAE_ERR_BAD_ARG;
-  if (O > OMAX || lk_lds(O, M, true) > 64 * 1024) return SCAE_ERR_UNSUPPORTED;
+  if (lk_lds(O, M, true) > 160 * 1024) return SCAE_ERR_UNSUPPORTED;
   return SCAE_OK;
 }
 }  // namespace
@@ -343,15 +374,24 @@ extern "C" int scae_capsule_likelihood_fwd_f32(
   if (rc) return rc;
   LkArgs a{vote, scale, vote_presence, dummy_vote, x, presence, B, O, M};
   const size_t lds = lk_lds(O, M, false);
+  const bool big = O > OMAX;
+  const void *fn = big ? reinterpret_cast<const void *>(likelihood_fwd_kernel<true>)
+                       : reinterpret_cast<const void *>(likelihood_fwd_kernel<false>);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(likelihood_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(likelihood_fwd_kernel, dim3(B < 1024 ? B : 1024), dim3(NT), lds,
-                     (hipStream_t)stream, a, log_prob_per_point, vote_presence_binary, winner,
-                     winner_presence, winner_idx, is_from_capsule, soft_winner,
-                     soft_winner_presence, posterior, mixing_log_prob, mixing_logit);
+#define SCAE_LK_FWD(BG)                                                                        \
+  hipLaunchKernelGGL(likelihood_fwd_kernel<BG>, dim3(B < 1024 ? B : 1024), dim3(NT), lds,      \
+                     (hipStream_t)stream, a, log_prob_per_point, vote_presence_binary, winner, \
+                     winner_presence, winner_idx, is_from_capsule, soft_winner,                \
+                     soft_winner_presence, posterior, mixing_log_prob, mixing_logit)
+  if (big) {
+    SCAE_LK_FWD(true);
+  } else {
+    SCAE_LK_FWD(false);
+  }
+#undef SCAE_LK_FWD
   return scae_launch_status();
 }
 
@@ -370,15 +410,24 @@ extern "C" int scae_capsule_likelihood_bwd_f32(
   if (rc) return rc;
   LkArgs a{vote, scale, vote_presence, dummy_vote, x, presence, B, O, M};
   const size_t lds = lk_lds(O, M, true);
+  const bool big = O > OMAX;
+  const void *fn = big ? reinterpret_cast<const void *>(likelihood_bwd_kernel<true>)
+                       : reinterpret_cast<const void *>(likelihood_bwd_kernel<false>);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(likelihood_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(likelihood_bwd_kernel, dim3(B < 1024 ? B : 1024), dim3(NT), lds,
-                     (hipStream_t)stream, a, winner_idx, g_lpp, g_winner, g_winner_presence,
-                     g_soft_winner, g_soft_winner_presence, g_posterior, g_mixing_log_prob,
-                     g_mixing_logit, gvote, gscale, gvote_presence, gx, gpresence,
-                     gdummy_partial);
+#define SCAE_LK_BWD(BG)                                                                         \
+  hipLaunchKernelGGL(likelihood_bwd_kernel<BG>, dim3(B < 1024 ? B : 1024), dim3(NT), lds,       \
+                     (hipStream_t)stream, a, winner_idx, g_lpp, g_winner, g_winner_presence,    \
+                     g_soft_winner, g_soft_winner_presence, g_posterior, g_mixing_log_prob,     \
+                     g_mixing_logit, gvote, gscale, gvote_presence, gx, gpresence,              \
+                     gdummy_partial)
+  if (big) {
+    SCAE_LK_BWD(true);
+  } else {
+    SCAE_LK_BWD(false);
+  }
+#undef SCAE_LK_BWD
   return scae_launch_status();
 }

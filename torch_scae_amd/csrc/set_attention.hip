@@ -16,6 +16,14 @@
 //   C[i][j]: lane l, reg r holds i = (l>>4)*4 + r, j = l&15
 #include "common.h"
 
+namespace scae_attn_big {   // set_attention_big.hip: sets beyond SCAE_ATTN_MAX_SET
+int fwd(const float *q, const float *k, const float *v, const float *presence, float *out,
+        float *probs, int HB, int N, int M, int dk, int dv, float sqrt_dk, hipStream_t st);
+int bwd(const float *q, const float *k, const float *v, const float *probs, const float *gout,
+        float *gq, float *gk, float *gv, float *gpresence, int HB, int N, int M, int dk, int dv,
+        float sqrt_dk, hipStream_t st);
+}  // namespace scae_attn_big
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -444,9 +452,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(
 
 int check_attn(int HB, int N, int M, int dk, int dv) {
   if (HB <= 0 || N <= 0 || M <= 0 || dk <= 0 || dv <= 0) return SCAE_ERR_BAD_ARG;
-  if (N > SCAE_ATTN_MAX_SET || M > SCAE_ATTN_MAX_SET) return SCAE_ERR_UNSUPPORTED;
   return SCAE_OK;
 }
+bool big_set(int N, int M) { return N > SCAE_ATTN_MAX_SET || M > SCAE_ATTN_MAX_SET; }
 
 int raise_lds(const void *kernel, size_t bytes) {
   if (bytes > 48 * 1024) {
@@ -466,6 +474,9 @@ extern "C" int scae_qkv_attention_fwd_f32(const float *q, const float *k, const 
   int rc = check_attn(HB, N, M, dk, dv);
   if (rc) return rc;
   SCAE_REQUIRE(q && k && v && out && probs && sqrt_dk > 0.f);
+  if (big_set(N, M))   // beyond the matrix-core kernels' tiles: the general form
+    return scae_attn_big::fwd(q, k, v, presence, out, probs, HB, N, M, dk, dv, sqrt_dk,
+                              (hipStream_t)stream);
   const int Npad = (N + 15) & ~15, Mpad = (M + 15) & ~15;
   const size_t lds = sizeof(float) * (size_t)(2 * Npad + Mpad) * LD;
   rc = raise_lds(reinterpret_cast<const void *>(attn_fwd_kernel), lds);
@@ -481,6 +492,7 @@ extern "C" int scae_qkv_attention_fwd_bf16(const uint16_t *q, const uint16_t *k,
                                            int dk, int dv, float sqrt_dk, void *stream) {
   int rc = check_attn(HB, N, M, dk, dv);
   if (rc) return rc;
+  if (big_set(N, M)) return SCAE_ERR_UNSUPPORTED;   // (the bf16 form has the tile limits)
   SCAE_REQUIRE(q && k && v && out && probs && sqrt_dk > 0.f);
   const size_t lds = sizeof(unsigned short) * 3 * (size_t)SCAE_ATTN_MAX_SET * LDH;
   hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k,
@@ -496,6 +508,9 @@ extern "C" int scae_qkv_attention_bwd_f32(const float *q, const float *k, const 
   int rc = check_attn(HB, N, M, dk, dv);
   if (rc) return rc;
   SCAE_REQUIRE(q && k && v && probs && gout && gq && gk && gv && sqrt_dk > 0.f);
+  if (big_set(N, M))
+    return scae_attn_big::bwd(q, k, v, probs, gout, gq, gk, gv, gpresence, HB, N, M, dk, dv,
+                              sqrt_dk, (hipStream_t)stream);
   const int Npad = (N + 15) & ~15, Mpad = (M + 15) & ~15;
   const size_t lds = sizeof(float) * (size_t)(3 * Npad + Mpad) * LD;
   rc = raise_lds(reinterpret_cast<const void *>(attn_bwd_kernel), lds);

@@ -84,8 +84,13 @@ def prepare_model_params(image_shape, n_classes, n_part_caps, n_obj_caps,
 # Hard shape limits of the HIP kernels behind the module surface (there is no
 # eager fallback): checked when the model is assembled, not at the first forward.
 KERNEL_LIMITS = dict(
-    n_part_caps=64,         # K2 attention sets, K4 lane groups
-    n_obj_caps=64,          # K4 (O <= 64), K2c seeds
+    # up to 64 / 64 everything runs on the matrix-core kernels; beyond that the
+    # general attention (set_attention_big.hip) and the two-pass capsule
+    # likelihood take over, bounded by what one problem's dS (N x M floats) /
+    # mixture statistics (3 x O x M floats) may occupy of a CU's 160 KB of LDS
+    n_part_caps=200,        # K2: n_part^2 floats of dS per set
+    n_obj_caps=200,
+    caps_product=13000,     # K4: n_obj * n_part (and K2's output attention)
     n_channels=4,           # K1 template planes
     template_texels=4096,   # K1: (C + 1) * th * tw floats of LDS per template
 )
@@ -105,6 +110,10 @@ def check_kernel_limits(params: dict):
     if n_obj > lim["n_obj_caps"]:
         problems.append(f"n_obj_caps={n_obj} > {lim['n_obj_caps']} "
                         "(capsule likelihood, output attention seeds)")
+    if n_obj * n_part > lim["caps_product"]:
+        problems.append(f"n_obj_caps * n_part_caps = {n_obj * n_part} > "
+                        f"{lim['caps_product']} (capsule likelihood: mixture "
+                        "statistics of one image in LDS)")
     if C > lim["n_channels"]:
         problems.append(f"{C} image channels > {lim['n_channels']} "
                         "(template render / mixture likelihood)")
