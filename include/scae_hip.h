@@ -71,6 +71,15 @@ int scae_geometric_transform_bwd_f32(const float *pose, const float *gout,
                                      int nonlinear, int as_matrix,
                                      void *stream);
 
+/* 3 x 3 products of the hierarchical CapsuleLayer.forward (object_decoder.py:184-191:
+ * torch.matmul(cvr.repeat(1, 1, n_votes, 1, 1), cpr)): out[c][v] = left[c] right[c][v]
+ *   left (n_caps,3,3)  right (n_caps,V,3,3)  out (n_caps,V,3,3); backward: gleft
+ *   (n_caps,3,3) nullable (the parent's transform may be a constant), gright like right. */
+int scae_mat3_mul_fwd_f32(const float *left, const float *right, float *out, int64_t n_caps,
+                          int V, void *stream);
+int scae_mat3_mul_bwd_f32(const float *left, const float *right, const float *gout,
+                          float *gleft, float *gright, int64_t n_caps, int V, void *stream);
+
 /* ------------------------------------------------------------------------
  * K2  qkv_attention                  replaces set_transformer.py:24-47
  *   q (HB,N,dk)  k (HB,M,dk)  v (HB,M,dv)  presence (HB,M) nullable

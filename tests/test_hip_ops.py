@@ -135,12 +135,18 @@ def test_qkv_attention_presence_gradient():
     assert_close(pg.grad / 1e32, pc.grad / 1e32, 1e-4, 1e-3, "gpresence")
 
 
-def test_qkv_attention_rejects_oversize_sets():
+def test_qkv_attention_size_limits():
+    """Sets beyond the 64-element tiles run on the general kernels (round 3);
+    what no kernel takes -- the backward parks one problem's dS, N x M floats,
+    in LDS -- is rejected loudly, not silently wrong."""
     from torch_scae_amd.ops import ScaeHipError
     from torch_scae_amd.set_transformer import qkv_attention
     x = torch.zeros(1, 65, 4, device="cuda")
+    assert qkv_attention(x, x, x).shape == (1, 65, 4)
+    big = torch.zeros(1, 300, 4, device="cuda", requires_grad=True)
+    out = qkv_attention(big, big, big)
     with pytest.raises(ScaeHipError):
-        qkv_attention(x, x, x)
+        out.sum().backward()
 
 
 BLOCKS = {
@@ -300,6 +306,30 @@ def test_capsule_layer_and_decoder_vs_golden(name):
                  c["dec_in/presence"].cuda())
     for k, ref in sub(c, "dec_out/").items():
         assert_close(r2[k], ref, ATOL, RTOL, "dec_out " + k)
+
+
+@pytest.mark.parametrize("B,Oc,V", [(3, 5, 7), (16, 24, 24), (2, 66, 70)])
+def test_mat3_mul_vs_matmul(B, Oc, V):
+    """The 3 x 3 products of the hierarchical CapsuleLayer.forward
+    (object_decoder.py:184-191) against torch.matmul in fp64, gradients of
+    both factors."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(B + V)
+    left = torch.randn(B, Oc, 1, 3, 3, generator=g)
+    right = torch.randn(B, Oc, V, 3, 3, generator=g)
+    w = torch.randn(B, Oc, V, 3, 3, generator=g)
+    ld, rd = left.double().requires_grad_(), right.double().requires_grad_()
+    ref = torch.matmul(ld.repeat(1, 1, V, 1, 1), rd)
+    (ref * w.double()).sum().backward()
+    lg, rg = leaf(left), leaf(right)
+    out = ops.mat3_mul(lg, rg)
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref.float(), 1e-5, 1e-5, "out")
+    assert_close(lg.grad, ld.grad.float(), 1e-4, 1e-5, "g_left")
+    assert_close(rg.grad, rd.grad.float(), 1e-5, 1e-5, "g_right")
+    # a constant parent transform: no gradient buffer is asked for
+    out2 = ops.mat3_mul(left.cuda(), leaf(right))
+    assert torch.equal(out2, out)
 
 
 def test_capsule_layer_hierarchical_vs_golden():

@@ -128,6 +128,8 @@ SIGNATURES = {
     "scae_geometric_transform_fwd_f32": [P, P, c_int64, c_int, c_int, c_int, P],
     "scae_geometric_transform_bwd_f32": [P, P, P, c_int64, c_int, c_int, c_int,
                                          P],
+    "scae_mat3_mul_fwd_f32": [P, P, P, c_int64, c_int, P],
+    "scae_mat3_mul_bwd_f32": [P, P, P, P, P, c_int64, c_int, P],
     "scae_qkv_attention_fwd_f32": [P, P, P, P, P, P, c_int, c_int, c_int,
                                    c_int, c_int, c_float, P],
     "scae_qkv_attention_fwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_int,

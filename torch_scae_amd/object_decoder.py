@@ -135,7 +135,8 @@ class CapsuleLayer(nn.Module):
         """object_decoder.py:184-187, :214-215: a parent capsule's transform
         (B,O,1,3,3) stands in for the capsule's own OVR and / or its presence
         (B,O,1) for the capsule's own.  Not on SCAE's path: the per-capsule
-        MLPs on K7, the pose transform on K5, the 3x3 products on the library."""
+        MLPs on K7, the pose transform on K5, the 3x3 products on
+        ``scae_mat3_mul_*`` (geometric_transform.hip)."""
         self._check_config()
         B = feature.shape[0]
         raw_caps_param = self.mlps(feature)                       # (B, O, D)
@@ -157,7 +158,10 @@ class CapsuleLayer(nn.Module):
                                           nonlinear=True, as_matrix=True)
         else:
             cvr = parent_transform
-        vote = torch.matmul(cvr.repeat(1, 1, self.n_votes, 1, 1), cpr)
+        if cvr.is_cuda and cvr.dtype == torch.float32 and cvr.shape[2] == 1:
+            vote = ops.mat3_mul(cvr, cpr)       # one launch, no repeat
+        else:
+            vote = torch.matmul(cvr.repeat(1, 1, self.n_votes, 1, 1), cpr)
         if self.noise_type == 'uniform':
             logit_caps = logit_caps + (rand_like(logit_caps) - 0.5) \
                 * self.noise_scale

@@ -402,6 +402,43 @@ def geometric_transform(pose, similarity=False, nonlinear=True,
     return _GeometricTransform.apply(pose, similarity, nonlinear, as_matrix)
 
 
+class _Mat3Mul(torch.autograd.Function):
+    """out[..., v, :, :] = left[..., 0, :, :] @ right[..., v, :, :] -- the
+    3 x 3 products of the hierarchical CapsuleLayer.forward
+    (object_decoder.py:184-191)."""
+
+    @staticmethod
+    def forward(ctx, left, right):
+        _need_hip(left, right)
+        V = right.shape[-3]
+        left, right = left.contiguous(), right.contiguous()
+        n_caps = right.numel() // (9 * V)
+        if left.numel() != n_caps * 9:
+            raise ScaeHipError("mat3_mul: one left matrix per capsule expected")
+        out = torch.empty_like(right)
+        _lib.call("scae_mat3_mul_fwd_f32", _p(left), _p(right), _p(out), n_caps,
+                  V, _stream(right))
+        ctx.save_for_backward(left, right)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        left, right = ctx.saved_tensors
+        V = right.shape[-3]
+        n_caps = right.numel() // (9 * V)
+        gright = torch.empty_like(right)
+        gleft = torch.empty_like(left) if ctx.needs_input_grad[0] else None
+        _lib.call("scae_mat3_mul_bwd_f32", _p(left), _p(right),
+                  _p(gout.contiguous()), _p(gleft), _p(gright), n_caps, V,
+                  _stream(right))
+        return gleft, gright
+
+
+def mat3_mul(left, right):
+    """left (..., 1, 3, 3) x right (..., V, 3, 3) -> (..., V, 3, 3)."""
+    return _Mat3Mul.apply(left, right)
+
+
 # ----------------------------------------------------------------------------
 # K2 qkv_attention (set_transformer.py:24-47)
 # ----------------------------------------------------------------------------
