@@ -472,6 +472,13 @@ def test_image_decoder_vs_golden(name):
     (16, 32, 3, (32, 32), (11, 11), True, False),     # cfg-5 shape
     (8, 48, 1, (40, 40), (11, 11), True, False),      # cfg-3 shape
     (4, 5, 3, (17, 23), (7, 9), False, True),         # ragged, temperature
+    # the wave-form kernels (alpha mode) off the beaten sizes: odd image and
+    # template sizes, 2 / 3 / 4 channels, learned output scale, H W not a
+    # multiple of 4 (render falls back), a set of 70 components
+    (4, 5, 3, (17, 23), (7, 9), True, True),
+    (3, 7, 2, (20, 12), (5, 6), True, False),
+    (2, 3, 4, (9, 16), (4, 3), True, True),
+    (2, 70, 1, (24, 24), (11, 11), True, False),
 ])
 def test_image_decoder_vs_oracle_full_size(B, M, C, HW, ts, alpha, scale):
     from torch_scae_amd.part_decoder import TemplateBasedImageDecoder

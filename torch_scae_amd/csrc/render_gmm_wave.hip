@@ -699,7 +699,7 @@ __global__ __launch_bounds__(NTB) void bwd_cell_kernel(
     // many parts per cell (few, large cells): fold the parts four to one until a texel's
     // corner sums are short again (fixed order)
     int P = S * G;
-    while (P > 32) {   // (workgroup-uniform)
+    while (P > 6) {   // (workgroup-uniform; phase 3 walks the parts serially per texel)
       const int q = (P + 3) >> 2, stride = q * ncells * (NM / 4);   // parts [j q, j q + q), j = 0..3
       float4 *dst = reinterpret_cast<float4 *>(s_part);
       for (int t = tid; t < stride; t += NTB) {
