@@ -703,9 +703,20 @@ __device__ __forceinline__ void reduce_wgrad(const float *__restrict__ partial,
   if (e < n) {
     const int tap = e / (Cout * Cin), rem = e - tap * Cout * Cin, co = rem / Cin,
               ci = rem - co * Cin;
+    // (the splits' loads are independent: eight in flight instead of a chain of `splits`
+    // L2 / MALL round trips; summed in split order all the same)
+    const float *src = partial + ((size_t)tap * Cout + co) * Cin + ci;
+    const size_t step = (size_t)9 * Cout * Cin;
     float acc = 0.f;
-    for (int s = 0; s < splits; ++s)
-      acc += partial[((size_t)(s * 9 + tap) * Cout + co) * Cin + ci];
+    int s = 0;
+    for (; s + 8 <= splits; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * step];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < splits; ++s) acc += src[(size_t)s * step];
     dw[((size_t)co * Cin + ci) * 9 + tap] = acc;
   } else if (e < n + Cout && db) {
     float acc = 0.f;
@@ -775,7 +786,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
                  (w_ % rb) * 256 + threadIdx.x);
     return;
   }
-  constexpr int K1 = CIN * 9 + 1;
+  constexpr int K1 = CIN * 9 + 1, NLD = 4;
   const FirstSplit f = first_split(g.B, g.Cout);
   const int n = blockIdx.x / f.slices, slice = blockIdx.x % f.slices;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -794,13 +805,13 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
     int oh = (pbeg + part) / g.OW, ow = (pbeg + part) - oh * g.OW;
     const size_t dstep = (size_t)f.parts * g.Cout;
     const float *dp = dpre + ((size_t)n * P + pbeg + part) * g.Cout + co;
-    for (int p = pbeg + part; p < pend; p += 4 * f.parts) {
-      float d[4];  // four gradient loads in flight
+    for (int p = pbeg + part; p < pend; p += NLD * f.parts) {
+      float d[NLD];  // gradient loads in flight (the loop is a chain of L2 round trips)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) d[u] = p + u * f.parts < pend ? dp[u * dstep] : 0.f;
-      dp += 4 * dstep;
+      for (int u = 0; u < NLD; ++u) d[u] = p + u * f.parts < pend ? dp[u * dstep] : 0.f;
+      dp += NLD * dstep;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NLD; ++u) {
         const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci)
