@@ -902,6 +902,20 @@ int scae_render_gmm_sums_bwd_f32(const scae_decoder_desc *d, const float *x,
                                  float *g_bg_image, float *g_scalar_partial, void *stream);
 
 
+/* scae_set_encoder_fwd_f32 and scae_render_gmm_logprob_sums_fwd_f32 as ONE launch:
+ * the two forward kernels are independent -- both only read the part encoder's outputs
+ * (stacked_capsule_auto_encoder.py:105-124 and :146-162 / :220) -- and the trunk leaves three
+ * quarters of the SIMDs idle, so the likelihood's workgroups ride as a second block range of
+ * its launch.  Falls back to the two launches where the shapes do not fit; identical results. */
+int scae_set_encoder_fwd_logprob_f32(int nseg, const float *const *seg_ptr,
+                                     const int *seg_width, const int *seg_row_stride,
+                                     const int64_t *seg_batch_stride, const float *presence,
+                                     const float *params, float *z, float *hsave, int B, int N,
+                                     int D, int Din, int Dout, int L, int layer_norm,
+                                     const scae_decoder_desc *d, const float *x,
+                                     float *tile_sums, float *lse_post, float *lse_prior,
+                                     void *stream);
+
 /* generic mixture over materialised tensors: distributions.py:34-47.
  *   loc (B,K,C,P), mixing_logits (B,K,Cm,P) with Cm in {1,C}, sigma (1) device
  *   scalar (the Normal's scale), x (B,C,P) -> log_prob (B,C,P). */

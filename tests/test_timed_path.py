@@ -254,3 +254,41 @@ def test_two_graph_collective_step_equals_plain_step_bitwise_cfg2(nccl_group):
         assert set(s) == set(s0)
         for k in s0:
             assert torch.equal(s0[k], s[k]), (mode, k)
+
+
+def test_likelihood_riding_in_the_trunk_launch_changes_nothing():
+    """TrainStep(fuse_kernels=True): the part decoder's likelihood forward runs
+    as a second block range of the object encoder's trunk launch
+    (csrc/trunk_logprob.hip) instead of a launch of its own.  Same kernels on
+    the same inputs: three replayed steps at cfg-2, B = 128, end bit for bit
+    on the state of the step with the two launches (noise on, generators
+    aligned), and the step really takes the shared launch."""
+    from torch_scae_amd import ops
+    cfg, B, sd, g = full_size_params("cfg2")
+    images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
+    labels = torch.randint(0, 10, (3, B), generator=g).cuda()
+    out, calls = {}, {}
+    real = ops._lib.call
+    for fuse in (True, False):
+        seen = calls[fuse] = []
+
+        def spy(name, *a, _seen=seen):
+            _seen.append(name)
+            return real(name, *a)
+        ops._lib.call = spy
+        try:
+            model, step = build_step(cfg, B, sd, fuse_kernels=fuse)
+            step.capture()
+        finally:
+            ops._lib.call = real
+        _set_counter(step, 1000)
+        out[fuse] = _three_steps(step, images, labels)
+    assert "scae_set_encoder_fwd_logprob_f32" in calls[True]
+    assert "scae_render_gmm_logprob_sums_fwd_f32" not in calls[True]
+    assert "scae_set_encoder_fwd_logprob_f32" not in calls[False]
+    assert "scae_render_gmm_logprob_sums_fwd_f32" in calls[False]
+    (l1, d1, s1), (l0, d0, s0) = out[True], out[False]
+    assert all(torch.equal(a, b) for a, b in zip(d0, d1))
+    assert l0 == l1, (l0, l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k

@@ -613,9 +613,11 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
   }
 }
 
+// The forward pass as a device function of workgroup `blk` of `nblk` (threads 0 .. 64 NT - 1 of
+// the workgroup; `smem`: its dynamic LDS) -- so that it can also run as a block range of a
+// launch it shares with an independent kernel (trunk_logprob.hip).
 template <int NT, bool BF>
-__global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void stw_fwd_body(const StArgs &a, float *smem, int blk_id, int nblk) {
   const Lay lay{a.Din, a.L, a.layer_norm};
   const int N = a.N, XS = xs_of(a.Din);
   Wave w;
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
   dma_wait();
   if (NT > 1) __syncthreads();
   int blk = 0;   // running SAB counter: parity picks the K / V buffers
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  for (int b = blk_id; b < a.B; b += nblk) {
     stage_input(a, b, w, X, XS);
     f32x4 pres;
     float kmask[NT];
@@ -673,8 +675,15 @@ __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
     save(a.z + (size_t)b * N * D);
   }
 }
+
+template <int NT, bool BF>
+__global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  stw_fwd_body<NT, BF>(a, smem, blockIdx.x, gridDim.x);
+}
 }  // namespace
 
+#ifndef SCAE_DEVICE_ONLY   // (trunk_logprob.hip includes this file for its device code)
 static int tiles_of(int N) { return (N + 15) / 16; }
 static size_t lds_need(int N, int Din, bool bwd) {
   switch (tiles_of(N)) {
@@ -719,4 +728,9 @@ int wave_launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
   }
 #undef SCAE_STW
 }
+#else
+// the LDS floats a forward workgroup needs (for the shared launch)
+template <int NT>
+static size_t stw_fwd_lds_floats(int Din) { return lds_floats<NT>(Din, false); }
+#endif
 }  // namespace scae_st

@@ -1,0 +1,84 @@
+// Two independent forward kernels in ONE launch: the object encoder's fused trunk (K2b,
+// set_encoder_wave.hip: one wave per 16-row tile of a set -- 256 waves on 1024 SIMDs at
+// cfg-2, a chain of dependent MFMA / LDS latencies) and the part decoder's likelihood (K1,
+// render_gmm_wave_dev.h: VALU work that fills the chip).  Both only need the part
+// encoder's outputs, kernels do not overlap on this stack (forked graphs serialise,
+// DESIGN.md section 5), so the likelihood's workgroups ride in the trunk's launch as a
+// second block range: 15.8 + 15.3 us become ~17.
+//   blocks [0, n_trunk)            : trunk workgroup (threads 0 .. 64 NT - 1; the other waves
+//                                    of the workgroup exit at once)
+//   blocks [n_trunk, + tiles * B)  : likelihood workgroup (tile, image)
+// Register allocation is the maximum of the two bodies (the trunk's, 82-104 VGPRs: the
+// likelihood keeps 5 waves per SIMD); dynamic LDS the maximum of the two.
+#include "common.h"
+#define SCAE_DEVICE_ONLY
+#include "set_encoder_wave.hip"
+#undef SCAE_DEVICE_ONLY
+#include "render_gmm_wave_dev.h"
+
+namespace {
+template <int NT, int C>
+__global__ __launch_bounds__(1024) void trunk_logprob_kernel(
+    scae_st::StArgs a, int n_trunk, scae_decoder_desc d, const float *__restrict__ x,
+    float *__restrict__ lse_post, float *__restrict__ lse_prior, int ppb, int tiles,
+    float *__restrict__ tile_sums) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < n_trunk) {   // (workgroup-uniform)
+    if (threadIdx.x >= 64 * NT) return;   // whole waves
+    scae_st::stw_fwd_body<NT, false>(a, smem, blockIdx.x, n_trunk);
+    return;
+  }
+  const int id = (int)blockIdx.x - n_trunk, b = id / tiles, tile = id - b * tiles;
+  scae_k1::logprob_wave_body<C>(d, x, nullptr, lse_post, lse_prior, ppb, tile_sums, smem, tile, b,
+                                tiles, blockDim.x);
+}
+
+template <int NT, int C>
+int launch(const scae_st::StArgs &a, int n_trunk, const scae_decoder_desc *d,
+           const scae_k1::LpTiling &t, const float *x, float *tile_sums, float *lse_post,
+           float *lse_prior, hipStream_t st) {
+  const size_t lds_t = scae_st::stw_fwd_lds_floats<NT>(a.Din) * sizeof(float);
+  const size_t lds_l = scae_k1::logprob_wave_lds(d);
+  const size_t lds = lds_t > lds_l ? lds_t : lds_l;
+  if (lds > 160 * 1024) return SCAE_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trunk_logprob_kernel<NT, C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int threads = t.ppb > 64 * NT ? t.ppb : 64 * NT;
+  hipLaunchKernelGGL((trunk_logprob_kernel<NT, C>), dim3(n_trunk + t.tiles * d->B), dim3(threads),
+                     lds, st, a, n_trunk, *d, x, lse_post, lse_prior, t.ppb, t.tiles, tile_sums);
+  return scae_launch_status();
+}
+}  // namespace
+
+namespace scae_fused {
+// true when the shared launch covers this pair of problems (fp32 trunk on the matrix-core
+// kernels, wave-form likelihood with 1 or 3 channels, the likelihood's workgroup at least as
+// wide as the trunk's)
+bool trunk_logprob_supported(const scae_st::StArgs &a, int Dh, const scae_decoder_desc *d) {
+  if (!scae_st::wave_supported(a, Dh) || a.bf16_attention) return false;
+  if (d->C != 1 && d->C != 3) return false;
+  const scae_k1::LpTiling t = scae_k1::lp_tiling(d);
+  const int nt = (a.N + 15) / 16;
+  return t.wave && t.ppb >= 64 * nt && t.ppb <= 1024;
+}
+
+int trunk_logprob_launch(const scae_st::StArgs &a, int n_trunk, const scae_decoder_desc *d,
+                         const float *x, float *tile_sums, float *lse_post, float *lse_prior,
+                         hipStream_t st) {
+  const scae_k1::LpTiling t = scae_k1::lp_tiling(d);
+  const int nt = (a.N + 15) / 16;
+#define SCAE_TL(NTV)                                                                        \
+  return d->C == 1 ? launch<NTV, 1>(a, n_trunk, d, t, x, tile_sums, lse_post, lse_prior, st) \
+                   : launch<NTV, 3>(a, n_trunk, d, t, x, tile_sums, lse_post, lse_prior, st)
+  switch (nt) {
+    case 1: SCAE_TL(1);
+    case 2: SCAE_TL(2);
+    case 3: SCAE_TL(3);
+    default: SCAE_TL(4);
+  }
+#undef SCAE_TL
+}
+}  // namespace scae_fused

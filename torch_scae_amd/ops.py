@@ -511,6 +511,83 @@ def _seg_arrays(segs):
     return ptrs, widths, rs, bs
 
 
+# ----------------------------------------------------------------------------
+# Two independent forward kernels in one launch (csrc/trunk_logprob.hip): inside a
+# training step the part decoder's likelihood of the step's own input image only
+# needs the part encoder's outputs, like the object encoder's trunk -- and the
+# trunk leaves three quarters of the SIMDs idle.  ``step_fusion(target)`` (set
+# by train_step.TrainStep) lets SCAE.forward prepare the likelihood as a RIDER
+# of the trunk's launch; ``render_gmm_log_prob_sums`` later finds the result
+# instead of launching.  Same kernels, same values, one launch fewer.
+# ----------------------------------------------------------------------------
+_FUSION_TARGET = None
+_PENDING_RIDER = None
+
+
+class step_fusion:
+    """``with step_fusion(image):`` -- the reconstruction target of the loss
+    that will follow the forward inside the block (None: no fusion)."""
+
+    def __init__(self, target):
+        self.target = target
+
+    def __enter__(self):
+        global _FUSION_TARGET, _PENDING_RIDER
+        self.prev = (_FUSION_TARGET, _PENDING_RIDER)
+        _FUSION_TARGET, _PENDING_RIDER = self.target, None
+        return self
+
+    def __exit__(self, *exc):
+        global _FUSION_TARGET, _PENDING_RIDER
+        _FUSION_TARGET, _PENDING_RIDER = self.prev
+        return False
+
+
+def fusion_target():
+    return _FUSION_TARGET
+
+
+class LogProbRider:
+    """The tile-sum likelihood of ``x`` under the mixture of ``inputs``
+    (DecoderInputs), prepared for the trunk's launch to carry."""
+
+    def __init__(self, inputs, x):
+        t = _prep_decoder(inputs.tensors())
+        _need_hip(x)
+        self.x = x.detach().contiguous()
+        self.desc, (B, M, C, th, tw, H, W) = _make_desc(t, inputs.output_size)
+        self._keep = t          # the descriptor holds raw pointers
+        dev, dt = t[0].device, t[0].dtype
+        tiles = _lib.load().scae_render_gmm_logprob_tiles(ctypes.byref(self.desc))
+        self.sums = torch.empty(B, tiles, device=dev, dtype=dt)
+        self.lse_post = torch.empty(B, C, H, W, device=dev, dtype=dt)
+        self.lse_prior = torch.empty(B, 1 if t[1] is not None else C, H, W,
+                                     device=dev, dtype=dt)
+        self.key = self.key_of(inputs, x)
+        self.launched = False
+
+    @staticmethod
+    def key_of(inputs, x):
+        return (x.data_ptr(), tuple(x.shape), tuple(inputs.output_size)) + tuple(
+            None if v is None else (v.data_ptr(), tuple(v.shape))
+            for v in inputs.tensors())
+
+
+def offer_log_prob_rider(inputs, x):
+    """Called by SCAE.forward ahead of the object encoder: the next fused trunk
+    launch carries this likelihood (if it can; else nothing happens)."""
+    global _PENDING_RIDER
+    _PENDING_RIDER = LogProbRider(inputs, x)
+    return _PENDING_RIDER
+
+
+def withdraw_log_prob_rider():
+    """After the object encoder: a rider nobody launched is dropped."""
+    global _PENDING_RIDER
+    if _PENDING_RIDER is not None and not _PENDING_RIDER.launched:
+        _PENDING_RIDER = None
+
+
 class _SetEncoder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, presence, packed, meta, *segs):
@@ -532,10 +609,21 @@ class _SetEncoder(torch.autograd.Function):
         # attention products of every block, forward and backward
         ctx.bf16 = bool(_MFMA_BF16 and lib.scae_set_encoder_bf16_supported(
             N, D, Din, Dout, L, int(layer_norm)))
-        _lib.call("scae_set_encoder_fwd_bf16" if ctx.bf16 else
-                  "scae_set_encoder_fwd_f32", len(segs), ptrs, widths, rs, bs,
-                  _p(presence), _p(packed), _p(z), _p(hsave), B, N, D, Din,
-                  Dout, L, int(layer_norm), _stream(packed))
+        rider = _PENDING_RIDER
+        if rider is not None and not rider.launched and not ctx.bf16 \
+                and rider.x.device == packed.device:
+            # the part decoder's likelihood rides in this launch
+            _lib.call("scae_set_encoder_fwd_logprob_f32", len(segs), ptrs,
+                      widths, rs, bs, _p(presence), _p(packed), _p(z),
+                      _p(hsave), B, N, D, Din, Dout, L, int(layer_norm),
+                      ctypes.byref(rider.desc), _p(rider.x), _p(rider.sums),
+                      _p(rider.lse_post), _p(rider.lse_prior), _stream(packed))
+            rider.launched = True
+        else:
+            _lib.call("scae_set_encoder_fwd_bf16" if ctx.bf16 else
+                      "scae_set_encoder_fwd_f32", len(segs), ptrs, widths, rs,
+                      bs, _p(presence), _p(packed), _p(z), _p(hsave), B, N, D,
+                      Din, Dout, L, int(layer_norm), _stream(packed))
         ctx.save_for_backward(packed, hsave, *segs,
                               *([presence] if presence is not None else []))
         ctx.has_presence = presence is not None
@@ -2460,19 +2548,23 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
     log_prob(x) instead of the per-pixel map -> (B, tiles)."""
 
     @staticmethod
-    def forward(ctx, output_size, x, *tensors):
+    def forward(ctx, output_size, x, rider, *tensors):
         t = _prep_decoder(tensors)
         _need_hip(x)
         x = x.detach().contiguous()
-        d, (B, M, C, th, tw, H, W) = _make_desc(t, output_size)
-        dev, dt = t[0].device, t[0].dtype
-        Cm = 1 if t[1] is not None else C
-        tiles = _lib.load().scae_render_gmm_logprob_tiles(ctypes.byref(d))
-        sums = torch.empty(B, tiles, device=dev, dtype=dt)
-        lse_post = torch.empty(B, C, H, W, device=dev, dtype=dt)
-        lse_prior = torch.empty(B, Cm, H, W, device=dev, dtype=dt)
-        _lib.call("scae_render_gmm_logprob_sums_fwd_f32", ctypes.byref(d),
-                  _p(x), _p(sums), _p(lse_post), _p(lse_prior), _stream(x))
+        if rider is not None:     # computed in the object encoder's launch
+            sums, lse_post, lse_prior = rider.sums, rider.lse_post, \
+                rider.lse_prior
+        else:
+            d, (B, M, C, th, tw, H, W) = _make_desc(t, output_size)
+            dev, dt = t[0].device, t[0].dtype
+            Cm = 1 if t[1] is not None else C
+            tiles = _lib.load().scae_render_gmm_logprob_tiles(ctypes.byref(d))
+            sums = torch.empty(B, tiles, device=dev, dtype=dt)
+            lse_post = torch.empty(B, C, H, W, device=dev, dtype=dt)
+            lse_prior = torch.empty(B, Cm, H, W, device=dev, dtype=dt)
+            _lib.call("scae_render_gmm_logprob_sums_fwd_f32", ctypes.byref(d),
+                      _p(x), _p(sums), _p(lse_post), _p(lse_prior), _stream(x))
         ctx.save_for_backward(x, lse_post, lse_prior,
                               *[v for v in t if v is not None])
         ctx.present = [v is not None for v in t]
@@ -2493,7 +2585,7 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
                                        alpha_shape=ctx.alpha_shape))
         if grads[1] is not None:
             grads[1] = grads[1].view(ctx.alpha_shape)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 def render_gmm_log_prob_sums(inputs: "DecoderInputs", x):
@@ -2507,7 +2599,14 @@ def render_gmm_log_prob_sums(inputs: "DecoderInputs", x):
     if x.requires_grad:
         raise ScaeHipError("fused log_prob does not differentiate w.r.t. its "
                            "target; use the materialised mixture for that")
-    return _RenderGmmLogProbSums.apply(inputs.output_size, x,
+    global _PENDING_RIDER
+    rider = _PENDING_RIDER
+    if rider is not None and rider.launched and \
+            rider.key == LogProbRider.key_of(inputs, x):
+        _PENDING_RIDER = None         # consumed
+    else:
+        rider = None
+    return _RenderGmmLogProbSums.apply(inputs.output_size, x, rider,
                                        *inputs.tensors())
 
 

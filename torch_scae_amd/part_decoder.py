@@ -119,6 +119,21 @@ class TemplateBasedImageDecoder(nn.Module):
         if background_value:
             self.bg_value = nn.Parameter(torch.tensor([0.0]))
 
+    def decoder_inputs(self, templates, pose, presence=None, bg_image=None):
+        """The compact description of one decoder call (what the fused
+        likelihood / render kernels read)."""
+        return ops.DecoderInputs(
+            tuple(self.output_size),
+            templates=templates,
+            templates_alpha=self.templates_alpha if self.use_alpha_channel
+            else None,
+            pose=pose, presence=presence, bg_image=bg_image,
+            bg_value=self.bg_value if self.background_value else None,
+            bg_mixing_logit=self.bg_mixing_logit,
+            temperature_logit=None if self.use_alpha_channel
+            else self.temperature_logit,
+            out_scale=self.scale if self.learn_output_scale else None)
+
     def forward(self, templates, pose, presence=None, bg_image=None):
         """templates (B,M,C,h,w), pose [B,M,6], presence [B,M] or None,
         bg_image [B,C,H,W] or None -> AttrDict(transformed_templates
@@ -136,17 +151,7 @@ class TemplateBasedImageDecoder(nn.Module):
             # forward-only feature of the kernels
             templates = templates.repeat_interleave(
                 pose.shape[0] // templates.shape[0], dim=0)
-        inputs = ops.DecoderInputs(
-            tuple(self.output_size),
-            templates=templates,
-            templates_alpha=self.templates_alpha if self.use_alpha_channel
-            else None,
-            pose=pose, presence=presence, bg_image=bg_image,
-            bg_value=self.bg_value if self.background_value else None,
-            bg_mixing_logit=self.bg_mixing_logit,
-            temperature_logit=None if self.use_alpha_channel
-            else self.temperature_logit,
-            out_scale=self.scale if self.learn_output_scale else None)
+        inputs = self.decoder_inputs(templates, pose, presence, bg_image)
         if self.learn_output_scale:
             scale = nn.functional.softplus(self.scale) + 1e-4
         else:

@@ -133,9 +133,14 @@ class SCAE(nn.Module):
                             else parts.feature)
         segments.append(in_templates.flatten(2))
         if hasattr(self.obj_encoder, "forward_segments"):
-            # fused trunk: the concat is never materialised
+            # fused trunk: the concat is never materialised.  Inside a
+            # training step (ops.step_fusion) the part decoder's likelihood of
+            # the step's input -- which needs nothing the object encoder
+            # produces -- rides in the trunk's launch
+            self._offer_likelihood_rider(image, templates, parts)
             obj_encoding = self.obj_encoder.forward_segments(segments,
                                                              in_presence)
+            ops.withdraw_log_prob_rider()
         else:
             obj_encoding = self.obj_encoder(torch.cat(segments, -1),
                                             in_presence)
@@ -222,6 +227,24 @@ class SCAE(nn.Module):
             res.posterior_cls_prob = self.prior_classifier(
                 res.posterior_mixing_prob.sum(-1).detach())
         return res
+
+    def _offer_likelihood_rider(self, image, templates, parts):
+        """stacked_capsule_auto_encoder.py:146-162 + :220 ahead of :126-130:
+        with 'enc' votes and presences the reconstruction's inputs are the
+        part encoder's own outputs."""
+        target = ops.fusion_target()
+        dec = self.part_decoder
+        if target is None or target.data_ptr() != image.data_ptr() or \
+                target.shape != image.shape or not torch.is_grad_enabled() \
+                or self.vote_type != 'enc' or self.presence_type != 'enc' \
+                or not self.fuse_loss_tail or self.recon_mse_weight > 0 \
+                or self.part_caps_sparsity_weight > 0 \
+                or not hasattr(dec, "decoder_inputs") \
+                or not getattr(dec, "use_alpha_channel", False) \
+                or templates.shape[0] != parts.pose.shape[0]:
+            return
+        ops.offer_log_prob_rider(
+            dec.decoder_inputs(templates, parts.pose, parts.presence), image)
 
     def _fused_class_probs(self, obj_encoding):
         from .object_decoder import CapsuleObjectDecoder

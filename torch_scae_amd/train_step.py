@@ -43,7 +43,7 @@ class TrainStep:
                  optimizer=True, momentum=0.9, weight_decay=0.0,
                  lr_decay_rate=0.997, autocast_dtype=None,
                  force_collective=False, overlap=True, lazy_render=True,
-                 prologue=True):
+                 prologue=True, fuse_kernels=True):
         self.model = model
         self.device = next(model.parameters()).device
         self.world = world()[1]
@@ -102,6 +102,9 @@ class TrainStep:
         self.loss = torch.zeros((), device=self.device)
         self._one = torch.ones((), device=self.device)   # d loss / d loss
         self.use_graph = use_graph
+        # independent kernels of the step sharing launches (ops.step_fusion:
+        # the reconstruction likelihood rides with the object encoder's trunk)
+        self.fuse_kernels = fuse_kernels
         self.skip_collective = False
         self._capturing = False
         self._stream = None
@@ -127,7 +130,8 @@ class TrainStep:
         """forward + loss + backward (split: down to the decoders' inputs)."""
         self.flat.clear_grads()
         with ops.mfma_bf16(self.autocast_dtype is not None), \
-                ops.step_prologue(self._pro), self._lazy():
+                ops.step_prologue(self._pro), self._lazy(), \
+                ops.step_fusion(self.image if self.fuse_kernels else None):
             res = self.model(self.image)
             loss, info = self.model.loss(res, self.image, self.label)
             # a resident seed: no ones_like fill per step; the column sums that
