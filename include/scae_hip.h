@@ -916,6 +916,26 @@ int scae_set_encoder_fwd_logprob_f32(int nseg, const float *const *seg_ptr,
                                      float *tile_sums, float *lse_post, float *lse_prior,
                                      void *stream);
 
+/* scae_render_gmm_sums_bwd_f32 and scae_capsule_likelihood_bwd_f32 as ONE launch: both
+ * backward kernels only wait for the loss tail's (stacked_capsule_auto_encoder.py:217-287)
+ * and are independent of each other; the capsule likelihood's one-workgroup-per-image kernel
+ * rides as the first block range of the reconstruction likelihood's launch.  `k` holds the
+ * arguments of scae_capsule_likelihood_bwd_f32 (same names).  Two launches where the shapes do
+ * not fit; identical results. */
+typedef struct scae_likelihood_bwd_desc {
+  const float *vote, *scale, *vote_presence, *dummy_vote, *x, *presence, *posterior;
+  const int64_t *winner_idx;
+  const float *g_lpp, *g_winner, *g_winner_presence, *g_soft_winner, *g_soft_winner_presence,
+      *g_posterior, *g_mixing_log_prob, *g_mixing_logit;
+  float *gvote, *gscale, *gvote_presence, *gx, *gpresence, *gdummy_partial;
+  int B, O, M;
+} scae_likelihood_bwd_desc;
+int scae_render_gmm_sums_bwd_likelihood_f32(
+    const scae_decoder_desc *d, const float *x, const float *lse_post, const float *lse_prior,
+    const float *g_tile_sums, float *g_templates, float *g_alpha_partial, float *g_pose,
+    float *g_presence, float *g_bg_image, float *g_scalar_partial,
+    const scae_likelihood_bwd_desc *k, void *stream);
+
 /* generic mixture over materialised tensors: distributions.py:34-47.
  *   loc (B,K,C,P), mixing_logits (B,K,Cm,P) with Cm in {1,C}, sigma (1) device
  *   scalar (the Normal's scale), x (B,C,P) -> log_prob (B,C,P). */

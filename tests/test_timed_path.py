@@ -259,7 +259,9 @@ def test_two_graph_collective_step_equals_plain_step_bitwise_cfg2(nccl_group):
 def test_likelihood_riding_in_the_trunk_launch_changes_nothing():
     """TrainStep(fuse_kernels=True): the part decoder's likelihood forward runs
     as a second block range of the object encoder's trunk launch
-    (csrc/trunk_logprob.hip) instead of a launch of its own.  Same kernels on
+    (csrc/trunk_logprob.hip) instead of a launch of its own, and the capsule
+    likelihood's backward as the first block range of the part decoder's
+    likelihood backward (csrc/render_bwd_likelihood.hip).  Same kernels on
     the same inputs: three replayed steps at cfg-2, B = 128, end bit for bit
     on the state of the step with the two launches (noise on, generators
     aligned), and the step really takes the shared launch."""
@@ -287,6 +289,13 @@ def test_likelihood_riding_in_the_trunk_launch_changes_nothing():
     assert "scae_render_gmm_logprob_sums_fwd_f32" not in calls[True]
     assert "scae_set_encoder_fwd_logprob_f32" not in calls[False]
     assert "scae_render_gmm_logprob_sums_fwd_f32" in calls[False]
+    # ... and the backward mirror image: the capsule likelihood's backward
+    # rides in the launch of the (parked) reconstruction likelihood's backward
+    assert "scae_render_gmm_sums_bwd_likelihood_f32" in calls[True]
+    assert "scae_render_gmm_sums_bwd_f32" not in calls[True]
+    assert "scae_capsule_likelihood_bwd_f32" not in calls[True]
+    assert "scae_render_gmm_sums_bwd_f32" in calls[False]
+    assert "scae_capsule_likelihood_bwd_f32" in calls[False]
     (l1, d1, s1), (l0, d0, s0) = out[True], out[False]
     assert all(torch.equal(a, b) for a, b in zip(d0, d1))
     assert l0 == l1, (l0, l1)

@@ -28,6 +28,17 @@ class DecoderDesc(Structure):
                 ("template_repeat", c_int)]
 
 
+class LikelihoodBwdDesc(Structure):
+    """struct scae_likelihood_bwd_desc"""
+    _fields_ = [(n, P) for n in (
+        "vote", "scale", "vote_presence", "dummy_vote", "x", "presence",
+        "posterior", "winner_idx", "g_lpp", "g_winner", "g_winner_presence",
+        "g_soft_winner", "g_soft_winner_presence", "g_posterior",
+        "g_mixing_log_prob", "g_mixing_logit", "gvote", "gscale",
+        "gvote_presence", "gx", "gpresence", "gdummy_partial")] + [
+        ("B", c_int), ("O", c_int), ("M", c_int)]
+
+
 class GemmDesc(Structure):
     """struct scae_gemm_desc"""
     _fields_ = [("A", P), ("B", P), ("C", P), ("bias", P), ("mask", P),
@@ -142,6 +153,7 @@ SIGNATURES = {
     "scae_set_encoder_fwd_f32": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7 + [P],
     "scae_set_encoder_bwd_f32": [c_int, P, P, P, P, P, P, P, P, P, P]
                                 + [c_int] * 7 + [P],
+    "scae_render_gmm_sums_bwd_likelihood_f32": [P] * 13,
     "scae_set_encoder_fwd_logprob_f32": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7
                                         + [P] * 6,
     "scae_set_encoder_bf16_supported": [c_int] * 6,

@@ -290,6 +290,7 @@ class deferred_param_sums:
         global _DEFERRED
         if self.outer is None:
             if exc[0] is None:
+                flush_pending_backward()
                 flush_param_sums()
             _DEFERRED = None
         return False
@@ -579,6 +580,44 @@ def offer_log_prob_rider(inputs, x):
     global _PENDING_RIDER
     _PENDING_RIDER = LogProbRider(inputs, x)
     return _PENDING_RIDER
+
+
+_PENDING_K1_BWD = None
+
+
+class _PendingK1Backward:
+    """The reconstruction likelihood's backward (K1), parked: its launch is
+    handed to the next backward node that can carry it -- the capsule
+    likelihood's, an independent one-workgroup-per-image kernel -- or
+    launched on its own by ``flush_pending_backward``."""
+
+    def __init__(self, desc, keep, inputs, outputs, stream_ref):
+        """``inputs`` / ``keep``: tensors kept alive until the launch;
+        ``outputs``: the gradient buffers.  Those handed to autograd are kept
+        as ADDRESSES only: a leaf's AccumulateGrad adopts a gradient it holds
+        the sole reference to and clones -- here: copies an unfilled buffer --
+        otherwise; autograd itself keeps them alive until their consumers
+        run, which is after this launch."""
+        self.desc, self.keep, self.ref = desc, (keep, inputs), stream_ref
+        self.ptrs = [ctypes.c_void_p(t.data_ptr()) if t is not None else None
+                     for t in inputs] + \
+                    [None if t is None else ctypes.c_void_p(
+                        t if isinstance(t, int) else t.data_ptr())
+                     for t in outputs]
+        self.keep_out = [t for t in outputs if not isinstance(t, int)]
+
+    def launch_alone(self):
+        _lib.call("scae_render_gmm_sums_bwd_f32", ctypes.byref(self.desc),
+                  *self.ptrs, _stream(self.ref))
+
+
+def flush_pending_backward():
+    """Launch a parked K1 backward nobody carried (e.g. no gradient reached
+    the capsule likelihood)."""
+    global _PENDING_K1_BWD
+    if _PENDING_K1_BWD is not None:
+        pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
+        pending.launch_alone()
 
 
 def withdraw_log_prob_rider():
@@ -2233,11 +2272,33 @@ class _CapsuleLikelihood(torch.autograd.Function):
         gdummy = torch.empty(B, M, 6, device=x.device, dtype=x.dtype)
         gin = [_c(g) for g in (g_lpp, g_w, g_wp, g_s, g_sp, g_post, g_mlp,
                                g_mlogit)]
-        _lib.call("scae_capsule_likelihood_bwd_f32", _p(vote), _p(scale),
-                  _p(vp), _p(dummy_vote), _p(x), _p(presence), _p(post),
-                  _p(widx), *[_p(g) for g in gin], _p(gvote), _p(gscale),
-                  _p(gvp), _p(gx), _p(gpres), _p(gdummy), B, O, M,
-                  _stream(vote))
+        global _PENDING_K1_BWD
+        pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
+        if pending is not None and pending.ref.device == vote.device:
+            # the parked K1 backward and this kernel in one launch
+            k = _lib.LikelihoodBwdDesc()
+            for name, t in zip(
+                    ("vote", "scale", "vote_presence", "dummy_vote", "x",
+                     "presence", "posterior", "winner_idx", "g_lpp",
+                     "g_winner", "g_winner_presence", "g_soft_winner",
+                     "g_soft_winner_presence", "g_posterior",
+                     "g_mixing_log_prob", "g_mixing_logit", "gvote", "gscale",
+                     "gvote_presence", "gx", "gpresence", "gdummy_partial"),
+                    (vote, scale, vp, dummy_vote, x, presence, post, widx,
+                     *gin, gvote, gscale, gvp, gx, gpres, gdummy)):
+                setattr(k, name, None if t is None else t.data_ptr())
+            k.B, k.O, k.M = B, O, M
+            _lib.call("scae_render_gmm_sums_bwd_likelihood_f32",
+                      ctypes.byref(pending.desc), *pending.ptrs,
+                      ctypes.byref(k), _stream(vote))
+        else:
+            if pending is not None:
+                pending.launch_alone()
+            _lib.call("scae_capsule_likelihood_bwd_f32", _p(vote), _p(scale),
+                      _p(vp), _p(dummy_vote), _p(x), _p(presence), _p(post),
+                      _p(widx), *[_p(g) for g in gin], _p(gvote), _p(gscale),
+                      _p(gvp), _p(gx), _p(gpres), _p(gdummy), B, O, M,
+                      _stream(vote))
         # the dummy vote only reaches the (soft) winner outputs: without a
         # gradient on those it gets none at all, as in the reference
         g_dummy = None
@@ -2409,7 +2470,7 @@ def _make_desc(tensors, output_size):
 
 def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
                       g_lp, g_tt, g_ml, g_tile=None, slots=None,
-                      alpha_shape=None):
+                      alpha_shape=None, park=False):
     (templates, alpha, pose, presence, bg_image, bg_value, bg_ml, temp,
      out_scale) = ctx_tensors
     d, (B, M, C, th, tw, H, W) = _make_desc(ctx_tensors, output_size)
@@ -2421,7 +2482,20 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
     g_presence = torch.empty_like(presence) if presence is not None else None
     g_bg_image = torch.empty_like(bg_image) if bg_image is not None else None
     g_scal = torch.empty(B, M + 1, 4, device=dev, dtype=dt)
-    if g_tile is not None:
+    if g_tile is not None and park:
+        # inside a training step: parked for the capsule likelihood's backward
+        # to carry (both only wait for the loss tail); the gradient buffers are
+        # handed to autograd now and filled by that launch -- their consumers
+        # (template generator, part encoder, the deferred column sums) all run
+        # after it
+        global _PENDING_K1_BWD
+        flush_pending_backward()
+        addr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        _PENDING_K1_BWD = _PendingK1Backward(
+            d, ctx_tensors, (x, lse_post, lse_prior, g_tile),
+            (addr(g_templates), g_alpha_p, addr(g_pose), addr(g_presence),
+             addr(g_bg_image), g_scal), templates)
+    elif g_tile is not None:
         _lib.call("scae_render_gmm_sums_bwd_f32", ctypes.byref(d), _p(x),
                   _p(lse_post), _p(lse_prior), _p(g_tile), _p(g_templates),
                   _p(g_alpha_p), _p(g_pose), _p(g_presence), _p(g_bg_image),
@@ -2582,7 +2656,12 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
                                        x, lse_post, lse_prior, None, None, None,
                                        g_tile=g_sums.contiguous(),
                                        slots=ctx.slots,
-                                       alpha_shape=ctx.alpha_shape))
+                                       alpha_shape=ctx.alpha_shape,
+                                       # (only where every consumer of the
+                                       # gradients runs later: sums deferred,
+                                       # inside a fused training step)
+                                       park=_FUSION_TARGET is not None
+                                       and _DEFERRED is not None))
         if grads[1] is not None:
             grads[1] = grads[1].view(ctx.alpha_shape)
         return (None, None, None, *grads)
