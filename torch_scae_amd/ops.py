@@ -533,9 +533,10 @@ class step_fusion:
         self.target = target
 
     def __enter__(self):
-        global _FUSION_TARGET, _PENDING_RIDER
+        global _FUSION_TARGET, _PENDING_RIDER, _PENDING_K1_BWD
         self.prev = (_FUSION_TARGET, _PENDING_RIDER)
         _FUSION_TARGET, _PENDING_RIDER = self.target, None
+        _PENDING_K1_BWD = None     # (a backward that raised may have left one)
         return self
 
     def __exit__(self, *exc):
