@@ -19,7 +19,7 @@ struct LkBwd {   // scae_likelihood_bwd_desc by value
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void bwd_cell_likelihood_kernel(
+__global__ __launch_bounds__(256, 5) void bwd_cell_likelihood_kernel(
     scae_decoder_desc d, const float *__restrict__ x, const float *__restrict__ lse_post,
     const float *__restrict__ lse_prior, const float *__restrict__ g_tile, int lp_tiles,
     int lp_ppb, float *__restrict__ g_templates, float *__restrict__ g_alpha_partial,
