@@ -521,6 +521,18 @@ int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, float noise_
                               int similarity, float *pooled, float *pose, float *presence,
                               float *feature, float *absence, int B, int HW, int A, int P,
                               void *stream);
+/* The 1x1 attention conv (part_encoder.py:70-73) fused into the head's forward:
+ * y (B,HW,A*P) = x (B,HW,C) w^T (A*P,C) + bias is computed slab by slab inside the
+ * pooling workgroups (fp32 MFMA) and written to y for the backward; everything else
+ * as scae_capsule_head_fwd_f32.  Supported for HW <= 32 and C a multiple of 64
+ * and at most 256
+ * (scae_capsule_head_conv_supported); x and w 16-byte aligned. */
+int scae_capsule_head_conv_supported(int HW, int A, int P, int C);
+int scae_capsule_head_conv_fwd_f32(const float *x, const float *w, const float *bias, int C,
+                                   float *y, const float *noise_u, float noise_scale,
+                                   int similarity, float *pooled, float *pose, float *presence,
+                                   float *feature, float *absence, int B, int HW, int A, int P,
+                                   void *stream);
 int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *noise_u,
                               float noise_scale, int similarity, const float *g_pose,
                               const float *g_presence, const float *g_feature,

@@ -1562,7 +1562,7 @@ def test_uniform_generator_advances_under_graph_replay():
         ops.uniform(1000, ref)                   # creates the stream's state
     torch.cuda.current_stream().wait_stream(s)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=s):
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
         out = ops.uniform(1000, ref)
     g.replay()
     first = out.clone()

@@ -221,6 +221,9 @@ SIGNATURES = {
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
                               c_float, c_float, c_float, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
+    "scae_capsule_head_conv_supported": [c_int] * 4,
+    "scae_capsule_head_conv_fwd_f32": [P, P, P, c_int, P, P, c_float, c_int, P, P, P, P, P]
+    + [c_int] * 4 + [P],
     "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
     "scae_template_color_supported": [c_int] * 4,
     "scae_template_color_partial_rows": [c_int] * 2,

@@ -10,6 +10,7 @@
 // The reference runs this as view / softmax / mul / reshape / sum kernels plus
 // their autograd graph; here it is one launch forward and one backward.
 #include "geometric_transform.h"
+#include "wave_mfma.h"
 
 namespace {
 constexpr int NT = 512;
@@ -27,6 +28,12 @@ struct PoolArgs {
   float *pose, *presence, *feature;                  // forward outputs
   float *absence;                                    // 1 - presence (nullable)
   const float *pooled, *g_pose, *g_presence, *g_feature, *g_feature2;  // backward inputs
+  // fused 1x1 attention conv (part_encoder.py:70-73), forward only: when cx is set the
+  // workgroup computes its own y slab = cx (B,HW,C) cw^T (A*P,C) + cb on the matrix
+  // cores instead of reading it, and writes it to cy for the backward
+  const float *cx, *cw, *cb;
+  float *cy;
+  int C;
 };
 
 __host__ __device__ inline int padded(int AP) { return AP | 1; }
@@ -66,6 +73,73 @@ __device__ __forceinline__ void stage_y(float *ys, const float *y, int HW, int A
   }
 }
 
+// The workgroup's y slab from the 1x1 conv itself (HW <= 32, C = 64 NB): x of the image
+// is staged once into xs[HW][C+4]; a wave owns 16 channels x all pixels, a chain of C/4
+// v_mfma_f32_16x16x4_f32 per 16-pixel tile whose weight operand the lane reads straight
+// from global as float4s (every weight is used by one workgroup per image only -- nothing
+// to share through LDS) -- ALL of them issued before x is staged, so that the one L2
+// round trip overlaps the staging.  Result + bias -> ys (for the pooling below) and -> the
+// global y (for the backward).
+// Measured (B=128, 25 pixels, 128 -> 24 x 23 channels): 17.4 us against 13.4 (K7 GEMM) + 6.7
+// (this kernel reading y).  The conv part is bound by the weight reads -- every workgroup
+// pulls its 70 KB slab through L2, 72 MB per launch -- not by the MFMAs (replacing them
+// with adds changes nothing) nor by latency (prefetching changes nothing); halving C per
+// unit to level the waves needs LDS float atomics, which cost 10 us on their own.
+template <int NB>
+__device__ __forceinline__ void conv_y(float *ys, float *xs, const PoolArgs &k, int b, int a0,
+                                       int AP, int APp, int ldy) {
+  using namespace scae_wave;
+  constexpr int C = 64 * NB, XS = C + 4, q4 = C / 4;
+  const int HW = k.HW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int ncol = (AP + 15) / 16, nrow = (HW + 15) / 16;
+  // k of MFMA j in round t = 16 t + 4 q + j (A and B agree): the four k groups of a
+  // weight row read 64 contiguous bytes per round
+  float4 wf[4 * NB];
+  auto load_w = [&](int col) {
+    const int ch = col * 16 + r;
+    const float *wr = k.cw + (size_t)(a0 * k.P + (ch < AP ? ch : AP - 1)) * C + 4 * q;
+#pragma unroll
+    for (int t = 0; t < 4 * NB; ++t) wf[t] = ld4(wr + 16 * t);
+  };
+  if (wave < ncol) load_w(wave);
+  const float *x = k.cx + (size_t)b * HW * C;
+  for (int e = threadIdx.x; e < HW * q4; e += NT) {
+    const int pix = e / q4, c = 4 * (e - pix * q4);
+    *reinterpret_cast<float4 *>(xs + pix * XS + c) = ld4(x + (size_t)pix * C + c);
+  }
+  __syncthreads();
+  float *y = k.cy + (size_t)b * HW * ldy + a0 * k.P;
+  for (int col = wave; col < ncol; col += NT / 64) {
+    if (col != wave) load_w(col);
+    const int ch = col * 16 + r;
+    const float bias = (k.cb && ch < AP) ? k.cb[a0 * k.P + ch] : 0.f;
+    for (int rt = 0; rt < nrow; ++rt) {
+      const int pix = rt * 16 + r;
+      const float *xr = xs + (pix < HW ? pix : HW - 1) * XS + 4 * q;
+      f32x4 acc = splat(0.f);
+#pragma unroll
+      for (int t = 0; t < 4 * NB; ++t) acc = mma16(acc, ld4(xr + 16 * t), wf[t]);
+      if (ch < AP) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = rt * 16 + 4 * q + j;
+          if (p < HW) {
+            const float v = acc[j] + bias;
+            ys[p * APp + ch] = v;
+            y[(size_t)p * ldy + ch] = v;
+          }
+        }
+      }
+    }
+  }
+}
+inline bool conv_y_supported(int HW, int C) { return HW <= 32 && C >= 64 && C % 64 == 0 && C <= 256; }
+// xs follows the forward's (ys, mask, pooled), on a 16-byte boundary
+__host__ __device__ inline int conv_x_offset(int HW, int A, int P) {
+  return (HW * padded(A * P) + A * HW + A * (P - 1) + 3) & ~3;
+}
+
 // mask[a][pix] = softmax over pixels of the capsule's logit channel: 32 lanes per
 // capsule (a group of capsules is only a handful -- one thread each would leave the
 // workgroup waiting on 3 x HW serial LDS round trips)
@@ -96,18 +170,27 @@ __device__ __forceinline__ void softmax_masks(float *mask, const float *ys, int 
 }
 
 __global__ __launch_bounds__(NT) void pool_fwd_kernel(PoolArgs k) {
-  extern __shared__ float lds[];
+  extern __shared__ __align__(16) float lds[];
   // this workgroup: capsules [a0, a0 + A) of image b (A = the group's size from here on)
   const int Af = k.A, A = Af / k.splits, b = blockIdx.x / k.splits,
             a0 = (blockIdx.x % k.splits) * A;
   const int HW = k.HW, P = k.P, AP = A * P, APp = padded(AP), ldy = Af * P;
   const size_t cap0 = (size_t)b * Af + a0;  // global index of the group's first capsule
   float *ys = lds, *mask = ys + HW * APp;
-  stage_y(ys, k.y + (size_t)b * HW * ldy + a0 * P, HW, AP, APp, ldy);
+  float *pooled = mask + A * HW;  // [A*(P-1)], head mode only
+  if (k.cx) {
+    float *xs = lds + conv_x_offset(HW, A, P);
+    switch (k.C / 64) {
+      case 1: conv_y<1>(ys, xs, k, b, a0, AP, APp, ldy); break;
+      case 2: conv_y<2>(ys, xs, k, b, a0, AP, APp, ldy); break;
+      case 3: conv_y<3>(ys, xs, k, b, a0, AP, APp, ldy); break;
+      default: conv_y<4>(ys, xs, k, b, a0, AP, APp, ldy); break;
+    }
+  } else
+    stage_y(ys, k.y + (size_t)b * HW * ldy + a0 * P, HW, AP, APp, ldy);
   __syncthreads();
   softmax_masks(mask, ys, HW, A, P, APp);
   __syncthreads();
-  float *pooled = mask + A * HW;  // [A*(P-1)], head mode only
   for (int e = threadIdx.x; e < A * (P - 1); e += NT) {
     const int a = e / (P - 1), p = e - a * (P - 1);
     float s = 0.f;
@@ -261,6 +344,36 @@ extern "C" int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, f
   SCAE_REQUIRE(y && pooled && pose && presence && (feature || P == 8));
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
                      lds_floats(HW, A / k.splits, P, false) * sizeof(float),
+                     (hipStream_t)stream, k);
+  return scae_launch_status();
+}
+
+extern "C" int scae_capsule_head_conv_supported(int HW, int A, int P, int C) {
+  return scae_attention_pool_supported(HW, A, P) && P >= 8 && conv_y_supported(HW, C);
+}
+
+// 1x1 attention conv + capsule head in one launch: y (B,HW,A*P) = x (B,HW,C) w^T + bias is
+// produced slab by slab inside the pooling workgroups (and written out for the backward)
+extern "C" int scae_capsule_head_conv_fwd_f32(const float *x, const float *w, const float *bias,
+                                              int C, float *y, const float *noise_u,
+                                              float noise_scale, int similarity, float *pooled,
+                                              float *pose, float *presence, float *feature,
+                                              float *absence, int B, int HW, int A, int P,
+                                              void *stream) {
+  PoolArgs k{};
+  k.cx = x, k.cw = w, k.cb = bias, k.cy = y, k.C = C;
+  k.out = pooled, k.B = B, k.HW = HW, k.A = A, k.P = P;
+  k.splits = pool_splits(B, A);
+  k.noise_u = noise_u, k.noise_scale = noise_scale, k.similarity = similarity;
+  k.pose = pose, k.presence = presence, k.feature = feature, k.absence = absence;
+  int rc = check(k);
+  if (rc) return rc;
+  if (!scae_capsule_head_conv_supported(HW, A, P, C)) return SCAE_ERR_UNSUPPORTED;
+  SCAE_REQUIRE(x && w && y && pooled && pose && presence && (feature || P == 8));
+  SCAE_REQUIRE((((size_t)x | (size_t)w) & 15) == 0);
+  const int Ag = A / k.splits;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
+                     (conv_x_offset(HW, Ag, P) + (size_t)HW * (C + 4)) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();
 }

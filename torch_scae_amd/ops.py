@@ -1276,16 +1276,23 @@ class _PartEncoder(torch.autograd.Function):
         P = att_w2.shape[0] // n_caps
         F = P - 8
         noise_u = _c(noise_u)
-        y = _conv1x1_fwd(x, att_w2, att_b.contiguous())
         new = lambda *shape: torch.empty(*shape, device=x.device, dtype=x.dtype)
         pooled, pose, presence = new(B, n_caps, P - 1), new(B, n_caps, 6), \
             new(B, n_caps)
         feature = new(B, n_caps, F) if F > 0 else None
         absence = new(B, n_caps, 1)
-        _lib.call("scae_capsule_head_fwd_f32", _p(y), _p(noise_u),
-                  float(noise_scale), int(similarity), _p(pooled), _p(pose),
-                  _p(presence), _p(feature), _p(absence), B, HW, n_caps, P,
-                  _stream(x))
+        head = (_p(noise_u), float(noise_scale), int(similarity), _p(pooled),
+                _p(pose), _p(presence), _p(feature), _p(absence), B, HW,
+                n_caps, P, _stream(x))
+        if _lib.load().scae_capsule_head_conv_supported(HW, n_caps, P, C):
+            # the 1x1 conv inside the pooling workgroups: one launch
+            y = new(B, HW, n_caps * P)
+            att_b = att_b.contiguous()
+            _lib.call("scae_capsule_head_conv_fwd_f32", _p(x), _p(att_w2),
+                      _p(att_b), C, _p(y), *head)
+        else:
+            y = _conv1x1_fwd(x, att_w2, att_b.contiguous())
+            _lib.call("scae_capsule_head_fwd_f32", _p(y), *head)
         ctx.save_for_backward(image, *acts, *wds, x, att_w2, y, pooled,
                               *([noise_u] if noise_u is not None else []))
         ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights], n_caps,

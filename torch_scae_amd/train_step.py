@@ -9,6 +9,7 @@ import contextlib
 import os
 
 import torch
+import torch.distributed as dist
 
 from . import ops
 from .data_parallel import (FlatParameters, RMSpropFlat, all_reduce_gradients,
@@ -222,7 +223,13 @@ class TrainStep:
         # parameter's AccumulateGrad node together with its stream
         self.graph = torch.cuda.CUDAGraph()
         self._capturing = True
-        with torch.cuda.graph(self.graph, stream=s):
+        # With a process group alive its watchdog thread polls HIP events at
+        # any time; under the default "global" capture mode such a poll during
+        # the capture is an error that aborts the process.  Then (and only
+        # then) the check is narrowed to the capturing thread.
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() \
+            else "global"
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode=mode):
             self._part_a()
             if not self.split:
                 self._part_b()
@@ -234,7 +241,8 @@ class TrainStep:
             # captures, and the graphs are always replayed A, B, A, B, ...
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, stream=s,
-                                  pool=self.graph.pool()):
+                                  pool=self.graph.pool(),
+                                  capture_error_mode=mode):
                 self._part_b()
         self._capturing = False
 
