@@ -1308,6 +1308,9 @@ def test_rmsprop_flat_vs_torch_optim(momentum):
     (128, 128, 5, 5, 24, 16, False, True),
     (5, 8, 3, 4, 5, 0, True, False),
     (7, 64, 2, 2, 6, 3, False, True),
+    (9, 192, 4, 8, 7, 5, True, True),      # fused conv: 32 pixels, ragged tiles
+    (3, 256, 3, 3, 16, 16, False, False),  # ... at its largest channel count
+    (3, 320, 3, 3, 4, 2, False, False),    # beyond it: GEMM + head
 ])
 def test_capsule_head_vs_oracle(B, C, H, W, A, F, sim, noisy):
     """part_encoder.py:71-92 end to end (conv1x1, pooling, split, noise,

@@ -1190,6 +1190,34 @@ class _AttentionConvPool(torch.autograd.Function):
         return (*_conv1x1_bwd(x, weight, dy), None)
 
 
+def _capsule_head_fwd(x, weight, bias, noise_u, n_caps, noise_scale,
+                      similarity):
+    """1x1 attention conv + capsule head forward -> (y, pooled, pose,
+    presence, feature or None, absence): one launch where the fused kernel
+    covers the shape, the K7 GEMM + the head kernel otherwise."""
+    B, HW, C = x.shape
+    P = weight.shape[0] // n_caps
+    F = P - 8
+    new = lambda *shape: torch.empty(*shape, device=x.device, dtype=x.dtype)
+    pooled, pose, presence = new(B, n_caps, P - 1), new(B, n_caps, 6), \
+        new(B, n_caps)
+    feature = new(B, n_caps, F) if F > 0 else None
+    absence = new(B, n_caps, 1)
+    head = (_p(noise_u), float(noise_scale), int(similarity), _p(pooled),
+            _p(pose), _p(presence), _p(feature), _p(absence), B, HW, n_caps, P,
+            _stream(x))
+    if _lib.load().scae_capsule_head_conv_supported(HW, n_caps, P, C) and \
+            (x.data_ptr() | weight.data_ptr()) % 16 == 0:
+        # the 1x1 conv inside the pooling workgroups
+        y = new(B, HW, n_caps * P)
+        _lib.call("scae_capsule_head_conv_fwd_f32", _p(x), _p(weight),
+                  _p(bias), C, _p(y), *head)
+    else:
+        y = _conv1x1_fwd(x, weight, bias)
+        _lib.call("scae_capsule_head_fwd_f32", _p(y), *head)
+    return y, pooled, pose, presence, feature, absence
+
+
 class _CapsuleHead(torch.autograd.Function):
     """The whole head of CapsuleImageEncoder.forward (part_encoder.py:71-92,
     n_poses = 6): 1x1 conv, attention pooling, split, presence noise +
@@ -1204,16 +1232,9 @@ class _CapsuleHead(torch.autograd.Function):
         B, HW, C = x.shape
         P = weight.shape[0] // n_caps
         F = P - 8
-        y = _conv1x1_fwd(x, weight, bias)
         new = lambda *shape: torch.empty(*shape, device=x.device, dtype=x.dtype)
-        pooled, pose, presence = new(B, n_caps, P - 1), new(B, n_caps, 6), \
-            new(B, n_caps)
-        feature = new(B, n_caps, F) if F > 0 else None
-        absence = new(B, n_caps, 1)
-        _lib.call("scae_capsule_head_fwd_f32", _p(y), _p(noise_u),
-                  float(noise_scale), int(similarity), _p(pooled), _p(pose),
-                  _p(presence), _p(feature), _p(absence), B, HW, n_caps, P,
-                  _stream(x))
+        y, pooled, pose, presence, feature, absence = _capsule_head_fwd(
+            x, weight, bias, noise_u, n_caps, noise_scale, similarity)
         ctx.save_for_backward(x, weight, y, pooled,
                               *([noise_u] if noise_u is not None else []))
         ctx.meta = (n_caps, float(noise_scale), int(similarity),
@@ -1277,22 +1298,9 @@ class _PartEncoder(torch.autograd.Function):
         F = P - 8
         noise_u = _c(noise_u)
         new = lambda *shape: torch.empty(*shape, device=x.device, dtype=x.dtype)
-        pooled, pose, presence = new(B, n_caps, P - 1), new(B, n_caps, 6), \
-            new(B, n_caps)
-        feature = new(B, n_caps, F) if F > 0 else None
-        absence = new(B, n_caps, 1)
-        head = (_p(noise_u), float(noise_scale), int(similarity), _p(pooled),
-                _p(pose), _p(presence), _p(feature), _p(absence), B, HW,
-                n_caps, P, _stream(x))
-        if _lib.load().scae_capsule_head_conv_supported(HW, n_caps, P, C):
-            # the 1x1 conv inside the pooling workgroups: one launch
-            y = new(B, HW, n_caps * P)
-            att_b = att_b.contiguous()
-            _lib.call("scae_capsule_head_conv_fwd_f32", _p(x), _p(att_w2),
-                      _p(att_b), C, _p(y), *head)
-        else:
-            y = _conv1x1_fwd(x, att_w2, att_b.contiguous())
-            _lib.call("scae_capsule_head_fwd_f32", _p(y), *head)
+        y, pooled, pose, presence, feature, absence = _capsule_head_fwd(
+            x, att_w2, att_b.contiguous(), noise_u, n_caps, noise_scale,
+            similarity)
         ctx.save_for_backward(image, *acts, *wds, x, att_w2, y, pooled,
                               *([noise_u] if noise_u is not None else []))
         ctx.meta = (tuple(strides), [tuple(w.shape) for w in weights], n_caps,
