@@ -528,6 +528,9 @@ int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, float noise_
  * and at most 256
  * (scae_capsule_head_conv_supported); x and w 16-byte aligned. */
 int scae_capsule_head_conv_supported(int HW, int A, int P, int C);
+/* ... and faster than GEMM + scae_capsule_head_fwd_f32: the fused form re-reads the
+ * weights per image, so it pays for small batches only (see attention_pool.hip). */
+int scae_capsule_head_conv_preferred(int B, int HW, int A, int P, int C);
 int scae_capsule_head_conv_fwd_f32(const float *x, const float *w, const float *bias, int C,
                                    float *y, const float *noise_u, float noise_scale,
                                    int similarity, float *pooled, float *pose, float *presence,

@@ -1304,6 +1304,51 @@ def test_rmsprop_flat_vs_torch_optim(momentum):
         assert_close(a, b, rtol=1e-5, atol=1e-6, what="param after 4 steps")
 
 
+@pytest.mark.parametrize("B,HW,C,A,P", [
+    (128, 25, 128, 24, 23),    # the bench workload: preferred
+    (40, 25, 128, 48, 23),     # many 16-channel tiles per wave
+    (2048, 9, 128, 8, 16),     # a batch where the GEMM form is preferred
+])
+def test_fused_head_conv_equals_gemm_plus_head(B, HW, C, A, P):
+    """scae_capsule_head_conv_fwd_f32 (1x1 conv inside the pooling workgroups)
+    against the K7 GEMM + scae_capsule_head_fwd_f32 it replaces, called
+    directly so that the size preference does not pick for us."""
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(B + HW + A)
+    x = torch.randn(B, HW, C, generator=g).cuda()
+    w = (torch.randn(A * P, C, generator=g) / C ** 0.5).cuda()
+    bias = torch.randn(A * P, generator=g).cuda()
+    u = torch.rand(B, A, generator=g).cuda()
+    assert _lib.load().scae_capsule_head_conv_supported(HW, A, P, C)
+    if (B, A) == (128, 24):
+        assert _lib.load().scae_capsule_head_conv_preferred(B, HW, A, P, C)
+    if B == 2048:
+        assert not _lib.load().scae_capsule_head_conv_preferred(B, HW, A, P, C)
+    new = lambda *shape: torch.empty(*shape, device="cuda")
+    outs = []
+    for fused in (True, False):
+        pooled, pose, pres = new(B, A, P - 1), new(B, A, 6), new(B, A)
+        feat, absence = new(B, A, max(P - 8, 1)), new(B, A, 1)
+        fp = feat.data_ptr() if P > 8 else None
+        head = (u.data_ptr(), 4.0, 1, pooled.data_ptr(), pose.data_ptr(),
+                pres.data_ptr(), fp, absence.data_ptr(), B, HW, A, P,
+                torch.cuda.current_stream().cuda_stream)
+        if fused:
+            y = new(B, HW, A * P)
+            _lib.call("scae_capsule_head_conv_fwd_f32", x.data_ptr(),
+                      w.data_ptr(), bias.data_ptr(), C, y.data_ptr(), *head)
+        else:
+            y = ops._conv1x1_fwd(x, w, bias)
+            _lib.call("scae_capsule_head_fwd_f32", y.data_ptr(), *head)
+        torch.cuda.synchronize()
+        outs.append((y, pooled, pose, pres, absence) + ((feat,) if P > 8 else ()))
+    ref = (x.double() @ w.double().t() + bias.double()).float()
+    assert_close(outs[0][0], ref, rtol=1e-5, atol=1e-5, what="fused y vs fp64")
+    for a, b, what in zip(outs[0], outs[1],
+                          ("y", "pooled", "pose", "presence", "absence", "feature")):
+        assert_close(a, b, rtol=1e-5, atol=1e-5, what=what)
+
+
 @pytest.mark.parametrize("B,C,H,W,A,F,sim,noisy", [
     (128, 128, 5, 5, 24, 16, False, True),
     (5, 8, 3, 4, 5, 0, True, False),

@@ -222,6 +222,7 @@ SIGNATURES = {
                               c_float, c_float, c_float, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_head_conv_supported": [c_int] * 4,
+    "scae_capsule_head_conv_preferred": [c_int] * 5,
     "scae_capsule_head_conv_fwd_f32": [P, P, P, c_int, P, P, c_float, c_int, P, P, P, P, P]
     + [c_int] * 4 + [P],
     "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],

@@ -352,6 +352,18 @@ extern "C" int scae_capsule_head_conv_supported(int HW, int A, int P, int C) {
   return scae_attention_pool_supported(HW, A, P) && P >= 8 && conv_y_supported(HW, C);
 }
 
+// Every workgroup reads its capsule group's weight slab once PER IMAGE (through L2): that
+// is what bounds the fused form, and it grows with the batch while the K7 GEMM's traffic
+// does not.  Preferred while the launch's weight reads stay below 48 MB (36 MB at B = 128,
+// 24 x 23 channels, C = 128: 17.4 us against 13.4 + 6.7; at B = 1024, 48 capsules the
+// same kernel takes 176 us against 32 + 50) and a wave owns at most two 16-channel tiles.
+extern "C" int scae_capsule_head_conv_preferred(int B, int HW, int A, int P, int C) {
+  if (B <= 0 || !scae_capsule_head_conv_supported(HW, A, P, C)) return 0;
+  const int group = A / pool_splits(B, A);
+  return (size_t)B * A * P * C * sizeof(float) <= ((size_t)48 << 20) &&
+         (group * P + 15) / 16 <= 2 * (NT / 64);
+}
+
 // 1x1 attention conv + capsule head in one launch: y (B,HW,A*P) = x (B,HW,C) w^T + bias is
 // produced slab by slab inside the pooling workgroups (and written out for the backward)
 extern "C" int scae_capsule_head_conv_fwd_f32(const float *x, const float *w, const float *bias,

@@ -1194,7 +1194,8 @@ def _capsule_head_fwd(x, weight, bias, noise_u, n_caps, noise_scale,
                       similarity):
     """1x1 attention conv + capsule head forward -> (y, pooled, pose,
     presence, feature or None, absence): one launch where the fused kernel
-    covers the shape, the K7 GEMM + the head kernel otherwise."""
+    covers the shape and its per-image weight reads stay cheap, the K7 GEMM +
+    the head kernel otherwise."""
     B, HW, C = x.shape
     P = weight.shape[0] // n_caps
     F = P - 8
@@ -1206,9 +1207,9 @@ def _capsule_head_fwd(x, weight, bias, noise_u, n_caps, noise_scale,
     head = (_p(noise_u), float(noise_scale), int(similarity), _p(pooled),
             _p(pose), _p(presence), _p(feature), _p(absence), B, HW, n_caps, P,
             _stream(x))
-    if _lib.load().scae_capsule_head_conv_supported(HW, n_caps, P, C) and \
+    if _lib.load().scae_capsule_head_conv_preferred(B, HW, n_caps, P, C) and \
             (x.data_ptr() | weight.data_ptr()) % 16 == 0:
-        # the 1x1 conv inside the pooling workgroups
+        # the 1x1 conv inside the pooling workgroups (small batches)
         y = new(B, HW, n_caps * P)
         _lib.call("scae_capsule_head_conv_fwd_f32", _p(x), _p(weight),
                   _p(bias), C, _p(y), *head)
