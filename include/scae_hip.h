@@ -325,6 +325,22 @@ int scae_gemm_pair_f32(const scae_gemm_desc *first, const scae_gemm_desc *second
 /* Up to 4 independent GEMMs of that kind in ONE launch (the four weight-gradient
  * GEMMs of a capsule's MLP chain once the data-gradient chain has run). */
 int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *stream);
+/* scae_seed_attention_mfma_bwd_{f32,bf16} and scae_gemm_multi_f32(descs, n) in ONE launch
+ * (csrc/seed_bwd_gemm.hip): in a training step the output attention's backward and the
+ * weight-gradient GEMMs of the capsule MLPs both wait for the MLPs' data-gradient chain
+ * only and neither fills the device.  SCAE_ERR_UNSUPPORTED unless the GEMMs take the
+ * 32 x 32 split-K tiles (then they fill the device alone: launch them separately). */
+int scae_seed_attention_mfma_bwd_gemm_f32(const float *h, const float *q, const float *wk,
+                                          const float *wv, const float *presence,
+                                          const float *gout, float *gh, float *partial, int B,
+                                          int N, int O, int C, const scae_gemm_desc *descs,
+                                          int n, void *stream);
+int scae_seed_attention_mfma_bwd_gemm_bf16(const float *h, const float *q, const float *wk,
+                                           const float *wv, const float *presence,
+                                           const float *gout, float *gh, float *partial, int B,
+                                           int N, int O, int C, const scae_gemm_desc *descs,
+                                           int n, void *stream);
+
 
 /* ------------------------------------------------------------------------
  * K7b a chain of up to 4 per-group layers in ONE launch -- the two ReLU MLPs

@@ -171,6 +171,10 @@ SIGNATURES = {
     "scae_seed_attention_mfma_bwd_f32": [P] * 8 + [c_int] * 4 + [P],
     "scae_seed_attention_mfma_fwd_bf16": [P] * 7 + [c_int] * 4 + [P],
     "scae_seed_attention_mfma_bwd_bf16": [P] * 8 + [c_int] * 4 + [P],
+    "scae_seed_attention_mfma_bwd_gemm_f32": [P] * 8 + [c_int] * 4
+    + [POINTER(GemmDesc), c_int, P],
+    "scae_seed_attention_mfma_bwd_gemm_bf16": [P] * 8 + [c_int] * 4
+    + [POINTER(GemmDesc), c_int, P],
     "scae_seed_attention_mfma_reduce_f32": [P, c_int] + [P] * 7 + [c_int] * 2 + [P],
     "scae_seed_fold_supported": [c_int] * 3,
     "scae_seed_fold_fwd_f32": [POINTER(SeedFoldDesc), P],
@@ -284,6 +288,9 @@ def load():
             c_int64 if name == "scae_loss_tail_workspace_floats" else c_int)
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -2     # SCAE_ERR_UNSUPPORTED
 
 
 def check(rc, what):

@@ -181,6 +181,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, float *smem, int z,
   }
 }
 
+#ifndef SCAE_DEVICE_ONLY   // (seed_bwd_gemm.hip includes this file for its device code)
 template <int SK, bool AK, bool BKC>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(NT) void gemm_pair_kernel(GemmPair p) {
     default: gemm_tile<SK, false, false>(g, smem, z, blockIdx.x, blockIdx.y); break;
   }
 }
+#endif
 
 // Up to four independent problems in one launch: a 1-D grid of exactly the tiles that exist
 // (problem p owns the block range [first[p], first[p + 1]): its (batch, tile row, tile
@@ -216,12 +218,12 @@ struct GemmMulti {
   GemmArgs g[4];
   int first[5], tx[4], ty[4], layout[4], n;
 };
+// tile `blk` of the problem list (seed_bwd_gemm.hip runs these as the tail of another launch)
 template <int SK>
-__global__ __launch_bounds__(NT) void gemm_multi_kernel(GemmMulti p) {
-  __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
+__device__ __forceinline__ void gemm_multi_body(const GemmMulti &p, float *smem, int blk) {
   int which = 0;
-  while (which + 1 < p.n && (int)blockIdx.x >= p.first[which + 1]) ++which;
-  const int id = blockIdx.x - p.first[which], per = p.tx[which] * p.ty[which];
+  while (which + 1 < p.n && blk >= p.first[which + 1]) ++which;
+  const int id = blk - p.first[which], per = p.tx[which] * p.ty[which];
   const int z = id / per, rem = id - z * per, by = rem / p.tx[which], bx = rem - by * p.tx[which];
   const GemmArgs &g = p.g[which];
   switch (p.layout[which]) {  // workgroup-uniform
@@ -231,6 +233,13 @@ __global__ __launch_bounds__(NT) void gemm_multi_kernel(GemmMulti p) {
     default: gemm_tile<SK, false, false>(g, smem, z, bx, by); break;
   }
 }
+#ifndef SCAE_DEVICE_ONLY
+template <int SK>
+__global__ __launch_bounds__(NT) void gemm_multi_kernel(GemmMulti p) {
+  __shared__ __attribute__((aligned(16))) float smem[Tile<SK>::SMEM];
+  gemm_multi_body<SK>(p, smem, blockIdx.x);
+}
+#endif
 
 // fewer 64 x 64 tiles than this: 32 x 32 split-K tiles (4x the workgroups)
 #ifndef SCAE_GEMM_SK_BELOW
@@ -238,6 +247,38 @@ __global__ __launch_bounds__(NT) void gemm_multi_kernel(GemmMulti p) {
 #endif
 constexpr long kSplitKBelow = SCAE_GEMM_SK_BELOW;
 
+int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
+  if (!d || !d->A || !d->B || !d->C || d->batch <= 0 || d->M <= 0 || d->N <= 0 || d->K <= 0)
+    return SCAE_ERR_BAD_ARG;
+  if (d->asum && d->a_kcontig) return SCAE_ERR_UNSUPPORTED;
+  g = GemmArgs{d->A, d->B, d->bias, d->mask, d->C, d->asum, d->c_nomask, (long)d->a_batch, (long)d->b_batch,
+               (long)d->c_batch, (long)d->bias_batch, (long)d->mask_batch, (long)d->asum_batch,
+               d->lda, d->ldb, d->ldc, d->bias_ld, d->ldmask, d->M, d->N, d->K, d->relu,
+               d->asum_ld > 0 ? d->asum_ld : 1};
+  return SCAE_OK;
+}
+
+// the 1-D tile grid of up to four problems; T: 32 (split-K tiles) or 64
+int plan_multi(GemmMulti &p, int &T, const scae_gemm_desc *descs, int n) {
+  if (!descs || n < 1 || n > 4) return SCAE_ERR_BAD_ARG;
+  p = GemmMulti{};
+  p.n = n;
+  long tiles64 = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = fill_args(p.g[i], descs + i);
+    if (rc) return rc;
+    p.layout[i] = 2 * (descs[i].a_kcontig != 0) + (descs[i].b_kcontig != 0);
+    tiles64 += (long)((descs[i].N + 63) / 64) * ((descs[i].M + 63) / 64) * descs[i].batch;
+  }
+  T = tiles64 < kSplitKBelow ? 32 : 64;
+  for (int i = 0; i < n; ++i) {
+    p.tx[i] = (descs[i].N + T - 1) / T, p.ty[i] = (descs[i].M + T - 1) / T;
+    p.first[i + 1] = p.first[i] + p.tx[i] * p.ty[i] * descs[i].batch;
+  }
+  return SCAE_OK;
+}
+
+#ifndef SCAE_DEVICE_ONLY
 template <int SK>
 void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
   constexpr int T = Tile<SK>::T;
@@ -251,7 +292,10 @@ void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
   else
     hipLaunchKernelGGL((gemm_kernel<SK, false, false>), grid, dim3(NT), 0, st, g);
 }
+#endif
 }  // namespace
+
+#ifndef SCAE_DEVICE_ONLY
 
 // bf16 operands (MODE 3, 128 x 128 tiles) unless a side is so short that most of a tile
 // would be padding (rows / columns past the problem are not loaded, only multiplied)
@@ -304,33 +348,12 @@ extern "C" int scae_gemm_bf16(const float *A, const float *B, float *C, const fl
                    asum_batch, asum_ld, relu, true, stream);
 }
 
-static int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
-  if (!d || !d->A || !d->B || !d->C || d->batch <= 0 || d->M <= 0 || d->N <= 0 || d->K <= 0)
-    return SCAE_ERR_BAD_ARG;
-  if (d->asum && d->a_kcontig) return SCAE_ERR_UNSUPPORTED;
-  g = GemmArgs{d->A, d->B, d->bias, d->mask, d->C, d->asum, d->c_nomask, (long)d->a_batch, (long)d->b_batch,
-               (long)d->c_batch, (long)d->bias_batch, (long)d->mask_batch, (long)d->asum_batch,
-               d->lda, d->ldb, d->ldc, d->bias_ld, d->ldmask, d->M, d->N, d->K, d->relu,
-               d->asum_ld > 0 ? d->asum_ld : 1};
-  return SCAE_OK;
-}
-
 static int gemm_multi_impl(const scae_gemm_desc *descs, int n, void *stream) {
   SCAE_REQUIRE(descs && n >= 1 && n <= 4);
-  GemmMulti p{};
-  p.n = n;
-  long tiles64 = 0;
-  for (int i = 0; i < n; ++i) {
-    int rc = fill_args(p.g[i], descs + i);
-    if (rc) return rc;
-    p.layout[i] = 2 * (descs[i].a_kcontig != 0) + (descs[i].b_kcontig != 0);
-    tiles64 += (long)((descs[i].N + 63) / 64) * ((descs[i].M + 63) / 64) * descs[i].batch;
-  }
-  const int T = tiles64 < kSplitKBelow ? 32 : 64;
-  for (int i = 0; i < n; ++i) {
-    p.tx[i] = (descs[i].N + T - 1) / T, p.ty[i] = (descs[i].M + T - 1) / T;
-    p.first[i + 1] = p.first[i] + p.tx[i] * p.ty[i] * descs[i].batch;
-  }
+  GemmMulti p;
+  int T;
+  int rc = plan_multi(p, T, descs, n);
+  if (rc) return rc;
   if (T == 32)
     hipLaunchKernelGGL(gemm_multi_kernel<1>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
   else
@@ -373,3 +396,4 @@ extern "C" int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_
 extern "C" int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *stream) {
   return gemm_multi_impl(descs, n, stream);
 }
+#endif  // SCAE_DEVICE_ONLY

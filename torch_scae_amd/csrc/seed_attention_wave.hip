@@ -242,15 +242,15 @@ __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
   }
 }
 
+// workgroup `blk` of `nblk` (seed_bwd_gemm.hip runs these as the head of a shared launch)
 template <int NT, bool BF>
-__global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void saw_bwd_body(const SwArgs &a, float *smem, int blk, int nblk) {
   const Tl<NT> tl{smem};
   const Lane l = make_lane();
   const int C = a.C, O = a.O, N = a.N, CW = C / 4, run = CW / 4;
   constexpr int TSN = Geo<NT>::TSN;
   const int npar = O * D + C * D + C;
-  float *part = a.partial + (size_t)blockIdx.x * npar;
+  float *part = a.partial + (size_t)blk * npar;
   float *scr = tl.scr();
   for (int i = threadIdx.x; i < Geo<NT>::LDS_FLOATS; i += NTH) smem[i] = 0.f;
   __syncthreads();
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
   bool first = true;
   auto put = [&](int idx, float v) { part[idx] = first ? v : part[idx] + v; };
   const int k0 = CW * l.v + run * l.q;   // this lane group's run of C in the dT product
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  for (int b = blk; b < a.B; b += nblk) {
     const float *gb = a.gout + (size_t)b * O * C;
     // dT = gout wv: partial over this wave's quarter of C
     {
@@ -374,7 +374,13 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
     __syncthreads();
   }
 }
+template <int NT, bool BF>
+__global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  saw_bwd_body<NT, BF>(a, smem, blockIdx.x, gridDim.x);
+}
 
+#ifndef SCAE_DEVICE_ONLY   // (seed_bwd_gemm.hip includes this file for its device code)
 // partial (rows, O*16 + C*16 + C) -> gq (O,C), gwk (C,16), gbk (C) = 0, gwv (C,16), gbv (C).
 // 1024 threads = 64 columns x 16 row parts: a column sum is 8-16 independent loads per
 // thread and one LDS meeting.  Blocks [0, nsum): 64 columns of [dwv | dbv] each; the
@@ -450,12 +456,14 @@ __global__ __launch_bounds__(RTH) void saw_reduce_kernel(const float *__restrict
   }
 }
 
+#endif
 int check(const SwArgs &a) {
   if (a.B <= 0 || a.N <= 0 || a.O <= 0 || a.C <= 0) return SCAE_ERR_BAD_ARG;
   if (a.N > 64 || a.O > 64 || (a.C & 63)) return SCAE_ERR_UNSUPPORTED;
   return SCAE_OK;
 }
 
+#ifndef SCAE_DEVICE_ONLY
 template <int NT, bool BF>
 int launch_nt(const SwArgs &a, bool bwd, hipStream_t st) {
   const size_t lds = Geo<NT>::LDS_FLOATS * sizeof(float);
@@ -477,7 +485,10 @@ int launch(const SwArgs &a, bool bwd, hipStream_t st) {
     return a.bf16 ? launch_nt<2, true>(a, bwd, st) : launch_nt<2, false>(a, bwd, st);
   return a.bf16 ? launch_nt<4, true>(a, bwd, st) : launch_nt<4, false>(a, bwd, st);
 }
+#endif
 }  // namespace
+
+#ifndef SCAE_DEVICE_ONLY
 
 extern "C" int scae_seed_attention_mfma_supported(int N, int O, int D_, int C) {
   return D_ == D && N > 0 && N <= 64 && O > 0 && O <= 64 && C > 0 && (C & 63) == 0 ? 1 : 0;
@@ -522,3 +533,4 @@ extern "C" int scae_seed_attention_mfma_reduce_f32(const float *partial, int row
                      partial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C, nsum);
   return scae_launch_status();
 }
+#endif  // SCAE_DEVICE_ONLY

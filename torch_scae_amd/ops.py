@@ -537,6 +537,7 @@ class step_fusion:
         self.prev = (_FUSION_TARGET, _PENDING_RIDER)
         _FUSION_TARGET, _PENDING_RIDER = self.target, None
         _PENDING_K1_BWD = None     # (a backward that raised may have left one)
+        globals()["_PENDING_WGRADS"] = None
         return self
 
     def __exit__(self, *exc):
@@ -612,12 +613,41 @@ class _PendingK1Backward:
                   *self.ptrs, _stream(self.ref))
 
 
+_PENDING_WGRADS = None
+
+
+class _PendingWeightGemms:
+    """The weight-gradient GEMMs of the capsule MLPs, parked: nothing reads a
+    weight gradient before the optimiser does, so their launch can wait for a
+    later backward node with CUs to spare -- the output attention's
+    (``_SeedAttention.backward``: one workgroup per set), which like them
+    depends on the MLPs' data-gradient chain only.  ``descs`` holds device
+    addresses; ``keep`` the INPUT tensors (the outputs are the gradients
+    handed to autograd, see ``_PendingK1Backward``)."""
+
+    def __init__(self, descs, n, keep, stream_ref):
+        self.descs, self.n, self.keep, self.ref = descs, n, keep, stream_ref
+
+    def launch_alone(self):
+        _lib.call("scae_gemm_multi_f32", self.descs, self.n, _stream(self.ref))
+
+
+def take_pending_weight_gemms():
+    global _PENDING_WGRADS
+    pending, _PENDING_WGRADS = _PENDING_WGRADS, None
+    return pending
+
+
 def flush_pending_backward():
-    """Launch a parked K1 backward nobody carried (e.g. no gradient reached
-    the capsule likelihood)."""
+    """Launch what is parked and nobody carried: the K1 backward (e.g. no
+    gradient reached the capsule likelihood), the capsule MLPs' weight
+    gradients (e.g. an object encoder without the matrix-core attention)."""
     global _PENDING_K1_BWD
     if _PENDING_K1_BWD is not None:
         pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
+        pending.launch_alone()
+    pending = take_pending_weight_gemms()
+    if pending is not None:
         pending.launch_alone()
 
 
@@ -812,9 +842,21 @@ class _SeedAttention(torch.autograd.Function):
             new = lambda *shape: torch.empty(*shape, device=h.device,  # noqa: E731
                                              dtype=h.dtype)
             partial, gh = new(rows, O * D + C * D + C), new(B, N, D)
-            _lib.call(_prec("scae_seed_attention_mfma_bwd_f32"), _p(h), _p(q), _p(wk),
-                      _p(wv), _p(presence), _p(gout.contiguous()), _p(gh),
-                      _p(partial), B, N, O, C, _stream(h))
+            args = (_p(h), _p(q), _p(wk), _p(wv), _p(presence),
+                    _p(gout.contiguous()), _p(gh), _p(partial), B, N, O, C)
+            parked, carried = take_pending_weight_gemms(), False
+            if parked is not None:
+                # the capsule MLPs' weight-gradient tiles as the tail of this launch
+                rc = getattr(lib, _prec("scae_seed_attention_mfma_bwd_gemm_f32"))(
+                    *args, parked.descs, parked.n, _stream(h))
+                if rc == _lib.ERR_UNSUPPORTED:   # large GEMMs: on their own
+                    parked.launch_alone()
+                else:
+                    _lib.check(rc, "scae_seed_attention_mfma_bwd_gemm")
+                    carried = True
+            if not carried:
+                _lib.call(_prec("scae_seed_attention_mfma_bwd_f32"), *args,
+                          _stream(h))
             # column sums of the partials, expanded to the operands' gradients
             gq, gwk, gbk, gwv, gbv = new(O, C), new(C, D), new(C), new(C, D), \
                 new(C)
@@ -1851,7 +1893,7 @@ def _chain_forward_desc(x, ones_flags, weights, biases):
 
 
 def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
-                    need_gx, gpre=None, votes=None):
+                    need_gx, gpre=None, votes=None, park=False):
     """The backward of the chain: the data-gradient chain (one launch; with
     ``votes`` -- a struct scae_votes_desc whose gall_param(_gated) rows are
     ``gpre`` -- the vote kernel's backward rides at its head), then every
@@ -1922,7 +1964,15 @@ def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
                               g_ld, g_b, False, x_ld, x_b, ldw, N * ldw,
                               asum=asum, asum_b=asum_b, asum_ld=asum_ld)
         gws[l] = gw
-    _lib.call("scae_gemm_multi_f32", descs, L, _stream(x))
+    if park and L <= 4:
+        global _PENDING_WGRADS
+        flush_pending = take_pending_weight_gemms()
+        if flush_pending is not None:
+            flush_pending.launch_alone()
+        _PENDING_WGRADS = _PendingWeightGemms(
+            descs, L, (x, gs, acts, [w for w in weights]), x)
+    else:
+        _lib.call("scae_gemm_multi_f32", descs, L, _stream(x))
     return gx, gws, gbs
 
 
@@ -2067,9 +2117,12 @@ class _ChainVotes(torch.autograd.Function):
         v.caps_arg = caps_arg.data_ptr()
         v.gall_param, v.gcpr_in, v.gall_param_gated = \
             gall.data_ptr(), gin.data_ptr(), ggated.data_ptr()
-        gx, gws, gbs = _chain_backward(x, weights, acts, ones_flags, has_bias,
-                                       False, ctx.slots, True, gpre=ggated,
-                                       votes=v)
+        # (inside a fused step the weight-gradient launch waits for the output
+        # attention's backward to carry it)
+        gx, gws, gbs = _chain_backward(
+            x, weights, acts, ones_flags, has_bias, False, ctx.slots, True,
+            gpre=ggated, votes=v,
+            park=_FUSION_TARGET is not None and _DEFERRED is not None)
         # bias gradients: batch sums of column blocks of gall (B, O*A)
         outs = [_grad_out(sl, t) for sl, t in zip(ctx.vslots, vargs)]
         gall_rows = torch.as_strided(gall, (B, O * ldp), (O * ldp, 1))
