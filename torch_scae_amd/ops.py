@@ -68,8 +68,10 @@ def _grad_out(slot, like, shape=None):
             return v
         # a SECOND gradient of the parameter (shared parameter, module applied
         # twice): autograd is about to add this buffer to the slot's contents,
-        # so whatever sum into the slot is still waiting has to run first
+        # so whatever sum into the slot -- or parked launch that writes it --
+        # is still waiting has to run first
         flush_param_sums()
+        flush_pending_backward()
     return torch.empty(shape, device=like.device, dtype=like.dtype)
 
 
@@ -1964,7 +1966,10 @@ def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
                               g_ld, g_b, False, x_ld, x_b, ldw, N * ldw,
                               asum=asum, asum_b=asum_b, asum_ld=asum_ld)
         gws[l] = gw
-    if park and L <= 4:
+    # (parked only when every output is a slot view taken here: a fresh buffer
+    # is accumulated by autograd as soon as this node returns)
+    if park and L <= 4 and all(_in_slot(t) for t in gws) and \
+            all(_in_slot(t) for t in gbs if t is not None):
         global _PENDING_WGRADS
         flush_pending = take_pending_weight_gemms()
         if flush_pending is not None:
