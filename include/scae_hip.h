@@ -842,6 +842,17 @@ int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                            int B, int O, int M, int ncls, int n_classes_cfg, int prior_type,
                            int post_type, int sparsity_on, const float *weights5,
                            float within_const, void *stream);
+/* scae_loss_tail_fwd_f32 with the workgroups of scae_class_probs_f32 (arguments cp_* ..
+ * n_extra, same meaning) riding in its per-image launch: both are one wave per image and
+ * independent, and in a training step nothing reads the class probabilities in between. */
+int scae_loss_tail_fwd_class_probs_f32(
+    const float *lpp, const float *posterior, const float *caps_presence, const float *cls_w,
+    const float *cls_b, const int64_t *label, const scae_loss_extras *extras, float *out12,
+    float *workspace, int B, int O, int M, int ncls, int n_classes_cfg, int prior_type,
+    int post_type, int sparsity_on, const float *weights5, float within_const,
+    const float *cp_caps_presence, const float *cp_posterior, const float *cp_w,
+    const float *cp_bias, float *prior_prob, float *post_prob, int cp_B, int cp_O, int cp_M,
+    int cp_ncls, const scae_scaled_sum *extra_sums, int n_extra, void *stream);
 int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
                            const float *caps_presence, const float *cls_w,
                            const float *cls_b, const int64_t *label,

@@ -249,6 +249,9 @@ SIGNATURES = {
     "scae_loss_tail_workspace_floats": [c_int] * 3,
     "scae_loss_tail_fwd_f32": [P] * 6 + [POINTER(LossExtras), P, P] + [c_int] * 8
     + [POINTER(c_float), c_float, P],
+    "scae_loss_tail_fwd_class_probs_f32": [P] * 6 + [POINTER(LossExtras), P, P]
+    + [c_int] * 8 + [POINTER(c_float), c_float] + [P] * 6 + [c_int] * 4
+    + [POINTER(ScaledSum), c_int, P],
     "scae_loss_tail_bwd_f32": [P] * 6 + [POINTER(LossExtras)] + [P] * 7
     + [c_int] * 8 + [POINTER(c_float), c_float, P],
     "scae_template_render_fwd_f32": [POINTER(DecoderDesc), P, P, P],

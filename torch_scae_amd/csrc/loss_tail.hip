@@ -15,6 +15,7 @@
 //                       rows from the saved statistics, a few more workgroups
 //                       reduce the classifier-parameter gradients over the batch.
 // No atomics, every output has one writer, fixed summation orders.
+#include "class_probs_dev.h"
 #include "common.h"
 
 namespace {
@@ -109,10 +110,18 @@ __device__ __forceinline__ float cls_xe(const TailArgs &a, const float *x, int l
   return mx2 + logf(sum2) - plabel;  // -log_softmax(p)[label]
 }
 
-__global__ __launch_bounds__(NTI) void tail_image_kernel(TailArgs a, Ws ws) {
+// Workgroups [B, B + n_cp) are the class-probability kernel's (class_probs_dev.h): in a
+// training step that launch -- same one-wave-per-image shape, independent of this one --
+// rides here.
+__global__ __launch_bounds__(NTI) void tail_image_kernel(TailArgs a, Ws ws, scae_cp::Args cpa,
+                                                        int n_cp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int B = a.B, O = a.O, M = a.M, b = blockIdx.x, lane = threadIdx.x;
-  (void)B;
+  if (b >= B) {   // workgroup-uniform
+    __shared__ scae_cp::Lds s_cpl;
+    scae_cp::body(cpa, s_cpl, b - B, lane);
+    return;
+  }
   float *s_cp = smem, *s_mass = smem + O, *s_raw = smem + 2 * O;
   float rc = 0.f, rm = 0.f;
   for (int o = lane; o < O; o += NTI) {
@@ -391,14 +400,12 @@ static int fill_tail(TailArgs &a, const float *lpp, const float *posterior, cons
   return SCAE_OK;
 }
 
-extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
-                                      const float *caps_presence, const float *cls_w,
-                                      const float *cls_b, const int64_t *label,
-                                      const scae_loss_extras *extras, float *out12,
-                                      float *workspace, int B, int O, int M, int ncls,
-                                      int n_classes_cfg, int prior_type, int post_type,
-                                      int sparsity_on, const float *weights5,
-                                      float within_const, void *stream) {
+static int tail_fwd(const float *lpp, const float *posterior, const float *caps_presence,
+                    const float *cls_w, const float *cls_b, const int64_t *label,
+                    const scae_loss_extras *extras, float *out12, float *workspace, int B, int O,
+                    int M, int ncls, int n_classes_cfg, int prior_type, int post_type,
+                    int sparsity_on, const float *weights5, float within_const,
+                    const scae_cp::Args *cpa, void *stream) {
   TailArgs a;
   int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
                      n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
@@ -409,10 +416,42 @@ extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
   if (x.rec_sums && x.n_rec <= 0) return SCAE_ERR_BAD_ARG;
   const Ws ws = carve_ws(workspace, B, O, ncls);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(tail_image_kernel, dim3(B), dim3(NTI), 3 * O * sizeof(float), st, a, ws);
+  const int n_cp = cpa ? cpa->B + cpa->extra.n : 0;
+  hipLaunchKernelGGL(tail_image_kernel, dim3(B + n_cp), dim3(NTI), 3 * O * sizeof(float), st, a,
+                     ws, cpa ? *cpa : scae_cp::Args{}, n_cp);
   hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NTC),
                      (2 * O + 6 * (NTC / 64)) * sizeof(float), st, a, x, ws, out12);
   return scae_launch_status();
+}
+
+extern "C" int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
+                                      const float *caps_presence, const float *cls_w,
+                                      const float *cls_b, const int64_t *label,
+                                      const scae_loss_extras *extras, float *out12,
+                                      float *workspace, int B, int O, int M, int ncls,
+                                      int n_classes_cfg, int prior_type, int post_type,
+                                      int sparsity_on, const float *weights5,
+                                      float within_const, void *stream) {
+  return tail_fwd(lpp, posterior, caps_presence, cls_w, cls_b, label, extras, out12, workspace,
+                  B, O, M, ncls, n_classes_cfg, prior_type, post_type, sparsity_on, weights5,
+                  within_const, nullptr, stream);
+}
+
+extern "C" int scae_loss_tail_fwd_class_probs_f32(
+    const float *lpp, const float *posterior, const float *caps_presence, const float *cls_w,
+    const float *cls_b, const int64_t *label, const scae_loss_extras *extras, float *out12,
+    float *workspace, int B, int O, int M, int ncls, int n_classes_cfg, int prior_type,
+    int post_type, int sparsity_on, const float *weights5, float within_const,
+    const float *cp_caps_presence, const float *cp_posterior, const float *cp_w,
+    const float *cp_bias, float *prior_prob, float *post_prob, int cp_B, int cp_O, int cp_M,
+    int cp_ncls, const scae_scaled_sum *extra_sums, int n_extra, void *stream) {
+  scae_cp::Args cpa;
+  int rc = scae_cp::fill(cpa, cp_caps_presence, cp_posterior, cp_w, cp_bias, prior_prob,
+                         post_prob, cp_B, cp_O, cp_M, cp_ncls, extra_sums, n_extra);
+  if (rc) return rc;
+  return tail_fwd(lpp, posterior, caps_presence, cls_w, cls_b, label, extras, out12, workspace,
+                  B, O, M, ncls, n_classes_cfg, prior_type, post_type, sparsity_on, weights5,
+                  within_const, &cpa, stream);
 }
 
 extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,

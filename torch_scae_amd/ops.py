@@ -539,12 +539,14 @@ class step_fusion:
         self.prev = (_FUSION_TARGET, _PENDING_RIDER)
         _FUSION_TARGET, _PENDING_RIDER = self.target, None
         _PENDING_K1_BWD = None     # (a backward that raised may have left one)
-        globals()["_PENDING_WGRADS"] = None
+        globals()["_PENDING_WGRADS"] = globals()["_PENDING_CLASS_PROBS"] = None
         return self
 
     def __exit__(self, *exc):
         global _FUSION_TARGET, _PENDING_RIDER
         _FUSION_TARGET, _PENDING_RIDER = self.prev
+        if exc[0] is None:
+            flush_pending_forward()    # (a block without the fused loss tail)
         return False
 
 
@@ -1427,6 +1429,33 @@ def attention_conv_pool(x, weight, bias, n_caps):
 # ----------------------------------------------------------------------------
 # class probabilities of SCAE.forward (stacked_capsule_auto_encoder.py:205-212)
 # ----------------------------------------------------------------------------
+_PENDING_CLASS_PROBS = None
+
+
+class _PendingClassProbs:
+    """The class-probability launch of SCAE.forward, parked inside a fused
+    step until ``_LossTail.forward`` carries it (or ``flush_pending_forward``
+    launches it: a step without the fused loss tail)."""
+
+    def __init__(self, args, keep, stream_ref):
+        self.args, self.keep, self.ref = args, keep, stream_ref
+
+    def launch_alone(self):
+        _lib.call("scae_class_probs_f32", *self.args, _stream(self.ref))
+
+
+def take_pending_class_probs():
+    global _PENDING_CLASS_PROBS
+    pending, _PENDING_CLASS_PROBS = _PENDING_CLASS_PROBS, None
+    return pending
+
+
+def flush_pending_forward():
+    pending = take_pending_class_probs()
+    if pending is not None:
+        pending.launch_alone()
+
+
 def class_probs_supported(O, ncls):
     return bool(_lib.load().scae_class_probs_supported(O, ncls))
 
@@ -1449,9 +1478,18 @@ class _ClassProbs(torch.autograd.Function):
         prior = torch.empty(B, ncls, device=cp.device, dtype=cp.dtype)
         posterior_prob = torch.empty_like(prior)
         extra = list(extra_sums or ())
-        _lib.call("scae_class_probs_f32", _p(cp), _p(post), _p(weight), _p(bias),
-                  _p(prior), _p(posterior_prob), B, O1 - 1, M, ncls,
-                  _sum_jobs(extra), len(extra), _stream(cp))
+        args = (_p(cp), _p(post), _p(weight), _p(bias), _p(prior),
+                _p(posterior_prob), B, O1 - 1, M, ncls, _sum_jobs(extra),
+                len(extra))
+        if _FUSION_TARGET is not None:
+            # inside a fused step nothing reads these before SCAE.loss: the
+            # launch waits for the loss tail's per-image launch to carry it
+            flush_pending_forward()
+            global _PENDING_CLASS_PROBS
+            _PENDING_CLASS_PROBS = _PendingClassProbs(
+                args, (cp, post, weight, bias, prior, posterior_prob, extra), cp)
+        else:
+            _lib.call("scae_class_probs_f32", *args, _stream(cp))
         ctx.save_for_backward(cp, post, weight, bias)
         ctx.set_materialize_grads(False)
         return prior, posterior_prob
@@ -2433,9 +2471,14 @@ class _LossTail(torch.autograd.Function):
         # per-image / per-column statistics the backward kernel reads back
         ws = torch.empty(_lib.load().scae_loss_tail_workspace_floats(
             ints[0], ints[1], ints[3]), device=lpp.device, dtype=lpp.dtype)
-        _lib.call("scae_loss_tail_fwd_f32", _p(lpp), _p(posterior),
-                  _p(caps_presence), _p(cls_w), _p(cls_b), lab, ctypes.byref(ex),
-                  _p(out), _p(ws), *ints, w5, wc, _stream(lpp))
+        tail = (_p(lpp), _p(posterior), _p(caps_presence), _p(cls_w), _p(cls_b),
+                lab, ctypes.byref(ex), _p(out), _p(ws), *ints, w5, wc)
+        parked = take_pending_class_probs()
+        if parked is not None:    # SCAE.forward's class probabilities ride along
+            _lib.call("scae_loss_tail_fwd_class_probs_f32", *tail, *parked.args,
+                      _stream(lpp))
+        else:
+            _lib.call("scae_loss_tail_fwd_f32", *tail, _stream(lpp))
         ctx.save_for_backward(lpp, posterior, caps_presence, ws,
                               *([cls_w, cls_b, label] if label is not None
                                 else []),

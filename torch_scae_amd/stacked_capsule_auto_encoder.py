@@ -262,6 +262,10 @@ class SCAE(nn.Module):
         sparsity_on = (self.prior_within_example_sparsity_weight > 0
                        or self.prior_between_example_sparsity_weight > 0)
         fused_tail = self._fused_tail_ok(res, label)
+        if not fused_tail:
+            # the op-by-op terms read the class probabilities and the scalar
+            # sums whose launch a fused step parks for the tail kernel
+            ops.flush_pending_forward()
 
         def tail(rec_sums=None, reg=None):
             # one kernel for the capsule-likelihood, sparsity and
