@@ -596,10 +596,7 @@ __device__ __forceinline__ void wgrad_pipe_tile(float *smem, int bx, int by, int
       }
     int s = 0;
     for (int c = 0; c < nchunk; ++c) {
-      if (LA == 2 && c + 1 < nchunk)
-        pipe::wait_vm<T::PPW>();
-      else
-        pipe::wait_vm<0>();
+      pipe::wait_chunk<T::PPW, LA>(min(LA - 1, nchunk - 1 - c));
       pipe::wg_barrier();
       float *s2 = smem + (s >= 1 ? s - 1 : T::NS - 1) * T::STAGE;
       const float *st = smem + s * T::STAGE;
@@ -888,7 +885,10 @@ WgradPlan wgrad_plan(int M, int Cin, int Cout) {
   return p;
 }
 
-// second-generation tile shapes (mfma_pipe.h)
+// second-generation tile shapes (mfma_pipe.h).  Ring depth: 3 stages; 4 / 5 / 6 measured at
+// B = 128 (-DSCAE_PIPE_NS=..): forward 82.0 -> 84.3 / 90.8 / 92.1 us, backward pairs 156.6 ->
+// 175.6 / 176.7 / 238 -- the small layers are bound by the dependent MFMA / LDS-read chain of
+// one wave per SIMD, not by DMA latency, and a deeper ring only costs co-resident workgroups.
 #ifndef SCAE_PIPE_NS
 #define SCAE_PIPE_NS 3
 #endif

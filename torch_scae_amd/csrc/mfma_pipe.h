@@ -44,6 +44,24 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// chunk c has landed when at most `younger` x PPW of this wave's DMA pieces -- those of the
+// chunks issued after it -- are still outstanding (vector memory returns in order)
+template <int PPW, int LA>
+__device__ __forceinline__ void wait_chunk(int younger) {   // wave-uniform
+  static_assert(5 * PPW <= 63, "vmcnt range");
+  if (LA >= 6 && younger >= 5)
+    wait_vm<5 * PPW>();
+  else if (LA >= 5 && younger >= 4)
+    wait_vm<4 * PPW>();
+  else if (LA >= 4 && younger >= 3)
+    wait_vm<3 * PPW>();
+  else if (LA >= 3 && younger >= 2)
+    wait_vm<2 * PPW>();
+  else if (LA >= 2 && younger >= 1)
+    wait_vm<PPW>();
+  else
+    wait_vm<0>();
+}
 __device__ __forceinline__ void wg_barrier() {
   // LDS reads of the previous chunk are complete (their results were consumed by
   // MFMAs already issued); only the barrier itself is needed
@@ -68,7 +86,7 @@ struct KK {
   static constexpr int PPW = RA + RB;                 // DMA pieces per wave and chunk
   static constexpr int RED = (KS - 1) * WN * MI * NI * 1024;   // k-split meeting slabs
   static constexpr int SMEM = NS * STAGE > RED ? NS * STAGE : RED;   // floats
-  static_assert(NI >= 1 && MI >= 1 && TA % 32 == 0 && TB % 32 == 0 && (NS == 2 || NS == 3),
+  static_assert(NI >= 1 && MI >= 1 && TA % 32 == 0 && TB % 32 == 0 && (NS >= 2 && NS <= 7),
                 "tile shape");
 };
 
@@ -169,10 +187,7 @@ __device__ __forceinline__ void kk_mainloop(int nchunk, float *smem, f32x16 (&ac
     const bool more = SCAE_PIPE_ABL != 1 && c + LA < nchunk;
     const auto ctx = chunk(c + LA);   // (a few scalar instructions; unused past the end)
     // chunk c has landed; younger chunks may still be in flight
-    if (LA == 2 && c + 1 < nchunk)
-      wait_vm<T::PPW>();
-    else
-      wait_vm<0>();
+    wait_chunk<T::PPW, LA>(min(LA - 1, nchunk - 1 - c));
     wg_barrier();   // everyone's pieces of chunk c; everyone done with chunk c - 1
     float *s2 = smem + (s >= 1 ? s - 1 : T::NS - 1) * T::STAGE;   // stage of chunk c - 1
     kk_compute<T>(smem + s * T::STAGE, acc, wn, ks, i, kk, more,
@@ -234,7 +249,7 @@ struct SS {
   static constexpr int PA = TA * BKW / 256, PB = TB * BKW / 256;   // pieces per chunk
   static constexpr int PPW = (PA + PB) / 4;
   static constexpr int SMEM = NS * STAGE;
-  static_assert(MI >= 1 && NI >= 1 && (PA + PB) % 4 == 0 && (NS == 2 || NS == 3), "tile shape");
+  static_assert(MI >= 1 && NI >= 1 && (PA + PB) % 4 == 0 && (NS >= 2 && NS <= 7), "tile shape");
 };
 
 template <class T, class Dma>
