@@ -1151,6 +1151,55 @@ def test_mnist_transform_on_device():
 # --------------------------------------------------------------------------
 # K2d weight folding (set_transformer.py:218-223 projections) vs fp64 algebra
 # --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,O,C,G,rows", [
+    (128, 24, 24, 256, 24, 128),    # the bench workload's shapes
+    (37, 20, 17, 128, 5, 37),
+])
+def test_attention_backward_carrying_weight_gemms_equals_separate_launches(
+        B, N, O, C, G, rows):
+    """scae_seed_attention_mfma_bwd_gemm_f32 (csrc/seed_bwd_gemm.hip): the
+    output attention's backward with weight-gradient GEMM tiles as the tail of
+    its grid, against the two launches it replaces -- bit for bit."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(B + O)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).cuda()
+    D = 16
+    h, q, wk, wv = rnd(B, N, D), rnd(O, C) / C ** .5, rnd(C, D) * .3, rnd(C, D) * .3
+    presence, gout = torch.rand(B, N, generator=g).cuda(), rnd(B, O, C)
+    # two weight-gradient problems gW[g] (n x k) = gpre[g]^T x[g], batch = G groups
+    probs = []
+    for n, k in ((32, 48), (50, 33)):
+        gpre, x = rnd(G, rows, n), rnd(G, rows, k)
+        probs.append((gpre, x, n, k))
+    st = torch.cuda.current_stream().cuda_stream
+    nrows = _lib.load().scae_seed_attention_mfma_rows(B)
+    results = []
+    for merged in (False, True):
+        gh = torch.empty(B, N, D, device="cuda")
+        partial = torch.empty(nrows, O * D + C * D + C, device="cuda")
+        gws = [torch.empty(G, n, k, device="cuda") for _, _, n, k in probs]
+        descs = (_lib.GemmDesc * len(probs))()
+        for i, ((gpre, x, n, k), gw) in enumerate(zip(probs, gws)):
+            descs[i] = ops._gemm_desc(ops._p(gpre), ops._p(x), ops._p(gw), G, n, k,
+                                      rows, False, n, rows * n, False, k,
+                                      rows * k, k, n * k)
+        args = (ops._p(h), ops._p(q), ops._p(wk), ops._p(wv), ops._p(presence),
+                ops._p(gout), ops._p(gh), ops._p(partial), B, N, O, C)
+        if merged:
+            _lib.call("scae_seed_attention_mfma_bwd_gemm_f32", *args, descs,
+                      len(probs), st)
+        else:
+            _lib.call("scae_seed_attention_mfma_bwd_f32", *args, st)
+            _lib.call("scae_gemm_multi_f32", descs, len(probs), st)
+        torch.cuda.synchronize()
+        results.append([gh, partial, *gws])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    ref = torch.einsum("grn,grk->gnk", probs[0][0].double(), probs[0][1].double())
+    assert_close(results[1][2], ref.float(), atol=1e-4, rtol=1e-5, what="gW")
+
+
 @pytest.mark.parametrize("O,C,D", [(24, 256, 16), (5, 64, 8), (32, 512, 32),
                                    (3, 128, 16), (9, 1024, 8)])
 def test_seed_fold_vs_fp64(O, C, D):
@@ -1492,6 +1541,44 @@ def test_class_probs_vs_torch():
         .backward()
     assert_close(Wh.grad, Wr.grad, 1e-6, 1e-4, "d_w")
     assert_close(bh.grad, br.grad, 1e-6, 1e-4, "d_b")
+
+
+def test_class_probs_riding_in_the_loss_tail_launch_changes_nothing():
+    """Inside ``ops.step_fusion`` the class-probability launch of SCAE.forward
+    waits for the loss tail's per-image launch and rides there
+    (scae_loss_tail_fwd_class_probs_f32): probabilities, the rider sum, the tail's
+    12-vector -- bit for bit what the separate launches give; without a tail
+    the block's exit launches it."""
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, Oc, M, ncls = 128, 24, 24, 10
+    lpp = torch.randn(B, M, generator=g).cuda()
+    post = torch.softmax(torch.randn(B, Oc + 1, M, generator=g), 1).cuda()
+    cp = torch.rand(B, Oc, generator=g).cuda()
+    W, bb = (torch.randn(ncls, Oc, generator=g) * .3).cuda(), \
+        (torch.randn(ncls, generator=g) * .1).cuda()
+    label = torch.randint(0, ncls, (B,), generator=g).cuda()
+    src = torch.randn(5000, generator=g).cuda()
+    target = torch.empty(1, device="cuda")      # any tensor: "a fused step"
+
+    def run(fused, with_tail=True):
+        total = torch.zeros((), device="cuda")
+        import contextlib
+        with (ops.step_fusion(target) if fused else contextlib.nullcontext()):
+            q1, q2 = ops.class_probs(cp, post, W, bb,
+                                     extra_sums=[(src, 0.5, total)])
+            out = ops.loss_tail(lpp, post, cp, W, bb, label, ncls, "l2", "l2",
+                                True, [1., 2., .35, .7, .2], None) \
+                if with_tail else None
+        torch.cuda.synchronize()
+        return q1, q2, total, out
+
+    plain, fused = run(False), run(True)
+    for a, b in zip(plain, fused):
+        assert torch.equal(a, b)
+    lone = run(True, with_tail=False)
+    for a, b in zip(plain[:3], lone[:3]):
+        assert torch.equal(a, b)
 
 
 def test_gemm_pair_equals_two_launches():
