@@ -832,6 +832,13 @@ typedef struct scae_loss_extras {
   float *loss;          /* forward: also receives out12[0] (a separate scalar) */
   const float *g_loss;  /* backward: gradient of that scalar, added to gout12[0];
                            gout12 may then be NULL (= zeros) */
+  /* A training step in which nothing reads the forward's scalars before the backward has
+   * run: with defer_combine the forward launches its per-image kernel only, and the batch
+   * combine (out12, loss) is one more workgroup of the BACKWARD launch, which then needs
+   * out12 (and loss) here.  scae_loss_tail_combine_f32 is that combine on its own, for a
+   * deferred forward that no backward followed. */
+  int defer_combine;
+  float *out12;
 } scae_loss_extras;
 int scae_loss_tail_supported(int B, int O, int ncls);
 int64_t scae_loss_tail_workspace_floats(int B, int O, int ncls);
@@ -842,6 +849,13 @@ int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                            int B, int O, int M, int ncls, int n_classes_cfg, int prior_type,
                            int post_type, int sparsity_on, const float *weights5,
                            float within_const, void *stream);
+int scae_loss_tail_combine_f32(const float *lpp, const float *posterior,
+                               const float *caps_presence, const float *cls_w,
+                               const float *cls_b, const int64_t *label,
+                               const scae_loss_extras *extras, float *out12, float *workspace,
+                               int B, int O, int M, int ncls, int n_classes_cfg, int prior_type,
+                               int post_type, int sparsity_on, const float *weights5,
+                               float within_const, void *stream);
 /* scae_loss_tail_fwd_f32 with the workgroups of scae_class_probs_f32 (arguments cp_* ..
  * n_extra, same meaning) riding in its per-image launch: both are one wave per image and
  * independent, and in a training step nothing reads the class probabilities in between. */

@@ -1581,6 +1581,45 @@ def test_class_probs_riding_in_the_loss_tail_launch_changes_nothing():
         assert torch.equal(a, b)
 
 
+def test_loss_tail_combine_inside_the_backward_launch_changes_nothing():
+    """Inside ``ops.step_fusion`` the whole-scalar loss tail leaves its batch
+    combine to the backward launch (scae_loss_extras.defer_combine): scalars
+    and gradients bit for bit those of the three-launch form; a forward no
+    backward follows is completed when the block exits."""
+    import contextlib
+    from torch_scae_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Oc, M, ncls = 128, 24, 24, 10
+    base = [torch.randn(B, M, generator=g),
+            torch.softmax(torch.randn(B, Oc + 1, M, generator=g), 1),
+            torch.rand(B, Oc, generator=g),
+            torch.randn(ncls, Oc, generator=g) * .3,
+            torch.randn(ncls, generator=g) * .1,
+            torch.randn(B, 25, generator=g), torch.rand(1, generator=g)]
+    label = torch.randint(0, ncls, (B,), generator=g).cuda()
+    target = torch.empty(1, device="cuda")
+
+    def run(fused, backward=True):
+        ins = [leaf(t) for t in base]
+        with (ops.step_fusion(target) if fused else contextlib.nullcontext()):
+            loss, out = ops.loss_tail_scalar(
+                *ins[:5], label, ncls, "l2", "kl", True, [1., 2., .35, .7, .2],
+                None, rec_sums=ins[5], reg=ins[6], w_reg=0.3)
+            if backward:
+                loss.backward()
+        torch.cuda.synchronize()
+        return [loss.detach(), out.detach()] + \
+            ([t.grad for t in ins] if backward else [])
+
+    plain, fused = run(False), run(True)
+    assert len(plain) == len(fused) == 9
+    for a, b in zip(plain, fused):
+        assert torch.equal(a, b)
+    lone = run(True, backward=False)
+    for a, b in zip(plain[:2], lone):
+        assert torch.equal(a, b)
+
+
 def test_gemm_pair_equals_two_launches():
     """scae_gemm_pair_f32: two differently shaped / laid out problems at once."""
     from torch_scae_amd import ops

@@ -103,7 +103,8 @@ class LossExtras(Structure):
     """struct scae_loss_extras"""
     _fields_ = [("rec_sums", P), ("n_rec", c_int), ("reg", P),
                 ("w_reg", c_float), ("g_rec_sums", P), ("g_reg", P),
-                ("loss", P), ("g_loss", P)]
+                ("loss", P), ("g_loss", P), ("defer_combine", c_int),
+                ("out12", P)]
 
 
 class SeedFoldDesc(Structure):
@@ -248,6 +249,8 @@ SIGNATURES = {
     "scae_loss_tail_supported": [c_int] * 3,
     "scae_loss_tail_workspace_floats": [c_int] * 3,
     "scae_loss_tail_fwd_f32": [P] * 6 + [POINTER(LossExtras), P, P] + [c_int] * 8
+    + [POINTER(c_float), c_float, P],
+    "scae_loss_tail_combine_f32": [P] * 6 + [POINTER(LossExtras), P, P] + [c_int] * 8
     + [POINTER(c_float), c_float, P],
     "scae_loss_tail_fwd_class_probs_f32": [P] * 6 + [POINTER(LossExtras), P, P]
     + [c_int] * 8 + [POINTER(c_float), c_float] + [P] * 6 + [c_int] * 4

@@ -20,9 +20,14 @@
 
 namespace {
 constexpr int NTI = 64;    // tail_image_kernel: one wave per image
-constexpr int NT = 256;    // backward workgroups
-constexpr int NTC = 1024;  // the one combine workgroup: its batch / column sums are
+#ifndef SCAE_TAIL_NT
+#define SCAE_TAIL_NT 512
+#endif
+constexpr int NTC = SCAE_TAIL_NT;  // the one combine workgroup: its batch / column sums are
                            // chains of L2 loads, 16 waves keep four times as many in flight
+constexpr int NT = NTC;    // backward workgroups: the same shape, so that the combine
+                           // workgroup can be one of them (deferred mode) and an image's
+                           // workgroup can form the column sums exactly as it does
 constexpr int MAXCLS = 32;
 
 struct TailArgs {
@@ -190,20 +195,12 @@ __device__ __forceinline__ float between_term(const float *col, int O, int type,
 // out: [0] loss  [1] log_prob  [2] prior_within [3] prior_between [4] post_within
 //      [5] post_between [6] prior_cls_xe [7] posterior_cls_xe [8] rec_ll [9] -rec_ll
 //      [10] -log_prob [11] reg
-__global__ __launch_bounds__(NTC) void tail_combine_kernel(TailArgs a, scae_loss_extras x, Ws ws,
-                                                          float *out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int B = a.B, O = a.O, tid = threadIdx.x;
-  float *col = smem, *red = smem + 2 * O;  // red: 6 * (NTC/64) floats
-  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int b = tid; b < B; b += NTC) {
-    const float4 p = *reinterpret_cast<const float4 *>(ws.part + (size_t)b * 8);
-    v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w;
-    v[4] += ws.part[(size_t)b * 8 + 4];
-  }
-  if (x.rec_sums)
-    for (int i = tid; i < x.n_rec; i += NTC) v[5] += x.rec_sums[i];
-  // column sums over the batch: 16 lanes per column, each takes every 16th image
+// column sums over the batch into col[2 O] (LDS; also published to ws.col when asked): 16
+// lanes per column, each takes every 16th image.  Every caller runs NTC threads, so the
+// summation order -- and the result, bit for bit -- is the same wherever it is formed.
+__device__ __forceinline__ void column_sums(const TailArgs &a, const Ws &ws, float *col, int tid,
+                                            bool publish) {
+  const int B = a.B, O = a.O;
   for (int e = tid; e < ((2 * O * 16 + NTC - 1) / NTC) * NTC; e += NTC) {
     const int c = e >> 4, l = e & 15, which = c / O, o = c - which * O;
     float t = 0.f;
@@ -221,8 +218,29 @@ __global__ __launch_bounds__(NTC) void tail_combine_kernel(TailArgs a, scae_loss
       t = (t0 + t1) + (t2 + t3);
     }
     t = scae::row_sum16(t);
-    if (c < 2 * O && l == 0) col[c] = ws.col[c] = t;
+    if (c < 2 * O && l == 0) {
+      col[c] = t;
+      if (publish) ws.col[c] = t;
+    }
   }
+}
+
+// out: [0] loss  [1] log_prob  [2] prior_within [3] prior_between [4] post_within
+//      [5] post_between [6] prior_cls_xe [7] posterior_cls_xe [8] rec_ll [9] -rec_ll
+//      [10] -log_prob [11] reg
+__device__ __forceinline__ void combine_body(const TailArgs &a, const scae_loss_extras &x,
+                                             const Ws &ws, float *out, float *smem) {
+  const int B = a.B, O = a.O, tid = threadIdx.x;
+  float *col = smem, *red = smem + 2 * O;  // red: 6 * (NTC/64) floats
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = tid; b < B; b += NTC) {
+    const float4 p = *reinterpret_cast<const float4 *>(ws.part + (size_t)b * 8);
+    v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w;
+    v[4] += ws.part[(size_t)b * 8 + 4];
+  }
+  if (x.rec_sums)
+    for (int i = tid; i < x.n_rec; i += NTC) v[5] += x.rec_sums[i];
+  column_sums(a, ws, col, tid, true);
   scae::block_sum<6, NTC>(v, red);  // (contains the barriers that publish col[])
   if (tid >= 64) return;
   float pb = 0.f, qb = 0.f;
@@ -239,6 +257,11 @@ __global__ __launch_bounds__(NTC) void tail_combine_kernel(TailArgs a, scae_loss
                      a.w_qb * qb + xe1 + xe2 - rec + x.w_reg * reg;
   out[0] = loss;
   if (x.loss) x.loss[0] = loss;
+}
+__global__ __launch_bounds__(NTC) void tail_combine_kernel(TailArgs a, scae_loss_extras x, Ws ws,
+                                                          float *out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  combine_body(a, x, ws, out, smem);
 }
 
 // d(gw * within + gb * between) / d x[b,o] for one image: x[o], col[o] in LDS
@@ -270,12 +293,19 @@ __device__ __forceinline__ void sparsity_grad(const float *x, const float *col, 
 
 // blockIdx.x < B: the gradient rows of image b.  blockIdx.x >= B: 64 outputs each
 // of the classifier-parameter gradients (4 lanes per output, interleaved over b).
+// x.defer_combine (a training step: nothing reads the forward's scalars before the backward
+// has run): the forward left the combine workgroup out -- it is the LAST workgroup of this
+// launch instead, and the image workgroups form the column sums they need themselves.
 __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extras x, Ws ws,
                                                       const float *gout /*[12]*/, float *g_lpp,
                                                       float *g_post, float *g_cp, float *g_w,
                                                       float *g_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int B = a.B, O = a.O, M = a.M, tid = threadIdx.x;
+  if (x.defer_combine && blockIdx.x + 1 == gridDim.x) {   // workgroup-uniform
+    combine_body(a, x, ws, x.out12, smem);
+    return;
+  }
   // d(total)/d(component): the loss plus whatever flowed into the individually
   // exposed log entries; d/d(loss) may arrive on the 12-vector, on the separate
   // scalar, or both
@@ -336,10 +366,13 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
   for (int o = tid; o < O; o += NT) {
     s_cp[o] = a.cp[(size_t)b * O + o];
     s_mass[o] = ws.mass[(size_t)b * O + o] / M;
-    col[o] = ws.col[o];
-    col[O + o] = ws.col[O + o];
+    if (!x.defer_combine) {
+      col[o] = ws.col[o];
+      col[O + o] = ws.col[O + o];
+    }
     gc[o] = gm[o] = 0.f;
   }
+  if (x.defer_combine) column_sums(a, ws, col, tid, false);
   __syncthreads();
   if (a.sparsity_on && tid < 64) {
     const float *p = ws.part + (size_t)b * 8;
@@ -377,6 +410,8 @@ extern "C" int64_t scae_loss_tail_workspace_floats(int B, int O, int ncls) {
   if (B <= 0 || O <= 0 || ncls < 0) return 0;
   return (int64_t)ws_floats(B, O, ncls);
 }
+
+static size_t combine_lds(int O) { return (2 * O + 6 * (NTC / 64)) * sizeof(float); }
 
 static int fill_tail(TailArgs &a, const float *lpp, const float *posterior, const float *cp,
                      const float *cls_w, const float *cls_b, const int64_t *label, int B,
@@ -419,8 +454,30 @@ static int tail_fwd(const float *lpp, const float *posterior, const float *caps_
   const int n_cp = cpa ? cpa->B + cpa->extra.n : 0;
   hipLaunchKernelGGL(tail_image_kernel, dim3(B + n_cp), dim3(NTI), 3 * O * sizeof(float), st, a,
                      ws, cpa ? *cpa : scae_cp::Args{}, n_cp);
-  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NTC),
-                     (2 * O + 6 * (NTC / 64)) * sizeof(float), st, a, x, ws, out12);
+  if (!x.defer_combine)   // (else: the backward launch -- or scae_loss_tail_combine_f32)
+    hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NTC), combine_lds(O), st, a, x, ws,
+                       out12);
+  return scae_launch_status();
+}
+
+extern "C" int scae_loss_tail_combine_f32(const float *lpp, const float *posterior,
+                                          const float *caps_presence, const float *cls_w,
+                                          const float *cls_b, const int64_t *label,
+                                          const scae_loss_extras *extras, float *out12,
+                                          float *workspace, int B, int O, int M, int ncls,
+                                          int n_classes_cfg, int prior_type, int post_type,
+                                          int sparsity_on, const float *weights5,
+                                          float within_const, void *stream) {
+  TailArgs a;
+  int rc = fill_tail(a, lpp, posterior, caps_presence, cls_w, cls_b, label, B, O, M, ncls,
+                     n_classes_cfg, prior_type, post_type, sparsity_on, weights5, within_const);
+  if (rc) return rc;
+  SCAE_REQUIRE(out12 && workspace);
+  scae_loss_extras x{};
+  if (extras) x = *extras;
+  if (x.rec_sums && x.n_rec <= 0) return SCAE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NTC), combine_lds(O),
+                     (hipStream_t)stream, a, x, carve_ws(workspace, B, O, ncls), out12);
   return scae_launch_status();
 }
 
@@ -475,9 +532,11 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
   if (x.reg && !x.g_reg) return SCAE_ERR_BAD_ARG;
   if (label) SCAE_REQUIRE(g_cls_w && g_cls_b);
   const Ws ws = carve_ws(const_cast<float *>(workspace), B, O, ncls);
+  if (x.defer_combine) SCAE_REQUIRE(x.out12);
   const int cls_blocks = label ? (ncls * O + ncls + NT / 4 - 1) / (NT / 4) : 0;
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3(B + cls_blocks), dim3(NT), 6 * O * sizeof(float),
-                     (hipStream_t)stream, a, x, ws, gout12, g_lpp, g_posterior,
-                     g_caps_presence, g_cls_w, g_cls_b);
+  const size_t lds = 6 * O * sizeof(float);
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(B + cls_blocks + (x.defer_combine ? 1 : 0)), dim3(NT),
+                     lds > combine_lds(O) ? lds : combine_lds(O), (hipStream_t)stream, a, x, ws,
+                     gout12, g_lpp, g_posterior, g_caps_presence, g_cls_w, g_cls_b);
   return scae_launch_status();
 }

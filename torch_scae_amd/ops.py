@@ -540,6 +540,7 @@ class step_fusion:
         _FUSION_TARGET, _PENDING_RIDER = self.target, None
         _PENDING_K1_BWD = None     # (a backward that raised may have left one)
         globals()["_PENDING_WGRADS"] = globals()["_PENDING_CLASS_PROBS"] = None
+        globals()["_PENDING_COMBINE"] = None
         return self
 
     def __exit__(self, *exc):
@@ -1450,10 +1451,41 @@ def take_pending_class_probs():
     return pending
 
 
+_PENDING_COMBINE = None
+
+
+class _PendingCombine:
+    """The batch combine of a loss-tail forward launched with
+    ``defer_combine``: carried by the tail's backward launch, or launched on
+    its own (``scae_loss_tail_combine_f32``) when no backward follows."""
+
+    def __init__(self, tail_args, keep, loss_ptr, out_ptr, stream_ref):
+        self.tail, self.keep, self.ref = tail_args, keep, stream_ref
+        self.loss_ptr, self.out_ptr = loss_ptr, out_ptr
+
+    def launch_alone(self):
+        ex = self.keep[-1]
+        ex.defer_combine = 0
+        _lib.call("scae_loss_tail_combine_f32", *self.tail, _stream(self.ref))
+
+
+def take_pending_combine():
+    global _PENDING_COMBINE
+    pending, _PENDING_COMBINE = _PENDING_COMBINE, None
+    return pending
+
+
+def flush_pending_combine():
+    pending = take_pending_combine()
+    if pending is not None:
+        pending.launch_alone()
+
+
 def flush_pending_forward():
     pending = take_pending_class_probs()
     if pending is not None:
         pending.launch_alone()
+    flush_pending_combine()
 
 
 def class_probs_supported(O, ncls):
@@ -2468,6 +2500,14 @@ class _LossTail(torch.autograd.Function):
             ex.reg, ex.w_reg = reg.data_ptr(), float(w_reg)
         loss = torch.empty((), device=lpp.device, dtype=lpp.dtype)
         ex.loss = loss.data_ptr()
+        # The whole training scalar inside a fused step: nothing reads the
+        # scalars before the backward has run, so the batch combine (one
+        # workgroup, a dependent launch of its own) becomes a workgroup of the
+        # backward launch.  A forward no backward follows is completed by
+        # ``flush_pending_forward`` (the step's exit).
+        defer = _FUSION_TARGET is not None and rec_sums is not None and \
+            any(ctx.needs_input_grad)
+        ex.defer_combine = int(defer)
         # per-image / per-column statistics the backward kernel reads back
         ws = torch.empty(_lib.load().scae_loss_tail_workspace_floats(
             ints[0], ints[1], ints[3]), device=lpp.device, dtype=lpp.dtype)
@@ -2487,6 +2527,15 @@ class _LossTail(torch.autograd.Function):
         ctx.has = (label is not None, rec_sums is not None, reg is not None)
         ctx.call = (ints, tuple(weights), wc, float(w_reg))
         ctx.set_materialize_grads(False)
+        ctx.deferred = None
+        if defer:
+            global _PENDING_COMBINE
+            flush_pending_combine()
+            # (addresses only: ``loss`` / ``out`` are this node's outputs)
+            ctx.deferred = _PENDING_COMBINE = _PendingCombine(
+                tail, (lpp, posterior, caps_presence, cls_w, cls_b, label,
+                       rec_sums, reg, ws, w5, ex), loss.data_ptr(),
+                out.data_ptr(), lpp)
         return loss, out
 
     @staticmethod
@@ -2520,6 +2569,11 @@ class _LossTail(torch.autograd.Function):
         if g_loss is not None:
             g_loss = g_loss.contiguous()
             ex.g_loss = g_loss.data_ptr()
+        pend = ctx.deferred
+        if pend is not None and pend is _PENDING_COMBINE:
+            # the forward's combine workgroup rides in this launch
+            take_pending_combine()
+            ex.defer_combine, ex.loss, ex.out12 = 1, pend.loss_ptr, pend.out_ptr
         w5 = (ctypes.c_float * 5)(*weights)
         lab = None if label is None else ctypes.c_void_p(label.data_ptr())
         _lib.call("scae_loss_tail_bwd_f32", _p(lpp), _p(posterior), _p(cp),
