@@ -849,6 +849,8 @@ int scae_loss_tail_fwd_f32(const float *lpp, const float *posterior,
                            int B, int O, int M, int ncls, int n_classes_cfg, int prior_type,
                            int post_type, int sparsity_on, const float *weights5,
                            float within_const, void *stream);
+/* defer_combine costs B^2 2 O extra loads in the backward: worth it for small batches only */
+int scae_loss_tail_defer_preferred(int B, int O);
 int scae_loss_tail_combine_f32(const float *lpp, const float *posterior,
                                const float *caps_presence, const float *cls_w,
                                const float *cls_b, const int64_t *label,

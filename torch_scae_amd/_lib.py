@@ -250,6 +250,7 @@ SIGNATURES = {
     "scae_loss_tail_workspace_floats": [c_int] * 3,
     "scae_loss_tail_fwd_f32": [P] * 6 + [POINTER(LossExtras), P, P] + [c_int] * 8
     + [POINTER(c_float), c_float, P],
+    "scae_loss_tail_defer_preferred": [c_int] * 2,
     "scae_loss_tail_combine_f32": [P] * 6 + [POINTER(LossExtras), P, P] + [c_int] * 8
     + [POINTER(c_float), c_float, P],
     "scae_loss_tail_fwd_class_probs_f32": [P] * 6 + [POINTER(LossExtras), P, P]

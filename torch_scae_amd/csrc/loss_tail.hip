@@ -20,14 +20,13 @@
 
 namespace {
 constexpr int NTI = 64;    // tail_image_kernel: one wave per image
-#ifndef SCAE_TAIL_NT
-#define SCAE_TAIL_NT 512
-#endif
-constexpr int NTC = SCAE_TAIL_NT;  // the one combine workgroup: its batch / column sums are
-                           // chains of L2 loads, 16 waves keep four times as many in flight
-constexpr int NT = NTC;    // backward workgroups: the same shape, so that the combine
-                           // workgroup can be one of them (deferred mode) and an image's
-                           // workgroup can form the column sums exactly as it does
+// Workgroup sizes of the combine (ONE workgroup: its batch / column sums are chains of L2
+// loads, more waves keep more of them in flight) and of the backward: at small batches
+// (scae_loss_tail_defer_preferred) both run NT_SMALL threads, so that the combine can be a
+// workgroup of the backward launch and an image's workgroup can form the column sums
+// exactly as the combine does; at large batches 1024 and 256 (measured best at B = 1024).
+// (A 1024-thread form of the small-batch backward took 16 us instead of 10.)
+constexpr int NT_SMALL = 512, NTC_LARGE = 1024, NTB_LARGE = 256;
 constexpr int MAXCLS = 32;
 
 struct TailArgs {
@@ -196,8 +195,9 @@ __device__ __forceinline__ float between_term(const float *col, int O, int type,
 //      [5] post_between [6] prior_cls_xe [7] posterior_cls_xe [8] rec_ll [9] -rec_ll
 //      [10] -log_prob [11] reg
 // column sums over the batch into col[2 O] (LDS; also published to ws.col when asked): 16
-// lanes per column, each takes every 16th image.  Every caller runs NTC threads, so the
-// summation order -- and the result, bit for bit -- is the same wherever it is formed.
+// lanes per column, each takes every 16th image: the summation order -- and the result, bit
+// for bit -- does not depend on who forms it (nor on NTC).
+template <int NTC>
 __device__ __forceinline__ void column_sums(const TailArgs &a, const Ws &ws, float *col, int tid,
                                             bool publish) {
   const int B = a.B, O = a.O;
@@ -228,6 +228,7 @@ __device__ __forceinline__ void column_sums(const TailArgs &a, const Ws &ws, flo
 // out: [0] loss  [1] log_prob  [2] prior_within [3] prior_between [4] post_within
 //      [5] post_between [6] prior_cls_xe [7] posterior_cls_xe [8] rec_ll [9] -rec_ll
 //      [10] -log_prob [11] reg
+template <int NTC>
 __device__ __forceinline__ void combine_body(const TailArgs &a, const scae_loss_extras &x,
                                              const Ws &ws, float *out, float *smem) {
   const int B = a.B, O = a.O, tid = threadIdx.x;
@@ -240,7 +241,7 @@ __device__ __forceinline__ void combine_body(const TailArgs &a, const scae_loss_
   }
   if (x.rec_sums)
     for (int i = tid; i < x.n_rec; i += NTC) v[5] += x.rec_sums[i];
-  column_sums(a, ws, col, tid, true);
+  column_sums<NTC>(a, ws, col, tid, true);
   scae::block_sum<6, NTC>(v, red);  // (contains the barriers that publish col[])
   if (tid >= 64) return;
   float pb = 0.f, qb = 0.f;
@@ -258,10 +259,11 @@ __device__ __forceinline__ void combine_body(const TailArgs &a, const scae_loss_
   out[0] = loss;
   if (x.loss) x.loss[0] = loss;
 }
+template <int NTC>
 __global__ __launch_bounds__(NTC) void tail_combine_kernel(TailArgs a, scae_loss_extras x, Ws ws,
                                                           float *out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  combine_body(a, x, ws, out, smem);
+  combine_body<NTC>(a, x, ws, out, smem);
 }
 
 // d(gw * within + gb * between) / d x[b,o] for one image: x[o], col[o] in LDS
@@ -296,6 +298,7 @@ __device__ __forceinline__ void sparsity_grad(const float *x, const float *col, 
 // x.defer_combine (a training step: nothing reads the forward's scalars before the backward
 // has run): the forward left the combine workgroup out -- it is the LAST workgroup of this
 // launch instead, and the image workgroups form the column sums they need themselves.
+template <int NT>
 __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extras x, Ws ws,
                                                       const float *gout /*[12]*/, float *g_lpp,
                                                       float *g_post, float *g_cp, float *g_w,
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int B = a.B, O = a.O, M = a.M, tid = threadIdx.x;
   if (x.defer_combine && blockIdx.x + 1 == gridDim.x) {   // workgroup-uniform
-    combine_body(a, x, ws, x.out12, smem);
+    combine_body<NT>(a, x, ws, x.out12, smem);
     return;
   }
   // d(total)/d(component): the loss plus whatever flowed into the individually
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(NT) void tail_bwd_kernel(TailArgs a, scae_loss_extr
     }
     gc[o] = gm[o] = 0.f;
   }
-  if (x.defer_combine) column_sums(a, ws, col, tid, false);
+  if (x.defer_combine) column_sums<NT>(a, ws, col, tid, false);
   __syncthreads();
   if (a.sparsity_on && tid < 64) {
     const float *p = ws.part + (size_t)b * 8;
@@ -411,7 +414,17 @@ extern "C" int64_t scae_loss_tail_workspace_floats(int B, int O, int ncls) {
   return (int64_t)ws_floats(B, O, ncls);
 }
 
-static size_t combine_lds(int O) { return (2 * O + 6 * (NTC / 64)) * sizeof(float); }
+static size_t combine_lds(int O) { return (2 * O + 6 * (NTC_LARGE / 64)) * sizeof(float); }
+// the combine workgroup on its own, in the shape this batch size takes
+static void launch_combine(const TailArgs &a, const scae_loss_extras &x, const Ws &ws, float *out12,
+                           hipStream_t st) {
+  if (scae_loss_tail_defer_preferred(a.B, a.O))
+    hipLaunchKernelGGL(tail_combine_kernel<NT_SMALL>, dim3(1), dim3(NT_SMALL), combine_lds(a.O), st,
+                       a, x, ws, out12);
+  else
+    hipLaunchKernelGGL(tail_combine_kernel<NTC_LARGE>, dim3(1), dim3(NTC_LARGE), combine_lds(a.O),
+                       st, a, x, ws, out12);
+}
 
 static int fill_tail(TailArgs &a, const float *lpp, const float *posterior, const float *cp,
                      const float *cls_w, const float *cls_b, const int64_t *label, int B,
@@ -455,9 +468,15 @@ static int tail_fwd(const float *lpp, const float *posterior, const float *caps_
   hipLaunchKernelGGL(tail_image_kernel, dim3(B + n_cp), dim3(NTI), 3 * O * sizeof(float), st, a,
                      ws, cpa ? *cpa : scae_cp::Args{}, n_cp);
   if (!x.defer_combine)   // (else: the backward launch -- or scae_loss_tail_combine_f32)
-    hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NTC), combine_lds(O), st, a, x, ws,
-                       out12);
+    launch_combine(a, x, ws, out12, st);
   return scae_launch_status();
+}
+
+// With defer_combine every image workgroup of the backward sums the 2 O columns over the whole
+// batch itself: B^2 2 O loads per launch, 3 MB at B = 128 (and a dependent launch saved) but
+// 540 MB at B = 1024, where the same kernel took 288 us instead of 60 + 30.  Preferred below 8 MB.
+extern "C" int scae_loss_tail_defer_preferred(int B, int O) {
+  return B > 0 && O > 0 && (long)B * B * 2 * O * (long)sizeof(float) <= (8l << 20);
 }
 
 extern "C" int scae_loss_tail_combine_f32(const float *lpp, const float *posterior,
@@ -476,8 +495,7 @@ extern "C" int scae_loss_tail_combine_f32(const float *lpp, const float *posteri
   scae_loss_extras x{};
   if (extras) x = *extras;
   if (x.rec_sums && x.n_rec <= 0) return SCAE_ERR_BAD_ARG;
-  hipLaunchKernelGGL(tail_combine_kernel, dim3(1), dim3(NTC), combine_lds(O),
-                     (hipStream_t)stream, a, x, carve_ws(workspace, B, O, ncls), out12);
+  launch_combine(a, x, carve_ws(workspace, B, O, ncls), out12, (hipStream_t)stream);
   return scae_launch_status();
 }
 
@@ -533,10 +551,18 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
   if (label) SCAE_REQUIRE(g_cls_w && g_cls_b);
   const Ws ws = carve_ws(const_cast<float *>(workspace), B, O, ncls);
   if (x.defer_combine) SCAE_REQUIRE(x.out12);
-  const int cls_blocks = label ? (ncls * O + ncls + NT / 4 - 1) / (NT / 4) : 0;
-  const size_t lds = 6 * O * sizeof(float);
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3(B + cls_blocks + (x.defer_combine ? 1 : 0)), dim3(NT),
-                     lds > combine_lds(O) ? lds : combine_lds(O), (hipStream_t)stream, a, x, ws,
-                     gout12, g_lpp, g_posterior, g_caps_presence, g_cls_w, g_cls_b);
+  const size_t lds = 6 * O * sizeof(float) > combine_lds(O) ? 6 * O * sizeof(float) : combine_lds(O);
+#define SCAE_TAIL_BWD(NTH)                                                                       \
+  do {                                                                                           \
+    const int cls_blocks = label ? (ncls * O + ncls + NTH / 4 - 1) / (NTH / 4) : 0;              \
+    hipLaunchKernelGGL(tail_bwd_kernel<NTH>, dim3(B + cls_blocks + (x.defer_combine ? 1 : 0)),   \
+                       dim3(NTH), lds, (hipStream_t)stream, a, x, ws, gout12, g_lpp, g_posterior, \
+                       g_caps_presence, g_cls_w, g_cls_b);                                       \
+  } while (0)
+  if (x.defer_combine || scae_loss_tail_defer_preferred(B, O))
+    SCAE_TAIL_BWD(NT_SMALL);
+  else
+    SCAE_TAIL_BWD(NTB_LARGE);
+#undef SCAE_TAIL_BWD
   return scae_launch_status();
 }

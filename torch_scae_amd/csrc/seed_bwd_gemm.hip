@@ -8,9 +8,9 @@
 // workgroups at B = 128, each a 15 us dependent chain on a quarter of the CUs -- and the four
 // GEMMs are ~1.4 k short 32 x 32 split-K tiles that would fill the rest.  Here the
 // attention workgroups are the head of the grid and the GEMM tiles its tail: 15.6 + 17.3 us
-// as two launches.  Launch-uniform resources are the attention's (148 VGPRs, 47 KB of LDS
-// at N, O <= 32): the GEMM tiles (108 VGPRs, 18 KB on their own) still fit three
-// workgroups per CU.
+// as two launches.  Launch-uniform resources are the attention's (160 VGPRs, 47 KB of LDS
+// at N, O <= 32 -- the only shape merged): the GEMM tiles (108 VGPRs, 18 KB on their own)
+// still fit three workgroups per CU.
 //
 // Both device bodies come from their own files, compiled here without their kernels and
 // entry points (SCAE_DEVICE_ONLY); each sits in a namespace of its own because the two tile
@@ -72,9 +72,11 @@ int impl(const float *h, const float *q, const float *wk, const float *wv,
   rc = scae_gemm::plan_multi(p, T, descs, n);
   if (rc) return rc;
   if (T != 32) return SCAE_ERR_UNSUPPORTED;   // (large problems fill the device on their own)
+  // sets of more than 32 elements: the attention's 4-tile form holds 268 VGPRs -- one GEMM
+  // workgroup per SIMD instead of four; the two launches are faster apart
+  if (N > 32 || O > 32) return SCAE_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (N <= 32 && O <= 32) return bf16 ? launch<2, true>(a, p, st) : launch<2, false>(a, p, st);
-  return bf16 ? launch<4, true>(a, p, st) : launch<4, false>(a, p, st);
+  return bf16 ? launch<2, true>(a, p, st) : launch<2, false>(a, p, st);
 }
 }  // namespace
 

@@ -2506,7 +2506,8 @@ class _LossTail(torch.autograd.Function):
         # backward launch.  A forward no backward follows is completed by
         # ``flush_pending_forward`` (the step's exit).
         defer = _FUSION_TARGET is not None and rec_sums is not None and \
-            any(ctx.needs_input_grad)
+            any(ctx.needs_input_grad) and \
+            bool(_lib.load().scae_loss_tail_defer_preferred(B, O))
         ex.defer_combine = int(defer)
         # per-image / per-column statistics the backward kernel reads back
         ws = torch.empty(_lib.load().scae_loss_tail_workspace_floats(
