@@ -431,6 +431,14 @@ int scae_gemm_bf16(const float *A, const float *B, float *C, const float *bias,
                    int ldmask, int64_t mask_batch, int64_t asum_batch, int asum_ld, int relu,
                    void *stream);
 int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
+/* scae_conv3x3_fwd_f32 (the 32 x 64 second-generation tiles: Cin % 32 == 0, Cout % 64 == 0)
+ * with the workgroups of scae_seed_fold_fwd_f32(fold) as the tail of its grid: in a training
+ * step the parameter-only folding products hide behind an early, large launch instead of
+ * lengthening the prologue.  SCAE_ERR_UNSUPPORTED: launch the two separately. */
+int scae_conv3x3_fwd_fold_f32(const float *in, const float *wf, const float *bias, float *out,
+                              const float *post_bias, float *out_post, int B, int IH, int IW,
+                              int Cin, int Cout, int stride, const scae_seed_fold_desc *fold,
+                              void *stream);
 int scae_conv3x3_fwd_bf16(const float *in, const float *wf, const float *bias, float *out,
                           const float *post_bias, float *out_post, int B, int IH, int IW, int Cin,
                           int Cout, int stride, void *stream);

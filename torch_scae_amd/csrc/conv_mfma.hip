@@ -27,6 +27,7 @@
 #include "mfma_tile.h"
 #include "mfma_pipe.h"
 #include "conv_first_dev.h"
+#include "seed_fold_dev.h"
 
 namespace {
 using namespace scae_tile;
@@ -436,6 +437,27 @@ __global__ __launch_bounds__(pipe::NT) void conv_fwd_pipe_kernel(
     ConvGeom g) {
   __shared__ __attribute__((aligned(1024))) float smem[T::SMEM];
   fwd_pipe_tile<T>(smem, blockIdx.x, blockIdx.y, in, wf, bias, out, post_bias, out_post, g);
+}
+
+// The forward of a layer with the parameter-only folding products of the output attention
+// (seed_fold_dev.h, K2d) as the tail of its grid.  In a training step those products used to
+// ride in the prologue launch, where they were the longest part (15.5 us; the image layer
+// next to them needs 11.5): nothing needs them before the object encoder, much later.  The
+// second layer's launch -- 648 workgroups at B = 128, four per CU by LDS, 60 VGPRs -- has
+// the room: 356 more workgroups of 256 threads fit beside its tiles (38 KB of LDS each,
+// <= 128 VGPRs), and their dependent L2 round trips hide behind its MFMAs.
+constexpr int FOLD_SMEM = 38 * 256;   // floats: scae_fold::lds_bytes(256, 16) = 37.0 KiB
+template <class T>
+__global__ __launch_bounds__(pipe::NT, 4) void conv_fwd_pipe_fold_kernel(
+    const float *__restrict__ in, const float *__restrict__ wf, const float *__restrict__ bias,
+    float *__restrict__ out, const float *__restrict__ post_bias, float *__restrict__ out_post,
+    ConvGeom g, int gx, int n_conv, scae_seed_fold_desc fold, scae_fold::Plan plan) {
+  __shared__ __attribute__((aligned(1024))) float smem[T::SMEM > FOLD_SMEM ? T::SMEM : FOLD_SMEM];
+  const int blk = blockIdx.x;
+  if (blk < n_conv)   // workgroup-uniform
+    fwd_pipe_tile<T>(smem, blk % gx, blk / gx, in, wf, bias, out, post_bias, out_post, g);
+  else
+    scae_fold::forward_block_any<16>(fold, plan, blk - n_conv, smem);
 }
 
 // ---- data gradient (tap classes as in dgrad_tile) -----------------------------------
@@ -1110,6 +1132,30 @@ extern "C" int scae_conv3x3_fwd_f32(const float *in, const float *wf, const floa
   return conv_fwd_impl(in, wf, bias, out, post_bias, out_post, B, IH, IW, Cin, Cout, stride,
                        false, stream);
 }
+// scae_conv3x3_fwd_f32 carrying scae_seed_fold_fwd_f32(fold) in the same launch
+extern "C" int scae_conv3x3_fwd_fold_f32(const float *in, const float *wf, const float *bias,
+                                         float *out, const float *post_bias, float *out_post,
+                                         int B, int IH, int IW, int Cin, int Cout, int stride,
+                                         const scae_seed_fold_desc *fold, void *stream) {
+  SCAE_REQUIRE(in && wf && bias && out && fold && B > 0 && stride > 0 && IH >= 3 && IW >= 3);
+  if (Cin % pipe::BK || Cout % PipeC2::TB) return SCAE_ERR_UNSUPPORTED;
+  const scae_seed_fold_desc &a = *fold;
+  if (!(a.seeds && a.wq && a.bq && a.wk && a.bk && a.wv && a.bv && a.wo && a.bo && a.w2 && a.b2 &&
+        a.q && a.wkf && a.bkf && a.wvf && a.bvf && a.wv2e))
+    return SCAE_ERR_BAD_ARG;
+  if (!scae_seed_fold_supported(a.O, a.C, a.D) ||
+      scae_fold::lds_bytes(a.C, a.D) > FOLD_SMEM * sizeof(float))
+    return SCAE_ERR_UNSUPPORTED;
+  ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
+  const int M = B * g.OH * g.OW, gx = Cout / PipeC2::TB,
+            n_conv = gx * ((M + PipeC2::TA - 1) / PipeC2::TA);
+  const scae_fold::Plan plan = scae_fold::plan(a.C, a.D);
+  hipLaunchKernelGGL(conv_fwd_pipe_fold_kernel<PipeC2>, dim3(n_conv + plan.blocks()),
+                     dim3(pipe::NT), 0, (hipStream_t)stream, in, wf, bias, out, post_bias, out_post,
+                     g, gx, n_conv, a, plan);
+  return scae_launch_status();
+}
+
 extern "C" int scae_conv3x3_fwd_bf16(const float *in, const float *wf, const float *bias,
                                      float *out, const float *post_bias, float *out_post, int B,
                                      int IH, int IW, int Cin, int Cout, int stride,

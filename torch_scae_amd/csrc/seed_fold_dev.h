@@ -52,7 +52,9 @@ __device__ __forceinline__ void rows_block(const float *W, int C, const float *m
 // RO rows of Wo: u = Wo[rows] Wv (thread = column j of u, Wv rows read coalesced, the
 // Wo rows broadcast from LDS), then [wvf | bvf][row] = u W2e + [0 | Wo[row] bv + bo].
 // LDS: ext C x (D+1) | rows RO x C (overwritten by u) | RO bias dots | 4 x RO x C partials.
-template <int D>
+// (KT: rows of Wv = independent 16-byte loads in flight per lane; 32 on its own, 16 where the
+// block rides in a launch whose register budget is smaller)
+template <int D, int KT = 32>
 __device__ __forceinline__ void wo_block(const scae_seed_fold_desc &a, int row0, float *lds) {
   constexpr int DP = D + 1;
   const int t = threadIdx.x, C = a.C;
@@ -91,7 +93,6 @@ __device__ __forceinline__ void wo_block(const scae_seed_fold_desc &a, int row0,
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < RO; ++r) acc[m][r] = 0.f;
-    constexpr int KT = 32;   // rows of Wv (independent 16-byte loads) in flight per lane
     for (int c = w * cq; c < (w + 1) * cq; c += KT, wvp += (size_t)KT * C) {
       float4 wv[KT];
 #pragma unroll
@@ -159,7 +160,7 @@ inline size_t lds_bytes(int C, int D) {
 }
 
 // block `blk` (of plan.blocks()) of the forward folding; 256 threads
-template <int D>
+template <int D, int KT = 32>
 __device__ __forceinline__ void forward_block(const scae_seed_fold_desc &a, const Plan &pl,
                                               int blk, float *lds) {
   constexpr int DP = D + 1, R = NT / DP;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void forward_block(const scae_seed_fold_desc &a, cons
     return;
   }
   if (blk < 2 * pl.nb + pl.no) {
-    wo_block<D>(a, (blk - 2 * pl.nb) * RO, lds);
+    wo_block<D, KT>(a, (blk - 2 * pl.nb) * RO, lds);
     return;
   }
   // q[:, c] = seeds Wq[c, :]^T + bq[c]: 8 lanes per seed o, each an 8-strided
@@ -207,13 +208,14 @@ __device__ __forceinline__ void forward_block(const scae_seed_fold_desc &a, cons
 }
 
 // runtime D -> template
+template <int KT = 32>
 __device__ __forceinline__ void forward_block_any(const scae_seed_fold_desc &a, const Plan &pl,
                                                   int blk, float *lds) {
   if (a.D == 16)
-    forward_block<16>(a, pl, blk, lds);
+    forward_block<16, KT>(a, pl, blk, lds);
   else if (a.D == 8)
-    forward_block<8>(a, pl, blk, lds);
+    forward_block<8, KT>(a, pl, blk, lds);
   else
-    forward_block<32>(a, pl, blk, lds);
+    forward_block<32, KT>(a, pl, blk, lds);
 }
 }  // namespace scae_fold

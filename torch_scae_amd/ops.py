@@ -145,6 +145,11 @@ class StepPrologue:
         # last computed from, its persistent outputs (act, wfs, wds)
         self.first_inputs = self.first_outs = None
         self.noise_fresh = self.fold_fresh = self.first_fresh = False
+        # the folding products ride in the encoder's second conv launch once
+        # that launch has shown it can carry them (``_conv_stack_fwd``): the
+        # prologue then leaves them out (they were its longest part)
+        self.fold_rides_conv = False
+        self.fold_conv_ok = None       # False: that launch cannot carry them
 
     def _first_desc(self, image):
         """scae_first_layer_desc of the registered image layer over ``image``."""
@@ -180,7 +185,8 @@ class StepPrologue:
         _need_hip(ref)
         P = ctypes.c_void_p
         desc = fdesc = None
-        if self.fold_outs is not None:
+        fold_here = self.fold_outs is not None and not self.fold_rides_conv
+        if fold_here:
             desc = ctypes.byref(_fold_desc(self.fold_inputs, self.fold_outs,
                                            *self.fold_dims))
         if first:
@@ -195,7 +201,7 @@ class StepPrologue:
                   _p(self.noise), n_noise, _p(self.noise_state), desc, fdesc,
                   _stream(ref))
         self.noise_fresh = self.noise is not None
-        self.fold_fresh = self.fold_outs is not None
+        self.fold_fresh = fold_here
         self.first_fresh = first
 
 
@@ -1055,10 +1061,28 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
         out = new(B, (ih - 3) // s + 1, (iw - 3) // s + 1, co)
         if l == L - 1 and post_bias is not None:
             x_post = torch.empty_like(out)
-        _lib.call(_prec("scae_conv3x3_fwd_f32"), _p(act), _p(wfs[l - 1]),
-                  _p(biases[l]), _p(out), _p(post_bias if x_post is not None
-                                             else None), _p(x_post),
-                  B, ih, iw, ci, co, s, st)
+        conv = (_p(act), _p(wfs[l - 1]), _p(biases[l]), _p(out),
+                _p(post_bias if x_post is not None else None), _p(x_post), B,
+                ih, iw, ci, co, s)
+        carried = False
+        if l == 1 and pro is not None and pro.fold_outs is not None:
+            # a training step's folding products ride in this launch (the
+            # largest early one); the prologue leaves them out from then on
+            if _MFMA_BF16 or pro.fold_conv_ok is False:
+                pro.fold_rides_conv = False
+            elif pro.fold_fresh:
+                pro.fold_rides_conv = True    # (from the next prologue launch)
+            else:
+                rc = _lib.load().scae_conv3x3_fwd_fold_f32(
+                    *conv, ctypes.byref(_fold_desc(
+                        pro.fold_inputs, pro.fold_outs, *pro.fold_dims)), st)
+                if rc == _lib.ERR_UNSUPPORTED:
+                    pro.fold_conv_ok = pro.fold_rides_conv = False
+                else:
+                    _lib.check(rc, "scae_conv3x3_fwd_fold_f32")
+                    carried = pro.fold_fresh = pro.fold_rides_conv = True
+        if not carried:
+            _lib.call(_prec("scae_conv3x3_fwd_f32"), *conv, st)
         acts.append(out)
         act = out
     return acts, wds, x_post
