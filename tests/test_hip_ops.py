@@ -1238,6 +1238,47 @@ def test_seed_fold_vs_fp64(O, C, D):
     assert_close(hip_in2[2].grad, torch.full((C,), float(O)), what="d_bq")
 
 
+def test_conv_layer_carrying_the_folding_products_equals_separate_launches():
+    """scae_conv3x3_fwd_fold_f32: the encoder's second conv layer with the
+    output attention's folding products as the tail of its grid, against
+    scae_conv3x3_fwd_f32 + scae_seed_fold_fwd_f32 (conv output bit for bit;
+    the products to round-off: the carried form keeps 16 instead of 32 loads in
+    flight, same sums in the same order)."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(21)
+    B, ih, iw, ci, co, s = 16, 19, 19, 128, 128, 2
+    O, C, D = 24, 256, 16
+    act = torch.rand(B, ih, iw, ci, generator=g).cuda()
+    wf = (torch.randn(co, 9, ci, generator=g) * .03).cuda()
+    bias = torch.randn(co, generator=g).cuda()
+    shapes = [(O, C), (C, C), (C,), (C, C), (C,), (C, C), (C,), (C, C), (C,),
+              (C, D), (C,)]
+    vals = [(torch.randn(*sh, generator=g) / sh[-1] ** .5).cuda() for sh in shapes]
+    oh = (ih - 3) // s + 1
+    st = torch.cuda.current_stream().cuda_stream
+    new = lambda *shape: torch.empty(*shape, device="cuda")
+    res = []
+    for carried in (False, True):
+        out = new(B, oh, oh, co)
+        fold = (new(O, C), new(C, D), new(C), new(C, D), new(C), new(C, D + 1),
+                new(C, C))
+        desc = ops._fold_desc(vals, fold, O, C, D)
+        conv = (ops._p(act), ops._p(wf), ops._p(bias), ops._p(out), None, None, B,
+                ih, iw, ci, co, s)
+        if carried:
+            _lib.call("scae_conv3x3_fwd_fold_f32", *conv, ctypes.byref(desc), st)
+        else:
+            _lib.call("scae_conv3x3_fwd_f32", *conv, st)
+            _lib.call("scae_seed_fold_fwd_f32", ctypes.byref(desc), st)
+        torch.cuda.synchronize()
+        res.append((out, *fold))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b, what in zip(res[0][1:], res[1][1:],
+                          ("q", "wkf", "bkf", "wvf", "bvf", "wv2e", "wowv")):
+        assert_close(a, b, rtol=1e-5, atol=1e-6, what=what)
+
+
 # --------------------------------------------------------------------------
 # K7 batched MFMA GEMM: all operand layouts, ragged shapes, epilogues
 # --------------------------------------------------------------------------
