@@ -506,6 +506,15 @@ int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const float *gate
 int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, const float *in, float *din,
                               float *partial, int B, int IH, int IW, int Cin, int Cout,
                               int stride, void *stream);
+/* scae_conv3x3_bwd_pair_f32 with the workgroups of scae_seed_fold_bwd_f32(fold, fold_grads) as
+ * the head of its grid: the folding products' backward writes parameter gradients only, so in
+ * a training step it may wait for this launch (256-thread workgroups, tens of microseconds
+ * of MFMA tiles to hide behind).  Same results, bit for bit, as the launch of its own.
+ * SCAE_ERR_UNSUPPORTED (folding width != 256, another tile form of the pair): launch both. */
+int scae_conv3x3_bwd_pair_fold_f32(const float *dpre, const float *wd, const float *in,
+                                   float *din, float *partial, int B, int IH, int IW, int Cin,
+                                   int Cout, int stride, const scae_seed_fold_desc *fold,
+                                   const scae_seed_fold_grads *fold_grads, void *stream);
 int scae_conv3x3_wgrad_splits(int B, int OH, int OW, int Cin, int Cout);
 int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float *partial, float *dw,
                            float *db, int B, int IH, int IW, int Cin, int Cout, int stride,

@@ -29,6 +29,13 @@
 #include "conv_first_dev.h"
 #include "seed_fold_dev.h"
 
+// (device code of the folding products' backward, for conv_bwd_pair_mixed_fold_kernel)
+#define SCAE_DEVICE_ONLY
+namespace scae_sf {
+#include "seed_fold.hip"
+}
+#undef SCAE_DEVICE_ONLY
+
 namespace {
 using namespace scae_tile;
 
@@ -695,6 +702,39 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_kernel(
   }
 }
 
+// The same launch with the backward of the output attention's folding products (seed_fold.hip,
+// K2d) as the HEAD of its grid.  That kernel writes parameter gradients only: in a training
+// step its launch waits (ops._PendingFoldBackward) for this one, the next with 256-thread
+// workgroups and time to spare -- 320 short latency-bound workgroups (the canonical 16 K
+// slices walked four per wave: the same bits as the 1024-thread launch) beside 32-75 us of
+// MFMA tiles, instead of 9 us of their own on the step's dependent chain.
+struct FoldRider {
+  int n;   // rider workgroups (blocks [0, n))
+  scae_seed_fold_desc a;
+  scae_seed_fold_grads g;
+  scae_sf::BwdPlan pl;
+};
+template <int DMODE, class TW>
+__global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_fold_kernel(
+    const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
+    float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
+    ConvGeom g, DgradPlan pl, int splits, PairGrid pg, FoldRider fr) {
+  constexpr int SM = Tile<DMODE>::SMEM > TW::SMEM ? Tile<DMODE>::SMEM : TW::SMEM;
+  static_assert(SM * sizeof(float) >= 24 * 1024, "the rider's partial tiles + row scratch");
+  __shared__ __attribute__((aligned(1024))) float smem[SM];
+  if ((int)blockIdx.x < fr.n) {   // workgroup-uniform; C = 256 threads, one part
+    scae_sf::fold_bwd_body<4, 4>(fr.a, fr.g, fr.pl, smem, blockIdx.x, threadIdx.x, 0, 1);
+    return;
+  }
+  const int bid = (int)blockIdx.x - fr.n;
+  if (bid < pg.nd) {
+    dgrad_tile<DMODE>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
+  } else {
+    const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
+    wgrad_pipe_tile<TW>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
+  }
+}
+
 // ---- small helpers ---------------------------------------------------------------
 // W[co][ci][3][3] -> Wf[co][tap][ci], Wd[ci][tap][co]
 __global__ void relayout_weights_kernel(const float *__restrict__ w, float *__restrict__ wf,
@@ -1255,7 +1295,8 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
 
 static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *in, float *din,
                               float *partial, int B, int IH, int IW, int Cin, int Cout,
-                              int stride, bool bf16, void *stream) {
+                              int stride, bool bf16, void *stream,
+                              const FoldRider *rider = nullptr) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, true);
   if (rc) return rc;
@@ -1264,6 +1305,10 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
   bf16 = bf16 && conv_bf16_shape((long)B * IH * IW, Cin, Cout);
   const DgradLaunch d = plan_dgrad(g, true, bf16);
   const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
+  if (rider) {   // only the mixed form below carries one
+    const char *pe = getenv("SCAE_K8_PAIR");
+    if (bf16 || d.cfg >= 0 || (pe && atoi(pe) < 0)) return SCAE_ERR_UNSUPPORTED;
+  }
   if (bf16) {   // both gradients on bf16 operands, 128 x 128 tiles
     const PairGrid bg{d.gx * d.ny, d.gx, Cin / 128, Cout / 128};
     hipLaunchKernelGGL((conv_bwd_pair_kernel<3, 3>), dim3(bg.nd + bg.wx * bg.wy * 9 * p.splits),
@@ -1295,6 +1340,17 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
 #define SCAE_PAIR_MIXED(DM)                                                                  \
   hipLaunchKernelGGL((conv_bwd_pair_mixed_kernel<DM, PipeW>), mgrid, dim3(NT), 0, st, dpre, wd, \
                      in, din, in, partial, g, d.pl, p.splits, mg)
+    if (rider) {
+      const dim3 rgrid(mgrid.x + rider->n);
+#define SCAE_PAIR_MIXED_FOLD(DM)                                                              \
+  hipLaunchKernelGGL((conv_bwd_pair_mixed_fold_kernel<DM, PipeW>), rgrid, dim3(NT), 0, st, dpre, \
+                     wd, in, din, in, partial, g, d.pl, p.splits, mg, *rider)
+      if (d.mode == 0) SCAE_PAIR_MIXED_FOLD(0);
+      else if (d.mode == 2) SCAE_PAIR_MIXED_FOLD(2);
+      else SCAE_PAIR_MIXED_FOLD(1);
+#undef SCAE_PAIR_MIXED_FOLD
+      return scae_launch_status();
+    }
     if (d.mode == 0) SCAE_PAIR_MIXED(0);
     else if (d.mode == 2) SCAE_PAIR_MIXED(2);
     else SCAE_PAIR_MIXED(1);
@@ -1320,6 +1376,30 @@ extern "C" int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, con
                                          int Cin, int Cout, int stride, void *stream) {
   return conv_bwd_pair_impl(dpre, wd, in, din, partial, B, IH, IW, Cin, Cout, stride, false,
                             stream);
+}
+// scae_conv3x3_bwd_pair_f32 carrying scae_seed_fold_bwd_f32(fold, fold_grads) in the same
+// launch (C = 256 folding width, the mixed tile form of the pair): else SCAE_ERR_UNSUPPORTED
+extern "C" int scae_conv3x3_bwd_pair_fold_f32(const float *dpre, const float *wd, const float *in,
+                                              float *din, float *partial, int B, int IH, int IW,
+                                              int Cin, int Cout, int stride,
+                                              const scae_seed_fold_desc *fold,
+                                              const scae_seed_fold_grads *fold_grads,
+                                              void *stream) {
+  int rc = scae_sf::check(fold);
+  if (rc) return rc;
+  rc = scae_sf::check_grads(fold_grads);
+  if (rc) return rc;
+  SCAE_REQUIRE(fold->wowv);
+  if (fold->C != NT) return SCAE_ERR_UNSUPPORTED;   // a row workgroup = one thread per column
+  FoldRider fr;
+  fr.a = *fold, fr.g = *fold_grads;
+  int parts;
+  size_t lds;
+  scae_sf::bwd_shape(fold, fr.pl, parts, lds);
+  if (parts != 4 || lds > 24 * 1024) return SCAE_ERR_UNSUPPORTED;
+  fr.n = fr.pl.ncol + fold->C;
+  return conv_bwd_pair_impl(dpre, wd, in, din, partial, B, IH, IW, Cin, Cout, stride, false,
+                            stream, &fr);
 }
 extern "C" int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *in,
                                           float *din, float *partial, int B, int IH, int IW,

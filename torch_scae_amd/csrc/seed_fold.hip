@@ -78,32 +78,41 @@ struct BwdPlan {
   int nt_w2, nt_seed;   // 16-output tiles: ceil((D+1) / 16), ceil(O / 16)
   int ncol;        // column workgroups (tiles)
 };
-template <int STEPS>   // 4-k steps per wave: (C / waves) / 4 = 16 / parts
-__global__ void fold_bwd_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g, BwdPlan pl) {
-  extern __shared__ float lds[];
-  const int C = a.C, D = a.D, DP = D + 1, j = threadIdx.x;
-  if ((int)blockIdx.x < pl.ncol) {
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nw = (blockDim.x * blockDim.y) >> 6;
+// Workgroup `blk` as thread (tx, ty) of a (C, parts) block.  STEPS = 4-k steps per K slice;
+// the K slices (C / (4 STEPS) of them, one per wave of the (C, 16 / STEPS)-thread launch) are
+// walked VW at a time by each wave of a smaller block (conv_mfma.hip runs these workgroups
+// as 256-thread riders of a convolution launch: parts = 1, VW = 4 at C = 256): the same
+// partial tiles meet in the same order, so the result does not depend on the block shape.
+template <int STEPS, int VW = 1>
+__device__ __forceinline__ void fold_bwd_body(const scae_seed_fold_desc &a,
+                                              const scae_seed_fold_grads &g, const BwdPlan &pl,
+                                              float *lds, int blk, int tx, int ty, int parts) {
+  const int C = a.C, D = a.D, DP = D + 1, j = tx;
+  if (blk < pl.ncol) {
+    const int tid = ty * C + tx, nw = VW * ((C * parts) >> 6);
     const int wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int kb = wave * 4 * STEPS;
-    int tile = blockIdx.x;
+    int tile = blk;
     const bool w2 = tile < pl.jt * pl.nt_w2;   // workgroup-uniform
     if (!w2) tile -= pl.jt * pl.nt_w2;
     const int j0 = (tile % pl.jt) * 16, n0 = (tile / pl.jt) * 16, nout = w2 ? DP : a.O;
     const int n = min(n0 + r, nout - 1);   // lanes past the last output repeat it (dropped below)
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (w2) {
-      mfma_cols<STEPS>(acc, a.wk, C, kb, j0, n, r, q,
-                       [&](int c, int d) { return ext_ptr(g.g_wkf, g.g_bkf, D, c, d); });
-      mfma_cols<STEPS>(acc, a.wowv, C, kb, j0, n, r, q,
-                       [&](int c, int d) { return ext_ptr(g.g_wvf, g.g_bvf, D, c, d); });
-    } else {
-      mfma_cols<STEPS>(acc, a.wq, C, kb, j0, n, r, q,
-                       [&](int c, int o) { return g.g_q + (size_t)o * C + c; });
-    }
-    // partial tiles [wave][row 4 q + e][col r] meet
 #pragma unroll
-    for (int e = 0; e < 4; ++e) lds[(wave * 16 + 4 * q + e) * 16 + r] = acc[e];
+    for (int v = 0; v < VW; ++v) {
+      const int slice = wave * VW + v, kb = slice * 4 * STEPS;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (w2) {
+        mfma_cols<STEPS>(acc, a.wk, C, kb, j0, n, r, q,
+                         [&](int c, int d) { return ext_ptr(g.g_wkf, g.g_bkf, D, c, d); });
+        mfma_cols<STEPS>(acc, a.wowv, C, kb, j0, n, r, q,
+                         [&](int c, int d) { return ext_ptr(g.g_wvf, g.g_bvf, D, c, d); });
+      } else {
+        mfma_cols<STEPS>(acc, a.wq, C, kb, j0, n, r, q,
+                         [&](int c, int o) { return g.g_q + (size_t)o * C + c; });
+      }
+      // partial tiles [slice][row 4 q + e][col r] meet
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[(slice * 16 + 4 * q + e) * 16 + r] = acc[e];
+    }
     __syncthreads();
     if (tid < 256) {
       const int row = tid >> 4, col = tid & 15;   // row: column jj of W, col: output
@@ -121,17 +130,17 @@ __global__ void fold_bwd_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g, B
     }
     return;
   }
-  const int c = blockIdx.x - pl.ncol;
+  const int c = blk - pl.ncol;
   float *vec = lds + 64 * 16;   // D + 1 floats behind the wave partials
   {  // gv2e[c, d] = sum_i Wo[i][c] [g_wvf|g_bvf][i, d]: thread (i = j, part) takes d = part, part + parts, ..
     const float wo = a.wo[(size_t)j * C + c];
     const int nw = C >> 6, wave = j >> 6;
-    for (int d = threadIdx.y; d < DP; d += blockDim.y) {
+    for (int d = ty; d < DP; d += parts) {
       const float v = scae::wave_sum(wo * ext_at(g.g_wvf, g.g_bvf, D, j, d));
       if ((j & 63) == 0) lds[d * nw + wave] = v;
     }
     __syncthreads();
-    const int t = threadIdx.y * C + j;
+    const int t = ty * C + j;
     if (t < DP) {
       float v = 0.f;
       for (int w = 0; w < nw; ++w) v += lds[t * nw + w];
@@ -140,7 +149,7 @@ __global__ void fold_bwd_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g, B
     __syncthreads();
   }
   const size_t e = (size_t)c * C + j;
-  for (int which = threadIdx.y; which < 4; which += blockDim.y) {
+  for (int which = ty; which < 4; which += parts) {
     float acc = 0.f;
     if (which == 0) {
       float sq = 0.f;
@@ -170,6 +179,27 @@ __global__ void fold_bwd_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g, B
     }
   }
 }
+template <int STEPS>   // 4-k steps per wave: (C / waves) / 4 = 16 / parts
+__global__ void fold_bwd_kernel(scae_seed_fold_desc a, scae_seed_fold_grads g, BwdPlan pl) {
+  extern __shared__ float lds[];
+  fold_bwd_body<STEPS>(a, g, pl, lds, blockIdx.x, threadIdx.x, threadIdx.y, blockDim.y);
+}
+// (C, parts) block shape, its dynamic LDS and the plan of a backward launch
+inline void bwd_shape(const scae_seed_fold_desc *desc, BwdPlan &pl, int &parts, size_t &lds) {
+  const int DP = desc->D + 1, C = desc->C;
+  parts = 1024 / C >= 4 ? 4 : (1024 / C >= 2 ? 2 : 1);
+  pl = BwdPlan{C / 16, (DP + 15) / 16, (desc->O + 15) / 16, 0};
+  pl.ncol = pl.jt * (pl.nt_w2 + pl.nt_seed);
+  // column jobs: waves x 16 x 16 partial tiles; row jobs: wave partials + a gv2e row
+  lds = (size_t)(C * parts / 64) * 256 * sizeof(float) + 8192;
+}
+inline int check_grads(const scae_seed_fold_grads *g) {
+  return g && g->g_q && g->g_wkf && g->g_bkf && g->g_wvf && g->g_bvf && g->d_seeds && g->d_wq &&
+                 g->d_bq && g->d_wk && g->d_bk && g->d_wv && g->d_bv && g->d_wo && g->d_bo &&
+                 g->d_w2 && g->d_b2
+             ? SCAE_OK
+             : SCAE_ERR_BAD_ARG;
+}
 
 int check(const scae_seed_fold_desc *a) {
   if (!a) return SCAE_ERR_BAD_ARG;
@@ -182,6 +212,7 @@ int check(const scae_seed_fold_desc *a) {
 }
 }  // namespace
 
+#ifndef SCAE_DEVICE_ONLY   // (conv_mfma.hip includes this file for its device code)
 extern "C" int scae_seed_fold_supported(int O, int C, int D) {
   if (!(O > 0 && O <= 64 && C >= 64 && C % 64 == 0 && C <= 1024 && (D == 8 || D == 16 || D == 32)))
     return 0;
@@ -216,17 +247,14 @@ extern "C" int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc,
   int rc = check(desc);
   if (rc) return rc;
   const scae_seed_fold_grads *g = grads;
-  SCAE_REQUIRE(g && g->g_q && g->g_wkf && g->g_bkf && g->g_wvf && g->g_bvf && g->d_seeds &&
-               g->d_wq && g->d_bq && g->d_wk && g->d_bk && g->d_wv && g->d_bv && g->d_wo &&
-               g->d_bo && g->d_w2 && g->d_b2);
+  rc = check_grads(g);
+  if (rc) return rc;
   SCAE_REQUIRE(desc->wowv);
-  const int DP = desc->D + 1, C = desc->C;
-  const int parts = 1024 / C >= 4 ? 4 : (1024 / C >= 2 ? 2 : 1);
-  BwdPlan pl{C / 16, (DP + 15) / 16, (desc->O + 15) / 16, 0};
-  pl.ncol = pl.jt * (pl.nt_w2 + pl.nt_seed);
-  // column jobs: waves x 16 x 16 partial tiles; row jobs: wave partials + a gv2e row
-  const size_t lds = (size_t)(C * parts / 64) * 256 * sizeof(float) + 8192;
-  const dim3 grid(pl.ncol + C), block(C, parts);
+  BwdPlan pl;
+  int parts;
+  size_t lds;
+  bwd_shape(desc, pl, parts, lds);
+  const dim3 grid(pl.ncol + desc->C), block(desc->C, parts);
   hipStream_t st = (hipStream_t)stream;
   if (parts == 4)
     hipLaunchKernelGGL(fold_bwd_kernel<4>, grid, block, lds, st, *desc, *g, pl);
@@ -236,3 +264,4 @@ extern "C" int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc,
     hipLaunchKernelGGL(fold_bwd_kernel<16>, grid, block, lds, st, *desc, *g, pl);
   return scae_launch_status();
 }
+#endif  // SCAE_DEVICE_ONLY

@@ -546,7 +546,7 @@ class step_fusion:
         _FUSION_TARGET, _PENDING_RIDER = self.target, None
         _PENDING_K1_BWD = None     # (a backward that raised may have left one)
         globals()["_PENDING_WGRADS"] = globals()["_PENDING_CLASS_PROBS"] = None
-        globals()["_PENDING_COMBINE"] = None
+        globals()["_PENDING_COMBINE"] = globals()["_PENDING_FOLD"] = None
         return self
 
     def __exit__(self, *exc):
@@ -643,6 +643,29 @@ class _PendingWeightGemms:
         _lib.call("scae_gemm_multi_f32", self.descs, self.n, _stream(self.ref))
 
 
+_PENDING_FOLD = None
+
+
+class _PendingFoldBackward:
+    """The backward of the output attention's folding products, parked: it
+    writes parameter gradients only, and waits for the part encoder's first
+    conv backward launch (``_conv_stack_bwd``) -- 256-thread workgroups and
+    tens of microseconds of matrix tiles to hide its dependent chain behind."""
+
+    def __init__(self, desc, grads, keep, stream_ref):
+        self.desc, self.grads, self.keep, self.ref = desc, grads, keep, stream_ref
+
+    def launch_alone(self):
+        _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(self.desc),
+                  ctypes.byref(self.grads), _stream(self.ref))
+
+
+def take_pending_fold():
+    global _PENDING_FOLD
+    pending, _PENDING_FOLD = _PENDING_FOLD, None
+    return pending
+
+
 def take_pending_weight_gemms():
     global _PENDING_WGRADS
     pending, _PENDING_WGRADS = _PENDING_WGRADS, None
@@ -657,9 +680,9 @@ def flush_pending_backward():
     if _PENDING_K1_BWD is not None:
         pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
         pending.launch_alone()
-    pending = take_pending_weight_gemms()
-    if pending is not None:
-        pending.launch_alone()
+    for pending in (take_pending_weight_gemms(), take_pending_fold()):
+        if pending is not None:
+            pending.launch_alone()
 
 
 def withdraw_log_prob_rider():
@@ -981,8 +1004,18 @@ class _SeedFold(torch.autograd.Function):
             setattr(g, name, t.data_ptr())
         for name, t in zip(_FOLD_INPUTS, grads):
             setattr(g, "d_" + name, t.data_ptr())
-        _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(desc), ctypes.byref(g),
-                  _stream(seeds))
+        if _FUSION_TARGET is not None and _DEFERRED is not None and \
+                all(_in_slot(t) for t in grads):
+            # parameter gradients only: the launch waits for a carrier
+            global _PENDING_FOLD
+            stale = take_pending_fold()
+            if stale is not None:
+                stale.launch_alone()
+            _PENDING_FOLD = _PendingFoldBackward(
+                desc, g, (inputs, outs, incoming), seeds)
+        else:
+            _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(desc),
+                      ctypes.byref(g), _stream(seeds))
         return tuple(grads)
 
 
@@ -1109,8 +1142,23 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
         din = new(B, ih, iw, ci)
         # weight-gradient partials and the (ReLU-gated) data gradient both
         # only wait for dpre: one launch
-        _lib.call(_prec("scae_conv3x3_bwd_pair_f32"), _p(dpre), _p(wds[l - 1]),
-                  _p(xin), _p(din), _p(partial), B, ih, iw, ci, co, s, st)
+        pair = (_p(dpre), _p(wds[l - 1]), _p(xin), _p(din), _p(partial), B, ih,
+                iw, ci, co, s)
+        # (the stack's largest launch, the second layer's, is the carrier)
+        parked, carried = (None if _MFMA_BF16 or l != 1
+                           else take_pending_fold()), False
+        if parked is not None:
+            # the folding products' backward as the head of this launch
+            rc = _lib.load().scae_conv3x3_bwd_pair_fold_f32(
+                *pair, ctypes.byref(parked.desc), ctypes.byref(parked.grads),
+                st)
+            if rc == _lib.ERR_UNSUPPORTED:
+                parked.launch_alone()
+            else:
+                _lib.check(rc, "scae_conv3x3_bwd_pair_fold_f32")
+                carried = True
+        if not carried:
+            _lib.call(_prec("scae_conv3x3_bwd_pair_f32"), *pair, st)
         pending.append((partial, gw, gb, co, ci, splits))
         gws[l], gbs[l] = gw, gb
         dpre = din
