@@ -510,7 +510,15 @@ int scae_conv3x3_bwd_pair_f32(const float *dpre, const float *wd, const float *i
  * the head of its grid: the folding products' backward writes parameter gradients only, so in
  * a training step it may wait for this launch (256-thread workgroups, tens of microseconds
  * of MFMA tiles to hide behind).  Same results, bit for bit, as the launch of its own.
+ * scae_conv3x3_bwd_pair_reduce_f32: the same for scae_seed_attention_mfma_reduce_f32
+ * (arguments rpartial .. C), whose outputs only the folding products' backward reads.
  * SCAE_ERR_UNSUPPORTED (folding width != 256, another tile form of the pair): launch both. */
+int scae_conv3x3_bwd_pair_reduce_f32(const float *dpre, const float *wd, const float *in,
+                                     float *din, float *partial, int B, int IH, int IW, int Cin,
+                                     int Cout, int stride, const float *rpartial, int rows,
+                                     const float *q, const float *wk, float *gq, float *gwk,
+                                     float *gbk, float *gwv, float *gbv, int O, int C,
+                                     void *stream);
 int scae_conv3x3_bwd_pair_fold_f32(const float *dpre, const float *wd, const float *in,
                                    float *din, float *partial, int B, int IH, int IW, int Cin,
                                    int Cout, int stride, const scae_seed_fold_desc *fold,

@@ -211,6 +211,8 @@ SIGNATURES = {
     "scae_conv3x3_fwd_bf16": [P] * 6 + [c_int] * 6 + [P],
     "scae_conv3x3_dgrad_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_bwd_pair_f32": [P] * 5 + [c_int] * 6 + [P],
+    "scae_conv3x3_bwd_pair_reduce_f32": [P] * 5 + [c_int] * 6 + [P, c_int] + [P] * 7
+    + [c_int] * 2 + [P],
     "scae_conv3x3_bwd_pair_fold_f32": [P] * 5 + [c_int] * 6
     + [POINTER(SeedFoldDesc), POINTER(SeedFoldGrads), P],
     "scae_conv3x3_bwd_pair_bf16": [P] * 5 + [c_int] * 6 + [P],

@@ -29,10 +29,18 @@
 #include "conv_first_dev.h"
 #include "seed_fold_dev.h"
 
-// (device code of the folding products' backward, for conv_bwd_pair_mixed_fold_kernel)
+#include <algorithm>
+
+#include "wave_mfma.h"
+
+// (device code of the riders of conv_bwd_pair_mixed_rider_kernel: the folding products'
+// backward and the output attention's partial-row reduction)
 #define SCAE_DEVICE_ONLY
 namespace scae_sf {
 #include "seed_fold.hip"
+}
+namespace scae_saw {
+#include "seed_attention_wave.hip"
 }
 #undef SCAE_DEVICE_ONLY
 
@@ -702,31 +710,40 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_kernel(
   }
 }
 
-// The same launch with the backward of the output attention's folding products (seed_fold.hip,
-// K2d) as the HEAD of its grid.  That kernel writes parameter gradients only: in a training
-// step its launch waits (ops._PendingFoldBackward) for this one, the next with 256-thread
-// workgroups and time to spare -- 320 short latency-bound workgroups (the canonical 16 K
-// slices walked four per wave: the same bits as the 1024-thread launch) beside 32-75 us of
-// MFMA tiles, instead of 9 us of their own on the step's dependent chain.
-struct FoldRider {
-  int n;   // rider workgroups (blocks [0, n))
+// The same launch with a rider as the HEAD of its grid: a kernel of the object encoder's
+// backward that writes parameter gradients only -- the output attention's partial-row
+// reduction (seed_attention_wave.hip, saw_reduce_body) or the backward of its folding
+// products (seed_fold.hip, fold_bwd_body; it reads what the reduction wrote, so the two ride
+// in consecutive launches).  In a training step those launches wait (ops._PendingReduce /
+// _PendingFoldBackward) for the part encoder's convolution backward, the next launches with
+// 256-thread workgroups and time to spare: ~100 / 320 short latency-bound workgroups
+// (canonical row parts / K slices walked four per thread / wave: the same bits as their
+// 1024-thread launches) beside 48 / 75 us of MFMA tiles, instead of 8.5 + 9 us of their own on
+// the step's dependent chain.
+struct PairRider {
+  int n;      // rider workgroups (blocks [0, n))
+  int kind;   // 1: reduce, 2: fold
+  scae_saw::ReduceArgs red;
   scae_seed_fold_desc a;
   scae_seed_fold_grads g;
   scae_sf::BwdPlan pl;
 };
 template <int DMODE, class TW>
-__global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_fold_kernel(
+__global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_rider_kernel(
     const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
     float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
-    ConvGeom g, DgradPlan pl, int splits, PairGrid pg, FoldRider fr) {
+    ConvGeom g, DgradPlan pl, int splits, PairGrid pg, PairRider r) {
   constexpr int SM = Tile<DMODE>::SMEM > TW::SMEM ? Tile<DMODE>::SMEM : TW::SMEM;
-  static_assert(SM * sizeof(float) >= 24 * 1024, "the rider's partial tiles + row scratch");
+  static_assert(SM * sizeof(float) >= 24 * 1024, "the riders' LDS");
   __shared__ __attribute__((aligned(1024))) float smem[SM];
-  if ((int)blockIdx.x < fr.n) {   // workgroup-uniform; C = 256 threads, one part
-    scae_sf::fold_bwd_body<4, 4>(fr.a, fr.g, fr.pl, smem, blockIdx.x, threadIdx.x, 0, 1);
+  if ((int)blockIdx.x < r.n) {   // workgroup-uniform
+    if (r.kind == 1)
+      scae_saw::saw_reduce_body<NT>(r.red, smem, blockIdx.x);
+    else   // C = 256 threads, one part
+      scae_sf::fold_bwd_body<4, 4>(r.a, r.g, r.pl, smem, blockIdx.x, threadIdx.x, 0, 1);
     return;
   }
-  const int bid = (int)blockIdx.x - fr.n;
+  const int bid = (int)blockIdx.x - r.n;
   if (bid < pg.nd) {
     dgrad_tile<DMODE>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
   } else {
@@ -1296,7 +1313,7 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
 static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *in, float *din,
                               float *partial, int B, int IH, int IW, int Cin, int Cout,
                               int stride, bool bf16, void *stream,
-                              const FoldRider *rider = nullptr) {
+                              const PairRider *rider = nullptr) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, true);
   if (rc) return rc;
@@ -1343,7 +1360,7 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
     if (rider) {
       const dim3 rgrid(mgrid.x + rider->n);
 #define SCAE_PAIR_MIXED_FOLD(DM)                                                              \
-  hipLaunchKernelGGL((conv_bwd_pair_mixed_fold_kernel<DM, PipeW>), rgrid, dim3(NT), 0, st, dpre, \
+  hipLaunchKernelGGL((conv_bwd_pair_mixed_rider_kernel<DM, PipeW>), rgrid, dim3(NT), 0, st, dpre, \
                      wd, in, din, in, partial, g, d.pl, p.splits, mg, *rider)
       if (d.mode == 0) SCAE_PAIR_MIXED_FOLD(0);
       else if (d.mode == 2) SCAE_PAIR_MIXED_FOLD(2);
@@ -1391,15 +1408,31 @@ extern "C" int scae_conv3x3_bwd_pair_fold_f32(const float *dpre, const float *wd
   if (rc) return rc;
   SCAE_REQUIRE(fold->wowv);
   if (fold->C != NT) return SCAE_ERR_UNSUPPORTED;   // a row workgroup = one thread per column
-  FoldRider fr;
-  fr.a = *fold, fr.g = *fold_grads;
+  PairRider r{};
+  r.kind = 2, r.a = *fold, r.g = *fold_grads;
   int parts;
   size_t lds;
-  scae_sf::bwd_shape(fold, fr.pl, parts, lds);
+  scae_sf::bwd_shape(fold, r.pl, parts, lds);
   if (parts != 4 || lds > 24 * 1024) return SCAE_ERR_UNSUPPORTED;
-  fr.n = fr.pl.ncol + fold->C;
+  r.n = r.pl.ncol + fold->C;
   return conv_bwd_pair_impl(dpre, wd, in, din, partial, B, IH, IW, Cin, Cout, stride, false,
-                            stream, &fr);
+                            stream, &r);
+}
+// ... carrying scae_seed_attention_mfma_reduce_f32(rpartial .. C) instead
+extern "C" int scae_conv3x3_bwd_pair_reduce_f32(const float *dpre, const float *wd,
+                                                const float *in, float *din, float *partial,
+                                                int B, int IH, int IW, int Cin, int Cout,
+                                                int stride, const float *rpartial, int rows,
+                                                const float *q, const float *wk, float *gq,
+                                                float *gwk, float *gbk, float *gwv, float *gbv,
+                                                int O, int C, void *stream) {
+  PairRider r{};
+  r.kind = 1;
+  int rc = scae_saw::reduce_args(r.red, rpartial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C);
+  if (rc) return rc;
+  r.n = scae_saw::reduce_blocks(r.red, NT);
+  return conv_bwd_pair_impl(dpre, wd, in, din, partial, B, IH, IW, Cin, Cout, stride, false,
+                            stream, &r);
 }
 extern "C" int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *in,
                                           float *din, float *partial, int B, int IH, int IW,

@@ -380,82 +380,106 @@ __global__ __launch_bounds__(NTH) void saw_bwd_kernel(SwArgs a) {
   saw_bwd_body<NT, BF>(a, smem, blockIdx.x, gridDim.x);
 }
 
-#ifndef SCAE_DEVICE_ONLY   // (seed_bwd_gemm.hip includes this file for its device code)
 // partial (rows, O*16 + C*16 + C) -> gq (O,C), gwk (C,16), gbk (C) = 0, gwv (C,16), gbv (C).
-// 1024 threads = 64 columns x 16 row parts: a column sum is 8-16 independent loads per
-// thread and one LDS meeting.  Blocks [0, nsum): 64 columns of [dwv | dbv] each; the
-// others first sum the O*16 columns of d(qk) (every one of them: 200 KB from L2) and
-// then produce 1024 entries of [gq | gwk].
+// The canonical form is 1024 threads = 64 columns x 16 row parts: a column sum is 8-16
+// independent loads per thread and one LDS meeting.  Blocks [0, nsum): 64 columns of
+// [dwv | dbv] each; the others first sum the O*16 columns of d(qk) (every one of them: 200 KB
+// from L2) and then produce RT entries of [gq | gwk].  A block of RT < 1024 threads walks
+// 1024 / RT row parts per thread (conv_mfma.hip runs these workgroups as 256-thread riders
+// of a convolution launch): the same partial sums meet in the same order, so the result does
+// not depend on the block shape.  lds: 16 * 65 + 64 * 16 floats.
 constexpr int RTH = 1024;
-__global__ __launch_bounds__(RTH) void saw_reduce_kernel(const float *__restrict__ partial,
-                                                         int rows, const float *__restrict__ q,
-                                                         const float *__restrict__ wk,
-                                                         float *__restrict__ gq,
-                                                         float *__restrict__ gwk,
-                                                         float *__restrict__ gbk,
-                                                         float *__restrict__ gwv,
-                                                         float *__restrict__ gbv, int O, int C,
-                                                         int nsum) {
-  __shared__ float red[16][65];
-  __shared__ float dqk[64 * D];
+struct ReduceArgs {
+  const float *partial;
+  int rows;
+  const float *q, *wk;
+  float *gq, *gwk, *gbk, *gwv, *gbv;
+  int O, C, nsum;
+};
+inline int reduce_blocks(const ReduceArgs &r, int RT) {
+  return r.nsum + (r.O * r.C + r.C * D + RT - 1) / RT;
+}
+template <int RT>
+__device__ __forceinline__ void saw_reduce_body(const ReduceArgs &a, float *lds, int blk) {
+  constexpr int VR = RTH / RT;   // row parts per thread
+  float (*red)[65] = reinterpret_cast<float (*)[65]>(lds);
+  float *dqk = lds + 16 * 65;
+  const float *__restrict__ partial = a.partial;
+  const int rows = a.rows, O = a.O, C = a.C, nsum = a.nsum;
   const int npar = O * D + C * D + C;
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  // sum of column `col` over the rows ry, ry + 16, ..; valid in the threads with ry == 0
+  const int cx = threadIdx.x & 63, ry0 = (threadIdx.x >> 6) * VR;
+  // sum of column `col` over the rows ry, ry + 16, ..; valid in the threads with ry0 == 0
   auto colsum = [&](int col, bool ok) {
-    float acc = 0.f;
-    if (ok) {
-      float v[8];
-      int r = ry;
-      for (; r + 7 * 16 < rows; r += 8 * 16) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + 16 * u) * npar + col];
+    for (int vr = 0; vr < VR; ++vr) {
+      const int ry = ry0 + vr;
+      float acc = 0.f;
+      if (ok) {
+        float v[8];
+        int r = ry;
+        for (; r + 7 * 16 < rows; r += 8 * 16) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+          for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + 16 * u) * npar + col];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < rows; r += 16) acc += partial[(size_t)r * npar + col];
       }
-      for (; r < rows; r += 16) acc += partial[(size_t)r * npar + col];
+      red[ry][cx] = acc;
     }
-    red[ry][cx] = acc;
     __syncthreads();
     float tot = 0.f;
-    if (ry == 0) {
+    if (ry0 == 0) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot += red[k][cx];
     }
     __syncthreads();
     return tot;
   };
-  if ((int)blockIdx.x < nsum) {   // gwv, gbv (and the zero bk gradient)
-    const int i = blockIdx.x * 64 + cx;
+  if (blk < nsum) {   // gwv, gbv (and the zero bk gradient)
+    const int i = blk * 64 + cx;
     const float tot = colsum(O * D + i, i < C * D + C);
-    if (ry == 0) {
+    if (ry0 == 0) {
       if (i < C * D)
-        gwv[i] = tot;
+        a.gwv[i] = tot;
       else if (i < C * D + C)
-        gbv[i - C * D] = tot;
-      if (i < C) gbk[i] = 0.f;
+        a.gbv[i - C * D] = tot;
+      if (i < C) a.gbk[i] = 0.f;
     }
     return;
   }
   for (int c0 = 0; c0 < O * D; c0 += 64) {
     const float tot = colsum(c0 + cx, c0 + cx < O * D);
-    if (ry == 0 && c0 + cx < O * D) dqk[c0 + cx] = tot;
+    if (ry0 == 0 && c0 + cx < O * D) dqk[c0 + cx] = tot;
   }
   __syncthreads();
-  const int i = ((int)blockIdx.x - nsum) * RTH + threadIdx.x;
+  const int i = (blk - nsum) * RT + threadIdx.x;
   if (i < O * C) {   // gq[o][c] = sum_i d(qk)[o][i] wk[c][i]
     const int o = i / C, c = i - o * C;
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < D; ++j) acc = fmaf(dqk[o * D + j], wk[(size_t)c * D + j], acc);
-    gq[i] = acc;
+    for (int j = 0; j < D; ++j) acc = fmaf(dqk[o * D + j], a.wk[(size_t)c * D + j], acc);
+    a.gq[i] = acc;
   } else if (i < O * C + C * D) {   // gwk[c][i] = sum_o q[o][c] d(qk)[o][i]
     const int e = i - O * C, c = e / D, j = e - c * D;
     float acc = 0.f;
-    for (int o = 0; o < O; ++o) acc = fmaf(q[(size_t)o * C + c], dqk[o * D + j], acc);
-    gwk[e] = acc;
+    for (int o = 0; o < O; ++o) acc = fmaf(a.q[(size_t)o * C + c], dqk[o * D + j], acc);
+    a.gwk[e] = acc;
   }
 }
-
+inline int reduce_args(ReduceArgs &r, const float *partial, int rows, const float *q,
+                       const float *wk, float *gq, float *gwk, float *gbk, float *gwv, float *gbv,
+                       int O, int C) {
+  SCAE_REQUIRE(partial && q && wk && gq && gwk && gbk && gwv && gbv && rows > 0 && O > 0 &&
+               O <= 64 && C > 0);
+  r = ReduceArgs{partial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C, (C * D + C + 63) / 64};
+  return SCAE_OK;
+}
+#ifndef SCAE_DEVICE_ONLY   // (seed_bwd_gemm.hip, conv_mfma.hip include this file for its device code)
+__global__ __launch_bounds__(RTH) void saw_reduce_kernel(ReduceArgs a) {
+  __shared__ float lds[16 * 65 + 64 * D];
+  saw_reduce_body<RTH>(a, lds, blockIdx.x);
+}
 #endif
 int check(const SwArgs &a) {
   if (a.B <= 0 || a.N <= 0 || a.O <= 0 || a.C <= 0) return SCAE_ERR_BAD_ARG;
@@ -526,11 +550,11 @@ extern "C" int scae_seed_attention_mfma_reduce_f32(const float *partial, int row
                                                    const float *wk, float *gq, float *gwk,
                                                    float *gbk, float *gwv, float *gbv, int O,
                                                    int C, void *stream) {
-  SCAE_REQUIRE(partial && q && wk && gq && gwk && gbk && gwv && gbv && rows > 0 && O > 0 &&
-               O <= 64 && C > 0);
-  const int nsum = (C * D + C + 63) / 64, nexp = (O * C + C * D + RTH - 1) / RTH;
-  hipLaunchKernelGGL(saw_reduce_kernel, dim3(nsum + nexp), dim3(RTH), 0, (hipStream_t)stream,
-                     partial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C, nsum);
+  ReduceArgs r;
+  int rc = reduce_args(r, partial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C);
+  if (rc) return rc;
+  hipLaunchKernelGGL(saw_reduce_kernel, dim3(reduce_blocks(r, RTH)), dim3(RTH), 0,
+                     (hipStream_t)stream, r);
   return scae_launch_status();
 }
 #endif  // SCAE_DEVICE_ONLY

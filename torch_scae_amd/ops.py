@@ -547,6 +547,7 @@ class step_fusion:
         _PENDING_K1_BWD = None     # (a backward that raised may have left one)
         globals()["_PENDING_WGRADS"] = globals()["_PENDING_CLASS_PROBS"] = None
         globals()["_PENDING_COMBINE"] = globals()["_PENDING_FOLD"] = None
+        globals()["_PENDING_REDUCE"] = None
         return self
 
     def __exit__(self, *exc):
@@ -643,6 +644,34 @@ class _PendingWeightGemms:
         _lib.call("scae_gemm_multi_f32", self.descs, self.n, _stream(self.ref))
 
 
+_PENDING_REDUCE = None
+
+
+class _PendingReduce:
+    """The partial-row reduction of the output attention's backward, parked
+    (its outputs feed the folding products' backward only): rides in the part
+    encoder's conv backward, one launch before ``_PendingFoldBackward``."""
+
+    def __init__(self, args, keep, stream_ref):
+        self.args, self.keep, self.ref = args, keep, stream_ref
+
+    def launch_alone(self):
+        _lib.call("scae_seed_attention_mfma_reduce_f32", *self.args,
+                  _stream(self.ref))
+
+
+def take_pending_reduce():
+    global _PENDING_REDUCE
+    pending, _PENDING_REDUCE = _PENDING_REDUCE, None
+    return pending
+
+
+def flush_pending_reduce():
+    pending = take_pending_reduce()
+    if pending is not None:
+        pending.launch_alone()
+
+
 _PENDING_FOLD = None
 
 
@@ -680,7 +709,8 @@ def flush_pending_backward():
     if _PENDING_K1_BWD is not None:
         pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
         pending.launch_alone()
-    for pending in (take_pending_weight_gemms(), take_pending_fold()):
+    for pending in (take_pending_weight_gemms(), take_pending_reduce(),
+                    take_pending_fold()):       # (the fold reads the reduction)
         if pending is not None:
             pending.launch_alone()
 
@@ -842,8 +872,9 @@ def seed_attention_supported(N, O, D, C):
 
 class _SeedAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, q, wk, bk, wv, bv, presence):
+    def forward(ctx, h, q, wk, bk, wv, bv, presence, from_fold=False):
         _need_hip(h, q, wk, bk, wv, bv, presence)
+        ctx.from_fold = bool(from_fold)
         h, q, wk, bk, wv, bv, presence = (_c(t) for t in (h, q, wk, bk, wv, bv,
                                                           presence))
         B, N, D = h.shape
@@ -894,10 +925,20 @@ class _SeedAttention(torch.autograd.Function):
             # column sums of the partials, expanded to the operands' gradients
             gq, gwk, gbk, gwv, gbv = new(O, C), new(C, D), new(C), new(C, D), \
                 new(C)
-            _lib.call("scae_seed_attention_mfma_reduce_f32", _p(partial), rows,
-                      _p(q), _p(wk), _p(gq), _p(gwk), _p(gbk), _p(gwv), _p(gbv),
-                      O, C, _stream(h))
-            return gh, gq, gwk, gbk, gwv, gbv, None
+            red = (_p(partial), rows, _p(q), _p(wk), _p(gq), _p(gwk), _p(gbk),
+                   _p(gwv), _p(gbv), O, C)
+            if ctx.from_fold and _FUSION_TARGET is not None and \
+                    _DEFERRED is not None:
+                # only the folding products' backward reads these: the launch
+                # waits for a carrier (``_SeedFold.backward`` launches it
+                # first if it does not wait itself)
+                global _PENDING_REDUCE
+                flush_pending_reduce()
+                _PENDING_REDUCE = _PendingReduce(red, (partial, q, wk), h)
+            else:
+                _lib.call("scae_seed_attention_mfma_reduce_f32", *red,
+                          _stream(h))
+            return gh, gq, gwk, gbk, gwv, gbv, None, None
         grid, S = lib.scae_seed_attention_grid(B, O), \
             lib.scae_seed_attention_splits(B, O)
         npar = O * C + 2 * C * D + 2 * C
@@ -914,7 +955,7 @@ class _SeedAttention(torch.autograd.Function):
         res = _sum_rows_multi(jobs)
         gq, gwk, gbk, gwv, gbv = res[0]
         gh = gh[0] if S == 1 else res[1][0]
-        return gh, gq, gwk, gbk, gwv, gbv, None
+        return gh, gq, gwk, gbk, gwv, gbv, None, None
 
 
 def seed_attention(h, q, wk, bk, wv, bv, presence=None):
@@ -922,7 +963,13 @@ def seed_attention(h, q, wk, bk, wv, bv, presence=None):
     K' = h wk^T + bk, V' = h wv^T + bv."""
     if presence is not None and presence.requires_grad:
         raise ScaeHipError("seed_attention treats presence as a constant")
-    return _SeedAttention.apply(h, q, wk, bk, wv, bv, presence)
+    # (do the five folded operands all come from ONE seed_fold call?  Then their
+    # gradients feed that node's backward only, and inside a fused step the
+    # reduction that produces them may wait for a carrier together with it)
+    fns = {t.grad_fn for t in (q, wk, bk, wv, bv)}
+    fn = next(iter(fns)) if len(fns) == 1 else None
+    from_fold = fn is not None and type(fn).__name__ == "_SeedFoldBackward"
+    return _SeedAttention.apply(h, q, wk, bk, wv, bv, presence, from_fold)
 
 
 # ----------------------------------------------------------------------------
@@ -1009,11 +1056,12 @@ class _SeedFold(torch.autograd.Function):
             # parameter gradients only: the launch waits for a carrier
             global _PENDING_FOLD
             stale = take_pending_fold()
-            if stale is not None:
+            if stale is not None:       # (never in a step: one fold per model)
                 stale.launch_alone()
             _PENDING_FOLD = _PendingFoldBackward(
                 desc, g, (inputs, outs, incoming), seeds)
         else:
+            flush_pending_reduce()      # (this launch reads what it writes)
             _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(desc),
                       ctypes.byref(g), _stream(seeds))
         return tuple(grads)
@@ -1132,6 +1180,7 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
     gws, gbs = [None] * L, [None] * L
     pending = []       # (partial, gw, gb, co, ci, splits): reduced in one launch
+    lib = _lib.load()
     for l in range(L - 1, 0, -1):
         co, ci = wshapes[l][0], wshapes[l][1]
         xin, s = acts[l - 1], strides[l]
@@ -1144,19 +1193,30 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
         # only wait for dpre: one launch
         pair = (_p(dpre), _p(wds[l - 1]), _p(xin), _p(din), _p(partial), B, ih,
                 iw, ci, co, s)
-        # (the stack's largest launch, the second layer's, is the carrier)
-        parked, carried = (None if _MFMA_BF16 or l != 1
-                           else take_pending_fold()), False
-        if parked is not None:
-            # the folding products' backward as the head of this launch
-            rc = _lib.load().scae_conv3x3_bwd_pair_fold_f32(
-                *pair, ctypes.byref(parked.desc), ctypes.byref(parked.grads),
-                st)
-            if rc == _lib.ERR_UNSUPPORTED:
-                parked.launch_alone()
-            else:
-                _lib.check(rc, "scae_conv3x3_bwd_pair_fold_f32")
-                carried = True
+        # parked parameter-gradient launches of the object encoder ride here:
+        # the attention's reduction in the third layer's launch, the folding
+        # products' backward (which reads it) in the second's, the largest
+        carried = False
+        if not _MFMA_BF16 and l <= 2:
+            parked = take_pending_reduce()
+            if parked is not None:
+                rc = lib.scae_conv3x3_bwd_pair_reduce_f32(
+                    *pair, *parked.args, st) if l == 2 else _lib.ERR_UNSUPPORTED
+                if rc == _lib.ERR_UNSUPPORTED:
+                    parked.launch_alone()
+                else:
+                    _lib.check(rc, "scae_conv3x3_bwd_pair_reduce_f32")
+                    carried = True
+            parked = None if carried or l != 1 else take_pending_fold()
+            if parked is not None:
+                rc = lib.scae_conv3x3_bwd_pair_fold_f32(
+                    *pair, ctypes.byref(parked.desc),
+                    ctypes.byref(parked.grads), st)
+                if rc == _lib.ERR_UNSUPPORTED:
+                    parked.launch_alone()
+                else:
+                    _lib.check(rc, "scae_conv3x3_bwd_pair_fold_f32")
+                    carried = True
         if not carried:
             _lib.call(_prec("scae_conv3x3_bwd_pair_f32"), *pair, st)
         pending.append((partial, gw, gb, co, ci, splits))
