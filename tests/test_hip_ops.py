@@ -1238,6 +1238,76 @@ def test_seed_fold_vs_fp64(O, C, D):
     assert_close(hip_in2[2].grad, torch.full((C,), float(O)), what="d_bq")
 
 
+def test_conv_backward_carrying_reduce_and_fold_backward_equals_separate_launches():
+    """scae_conv3x3_bwd_pair_reduce_f32 / _fold_f32: a conv layer's backward
+    launch with the output attention's partial-row reduction, resp. the
+    folding products' backward, as 256-thread workgroups at the head of its
+    grid -- bit for bit what scae_conv3x3_bwd_pair_f32 +
+    scae_seed_attention_mfma_reduce_f32 + scae_seed_fold_bwd_f32 (1024-thread
+    workgroups) give."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(33)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).cuda()
+    new = lambda *shape: torch.empty(*shape, device="cuda")
+    B, ih, ci, co, s = 128, 9, 128, 128, 1
+    oh = ih - 2
+    xin, dpre = torch.relu(rnd(B, ih, ih, ci)), rnd(B, oh, oh, co)
+    wd = rnd(ci, 9, co) * .03
+    O, C, D, rows = 24, 256, 16, 128
+    partial_rows = rnd(rows, O * D + C * D + C)
+    q, wk = rnd(O, C), rnd(C, D)
+    shapes = [(O, C), (C, C), (C,), (C, C), (C,), (C, C), (C,), (C, C), (C,),
+              (C, D), (C,)]
+    vals = [rnd(*sh) / sh[-1] ** .5 for sh in shapes]
+    fold_outs = (new(O, C), new(C, D), new(C), new(C, D), new(C), new(C, D + 1),
+                 new(C, C))
+    st = torch.cuda.current_stream().cuda_stream
+    lib = _lib.load()
+    _lib.call("scae_seed_fold_fwd_f32",
+              ctypes.byref(ops._fold_desc(vals, fold_outs, O, C, D)), st)
+    splits = lib.scae_conv3x3_wgrad_splits(B, oh, oh, ci, co)
+    res = []
+    for carried in (False, True):
+        outs = []
+        for which in ("reduce", "fold"):
+            din, part = new(B, ih, ih, ci), new(splits * (9 * co * ci + co))
+            pair = (ops._p(dpre), ops._p(wd), ops._p(xin), ops._p(din),
+                    ops._p(part), B, ih, ih, ci, co, s)
+            if which == "reduce":
+                red_out = [new(O, C), new(C, D), new(C), new(C, D), new(C)]
+                red = (ops._p(partial_rows), rows, ops._p(q), ops._p(wk),
+                       *[ops._p(t) for t in red_out], O, C)
+                if carried:
+                    _lib.call("scae_conv3x3_bwd_pair_reduce_f32", *pair, *red, st)
+                else:
+                    _lib.call("scae_conv3x3_bwd_pair_f32", *pair, st)
+                    _lib.call("scae_seed_attention_mfma_reduce_f32", *red, st)
+                outs += [din, part, *red_out]
+            else:
+                desc = ops._fold_desc(vals, fold_outs, O, C, D)
+                gr = _lib.SeedFoldGrads()
+                for name, t in zip(("g_q", "g_wkf", "g_bkf", "g_wvf", "g_bvf"),
+                                   red_out):
+                    setattr(gr, name, t.data_ptr())
+                grads = [torch.empty_like(v) for v in vals]
+                for name, t in zip(ops._FOLD_INPUTS, grads):
+                    setattr(gr, "d_" + name, t.data_ptr())
+                if carried:
+                    _lib.call("scae_conv3x3_bwd_pair_fold_f32", *pair,
+                              ctypes.byref(desc), ctypes.byref(gr), st)
+                else:
+                    _lib.call("scae_conv3x3_bwd_pair_f32", *pair, st)
+                    _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(desc),
+                              ctypes.byref(gr), st)
+                outs += [din, part, *grads]
+            torch.cuda.synchronize()
+        res.append(outs)
+    assert len(res[0]) == len(res[1]) == 7 + 2 + 11
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), i
+
+
 def test_conv_layer_carrying_the_folding_products_equals_separate_launches():
     """scae_conv3x3_fwd_fold_f32: the encoder's second conv layer with the
     output attention's folding products as the tail of its grid, against
