@@ -582,6 +582,20 @@ int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *
                               const float *g_presence, const float *g_feature,
                               const float *g_feature2, float *dy, int B, int HW, int A, int P,
                               void *stream);
+/* scae_capsule_head_bwd_f32 with scae_template_color_bwd_f32 (arguments logits ..
+ * color_nonlin, M = A; tc_g_feature is both that kernel's g_feature output and this one's
+ * g_feature2) in front of it, workgroup by workgroup: both run one workgroup per (image,
+ * capsule group) over the same groups, and the head only needs the colour MLP's feature
+ * gradient of its own capsules.  SCAE_ERR_UNSUPPORTED (F != P - 8, different grouping):
+ * launch the two in turn. */
+int scae_capsule_head_bwd_tc_f32(
+    const float *y, const float *pooled, const float *noise_u, float noise_scale, int similarity,
+    const float *g_pose, const float *g_presence, const float *g_feature, float *dy, int B,
+    int HW, int A, int P, const float *logits, const float *feature, const float *w1,
+    const float *b1, const float *w2, const float *b2, const float *color,
+    const float *g_templates, const float *g_raw, float *g_logits, float *tc_g_feature,
+    float *partial, int C, int hw, int F, int H1, int template_nonlin, int color_nonlin,
+    void *stream);
 
 /* ------------------------------------------------------------------------
  * Optimiser step on the flat parameter buffer

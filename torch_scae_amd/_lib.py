@@ -236,6 +236,8 @@ SIGNATURES = {
     "scae_capsule_head_conv_fwd_f32": [P, P, P, c_int, P, P, c_float, c_int, P, P, P, P, P]
     + [c_int] * 4 + [P],
     "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
+    "scae_capsule_head_bwd_tc_f32": [P, P, P, c_float, c_int, P, P, P, P] + [c_int] * 4
+    + [P] * 12 + [c_int] * 6 + [P],
     "scae_template_color_supported": [c_int] * 4,
     "scae_template_color_partial_rows": [c_int] * 2,
     "scae_template_color_fwd_f32": [P] * 9 + [c_int] * 8 + [P],

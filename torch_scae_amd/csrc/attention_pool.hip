@@ -12,6 +12,13 @@
 #include "geometric_transform.h"
 #include "wave_mfma.h"
 
+// (device code of the template colour MLP's backward, for pool_tc_bwd_kernel)
+#define SCAE_DEVICE_ONLY
+namespace scae_tc {
+#include "template_color.hip"
+}
+#undef SCAE_DEVICE_ONLY
+
 namespace {
 constexpr int NT = 512;
 
@@ -223,10 +230,8 @@ __global__ __launch_bounds__(NT) void pool_fwd_kernel(PoolArgs k) {
 }
 
 // g (B, A, P-1) -> dy (B, HW, A*P)
-__global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
-  extern __shared__ float lds[];
-  const int Af = k.A, A = Af / k.splits, b = blockIdx.x / k.splits,
-            a0 = (blockIdx.x % k.splits) * A;
+__device__ __forceinline__ void pool_bwd_body(const PoolArgs &k, float *lds, int blk) {
+  const int Af = k.A, A = Af / k.splits, b = blk / k.splits, a0 = (blk % k.splits) * A;
   const int HW = k.HW, P = k.P, AP = A * P, APp = padded(AP), ldy = Af * P;
   const size_t cap0 = (size_t)b * Af + a0;
   float *ys = lds, *mask = ys + HW * APp, *t = mask + A * HW, *gs = t + A * HW,
@@ -288,6 +293,29 @@ __global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
         p < P - 1 ? gs[a * (P - 1) + p] * m : m * (t[a * HW + pix] - sa[a]);
   }
 }
+__global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
+  extern __shared__ float lds[];
+  pool_bwd_body(k, lds, blockIdx.x);
+}
+
+// The head's backward with the template colour MLP's backward (template_color.hip, K10) in
+// front of it, workgroup by workgroup: both are decomposed into (image, capsule group)
+// workgroups over the same groups, and the only thing the head needs from the colour MLP is
+// the feature gradient of ITS OWN capsules -- so the colour workgroup of a group runs first
+// inside the head's workgroup of that group (512 threads; its sums each have one owner: the
+// bits do not depend on the block size), writes g_feature, and the head's part reads it back
+// as g_feature2 after a barrier.  The colour kernel's elementwise template-logit blocks are
+// the tail of the grid.  11.4 + 12.4 us as two dependent launches.
+__global__ __launch_bounds__(NT) void pool_tc_bwd_kernel(PoolArgs k, scae_tc::TcArgs tk, int nA) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= nA) {   // workgroup-uniform
+    scae_tc::tc_bwdB_body(tk, (int)blockIdx.x - nA);
+    return;
+  }
+  scae_tc::tc_bwdA_body<NT>(tk, lds, blockIdx.x);
+  __syncthreads();   // (its g_feature rows are written; its LDS is dead)
+  pool_bwd_body(k, lds, blockIdx.x);
+}
 
 int check(const PoolArgs &k) {
   if (k.B <= 0 || k.HW <= 0 || k.A <= 0 || k.P < 2) return SCAE_ERR_BAD_ARG;
@@ -295,6 +323,41 @@ int check(const PoolArgs &k) {
   return SCAE_OK;
 }
 }  // namespace
+
+// scae_capsule_head_bwd_f32 with scae_template_color_bwd_f32 (arguments logits .. color_nonlin;
+// its g_feature output is this launch's g_feature2) in front of it
+extern "C" int scae_capsule_head_bwd_tc_f32(
+    const float *y, const float *pooled, const float *noise_u, float noise_scale, int similarity,
+    const float *g_pose, const float *g_presence, const float *g_feature, float *dy, int B,
+    int HW, int A, int P, const float *logits, const float *feature, const float *w1,
+    const float *b1, const float *w2, const float *b2, const float *color,
+    const float *g_templates, const float *g_raw, float *g_logits, float *tc_g_feature,
+    float *partial, int C, int hw, int F, int H1, int template_nonlin, int color_nonlin,
+    void *stream) {
+  PoolArgs k{};
+  k.y = y, k.dy = dy, k.B = B, k.HW = HW, k.A = A, k.P = P;
+  k.splits = pool_splits(B, A);
+  k.noise_u = noise_u, k.noise_scale = noise_scale, k.similarity = similarity;
+  k.pooled = pooled, k.g_pose = g_pose, k.g_presence = g_presence, k.g_feature = g_feature;
+  k.g_feature2 = tc_g_feature;
+  int rc = check(k);
+  if (rc) return rc;
+  if (P < 8) return SCAE_ERR_UNSUPPORTED;
+  SCAE_REQUIRE(y && pooled && dy);
+  scae_tc::TcArgs tk;
+  rc = scae_tc::bwd_args(tk, logits, feature, w1, b1, w2, b2, color, g_templates, g_raw, g_logits,
+                         tc_g_feature, partial, B, A, C, hw, F, H1, template_nonlin,
+                         color_nonlin);
+  if (rc) return rc;
+  // the same groups on both sides, and the colour MLP's features are the head's special ones
+  if (tk.splits != k.splits || F != P - 8) return SCAE_ERR_UNSUPPORTED;
+  const size_t lp = lds_floats(HW, A / k.splits, P, true),
+               lt = scae_tc::lds_floats(A / k.splits, C, F, H1, true);
+  const int nA = B * k.splits;
+  hipLaunchKernelGGL(pool_tc_bwd_kernel, dim3(nA + scae_tc::bwd_elementwise_blocks(tk)), dim3(NT),
+                     (lp > lt ? lp : lt) * sizeof(float), (hipStream_t)stream, k, tk, nA);
+  return scae_launch_status();
+}
 
 extern "C" int scae_attention_pool_supported(int HW, int A, int P) {
   if (HW <= 0 || A <= 0 || P < 2) return 0;

@@ -75,6 +75,7 @@ inline size_t lds_floats(int M, int C, int F, int H1, bool bwd) {
 
 // stages the MLP and evaluates it for M capsules whose features start at `feature`:
 // h1 (post-ReLU), pre2 (second layer pre-activation)
+template <int NT>   // block size (any: every sum has one owner)
 __device__ __forceinline__ void mlp_forward(const Lds &l, const TcArgs &k, const float *feature,
                                             int M) {
   const int t = threadIdx.x;
@@ -113,13 +114,14 @@ __device__ __forceinline__ float color_grad(float pre2, int cnl) {
 
 // One workgroup per (image b, group of M capsules starting at m0): capsules are
 // independent, and an image alone would leave half of the CUs idle at B=128.
+#ifndef SCAE_DEVICE_ONLY   // (attention_pool.hip includes this file for its device code)
 __global__ __launch_bounds__(NT) void tc_fwd_kernel(TcArgs k) {
   extern __shared__ float lds[];
   const int M = k.M / k.splits, b = blockIdx.x / k.splits, m0 = (blockIdx.x % k.splits) * M;
   const Lds l = carve(lds, k, M);
   const int t = threadIdx.x, MC = M * k.C;
   const size_t cap0 = (size_t)b * k.M + m0;  // global index of the group's first capsule
-  mlp_forward(l, k, k.feature + cap0 * k.F, M);
+  mlp_forward<NT>(l, k, k.feature + cap0 * k.F, M);
   for (int e = t; e < MC; e += NT) {
     const float col = color_of(l.pre2[e], k.cnl);
     l.pre2[e] = col;
@@ -134,14 +136,16 @@ __global__ __launch_bounds__(NT) void tc_fwd_kernel(TcArgs k) {
     if (b == 0) k.raw[(size_t)m0 * k.C * k.hw + e] = r;
   }
 }
+#endif
 
+template <int NT>   // block size (any: every sum below has one owner)
 __device__ __forceinline__ void tc_bwdA_body(const TcArgs &k, float *lds, int block) {
   const int M = k.M / k.splits, b = block / k.splits, m0 = (block % k.splits) * M;
   const Lds l = carve(lds, k, M);
   float *g2 = l.pre2 + M * k.C, *g1 = g2 + M * k.C;
   const int t = threadIdx.x, MC = M * k.C, wave = t >> 6, lane = t & 63;
   const size_t cap0 = (size_t)b * k.M + m0;
-  mlp_forward(l, k, k.feature + cap0 * k.F, M);
+  mlp_forward<NT>(l, k, k.feature + cap0 * k.F, M);
   // g_colour[m,c] = sum_t g_templates[b,m,c,t] * raw[m,c,t]; then through the colour
   // non-linearity and the second ReLU -> g2 (gradient w.r.t. pre2)
   const float *logits = k.logits + (size_t)m0 * k.C * k.hw;
@@ -187,21 +191,26 @@ __device__ __forceinline__ void tc_bwdA_body(const TcArgs &k, float *lds, int bl
 }
 
 // workgroup (256 texels, 4 batch parts)
+// 256 texels x 4 batch parts per workgroup; a block of fewer than 1024 threads walks
+// several parts per thread (same partial sums, same order)
 __device__ __forceinline__ void tc_bwdB_body(const TcArgs &k, int block) {
   __shared__ float red[4][256];
-  const int tx = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int tx = threadIdx.x & 255, vp = 4 / ((int)blockDim.x >> 8);
   const int e = block * 256 + tx, MC = k.M * k.C;
   const int n = MC * k.hw;
-  float s = 0.f;
-  if (e < n) {
-    const int mc = e / k.hw, per = (k.B + 3) / 4, b0 = part * per, b1 = min(k.B, b0 + per);
+  for (int v = 0; v < vp; ++v) {
+    const int part = (threadIdx.x >> 8) * vp + v;
+    float s = 0.f;
+    if (e < n) {
+      const int mc = e / k.hw, per = (k.B + 3) / 4, b0 = part * per, b1 = min(k.B, b0 + per);
 #pragma unroll 8
-    for (int b = b0; b < b1; ++b)
-      s = fmaf(k.g_templates[(size_t)b * n + e], k.color[(size_t)b * MC + mc], s);
+      for (int b = b0; b < b1; ++b)
+        s = fmaf(k.g_templates[(size_t)b * n + e], k.color[(size_t)b * MC + mc], s);
+    }
+    red[part][tx] = s;
   }
-  red[part][tx] = s;
   __syncthreads();
-  if (part == 0 && e < n) {
+  if (threadIdx.x < 256 && e < n) {
     float tot = (red[0][tx] + red[1][tx]) +
                 (red[2][tx] + red[3][tx]);
     if (k.g_raw) tot += k.g_raw[e];
@@ -209,15 +218,15 @@ __device__ __forceinline__ void tc_bwdB_body(const TcArgs &k, int block) {
   }
 }
 
-// the two halves are independent (A: per (image, capsule group) colour-MLP backward,
-// B: per texel batch sums for the template logits): one launch, A's workgroups first
+#ifndef SCAE_DEVICE_ONLY
 __global__ __launch_bounds__(NT) void tc_bwd_kernel(TcArgs k, int nA) {
   extern __shared__ float lds[];
   if ((int)blockIdx.x < nA)  // workgroup-uniform
-    tc_bwdA_body(k, lds, blockIdx.x);
+    tc_bwdA_body<NT>(k, lds, blockIdx.x);
   else
     tc_bwdB_body(k, (int)blockIdx.x - nA);
 }
+#endif
 
 // capsule groups per image: enough workgroups to cover the 256 CUs twice
 inline int tc_splits(int B, int M) {
@@ -237,8 +246,30 @@ int check(const TcArgs &k) {
   if (!scae_template_color_supported(k.M, k.C, k.F, k.H1)) return SCAE_ERR_UNSUPPORTED;
   return SCAE_OK;
 }
+// the arguments of a backward launch, checked
+int bwd_args(TcArgs &k, const float *logits, const float *feature, const float *w1,
+             const float *b1, const float *w2, const float *b2, const float *color,
+             const float *g_templates, const float *g_raw, float *g_logits, float *g_feature,
+             float *partial, int B, int M, int C, int hw, int F, int H1, int template_nonlin,
+             int color_nonlin) {
+  k = TcArgs{};
+  k.logits = logits, k.feature = feature, k.w1 = w1, k.b1 = b1, k.w2 = w2, k.b2 = b2;
+  k.color = const_cast<float *>(color);
+  k.g_templates = g_templates, k.g_raw = g_raw, k.g_logits = g_logits;
+  k.g_feature = g_feature, k.partial = partial;
+  k.B = B, k.M = M, k.C = C, k.hw = hw, k.F = F, k.H1 = H1;
+  k.tnl = template_nonlin, k.cnl = color_nonlin;
+  k.splits = tc_splits(B, M);
+  int rc = check(k);
+  if (rc) return rc;
+  SCAE_REQUIRE(logits && feature && w1 && b1 && w2 && b2 && color && g_templates && g_logits &&
+               g_feature && partial);
+  return SCAE_OK;
+}
+inline int bwd_elementwise_blocks(const TcArgs &k) { return (k.M * k.C * k.hw + 255) / 256; }
 }  // namespace
 
+#ifndef SCAE_DEVICE_ONLY
 extern "C" int scae_template_color_supported(int M, int C, int F, int H1) {
   if (M <= 0 || C <= 0 || F <= 0 || H1 <= 0) return 0;
   return lds_floats(M, C, F, H1, true) * sizeof(float) <= 64 * 1024;
@@ -272,25 +303,18 @@ extern "C" int scae_template_color_bwd_f32(const float *logits, const float *fea
                                            float *g_logits, float *g_feature, float *partial,
                                            int B, int M, int C, int hw, int F, int H1,
                                            int template_nonlin, int color_nonlin, void *stream) {
-  TcArgs k{};
-  k.logits = logits, k.feature = feature, k.w1 = w1, k.b1 = b1, k.w2 = w2, k.b2 = b2;
-  k.color = const_cast<float *>(color);
-  k.g_templates = g_templates, k.g_raw = g_raw, k.g_logits = g_logits;
-  k.g_feature = g_feature, k.partial = partial;
-  k.B = B, k.M = M, k.C = C, k.hw = hw, k.F = F, k.H1 = H1;
-  k.tnl = template_nonlin, k.cnl = color_nonlin;
-  k.splits = tc_splits(B, M);
-  int rc = check(k);
+  TcArgs k;
+  int rc = bwd_args(k, logits, feature, w1, b1, w2, b2, color, g_templates, g_raw, g_logits,
+                    g_feature, partial, B, M, C, hw, F, H1, template_nonlin, color_nonlin);
   if (rc) return rc;
-  SCAE_REQUIRE(logits && feature && w1 && b1 && w2 && b2 && color && g_templates && g_logits &&
-               g_feature && partial);
-  hipStream_t st = (hipStream_t)stream;
-  const int n = M * C * hw, nA = B * k.splits;
-  hipLaunchKernelGGL(tc_bwd_kernel, dim3(nA + (n + 255) / 256), dim3(NT),
-                     lds_floats(M / k.splits, C, F, H1, true) * sizeof(float), st, k, nA);
+  const int nA = B * k.splits;
+  hipLaunchKernelGGL(tc_bwd_kernel, dim3(nA + bwd_elementwise_blocks(k)), dim3(NT),
+                     lds_floats(M / k.splits, C, F, H1, true) * sizeof(float),
+                     (hipStream_t)stream, k, nA);
   return scae_launch_status();
 }
 
 extern "C" int scae_template_color_partial_rows(int B, int M) {
   return B > 0 && M > 0 ? B * tc_splits(B, M) : 0;
 }
+#endif  // SCAE_DEVICE_ONLY

@@ -547,7 +547,7 @@ class step_fusion:
         _PENDING_K1_BWD = None     # (a backward that raised may have left one)
         globals()["_PENDING_WGRADS"] = globals()["_PENDING_CLASS_PROBS"] = None
         globals()["_PENDING_COMBINE"] = globals()["_PENDING_FOLD"] = None
-        globals()["_PENDING_REDUCE"] = None
+        globals()["_PENDING_REDUCE"] = globals()["_PENDING_TC"] = None
         return self
 
     def __exit__(self, *exc):
@@ -644,6 +644,35 @@ class _PendingWeightGemms:
         _lib.call("scae_gemm_multi_f32", self.descs, self.n, _stream(self.ref))
 
 
+_PENDING_TC = None
+
+
+class _PendingTcBackward:
+    """The template colour MLP's backward, parked for the part-capsule head's
+    backward launch (same workgroup decomposition; the head reads its
+    ``g_feature``, at ``gf_ptr``).  ``keep``: inputs only."""
+
+    def __init__(self, ptrs, bm, dims, keep, gf_ptr, stream_ref):
+        self.ptrs, self.bm, self.dims = ptrs, bm, dims
+        self.keep, self.gf_ptr, self.ref = keep, gf_ptr, stream_ref
+
+    def launch_alone(self):
+        _lib.call("scae_template_color_bwd_f32", *self.ptrs, *self.bm,
+                  *self.dims, _stream(self.ref))
+
+
+def take_pending_tc():
+    global _PENDING_TC
+    pending, _PENDING_TC = _PENDING_TC, None
+    return pending
+
+
+def flush_pending_tc():
+    pending = take_pending_tc()
+    if pending is not None:
+        pending.launch_alone()
+
+
 _PENDING_REDUCE = None
 
 
@@ -709,7 +738,8 @@ def flush_pending_backward():
     if _PENDING_K1_BWD is not None:
         pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
         pending.launch_alone()
-    for pending in (take_pending_weight_gemms(), take_pending_reduce(),
+    for pending in (take_pending_tc(), take_pending_weight_gemms(),
+                    take_pending_reduce(),
                     take_pending_fold()):       # (the fold reads the reduction)
         if pending is not None:
             pending.launch_alone()
@@ -1433,6 +1463,7 @@ class _CapsuleHead(torch.autograd.Function):
         noise_u = ctx.saved_tensors[4] if has_noise else None
         B, HW, C = x.shape
         dy = torch.empty_like(y)
+        flush_pending_tc()       # (this launch may read its g_feature)
         _lib.call("scae_capsule_head_bwd_f32", _p(y), _p(pooled), _p(noise_u),
                   noise_scale, similarity, _p(_c(g_pose)), _p(_c(g_presence)),
                   _p(_c(g_feature)), None, _p(dy), B, HW, A,
@@ -1513,10 +1544,29 @@ class _PartEncoder(torch.autograd.Function):
         noise_u = saved[2 * L + 4] if has_noise else None
         B, HW, C = x.shape
         dy = torch.empty_like(y)
-        _lib.call("scae_capsule_head_bwd_f32", _p(y), _p(pooled), _p(noise_u),
-                  noise_scale, similarity, _p(_c(g_pose)), _p(_c(g_presence)),
-                  _p(_c(g_feature)), _p(_c(g_twin)), _p(dy), B, HW, A,
-                  att_w2.shape[0] // A, _stream(x))
+        P_ = att_w2.shape[0] // A
+        head = (_p(y), _p(pooled), _p(noise_u), noise_scale, similarity,
+                _p(_c(g_pose)), _p(_c(g_presence)))
+        parked, carried = take_pending_tc(), False
+        if parked is not None:
+            # the colour MLP's backward in front of the head's, workgroup by
+            # workgroup -- if its g_feature is one of the two gradients here
+            mine = [t for t in (g_twin, g_feature) if t is not None
+                    and t.is_contiguous() and t.data_ptr() == parked.gf_ptr]
+            rc = _lib.ERR_UNSUPPORTED
+            if len(mine) == 1 and parked.bm == (B, A):
+                other = g_feature if mine[0] is g_twin else g_twin
+                rc = _lib.load().scae_capsule_head_bwd_tc_f32(
+                    *head, _p(_c(other)), _p(dy), B, HW, A, P_, *parked.ptrs,
+                    *parked.dims, _stream(x))
+            if rc == _lib.ERR_UNSUPPORTED:
+                parked.launch_alone()
+            else:
+                _lib.check(rc, "scae_capsule_head_bwd_tc_f32")
+                carried = True
+        if not carried:
+            _lib.call("scae_capsule_head_bwd_f32", *head, _p(_c(g_feature)),
+                      _p(_c(g_twin)), _p(dy), B, HW, A, P_, _stream(x))
         act = acts[-1]
         g_attw = _grad_out(ctx.slots[1], x, attw_shape)
         g_attb = _grad_out(ctx.slots[2], x, (att_w2.shape[0],))
@@ -1726,15 +1776,31 @@ class _ColoredTemplates(torch.autograd.Function):
         rows = _lib.load().scae_template_color_partial_rows(B, M)
         partial = torch.empty(rows, n3 + C, device=logits.device,
                               dtype=logits.dtype)
-        _lib.call("scae_template_color_bwd_f32", _p(logits), _p(feature),
-                  _p(w1), _p(b1), _p(w2), _p(b2), _p(color),
-                  _p(g_templates.contiguous()), _p(_c(g_raw)), _p(g_logits),
-                  _p(g_feature), _p(partial), B, M, C, th * tw, F, H1,
-                  *ctx.codes, _stream(logits))
+        g_templates, g_raw = g_templates.contiguous(), _c(g_raw)
+        ptrs = (_p(logits), _p(feature), _p(w1), _p(b1), _p(w2), _p(b2),
+                _p(color), _p(g_templates), _p(g_raw), _p(g_logits),
+                _p(g_feature), _p(partial))
+        dims = (C, th * tw, F, H1, *ctx.codes)
+        outs = [_grad_out(sl, t) for sl, t in zip(ctx.slots[1:],
+                                                  (w1, b1, w2, b2))]
+        # (parked only when the column sums of ``partial`` wait too)
+        if _FUSION_TARGET is not None and _DEFERRED is not None and \
+                _in_slot(g_logits) and all(_in_slot(o) for o in outs):
+            # the part-capsule head's backward, the only reader of g_feature,
+            # runs the same (image, capsule group) workgroups: this launch
+            # waits for it (``_PartEncoder.backward`` / ``_CapsuleHead.backward``
+            # launch it first if they cannot carry it)
+            global _PENDING_TC
+            flush_pending_tc()
+            _PENDING_TC = _PendingTcBackward(
+                ptrs, (B, M), dims, (logits, feature, w1, b1, w2, b2, color,
+                                     g_templates, g_raw, partial),
+                g_feature.data_ptr(), logits)
+        else:
+            _lib.call("scae_template_color_bwd_f32", *ptrs, B, M, *dims,
+                      _stream(logits))
         gw1, gb1, gw2, gb2 = _sum_rows(
-            partial, [(H1, F), (H1,), (C, H1), (C,)],
-            outs=[_grad_out(sl, t) for sl, t in zip(ctx.slots[1:],
-                                                    (w1, b1, w2, b2))],
+            partial, [(H1, F), (H1,), (C, H1), (C,)], outs=outs,
             defer=all(sl is not None for sl in ctx.slots[1:5]))
         return g_logits, g_feature, gw1, gb1, gw2, gb2, None, None
 
