@@ -1238,6 +1238,48 @@ def test_seed_fold_vs_fp64(O, C, D):
     assert_close(hip_in2[2].grad, torch.full((C,), float(O)), what="d_bq")
 
 
+def test_head_backward_with_colour_backward_in_front_equals_separate_launches():
+    """scae_capsule_head_bwd_tc_f32 (the colour MLP's backward and the head's in
+    one grid, workgroup by workgroup) against scae_template_color_bwd_f32 +
+    scae_capsule_head_bwd_f32 -- bit for bit."""
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(44)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).cuda()
+    new = lambda *shape: torch.empty(*shape, device="cuda")
+    B, HW, A, F, C, hw, H1 = 128, 25, 24, 16, 1, 121, 32
+    P = F + 8
+    y, pooled = rnd(B, HW, A * P), rnd(B, A, P - 1)
+    noise_u = torch.rand(B, A, generator=g).cuda()
+    g_pose, g_pres, g_feat = rnd(B, A, 6), rnd(B, A), rnd(B, A, F)
+    logits, feature = rnd(A, C, hw), rnd(B, A, F)
+    w1, b1, w2, b2 = rnd(H1, F) * .2, rnd(H1) * .1, rnd(C, H1) * .2, rnd(C) * .1
+    color, g_templates, g_raw = torch.rand(B, A, C, generator=g).cuda(), \
+        rnd(B, A, C, hw), rnd(A, C, hw)
+    rows = _lib.load().scae_template_color_partial_rows(B, A)
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for merged in (False, True):
+        dy, g_logits, tc_gf = new(B, HW, A * P), new(A, C, hw), new(B, A, F)
+        partial = new(rows, H1 * F + H1 + C * H1 + C)
+        tc_ptrs = tuple(ops._p(t) for t in (logits, feature, w1, b1, w2, b2, color,
+                                            g_templates, g_raw, g_logits, tc_gf,
+                                            partial))
+        dims = (C, hw, F, H1, 1, 1)
+        head = (ops._p(y), ops._p(pooled), ops._p(noise_u), 4.0, 1, ops._p(g_pose),
+                ops._p(g_pres), ops._p(g_feat))
+        if merged:
+            _lib.call("scae_capsule_head_bwd_tc_f32", *head, ops._p(dy), B, HW, A,
+                      P, *tc_ptrs, *dims, st)
+        else:
+            _lib.call("scae_template_color_bwd_f32", *tc_ptrs, B, A, *dims, st)
+            _lib.call("scae_capsule_head_bwd_f32", *head, ops._p(tc_gf),
+                      ops._p(dy), B, HW, A, P, st)
+        torch.cuda.synchronize()
+        res.append((dy, g_logits, tc_gf, partial))
+    for a, b, what in zip(res[0], res[1], ("dy", "g_logits", "g_feature", "partial")):
+        assert torch.equal(a, b), what
+
+
 def test_conv_backward_carrying_reduce_and_fold_backward_equals_separate_launches():
     """scae_conv3x3_bwd_pair_reduce_f32 / _fold_f32: a conv layer's backward
     launch with the output attention's partial-row reduction, resp. the
