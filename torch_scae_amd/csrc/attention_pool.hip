@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NT) void pool_bwd_kernel(PoolArgs k) {
 __global__ __launch_bounds__(NT) void pool_tc_bwd_kernel(PoolArgs k, scae_tc::TcArgs tk, int nA) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= nA) {   // workgroup-uniform
-    scae_tc::tc_bwdB_body(tk, (int)blockIdx.x - nA);
+    scae_tc::tc_bwdB_body<NT>(tk, (int)blockIdx.x - nA);
     return;
   }
   scae_tc::tc_bwdA_body<NT>(tk, lds, blockIdx.x);
@@ -351,6 +351,10 @@ extern "C" int scae_capsule_head_bwd_tc_f32(
   if (rc) return rc;
   // the same groups on both sides, and the colour MLP's features are the head's special ones
   if (tk.splits != k.splits || F != P - 8) return SCAE_ERR_UNSUPPORTED;
+  // Large batches (one workgroup per image, >= 512 images) are not latency-bound: there the
+  // two kernels are faster apart (B = 1024, 48 capsules: 240 us merged, 140 + 50 apart -- the
+  // head's workgroups are LDS-heavy and the colour MLP's serial part sits on top of each)
+  if (k.splits == 1) return SCAE_ERR_UNSUPPORTED;
   const size_t lp = lds_floats(HW, A / k.splits, P, true),
                lt = scae_tc::lds_floats(A / k.splits, C, F, H1, true);
   const int nA = B * k.splits;

@@ -193,13 +193,16 @@ __device__ __forceinline__ void tc_bwdA_body(const TcArgs &k, float *lds, int bl
 // workgroup (256 texels, 4 batch parts)
 // 256 texels x 4 batch parts per workgroup; a block of fewer than 1024 threads walks
 // several parts per thread (same partial sums, same order)
+template <int NT>   // block size: 256, 512 or 1024
 __device__ __forceinline__ void tc_bwdB_body(const TcArgs &k, int block) {
   __shared__ float red[4][256];
-  const int tx = threadIdx.x & 255, vp = 4 / ((int)blockDim.x >> 8);
+  constexpr int VP = 4 / (NT / 256);
+  const int tx = threadIdx.x & 255;
   const int e = block * 256 + tx, MC = k.M * k.C;
   const int n = MC * k.hw;
-  for (int v = 0; v < vp; ++v) {
-    const int part = (threadIdx.x >> 8) * vp + v;
+#pragma unroll
+  for (int v = 0; v < VP; ++v) {
+    const int part = (threadIdx.x >> 8) * VP + v;
     float s = 0.f;
     if (e < n) {
       const int mc = e / k.hw, per = (k.B + 3) / 4, b0 = part * per, b1 = min(k.B, b0 + per);
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(NT) void tc_bwd_kernel(TcArgs k, int nA) {
   if ((int)blockIdx.x < nA)  // workgroup-uniform
     tc_bwdA_body<NT>(k, lds, blockIdx.x);
   else
-    tc_bwdB_body(k, (int)blockIdx.x - nA);
+    tc_bwdB_body<NT>(k, (int)blockIdx.x - nA);
 }
 #endif
 
