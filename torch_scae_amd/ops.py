@@ -958,7 +958,7 @@ class _SeedAttention(torch.autograd.Function):
             red = (_p(partial), rows, _p(q), _p(wk), _p(gq), _p(gwk), _p(gbk),
                    _p(gwv), _p(gbv), O, C)
             if ctx.from_fold and _FUSION_TARGET is not None and \
-                    _DEFERRED is not None:
+                    _DEFERRED is not None and not _MFMA_BF16:
                 # only the folding products' backward reads these: the launch
                 # waits for a carrier (``_SeedFold.backward`` launches it
                 # first if it does not wait itself)
@@ -1081,8 +1081,10 @@ class _SeedFold(torch.autograd.Function):
             setattr(g, name, t.data_ptr())
         for name, t in zip(_FOLD_INPUTS, grads):
             setattr(g, "d_" + name, t.data_ptr())
+        # (bf16 mode has no carrier: the conv backward takes another tile form,
+        # and a launch that only waits runs later, on colder caches)
         if _FUSION_TARGET is not None and _DEFERRED is not None and \
-                all(_in_slot(t) for t in grads):
+                not _MFMA_BF16 and all(_in_slot(t) for t in grads):
             # parameter gradients only: the launch waits for a carrier
             global _PENDING_FOLD
             stale = take_pending_fold()
