@@ -88,6 +88,11 @@ FULL = {
                          n_obj_caps=32,
                          scae_params=dict(reconstruct_alternatives=False)),
                     128),
+    # configs[0]'s batch size (the reference's own CPU-runnable case): the
+    # same kernels as cfg2 on a quarter of the grid
+    "cfg2_bs32": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24,
+                       n_obj_caps=24,
+                       scae_params=dict(reconstruct_alternatives=False)), 32),
     # configs[2]'s shape (48 / 64 capsules, bs=1024) on the fp32 path
     "cfg3_shape": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=48,
                         n_obj_caps=64,
@@ -177,6 +182,53 @@ def test_scae_vs_oracle_full_size(name):
     assert off[0][0] <= 1e-4, "gradient entries off by more than 1e-4 of " \
         "their tensor's largest entry: " + ", ".join(
             f"{k} {r:.2e}" for r, k in off[:8] if r > 1e-4)
+
+
+def test_reconstruct_alternatives_vs_oracle_full_size():
+    """``reconstruct_alternatives=True`` (the constructor default,
+    stacked_capsule_auto_encoder.py:164-195) at cfg-2's full size: the three
+    extra reconstructions -- bottom-up, top-down from the winners, and the
+    B x O = 3072 per-object-capsule virtual images that read their image's
+    templates through ``template_repeat`` -- and ``rec`` itself, each with
+    ``pdf.mode()`` (:50-77), against the oracle.  (``bench.py`` times this
+    forward as an extra workload; round 3 pinned it on a 16 x 16 golden only.)"""
+    from tests.gate_screen import screened_scae_batch
+    cfg, B, sd, g = full_size_params("cfg2")
+    cfg = dict(cfg, scae_params=dict(reconstruct_alternatives=True))
+    image, label, noise = screened_scae_batch(O, cfg, sd, B, g)
+    ocfg = O.prepare_model_params(**cfg)
+    with torch.no_grad():
+        ores = O.scae_forward(sd, ocfg, image, noise, training=True)
+    from torch_scae_amd import factory, nn_utils
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    assert model.reconstruct_alternatives
+    with torch.no_grad(), nn_utils.fixed_noise(noise):
+        res = model(image.cuda())
+    n_obj = cfg["n_obj_caps"]
+    for key, n_img in (("rec", B), ("bottom_up_rec", B), ("top_down_rec", B),
+                       ("top_down_per_caps_rec", B * n_obj)):
+        got, ref = res[key], ores[key]
+        assert got.transformed_templates.shape[0] == n_img, key
+        assert_close(got.transformed_templates, ref.transformed_templates,
+                     1e-5, 1e-4, key + ".transformed_templates")
+        assert_close(got.mixing_logits, ref.mixing_logits, 2e-5, 1e-4,
+                     key + ".mixing_logits")
+        # the mode takes the component with the largest mixing log-prob: a
+        # pixel whose two best components tie within round-off may pick the
+        # other one; every other pixel agrees to 1e-4
+        mode = got.pdf.mode().cpu()
+        omode = O.gmm_mode(ref.transformed_templates, ref.scale,
+                           ref.mixing_logits)
+        bad = (mode - omode).abs() > 1e-4 + 1e-4 * omode.abs()
+        assert float(bad.float().mean()) <= 1e-5, (key, int(bad.sum()))
+        del mode, omode, bad
+    assert_close(res.winner, ores.winner, 1e-4, 1e-4, "winner")
+    assert torch.equal(res.vote_presence_binary.cpu() > 0.5,
+                       ores.vote_presence_binary > 0.5)
 
 
 def test_scae_forward_is_stochastic_like_the_reference():

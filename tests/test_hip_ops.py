@@ -1,6 +1,7 @@
 """GPU parity: every HIP op (through the C ABI) against the golden vectors
 captured from the reference and against the CPU oracle on random inputs.
 Tolerances are the north-star's 1e-4 (fp32), written per assertion."""
+import numpy as np
 import pytest
 import torch
 
@@ -481,21 +482,30 @@ def test_image_decoder_vs_golden(name):
     (2, 70, 1, (24, 24), (11, 11), True, False),
 ])
 def test_image_decoder_vs_oracle_full_size(B, M, C, HW, ts, alpha, scale):
+    g = torch.Generator().manual_seed(5)
+    pose = torch.randn(B, M, 6, generator=g) * 0.5
+    pose[:, :, 0] += 1.0
+    pose[:, :, 4] += 1.0
+    presence = torch.rand(B, M, generator=g)
+    _decoder_vs_oracle(B, M, C, HW, ts, alpha, scale, pose, presence, g)
+
+
+def _decoder_vs_oracle(B, M, C, HW, ts, alpha, scale, pose, presence, g,
+                       tile_sums=False):
+    """TemplateBasedImageDecoder + mixture log-likelihood and all gradients
+    against the oracle for given poses / presences.  ``tile_sums``: through
+    ``log_prob_tile_sums`` -- the training step's form, whose backward is the
+    cell-gather kernel -- instead of the per-pixel map."""
     from torch_scae_amd.part_decoder import TemplateBasedImageDecoder
     torch.manual_seed(0)
     dec = TemplateBasedImageDecoder(M, ts, HW, learn_output_scale=scale,
                                     use_alpha_channel=alpha)
-    g = torch.Generator().manual_seed(5)
     with torch.no_grad():
         for p in dec.parameters():
             p.copy_(torch.randn(p.shape, generator=g) * 0.5)
     P = {"d." + k: v.clone().requires_grad_(True)
          for k, v in dec.state_dict().items()}
     templates = torch.rand(B, M, C, *ts, generator=g)
-    pose = torch.randn(B, M, 6, generator=g) * 0.5
-    pose[:, :, 0] += 1.0
-    pose[:, :, 4] += 1.0
-    presence = torch.rand(B, M, generator=g)
     x = torch.rand(B, C, *HW, generator=g)
     cfg = dict(output_size=HW, learn_output_scale=scale,
                use_alpha_channel=alpha)
@@ -510,12 +520,18 @@ def test_image_decoder_vs_oracle_full_size(B, M, C, HW, ts, alpha, scale):
     dec = dec.cuda()
     tg, pg_, prg = leaf(templates), leaf(pose), leaf(presence)
     rg = dec(tg, pg_, prg)
-    lpg = rg.pdf.log_prob(x.cuda())
-    lpg.flatten(1).sum(-1).mean().backward()
+    if tile_sums:
+        sums = rg.pdf.log_prob_tile_sums(x.cuda())
+        (sums.sum() / B).backward()
+        assert_close(sums.sum(1), lpo.flatten(1).sum(1), 1e-4 * float(
+            lpo.flatten(1).sum(1).abs().max()), 1e-4, "image totals")
+    else:
+        lpg = rg.pdf.log_prob(x.cuda())
+        lpg.flatten(1).sum(-1).mean().backward()
+        assert_close(lpg, lpo, 1e-4, 1e-4, "log_prob")
     assert_close(rg.transformed_templates, ro.transformed_templates, 1e-5,
                  1e-4, "tt")
     assert_close(rg.mixing_logits, ro.mixing_logits, 2e-5, 1e-4, "ml")
-    assert_close(lpg, lpo, 1e-4, 1e-4, "log_prob")
     for name, a, b in (("templates", tg.grad, tc.grad),
                        ("pose", pg_.grad, pc.grad),
                        ("presence", prg.grad, prc.grad)):
@@ -528,6 +544,69 @@ def test_image_decoder_vs_oracle_full_size(B, M, C, HW, ts, alpha, scale):
             continue
         assert_close(p.grad, ref, 1e-4 * max(1.0, float(ref.abs().max())),
                      5e-4, "pgrad " + k)
+
+
+def _regime_inputs(regime, B, M, C, HW, g):
+    """(pose, presence) of a pose regime a training run passes through.
+
+    init:      what a freshly initialised part encoder emits for U[0,1)
+               images (the factory's model of that shape, eval mode);
+    collapsed: the state ``bench.py``'s U[0,1) batches train into within
+               ~200 steps -- pose scale ~0.01,
+               so that the whole image falls into one or two texel cells of a
+               template (the K1 backward then splits a cell over row slices x
+               row segments), presences 1e-18 and exactly 0;
+    mixed:     half of the capsules collapsed, half at unit scale, a few with
+               a single collapsed axis (one texel column / row)."""
+    if regime == "init":
+        from torch_scae_amd import factory
+        torch.manual_seed(3)
+        np.random.seed(3)
+        model = factory.make_scae(dict(
+            image_shape=(C, *HW), n_classes=10, n_part_caps=M, n_obj_caps=M,
+            scae_params=dict(reconstruct_alternatives=False))).cuda().eval()
+        with torch.no_grad():
+            parts = model.part_encoder(torch.rand(B, C, *HW, generator=g).cuda())
+        return parts.pose.cpu().clone(), parts.presence.cpu().clone()
+    unit = torch.randn(B, M, 6, generator=g) * 0.5
+    unit[:, :, 0] += 1.0
+    unit[:, :, 4] += 1.0
+    small = torch.randn(B, M, 6, generator=g) * 0.003
+    small[:, :, 0] += 0.01
+    small[:, :, 4] += 0.01
+    # translations anywhere in (and a little beyond) the template
+    small[:, :, 2] = torch.rand(B, M, generator=g) * 2.4 - 1.2
+    small[:, :, 5] = torch.rand(B, M, generator=g) * 2.4 - 1.2
+    presence = torch.rand(B, M, generator=g)
+    if regime == "collapsed":
+        pose = small
+        presence = torch.where(presence < 0.5, torch.full_like(presence, 1e-18),
+                               torch.zeros_like(presence))
+        presence[:, 0] = torch.rand(B, generator=g)      # one live capsule
+        return pose, presence
+    assert regime == "mixed"
+    pick = torch.rand(B, M, generator=g)
+    pose = torch.where((pick < 0.5)[..., None], small, unit)
+    one_axis = (pick >= 0.5) & (pick < 0.65)
+    pose[..., 0] = torch.where(one_axis, small[..., 0], pose[..., 0])
+    pose[..., 1] = torch.where(one_axis, small[..., 1], pose[..., 1])
+    presence = torch.where(pick < 0.25, torch.full_like(presence, 1e-18),
+                           presence)
+    return pose, presence
+
+
+@pytest.mark.parametrize("tile_sums", [False, True], ids=["pixels", "sums"])
+@pytest.mark.parametrize("regime", ["init", "collapsed", "mixed"])
+@pytest.mark.parametrize("B,M,C,HW", [(128, 24, 1, (40, 40)),     # cfg-2
+                                      (32, 32, 3, (32, 32))])     # cfg-5 shape
+def test_image_decoder_vs_oracle_pose_regimes(B, M, C, HW, regime, tile_sums):
+    """The pose regimes of a training run (round-3 review: every full-size
+    decoder test drew unit-scale poses, while the timed step runs on
+    collapsed ones)."""
+    g = torch.Generator().manual_seed(17)
+    pose, presence = _regime_inputs(regime, B, M, C, HW, g)
+    _decoder_vs_oracle(B, M, C, HW, (11, 11), True, False, pose, presence, g,
+                       tile_sums=tile_sums)
 
 
 @pytest.mark.parametrize("B,M,C,HW,ts,alpha", [
@@ -1979,6 +2058,8 @@ def test_part_encoder_node_vs_fp64_composition(B, C0, HW, chans, strides, A, F,
     (64, 48, 48, 16, 16, "mixed"),       # SAB of cfg-3
     (5, 33, 17, 70, 130, "mixed"),       # ragged, multi-chunk
     (7, 1, 1, 3, 5, None),               # degenerate
+    (3, 72, 80, 32, 48, "mixed"),        # beyond the bf16 kernel's 64-element
+                                         # tiles: general fp32 kernel, upcast
 ])
 def test_qkv_attention_bf16_vs_oracle(HB, N, M, dk, dv, pres):
     """bf16 operands on the bf16 matrix cores, fp32 accumulate / softmax.  The
@@ -2561,14 +2642,14 @@ def test_deferred_sums_with_a_parameter_used_twice():
         real = ops._launch_sum_units
 
         def spy(units):
-            launched.append((len(units), ops._DEFERRED is not None
-                             and len(ops._DEFERRED)))
+            q = ops.step_plan.current().deferred
+            launched.append((len(units), q is not None and len(q)))
             return real(units)
         ops._launch_sum_units = spy
         try:
             with ops.deferred_param_sums():
                 loss_of(tg, twice).backward()
-                waiting = len(ops._DEFERRED)
+                waiting = len(ops.step_plan.current().deferred)
         finally:
             ops._launch_sum_units = real
         flat.gather_grads()

@@ -278,6 +278,9 @@ def test_factory_rejects_configurations_outside_the_kernel_limits():
     for bad, needle in ((dict(n_part_caps=201), "n_part_caps"),
                         (dict(n_obj_caps=201, n_part_caps=10), "n_obj_caps"),
                         (dict(n_obj_caps=150, n_part_caps=100), "n_obj_caps * n_part_caps"),
+                        # (inside the product limit, outside the
+                        # capsule likelihood's own LDS budget)
+                        (dict(n_obj_caps=65, n_part_caps=200), "3 * n_obj_caps + 14"),
                         (dict(image_shape=(5, 40, 40)), "channels"),
                         (dict(pcae_template_generator_params=dict(
                             template_size=(64, 64))), "th*tw")):

@@ -81,6 +81,101 @@ def build_step(cfg, B, sd, **kw):
     return model, TrainStep(model, B, cfg["image_shape"], **kw)
 
 
+def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
+                         loss_rtol=1e-4, entry_bar=1e-4, l2_bar=None,
+                         update_l2=5e-2, what=""):
+    """``iters`` replays of ``step`` against the oracle + torch.optim.RMSprop
+    started from the model's CURRENT state (``P``: leaf copies of it).
+    ``entry_bar``: every entry of every parameter gradient within that fraction
+    of its tensor's largest entry; ``l2_bar``: additionally a relative-L2 bound
+    per tensor (bf16 operands); ``update_l2`` None: no per-step update check."""
+    ocfg = O.prepare_model_params(**cfg)
+    ropt = torch.optim.RMSprop(list(P.values()), lr=lr, alpha=0.99,
+                               momentum=0.9, eps=1e-2 / B ** 2)
+    from tests.gate_screen import screened_batch_for_noise
+    for it in range(iters):
+        # the SAME state-before on both sides, every step: RMSprop's update is
+        # ~10 lr sign(g) wherever |g| >> eps, so an entry whose gradient is at
+        # round-off level may move 1e-4 apart in ONE step without either side
+        # being wrong -- left alone, step 2 would compare gradients taken at
+        # different parameters
+        now = model.state_dict()
+        sq = flat_named(step, step.opt.square_avg)
+        mom = flat_named(step, step.opt.buf)
+        with torch.no_grad():
+            for k, p in P.items():
+                p.copy_(now[k])
+        flat_noise = predict_noise(step)
+        noise = split_noise(flat_noise, cfg, B)
+        image, label = screened_batch_for_noise(
+            O, cfg, {k: p.detach() for k, p in P.items()}, noise, g)
+        ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label, noise)
+        ref_before = {k: p.detach().clone() for k, p in P.items()}
+        ropt.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            for k, p in P.items():
+                p.grad = ref_grads[k]
+                if p.grad is None:
+                    continue
+                # torch.optim.RMSprop's own state of this parameter, set to
+                # the fused optimiser's (zeros at a fresh start; the running
+                # averages when the step continues a trained state)
+                st = ropt.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["square_avg"] = torch.zeros_like(p)
+                    st["momentum_buffer"] = torch.zeros_like(p)
+                st["square_avg"].copy_(sq[k])
+                st["momentum_buffer"].copy_(mom[k])
+        ropt.step()
+
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        loss = step(image.cuda(), label.cuda())
+        torch.cuda.synchronize()
+        # the replay consumed exactly the predicted draws
+        assert torch.equal(step._pro.noise, flat_noise), (what, it)
+        assert abs(float(loss) - float(ref_loss)) <= \
+            loss_rtol * abs(float(ref_loss)), (what, it, float(loss),
+                                               float(ref_loss))
+        # every entry of every parameter gradient within ``entry_bar`` of its
+        # tensor's largest entry (the screened batch has no borderline gate)
+        grads, off, l2, n = flat_grads(step), [], [], 0
+        for k, ref in ref_grads.items():
+            if ref is None:
+                continue
+            scale = float(ref.abs().max())
+            got = grads[k].detach().cpu()
+            if scale == 0.0:
+                assert float(got.abs().max()) <= 1e-6, (what, it, k)
+                continue
+            off.append((float((got - ref).abs().max()) / scale, k))
+            l2.append((float((got - ref).norm()) / float(ref.norm()), k))
+            n += 1
+        assert n > 200
+        off.sort(reverse=True)
+        l2.sort(reverse=True)
+        assert off[0][0] <= entry_bar, (what, it, off[:6])
+        if l2_bar is not None:
+            assert l2[0][0] <= l2_bar, (what, it, l2[:6])
+        if update_l2 is None:
+            continue
+        # the fused RMSprop moved every tensor like torch.optim.RMSprop did:
+        # a step is ~10 lr sign(g) for |g| >> eps, so the few entries with a
+        # gradient at round-off level differ; 5 % relative L2 per tensor
+        # (a wrong gradient or optimiser state gives O(1))
+        after = model.state_dict()
+        for k in ref_before:
+            d_ref = P[k].detach() - ref_before[k]
+            d_hip = (after[k] - before[k]).cpu()
+            nr = float(d_ref.norm())
+            if nr == 0.0:
+                assert float(d_hip.abs().max()) == 0.0, (what, it, k)
+                continue
+            assert float((d_hip - d_ref).norm()) <= update_l2 * nr, \
+                (what, it, k, float((d_hip - d_ref).norm()), nr)
+    return off[0], l2[0]
+
+
 @pytest.mark.parametrize("name", ["cfg2", "cfg5", "mnist_40_32"])
 def test_replayed_train_step_vs_oracle(name):
     cfg, B, sd, g = full_size_params(name)
@@ -92,81 +187,79 @@ def test_replayed_train_step_vs_oracle(name):
     assert step._pro.fold_outs is not None and step._pro.first_outs is not None
 
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ocfg = O.prepare_model_params(**cfg)
     lr = 3e-5
-    ropt = torch.optim.RMSprop(list(P.values()), lr=lr, alpha=0.99,
-                               momentum=0.9, eps=1e-2 / B ** 2)
-    from tests.gate_screen import screened_batch_for_noise
-    for it in range(3):
-        # the SAME state-before on both sides, every step: RMSprop's update is
-        # ~10 lr sign(g) wherever |g| >> eps, so an entry whose gradient is at
-        # round-off level may move 1e-4 apart in ONE step without either side
-        # being wrong -- left alone, step 2 would compare gradients taken at
-        # different parameters
-        if it > 0:
-            now = model.state_dict()
-            sq = flat_named(step, step.opt.square_avg)
-            mom = flat_named(step, step.opt.buf)
-            with torch.no_grad():
-                for k, p in P.items():
-                    p.copy_(now[k])
-                    if p in ropt.state:
-                        ropt.state[p]["square_avg"].copy_(sq[k])
-                        ropt.state[p]["momentum_buffer"].copy_(mom[k])
-        flat_noise = predict_noise(step)
-        noise = split_noise(flat_noise, cfg, B)
-        image, label = screened_batch_for_noise(
-            O, cfg, {k: p.detach() for k, p in P.items()}, noise, g)
-        ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label, noise)
-        ref_before = {k: p.detach().clone() for k, p in P.items()}
-        ropt.zero_grad(set_to_none=True)
-        for k, p in P.items():
-            p.grad = ref_grads[k]
-        ropt.step()
-
-        before = {k: v.clone() for k, v in model.state_dict().items()}
-        loss = step(image.cuda(), label.cuda())
-        torch.cuda.synchronize()
-        # the replay consumed exactly the predicted draws
-        assert torch.equal(step._pro.noise, flat_noise), it
-        assert abs(float(loss) - float(ref_loss)) <= \
-            1e-4 * abs(float(ref_loss)), (it, float(loss), float(ref_loss))
-        # every entry of every parameter gradient within 1e-4 of its tensor's
-        # largest entry (the screened batch has no borderline gate)
-        grads, off, n = flat_grads(step), [], 0
-        for k, ref in ref_grads.items():
-            if ref is None:
-                continue
-            scale = float(ref.abs().max())
-            got = grads[k].detach().cpu()
-            if scale == 0.0:
-                assert float(got.abs().max()) <= 1e-6, (it, k)
-                continue
-            off.append((float((got - ref).abs().max()) / scale, k))
-            n += 1
-        assert n > 200
-        off.sort(reverse=True)
-        assert off[0][0] <= 1e-4, (it, off[:6])
-        # the fused RMSprop moved every tensor like torch.optim.RMSprop did:
-        # a step is ~10 lr sign(g) for |g| >> eps, so the few entries with a
-        # gradient at round-off level differ; 5 % relative L2 per tensor
-        # (a wrong gradient or optimiser state gives O(1))
-        after = model.state_dict()
-        for k in ref_before:
-            d_ref = P[k].detach() - ref_before[k]
-            d_hip = (after[k] - before[k]).cpu()
-            nr = float(d_ref.norm())
-            if nr == 0.0:
-                assert float(d_hip.abs().max()) == 0.0, (it, k)
-                continue
-            assert float((d_hip - d_ref).norm()) <= 5e-2 * nr, \
-                (it, k, float((d_hip - d_ref).norm()), nr)
+    check_replayed_steps(model, step, cfg, B, P, g, 3, lr=lr, what=name)
     final = model.state_dict()
     for k, p in P.items():
         assert_close(final[k].cpu(), p.detach(), 1e-4, 2e-3, "param " + k)
         # ... and tighter, against what three such steps can move at all
         assert float((final[k].cpu() - p.detach()).abs().max()) <= \
             0.05 * 3 * 10 * lr, k
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_replayed_cfg3_step_vs_oracle(bf16):
+    """BASELINE.json configs[2]'s shape (48 / 64 capsules, B = 1024) as
+    ``bench.py`` times it: the REPLAYED step, whose kernel selections differ
+    from B = 128 (``gemm_multi_kernel<0>``, separate ``pool_bwd`` / ``tc_bwd``,
+    ``saw_bwd_kernel<4>``, the large-batch loss tail).  fp32: the 1e-4 bars of
+    the other configurations.  ``--bf16`` (``autocast_dtype=torch.bfloat16``:
+    bf16 operands on the matrix cores, fp32 accumulation): loss 2^-7 relative,
+    every gradient tensor 5e-2 relative L2 AND every entry within 2^-5 of its
+    tensor's largest entry, against the fp32 oracle."""
+    cfg, B, sd, g = full_size_params("cfg3_shape")
+    kw = dict(autocast_dtype=torch.bfloat16) if bf16 else {}
+    model, step = build_step(cfg, B, sd, **kw)
+    step.capture()
+    assert step.graph is not None and step._pro.noise is not None
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    if bf16:
+        worst, worst_l2 = check_replayed_steps(
+            model, step, cfg, B, P, g, 1, loss_rtol=2.0 ** -7,
+            entry_bar=2.0 ** -5, l2_bar=5e-2, update_l2=None, what="cfg3 bf16")
+    else:
+        worst, worst_l2 = check_replayed_steps(
+            model, step, cfg, B, P, g, 1, what="cfg3 fp32")
+    print(f"cfg3 {'bf16' if bf16 else 'fp32'} replayed step: worst entry "
+          f"{worst}, worst L2 {worst_l2}")
+
+
+def test_replayed_step_on_the_state_the_bench_ends_in():
+    """``bench.py`` trains on U[0,1) noise images for hundreds of steps before
+    and while it times; on such data the part capsules switch off (DESIGN.md
+    section 5, round 3): presences underflow and the pose scale collapses, so
+    that a whole image falls into one or two texel cells of a template --
+    the regime in which the K1 backward splits a cell over (row slice x row
+    segment) lanes.  400 replayed steps on the bench's kind of batch, then
+    the replayed step is held to the oracle from THAT state (same bars as at
+    initialisation)."""
+    cfg, B, sd, g = full_size_params("cfg2")
+    model, step = build_step(cfg, B, sd)
+    step.capture()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for _ in range(400):
+        image = torch.rand(B, *cfg["image_shape"], device="cuda",
+                           generator=gen)
+        label = torch.randint(0, 10, (B,), device="cuda", generator=gen)
+        step(image, label)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        parts = model.part_encoder.eval()(image)
+        model.part_encoder.train()
+    pres, pose = parts.presence.float(), parts.pose.float()
+    lin = torch.stack([pose[..., 0], pose[..., 1], pose[..., 3],
+                       pose[..., 4]], -1).abs().amax(-1)
+    print(f"state after 400 steps: presence median {float(pres.median()):.3e} "
+          f"min {float(pres.min()):.3e}; pose linear part median "
+          f"{float(lin.median()):.3e} min {float(lin.min()):.3e}")
+    # the regime is the trained one, not the initial one
+    assert float(pres.median()) < 0.05 or float(lin.median()) < 0.2, \
+        (float(pres.median()), float(lin.median()))
+    P = {k: v.detach().cpu().clone().requires_grad_(True)
+         for k, v in model.state_dict().items()}
+    worst, _ = check_replayed_steps(model, step, cfg, B, P, g, 2,
+                                    what="after 400 steps")
+    print("worst gradient entry after 400 steps:", worst)
 
 
 def _set_counter(step, value):

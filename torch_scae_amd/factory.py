@@ -90,7 +90,10 @@ KERNEL_LIMITS = dict(
     # mixture statistics (3 x O x M floats) may occupy of a CU's 160 KB of LDS
     n_part_caps=200,        # K2: n_part^2 floats of dS per set
     n_obj_caps=200,
-    caps_product=13000,     # K4: n_obj * n_part (and K2's output attention)
+    caps_product=13000,     # K2's output attention: n_obj * n_part
+    # K4 (capsule_likelihood_dev.h, lk_lds): (3 * n_obj + 14) * n_part floats
+    # of one image's mixture statistics in the 160 KB of LDS
+    likelihood_floats=40960,
     n_channels=4,           # K1 template planes
     template_texels=4096,   # K1: (C + 1) * th * tw floats of LDS per template
 )
@@ -114,6 +117,11 @@ def check_kernel_limits(params: dict):
         problems.append(f"n_obj_caps * n_part_caps = {n_obj * n_part} > "
                         f"{lim['caps_product']} (capsule likelihood: mixture "
                         "statistics of one image in LDS)")
+    if (3 * n_obj + 14) * n_part > lim["likelihood_floats"]:
+        problems.append(f"(3 * n_obj_caps + 14) * n_part_caps = "
+                        f"{(3 * n_obj + 14) * n_part} > "
+                        f"{lim['likelihood_floats']} (capsule likelihood: one "
+                        "image's mixture statistics in LDS)")
     if C > lim["n_channels"]:
         problems.append(f"{C} image channels > {lim['n_channels']} "
                         "(template render / mixture likelihood)")

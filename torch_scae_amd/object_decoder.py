@@ -262,36 +262,42 @@ class CapsuleObjectDecoder(nn.Module):
         return res
 
 
+# Host-side (op-by-op) forms of the three sparsity penalties; inside a fused
+# step the loss-tail kernel (csrc/loss_tail.hip) computes the same terms.  Each
+# returns (within-example term, between-example term).
 def capsule_l2_loss(caps_presence, n_classes: int,
-                    within_example_constant=None, **unused_kwargs):
-    """l2 penalty on capsule activations (object_decoder.py:433-452)."""
-    del unused_kwargs
-    batch_size, num_caps = caps_presence.shape
-    if within_example_constant is None:
-        within_example_constant = float(num_caps) / n_classes
-    within_example = torch.mean(
-        (caps_presence.sum(1) - within_example_constant) ** 2)
-    between_example_constant = float(batch_size) / n_classes
-    between_example = torch.mean(
-        (caps_presence.sum(0) - between_example_constant) ** 2)
-    return within_example, between_example
+                    within_example_constant=None, **_ignored):
+    """Squared distance of the activation mass per example (row sums) and per
+    capsule (column sums) from an even spread over ``n_classes`` classes
+    (object_decoder.py:433-452)."""
+    n_examples, n_caps = caps_presence.shape
+    row_target = n_caps / n_classes if within_example_constant is None \
+        else within_example_constant
+    col_target = n_examples / n_classes
+    row_mass, col_mass = caps_presence.sum(1), caps_presence.sum(0)
+    return ((row_mass - row_target).square().mean(),
+            (col_mass - col_target).square().mean())
 
 
-def capsule_entropy_loss(caps_presence, k=1, **unused_kwargs):
-    """entropy of capsule activations (object_decoder.py:456-471)."""
-    del unused_kwargs
-    within_prob = math_ops.normalize(caps_presence, 1)
-    within_example = math_ops.cross_entropy_safe(within_prob, within_prob * k)
-    between_prob = math_ops.normalize(torch.sum(caps_presence, 0), 0)
-    between_example = math_ops.cross_entropy_safe(between_prob,
-                                                  between_prob * k)
-    return within_example, -between_example
+def _scaled_self_entropy(mass, dim, k):
+    """cross_entropy_safe(p, k p) of ``mass`` normalised along ``dim``."""
+    p = math_ops.normalize(mass, dim)
+    return math_ops.cross_entropy_safe(p, k * p)
 
 
-def neg_capsule_kl(caps_presence, **unused_kwargs):
-    """object_decoder.py:475-479."""
-    del unused_kwargs
-    return capsule_entropy_loss(caps_presence, k=int(caps_presence.shape[-1]))
+def capsule_entropy_loss(caps_presence, k=1, **_ignored):
+    """Entropy of the activations within an example (to be lowered) and of the
+    batch totals between capsules (to be raised, hence the sign)
+    (object_decoder.py:456-471)."""
+    within = _scaled_self_entropy(caps_presence, 1, k)
+    between = _scaled_self_entropy(caps_presence.sum(0), 0, k)
+    return within, -between
+
+
+def neg_capsule_kl(caps_presence, **_ignored):
+    """KL to the uniform distribution over capsules = the entropy form with
+    k = number of capsules (object_decoder.py:475-479)."""
+    return capsule_entropy_loss(caps_presence, k=caps_presence.shape[-1])
 
 
 def sparsity_loss(loss_type, *args, **kwargs):

@@ -7,12 +7,14 @@ current HIP stream (so everything composes with ``torch.cuda.graph`` capture
 and with autograd's backward thread).  No op has a CPU or eager fallback.
 """
 import ctypes
+import functools
 
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, step_plan
 from ._lib import DecoderDesc, ScaeHipError
+from .step_plan import StepPlan, current as _plan
 
 __all__ = ["geometric_transform", "qkv_attention", "set_encoder", "grouped_mlp", "seed_attention", "seed_attention_supported", "seed_fold", "seed_fold_supported", "loss_tail", "loss_tail_scalar", "loss_tail_supported", "capsule_votes",
            "capsule_likelihood", "colored_templates", "template_color_supported", "attention_conv_pool", "attention_pool_supported", "capsule_head", "part_encoder", "conv_stack", "conv_stack_supported",
@@ -46,6 +48,33 @@ def _stream(ref):
 
 def _detached(t):
     return None if t is None else t.detach()
+
+
+def _fwd(f):
+    """``forward`` of a plan-aware autograd node: the step plan of the calling
+    thread (step_plan.current) is kept on the node for its backward."""
+    node = f.__qualname__
+
+    @functools.wraps(f)
+    def forward(ctx, *args):
+        ctx.plan = plan = _plan()
+        plan.enter(node)
+        return f(ctx, *args)
+    return staticmethod(forward)
+
+
+def _bwd(f):
+    """``backward`` of a plan-aware autograd node.  Autograd's worker thread
+    does not inherit context variables: the node's own plan is made current
+    while it runs, and whatever is parked on that plan and read by this node
+    (step_plan.RIDES) is launched first."""
+    node = f.__qualname__
+
+    @functools.wraps(f)
+    def backward(ctx, *grads):
+        with step_plan.running(ctx.plan, node):
+            return f(ctx, *grads)
+    return staticmethod(backward)
 
 
 def _slot(t, ctx=None):
@@ -96,34 +125,23 @@ def scaled_sums(jobs):
               _stream(jobs[0][0]))
 
 
-_NOISE_STATE = {}
-
 # BASELINE.json configs[2] ("bs=1024 bf16"): inside ``mfma_bf16()`` the GEMM-shaped kernels
 # (K7 batched GEMMs, K8 convolutions) round their fp32 operands to bf16 on the way into LDS
 # and multiply on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 results) wherever the
 # problem is large enough for the 128 x 128 tiles; everything else stays fp32.  The
 # context has to cover the backward pass as well (train_step.TrainStep does that).
-_MFMA_BF16 = False
+# The flag is a field of the current step plan (step_plan.StepPlan.bf16).
+def mfma_bf16(enabled=True):
+    return _plan().precision(enabled)
 
 
-class mfma_bf16:
-    def __init__(self, enabled=True):
-        self.enabled = bool(enabled)
-
-    def __enter__(self):
-        global _MFMA_BF16
-        self.prev, _MFMA_BF16 = _MFMA_BF16, self.enabled
-        return self
-
-    def __exit__(self, *exc):
-        global _MFMA_BF16
-        _MFMA_BF16 = self.prev
-        return False
+def _bf16():
+    return _plan().bf16
 
 
 def _prec(name):
     """C entry point of a GEMM-shaped launcher for the current precision."""
-    return name.replace("_f32", "_bf16") if _MFMA_BF16 else name
+    return name.replace("_f32", "_bf16") if _plan().bf16 else name
 
 
 class StepPrologue:
@@ -205,31 +223,19 @@ class StepPrologue:
         self.first_fresh = first
 
 
-_PROLOGUE = None
-
-
-class step_prologue:
-    """``with step_prologue(pro):`` -- see ``StepPrologue`` (``pro`` None: no-op)."""
-
-    def __init__(self, pro):
-        self.pro = pro
-
-    def __enter__(self):
-        global _PROLOGUE
-        self.prev, _PROLOGUE = _PROLOGUE, self.pro
-        return self.pro
-
-    def __exit__(self, *exc):
-        global _PROLOGUE
-        _PROLOGUE = self.prev
-        return False
+def step_prologue(pro):
+    """``with step_prologue(pro):`` -- see ``StepPrologue`` (``pro`` None:
+    no-op); a field of the current step plan."""
+    return _plan().with_prologue(pro)
 
 
 def reset_noise():
     """Restart the device noise generators from ``torch.initial_seed()`` (call
     after ``torch.manual_seed`` to replay a noise sequence; not inside a graph
-    capture)."""
-    _NOISE_STATE.clear()
+    capture).  Every step plan has its own generators: the current one's and
+    the process-wide ones restart."""
+    _plan().noise.clear()
+    step_plan.ambient.noise.clear()
 
 
 def uniform(n, ref):
@@ -240,12 +246,13 @@ def uniform(n, ref):
     _need_hip(ref)
     seed = int(torch.initial_seed()) & ((1 << 63) - 1)
     key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
-    state = _NOISE_STATE.get(key)
+    plan = _plan()
+    state = plan.noise.get(key)
     if state is None or (state[0] != seed and
                          not torch.cuda.is_current_stream_capturing()):
-        state = _NOISE_STATE[key] = (seed, torch.tensor(
+        state = plan.noise[key] = (seed, torch.tensor(
             [seed, 0, 0], dtype=torch.int64).to(ref.device))
-    pro = _PROLOGUE
+    pro = plan.prologue
     if pro is not None:
         if pro.noise is not None and pro.noise.numel() == int(n) \
                 and pro.noise_state is state[1] and pro.noise_fresh:
@@ -276,39 +283,20 @@ def _sum_rows(partial, shapes, starts=None, period=0, outs=None, transpose=0,
 
 
 _SUMS_PER_LAUNCH = 16
-_DEFERRED = None        # list of pending units while deferral is on
 
 
-class deferred_param_sums:
+def deferred_param_sums():
     """Inside this context the column-sum jobs marked ``defer`` -- those whose
     outputs are parameter gradients, which nothing but the optimiser / the
-    gradient all-reduce reads -- are queued instead of launched;
-    ``flush_param_sums()`` (and leaving the context) runs everything queued in
-    one launch per 16 jobs.  A training step's backward then ends in ONE
-    column-sum launch instead of one per op."""
-
-    def __enter__(self):
-        global _DEFERRED
-        self.outer = _DEFERRED
-        if _DEFERRED is None:
-            _DEFERRED = []
-        return self
-
-    def __exit__(self, *exc):
-        global _DEFERRED
-        if self.outer is None:
-            if exc[0] is None:
-                flush_pending_backward()
-                flush_param_sums()
-            _DEFERRED = None
-        return False
+    gradient all-reduce reads -- are queued (on the current step plan) instead
+    of launched; ``flush_param_sums()`` (and leaving the context) runs
+    everything queued in one launch per 16 jobs.  A training step's backward
+    then ends in ONE column-sum launch instead of one per op."""
+    return _plan().deferring()
 
 
 def flush_param_sums():
-    if _DEFERRED:
-        units = list(_DEFERRED)
-        del _DEFERRED[:]
-        _launch_sum_units(units)
+    _plan().flush_sums()
 
 
 def _launch_sum_units(units):
@@ -337,6 +325,7 @@ def _sum_rows_multi(jobs):
     too.  (Not covered: a parameter that ALSO feeds an op outside this
     package; the models of this package have none.)"""
     units, later, results = [], [], []
+    plan = _plan()
     for job in jobs:
         partial, shapes = job["partial"], job["shapes"]
         starts, period = job.get("starts"), job.get("period", 0)
@@ -358,14 +347,14 @@ def _sum_rows_multi(jobs):
             pos += width
             outs.append(o)
         results.append(outs)
-        dst = later if (_DEFERRED is not None and job.get("defer")
+        dst = later if (plan.deferred is not None and job.get("defer")
                         and all(_in_slot(o) for o in outs)) else units
         for k in range(0, len(shapes), 8):
             dst.append((partial, rows, cols, ctypes.cast(
                 ctypes.byref(segs, k * ctypes.sizeof(_lib.SumSegment)),
                 ctypes.POINTER(_lib.SumSegment)), min(8, len(shapes) - k), segs))
     if later:
-        _DEFERRED.extend(later)
+        plan.deferred.extend(later)
     if units:
         _launch_sum_units(units)
     return results
@@ -375,7 +364,7 @@ def _sum_rows_multi(jobs):
 # K5 geometric_transform (cv_ops.py:20-76)
 # ----------------------------------------------------------------------------
 class _GeometricTransform(torch.autograd.Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, pose, similarity, nonlinear, as_matrix):
         _need_hip(pose)
         pose = pose.contiguous()
@@ -392,7 +381,7 @@ class _GeometricTransform(torch.autograd.Function):
             out = out.view(*pose.shape[:-1], 3, 3)
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         (pose,) = ctx.saved_tensors
         n = pose.numel() // 6
@@ -416,7 +405,7 @@ class _Mat3Mul(torch.autograd.Function):
     3 x 3 products of the hierarchical CapsuleLayer.forward
     (object_decoder.py:184-191)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, left, right):
         _need_hip(left, right)
         V = right.shape[-3]
@@ -430,7 +419,7 @@ class _Mat3Mul(torch.autograd.Function):
         ctx.save_for_backward(left, right)
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         left, right = ctx.saved_tensors
         V = right.shape[-3]
@@ -457,7 +446,7 @@ class _QKVAttention(torch.autograd.Function):
     softmax; output bf16, probabilities kept in fp32), backward on the fp32
     kernel with upcast operands."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, q, k, v, presence):
         bf16 = q.dtype == torch.bfloat16
         if bf16:
@@ -474,16 +463,27 @@ class _QKVAttention(torch.autograd.Function):
         out = torch.empty(HB, N, dv, device=q.device, dtype=q.dtype)
         probs = torch.empty(HB, N, M, device=q.device, dtype=torch.float32)
         sqrt_dk = float(np.float32(np.sqrt(dk)))
-        _lib.call("scae_qkv_attention_fwd_bf16" if bf16 else
-                  "scae_qkv_attention_fwd_f32", _p(q), _p(k), _p(v),
-                  _p(presence), _p(out), _p(probs), HB, N, M, dk, dv, sqrt_dk,
-                  _stream(q))
+        if bf16 and (N > 64 or M > 64):
+            # the bf16 kernel has the 64-element tile limits of the matrix-core
+            # forms: larger sets take the general fp32 kernel on upcast
+            # operands (fp32 accumulate as before; output rounded to bf16)
+            q32, k32, v32 = q.float(), k.float(), v.float()
+            out32 = torch.empty(HB, N, dv, device=q.device, dtype=torch.float32)
+            _lib.call("scae_qkv_attention_fwd_f32", _p(q32), _p(k32), _p(v32),
+                      _p(presence), _p(out32), _p(probs), HB, N, M, dk, dv,
+                      sqrt_dk, _stream(q))
+            out.copy_(out32)
+        else:
+            _lib.call("scae_qkv_attention_fwd_bf16" if bf16 else
+                      "scae_qkv_attention_fwd_f32", _p(q), _p(k), _p(v),
+                      _p(presence), _p(out), _p(probs), HB, N, M, dk, dv,
+                      sqrt_dk, _stream(q))
         ctx.save_for_backward(q, k, v, probs)
         ctx.has_presence = presence is not None
         ctx.sqrt_dk = sqrt_dk
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         q, k, v, probs = ctx.saved_tensors
         dtype = q.dtype
@@ -521,45 +521,29 @@ def _seg_arrays(segs):
 
 
 # ----------------------------------------------------------------------------
-# Two independent forward kernels in one launch (csrc/trunk_logprob.hip): inside a
-# training step the part decoder's likelihood of the step's own input image only
+# Independent kernels sharing launches.  Inside a training step
+# (``step_fusion(target)``, opened by train_step.TrainStep on its own step plan)
+# a launch may be PARKED by the node that owns it and carried by a later node's
+# launch; step_plan.RIDES is the table of these merges and the step plan the
+# only holder of parked work.  The classes below are the parked launches: the
+# arguments of the stand-alone launcher (``launch_alone``) which the carrier's
+# merged launcher takes as well.  Same kernels, same values, fewer launches.
+#
+# Forward: the part decoder's likelihood of the step's own input image only
 # needs the part encoder's outputs, like the object encoder's trunk -- and the
-# trunk leaves three quarters of the SIMDs idle.  ``step_fusion(target)`` (set
-# by train_step.TrainStep) lets SCAE.forward prepare the likelihood as a RIDER
-# of the trunk's launch; ``render_gmm_log_prob_sums`` later finds the result
-# instead of launching.  Same kernels, same values, one launch fewer.
+# trunk leaves three quarters of the SIMDs idle (csrc/trunk_logprob.hip).
+# SCAE.forward prepares the likelihood as a RIDER of the trunk's launch;
+# ``render_gmm_log_prob_sums`` later finds the result instead of launching.
 # ----------------------------------------------------------------------------
-_FUSION_TARGET = None
-_PENDING_RIDER = None
-
-
-class step_fusion:
+def step_fusion(target):
     """``with step_fusion(image):`` -- the reconstruction target of the loss
-    that will follow the forward inside the block (None: no fusion)."""
-
-    def __init__(self, target):
-        self.target = target
-
-    def __enter__(self):
-        global _FUSION_TARGET, _PENDING_RIDER, _PENDING_K1_BWD
-        self.prev = (_FUSION_TARGET, _PENDING_RIDER)
-        _FUSION_TARGET, _PENDING_RIDER = self.target, None
-        _PENDING_K1_BWD = None     # (a backward that raised may have left one)
-        globals()["_PENDING_WGRADS"] = globals()["_PENDING_CLASS_PROBS"] = None
-        globals()["_PENDING_COMBINE"] = globals()["_PENDING_FOLD"] = None
-        globals()["_PENDING_REDUCE"] = globals()["_PENDING_TC"] = None
-        return self
-
-    def __exit__(self, *exc):
-        global _FUSION_TARGET, _PENDING_RIDER
-        _FUSION_TARGET, _PENDING_RIDER = self.prev
-        if exc[0] is None:
-            flush_pending_forward()    # (a block without the fused loss tail)
-        return False
+    that will follow the forward inside the block (None: no fusion), on the
+    current step plan."""
+    return _plan().fusing(target)
 
 
 def fusion_target():
-    return _FUSION_TARGET
+    return _plan().target
 
 
 class LogProbRider:
@@ -591,19 +575,22 @@ class LogProbRider:
 def offer_log_prob_rider(inputs, x):
     """Called by SCAE.forward ahead of the object encoder: the next fused trunk
     launch carries this likelihood (if it can; else nothing happens)."""
-    global _PENDING_RIDER
-    _PENDING_RIDER = LogProbRider(inputs, x)
-    return _PENDING_RIDER
+    plan = _plan()
+    plan.rider = LogProbRider(inputs, x)
+    return plan.rider
 
 
-_PENDING_K1_BWD = None
+def withdraw_log_prob_rider():
+    """After the object encoder: a rider nobody launched is dropped."""
+    plan = _plan()
+    if plan.rider is not None and not plan.rider.launched:
+        plan.rider = None
 
 
 class _PendingK1Backward:
-    """The reconstruction likelihood's backward (K1), parked: its launch is
-    handed to the next backward node that can carry it -- the capsule
-    likelihood's, an independent one-workgroup-per-image kernel -- or
-    launched on its own by ``flush_pending_backward``."""
+    """RIDES['k1_bwd']: the reconstruction likelihood's backward (K1), parked
+    for the capsule likelihood's backward -- an independent
+    one-workgroup-per-image kernel -- to carry."""
 
     def __init__(self, desc, keep, inputs, outputs, stream_ref):
         """``inputs`` / ``keep``: tensors kept alive until the launch;
@@ -611,7 +598,8 @@ class _PendingK1Backward:
         as ADDRESSES only: a leaf's AccumulateGrad adopts a gradient it holds
         the sole reference to and clones -- here: copies an unfilled buffer --
         otherwise; autograd itself keeps them alive until their consumers
-        run, which is after this launch."""
+        run, which is after this launch (every plan-aware node launches a
+        parked K1 before it starts, step_plan.RIDES)."""
         self.desc, self.keep, self.ref = desc, (keep, inputs), stream_ref
         self.ptrs = [ctypes.c_void_p(t.data_ptr()) if t is not None else None
                      for t in inputs] + \
@@ -625,17 +613,14 @@ class _PendingK1Backward:
                   *self.ptrs, _stream(self.ref))
 
 
-_PENDING_WGRADS = None
-
-
 class _PendingWeightGemms:
-    """The weight-gradient GEMMs of the capsule MLPs, parked: nothing reads a
-    weight gradient before the optimiser does, so their launch can wait for a
-    later backward node with CUs to spare -- the output attention's
-    (``_SeedAttention.backward``: one workgroup per set), which like them
-    depends on the MLPs' data-gradient chain only.  ``descs`` holds device
-    addresses; ``keep`` the INPUT tensors (the outputs are the gradients
-    handed to autograd, see ``_PendingK1Backward``)."""
+    """RIDES['wgrads']: the weight-gradient GEMMs of the capsule MLPs.
+    Nothing reads a weight gradient before the optimiser does, so their launch
+    waits for a later backward node with CUs to spare -- the output
+    attention's (one workgroup per set), which like them depends on the MLPs'
+    data-gradient chain only.  ``descs`` holds device addresses; ``keep`` the
+    INPUT tensors (the outputs are the gradients handed to autograd, see
+    ``_PendingK1Backward``)."""
 
     def __init__(self, descs, n, keep, stream_ref):
         self.descs, self.n, self.keep, self.ref = descs, n, keep, stream_ref
@@ -644,13 +629,10 @@ class _PendingWeightGemms:
         _lib.call("scae_gemm_multi_f32", self.descs, self.n, _stream(self.ref))
 
 
-_PENDING_TC = None
-
-
 class _PendingTcBackward:
-    """The template colour MLP's backward, parked for the part-capsule head's
-    backward launch (same workgroup decomposition; the head reads its
-    ``g_feature``, at ``gf_ptr``).  ``keep``: inputs only."""
+    """RIDES['tc_bwd']: the template colour MLP's backward, parked for the
+    part-capsule head's backward launch (same workgroup decomposition; the
+    head reads its ``g_feature``, at ``gf_ptr``).  ``keep``: inputs only."""
 
     def __init__(self, ptrs, bm, dims, keep, gf_ptr, stream_ref):
         self.ptrs, self.bm, self.dims = ptrs, bm, dims
@@ -661,25 +643,11 @@ class _PendingTcBackward:
                   *self.dims, _stream(self.ref))
 
 
-def take_pending_tc():
-    global _PENDING_TC
-    pending, _PENDING_TC = _PENDING_TC, None
-    return pending
-
-
-def flush_pending_tc():
-    pending = take_pending_tc()
-    if pending is not None:
-        pending.launch_alone()
-
-
-_PENDING_REDUCE = None
-
-
 class _PendingReduce:
-    """The partial-row reduction of the output attention's backward, parked
-    (its outputs feed the folding products' backward only): rides in the part
-    encoder's conv backward, one launch before ``_PendingFoldBackward``."""
+    """RIDES['reduce']: the partial-row reduction of the output attention's
+    backward (its outputs feed the folding products' backward only): rides in
+    the part encoder's conv backward, one launch before
+    ``_PendingFoldBackward``."""
 
     def __init__(self, args, keep, stream_ref):
         self.args, self.keep, self.ref = args, keep, stream_ref
@@ -689,26 +657,12 @@ class _PendingReduce:
                   _stream(self.ref))
 
 
-def take_pending_reduce():
-    global _PENDING_REDUCE
-    pending, _PENDING_REDUCE = _PENDING_REDUCE, None
-    return pending
-
-
-def flush_pending_reduce():
-    pending = take_pending_reduce()
-    if pending is not None:
-        pending.launch_alone()
-
-
-_PENDING_FOLD = None
-
-
 class _PendingFoldBackward:
-    """The backward of the output attention's folding products, parked: it
-    writes parameter gradients only, and waits for the part encoder's first
-    conv backward launch (``_conv_stack_bwd``) -- 256-thread workgroups and
-    tens of microseconds of matrix tiles to hide its dependent chain behind."""
+    """RIDES['fold_bwd']: the backward of the output attention's folding
+    products.  It writes parameter gradients only, and waits for the part
+    encoder's first conv backward launch (``_conv_stack_bwd``) -- 256-thread
+    workgroups and tens of microseconds of matrix tiles to hide its dependent
+    chain behind."""
 
     def __init__(self, desc, grads, keep, stream_ref):
         self.desc, self.grads, self.keep, self.ref = desc, grads, keep, stream_ref
@@ -718,42 +672,15 @@ class _PendingFoldBackward:
                   ctypes.byref(self.grads), _stream(self.ref))
 
 
-def take_pending_fold():
-    global _PENDING_FOLD
-    pending, _PENDING_FOLD = _PENDING_FOLD, None
-    return pending
-
-
-def take_pending_weight_gemms():
-    global _PENDING_WGRADS
-    pending, _PENDING_WGRADS = _PENDING_WGRADS, None
-    return pending
-
-
 def flush_pending_backward():
     """Launch what is parked and nobody carried: the K1 backward (e.g. no
     gradient reached the capsule likelihood), the capsule MLPs' weight
-    gradients (e.g. an object encoder without the matrix-core attention)."""
-    global _PENDING_K1_BWD
-    if _PENDING_K1_BWD is not None:
-        pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
-        pending.launch_alone()
-    for pending in (take_pending_tc(), take_pending_weight_gemms(),
-                    take_pending_reduce(),
-                    take_pending_fold()):       # (the fold reads the reduction)
-        if pending is not None:
-            pending.launch_alone()
-
-
-def withdraw_log_prob_rider():
-    """After the object encoder: a rider nobody launched is dropped."""
-    global _PENDING_RIDER
-    if _PENDING_RIDER is not None and not _PENDING_RIDER.launched:
-        _PENDING_RIDER = None
+    gradients (e.g. an object encoder without the matrix-core attention), ..."""
+    _plan().flush_scope("deferring")
 
 
 class _SetEncoder(torch.autograd.Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, presence, packed, meta, *segs):
         D, Dout, L, layer_norm = meta
         _need_hip(presence, packed, *segs)
@@ -771,9 +698,9 @@ class _SetEncoder(torch.autograd.Function):
         ptrs, widths, rs, bs = _seg_arrays(segs)
         # configs[2]'s precision (inside ``mfma_bf16()``): bf16 operands for the
         # attention products of every block, forward and backward
-        ctx.bf16 = bool(_MFMA_BF16 and lib.scae_set_encoder_bf16_supported(
+        ctx.bf16 = bool(_bf16() and lib.scae_set_encoder_bf16_supported(
             N, D, Din, Dout, L, int(layer_norm)))
-        rider = _PENDING_RIDER
+        rider = ctx.plan.rider
         if rider is not None and not rider.launched and not ctx.bf16 \
                 and rider.x.device == packed.device:
             # the part decoder's likelihood rides in this launch
@@ -796,7 +723,7 @@ class _SetEncoder(torch.autograd.Function):
         ctx.slot = _slot(packed, ctx)
         return z
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gz):
         packed, hsave = ctx.saved_tensors[:2]
         segs = list(ctx.saved_tensors[2:2 + ctx.nseg])
@@ -849,7 +776,7 @@ class _PackParams(torch.autograd.Function):
     ``_flat_param_groups`` that way) the result aliases them -- no copy -- and
     the gradient is handed back as views of one buffer."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, *parts):
         ctx.shapes = [tuple(p.shape) for p in parts]
         adjacent = all(p.is_contiguous() for p in parts) and all(
@@ -863,7 +790,7 @@ class _PackParams(torch.autograd.Function):
                       (total,), (1,))
         return torch.cat([p.reshape(-1) for p in parts])
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g):
         out, off = [], 0
         for shape in ctx.shapes:
@@ -901,7 +828,7 @@ def seed_attention_supported(N, O, D, C):
 
 
 class _SeedAttention(torch.autograd.Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, h, q, wk, bk, wv, bv, presence, from_fold=False):
         _need_hip(h, q, wk, bk, wv, bv, presence)
         ctx.from_fold = bool(from_fold)
@@ -925,7 +852,7 @@ class _SeedAttention(torch.autograd.Function):
         ctx.has_presence = presence is not None
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gout):
         h, q, wk, bk, wv, bv = ctx.saved_tensors[:6]
         presence = ctx.saved_tensors[6] if ctx.has_presence else None
@@ -939,7 +866,8 @@ class _SeedAttention(torch.autograd.Function):
             partial, gh = new(rows, O * D + C * D + C), new(B, N, D)
             args = (_p(h), _p(q), _p(wk), _p(wv), _p(presence),
                     _p(gout.contiguous()), _p(gh), _p(partial), B, N, O, C)
-            parked, carried = take_pending_weight_gemms(), False
+            plan = ctx.plan
+            parked, carried = plan.take("wgrads"), False
             if parked is not None:
                 # the capsule MLPs' weight-gradient tiles as the tail of this launch
                 rc = getattr(lib, _prec("scae_seed_attention_mfma_bwd_gemm_f32"))(
@@ -957,14 +885,11 @@ class _SeedAttention(torch.autograd.Function):
                 new(C)
             red = (_p(partial), rows, _p(q), _p(wk), _p(gq), _p(gwk), _p(gbk),
                    _p(gwv), _p(gbv), O, C)
-            if ctx.from_fold and _FUSION_TARGET is not None and \
-                    _DEFERRED is not None and not _MFMA_BF16:
+            if ctx.from_fold and plan.parking and not plan.bf16:
                 # only the folding products' backward reads these: the launch
-                # waits for a carrier (``_SeedFold.backward`` launches it
-                # first if it does not wait itself)
-                global _PENDING_REDUCE
-                flush_pending_reduce()
-                _PENDING_REDUCE = _PendingReduce(red, (partial, q, wk), h)
+                # waits for a carrier (RIDES['reduce']: launched ahead of
+                # ``_SeedFold.backward``, which parks itself behind it)
+                plan.park("reduce", _PendingReduce(red, (partial, q, wk), h))
             else:
                 _lib.call("scae_seed_attention_mfma_reduce_f32", *red,
                           _stream(h))
@@ -1028,7 +953,7 @@ class _SeedFold(torch.autograd.Function):
     """(seeds, Wq, bq, Wk, bk, Wv, bv, Wo, bo, W2, b2) -> (q, wkf, bkf, wvf,
     bvf) consumed by seed_attention."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, *inputs):
         _need_hip(*inputs)
         ctx.slots = [_slot(t, ctx) for t in inputs]
@@ -1038,7 +963,7 @@ class _SeedFold(torch.autograd.Function):
         D = w2.shape[1]
         new = lambda *shape: torch.empty(*shape, device=seeds.device,
                                          dtype=seeds.dtype)
-        pro, launch = _PROLOGUE, True
+        pro, launch = ctx.plan.prologue, True
         if pro is not None:
             ptrs = [t.data_ptr() for t in inputs]
             if pro.fold_outs is not None and pro.fold_dims == (O, C, D) and \
@@ -1063,7 +988,7 @@ class _SeedFold(torch.autograd.Function):
         return tuple(t.view_as(t) for t in outs[:5]) if pro is not None \
             else outs[:5]
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_q, g_wkf, g_bkf, g_wvf, g_bvf):
         inputs, outs = ctx.saved_tensors[:11], ctx.saved_tensors[11:]
         seeds, w2 = inputs[0], inputs[9]
@@ -1083,17 +1008,19 @@ class _SeedFold(torch.autograd.Function):
             setattr(g, "d_" + name, t.data_ptr())
         # (bf16 mode has no carrier: the conv backward takes another tile form,
         # and a launch that only waits runs later, on colder caches)
-        if _FUSION_TARGET is not None and _DEFERRED is not None and \
-                not _MFMA_BF16 and all(_in_slot(t) for t in grads):
-            # parameter gradients only: the launch waits for a carrier
-            global _PENDING_FOLD
-            stale = take_pending_fold()
-            if stale is not None:       # (never in a step: one fold per model)
-                stale.launch_alone()
-            _PENDING_FOLD = _PendingFoldBackward(
-                desc, g, (inputs, outs, incoming), seeds)
+        plan = ctx.plan
+        reduce = plan.take("reduce")   # (this launch reads what that one writes)
+        if plan.parking and not plan.bf16 and \
+                all(_in_slot(t) for t in grads):
+            # parameter gradients only: the launch waits for a carrier, behind
+            # the reduction it reads (table order)
+            if reduce is not None:
+                plan.park("reduce", reduce)
+            plan.park("fold_bwd", _PendingFoldBackward(
+                desc, g, (inputs, outs, incoming), seeds))
         else:
-            flush_pending_reduce()      # (this launch reads what it writes)
+            if reduce is not None:
+                reduce.launch_alone()
             _lib.call("scae_seed_fold_bwd_f32", ctypes.byref(desc),
                       ctypes.byref(g), _stream(seeds))
         return tuple(grads)
@@ -1129,7 +1056,7 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=image.dtype)
     c1, s = weights[0].shape[0], strides[0]
     oh, ow = (H - 3) // s + 1, (W - 3) // s + 1
-    pro, launch = _PROLOGUE, True
+    pro, launch = _plan().prologue, True
     key = lambda ts: [(t.data_ptr(), tuple(t.shape)) for t in ts]
     if pro is not None and pro.first_outs is not None and \
             key([image, *weights, *biases]) == key(
@@ -1181,7 +1108,7 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
         if l == 1 and pro is not None and pro.fold_outs is not None:
             # a training step's folding products ride in this launch (the
             # largest early one); the prologue leaves them out from then on
-            if _MFMA_BF16 or pro.fold_conv_ok is False:
+            if _bf16() or pro.fold_conv_ok is False:
                 pro.fold_rides_conv = False
             elif pro.fold_fresh:
                 pro.fold_rides_conv = True    # (from the next prologue launch)
@@ -1212,7 +1139,7 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
     gws, gbs = [None] * L, [None] * L
     pending = []       # (partial, gw, gb, co, ci, splits): reduced in one launch
-    lib = _lib.load()
+    lib, plan = _lib.load(), _plan()
     for l in range(L - 1, 0, -1):
         co, ci = wshapes[l][0], wshapes[l][1]
         xin, s = acts[l - 1], strides[l]
@@ -1229,8 +1156,8 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
         # the attention's reduction in the third layer's launch, the folding
         # products' backward (which reads it) in the second's, the largest
         carried = False
-        if not _MFMA_BF16 and l <= 2:
-            parked = take_pending_reduce()
+        if not plan.bf16 and l <= 2:
+            parked = plan.take("reduce")
             if parked is not None:
                 rc = lib.scae_conv3x3_bwd_pair_reduce_f32(
                     *pair, *parked.args, st) if l == 2 else _lib.ERR_UNSUPPORTED
@@ -1239,7 +1166,7 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
                 else:
                     _lib.check(rc, "scae_conv3x3_bwd_pair_reduce_f32")
                     carried = True
-            parked = None if carried or l != 1 else take_pending_fold()
+            parked = None if carried or l != 1 else plan.take("fold_bwd")
             if parked is not None:
                 rc = lib.scae_conv3x3_bwd_pair_fold_f32(
                     *pair, ctypes.byref(parked.desc),
@@ -1276,7 +1203,7 @@ class _ConvStack(torch.autograd.Function):
     """relu(conv3x3(.. relu(conv3x3(image)) ..)): image (B, C, H, W) NCHW ->
     (B, C_last, OH, OW) as a channels-last view.  Intermediates are NHWC."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, image, strides, *wb):
         _need_hip(image, *wb)
         L = len(strides)
@@ -1290,7 +1217,7 @@ class _ConvStack(torch.autograd.Function):
         ctx.refs = [tuple(t.shape) for t in wb]
         return acts[-1].permute(0, 3, 1, 2)
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gy):
         strides, wshapes = ctx.meta
         L = len(strides)
@@ -1376,7 +1303,7 @@ class _AttentionConvPool(torch.autograd.Function):
     y = x weight^T + bias, then per capsule the softmax-over-pixels of its
     last channel pools its other P-1 channels."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias, n_caps):
         _need_hip(x, weight, bias)
         x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
@@ -1390,7 +1317,7 @@ class _AttentionConvPool(torch.autograd.Function):
         ctx.n_caps = n_caps
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         B, HW, C = x.shape
@@ -1436,7 +1363,7 @@ class _CapsuleHead(torch.autograd.Function):
     sigmoid, geometric_transform -> (pose (B,A,6), presence (B,A), feature
     (B,A,F) or None)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias, noise_u, n_caps, noise_scale, similarity):
         _need_hip(x, weight, bias, noise_u)
         x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
@@ -1458,14 +1385,15 @@ class _CapsuleHead(torch.autograd.Function):
         ctx.mark_non_differentiable(absence)
         return pose, presence, feature, absence
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_pose, g_presence, g_feature, _g_absence):
         x, weight, y, pooled = ctx.saved_tensors[:4]
         A, noise_scale, similarity, has_noise = ctx.meta
         noise_u = ctx.saved_tensors[4] if has_noise else None
         B, HW, C = x.shape
         dy = torch.empty_like(y)
-        flush_pending_tc()       # (this launch may read its g_feature)
+        # (a parked colour-MLP backward, whose g_feature this launch may read,
+        # was launched on entry: RIDES['tc_bwd'].readers)
         _lib.call("scae_capsule_head_bwd_f32", _p(y), _p(pooled), _p(noise_u),
                   noise_scale, similarity, _p(_c(g_pose)), _p(_c(g_presence)),
                   _p(_c(g_feature)), None, _p(dy), B, HW, A,
@@ -1493,7 +1421,7 @@ class _PartEncoder(torch.autograd.Function):
     the two consumers of ``feature`` get separate outputs whose gradients the
     head kernel adds."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, image, strides, post_bias, att_w, att_b, noise_u, n_caps,
                 noise_scale, similarity, *wb):
         _need_hip(image, post_bias, att_w, att_b, noise_u, *wb)
@@ -1535,7 +1463,7 @@ class _PartEncoder(torch.autograd.Function):
         ctx.mark_non_differentiable(absence)
         return pose, presence, feature, twin, absence
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_pose, g_presence, g_feature, g_twin, _g_absence):
         (strides, wshapes, A, noise_scale, similarity, has_noise, pb_shape,
          attw_shape) = ctx.meta
@@ -1549,7 +1477,7 @@ class _PartEncoder(torch.autograd.Function):
         P_ = att_w2.shape[0] // A
         head = (_p(y), _p(pooled), _p(noise_u), noise_scale, similarity,
                 _p(_c(g_pose)), _p(_c(g_presence)))
-        parked, carried = take_pending_tc(), False
+        parked, carried = ctx.plan.take("tc_bwd"), False
         if parked is not None:
             # the colour MLP's backward in front of the head's, workgroup by
             # workgroup -- if its g_feature is one of the two gradients here
@@ -1614,13 +1542,11 @@ def attention_conv_pool(x, weight, bias, n_caps):
 # ----------------------------------------------------------------------------
 # class probabilities of SCAE.forward (stacked_capsule_auto_encoder.py:205-212)
 # ----------------------------------------------------------------------------
-_PENDING_CLASS_PROBS = None
-
-
 class _PendingClassProbs:
-    """The class-probability launch of SCAE.forward, parked inside a fused
-    step until ``_LossTail.forward`` carries it (or ``flush_pending_forward``
-    launches it: a step without the fused loss tail)."""
+    """RIDES['class_probs']: the class-probability launch of SCAE.forward,
+    parked inside a fused step until ``_LossTail.forward`` carries it (or
+    ``flush_pending_forward`` launches it: a step without the fused loss
+    tail)."""
 
     def __init__(self, args, keep, stream_ref):
         self.args, self.keep, self.ref = args, keep, stream_ref
@@ -1629,19 +1555,10 @@ class _PendingClassProbs:
         _lib.call("scae_class_probs_f32", *self.args, _stream(self.ref))
 
 
-def take_pending_class_probs():
-    global _PENDING_CLASS_PROBS
-    pending, _PENDING_CLASS_PROBS = _PENDING_CLASS_PROBS, None
-    return pending
-
-
-_PENDING_COMBINE = None
-
-
 class _PendingCombine:
-    """The batch combine of a loss-tail forward launched with
-    ``defer_combine``: carried by the tail's backward launch, or launched on
-    its own (``scae_loss_tail_combine_f32``) when no backward follows."""
+    """RIDES['combine']: the batch combine of a loss-tail forward launched
+    with ``defer_combine``: carried by the tail's backward launch, or launched
+    on its own (``scae_loss_tail_combine_f32``) when no backward follows."""
 
     def __init__(self, tail_args, keep, loss_ptr, out_ptr, stream_ref):
         self.tail, self.keep, self.ref = tail_args, keep, stream_ref
@@ -1653,23 +1570,10 @@ class _PendingCombine:
         _lib.call("scae_loss_tail_combine_f32", *self.tail, _stream(self.ref))
 
 
-def take_pending_combine():
-    global _PENDING_COMBINE
-    pending, _PENDING_COMBINE = _PENDING_COMBINE, None
-    return pending
-
-
-def flush_pending_combine():
-    pending = take_pending_combine()
-    if pending is not None:
-        pending.launch_alone()
-
-
 def flush_pending_forward():
-    pending = take_pending_class_probs()
-    if pending is not None:
-        pending.launch_alone()
-    flush_pending_combine()
+    """Launch the forward launches still parked on the current plan (the
+    op-by-op loss reads what they write)."""
+    _plan().flush_scope("fusing")
 
 
 def class_probs_supported(O, ncls):
@@ -1683,7 +1587,7 @@ class _ClassProbs(torch.autograd.Function):
     reference, whose inputs are detached); the rarely-needed backward runs the
     plain ops."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, caps_presence, posterior, weight, bias, extra_sums):
         _need_hip(caps_presence, posterior, weight, bias)
         cp, post = caps_presence.detach().contiguous(), \
@@ -1697,20 +1601,20 @@ class _ClassProbs(torch.autograd.Function):
         args = (_p(cp), _p(post), _p(weight), _p(bias), _p(prior),
                 _p(posterior_prob), B, O1 - 1, M, ncls, _sum_jobs(extra),
                 len(extra))
-        if _FUSION_TARGET is not None:
+        if ctx.plan.fused:
             # inside a fused step nothing reads these before SCAE.loss: the
             # launch waits for the loss tail's per-image launch to carry it
-            flush_pending_forward()
-            global _PENDING_CLASS_PROBS
-            _PENDING_CLASS_PROBS = _PendingClassProbs(
-                args, (cp, post, weight, bias, prior, posterior_prob, extra), cp)
+            ctx.plan.flush_scope("fusing")
+            ctx.plan.park("class_probs", _PendingClassProbs(
+                args, (cp, post, weight, bias, prior, posterior_prob, extra),
+                cp))
         else:
             _lib.call("scae_class_probs_f32", *args, _stream(cp))
         ctx.save_for_backward(cp, post, weight, bias)
         ctx.set_materialize_grads(False)
         return prior, posterior_prob
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_prior, g_post):
         cp, post, weight, bias = ctx.saved_tensors
         with torch.enable_grad():
@@ -1744,8 +1648,9 @@ def template_color_supported(M, C, F, H1, template_nonlin, color_nonlin):
 
 
 class _ColoredTemplates(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, feature, w1, b1, w2, b2, tnl, cnl):
+    @_fwd
+    def forward(ctx, logits, feature, w1, b1, w2, b2, tnl, cnl,
+                feature_node=None):
         _need_hip(logits, feature, w1, b1, w2, b2)
         logits, feature, w1, b1, w2, b2 = (t.contiguous() for t in (
             logits, feature, w1, b1, w2, b2))
@@ -1762,9 +1667,14 @@ class _ColoredTemplates(torch.autograd.Function):
         ctx.codes = (tnl, cnl)
         ctx.slots = [_slot(t, ctx) for t in (logits, w1, b1, w2, b2)]
         ctx.set_materialize_grads(False)
+        # may the backward's launch wait for the part-capsule head's?  Only
+        # when that node is the SOLE reader of g_feature: the fused part
+        # encoder hands every consumer of ``feature`` its own output (the
+        # twin), so autograd never adds anything to this one's gradient
+        ctx.feature_node = feature_node
         return raw, templates
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_raw, g_templates):
         logits, feature, w1, b1, w2, b2, color = ctx.saved_tensors
         _, M, C, th, tw = logits.shape
@@ -1786,34 +1696,35 @@ class _ColoredTemplates(torch.autograd.Function):
         outs = [_grad_out(sl, t) for sl, t in zip(ctx.slots[1:],
                                                   (w1, b1, w2, b2))]
         # (parked only when the column sums of ``partial`` wait too)
-        if _FUSION_TARGET is not None and _DEFERRED is not None and \
-                _in_slot(g_logits) and all(_in_slot(o) for o in outs):
+        if ctx.plan.parking and ctx.feature_node == "_PartEncoderBackward" \
+                and _in_slot(g_logits) and all(_in_slot(o) for o in outs):
             # the part-capsule head's backward, the only reader of g_feature,
             # runs the same (image, capsule group) workgroups: this launch
-            # waits for it (``_PartEncoder.backward`` / ``_CapsuleHead.backward``
-            # launch it first if they cannot carry it)
-            global _PENDING_TC
-            flush_pending_tc()
-            _PENDING_TC = _PendingTcBackward(
+            # waits for it (``_PartEncoder.backward`` launches it first if it
+            # cannot carry it)
+            ctx.plan.park("tc_bwd", _PendingTcBackward(
                 ptrs, (B, M), dims, (logits, feature, w1, b1, w2, b2, color,
                                      g_templates, g_raw, partial),
-                g_feature.data_ptr(), logits)
+                g_feature.data_ptr(), logits))
         else:
             _lib.call("scae_template_color_bwd_f32", *ptrs, B, M, *dims,
                       _stream(logits))
         gw1, gb1, gw2, gb2 = _sum_rows(
             partial, [(H1, F), (H1,), (C, H1), (C,)], outs=outs,
             defer=all(sl is not None for sl in ctx.slots[1:5]))
-        return g_logits, g_feature, gw1, gb1, gw2, gb2, None, None
+        return g_logits, g_feature, gw1, gb1, gw2, gb2, None, None, None
 
 
 def colored_templates(template_logits, feature, w1, b1, w2, b2,
                       template_nonlin, color_nonlin):
     """-> (raw_templates (1,M,C,h,w), templates (B,M,C,h,w)); nonlin names
     'sigmoid' | 'relu1'."""
+    # (which node made ``feature``: see _ColoredTemplates.forward)
+    node = type(feature.grad_fn).__name__ if feature.grad_fn is not None \
+        else None
     return _ColoredTemplates.apply(template_logits, feature, w1, b1, w2, b2,
                                    _NONLIN_CODE[template_nonlin],
-                                   _NONLIN_CODE[color_nonlin])
+                                   _NONLIN_CODE[color_nonlin], node)
 
 
 # ----------------------------------------------------------------------------
@@ -1869,7 +1780,7 @@ class _GroupedMLP(torch.autograd.Function):
     the ReLU output of a producer with ``grad_pregated`` -- the returned input
     gradient is gated by x > 0 in the epilogue of the data-gradient GEMM."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, ones_input, n_layers, grad_pregated, x_is_relu,
                 pad_out, *wb):
         _need_hip(x, *wb)
@@ -1913,7 +1824,7 @@ class _GroupedMLP(torch.autograd.Function):
         ctx.slots = [_slot(t, ctx) for t in wb]
         return acts[-1]
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gy):
         ones_input, L, has_bias, pregated, x_is_relu = ctx.meta
         x = ctx.saved_tensors[0]
@@ -1994,7 +1905,7 @@ class _Linear(torch.autograd.Function):
     epilogue), backward one (weight + bias gradient and data gradient as a
     pair)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias):
         _need_hip(x, weight, bias)
         N, K = weight.shape
@@ -2012,7 +1923,7 @@ class _Linear(torch.autograd.Function):
         ctx.slots = (_slot(weight, ctx), _slot(bias, ctx) if bias is not None else None)
         return y.view(*x.shape[:-1], N)
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gy):
         x2, weight = ctx.saved_tensors
         N, K = weight.shape
@@ -2050,7 +1961,7 @@ class HipLinear(torch.nn.Linear):
 
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and \
-                self.weight.dtype == torch.float32 and not _MFMA_BF16 and \
+                self.weight.dtype == torch.float32 and not _bf16() and \
                 not torch.is_autocast_enabled("cuda"):
             return linear(x, self.weight, self.bias)
         return torch.nn.functional.linear(x, self.weight, self.bias)
@@ -2061,7 +1972,7 @@ class _LayerNorm(torch.autograd.Function):
     (set_transformer.py:114-131): one wave per row; the weight / bias gradients
     leave as per-workgroup partial rows summed by ``_sum_rows``."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias, eps):
         _need_hip(x, weight, bias)
         d = x.shape[-1]
@@ -2081,7 +1992,7 @@ class _LayerNorm(torch.autograd.Function):
                      _slot(bias, ctx) if bias is not None else None)
         return y.view(x.shape)
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gy):
         x2, mean, rstd = ctx.saved_tensors[:3]
         weight = ctx.saved_tensors[3] if ctx.has[0] else None
@@ -2122,7 +2033,7 @@ class HipLayerNorm(torch.nn.LayerNorm):
 def mlp_chain_supported(x, layers):
     """The one-launch chain (csrc/mlp_chain.hip) covers fp32, <= 4 layers,
     widths <= scae_mlp_chain_max_width()."""
-    if _MFMA_BF16 or not x.is_cuda or x.dtype != torch.float32 or \
+    if _bf16() or not x.is_cuda or x.dtype != torch.float32 or \
             not 1 <= len(layers) <= 4:
         return False
     wmax = _lib.load().scae_mlp_chain_max_width()
@@ -2240,12 +2151,8 @@ def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
     # is accumulated by autograd as soon as this node returns)
     if park and L <= 4 and all(_in_slot(t) for t in gws) and \
             all(_in_slot(t) for t in gbs if t is not None):
-        global _PENDING_WGRADS
-        flush_pending = take_pending_weight_gemms()
-        if flush_pending is not None:
-            flush_pending.launch_alone()
-        _PENDING_WGRADS = _PendingWeightGemms(
-            descs, L, (x, gs, acts, [w for w in weights]), x)
+        _plan().park("wgrads", _PendingWeightGemms(
+            descs, L, (x, gs, acts, [w for w in weights]), x))
     else:
         _lib.call("scae_gemm_multi_f32", descs, L, _stream(x))
     return gx, gws, gbs
@@ -2260,7 +2167,7 @@ class _MLPChain(torch.autograd.Function):
     (``_GroupedMLP``'s ``grad_pregated`` contract); backward = one launch for
     the data-gradient chain + one for all weight-gradient GEMMs."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, ones_flags, x_is_relu, *wb):
         L = len(ones_flags)
         _need_hip(x, *wb)
@@ -2276,7 +2183,7 @@ class _MLPChain(torch.autograd.Function):
         ctx.slots = [_slot(t, ctx) for t in wb]
         return acts[-1]
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gy):
         ones_flags, has_bias, x_is_relu = ctx.meta
         L = len(ones_flags)
@@ -2302,7 +2209,7 @@ class _ChainVotes(torch.autograd.Function):
     gradients (one launch), the bias column sums (deferred).  Outputs as
     ``capsule_votes``."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, ones_flags, vflags, noise_scale, cpr_static, b_cvr,
                 b_caps, b_vote, b_scale, noise_caps, noise_vote, *wb):
         L = len(ones_flags)
@@ -2357,7 +2264,7 @@ class _ChainVotes(torch.autograd.Function):
         ctx.mark_non_differentiable(reg)
         return vote, scale, vp, lc, lv, reg_loss, caps_presence, reg
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gvote, gscale, gvp, glc, glv, greg, gcp, _greg_partial):
         ones_flags, has_bias, noise_scale, (V, ldp, sim, lvs, adef) = ctx.meta
         L = len(ones_flags)
@@ -2397,7 +2304,7 @@ class _ChainVotes(torch.autograd.Function):
         gx, gws, gbs = _chain_backward(
             x, weights, acts, ones_flags, has_bias, False, ctx.slots, True,
             gpre=ggated, votes=v,
-            park=_FUSION_TARGET is not None and _DEFERRED is not None)
+            park=ctx.plan.parking)
         # bias gradients: batch sums of column blocks of gall (B, O*A)
         outs = [_grad_out(sl, t) for sl, t in zip(ctx.vslots, vargs)]
         gall_rows = torch.as_strided(gall, (B, O * ldp), (O * ldp, 1))
@@ -2456,7 +2363,7 @@ def grouped_mlp(x, weights, biases, ones_input=False, grad_pregated=False,
 # K3 capsule votes (object_decoder.py:160-225)
 # ----------------------------------------------------------------------------
 class _CapsuleVotes(torch.autograd.Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, all_param, cpr_static, b_cvr, b_caps, b_vote, b_scale,
                 noise_caps, noise_vote, noise_scale, similarity,
                 learn_vote_scale, allow_deformations, param_is_relu,
@@ -2502,7 +2409,7 @@ class _CapsuleVotes(torch.autograd.Function):
         ctx.mark_non_differentiable(reg)
         return vote, scale, vp, lc, lv, reg_loss, caps_presence, reg
 
-    @staticmethod
+    @_bwd
     def backward(ctx, gvote, gscale, gvp, glc, glv, greg, gcp, _greg_partial):
         saved = list(ctx.saved_tensors)
         caps_arg = saved.pop(0)
@@ -2566,7 +2473,7 @@ def capsule_votes(all_param, cpr_static, bias_cvr, bias_caps, bias_vote,
 # K4 capsule likelihood (object_decoder.py:257-372)
 # ----------------------------------------------------------------------------
 class _CapsuleLikelihood(torch.autograd.Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, vote, scale, vp, dummy_vote, x, presence, defer_sum):
         _need_hip(vote, scale, vp, dummy_vote, x, presence)
         vote, scale, vp, dummy_vote, x, presence = (
@@ -2600,7 +2507,7 @@ class _CapsuleLikelihood(torch.autograd.Function):
         return (lpp, binary, winner, winner_p, widx, from_caps, soft, soft_p,
                 post, mlp, mlogit, log_prob)
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_lpp, _gb, g_w, g_wp, _gi, _gf, g_s, g_sp, g_post,
                  g_mlp, g_mlogit, g_log_prob):
         saved = ctx.saved_tensors
@@ -2617,8 +2524,13 @@ class _CapsuleLikelihood(torch.autograd.Function):
         gdummy = torch.empty(B, M, 6, device=x.device, dtype=x.dtype)
         gin = [_c(g) for g in (g_lpp, g_w, g_wp, g_s, g_sp, g_post, g_mlp,
                                g_mlogit)]
-        global _PENDING_K1_BWD
-        pending, _PENDING_K1_BWD = _PENDING_K1_BWD, None
+        pending = ctx.plan.take("k1_bwd")
+        if pending is not None and any(
+                g is not None for g in (g_w, g_wp, g_s, g_sp)):
+            # a decoder fed by the (soft) winners ('soft' / 'hard' votes or
+            # presences): these gradients are the parked launch's outputs
+            pending.launch_alone()
+            pending = None
         if pending is not None and pending.ref.device == vote.device:
             # the parked K1 backward and this kernel in one launch
             k = _lib.LikelihoodBwdDesc()
@@ -2674,7 +2586,7 @@ def loss_tail_supported(B, O, n_classes):
 
 
 class _LossTail(torch.autograd.Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, lpp, posterior, caps_presence, cls_w, cls_b, label,
                 rec_sums, reg, cfg):
         _need_hip(lpp, posterior, caps_presence, cls_w, cls_b, rec_sums, reg)
@@ -2705,7 +2617,7 @@ class _LossTail(torch.autograd.Function):
         # workgroup, a dependent launch of its own) becomes a workgroup of the
         # backward launch.  A forward no backward follows is completed by
         # ``flush_pending_forward`` (the step's exit).
-        defer = _FUSION_TARGET is not None and rec_sums is not None and \
+        defer = ctx.plan.fused and rec_sums is not None and \
             any(ctx.needs_input_grad) and \
             bool(_lib.load().scae_loss_tail_defer_preferred(B, O))
         ex.defer_combine = int(defer)
@@ -2714,7 +2626,7 @@ class _LossTail(torch.autograd.Function):
             ints[0], ints[1], ints[3]), device=lpp.device, dtype=lpp.dtype)
         tail = (_p(lpp), _p(posterior), _p(caps_presence), _p(cls_w), _p(cls_b),
                 lab, ctypes.byref(ex), _p(out), _p(ws), *ints, w5, wc)
-        parked = take_pending_class_probs()
+        parked = ctx.plan.take("class_probs")
         if parked is not None:    # SCAE.forward's class probabilities ride along
             _lib.call("scae_loss_tail_fwd_class_probs_f32", *tail, *parked.args,
                       _stream(lpp))
@@ -2730,16 +2642,15 @@ class _LossTail(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.deferred = None
         if defer:
-            global _PENDING_COMBINE
-            flush_pending_combine()
             # (addresses only: ``loss`` / ``out`` are this node's outputs)
-            ctx.deferred = _PENDING_COMBINE = _PendingCombine(
+            ctx.deferred = _PendingCombine(
                 tail, (lpp, posterior, caps_presence, cls_w, cls_b, label,
                        rec_sums, reg, ws, w5, ex), loss.data_ptr(),
                 out.data_ptr(), lpp)
+            ctx.plan.park("combine", ctx.deferred)
         return loss, out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_loss, gout):
         saved = list(ctx.saved_tensors)
         lpp, posterior, cp, ws = saved[:4]
@@ -2771,9 +2682,9 @@ class _LossTail(torch.autograd.Function):
             g_loss = g_loss.contiguous()
             ex.g_loss = g_loss.data_ptr()
         pend = ctx.deferred
-        if pend is not None and pend is _PENDING_COMBINE:
+        if pend is not None and ctx.plan.holds("combine", pend):
             # the forward's combine workgroup rides in this launch
-            take_pending_combine()
+            ctx.plan.take("combine")
             ex.defer_combine, ex.loss, ex.out12 = 1, pend.loss_ptr, pend.out_ptr
         w5 = (ctypes.c_float * 5)(*weights)
         lab = None if label is None else ctypes.c_void_p(label.data_ptr())
@@ -2861,13 +2772,13 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
         # handed to autograd now and filled by that launch -- their consumers
         # (template generator, part encoder, the deferred column sums) all run
         # after it
-        global _PENDING_K1_BWD
-        flush_pending_backward()
+        plan = _plan()
+        plan.flush_scope("deferring")
         addr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
-        _PENDING_K1_BWD = _PendingK1Backward(
+        plan.park("k1_bwd", _PendingK1Backward(
             d, ctx_tensors, (x, lse_post, lse_prior, g_tile),
             (addr(g_templates), g_alpha_p, addr(g_pose), addr(g_presence),
-             addr(g_bg_image), g_scal), templates)
+             addr(g_bg_image), g_scal), templates))
     elif g_tile is not None:
         _lib.call("scae_render_gmm_sums_bwd_f32", ctypes.byref(d), _p(x),
                   _p(lse_post), _p(lse_prior), _p(g_tile), _p(g_templates),
@@ -2916,7 +2827,7 @@ def _prep_decoder(tensors):
 class _RenderTemplates(torch.autograd.Function):
     """materialising path: (transformed_templates, mixing_logits)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, output_size, *tensors):
         t = _prep_decoder(tensors)
         d, (B, M, C, th, tw, H, W) = _make_desc(t, output_size)
@@ -2934,7 +2845,7 @@ class _RenderTemplates(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         return tt, ml
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_tt, g_ml):
         if g_tt is None and g_ml is None:
             return (None,) * 10
@@ -2952,7 +2863,7 @@ class _RenderTemplates(torch.autograd.Function):
 class _RenderGmmLogProb(torch.autograd.Function):
     """fused path: log_prob(x) from the compact decoder inputs."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, output_size, x, *tensors):
         t = _prep_decoder(tensors)
         _need_hip(x)
@@ -2973,7 +2884,7 @@ class _RenderGmmLogProb(torch.autograd.Function):
         ctx.slots = [_slot(v, ctx) for v in tensors]
         return lp
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_lp):
         x, lse_post, lse_prior = ctx.saved_tensors[:3]
         it = iter(ctx.saved_tensors[3:])
@@ -2994,8 +2905,9 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
     """fused path for the training loss: per (image, pixel tile) sums of
     log_prob(x) instead of the per-pixel map -> (B, tiles)."""
 
-    @staticmethod
-    def forward(ctx, output_size, x, rider, *tensors):
+    @_fwd
+    def forward(ctx, output_size, x, rider, parkable, *tensors):
+        ctx.parkable = bool(parkable)
         t = _prep_decoder(tensors)
         _need_hip(x)
         x = x.detach().contiguous()
@@ -3020,7 +2932,7 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
         ctx.slots = [_slot(v, ctx) for v in tensors]
         return sums
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g_sums):
         x, lse_post, lse_prior = ctx.saved_tensors[:3]
         it = iter(ctx.saved_tensors[3:])
@@ -3032,12 +2944,18 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
                                        alpha_shape=ctx.alpha_shape,
                                        # (only where every consumer of the
                                        # gradients runs later: sums deferred,
-                                       # inside a fused training step)
-                                       park=_FUSION_TARGET is not None
-                                       and _DEFERRED is not None))
+                                       # inside a fused training step, pose
+                                       # and presence not the capsule
+                                       # likelihood's own outputs)
+                                       park=ctx.plan.parking
+                                       and ctx.parkable))
         if grads[1] is not None:
             grads[1] = grads[1].view(ctx.alpha_shape)
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
+
+
+_K1_GRADIENT_READERS = ("_ColoredTemplatesBackward", "_PartEncoderBackward",
+                        "_CapsuleHeadBackward")
 
 
 def render_gmm_log_prob_sums(inputs: "DecoderInputs", x):
@@ -3051,14 +2969,24 @@ def render_gmm_log_prob_sums(inputs: "DecoderInputs", x):
     if x.requires_grad:
         raise ScaeHipError("fused log_prob does not differentiate w.r.t. its "
                            "target; use the materialised mixture for that")
-    global _PENDING_RIDER
-    rider = _PENDING_RIDER
+    plan = _plan()
+    rider = plan.rider
     if rider is not None and rider.launched and \
             rider.key == LogProbRider.key_of(inputs, x):
-        _PENDING_RIDER = None         # consumed
+        plan.rider = None         # consumed
     else:
         rider = None
-    return _RenderGmmLogProbSums.apply(inputs.output_size, x, rider,
+    # the backward's launch may wait for the capsule likelihood's backward to
+    # carry it (RIDES['k1_bwd']) when every reader of its outputs is a
+    # plan-aware node (which launches a parked K1 before it starts) or a leaf
+    # -- and not that carrier itself: a decoder fed with the likelihood's
+    # (soft) winners, vote_type / presence_type 'soft' or 'hard'
+    # (stacked_capsule_auto_encoder.py:146-156), is read by it
+    parkable = all(
+        t is None or t.grad_fn is None
+        or type(t.grad_fn).__name__ in _K1_GRADIENT_READERS
+        for t in (inputs.templates, inputs.pose, inputs.presence))
+    return _RenderGmmLogProbSums.apply(inputs.output_size, x, rider, parkable,
                                        *inputs.tensors())
 
 
@@ -3093,7 +3021,7 @@ def _gmm_dims(loc, ml):
 
 
 class _GmmLogProb(torch.autograd.Function):
-    @staticmethod
+    @_fwd
     def forward(ctx, loc, ml, sigma, x):
         _need_hip(loc, ml, sigma, x)
         loc, ml, sigma, x = _c(loc), _c(ml), _c(sigma), _c(x)
@@ -3104,7 +3032,7 @@ class _GmmLogProb(torch.autograd.Function):
         ctx.save_for_backward(loc, ml, sigma, x)
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g):
         loc, ml, sigma, x = ctx.saved_tensors
         B, K, C, Cm, P = _gmm_dims(loc, ml)
@@ -3137,7 +3065,7 @@ class _GmmMean(torch.autograd.Function):
     w.r.t. both operands; the backward of this inspection path is composed
     from device tensor ops."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, loc, ml):
         loc, ml = _c(loc), _c(ml)
         B, K, C, Cm, P = _gmm_dims(loc, ml)
@@ -3147,7 +3075,7 @@ class _GmmMean(torch.autograd.Function):
         ctx.save_for_backward(loc, ml)
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g):
         loc, ml = ctx.saved_tensors
         prob = torch.softmax(ml, 1)
@@ -3173,7 +3101,7 @@ class _GmmMode(torch.autograd.Function):
     differentiable w.r.t. loc only -- the incoming gradient goes to the winning
     component -- exactly like the reference's sum(one_hot * loc)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, loc, ml, sigma, maximum):
         loc, ml = _c(loc), _c(ml)
         B, K, C, Cm, P = _gmm_dims(loc, ml)
@@ -3184,7 +3112,7 @@ class _GmmMode(torch.autograd.Function):
         ctx.loc_shape = loc.shape
         return out
 
-    @staticmethod
+    @_bwd
     def backward(ctx, g):
         (ml,) = ctx.saved_tensors
         # (with `maximum` and a shared scale the added density is the same

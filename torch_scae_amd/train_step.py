@@ -77,6 +77,11 @@ class TrainStep:
         # the batch hand-over in ONE launch ahead of the step (ops.StepPrologue)
         self._pro = ops.StepPrologue() if prologue and \
             self.device.type == "cuda" else None
+        # this step's launch plan (step_plan.py): the only holder of its
+        # parked launches, deferred column sums, prologue buffers and noise
+        # generators -- nothing of a step lives in module state, so several
+        # steps (models) can interleave in one process
+        self.plan = ops.StepPlan("train step", prologue=self._pro)
         self.collective_mode = None if not self.collective else \
             "in graph" if self.in_graph_collective else \
             "2 buckets, the first overlapping the encoder backward" \
@@ -130,14 +135,15 @@ class TrainStep:
     def _part_a(self):
         """forward + loss + backward (split: down to the decoders' inputs)."""
         self.flat.clear_grads()
-        with ops.mfma_bf16(self.autocast_dtype is not None), \
-                ops.step_prologue(self._pro), self._lazy(), \
-                ops.step_fusion(self.image if self.fuse_kernels else None):
+        plan = self.plan
+        with plan.active(), plan.precision(self.autocast_dtype is not None), \
+                self._lazy(), \
+                plan.fusing(self.image if self.fuse_kernels else None):
             res = self.model(self.image)
             loss, info = self.model.loss(res, self.image, self.label)
             # a resident seed: no ones_like fill per step; the column sums that
             # only produce parameter gradients wait for ONE launch at the end
-            with ops.deferred_param_sums():
+            with plan.deferring():
                 loss.backward(self._one)
         self._cut = res.get("_phase_cut") if self.split else None
         self.flat.gather_grads(None if self._cut is None else 0)
@@ -168,8 +174,9 @@ class TrainStep:
         self._cut = None
         keep = [(t, l.grad) for t, l in zip(srcs, leaves)
                 if l.grad is not None]
-        with ops.mfma_bf16(self.autocast_dtype is not None), \
-                ops.deferred_param_sums():
+        plan = self.plan
+        with plan.active(), plan.precision(self.autocast_dtype is not None), \
+                plan.deferring():
             torch.autograd.backward([t for t, _ in keep],
                                     [g for _, g in keep])
         self.flat.gather_grads(1)
@@ -258,7 +265,8 @@ class TrainStep:
     def _refresh_prologue(self):
         """Noise + folding products for the next forward (no batch)."""
         if self._pro is not None:
-            self._pro.launch(stream_ref=self.image)
+            with self.plan.active():
+                self._pro.launch(stream_ref=self.image)
 
     def _stage(self, image, label):
         """The batch into the resident input buffers: one launch when both
@@ -272,7 +280,8 @@ class TrainStep:
             and image.device == self.device == label.device
         if self._pro is not None:
             if direct:
-                self._pro.launch(self.image, image, self.label, label)
+                with self.plan.active():
+                    self._pro.launch(self.image, image, self.label, label)
             else:
                 self.image.copy_(image, non_blocking=True)
                 self.label.copy_(label, non_blocking=True)
