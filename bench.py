@@ -99,7 +99,14 @@ def parse():
                          "forward, one of them over B x n_obj_caps images")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: one all-reduce after the whole backward instead "
-                         "of the bucketed one that overlaps the encoder backward")
+                         "of the bucketed one that overlaps the encoder backward "
+                         "(= --comm-mode '1 bucket')")
+    ap.add_argument("--comm-mode", default="auto",
+                    choices=["auto", "2 buckets", "1 bucket", "in graph"],
+                    help="N>1 / --force-spawn: how the gradient all-reduce is "
+                         "scheduled (train_step.TrainStep).  auto: all three "
+                         "are measured on the ranks at hand (comm.modes) and "
+                         "the fastest one runs the timed region")
     return ap.parse_args()
 
 
@@ -532,6 +539,67 @@ def timing_summary(block_s, steps):
             "p90_ms": round(ms[-1 - len(ms) // 10], 4)}
 
 
+def capsule_state(model, image):
+    """Where training has taken the part capsules: presence and the scale of
+    the pose's linear part for a batch (eval mode: no presence noise).  On
+    U[0,1) noise images the capsules switch off (presence -> 1e-18, scale ->
+    0.01: the data-dependent K1 backward then runs in its collapsed-pose
+    regime); structured images keep them alive."""
+    enc = model.part_encoder
+    was = enc.training
+    with torch.no_grad():
+        parts = enc.eval()(image)
+    enc.train(was)
+    pres, pose = parts.presence.float(), parts.pose.float()
+    lin = torch.stack([pose[..., 0], pose[..., 1], pose[..., 3],
+                       pose[..., 4]], -1).abs().amax(-1)
+    return {"presence_median": float(pres.median()),
+            "presence_mean": float(pres.mean()),
+            "presence_below_1e-16": round(float((pres < 1e-16).float().mean()), 4),
+            "pose_scale_median": round(float(lin.median()), 4),
+            "pose_scale_min": round(float(lin.min()), 4)}
+
+
+def structured_leg(device, n_steps=600):
+    """cfg-2 trained on STRUCTURED synthetic images (data.stroke_batches: ten
+    stroke glyphs under random affine warps) instead of U[0,1) noise: the same
+    replayed step, timed over `n_steps` steps in blocks of 50, with the state
+    of the part capsules before / after next to it (and, for contrast, after
+    the same number of steps on noise)."""
+    from torch_scae_amd.data import stroke_batches
+    cfg = CONFIGS["mnist_24_24_bs128"]
+    B = cfg["batch"]
+    out = {"workload": "mnist_24_24_bs128 on structured synthetic images "
+                       "(data.stroke_batches: 10 stroke glyphs, random affine "
+                       f"warps), {n_steps} steps", "steps": n_steps}
+    for kind in ("strokes", "noise"):
+        step = make_step(cfg, device, seed=0)
+        if kind == "strokes":
+            images, labels = stroke_batches(32, B, cfg["model"]["image_shape"],
+                                            seed=3000, device=device)
+        else:
+            images, labels = synthetic_batches(cfg, device, 3000, n_batches=32)
+        n = images.shape[0]
+        before = capsule_state(step.model, images[0])
+        first = float(step(images[0], labels[0]))
+        blocks = timed_blocks(step, images, labels, 50, 0, n_steps // 50,
+                              torch.cuda.synchronize)
+        t = timing_summary(blocks, 50)
+        leg = {"ms_per_step": t["median_ms"],
+               "images_per_sec": round(B / t["median_ms"] * 1e3, 1),
+               "timing": t, "loss_first": round(first, 3),
+               "loss_last": round(float(step.loss), 3),
+               "capsules_before": before,
+               "capsules_after": capsule_state(step.model, images[n - 1])}
+        if kind == "strokes":
+            out.update(leg)
+        else:
+            out["same_steps_on_uniform_noise"] = leg
+        del step
+        torch.cuda.empty_cache()
+    return out
+
+
 def extra_workloads(device, budget_s=25.0):
     """The other BASELINE.json configurations and step variants, one short
     measurement each on this GPU (same timing procedure, 5 blocks of 20 steps
@@ -584,33 +652,48 @@ def extra_workloads(device, budget_s=25.0):
     return out
 
 
+def probe_modes(make, which, images, labels, barrier, reduce_max, steps=40,
+                warmup=10, blocks=3):
+    """ms per step of the collective modes `which` of TrainStep on the ranks at
+    hand, each on a FRESH model (the step time depends on how far training has
+    got, see capsule_state): the contract's timing procedure (barrier +
+    synchronize around exactly `steps` steps, MAX over ranks), median of
+    `blocks`.  Every rank gets the same numbers, hence the same choice.
+    "off": the collective-free build of the same step (its ranks drift apart,
+    so it runs last)."""
+    out = {}
+    for mode in which:
+        step = make(mode)
+        t = timed_blocks(step, images, labels, steps, warmup, blocks, barrier,
+                         reduce_max)
+        out[mode] = {"ms_per_step": round(float(np.median(t)) / steps * 1e3, 4),
+                     "runs_as": step.collective_mode}
+        del step
+        torch.cuda.empty_cache()
+    return out
+
+
 def comm_diagnostics(step, images, labels, steps, barrier, device, world):
-    """N > 1 (or --force-spawn): where the step's time goes around the
-    collective, from HIP events on this rank's streams.  allreduce_us: the
-    flat-gradient all-reduce(s) alone (mean of 20, back to back, nothing to
-    overlap); step_no_comm_ms: the same replayed step with the collective
-    switched off (identical kernels, no RCCL call); exposed_us = step with
-    collective - step without = what the overlap did not hide."""
+    """N > 1 (or --force-spawn): the collective by itself, from HIP events on
+    this rank's streams.  allreduce_us: the flat-gradient all-reduce(s) alone
+    (mean of 20, back to back, nothing to overlap); step_ms: the timed step
+    once more, per rank.  What the collective costs the step (graph split and
+    stream hand-offs included) is in ``modes``: every mode and the
+    collective-free build, each measured on a fresh model."""
     n = images.shape[0]
 
-    def run(k):
+    def run(st, k):
         barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), \
             torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(k):
-            step(images[i % n], labels[i % n])
+            st(images[i % n], labels[i % n])
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / k        # ms per step on this rank
 
-    with_comm = run(steps)
-    step.skip_collective = True
-    try:
-        run(3)
-        without = run(steps)
-    finally:
-        step.skip_collective = False
+    with_comm = run(step, steps)
     buckets = [0, 1] if step.split else [None]
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), \
@@ -628,7 +711,7 @@ def comm_diagnostics(step, images, labels, steps, barrier, device, world):
     e1.record()
     torch.cuda.synchronize()
     allreduce_us = e0.elapsed_time(e1) / reps * 1e3
-    mine = torch.tensor([with_comm, without, allreduce_us], device=device,
+    mine = torch.tensor([with_comm, allreduce_us], device=device,
                         dtype=torch.float64)
     every = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(every, mine)
@@ -640,17 +723,13 @@ def comm_diagnostics(step, images, labels, steps, barrier, device, world):
         "bucket_bytes": [step.flat.n_front * 4,
                          (step.flat.numel - step.flat.n_front) * 4]
         if step.split else [nbytes],
-        "allreduce_us": round(float(every[:, 2].max()), 1),
+        "allreduce_us": round(float(every[:, 1].max()), 1),
         "allreduce_busbw_GBps": round(
             2 * (world - 1) / max(1, world) * nbytes
-            / (float(every[:, 2].max()) * 1e-6) / 1e9, 1),
+            / (float(every[:, 1].max()) * 1e-6) / 1e9, 1),
         "step_ms": round(float(every[:, 0].max()), 4),
-        "step_no_comm_ms": round(float(every[:, 1].max()), 4),
-        "exposed_us": round(float(every[:, 0].max() - every[:, 1].max())
-                            * 1e3, 1),
         "per_rank_ms": [round(float(v), 4) for v in every[:, 0]],
-        "per_rank_no_comm_ms": [round(float(v), 4) for v in every[:, 1]],
-        "per_rank_allreduce_us": [round(float(v), 1) for v in every[:, 2]],
+        "per_rank_allreduce_us": [round(float(v), 1) for v in every[:, 1]],
         "note": "HIP-event times per rank over %d steps; busbw = 2(N-1)/N x "
                 "bytes / allreduce time (ring convention)" % steps,
     }
@@ -683,13 +762,15 @@ def main():
     cfg = CONFIGS[args.workload]
     B = cfg["batch"]
     lazy = not args.eager_render
-    step = make_step(cfg, device, alternatives=args.alternatives,
-                     use_graph=not args.no_graph,
-                     optimizer=not args.no_optimizer,
-                     autocast_dtype=torch.bfloat16 if args.bf16 else None,
-                     force_collective=args.force_spawn,
-                     overlap=not args.no_overlap, lazy_render=lazy)
     images, labels = synthetic_batches(cfg, device, 1000 + rank)
+
+    def make(mode):
+        return make_step(cfg, device, alternatives=args.alternatives,
+                         use_graph=not args.no_graph,
+                         optimizer=not args.no_optimizer,
+                         autocast_dtype=torch.bfloat16 if args.bf16 else None,
+                         force_collective=args.force_spawn,
+                         lazy_render=lazy, collective_mode=mode)
 
     def barrier():
         if collective:
@@ -703,6 +784,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t]
 
+    # how the gradient all-reduce is scheduled: measured, not assumed
+    mode, modes = None, None
+    if collective:
+        from torch_scae_amd.train_step import TrainStep
+        mode = "1 bucket" if args.no_overlap else args.comm_mode
+        which = TrainStep.MODES if mode == "auto" else (mode,)
+        modes = probe_modes(make, which + ("off",), images, labels, barrier,
+                            reduce_max)
+        if mode == "auto":
+            mode = min(which, key=lambda m: modes[m]["ms_per_step"])
+    step = make(mode)
+
     # the timed region of the contract -- W warm-ups, then EXACTLY K steps
     # between barrier + synchronize, MAX over ranks -- repeated `blocks` times
     # back to back; the reported step time is the MEDIAN block
@@ -710,10 +803,17 @@ def main():
                           max(1, args.blocks), barrier, reduce_max)
     timing = timing_summary(blocks, args.steps)
     final_loss = float(step.loss)
+    final_state = capsule_state(step.model, images[0])
     comm = None
     if collective:
         comm = comm_diagnostics(step, images, labels, max(10, args.steps),
                                 barrier, device, world)
+        comm["modes"] = modes
+        comm["chosen"] = mode
+        # same stage of training on both sides (fresh models)
+        comm["step_no_comm_ms"] = modes["off"]["ms_per_step"]
+        comm["exposed_us"] = round((modes[mode]["ms_per_step"]
+                                    - modes["off"]["ms_per_step"]) * 1e3, 1)
 
     result = None
     if rank == 0:
@@ -746,6 +846,14 @@ def main():
                 "reconstruct_alternatives": bool(args.alternatives),
                 "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                 "final_loss": round(final_loss, 3),
+                # (the timed steps also train: what the data-dependent kernels
+                # ran on by the end -- see extra_workloads' structured leg)
+                "capsules_after": final_state,
+                "data_note": "U[0,1) noise images carry nothing to model: the "
+                             "part capsules switch off within ~600 steps "
+                             "(capsules_after) and K1's backward then skips "
+                             "them (exact zeros); extra_workloads' structured "
+                             "leg times the same step with live capsules",
             },
         }
         if comm is not None:
@@ -769,6 +877,7 @@ def main():
             del step
             torch.cuda.empty_cache()
             result["extra_workloads"] = extra_workloads(device)
+            result["extra_workloads"].append(structured_leg(device))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
         print(json.dumps(result), flush=True)

@@ -285,6 +285,7 @@ __device__ __forceinline__ void bwd_cell_body(
   float *s_part = reinterpret_cast<float *>(s_id + ((chunk_px + 3) & ~3));   // max_items x NM
   float *s_tex = s_part + (size_t)max_items * NM;       // NV x tsz
   float *s_red = s_tex + ((NV * tsz + 3) & ~3);         // 8 x (NTB / 64) <= 64
+  float *s_cf = s_red + 64;                             // kCellCoef: workgroup-uniform values
 
   if (k == M) {   // background component: no texels, three scalar sums
     struct { float bg_ml, bg_val, inv_var; } sc = {softplusf_(d.bg_mixing_logit[0]),
@@ -324,9 +325,8 @@ __device__ __forceinline__ void bwd_cell_body(
 
   // A component whose presence is below log_safe's threshold has the mixing logit
   // -1e8 (math_ops.py:18-22): its responsibilities underflow to exactly 0 in fp32 and with
-  // them every gradient of this workgroup -- zeros, without the pixel loop.  (Part capsules
-  // that training has switched off cost nothing; on U[0,1) noise images that is all of them
-  // after a few hundred steps)
+  // them every gradient of this workgroup -- zeros, without the pixel loop.
+  const float hx = 0.5f * (float)tw, hy = 0.5f * (float)th;
   if (d.presence && d.presence[b * M + k] < scae::kLogSafeEps) {   // (workgroup-uniform)
     float *o_t = g_templates + ((size_t)b * M + k) * C * tsz;
     for (int e = tid; e < C * tsz; e += NTB) o_t[e] = 0.f;
@@ -354,34 +354,55 @@ __device__ __forceinline__ void bwd_cell_body(
     }
     for (int e = tid; e < NV * tsz; e += NTB) s_tex[e] = 0.f;
   }
-  const float *pa = d.pose + ((size_t)b * M + k) * 6;
-  const float pa6[6] = {pa[0], pa[1], pa[2], pa[3], pa[4], pa[5]};
-  const float hx = 0.5f * (float)tw, hy = 0.5f * (float)th;
-  const float A0 = hx * pa[0], A1 = hx * pa[1], A2 = hx * (pa[2] + 1.f) - 0.5f;
-  const float A3 = hy * pa[3], A4 = hy * pa[4], A5 = hy * (pa[5] + 1.f) - 0.5f;
-  const float lsp = d.presence ? log_safe(d.presence[b * M + k]) : 0.f;
+  // What is uniform over the workgroup is computed by ONE lane and read back from LDS (as
+  // written first, all four waves derived the same ~250 values: a sixth of the kernel's
+  // instructions).  s_cf: [0..5] pose, [6] log presence, [8..13] the same map over pixel
+  // indices (j, i):  ix = ax j + bx i + c0x,  iy = ay j + by i + c0y, [14] 1 / det,
+  // [15..16] d(row) per unit ix / iy, [17..18] 1 / ax, 1 / ay, [19] flags; per chunk
+  // [20..25] the cell box and the split (phase 2).
+  constexpr float kSlack = 0.02f;
+  if (tid == 0) {
+    const float *pa = d.pose + ((size_t)b * M + k) * 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s_cf[i] = pa[i];
+    s_cf[6] = d.presence ? log_safe(d.presence[b * M + k]) : 0.f;
+    s_cf[7] = 0.f;
+    const float A0 = hx * pa[0], A1 = hx * pa[1], A2 = hx * (pa[2] + 1.f) - 0.5f;
+    const float A3 = hy * pa[3], A4 = hy * pa[4], A5 = hy * (pa[5] + 1.f) - 0.5f;
+    const float ax = A0 * 2.f * inv_wf, bx = A1 * 2.f * inv_hf;
+    const float c0x = fmaf(A0, inv_wf - 1.f, fmaf(A1, inv_hf - 1.f, A2));
+    const float ay = A3 * 2.f * inv_wf, by = A4 * 2.f * inv_hf;
+    const float c0y = fmaf(A3, inv_wf - 1.f, fmaf(A4, inv_hf - 1.f, A5));
+    const float det = ax * by - bx * ay;
+    // The inverse map only has to give a SUPERSET of a cell's pixels (membership is the
+    // parked cell id).  Phase 1's positions and this affine model agree to ~1e-5 texels, so
+    // an interval bound is off by 1e-5 / |slope| pixels: with slopes above 1e-3 a slack of
+    // 0.02 pixels covers it; flatter maps (and NaNs) take the whole row / all rows.
+    const float span = fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by);
+    const bool det_ok = fabsf(det) > 1e-3f * span && fabsf(det) < 1e30f;   // (false for NaN too)
+    const float inv_det = det_ok ? __builtin_amdgcn_rcpf(det) : 0.f;
+    const bool ax_ok = fabsf(ax) > 1e-3f && fabsf(ax) < 1e30f, ay_ok = fabsf(ay) > 1e-3f && fabsf(ay) < 1e30f;
+    s_cf[8] = ax, s_cf[9] = bx, s_cf[10] = c0x, s_cf[11] = ay, s_cf[12] = by, s_cf[13] = c0y;
+    s_cf[14] = inv_det;
+    s_cf[15] = -ay * inv_det, s_cf[16] = ax * inv_det;
+    s_cf[17] = ax_ok ? __builtin_amdgcn_rcpf(ax) : 0.f, s_cf[18] = ay_ok ? __builtin_amdgcn_rcpf(ay) : 0.f;
+    s_cf[19] = __int_as_float((det_ok ? 1 : 0) | (ax_ok ? 2 : 0) | (ay_ok ? 4 : 0));
+  }
   const float txf = (float)tw, tyf = (float)th, pwf = (float)pw;
   const float *s_tap = s_pl + (size_t)(2 * pw + 2) * TX;
-  // the same map over pixel indices (j, i):  ix = ax j + bx i + c0x,  iy = ay j + by i + c0y
-  const float ax = A0 * 2.f * inv_wf, bx = A1 * 2.f * inv_hf;
-  const float c0x = fmaf(A0, inv_wf - 1.f, fmaf(A1, inv_hf - 1.f, A2));
-  const float ay = A3 * 2.f * inv_wf, by = A4 * 2.f * inv_hf;
-  const float c0y = fmaf(A3, inv_wf - 1.f, fmaf(A4, inv_hf - 1.f, A5));
-  const float det = ax * by - bx * ay;
-  // The inverse map only has to give a SUPERSET of a cell's pixels (membership is the
-  // parked cell id).  Phase 1's positions and this affine model agree to ~1e-5 texels, so an
-  // interval bound is off by 1e-5 / |slope| pixels: with slopes above 1e-3 a slack of 0.02
-  // pixels covers it; flatter maps (and NaNs) take the whole row / all rows.
-  const float span = fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by);
-  const bool det_ok = fabsf(det) > 1e-3f * span && fabsf(det) < 1e30f;   // (false for NaN too)
-  const float inv_det = det_ok ? __builtin_amdgcn_rcpf(det) : 0.f;
-  const bool ax_ok = fabsf(ax) > 1e-3f && fabsf(ax) < 1e30f, ay_ok = fabsf(ay) > 1e-3f && fabsf(ay) < 1e30f;
-  constexpr float kSlack = 0.02f;
-  const float inv_ax = ax_ok ? __builtin_amdgcn_rcpf(ax) : 0.f, inv_ay = ay_ok ? __builtin_amdgcn_rcpf(ay) : 0.f;
-  const float dix = -ay * inv_det, diy = ax * inv_det;   // d(row) per unit ix / iy
+  __syncthreads();
+  // (uniform values: one LDS read each, kept in scalar registers)
+  auto uni = [&](int i) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_cf[i])));
+  };
+  const float pa6[6] = {uni(0), uni(1), uni(2), uni(3), uni(4), uni(5)};
+  const float lsp = uni(6);
+  const float ax = uni(8), bx = uni(9), c0x = uni(10), ay = uni(11), by = uni(12), c0y = uni(13);
+  const float inv_det = uni(14), dix = uni(15), diy = uni(16), inv_ax = uni(17), inv_ay = uni(18);
+  const int cflags = __float_as_int(uni(19));
+  const bool det_ok = cflags & 1, ax_ok = cflags & 2, ay_ok = cflags & 4;
   // log2-domain constants of the two exponentials of a term
   const float hvar2 = kLog2e * hvar, knorm2 = kLog2e * knorm;
-  __syncthreads();
 
   float acc[8];   // 6 pose sums, sum of d/d(mixing logit), sigma
 #pragma unroll
@@ -452,14 +473,11 @@ __device__ __forceinline__ void bwd_cell_body(
       }
       s_id[pl] = idx;
     }
-    __syncthreads();
-
-#if SCAE_CELL_ABL != 1
-    // ---- phase 2: lane = (cell, row slice) -------------------------------------------
-    // cells the chunk's pixels can lie in: the image of the chunk rectangle's corners;
-    // only cells with a corner inside the template matter (cx in [-1, tw - 1])
-    int cxlo, cylo, ncx, ncy;
-    {
+    // (lane 0, before the barrier that publishes the records:) the cells the chunk's pixels
+    // can lie in -- the image of the chunk rectangle's corners; only cells with a corner
+    // inside the template matter (cx in [-1, tw - 1]) -- and the split of a cell over lanes
+    if (tid == 0) {
+      int cxlo, cylo, ncx, ncy;
       const float jx = ax * (float)(W - 1), jy = ay * (float)(W - 1);
       const float xa = fmaf(bx, (float)r0, c0x), xb = fmaf(bx, (float)(r1 - 1), c0x);
       const float ya = fmaf(by, (float)r0, c0y), yb = fmaf(by, (float)(r1 - 1), c0y);
@@ -472,21 +490,35 @@ __device__ __forceinline__ void bwd_cell_body(
       const int cxhi = (int)fmaxf(fminf(floorf(xmax + 0.01f), txf - 1.f), -2.f);
       const int cyhi = (int)fmaxf(fminf(floorf(ymax + 0.01f), tyf - 1.f), -2.f);
       ncx = max(cxhi - cxlo + 1, 0), ncy = max(cyhi - cylo + 1, 0);
+      const int ncells = ncx * ncy;
+      // A cell's pixels are split over P = S x G lanes: S row slices (rows i = ilo + s, step
+      // S) times G segments of each row's interval -- as many as the item budget allows, so
+      // that a pose that puts the whole image into a few cells (a collapsed scale: one
+      // cell, 1600 pixels) still spreads over the workgroup instead of serialising on a
+      // handful of lanes.
+      int S = 1, G = 1;
+      if (ncells > 0) {
+        const int L = max(item_budget / ncells, 1);
+        const int rows_cell = det_ok ? min(r1 - r0, (int)fminf(fabsf(dix) + fabsf(diy), 1e4f) + 2)
+                                     : r1 - r0;
+        S = min(min(L, rows_cell), 64);
+        const float run = fminf(ax_ok ? fabsf(inv_ax) : 1e4f, ay_ok ? fabsf(inv_ay) : 1e4f);
+        const int jspan = min(W, (int)fminf(run, 1e4f) + 2);   // pixels of a row inside one cell
+        G = max(1, min(L / S, jspan >> 2));
+      }
+      int *ci = reinterpret_cast<int *>(s_cf + 20);
+      ci[0] = cxlo, ci[1] = cylo, ci[2] = ncx, ci[3] = ncy, ci[4] = S, ci[5] = G;
     }
+    __syncthreads();
+
+#if SCAE_CELL_ABL != 1
+    // ---- phase 2: lane = (cell, row slice) -------------------------------------------
+    const int *ci = reinterpret_cast<const int *>(s_cf + 20);
+    const int cxlo = __builtin_amdgcn_readfirstlane(ci[0]), cylo = __builtin_amdgcn_readfirstlane(ci[1]);
+    const int ncx = __builtin_amdgcn_readfirstlane(ci[2]), ncy = __builtin_amdgcn_readfirstlane(ci[3]);
+    const int S = __builtin_amdgcn_readfirstlane(ci[4]), G = __builtin_amdgcn_readfirstlane(ci[5]);
     const int ncells = ncx * ncy;   // (workgroup-uniform)
-    // A cell's pixels are split over P = S x G lanes: S row slices (rows i = ilo + s, step S)
-    // times G segments of each row's interval -- as many as the item budget allows, so that
-    // a pose that puts the whole image into a few cells (a collapsed scale: one cell, 1600
-    // pixels) still spreads over the workgroup instead of serialising on a handful of lanes.
-    int S = 1, G = 1;
     if (ncells > 0) {
-      const int L = max(item_budget / ncells, 1);
-      const int rows_cell = det_ok ? min(r1 - r0, (int)fminf(fabsf(dix) + fabsf(diy), 1e4f) + 2)
-                                   : r1 - r0;
-      S = min(min(L, rows_cell), 64);
-      const float run = fminf(ax_ok ? fabsf(inv_ax) : 1e4f, ay_ok ? fabsf(inv_ay) : 1e4f);
-      const int jspan = min(W, (int)fminf(run, 1e4f) + 2);   // pixels of a row inside one cell
-      G = max(1, min(L / S, jspan >> 2));
       const int nparts = S * G, nitems = ncells * nparts;
       const float inv_nc = __builtin_amdgcn_rcpf((float)ncells), inv_ncx = __builtin_amdgcn_rcpf((float)ncx);
       const float inv_G = __builtin_amdgcn_rcpf((float)G);
@@ -660,7 +692,7 @@ CellGeom cell_geom(const scae_decoder_desc *d) {
   const size_t chunk_px = (size_t)rows * d->W, tsz = (size_t)d->th * d->tw;
   const size_t floats = ((pad_elems(d->th, d->tw) * TX + 3) & ~3) + ((chunk_px * RS + 3) & ~(size_t)3) +
                         ((chunk_px + 3) & ~(size_t)3) + (size_t)g.max_items * 4 * NV +
-                        ((NV * tsz + 3) & ~(size_t)3) + 64;
+                        ((NV * tsz + 3) & ~(size_t)3) + 64 + 32;
   g.lds = floats * sizeof(float) <= 64 * 1024 ? floats * sizeof(float) : 0;
   return g;
 }

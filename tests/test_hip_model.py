@@ -474,10 +474,22 @@ def test_train_step_collective_paths_match_plain_step_bitwise(nccl_group):
         assert (two.graph_b is not None) == use_graph
         one, l1, sd1 = run(use_graph, force_collective=True, overlap=False)
         assert not one.split and one.collective_mode.startswith("1 bucket")
-        assert l0 == l1 == l2, (l0, l1, l2)
+        # the all-reduce and the optimiser captured inside the one graph
+        ing, l3, sd3 = run(use_graph, force_collective=True,
+                           collective_mode="in graph")
+        assert not ing.split and ing.in_graph_collective == use_graph
+        assert ing.collective_mode == ("in graph" if use_graph
+                                       else "1 bucket after the backward")
+        # ... and switched off by name (bench.py's no-comm leg)
+        off, l4, sd4 = run(use_graph, force_collective=True,
+                           collective_mode="off")
+        assert not off.collective and off.collective_mode is None
+        assert l0 == l1 == l2 == l3 == l4, (l0, l1, l2, l3, l4)
         for k in sd0:
             assert torch.equal(sd0[k], sd1[k]), (use_graph, "1 bucket", k)
             assert torch.equal(sd0[k], sd2[k]), (use_graph, "2 buckets", k)
+            assert torch.equal(sd0[k], sd3[k]), (use_graph, "in graph", k)
+            assert torch.equal(sd0[k], sd4[k]), (use_graph, "off", k)
 
 
 def test_step_prologue_gives_the_same_step():

@@ -280,7 +280,7 @@ def test_factory_rejects_configurations_outside_the_kernel_limits():
                         (dict(n_obj_caps=150, n_part_caps=100), "n_obj_caps * n_part_caps"),
                         # (inside the product limit, outside the
                         # capsule likelihood's own LDS budget)
-                        (dict(n_obj_caps=65, n_part_caps=200), "3 * n_obj_caps + 14"),
+                        (dict(n_obj_caps=65, n_part_caps=200), "n_obj_caps [+] 14"),
                         (dict(image_shape=(5, 40, 40)), "channels"),
                         (dict(pcae_template_generator_params=dict(
                             template_size=(64, 64))), "th*tw")):

@@ -246,7 +246,12 @@ def test_fused_train_step_vs_oracle_for_every_decoder_feed(vote_type,
         assert calls.index("scae_render_gmm_sums_bwd_f32") < \
             calls.index("scae_capsule_likelihood_bwd_f32")
     assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
-    worst = _assert_grads(_flat_grads(step), ref_grads, 1e-4,
+    # (a 'soft' / 'hard' presence reaches the decoder as a sum over capsule
+    # posteriors and leaves through 1 / presence: a few 1e-4 of fp32 round-off
+    # in the part encoder's gradients, measured 1.6e-4; a wrongly ordered
+    # launch gives O(1))
+    bar = 1e-4 if presence_type == "enc" else 3e-4
+    worst = _assert_grads(_flat_grads(step), ref_grads, bar,
                           (vote_type, presence_type))
     print(vote_type, presence_type, "worst gradient entry", worst)
 

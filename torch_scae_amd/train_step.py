@@ -36,22 +36,39 @@ class TrainStep:
       graphs with the collective between them.)
     * ``"1 bucket"``: one graph, one all-reduce of the whole flat buffer after
       it (``overlap=False``, or a model without the cut).
-    * ``"in graph"`` (env ``SCAE_GRAPH_ALLREDUCE=1``): the all-reduce and the
-      RMSprop step captured inside the one graph.
+    * ``"in graph"`` (``collective_mode="in graph"`` or env
+      ``SCAE_GRAPH_ALLREDUCE=1``): the all-reduce and the RMSprop step captured
+      inside the one graph -- no host-side stream hand-off at all, nothing
+      overlapped.
+    ``collective_mode``: one of the three names (``"2 buckets"`` falls back to
+    ``"1 bucket"`` for a model without the backward cut), ``"off"`` (no
+    collective even with ranks: measurements only -- the ranks' parameters
+    drift apart) or None (two buckets where possible).  ``bench.py`` measures
+    all three on the ranks it is given and takes the fastest.
     """
+
+    MODES = ("2 buckets", "1 bucket", "in graph")
 
     def __init__(self, model, batch_size, image_shape, lr=3e-5, use_graph=True,
                  optimizer=True, momentum=0.9, weight_decay=0.0,
                  lr_decay_rate=0.997, autocast_dtype=None,
                  force_collective=False, overlap=True, lazy_render=True,
-                 prologue=True, fuse_kernels=True):
+                 prologue=True, fuse_kernels=True, collective_mode=None):
         self.model = model
         self.device = next(model.parameters()).device
         self.world = world()[1]
-        self.collective = self.world > 1 or (
-            force_collective and torch.distributed.is_initialized())
+        if collective_mode is None and \
+                os.environ.get("SCAE_GRAPH_ALLREDUCE", "0") == "1":
+            collective_mode = "in graph"
+        if collective_mode not in (None, "off") + self.MODES:
+            raise ValueError(f"collective_mode must be one of {self.MODES}, "
+                             f"'off' or None, got {collective_mode!r}")
+        self.collective = collective_mode != "off" and (
+            self.world > 1 or (force_collective
+                               and torch.distributed.is_initialized()))
         self.in_graph_collective = self.collective and use_graph and \
-            os.environ.get("SCAE_GRAPH_ALLREDUCE", "0") == "1"
+            collective_mode == "in graph"
+        overlap = overlap and collective_mode in (None, "2 buckets")
         self.split = bool(self.collective and overlap
                           and not self.in_graph_collective
                           # the conditions under which SCAE._forward cuts
