@@ -26,9 +26,15 @@ import contextlib
 import torch
 import torch.nn.functional as F
 
-SAFETY = 4.0          # margin = SAFETY x observed fp32 round-off of the layer
+# margin = SAFETY x observed fp32 round-off of the layer.  The round-off observed is the
+# ORACLE's (blocked CPU sums); the HIP convolutions add their 1152 products in MFMA
+# order, whose error is a few times larger: with SAFETY 4 a seed sweep of the replayed
+# step (tools/replay_sweep.py, 15 step samples, either kernel generation) showed the
+# worst gradient entry at 5e-6 .. 3e-5 of its tensor's largest for most steps and at
+# 1e-4 .. 2e-4 for one in eight -- single gate flips the screen had let through.
+SAFETY = 8.0
 FLOOR = 2e-7          # ... but at least this (relative to the layer's max)
-MIN_KEPT_RATIO = 0.5
+MIN_KEPT_RATIO = 0.45
 LAST_STATS = []       # [(what, kept, drawn)] of the most recent calls
 
 

@@ -2227,12 +2227,16 @@ def test_stage_batch_one_launch():
     (40, 2, 300, [200, 70, 33, 391], 2),       # 3 k-chunks, several tiles per wave, cfg-3's width
     (20, 3, 704, [130, 7], None),              # the widest input the kernel takes
 ])
-def test_mlp_chain_vs_fp64(B, G, Kin, dims, ones_at):
+@pytest.mark.parametrize("row_tile", [16, 32])
+def test_mlp_chain_vs_fp64(B, G, Kin, dims, ones_at, row_tile, monkeypatch):
     """K7b (object_decoder.py:86-107, :137-158, the cat with caps_exist of
     :149): all layers of the per-capsule MLP chain in one launch, and its
     backward (data-gradient chain + one weight-gradient launch), against fp64
-    algebra; bar 1e-4 relative to each tensor's largest entry."""
+    algebra; bar 1e-4 relative to each tensor's largest entry.  ``row_tile``:
+    batch rows per workgroup -- 32 is what large batches take (the activation
+    buffers then are as wide as what each holds), forced here at every size."""
     from torch_scae_amd import ops
+    monkeypatch.setenv("SCAE_CHAIN_RB", str(row_tile))
     g = torch.Generator().manual_seed(B + G + Kin)
     layers, K = [], Kin
     for l, N in enumerate(dims):
@@ -2302,13 +2306,19 @@ def test_mlp_chain_vs_fp64(B, G, Kin, dims, ones_at):
 
 @pytest.mark.parametrize("B,O,V,noise,sim", [(128, 24, 24, True, True),
                                               (37, 5, 7, False, False),
-                                              (16, 4, 5, True, True)])
-def test_chain_votes_matches_chain_then_votes(B, O, V, noise, sim):
+                                              (16, 4, 5, True, True),
+                                              (70, 6, 48, True, False)])
+@pytest.mark.parametrize("row_tile", [16, 32])
+def test_chain_votes_matches_chain_then_votes(B, O, V, noise, sim, row_tile,
+                                              monkeypatch):
     """K7b + K3 in one launch (forward) / K3-backward + data-gradient chain in one
     launch (backward) against the same two ops launched separately: every
     output and every gradient, 1e-5 relative to the tensor's largest entry
-    (the only difference is the order of two small sums)."""
+    (the only difference is the order of two small sums).  ``row_tile`` as in
+    test_mlp_chain_vs_fp64: with 32 rows the vote blocks run twice per
+    workgroup, their scratch in the weight tiles."""
     from torch_scae_amd import ops
+    monkeypatch.setenv("SCAE_CHAIN_RB", str(row_tile))
     g = torch.Generator().manual_seed(B * O + V)
     Kin, H, Dc, A = 64, 48, 12, 8 * V + 7
     dims = [(H, Kin, True, False), (Dc, H, True, False), (H, Dc + 1, False, True),

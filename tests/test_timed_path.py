@@ -153,11 +153,12 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
                 continue
             scale = float(ref.abs().max())
             got = grads[k].detach().cpu()
-            if scale == 0.0:
-                assert float(got.abs().max()) <= 1e-6, (what, it, k)
+            if scale < 1e-30:   # exactly zero, or denormal dust (the HIP side flushes it)
+                assert float(got.abs().max()) <= max(1e-6, entry_bar * entry_abs), \
+                    (what, it, k)
                 continue
             off.append((float((got - ref).abs().max()) / (scale + entry_abs), k))
-            l2.append((float((got - ref).norm()) / float(ref.norm()), k))
+            l2.append((float((got - ref).double().norm()) / float(ref.double().norm()), k))
             n += 1
         assert n > min_tensors
         off.sort(reverse=True)
@@ -289,47 +290,46 @@ def test_fifty_replayed_steps_vs_oracle_and_torch_rmsprop():
 
 
 def test_replayed_step_on_the_state_the_bench_ends_in():
-    """``bench.py`` trains on U[0,1) noise images for hundreds of steps before
+    """``bench.py`` trains on U[0,1) noise images for thousands of steps before
     and while it times; on such data the part capsules switch off (DESIGN.md
-    section 5, round 3): presences underflow and the pose scale collapses, so
-    that a whole image falls into one or two texel cells of a template --
-    the regime in which the K1 backward splits a cell over (row slice x row
-    segment) lanes, and in which a component whose presence is below
-    log_safe's 1e-16 gets exactly zero gradients without its pixel loop.
-    Replayed steps on the bench's kind of batch until the capsules are off
-    (~600-4000 steps), then the replayed step is held to the oracle from THAT
-    state (same bars as at initialisation)."""
-    cfg, B, sd, g = full_size_params("cfg2")
-    model, step = build_step(cfg, B, sd)
+    section 5): presences fall below log_safe's 1e-16 and the pose scale
+    collapses, so that a whole image falls into one or two texel cells of a
+    template -- the regime in which the K1 backward splits a cell over (row
+    slice x row segment) lanes, and in which a component with such a presence
+    gets exactly zero gradients without its pixel loop.  The bench's own model
+    (its seed, its batches, TrainStep's defaults) is stepped until it is there
+    (bench.py reports it after 600 steps), then the replayed step is held to the
+    oracle from THAT state, with the bars of the initial state."""
+    import bench
+    cfg_b = bench.CONFIGS["mnist_24_24_bs128"]
+    cfg, B = cfg_b["model"], cfg_b["batch"]
+    from torch_scae_amd import ops
+    torch.manual_seed(1234)
+    ops.reset_noise()
+    step = bench.make_step(cfg_b, torch.device("cuda", 0))
+    model = step.model
     step.capture()
-    gen = torch.Generator(device="cuda").manual_seed(11)
-    pool = [(torch.rand(B, *cfg["image_shape"], device="cuda", generator=gen),
-             torch.randint(0, 10, (B,), device="cuda", generator=gen))
-            for _ in range(8)]
-    for n_steps in range(500, 6001, 500):
+    images, labels = bench.synthetic_batches(cfg_b, torch.device("cuda", 0), 1000)
+    state = None
+    for n_steps in range(500, 4001, 500):
         for i in range(500):
-            step(*pool[i % 8])
+            step(images[i % 8], labels[i % 8])
         torch.cuda.synchronize()
-        with torch.no_grad():
-            parts = model.part_encoder.eval()(pool[0][0])
-            model.part_encoder.train()
-        pres, pose = parts.presence.float(), parts.pose.float()
-        lin = torch.stack([pose[..., 0], pose[..., 1], pose[..., 3],
-                           pose[..., 4]], -1).abs().amax(-1)
-        print(f"state after {n_steps} steps: presence median "
-              f"{float(pres.median()):.3e} max {float(pres.max()):.3e}; pose "
-              f"linear part median {float(lin.median()):.3e}")
-        if float(pres.median()) < 1e-6 and float(lin.median()) < 0.1:
+        state = bench.capsule_state(model, images[0])
+        print(f"after {n_steps} steps: {state}")
+        if state["presence_below_1e-16"] == 1.0:
             break
-    # the regime is the trained one: capsules off (their K1 backward
-    # workgroups take the zero-gradient exit), poses collapsed
-    assert float(pres.median()) < 1e-6 and float(lin.median()) < 0.1, \
-        (float(pres.median()), float(lin.median()))
+    # the regime is the trained one: every capsule off, poses collapsed
+    assert state["presence_below_1e-16"] == 1.0 and \
+        state["pose_scale_median"] < 0.1, state
+    g = torch.Generator().manual_seed(5)
     P = {k: v.detach().cpu().clone().requires_grad_(True)
          for k, v in model.state_dict().items()}
+    # (with every part capsule off, the gradients that pass through the part
+    # decoder are exactly zero on both sides: fewer tensors carry an error)
     worst, _ = check_replayed_steps(model, step, cfg, B, P, g, 2,
-                                    what="after 400 steps")
-    print("worst gradient entry after 400 steps:", worst)
+                                    what="trained state", min_tensors=50)
+    print("worst gradient entry in the trained state:", worst)
 
 
 def _set_counter(step, value):

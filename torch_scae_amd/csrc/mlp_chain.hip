@@ -5,7 +5,9 @@
 // parameters; the reference: a Python loop of 4*O nn.Linear calls).  As four batched
 // GEMM launches (K7, gemm_mfma.hip) the chain costs four dependent-dispatch floors and
 // three round trips of the hidden activations through L2 for ~0.4 GFLOP; here a
-// workgroup carries 16 batch rows of ONE group through all the layers:
+// workgroup carries 16 (32 at large batches: every weight element then serves two MFMA
+// row blocks, and the group's weight set is streamed from L2 half as often) batch rows of
+// ONE group through all the layers:
 //   * the 16 x K activation block lives in LDS (two ping-pong buffers); each weight element
 //     is used exactly once per workgroup: it is loaded coalesced, parked in registers, and
 //     passes through a wave-private LDS tile on its way to the MFMA fragment;
@@ -27,7 +29,7 @@
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int NW = 8, NT = 64 * NW, RB = 16, MAXL = 4, CH = 8;
+constexpr int NW = 8, NT = 64 * NW, MAXL = 4, CH = 8;   // (16 RBT batch rows per workgroup)
 constexpr int WLD = 128 + 4;   // row stride of a wave's weight tile: (WLD / 4) odd
 
 struct Layer {
@@ -47,7 +49,8 @@ struct Chain {
   Layer l[MAXL];
   const float *in;
   long in_gs, in_bs;
-  int n, in_dim, B, G, stride;   // stride: floats per LDS activation row
+  int n, in_dim, B, G;
+  int stride[2];   // floats per LDS row of activation buffer 0 (input, odd layers' outputs) / 1
   // the capsule votes (K3) at the end of the forward chain / at the head of the
   // data-gradient chain
   int votes;
@@ -92,10 +95,10 @@ __device__ __forceinline__ float4 bload4(rsrc_t rs, int byte_off) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                      __uint_as_float(v.w));
 }
-template <bool BWD>
+template <bool BWD, int RBT>
 __device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g, int b0, int B,
                                            int tile, int ch, int nch, int lane, float4 (&buf)[CH],
-                                           float4 &epi) {
+                                           float4 (&epi)[RBT]) {
   const int n0 = 16 * tile, k0 = 128 * ch, ldw = L.ldw, LN = L.N;
   // rows of the matrix: N (forward) / K (data gradient)
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -113,16 +116,19 @@ __device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g
     const int r = lane & 15, q = lane >> 4, col = n0 + r;
     const bool cok = col < LN;
     if (!BWD) {
-      epi.x = L.bias ? ldg(L.bias + (size_t)g * L.bias_gs, (size_t)col * L.bias_ld, cok) : 0.f;
+      epi[0].x = L.bias ? ldg(L.bias + (size_t)g * L.bias_gs, (size_t)col * L.bias_ld, cok) : 0.f;
     } else {
-      epi = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (L.gate) {
-        const float *gp = L.gate + (size_t)g * L.gate_gs;
-        const int b = b0 + 4 * q;
-        epi.x = ldg(gp, (size_t)b * L.gate_bs + col, cok && b < B);
-        epi.y = ldg(gp, (size_t)(b + 1) * L.gate_bs + col, cok && b + 1 < B);
-        epi.z = ldg(gp, (size_t)(b + 2) * L.gate_bs + col, cok && b + 2 < B);
-        epi.w = ldg(gp, (size_t)(b + 3) * L.gate_bs + col, cok && b + 3 < B);
+#pragma unroll
+      for (int rb = 0; rb < RBT; ++rb) {
+        epi[rb] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (L.gate) {
+          const float *gp = L.gate + (size_t)g * L.gate_gs;
+          const int b = b0 + 16 * rb + 4 * q;
+          epi[rb].x = ldg(gp, (size_t)b * L.gate_bs + col, cok && b < B);
+          epi[rb].y = ldg(gp, (size_t)(b + 1) * L.gate_bs + col, cok && b + 1 < B);
+          epi[rb].z = ldg(gp, (size_t)(b + 2) * L.gate_bs + col, cok && b + 2 < B);
+          epi[rb].w = ldg(gp, (size_t)(b + 3) * L.gate_bs + col, cok && b + 3 < B);
+        }
       }
     }
   }
@@ -140,27 +146,31 @@ __device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g
 // their way to the MFMA fragments (transposed on the way in for the data-gradient form).
 // One workgroup barrier per layer boundary separates the writes of a layer's output from
 // its reads.
-template <bool BWD>
+template <bool BWD, int RBT>
 __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
+  constexpr int RB = 16 * RBT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63,
             r = lane & 15, q = lane >> 4;
   const int g = blockIdx.x % c.G, b0 = (blockIdx.x / c.G) * RB;
-  float *wtile = smem + 2 * RB * c.stride + wid * (16 * WLD);   // this wave's weight tile
+  // activation buffer p: rows of c.stride[p] floats
+  auto buf = [&](int p) { return smem + (p ? RB * c.stride[0] : 0); };
+  float *wbase = smem + RB * (c.stride[0] + c.stride[1]);
+  float *wtile = wbase + wid * (16 * WLD);   // this wave's weight tile
   // registers -> the wave's LDS tile [16 columns][128 k (+4)]
-  auto park = [&](const float4 (&buf)[CH]) {
+  auto park = [&](const float4 (&buf4)[CH]) {
     if (!BWD) {
       float *d = wtile + (lane >> 5) * WLD + 4 * (lane & 31);
 #pragma unroll
-      for (int i = 0; i < CH; ++i) *reinterpret_cast<float4 *>(d + 2 * i * WLD) = buf[i];
+      for (int i = 0; i < CH; ++i) *reinterpret_cast<float4 *>(d + 2 * i * WLD) = buf4[i];
     } else {   // transposed: (k, 4 columns) -> [column][k]; banks 16 cq + 4 j + k: distinct
       float *d = wtile + 4 * (lane & 3) * WLD + (lane >> 2);
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        d[16 * i] = buf[i].x;
-        d[WLD + 16 * i] = buf[i].y;
-        d[2 * WLD + 16 * i] = buf[i].z;
-        d[3 * WLD + 16 * i] = buf[i].w;
+        d[16 * i] = buf4[i].x;
+        d[WLD + 16 * i] = buf4[i].y;
+        d[2 * WLD + 16 * i] = buf4[i].z;
+        d[3 * WLD + 16 * i] = buf4[i].w;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own tile
@@ -168,18 +178,24 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
   auto ntiles_of = [&](int li) { return (c.l[li].N + 15) >> 4; };
   auto nch_of = [&](int li) { return (((c.l[li].K + 15) >> 4) + CH - 1) / CH; };
 
-  float4 f[CH], fe = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 f[CH], fe[RBT];
+#pragma unroll
+  for (int rb = 0; rb < RBT; ++rb) fe[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
   // the first weights go out before the input block is staged
   if (wid < ntiles_of(0))
-    fetch_item<BWD>(c.l[0], c.l[0].w + (size_t)g * c.l[0].w_gs, g, b0, c.B, wid, 0, nch_of(0), lane,
-                    f, fe);
+    fetch_item<BWD, RBT>(c.l[0], c.l[0].w + (size_t)g * c.l[0].w_gs, g, b0, c.B, wid, 0, nch_of(0),
+                         lane, f, fe);
   if (BWD && c.votes) {
     // the chain's input block = the vote kernel's gradient rows, made here (K3 backward
-    // for the block's 16 capsules; also written to global memory for the weight-gradient
-    // GEMM and the bias sums)
-    scae_votes::bwd_block<NT>(c.va, c.vg, smem, c.stride, smem + RB * c.stride, b0, g);
+    // for the block's capsules, 16 at a time; also written to global memory for the
+    // weight-gradient GEMM and the bias sums).  Scratch: the other activation buffer
+    // (one row block) / the weight tiles, which nobody has parked anything in yet.
+#pragma unroll
+    for (int rb = 0; rb < RBT; ++rb)
+      scae_votes::bwd_block<NT>(c.va, c.vg, smem + 16 * rb * c.stride[0], c.stride[0],
+                                RBT == 1 ? buf(1) : wbase, b0 + 16 * rb, g);
   } else
-  {  // the block's input rows, zero padded to a multiple of 16 columns / to 16 rows; eight
+  {  // the block's input rows, zero padded to a multiple of 16 columns / to RB rows; eight
      // independent loads per thread in flight (a load-store loop pays a memory round trip
      // per iteration)
     const int k16 = (c.in_dim + 15) & ~15, total = RB * k16;
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int e = e0 + j * NT, row = e / k16, k = e - row * k16, b = b0 + row;
-        at[j] = row * c.stride + k;
+        at[j] = row * c.stride[0] + k;
         v[j] = ldg(src, (size_t)b * c.in_bs + k, e < total && b < c.B && k < c.in_dim);
       }
 #pragma unroll
@@ -205,46 +221,60 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
       const float *W = L.w + (size_t)g * L.w_gs;
       const int nch = nch_of(li), ntiles = ntiles_of(li), nsteps = (L.K + 15) >> 4;
       const bool last = li + 1 == c.n;
-      const float *cur = smem + (li & 1) * RB * c.stride;
-      float *nxt = smem + ((li + 1) & 1) * RB * c.stride;
+      const float *cur = buf(li & 1);
+      float *nxt = buf((li + 1) & 1);
+      const int cs = c.stride[li & 1], ns = c.stride[(li + 1) & 1];
       float *out = L.out ? L.out + (size_t)g * L.out_gs : nullptr;
       __syncthreads();   // the layer's input block is complete
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[RBT];
       for (int tile = wid; tile < ntiles; tile += NW) {
         for (int ch = 0; ch < nch; ++ch) {
           park(f);   // (waits for the item's loads)
-          const float4 epi = fe;
+          float4 epi[RBT];
+#pragma unroll
+          for (int rb = 0; rb < RBT; ++rb) epi[rb] = fe[rb];
           // the next item's loads fly while this one is multiplied
           if (ch + 1 < nch) {
-            fetch_item<BWD>(L, W, g, b0, c.B, tile, ch + 1, nch, lane, f, fe);
+            fetch_item<BWD, RBT>(L, W, g, b0, c.B, tile, ch + 1, nch, lane, f, fe);
           } else if (tile + NW < ntiles) {
-            fetch_item<BWD>(L, W, g, b0, c.B, tile + NW, 0, nch, lane, f, fe);
+            fetch_item<BWD, RBT>(L, W, g, b0, c.B, tile + NW, 0, nch, lane, f, fe);
           } else if (li + 1 < MAXL && li + 1 < c.n) {
             const Layer &Ln = c.l[li + 1 < MAXL ? li + 1 : li];
             if (wid < ntiles_of(li + 1 < MAXL ? li + 1 : li))
-              fetch_item<BWD>(Ln, Ln.w + (size_t)g * Ln.w_gs, g, b0, c.B, wid, 0,
-                              nch_of(li + 1 < MAXL ? li + 1 : li), lane, f, fe);
+              fetch_item<BWD, RBT>(Ln, Ln.w + (size_t)g * Ln.w_gs, g, b0, c.B, wid, 0,
+                                   nch_of(li + 1 < MAXL ? li + 1 : li), lane, f, fe);
           }
-          if (ch == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const float *arow = cur + r * c.stride + 128 * ch + 4 * q;
+          if (ch == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RBT; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+          const float *arow = cur + r * cs + 128 * ch + 4 * q;
           const float *brow = wtile + r * WLD + 4 * q;
 #pragma unroll
           for (int s = 0; s < CH; ++s)
-            if (ch * CH + s < nsteps) acc = mma16(acc, ld4(arow + 16 * s), ld4(brow + 16 * s));   // uniform
+            if (ch * CH + s < nsteps) {   // (uniform)
+              const float4 bw = ld4(brow + 16 * s);
+#pragma unroll
+              for (int rb = 0; rb < RBT; ++rb)
+                acc[rb] = mma16(acc[rb], ld4(arow + 16 * rb * cs + 16 * s), bw);
+            }
           if (ch != nch - 1) continue;
           const int col = 16 * tile + r;
           const bool cok = col < L.N;
-          const float bias = BWD ? 0.f : epi.x;
-          const float gt[4] = {BWD ? epi.x : 1.f, BWD ? epi.y : 1.f, BWD ? epi.z : 1.f,
-                               BWD ? epi.w : 1.f};
+          const float bias = BWD ? 0.f : epi[0].x;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = 4 * q + e, b = b0 + row;
-            float v = acc[e] + bias;
-            if (L.relu) v = fmaxf(v, 0.f);
-            v = cok && gt[e] > 0.f ? v : 0.f;   // (also the zero padding of the next contraction)
-            if (!last || (!BWD && c.votes)) nxt[row * c.stride + col] = v;
-            if (out && cok && b < c.B) out[(size_t)b * L.out_bs + col] = v;
+          for (int rb = 0; rb < RBT; ++rb) {
+            const float gt[4] = {BWD ? epi[rb].x : 1.f, BWD ? epi[rb].y : 1.f, BWD ? epi[rb].z : 1.f,
+                                 BWD ? epi[rb].w : 1.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int row = 16 * rb + 4 * q + e, b = b0 + row;
+              float v = acc[rb][e] + bias;
+              if (L.relu) v = fmaxf(v, 0.f);
+              v = cok && gt[e] > 0.f ? v : 0.f;   // (also the zero padding of the next contraction)
+              if (!last || (!BWD && c.votes)) nxt[row * ns + col] = v;
+              if (out && cok && b < c.B) out[(size_t)b * L.out_bs + col] = v;
+            }
           }
         }
       }
@@ -252,16 +282,20 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
       if (wid >= ntiles && li + 1 < MAXL && li + 1 < c.n) {
         const Layer &Ln = c.l[li + 1 < MAXL ? li + 1 : li];
         if (wid < ntiles_of(li + 1 < MAXL ? li + 1 : li))
-          fetch_item<BWD>(Ln, Ln.w + (size_t)g * Ln.w_gs, g, b0, c.B, wid, 0,
-                          nch_of(li + 1 < MAXL ? li + 1 : li), lane, f, fe);
+          fetch_item<BWD, RBT>(Ln, Ln.w + (size_t)g * Ln.w_gs, g, b0, c.B, wid, 0,
+                               nch_of(li + 1 < MAXL ? li + 1 : li), lane, f, fe);
       }
     }
   }
   if (!BWD && c.votes) {
-    // K3 forward for the block's 16 capsules from their parameter rows in LDS
-    __syncthreads();
-    scae_votes::fwd_block<NT>(c.va, c.vo, smem + (c.n & 1) * RB * c.stride, c.stride,
-                              smem + ((c.n + 1) & 1) * RB * c.stride, b0, g);
+    // K3 forward for the block's capsules (16 at a time) from their parameter rows in LDS
+#pragma unroll
+    for (int rb = 0; rb < RBT; ++rb) {
+      __syncthreads();
+      scae_votes::fwd_block<NT>(c.va, c.vo, buf(c.n & 1) + 16 * rb * c.stride[c.n & 1],
+                                c.stride[c.n & 1], RBT == 1 ? buf((c.n + 1) & 1) : wbase,
+                                b0 + 16 * rb, g);
+    }
   }
 }
 
@@ -290,7 +324,9 @@ int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd, const scae_votes_desc
   if (maxdim > scae_mlp_chain_max_width()) return SCAE_ERR_UNSUPPORTED;
   c.in = d->in, c.in_gs = (long)d->in_gs, c.in_bs = (long)d->in_bs;
   c.n = d->n_layers, c.in_dim = d->in_dim, c.B = d->B, c.G = d->G;
-  c.stride = ((maxdim + 15) & ~15) + 4;   // (stride / 4) odd: conflict-free b128 row reads
+  // (stride / 4) odd: conflict-free b128 row reads.  One stride for both buffers here;
+  // launch() narrows each buffer to what it holds when it takes 32 rows per workgroup
+  c.stride[0] = c.stride[1] = ((maxdim + 15) & ~15) + 4;
   c.votes = 0;
   if (v) {
     const int V = v->V, A = 8 * V + 7;
@@ -325,20 +361,45 @@ int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd, const scae_votes_desc
   return SCAE_OK;
 }
 
+#ifndef SCAE_CHAIN_RB32_MIN_WGS
+#define SCAE_CHAIN_RB32_MIN_WGS 512   // 32-row workgroups only while >= 2 of them per CU remain
+#endif
+template <bool BWD, int RBT>
+int launch_rb(const Chain &c, void *stream) {
+  constexpr int RB = 16 * RBT;
+  const size_t lds = ((size_t)RB * (c.stride[0] + c.stride[1]) + (size_t)NW * 16 * WLD) * sizeof(float);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<BWD, RBT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int blocks = c.G * ((c.B + RB - 1) / RB);
+  hipLaunchKernelGGL((chain_kernel<BWD, RBT>), dim3(blocks), dim3(NT), lds, (hipStream_t)stream, c);
+  return scae_launch_status();
+}
+
 template <bool BWD>
 int launch(const scae_mlp_chain_desc *d, const scae_votes_desc *v, void *stream) {
   Chain c{};
   int rc = fill(c, d, BWD, v);
   if (rc) return rc;
-  const size_t lds = ((size_t)2 * RB * c.stride + (size_t)NW * 16 * WLD) * sizeof(float);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<BWD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  const int blocks = c.G * ((c.B + RB - 1) / RB);
-  hipLaunchKernelGGL(chain_kernel<BWD>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, c);
-  return scae_launch_status();
+  // Large batches: 32 rows per workgroup.  Buffer 0 holds the input block and the outputs
+  // of the odd layers (the last layer's only when the vote kernel reads it from LDS),
+  // buffer 1 the even layers' -- each as wide as what it holds; the vote blocks take their
+  // scratch in the weight tiles.
+  const char *env = getenv("SCAE_CHAIN_RB");   // (16 | 32: force a row tile -- tests, measurements)
+  const int want = env ? atoi(env) : 0;
+  Chain c2 = c;
+  int dim[2] = {c.in_dim, 16};
+  for (int i = 0; i < c.n; ++i)
+    if (i + 1 < c.n || (!BWD && c.votes)) dim[(i + 1) & 1] = dim[(i + 1) & 1] > c.l[i].N ? dim[(i + 1) & 1] : c.l[i].N;
+  c2.stride[0] = ((dim[0] + 15) & ~15) + 4, c2.stride[1] = ((dim[1] + 15) & ~15) + 4;
+  const size_t lds2 = ((size_t)32 * (c2.stride[0] + c2.stride[1]) + (size_t)NW * 16 * WLD) * sizeof(float);
+  const bool scratch_ok = !c.votes || (size_t)16 * c.va.V * 7 <= (size_t)NW * 16 * WLD;
+  const bool big = c.G * ((c.B + 31) / 32) >= SCAE_CHAIN_RB32_MIN_WGS;
+  if (lds2 <= 160 * 1024 && scratch_ok && want != 16 && (big || want == 32))
+    return launch_rb<BWD, 2>(c2, stream);
+  return launch_rb<BWD, 1>(c, stream);
 }
 }  // namespace
 
