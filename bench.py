@@ -663,11 +663,16 @@ def probe_modes(make, which, images, labels, barrier, reduce_max, steps=40,
     so it runs last)."""
     out = {}
     for mode in which:
-        step = make(mode)
-        t = timed_blocks(step, images, labels, steps, warmup, blocks, barrier,
-                         reduce_max)
-        out[mode] = {"ms_per_step": round(float(np.median(t)) / steps * 1e3, 4),
-                     "runs_as": step.collective_mode}
+        step = None
+        try:
+            step = make(mode)
+            t = timed_blocks(step, images, labels, steps, warmup, blocks,
+                             barrier, reduce_max)
+            out[mode] = {"ms_per_step": round(float(np.median(t)) / steps * 1e3, 4),
+                         "runs_as": step.collective_mode}
+        except Exception as e:      # a mode this stack cannot run is not chosen
+            out[mode] = {"ms_per_step": float("inf"), "error": repr(e)[:200]}
+            torch.cuda.synchronize()
         del step
         torch.cuda.empty_cache()
     return out

@@ -84,7 +84,8 @@ def build_step(cfg, B, sd, **kw):
 def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
                          loss_rtol=1e-4, entry_bar=1e-4, l2_bar=None,
                          update_l2=5e-2, what="", min_tensors=200, screen=True,
-                         entry_abs=0.0, fp64_judge=False, make_batch=None):
+                         entry_abs=0.0, fp64_judge=False, make_batch=None,
+                         shared=None):
     """``iters`` replays of ``step`` against the oracle + torch.optim.RMSprop
     started from the model's CURRENT state (``P``: leaf copies of it).
     ``entry_bar``: every entry of every parameter gradient within that fraction
@@ -96,7 +97,9 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
     evaluation by more than 1e-4 of some small tensors: an entry may then be as
     far from the fp64 oracle as 1e-4 of its tensor's largest + 4 x the fp32
     oracle's own worst error on that tensor, and tensors whose gradient is
-    below 1e-10 everywhere (dust next to RMSprop's eps) only have to be dust; ``l2_bar``: additionally a relative-L2 bound
+    below 1e-10 everywhere (dust next to RMSprop's eps) only have to be dust;
+    ``shared``: a dict through which two runs from the same state and noise
+    (fp32 and bf16 operands) share the screened batch and the oracle's result; ``l2_bar``: additionally a relative-L2 bound
     per tensor (bf16 operands); ``update_l2`` None: no per-step update check."""
     ocfg = O.prepare_model_params(**cfg)
     ropt = torch.optim.RMSprop(list(P.values()), lr=lr, alpha=0.99,
@@ -116,7 +119,11 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
                 p.copy_(now[k])
         flat_noise = predict_noise(step)
         noise = split_noise(flat_noise, cfg, B)
-        if screen:
+        reuse = shared.get(it) if shared is not None else None
+        if reuse is not None:
+            assert torch.equal(reuse["noise"], flat_noise.cpu())
+            image, label = reuse["image"], reuse["label"]
+        elif screen:
             image, label = screened_batch_for_noise(
                 O, cfg, {k: p.detach() for k, p in P.items()}, noise, g,
                 n_classes=cfg["n_classes"])
@@ -125,7 +132,17 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
         else:
             image = torch.rand(B, *cfg["image_shape"], generator=g)
             label = torch.randint(0, cfg["n_classes"], (B,), generator=g)
-        ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label, noise)
+        if reuse is not None:
+            ref_loss, ref_grads = reuse["loss"], reuse["grads"]
+            for k, p in P.items():
+                p.grad = ref_grads[k]
+        else:
+            ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label, noise)
+            if shared is not None:
+                shared[it] = dict(noise=flat_noise.cpu(), image=image, label=label,
+                                  loss=ref_loss.detach(),
+                                  grads={k: None if v is None else v.clone()
+                                         for k, v in ref_grads.items()})
         slack = {}
         if fp64_judge:
             P64 = {k: p.detach().double().requires_grad_(True)
@@ -229,35 +246,42 @@ def test_replayed_train_step_vs_oracle(name):
             0.05 * 3 * 10 * lr, k
 
 
-@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
-def test_replayed_cfg3_step_vs_oracle(bf16):
+def test_replayed_cfg3_step_vs_oracle():
     """BASELINE.json configs[2]'s shape (48 / 64 capsules, B = 1024) as
     ``bench.py`` times it: the REPLAYED step, whose kernel selections differ
     from B = 128 (``gemm_multi_kernel<0>``, separate ``pool_bwd`` / ``tc_bwd``,
-    ``saw_bwd_kernel<4>``, the large-batch loss tail).  fp32: the 1e-4 bars of
-    the other configurations.  ``--bf16`` (``autocast_dtype=torch.bfloat16``:
-    bf16 operands on the matrix cores, fp32 accumulation): loss 2^-7 relative,
-    every gradient tensor 5e-2 relative L2 AND every entry within 2^-3 of its
-    tensor's largest entry, against the fp32 oracle.  (Measured worst entry:
-    0.06 of its tensor's largest, in the per-capsule MLP weights -- operands
-    rounded to 2^-9 flip the ReLU gates of the ~0.3 % of units within that
-    rounding of zero, which moves single entries of a 1024-sample sum by a
-    sample's share; 2^-5 is not what bf16 operands deliver.)"""
+    ``saw_bwd_kernel<4>``, the large-batch loss tail, 32-row capsule-MLP
+    workgroups).  fp32: the 1e-4 bars of the other configurations.  ``--bf16``
+    (``autocast_dtype=torch.bfloat16``: bf16 operands on the matrix cores,
+    fp32 accumulation): loss 2^-7 relative, every gradient tensor 5e-2
+    relative L2 AND every entry within 2^-3 of its tensor's largest entry,
+    against the fp32 oracle.  (Measured worst entry: 0.06 of its tensor's
+    largest, in the per-capsule MLP weights -- operands rounded to 2^-9 flip
+    the ReLU gates of the ~0.3 % of units within that rounding of zero, which
+    moves single entries of a 1024-sample sum by a sample's share; 2^-5 is
+    not what bf16 operands deliver.)  Both precisions start from the same
+    state and draw the same noise, so they share one screened batch and one
+    oracle evaluation."""
     cfg, B, sd, g = full_size_params("cfg3_shape")
-    kw = dict(autocast_dtype=torch.bfloat16) if bf16 else {}
-    model, step = build_step(cfg, B, sd, **kw)
-    step.capture()
-    assert step.graph is not None and step._pro.noise is not None
-    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    if bf16:
-        worst, worst_l2 = check_replayed_steps(
-            model, step, cfg, B, P, g, 1, loss_rtol=2.0 ** -7,
-            entry_bar=2.0 ** -3, l2_bar=5e-2, update_l2=None, what="cfg3 bf16")
-    else:
-        worst, worst_l2 = check_replayed_steps(
-            model, step, cfg, B, P, g, 1, what="cfg3 fp32")
-    print(f"cfg3 {'bf16' if bf16 else 'fp32'} replayed step: worst entry "
-          f"{worst}, worst L2 {worst_l2}")
+    shared = {}
+    for bf16 in (False, True):
+        kw = dict(autocast_dtype=torch.bfloat16) if bf16 else {}
+        model, step = build_step(cfg, B, sd, **kw)
+        step.capture()
+        assert step.graph is not None and step._pro.noise is not None
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        if bf16:
+            worst, worst_l2 = check_replayed_steps(
+                model, step, cfg, B, P, g, 1, loss_rtol=2.0 ** -7,
+                entry_bar=2.0 ** -3, l2_bar=5e-2, update_l2=None,
+                what="cfg3 bf16", shared=shared)
+        else:
+            worst, worst_l2 = check_replayed_steps(
+                model, step, cfg, B, P, g, 1, what="cfg3 fp32", shared=shared)
+        print(f"cfg3 {'bf16' if bf16 else 'fp32'} replayed step: worst entry "
+              f"{worst}, worst L2 {worst_l2}")
+        del model, step
+        torch.cuda.empty_cache()
 
 
 def test_fifty_replayed_steps_vs_oracle_and_torch_rmsprop():
