@@ -671,7 +671,7 @@ def probe_modes(make, which, images, labels, barrier, reduce_max, steps=40,
             out[mode] = {"ms_per_step": round(float(np.median(t)) / steps * 1e3, 4),
                          "runs_as": step.collective_mode}
         except Exception as e:      # a mode this stack cannot run is not chosen
-            out[mode] = {"ms_per_step": float("inf"), "error": repr(e)[:200]}
+            out[mode] = {"ms_per_step": None, "error": repr(e)[:200]}
             torch.cuda.synchronize()
         del step
         torch.cuda.empty_cache()
@@ -798,7 +798,7 @@ def main():
         modes = probe_modes(make, which + ("off",), images, labels, barrier,
                             reduce_max)
         if mode == "auto":
-            mode = min(which, key=lambda m: modes[m]["ms_per_step"])
+            mode = min(which, key=lambda m: modes[m]["ms_per_step"] or 1e9)
     step = make(mode)
 
     # the timed region of the contract -- W warm-ups, then EXACTLY K steps
@@ -817,8 +817,9 @@ def main():
         comm["chosen"] = mode
         # same stage of training on both sides (fresh models)
         comm["step_no_comm_ms"] = modes["off"]["ms_per_step"]
-        comm["exposed_us"] = round((modes[mode]["ms_per_step"]
-                                    - modes["off"]["ms_per_step"]) * 1e3, 1)
+        if modes[mode]["ms_per_step"] and modes["off"]["ms_per_step"]:
+            comm["exposed_us"] = round((modes[mode]["ms_per_step"]
+                                        - modes["off"]["ms_per_step"]) * 1e3, 1)
 
     result = None
     if rank == 0:
