@@ -577,6 +577,19 @@ int scae_capsule_head_conv_fwd_f32(const float *x, const float *w, const float *
                                    int similarity, float *pooled, float *pose, float *presence,
                                    float *feature, float *absence, int B, int HW, int A, int P,
                                    void *stream);
+/* scae_capsule_head_conv_fwd_f32 with scae_template_color_fwd_f32 (TemplateGenerator.forward,
+ * part_decoder.py:78-110; arguments logits .. color_nonlin, M = A, its `feature` input is
+ * this launch's `feature` output) behind it, workgroup by workgroup: the colour MLP of an
+ * (image, capsule group) needs the special features of its own capsules only.
+ * SCAE_ERR_UNSUPPORTED (F != P - 8, different grouping, one group per image): launch the two
+ * in turn. */
+int scae_capsule_head_conv_fwd_tc_f32(
+    const float *x, const float *w, const float *bias, int C, float *y, const float *noise_u,
+    float noise_scale, int similarity, float *pooled, float *pose, float *presence,
+    float *feature, float *absence, int B, int HW, int A, int P, const float *logits,
+    const float *w1, const float *b1, const float *w2, const float *b2, float *raw,
+    float *templates, float *color, int Ct, int hw, int F, int H1, int template_nonlin,
+    int color_nonlin, void *stream);
 int scae_capsule_head_bwd_f32(const float *y, const float *pooled, const float *noise_u,
                               float noise_scale, int similarity, const float *g_pose,
                               const float *g_presence, const float *g_feature,

@@ -513,6 +513,9 @@ def test_likelihood_riding_in_the_trunk_launch_changes_nothing():
             ops._lib.call = real
         _set_counter(step, 1000)
         out[fuse] = _three_steps(step, images, labels)
+    # the template generator's colour kernel rides behind the part encoder's head
+    assert "scae_template_color_fwd_f32" in calls[False]
+    assert "scae_template_color_fwd_f32" not in calls[True]
     assert "scae_set_encoder_fwd_logprob_f32" in calls[True]
     assert "scae_render_gmm_logprob_sums_fwd_f32" not in calls[True]
     assert "scae_set_encoder_fwd_logprob_f32" not in calls[False]

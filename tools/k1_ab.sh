@@ -1,5 +1,6 @@
 #!/bin/bash
-# K1 backward A/B: the in-tree build against tools/ablibs/libold.so, three pose regimes
+# K1 backward A/B: the in-tree build against tools/ablibs/libold.so (build it from the commit to
+# compare with: git stash / checkout, make, cp torch_scae_amd/lib/libscae_hip.so tools/ablibs/libold.so), three pose regimes
 # (unit / init through bench.time_k1_kernels, trained = after NSTEPS bench steps).
 out=${1:-gpurun_out/k1_ab}
 mkdir -p $out

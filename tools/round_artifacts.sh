@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/round_artifacts.sh r02 [notests] -- refresh the round's measurement artifacts into
 # gpurun_out/<round>/ (run on the GPU box from the repo root; copy what is to be judged into profiles/<round>/)
-RN=${1:-r03}; R=$PWD; O=$R/gpurun_out/$RN; mkdir -p $O; export TMPDIR=/tmp
+RN=${1:-r04}; R=$PWD; O=$R/gpurun_out/$RN; mkdir -p $O; export TMPDIR=/tmp
 if [ "$2" != "notests" ]; then
   timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "^FAILED|^E  |passed|failed" | tail -12 > $O/pytest_gpu.txt
 fi

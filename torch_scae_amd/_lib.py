@@ -235,6 +235,8 @@ SIGNATURES = {
     "scae_capsule_head_conv_preferred": [c_int] * 5,
     "scae_capsule_head_conv_fwd_f32": [P, P, P, c_int, P, P, c_float, c_int, P, P, P, P, P]
     + [c_int] * 4 + [P],
+    "scae_capsule_head_conv_fwd_tc_f32": [P, P, P, c_int, P, P, c_float, c_int, P, P, P, P, P]
+    + [c_int] * 4 + [P] * 8 + [c_int] * 6 + [P],
     "scae_capsule_head_bwd_f32": [P, P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_head_bwd_tc_f32": [P, P, P, c_float, c_int, P, P, P, P] + [c_int] * 4
     + [P] * 12 + [c_int] * 6 + [P],
@@ -316,3 +318,14 @@ def check(rc, what):
 
 def call(name, *args):
     check(getattr(load(), name)(*args), name)
+
+
+def try_call(name, *args):
+    """``call`` for a merged launcher that may decline a shape: True when it
+    ran, False for SCAE_ERR_UNSUPPORTED (the caller launches the parts in
+    turn); any other error raises."""
+    rc = getattr(load(), name)(*args)
+    if rc == ERR_UNSUPPORTED:
+        return False
+    check(rc, name)
+    return True

@@ -176,11 +176,9 @@ __device__ __forceinline__ void softmax_masks(float *mask, const float *ys, int 
   }
 }
 
-__global__ __launch_bounds__(NT) void pool_fwd_kernel(PoolArgs k) {
-  extern __shared__ __align__(16) float lds[];
+__device__ __forceinline__ void pool_fwd_body(const PoolArgs &k, float *lds, int blk) {
   // this workgroup: capsules [a0, a0 + A) of image b (A = the group's size from here on)
-  const int Af = k.A, A = Af / k.splits, b = blockIdx.x / k.splits,
-            a0 = (blockIdx.x % k.splits) * A;
+  const int Af = k.A, A = Af / k.splits, b = blk / k.splits, a0 = (blk % k.splits) * A;
   const int HW = k.HW, P = k.P, AP = A * P, APp = padded(AP), ldy = Af * P;
   const size_t cap0 = (size_t)b * Af + a0;  // global index of the group's first capsule
   float *ys = lds, *mask = ys + HW * APp;
@@ -227,6 +225,23 @@ __global__ __launch_bounds__(NT) void pool_fwd_kernel(PoolArgs k) {
       const int a = e / F, f = e - a * F;
       k.feature[cap0 * F + e] = pooled[a * (P - 1) + 7 + f];
     }
+}
+__global__ __launch_bounds__(NT) void pool_fwd_kernel(PoolArgs k) {
+  extern __shared__ __align__(16) float lds[];
+  pool_fwd_body(k, lds, blockIdx.x);
+}
+
+// The head's forward with the template colour MLP's forward (template_color.hip, K10)
+// behind it, workgroup by workgroup -- the mirror image of pool_tc_bwd_kernel below: the
+// colour MLP of an (image, capsule group) only needs the special features of ITS OWN
+// capsules, which this workgroup has just written; tc_fwd (6 us, a dependent launch of its
+// own in the step) becomes the tail of the head's workgroups.
+__global__ __launch_bounds__(NT) void pool_tc_fwd_kernel(PoolArgs k, scae_tc::TcArgs tk) {
+  extern __shared__ __align__(16) float lds[];
+  pool_fwd_body(k, lds, blockIdx.x);
+  __threadfence_block();
+  __syncthreads();   // (the group's feature rows are written; the head's LDS is dead)
+  scae_tc::tc_fwd_body<NT>(tk, lds, blockIdx.x);
 }
 
 // g (B, A, P-1) -> dy (B, HW, A*P)
@@ -454,6 +469,46 @@ extern "C" int scae_capsule_head_conv_fwd_f32(const float *x, const float *w, co
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
                      (conv_x_offset(HW, Ag, P) + (size_t)HW * (C + 4)) * sizeof(float),
                      (hipStream_t)stream, k);
+  return scae_launch_status();
+}
+
+// scae_capsule_head_conv_fwd_f32 with scae_template_color_fwd_f32 (arguments logits ..
+// color_nonlin; its `feature` input is this launch's `feature` output) behind it
+extern "C" int scae_capsule_head_conv_fwd_tc_f32(
+    const float *x, const float *w, const float *bias, int C, float *y, const float *noise_u,
+    float noise_scale, int similarity, float *pooled, float *pose, float *presence,
+    float *feature, float *absence, int B, int HW, int A, int P, const float *logits,
+    const float *w1, const float *b1, const float *w2, const float *b2, float *raw,
+    float *templates, float *color, int Ct, int hw, int F, int H1, int template_nonlin,
+    int color_nonlin, void *stream) {
+  PoolArgs k{};
+  k.cx = x, k.cw = w, k.cb = bias, k.cy = y, k.C = C;
+  k.out = pooled, k.B = B, k.HW = HW, k.A = A, k.P = P;
+  k.splits = pool_splits(B, A);
+  k.noise_u = noise_u, k.noise_scale = noise_scale, k.similarity = similarity;
+  k.pose = pose, k.presence = presence, k.feature = feature, k.absence = absence;
+  int rc = check(k);
+  if (rc) return rc;
+  if (!scae_capsule_head_conv_supported(HW, A, P, C)) return SCAE_ERR_UNSUPPORTED;
+  SCAE_REQUIRE(x && w && y && pooled && pose && presence && feature);
+  SCAE_REQUIRE((((size_t)x | (size_t)w) & 15) == 0);
+  scae_tc::TcArgs tk{};
+  tk.logits = logits, tk.feature = feature, tk.w1 = w1, tk.b1 = b1, tk.w2 = w2, tk.b2 = b2;
+  tk.raw = raw, tk.templates = templates, tk.color = color;
+  tk.B = B, tk.M = A, tk.C = Ct, tk.hw = hw, tk.F = F, tk.H1 = H1;
+  tk.tnl = template_nonlin, tk.cnl = color_nonlin;
+  tk.splits = scae_tc::tc_splits(B, A);
+  rc = scae_tc::check(tk);
+  if (rc) return rc;
+  SCAE_REQUIRE(logits && w1 && b1 && w2 && b2 && raw && templates && color);
+  // the same groups on both sides, the colour MLP's features are the head's special ones;
+  // large batches (one workgroup per image) are not latency-bound: the kernels stay apart
+  if (tk.splits != k.splits || F != P - 8 || k.splits == 1) return SCAE_ERR_UNSUPPORTED;
+  const int Ag = A / k.splits;
+  const size_t lp = conv_x_offset(HW, Ag, P) + (size_t)HW * (C + 4),
+               lt = scae_tc::lds_floats(Ag, Ct, F, H1, false);
+  hipLaunchKernelGGL(pool_tc_fwd_kernel, dim3(B * k.splits), dim3(NT),
+                     (lp > lt ? lp : lt) * sizeof(float), (hipStream_t)stream, k, tk);
   return scae_launch_status();
 }
 

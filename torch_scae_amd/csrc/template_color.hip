@@ -113,11 +113,13 @@ __device__ __forceinline__ float color_grad(float pre2, int cnl) {
 }
 
 // One workgroup per (image b, group of M capsules starting at m0): capsules are
-// independent, and an image alone would leave half of the CUs idle at B=128.
-#ifndef SCAE_DEVICE_ONLY   // (attention_pool.hip includes this file for its device code)
-__global__ __launch_bounds__(NT) void tc_fwd_kernel(TcArgs k) {
-  extern __shared__ float lds[];
-  const int M = k.M / k.splits, b = blockIdx.x / k.splits, m0 = (blockIdx.x % k.splits) * M;
+// independent, and an image alone would leave half of the CUs idle at B=128.  As a device
+// function (block `blk` of B * splits, NT threads -- any: every sum has one owner), so that
+// the part-capsule head's forward workgroup of the same group can run it behind itself
+// (attention_pool.hip, pool_tc_fwd_kernel).
+template <int NT>
+__device__ __forceinline__ void tc_fwd_body(const TcArgs &k, float *lds, int blk) {
+  const int M = k.M / k.splits, b = blk / k.splits, m0 = (blk % k.splits) * M;
   const Lds l = carve(lds, k, M);
   const int t = threadIdx.x, MC = M * k.C;
   const size_t cap0 = (size_t)b * k.M + m0;  // global index of the group's first capsule
@@ -135,6 +137,11 @@ __global__ __launch_bounds__(NT) void tc_fwd_kernel(TcArgs k) {
     dst[e] = r * l.pre2[e / k.hw];
     if (b == 0) k.raw[(size_t)m0 * k.C * k.hw + e] = r;
   }
+}
+#ifndef SCAE_DEVICE_ONLY   // (attention_pool.hip includes this file for its device code)
+__global__ __launch_bounds__(NT) void tc_fwd_kernel(TcArgs k) {
+  extern __shared__ float lds[];
+  tc_fwd_body<NT>(k, lds, blockIdx.x);
 }
 #endif
 

@@ -1349,6 +1349,23 @@ def _capsule_head_fwd(x, weight, bias, noise_u, n_caps, noise_scale,
             (x.data_ptr() | weight.data_ptr()) % 16 == 0:
         # the 1x1 conv inside the pooling workgroups (small batches)
         y = new(B, HW, n_caps * P)
+        offer = _plan().offers.get("tc_fwd")
+        if offer is not None and feature is not None and offer.result is None \
+                and offer.M == n_caps and offer.F == F and offer.ok:
+            # RIDES['tc_fwd']: the template generator's colour MLP behind the
+            # head, workgroup by workgroup (it reads ``feature``, made here)
+            raw = new(1, n_caps, offer.C, *offer.hw)
+            templates = new(B, n_caps, offer.C, *offer.hw)
+            color = new(B, n_caps, offer.C)
+            if _lib.try_call(
+                    "scae_capsule_head_conv_fwd_tc_f32", _p(x), _p(weight),
+                    _p(bias), C, _p(y), *head[:-1],
+                    *[_p(t) for t in offer.params], _p(raw), _p(templates),
+                    _p(color), offer.C, offer.hw[0] * offer.hw[1], F, offer.H1,
+                    *offer.codes, head[-1]):
+                offer.result, offer.feature = (raw, templates, color), feature
+                return y, pooled, pose, presence, feature, absence
+            offer.ok = False
         _lib.call("scae_capsule_head_conv_fwd_f32", _p(x), _p(weight),
                   _p(bias), C, _p(y), *head)
     else:
@@ -1647,6 +1664,44 @@ def template_color_supported(M, C, F, H1, template_nonlin, color_nonlin):
             and bool(_lib.load().scae_template_color_supported(M, C, F, H1)))
 
 
+class _TcOffer:
+    """RIDES['tc_fwd']: the template generator's colour-MLP forward, offered
+    (by SCAE.forward, ahead of the part encoder) to the part-capsule head's
+    launch, which produces the ``feature`` it reads."""
+
+    def __init__(self, logits, w1, b1, w2, b2, tnl, cnl):
+        _need_hip(logits, w1, b1, w2, b2)
+        self.params = [t.detach().contiguous() for t in (logits, w1, b1, w2, b2)]
+        _, self.M, self.C, th, tw = logits.shape
+        self.hw, self.F, self.H1 = (th, tw), w1.shape[1], w1.shape[0]
+        self.codes = (tnl, cnl)
+        self.result = self.feature = None
+        self.ok = True
+
+    def serves(self, logits, feature, w1, b1, w2, b2, tnl, cnl):
+        return self.result is not None and self.codes == (tnl, cnl) and \
+            self.feature.data_ptr() == feature.data_ptr() and \
+            self.feature.shape == feature.shape and all(
+                a.data_ptr() == b.data_ptr() and a.shape == b.shape
+                for a, b in zip(self.params, (logits, w1, b1, w2, b2)))
+
+
+def offer_colored_templates(template_logits, w1, b1, w2, b2, template_nonlin,
+                            color_nonlin):
+    """Inside a fused step: let the part encoder's head launch carry the
+    coloured-template kernel that the next ``colored_templates`` call with
+    these parameters (and that encoder's ``feature``) would launch."""
+    plan = _plan()
+    if plan.fused and torch.is_grad_enabled() and template_logits.is_cuda:
+        plan.offer("tc_fwd", _TcOffer(template_logits, w1, b1, w2, b2,
+                                      _NONLIN_CODE[template_nonlin],
+                                      _NONLIN_CODE[color_nonlin]))
+
+
+def withdraw_colored_templates_offer():
+    _plan().claim("tc_fwd")
+
+
 class _ColoredTemplates(torch.autograd.Function):
     @_fwd
     def forward(ctx, logits, feature, w1, b1, w2, b2, tnl, cnl,
@@ -1658,11 +1713,17 @@ class _ColoredTemplates(torch.autograd.Function):
         B, F, H1 = feature.shape[0], feature.shape[2], w1.shape[0]
         new = lambda *shape: torch.empty(*shape, device=logits.device,
                                          dtype=logits.dtype)
-        raw, templates, color = new(1, M, C, th, tw), new(B, M, C, th, tw), \
-            new(B, M, C)
-        _lib.call("scae_template_color_fwd_f32", _p(logits), _p(feature),
-                  _p(w1), _p(b1), _p(w2), _p(b2), _p(raw), _p(templates),
-                  _p(color), B, M, C, th * tw, F, H1, tnl, cnl, _stream(logits))
+        offer = ctx.plan.claim("tc_fwd")
+        if offer is not None and offer.serves(logits, feature, w1, b1, w2, b2,
+                                              tnl, cnl):
+            raw, templates, color = offer.result     # made in the head's launch
+        else:
+            raw, templates, color = new(1, M, C, th, tw), \
+                new(B, M, C, th, tw), new(B, M, C)
+            _lib.call("scae_template_color_fwd_f32", _p(logits), _p(feature),
+                      _p(w1), _p(b1), _p(w2), _p(b2), _p(raw), _p(templates),
+                      _p(color), B, M, C, th * tw, F, H1, tnl, cnl,
+                      _stream(logits))
         ctx.save_for_backward(logits, feature, w1, b1, w2, b2, color)
         ctx.codes = (tnl, cnl)
         ctx.slots = [_slot(t, ctx) for t in (logits, w1, b1, w2, b2)]

@@ -109,9 +109,13 @@ class SCAE(nn.Module):
 
     def _forward(self, image):
         batch_size = image.shape[0]
+        # (inside a training step the template generator's colour kernel rides
+        # behind the part encoder's head, which makes the features it reads)
+        self._offer_template_colours(image)
         parts = self.part_encoder(image)
         templates = self.template_generator(feature=parts.feature,
                                             batch_size=batch_size).templates
+        ops.withdraw_colored_templates_offer()
 
         # object encoder input: [pose, 1 - presence | feature | templates];
         # pose / presence / templates detached, the feature skip-connection
@@ -227,6 +231,18 @@ class SCAE(nn.Module):
             res.posterior_cls_prob = self.prior_classifier(
                 res.posterior_mixing_prob.sum(-1).detach())
         return res
+
+    def _offer_template_colours(self, image):
+        tg = self.template_generator
+        mlp = getattr(tg, "templates_color_mlp", None)
+        if not image.is_cuda or image.dtype != torch.float32 or \
+                not getattr(tg, "colorize_templates", False) or mlp is None \
+                or len(mlp) != 4 or tg._nonlin_names[0] not in ops._NONLIN_CODE \
+                or tg._nonlin_names[1] not in ops._NONLIN_CODE:
+            return
+        ops.offer_colored_templates(tg.template_logits, mlp[0].weight,
+                                    mlp[0].bias, mlp[2].weight, mlp[2].bias,
+                                    *tg._nonlin_names)
 
     def _offer_likelihood_rider(self, image, templates, parts):
         """stacked_capsule_auto_encoder.py:146-162 + :220 ahead of :126-130:

@@ -37,7 +37,9 @@ class Ride:
               results autograd may add to it -- so the launch must have been
               issued before they start (``ANY``: every node but the carriers);
     scope:    the ``StepPlan`` scope whose end launches whatever nobody
-              carried ("fusing" / "deferring");
+              carried ("fusing" / "deferring"); "offer": a launch OFFERED ahead
+              of its own node to an earlier node's launch (``StepPlan.offer`` /
+              ``claim``) -- its node finds the result, or launches as usual;
     abi:      the merged C-ABI launcher (documentation; include/scae_hip.h)."""
 
     __slots__ = ("carriers", "readers", "scope", "abi", "what")
@@ -50,6 +52,14 @@ class Ride:
 # Ordered: a row may read what an earlier row writes (the folding products'
 # backward reads the attention's reduction), so flushes walk the table in order.
 RIDES = collections.OrderedDict([
+    ("tc_fwd", Ride(
+        "the colour MLP's forward (K10)",
+        carriers=("_PartEncoder.forward",), scope="offer",
+        abi="scae_capsule_head_conv_fwd_tc_f32")),
+    ("logprob_fwd", Ride(
+        "the reconstruction likelihood's forward (K1)",
+        carriers=("_SetEncoder.forward",), scope="offer",
+        abi="scae_set_encoder_fwd_logprob_f32")),
     ("class_probs", Ride(
         "SCAE.forward's two classifier heads (one wave per image)",
         carriers=("_LossTail.forward",), scope="fusing",
@@ -89,6 +99,7 @@ class StepPlan:
         self.name = name
         self.target = None        # the loss's reconstruction target while fusing
         self.rider = None         # ops.LogProbRider offered to the trunk launch
+        self.offers = {}          # kind -> launch offered to an earlier node's launch
         self.parked = {}          # kind -> parked launch (has .launch_alone())
         self.deferred = None      # queued column-sum units while deferring
         self.prologue = prologue  # ops.StepPrologue or None
@@ -116,8 +127,15 @@ class StepPlan:
         return self.target is not None and self.deferred is not None
 
     # -- parked launches --------------------------------------------------
+    def offer(self, kind, work):
+        assert RIDES[kind].scope == "offer", kind
+        self.offers[kind] = work
+
+    def claim(self, kind):
+        return self.offers.pop(kind, None)
+
     def park(self, kind, work):
-        assert kind in RIDES, kind
+        assert kind in RIDES and RIDES[kind].scope != "offer", kind
         stale = self.parked.pop(kind, None)
         if stale is not None:        # (never within one step of one model)
             stale.launch_alone()
@@ -170,12 +188,14 @@ class StepPlan:
         prev = (self.target, self.rider)
         self.target, self.rider = target, None
         self.parked.clear()      # (a backward that raised may have left some)
+        self.offers.clear()
         ok = False
         try:
             yield self
             ok = True
         finally:
             self.target, self.rider = prev
+            self.offers.clear()
             if ok:
                 self.flush_scope("fusing")   # (a block without the fused tail)
 
