@@ -376,12 +376,21 @@ def test_two_steps_interleaved_in_one_process_equal_the_steps_run_apart():
         assert sa.plan.holds("class_probs") or sa.plan.holds("combine")
         ra = backward(sa, la, ka)
         rb = backward(sb, lb, kb)
-    for (l0, g0), (l1, g1) in zip(apart, (ra, rb)):
+    def differing(step, a, b):
+        nm = {id(p): n for n, p in step.model.named_parameters()}
+        return [(nm[id(p)], float((a[o:o + p.numel()] - b[o:o + p.numel()])
+                                  .abs().max()))
+                for p, o in zip(step.flat.params, step.flat.offsets)
+                if not torch.equal(a[o:o + p.numel()], b[o:o + p.numel()])]
+
+    for step, (l0, g0), (l1, g1) in zip((sa, sb), apart, (ra, rb)):
         assert l0 == l1, (l0, l1)
-        assert torch.equal(g0, g1)
+        assert torch.equal(g0, g1), ("interleaved", differing(step, g0, g1)[:8])
         assert float(g0.abs().max()) > 0
     # and the plain step of the class gives the same bits as the hand-run one
     for step, batch, (l0, g0) in zip(build(), batches, apart):
         loss = step(*batch)
         torch.cuda.synchronize()
-        assert float(loss) == l0 and torch.equal(step.flat.flat_grad, g0)
+        assert float(loss) == l0
+        assert torch.equal(step.flat.flat_grad, g0), \
+            ("plain", differing(step, step.flat.flat_grad, g0)[:8])

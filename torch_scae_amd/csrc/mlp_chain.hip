@@ -29,8 +29,15 @@
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int NW = 8, NT = 64 * NW, MAXL = 4, CH = 8;   // (16 RBT batch rows per workgroup)
-constexpr int WLD = 128 + 4;   // row stride of a wave's weight tile: (WLD / 4) odd
+#ifndef SCAE_CHAIN_CH
+#define SCAE_CHAIN_CH 4   // 16-wide k steps per item: 64-wide chunks, 35 KB of weight tiles (8: 128-wide, 68 KB)
+#endif
+constexpr int NW = 8, NT = 64 * NW, MAXL = 4, CH = SCAE_CHAIN_CH;   // (16 RBT batch rows per workgroup)
+constexpr int KC = 16 * CH;          // contraction columns of one item
+constexpr int QPR = KC / 4;          // 16-byte quads per weight row of an item (forward form)
+constexpr int RPI = 64 / QPR;        // weight rows one wave instruction fetches (forward form)
+static_assert(CH == 8 || CH == 4, "chunk widths of 128 or 64");
+constexpr int WLD = KC + 4;   // row stride of a wave's weight tile: (WLD / 4) odd
 
 struct Layer {
   const float *w;
@@ -51,6 +58,7 @@ struct Chain {
   long in_gs, in_bs;
   int n, in_dim, B, G;
   int stride[2];   // floats per LDS row of activation buffer 0 (input, odd layers' outputs) / 1
+  int wscratch;    // the vote blocks take their scratch in the weight tiles (narrow buffer 1)
   // the capsule votes (K3) at the end of the forward chain / at the head of the
   // data-gradient chain
   int votes;
@@ -99,14 +107,14 @@ template <bool BWD, int RBT>
 __device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g, int b0, int B,
                                            int tile, int ch, int nch, int lane, float4 (&buf)[CH],
                                            float4 (&epi)[RBT]) {
-  const int n0 = 16 * tile, k0 = 128 * ch, ldw = L.ldw, LN = L.N;
+  const int n0 = 16 * tile, k0 = KC * ch, ldw = L.ldw, LN = L.N;
   // rows of the matrix: N (forward) / K (data gradient)
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(W), 0, (BWD ? L.K : L.N) * ldw * 4, 0x00020000);
   if (!BWD) {
-    const int o = ((n0 + (lane >> 5)) * ldw + k0 + 4 * (lane & 31)) * 4;
+    const int o = ((n0 + lane / QPR) * ldw + k0 + 4 * (lane % QPR)) * 4;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) buf[i] = bload4(rs, o + 2 * i * ldw * 4);
+    for (int i = 0; i < CH; ++i) buf[i] = bload4(rs, o + RPI * i * ldw * 4);
   } else {
     const int o = ((k0 + (lane >> 2)) * ldw + n0 + 4 * (lane & 3)) * 4;
 #pragma unroll
@@ -160,9 +168,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
   // registers -> the wave's LDS tile [16 columns][128 k (+4)]
   auto park = [&](const float4 (&buf4)[CH]) {
     if (!BWD) {
-      float *d = wtile + (lane >> 5) * WLD + 4 * (lane & 31);
+      float *d = wtile + (lane / QPR) * WLD + 4 * (lane % QPR);
 #pragma unroll
-      for (int i = 0; i < CH; ++i) *reinterpret_cast<float4 *>(d + 2 * i * WLD) = buf4[i];
+      for (int i = 0; i < CH; ++i) *reinterpret_cast<float4 *>(d + RPI * i * WLD) = buf4[i];
     } else {   // transposed: (k, 4 columns) -> [column][k]; banks 16 cq + 4 j + k: distinct
       float *d = wtile + 4 * (lane & 3) * WLD + (lane >> 2);
 #pragma unroll
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
 #pragma unroll
     for (int rb = 0; rb < RBT; ++rb)
       scae_votes::bwd_block<NT>(c.va, c.vg, smem + 16 * rb * c.stride[0], c.stride[0],
-                                RBT == 1 ? buf(1) : wbase, b0 + 16 * rb, g);
+                                c.wscratch ? wbase : buf(1), b0 + 16 * rb, g);
   } else
   {  // the block's input rows, zero padded to a multiple of 16 columns / to RB rows; eight
      // independent loads per thread in flight (a load-store loop pays a memory round trip
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
 #pragma unroll
             for (int rb = 0; rb < RBT; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
-          const float *arow = cur + r * cs + 128 * ch + 4 * q;
+          const float *arow = cur + r * cs + KC * ch + 4 * q;
           const float *brow = wtile + r * WLD + 4 * q;
 #pragma unroll
           for (int s = 0; s < CH; ++s)
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
     for (int rb = 0; rb < RBT; ++rb) {
       __syncthreads();
       scae_votes::fwd_block<NT>(c.va, c.vo, buf(c.n & 1) + 16 * rb * c.stride[c.n & 1],
-                                c.stride[c.n & 1], RBT == 1 ? buf((c.n + 1) & 1) : wbase,
+                                c.stride[c.n & 1], c.wscratch ? wbase : buf((c.n + 1) & 1),
                                 b0 + 16 * rb, g);
     }
   }
@@ -397,9 +405,18 @@ int launch(const scae_mlp_chain_desc *d, const scae_votes_desc *v, void *stream)
   const size_t lds2 = ((size_t)32 * (c2.stride[0] + c2.stride[1]) + (size_t)NW * 16 * WLD) * sizeof(float);
   const bool scratch_ok = !c.votes || (size_t)16 * c.va.V * 7 <= (size_t)NW * 16 * WLD;
   const bool big = c.G * ((c.B + 31) / 32) >= SCAE_CHAIN_RB32_MIN_WGS;
-  if (lds2 <= 160 * 1024 && scratch_ok && want != 16 && (big || want == 32))
+  c2.wscratch = 1;
+  // 16 rows with narrow buffers where that lets TWO workgroups share a CU's LDS (16 waves
+  // per CU cover each other's dependent fetch / park / multiply sequence: at the cfg-3 shape
+  // 5.34 ms per step against 5.38 with 32 rows and one workgroup per CU, 5.48 with 16 rows
+  // and one; cfg-5 0.870 against 0.894); 32 rows where only one fits anyway
+  const size_t lds1 = ((size_t)16 * (c.stride[0] + c.stride[1]) + (size_t)NW * 16 * WLD) * sizeof(float);
+  const size_t lds1n = ((size_t)16 * (c2.stride[0] + c2.stride[1]) + (size_t)NW * 16 * WLD) * sizeof(float);
+  const bool narrow16 = scratch_ok && lds1 > 80 * 1024 && lds1n <= 80 * 1024;
+  if (lds2 <= 160 * 1024 && scratch_ok && want != 16 && (want == 32 || (big && !narrow16)))
     return launch_rb<BWD, 2>(c2, stream);
-  return launch_rb<BWD, 1>(c, stream);
+  if (narrow16) return launch_rb<BWD, 1>(c2, stream);
+  return launch_rb<BWD, 1>(c, stream);   // (one stride, scratch in buffer 1)
 }
 }  // namespace
 

@@ -2663,7 +2663,13 @@ class _LossTail(torch.autograd.Function):
         w5 = (ctypes.c_float * 5)(*weights)
         ints = (B, O, M, ncls, int(n_classes_cfg or 0), prior_type, post_type,
                 int(sparsity_on))
-        out = torch.empty(12, device=lpp.device, dtype=lpp.dtype)
+        # the two outputs are views of ONE buffer that the node (and a parked
+        # combine) keeps alive: a deferred combine writes them during the
+        # backward pass, by address -- also when the caller has dropped the log
+        # vector by then (the outputs themselves cannot be held: they point
+        # back at this node)
+        both = torch.empty(16, device=lpp.device, dtype=lpp.dtype)
+        out = both[:12]
         wc = float("nan") if within_const is None else float(within_const)
         lab = None if label is None else ctypes.c_void_p(label.data_ptr())
         ex = _lib.LossExtras()
@@ -2671,7 +2677,7 @@ class _LossTail(torch.autograd.Function):
             ex.rec_sums, ex.n_rec = rec_sums.data_ptr(), rec_sums.numel()
         if reg is not None:
             ex.reg, ex.w_reg = reg.data_ptr(), float(w_reg)
-        loss = torch.empty((), device=lpp.device, dtype=lpp.dtype)
+        loss = both[12]
         ex.loss = loss.data_ptr()
         # The whole training scalar inside a fused step: nothing reads the
         # scalars before the backward has run, so the batch combine (one
@@ -2706,7 +2712,7 @@ class _LossTail(torch.autograd.Function):
             # (addresses only: ``loss`` / ``out`` are this node's outputs)
             ctx.deferred = _PendingCombine(
                 tail, (lpp, posterior, caps_presence, cls_w, cls_b, label,
-                       rec_sums, reg, ws, w5, ex), loss.data_ptr(),
+                       rec_sums, reg, ws, w5, both, ex), loss.data_ptr(),
                 out.data_ptr(), lpp)
             ctx.plan.park("combine", ctx.deferred)
         return loss, out
