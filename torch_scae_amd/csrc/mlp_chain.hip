@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SCAE_CHAIN_CH
 #define SCAE_CHAIN_CH 4   // 16-wide k steps per item: 64-wide chunks, 35 KB of weight tiles (8: 128-wide, 68 KB)
 #endif
+#ifndef SCAE_CHAIN_LB4
+#define SCAE_CHAIN_LB4 1
+#endif
 constexpr int NW = 8, NT = 64 * NW, MAXL = 4, CH = SCAE_CHAIN_CH;   // (16 RBT batch rows per workgroup)
 constexpr int KC = 16 * CH;          // contraction columns of one item
 constexpr int QPR = KC / 4;          // 16-byte quads per weight row of an item (forward form)
@@ -154,8 +157,9 @@ __device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g
 // their way to the MFMA fragments (transposed on the way in for the data-gradient form).
 // One workgroup barrier per layer boundary separates the writes of a layer's output from
 // its reads.
+// (16-row workgroups: four waves per SIMD, so that two of them share a CU)
 template <bool BWD, int RBT>
-__global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
+__global__ __launch_bounds__(NT, (RBT == 1 && SCAE_CHAIN_LB4) ? 4 : 2) void chain_kernel(Chain c) {
   constexpr int RB = 16 * RBT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63,
@@ -237,8 +241,8 @@ __global__ __launch_bounds__(NT) void chain_kernel(Chain c) {
       f32x4 acc[RBT];
       for (int tile = wid; tile < ntiles; tile += NW) {
         for (int ch = 0; ch < nch; ++ch) {
-          park(f);   // (waits for the item's loads)
           float4 epi[RBT];
+          park(f);   // (waits for the item's loads)
 #pragma unroll
           for (int rb = 0; rb < RBT; ++rb) epi[rb] = fe[rb];
           // the next item's loads fly while this one is multiplied
