@@ -51,17 +51,19 @@ def pad_and_translate(images, out_size=(40, 40), generator=None, shifts=None):
 
 
 def stroke_batches(n_batches, batch, image_shape, seed=0, device="cpu",
-                   n_classes=10, strokes=4):
+                   n_classes=10, strokes=4, glyph_seed=None):
     """-> (images (n_batches, B, C, H, W) float32 in [0, 1], labels
     (n_batches, B) int64).  Class c is a fixed glyph of ``strokes`` line
-    segments (drawn once from ``seed``); a sample is its glyph under a random
+    segments (drawn once from ``seed``, or from ``glyph_seed`` when given: a
+    held-out set is the same ``glyph_seed`` under another ``seed``); a sample is its glyph under a random
     rotation (+-25 degrees), scale (0.75 .. 1.1), shear and translation
     (+-0.2), drawn with a soft pen (Gaussian profile, sigma 0.07 of the half
     image) -- evaluated analytically per pixel on ``device``."""
     C, H, W = image_shape
     g = torch.Generator(device="cpu").manual_seed(seed)
     # glyphs: endpoints in [-0.75, 0.75]^2, consecutive strokes share an endpoint
-    pts = torch.rand(n_classes, strokes + 1, 2, generator=g) * 1.5 - 0.75
+    gg = g if glyph_seed is None else torch.Generator(device="cpu").manual_seed(glyph_seed)
+    pts = torch.rand(n_classes, strokes + 1, 2, generator=gg) * 1.5 - 0.75
     N = n_batches * batch
     labels = torch.randint(0, n_classes, (N,), generator=g)
     ang = (torch.rand(N, generator=g) * 2 - 1) * math.radians(25.0)
