@@ -31,9 +31,31 @@
 #include "set_encoder_args.h"
 #include "wave_mfma.h"
 
+// This file's device code is compiled twice -- here and inside trunk_logprob.hip's shared
+// launch -- and both must produce the same bits (tests/test_timed_path.py): no implicit
+// multiply-add contraction, whose choice depends on the surrounding code; the fused
+// operations below are written as fmaf.
+#pragma clang fp contract(off)
+
 namespace scae_st {
 namespace {
 using namespace scae_wave;
+
+// -DSCAE_STW_PROF: s_memtime stamps of workgroup 5's first lane at the stage boundaries of
+// the backward kernel (tools/stw_prof.py reads them through scae_debug_stw_prof)
+#ifdef SCAE_STW_PROF
+__device__ unsigned long long g_stw_prof[160];
+__device__ int g_stw_n;
+#define STW_T()                                                                  \
+  do {                                                                           \
+    if (blockIdx.x == 5 && threadIdx.x == 0) {                                   \
+      const int i_ = g_stw_n;                                                    \
+      if (i_ < 160) g_stw_prof[i_] = __builtin_readcyclecounter(), g_stw_n = i_ + 1; \
+    }                                                                            \
+  } while (0)
+#else
+#define STW_T()
+#endif
 
 struct Lay {   // packed parameter offsets (floats), see set_encoder.hip
   int Din, L, ln;
@@ -118,7 +140,12 @@ __device__ __forceinline__ void layer_norm(f32x4 &v, float gamma, float beta, f3
     const float x = v[e];
     const float mean = rsum(x) * (1.f / D);
     const float d = x - mean;
+#ifdef SCAE_NO_RSQ
     const float rs = 1.f / sqrtf(rsum(d * d) * (1.f / D) + kLnEps);
+#else
+    const float rs = __builtin_amdgcn_rsqf(rsum(d * d) * (1.f / D) + kLnEps);   // (1 ulp; the
+    // argument is >= 1e-5: the IEEE sqrt + division were ~40 instructions per row)
+#endif
     const float h = d * rs;
     if (KEEP) xh[e] = h, rstd[e] = rs;
     v[e] = fmaf(h, gamma, beta);
@@ -147,7 +174,7 @@ struct Geo {
   static constexpr int TSN = 16 * NT + 8;
   static constexpr int SMALL = 16 * NT * RS > 16 * TSN ? 16 * NT * RS : 16 * TSN;
   static constexpr int LARGE = 16 * NT * TSN;
-  static constexpr int SCR = (NT > 1 ? NT - 1 : 1) * (5 * 256 + 10 * D);   // hand-over area
+  static constexpr int SCR = NT * (5 * 256 + 10 * D);   // hand-over area: a slot per wave
 };
 enum {
   S_HS = 0, S_QS,                      // private rows: Hs = As = GR, Qs = H1s
@@ -197,6 +224,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
     g1 = Wl[lay.ln1() + r], be1 = Wl[lay.ln1() + D + r];
   }
   if (KEEP) st->hin = h;
+  STW_T();
   // q, k, v projections of the own rows
   w.wr_rows(Hs, h);
   lds_fence();
@@ -217,6 +245,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   }
   lds_fence();
   if (NT > 1) __syncthreads();   // the other wave's keys / values
+  STW_T();
   // routing logits (q k^T - (1 - presence_m) 1e32) / sqrt(d), softmax over the keys m
   f32x4 s[NT];
   {
@@ -224,6 +253,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
 #pragma unroll
     for (int u = 0; u < NT; ++u) s[u] = mma16p<BF>(splat(0.f), qa, w.rd16(Ks, u));
   }
+  STW_T();
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     // (sqrt(16) = 4: the division is an exact multiplication)
@@ -236,7 +266,11 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
     mx = rmax(mx);
 #pragma unroll
     for (int u = 0; u < NT; ++u) v[u] = __expf(v[u] - mx), sum += v[u];   // exp(-inf) = 0
+#ifdef SCAE_NO_RCP
     const float inv = 1.f / rsum(sum);
+#else
+    const float inv = __builtin_amdgcn_rcpf(rsum(sum));   // (sum >= 1: the row maximum's term)
+#endif
 #pragma unroll
     for (int u = 0; u < NT; ++u) s[u][e] = v[u] * inv;
   }
@@ -244,11 +278,13 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
 #pragma unroll
     for (int u = 0; u < NT; ++u) st->p[u] = s[u];
   }
+  STW_T();
   // a = P V
   w.template wr_nn<NT>(Ps, s);
   lds_fence();
   const f32x4 ao = mma_np<NT, BF>(splat(0.f), w, Ps, t, Vt, 0);   // B[k = m][c]: row c of Vt
   if (KEEP) st->ao = ao;
+  STW_T();
   // r = (Wo a + bo + h) presence_n; LN0
   w.wr_rows(As, ao);
   lds_fence();
@@ -257,6 +293,7 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
   for (int e = 0; e < 4; ++e) h1[e] = (h1[e] + h[e]) * pres[e];
   f32x4 dummy;
   if (lay.ln) layer_norm<KEEP>(h1, g0, be0, KEEP ? st->xh0 : dummy, KEEP ? st->rstd0 : dummy);
+  STW_T();
   // h2 = h1 + relu(Wf h1 + bf); LN1
   w.wr_rows(H1s, h1);
   lds_fence();
@@ -265,11 +302,12 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
 #pragma unroll
   for (int e = 0; e < 4; ++e) h[e] = h1[e] + fmaxf(tv[e], 0.f);
   if (lay.ln) layer_norm<KEEP>(h, g1, be1, KEEP ? st->xh1 : dummy, KEEP ? st->rstd1 : dummy);
+  STW_T();
 }
 
 // LDS of a workgroup (floats).  Forward: X [16 NT][XS] | W1s [16][XS] | small | large.
-// Backward: W1s | small | hand-over area | arena, the arena holding the large tiles during
-// the blocks and X afterwards (the input is only needed for the fc1 weight gradient).
+// Backward: small | hand-over area | large (fc1's backward reads its operands from global
+// memory).
 __host__ __device__ inline int xs_of(int Din) { return (Din + 15) / 16 * 16 + 4; }
 template <int NT>
 __host__ __device__ inline size_t lds_floats(int Din, bool bwd) {
@@ -277,10 +315,8 @@ __host__ __device__ inline size_t lds_floats(int Din, bool bwd) {
   if (!bwd)
     return (16 * NT + 16) * xs + (size_t)S_FWD_SMALL * Geo<NT>::SMALL +
            (size_t)L_FWD_LARGE * Geo<NT>::LARGE;
-  const size_t arena = (size_t)L_BWD_LARGE * Geo<NT>::LARGE > 16 * NT * xs
-                           ? (size_t)L_BWD_LARGE * Geo<NT>::LARGE
-                           : 16 * NT * xs;
-  return 16 * xs + (size_t)S_BWD_SMALL * Geo<NT>::SMALL + Geo<NT>::SCR + arena;
+  return (size_t)S_BWD_SMALL * Geo<NT>::SMALL + Geo<NT>::SCR +
+         (size_t)L_BWD_LARGE * Geo<NT>::LARGE;
 }
 
 // 4 bytes per lane, global -> LDS (lane l lands at lds + 4 l bytes): a row of up to 64
@@ -306,17 +342,71 @@ __device__ __forceinline__ void dma_wait() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// the own rows of the set's input (segments side by side) into X; X's padding stays zero
-__device__ __forceinline__ void stage_input(const StArgs &a, int b, const Wave &w, float *X,
-                                            int XS) {
+// [p, p + n) floats of LDS (p 16-byte aligned, n a multiple of 4) <- 0, 16 bytes per lane
+__device__ __forceinline__ void lds_zero(float *p, int n, int tid, int nthreads) {
+  for (int i = 4 * tid; i < n; i += 4 * nthreads)
+    *reinterpret_cast<float4 *>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// The own rows of the set's input (segments side by side) into X; X's padding stays zero.
+// Wide segments travel by LDS-DMA (one instruction per 64 floats of a row, asynchronous; an
+// LDS-DMA instruction costs the wave 60-100 cycles of issue whatever it moves).  A narrow
+// segment would cost an instruction per ROW -- the 16 x (6 | 1 | 16) rows of cfg-2 were 48 of
+// the wave's 80 -- so the narrow segments' columns of the 16 rows are walked as ONE index
+// space, a lane per float, through registers: NF loads per lane.  Two halves: every transfer
+// is issued before the caller does anything else, `commit` writes the registers to LDS.
+constexpr int NARROW = 16;   // widest segment that goes through registers ...
+constexpr int NF = 6;        // ... while rows x (their widths) fits 64 NF floats (else: all by DMA)
+struct NarrowRows {
+  float v[NF];
+  int off[NF];   // LDS float index, -1: nothing
+};
+__device__ __forceinline__ void stage_input_issue(const StArgs &a, int b, const Wave &w, float *X,
+                                                  int XS, NarrowRows &nr) {
   const int n0 = 16 * w.t, n1 = min(a.N, n0 + 16);
+  int wn = 0;
+#pragma unroll
+  for (int s = 0; s < MAXSEG; ++s)
+    if (s < a.nseg && a.seg[s].width <= NARROW) wn += a.seg[s].width;
+  const int total = (n1 - n0) * wn;
+  const bool regs = total > 0 && total <= 64 * NF;
   int col = 0;
 #pragma unroll 1
   for (int s = 0; s < a.nseg; ++s) {
-    dma_rows(a.seg[s].ptr + (size_t)b * a.seg[s].bs, a.seg[s].rs, n0, n1, a.seg[s].width,
-             X + col, XS, w.lane);
-    col += a.seg[s].width;
+    const Seg &sg = a.seg[s];
+    if (!(regs && sg.width <= NARROW))
+      dma_rows(sg.ptr + (size_t)b * sg.bs, sg.rs, n0, n1, sg.width, X + col, XS, w.lane);
+    col += sg.width;
   }
+  const float inv_wn = 1.f / (float)(wn > 0 ? wn : 1);   // ((i + 0.5) / wn is exact enough here)
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int i = 64 * j + w.lane;
+    nr.off[j] = -1, nr.v[j] = 0.f;
+    if (regs && i < total) {
+      const int n = (int)(((float)i + 0.5f) * inv_wn), cn = i - n * wn;
+      const float *src = nullptr;
+      int rs = 0, dc = 0, c0 = 0, c0n = 0;
+#pragma unroll
+      for (int s = 0; s < MAXSEG; ++s) {
+        if (s < a.nseg) {
+          const Seg &sg = a.seg[s];
+          if (sg.width <= NARROW) {
+            if (cn >= c0n) src = sg.ptr + (size_t)b * sg.bs + (cn - c0n), rs = sg.rs, dc = c0 + cn - c0n;
+            c0n += sg.width;
+          }
+          c0 += sg.width;
+        }
+      }
+      nr.off[j] = (n0 + n) * XS + dc;
+      nr.v[j] = src[(size_t)(n0 + n) * rs];
+    }
+  }
+}
+__device__ __forceinline__ void stage_input_commit(float *X, const NarrowRows &nr) {
+#pragma unroll
+  for (int j = 0; j < NF; ++j)
+    if (nr.off[j] >= 0) X[nr.off[j]] = nr.v[j];
 }
 
 // fc1 of the own tile: x W1^T + b1, two independent accumulation chains
@@ -391,6 +481,7 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
   lg.w[4] = mma16(splat(0.f), rdT_own(w, XT1), rdT_own(w, XT2));
   lg.v[4] = csum(gt);
   f32x4 g1 = mma16(G, w.rd16(GR, t), wfT);   // g_h2 + g_t Wf
+  STW_T();
   // LN0, presence gate, output projection
   if (lay.ln) layer_norm_bwd(g1, Wl[lay.ln0() + r], st.xh0, st.rstd0, lg.v[5], lg.v[6]);
   f32x4 go;
@@ -403,6 +494,7 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
   lg.w[3] = mma16(splat(0.f), rdT_own(w, XT1), rdT_own(w, XT2));
   lg.v[3] = csum(go);
   const f32x4 ga = mma16(splat(0.f), w.rd16(GR, t), woT);
+  STW_T();
   // attention: dP = GA V^T, softmax backward
   w.wr_rows(GR, ga);
   w.wr_cols(GT, ga);
@@ -422,14 +514,17 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
 #pragma unroll
     for (int u = 0; u < NT; ++u) ds[u][e] = st.p[u][e] * (ds[u][e] - dot) * inv_sqrt_d;
   }
+  STW_T();
   w.template wr_nn<NT>(DSR, ds);
   w.template wr_nn_t<NT>(DST, ds);
   w.template wr_nn_t<NT>(PT, st.p);
   lds_fence();
   if (NT > 1) __syncthreads();   // the other wave's dS^T, P^T, GA^T columns
+  STW_T();
   const f32x4 dq = mma_np<NT, BF>(splat(0.f), w, DSR, t, Kt, 0);   // sum_m dS[n][m] K[m][i]
   const f32x4 dk = mma_np<NT, BF>(splat(0.f), w, DST, t, Qt, 0);   // sum_n dS[n][m] Q[n][i]
   const f32x4 dv = mma_np<NT, BF>(splat(0.f), w, PT, t, GT, 0);    // sum_n P[n][m] GA[n][i]
+  STW_T();
   // projections: weight gradients and the gradient w.r.t. the block input
   w.wr_cols(XT2, st.hin);
   f32x4 gin = go;
@@ -445,50 +540,78 @@ __device__ __forceinline__ void sab_backward(const Wave &w, const Lay &lay, cons
     gin = mma16(gin, w.rd16(GR, t), wT[m]);
   }
   G = gin;
+  STW_T();
 }
 
-// own-rows parameter gradients -> the workgroup's row of the partial matrix (wave 0
-// writes; the other waves hand their values over through LDS)
+// own-rows parameter gradients -> the workgroup's row of the partial matrix.  One wave
+// stores its registers; several waves meet in LDS (a slot per wave) and the whole workgroup
+// sums and stores, a thread per value: coalesced, and nobody reads 29 LDS values in a row
+// (the hand-over to wave 0 was 1.2 us per block).
 template <int NT>
 __device__ __forceinline__ void flush_layer(const Wave &w, const Lay &lay, const Tiles<NT> &tl,
                                             const LayerGrads &lg, float *part, bool first) {
-  constexpr int PW = 5 * 256 + 10 * D;   // hand-over floats per wave: 5 matrices, 9 (+1) vectors
-  if (NT > 1) {
-    if (w.t > 0) {
-      float *scr = tl.scr + (w.t - 1) * PW;
-#pragma unroll
-      for (int m = 0; m < 5; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) scr[m * 256 + (4 * w.q + e) * D + w.r] = lg.w[m][e];
-      if (w.q == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) scr[5 * 256 + i * D + w.r] = lg.v[i];
-      }
-    }
-    lds_fence();
-    __syncthreads();
-    if (w.t > 0) return;
-  }
+  constexpr int PW = 5 * 256 + 10 * D;   // floats per wave: 5 matrices, 9 (+1) vectors
   auto put = [&](int idx, float v) { part[idx] = first ? v : part[idx] + v; };
-  auto others = [&](int off) {
-    float v = 0.f;
+  if (NT == 1) {
 #pragma unroll
-    for (int t = 1; t < NT; ++t) v += tl.scr[(t - 1) * PW + off];
-    return v;
-  };
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) put(lay.w(m) + (4 * w.q + e) * D + w.r, lg.w[m][e]);
+    if (w.q == 0) {
+      const int voff[9] = {lay.b(0), lay.b(1), lay.b(2), lay.b(3), lay.b(4), lay.ln0(),
+                           lay.ln0() + D, lay.ln1(), lay.ln1() + D};
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+        if (i < 5 || lay.ln) put(voff[i] + w.r, lg.v[i]);
+    }
+    return;
+  }
+  float *mine = tl.scr + w.t * PW;
 #pragma unroll
   for (int m = 0; m < 5; ++m)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ij = (4 * w.q + e) * D + w.r;
-      put(lay.w(m) + ij, lg.w[m][e] + others(m * 256 + ij));
-    }
+    for (int e = 0; e < 4; ++e) mine[m * 256 + (4 * w.q + e) * D + w.r] = lg.w[m][e];
   if (w.q == 0) {
-    const int voff[9] = {lay.b(0), lay.b(1), lay.b(2), lay.b(3), lay.b(4), lay.ln0(),
-                         lay.ln0() + D, lay.ln1(), lay.ln1() + D};
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
-      if (i < 5 || lay.ln) put(voff[i] + w.r, lg.v[i] + others(5 * 256 + i * D + w.r));
+    for (int i = 0; i < 9; ++i) mine[5 * 256 + i * D + w.r] = lg.v[i];
+  }
+  lds_fence();
+  __syncthreads();
+  static_assert(D == 16, "vector index split");
+  // 356 items of four values: 320 of the five [16][16] matrices, 36 of the nine vectors; every
+  // offset of the packed layout is a multiple of four floats (16 bytes with the row's base)
+  constexpr int NTH = 64 * NT, NI = 5 * 64 + 9 * 4, ITS = (NI + NTH - 1) / NTH;
+  float4 v[ITS];
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int k = 4 * min((int)threadIdx.x + NTH * it, NI - 1);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 1; t < NT; ++t) {
+      const float4 x = ld4(tl.scr + t * PW + k);
+      o.x += x.x, o.y += x.y, o.z += x.z, o.w += x.w;
+    }
+    const float4 x = ld4(tl.scr + k);   // (wave 0's + the others' in order: the sum the
+    v[it] = make_float4(x.x + o.x, x.y + o.y, x.z + o.z, x.w + o.w);   // hand-over made)
+  }
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int item = (int)threadIdx.x + NTH * it, k = 4 * item;
+    const int m = k >> 8, iv = (k - 5 * 256) >> 4;
+    const int wm = m * 272 + (m == 4 && lay.ln ? 32 : 0);   // lay.w(m)
+    const int vo = iv < 5 ? iv * 272 + (iv == 4 && lay.ln ? 32 : 0) + 256   // lay.b(iv)
+                          : iv == 5 ? lay.ln0()
+                                    : iv == 6 ? lay.ln0() + D : iv == 7 ? lay.ln1() : lay.ln1() + D;
+    const bool mat = k < 5 * 256;
+    if (item < NI && (mat || iv < 5 || lay.ln)) {
+      float4 *dst = reinterpret_cast<float4 *>(part + (mat ? wm + (k & 255) : vo + (k & 15)));
+      float4 r = v[it];
+      if (!first) {
+        const float4 p = *dst;
+        r.x += p.x, r.y += p.y, r.z += p.z, r.w += p.w;
+      }
+      *dst = r;
+    }
   }
 }
 
@@ -496,23 +619,24 @@ template <int NT, bool BF>
 __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Lay lay{a.Din, a.L, a.layer_norm};
-  const int N = a.N, XS = xs_of(a.Din), Din = a.Din;
+  const int N = a.N, Din = a.Din;
   Wave w;
   w.lane = threadIdx.x & 63, w.r = w.lane & 15, w.q = w.lane >> 4;
   w.t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   w.ts = Geo<NT>::TSN;
-  // W1s | small slots | hand-over area | arena (large tiles during the blocks, X after them)
-  float *W1s = smem, *sm = W1s + 16 * XS, *scr = sm + S_BWD_SMALL * Geo<NT>::SMALL,
-        *arena = scr + Geo<NT>::SCR, *X = arena;
+  // small slots | hand-over area | large tiles
+  float *sm = smem, *scr = sm + S_BWD_SMALL * Geo<NT>::SMALL, *arena = scr + Geo<NT>::SCR;
   const Tiles<NT> tiles{sm, arena, scr};
   const int lds_total = (int)lds_floats<NT>(Din, true);
-  for (int i = threadIdx.x; i < lds_total; i += 64 * NT) smem[i] = 0.f;
+#ifdef SCAE_STW_PROF
+  if (blockIdx.x == 5 && threadIdx.x == 0) g_stw_n = 0;
+#endif
+  STW_T();
+  lds_zero(smem, lds_total, threadIdx.x, 64 * NT);
   lds_fence();
   if (NT > 1) __syncthreads();
-  dma_rows(a.params, Din, w.t, D, Din, W1s, XS, w.lane, NT);
-  dma_wait();
-  if (NT > 1) __syncthreads();
   float *part = a.pg_partial + (size_t)blockIdx.x * lay.total();
+  STW_T();
   bool first = true;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     f32x4 pres, G;
@@ -542,23 +666,75 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
       LayerGrads lg;
       sab_backward<NT, BF>(w, lay, Wl, tiles, G, pres, N, a.sqrt_d, st, lg);
       flush_layer<NT>(w, lay, tiles, lg, part + lay.layer(l), first);
+  STW_T();
     }
-    // fc1: db1, dW1 = G^T x (column tiles split between the waves, K over all rows),
-    // input gradients of the segments that want one.  The arena's N x N tiles are dead
-    // (every wave is past the last block's hand-over barrier): the input rows move in.
-    if (NT > 1) __syncthreads();
-    for (int i = threadIdx.x; i < 16 * NT * XS; i += 64 * NT) X[i] = 0.f;
-    lds_fence();
-    stage_input(a, b, w, X, XS);
+    // fc1: db1, dW1 = G^T x (column tiles split between the waves, K over all rows), input
+    // gradients g W1 of the segments that want one.  Both B operands -- a column of the
+    // set's input rows, a column of W1 -- come straight from global memory, 16 consecutive
+    // columns per row group: every load of the first chunks is in flight before the first
+    // product.  (Staging the input rows in LDS cost the wave one LDS-DMA instruction per
+    // (row, segment), 60-100 cycles of issue each: 10 us^-1 of this kernel at cfg-2.)
     float *GT = tiles.small(S_GT), *GR = tiles.small(S_GR);
+    constexpr int XT = NT <= 2 ? 5 : (NT == 3 ? 3 : 2);   // dW1 tiles per chunk (4 NT floats each)
+    constexpr int WT = 10;                                  // input-gradient tiles per chunk
+    const int ntile = (Din + 15) / 16;
+    // column c of the concatenated input: its segment, as the lane sees it
+    struct Col {
+      const float *x;   // element (b, row 0, c)
+      float *g;         // gradient of element (b, row 0, c), or null
+      int rs, wd;       // row strides of the two
+    };
+    auto column = [&](int c) {
+      Col k{nullptr, nullptr, 0, 0};
+      int c0 = 0;
+#pragma unroll
+      for (int sgi = 0; sgi < MAXSEG; ++sgi) {
+        if (sgi < a.nseg) {
+          const Seg &sg = a.seg[sgi];
+          if (c >= c0) {
+            k.x = sg.ptr + (size_t)b * sg.bs + (c - c0);
+            k.g = sg.grad ? sg.grad + (size_t)b * N * sg.width + (c - c0) : nullptr;
+            k.rs = sg.rs, k.wd = sg.width;
+          }
+          c0 += sg.width;
+        }
+      }
+      return k;
+    };
+    float xv[XT][4 * NT];
+    auto load_x = [&](int jt0) {   // tiles jt0 + NT i of this wave
+#pragma unroll
+      for (int i = 0; i < XT; ++i) {
+        const int jt = jt0 + NT * i;
+        if (jt < ntile) {
+          const Col k = column(min(16 * jt + w.r, Din - 1));
+#pragma unroll
+          for (int j = 0; j < 4 * NT; ++j)   // (rows >= N meet zero rows of G: any finite value)
+            xv[i][j] = k.x[(size_t)min(4 * NT * w.q + j, N - 1) * k.rs];
+        }
+      }
+    };
+    float4 wv[WT];
+    auto load_w = [&](int jt0) {
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        const int jt = jt0 + i;
+        if (jt < ntile) {
+          const float *wp = a.params + (size_t)(4 * w.q) * Din + min(16 * jt + w.r, Din - 1);
+          wv[i] = make_float4(wp[0], wp[Din], wp[2 * Din], wp[3 * Din]);
+        }
+      }
+    };
+    load_x(w.t);
+    load_w(0);
     w.wr_cols(GT, G);
     w.wr_rows(GR, G);
     const float db1 = csum(G);
     constexpr int PW = 5 * 256 + 10 * D;
     if (NT > 1 && w.t > 0 && w.q == 0) scr[(w.t - 1) * PW + 5 * 256 + 9 * D + w.r] = db1;
-    dma_wait();
     lds_fence();
     if (NT > 1) __syncthreads();
+  STW_T();
     if (w.t == 0 && w.q == 0) {
       float v = db1;
 #pragma unroll
@@ -567,49 +743,56 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
     }
     {
       const FK<NT> ga = w.template rdk<NT>(GT, 0);   // A[row i][k = n]: row i of G^T
-      for (int jt = w.t; jt * 16 < Din; jt += NT) {
-        FK<NT> xb;   // B[k = n][col]: column 16 jt + r of X
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float *xp = X + (4 * NT * w.q + 4 * j) * XS + 16 * jt + w.r;
-          xb.v[j] = make_float4(xp[0], xp[XS], xp[2 * XS], xp[3 * XS]);
-        }
-        const f32x4 acc = mmak<NT>(splat(0.f), ga, xb);
-        if (16 * jt + w.r < Din) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int idx = (4 * w.q + e) * Din + 16 * jt + w.r;
-            part[idx] = first ? acc[e] : part[idx] + acc[e];
-          }
-        }
-      }
-    }
-    {
-      const float4 ga = w.rd16(GR, w.t);
-      int col = 0;
 #pragma unroll 1
-      for (int s = 0; s < a.nseg; ++s) {
-        const int wd = a.seg[s].width;
-        float *gdst = a.seg[s].grad;
-        if (gdst) {
-          for (int j0 = 0; j0 < wd; j0 += 16) {
-            const float *wp = W1s + (4 * w.q) * XS + col + j0 + w.r;
-            const f32x4 o = mma16(splat(0.f), ga,
-                                  make_float4(wp[0], wp[XS], wp[2 * XS], wp[3 * XS]));
-            if (j0 + w.r < wd) {
+      for (int jt0 = w.t; jt0 < ntile; jt0 += NT * XT) {
+        if (jt0 != w.t) load_x(jt0);
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+          const int jt = jt0 + NT * i;
+          if (jt < ntile) {
+            FK<NT> xb;   // B[k = n][col]: column 16 jt + r of the input
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              xb.v[j] = make_float4(xv[i][4 * j], xv[i][4 * j + 1], xv[i][4 * j + 2],
+                                    xv[i][4 * j + 3]);
+            const f32x4 acc = mmak<NT>(splat(0.f), ga, xb);
+            if (16 * jt + w.r < Din) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const int n = 16 * w.t + 4 * w.q + e;
-                if (n < N) gdst[((size_t)b * N + n) * wd + j0 + w.r] = o[e];
+                const int idx = (4 * w.q + e) * Din + 16 * jt + w.r;
+                part[idx] = first ? acc[e] : part[idx] + acc[e];
               }
             }
           }
         }
-        col += wd;
+      }
+    }
+  STW_T();
+    {
+      const float4 ga = w.rd16(GR, w.t);
+#pragma unroll 1
+      for (int jt0 = 0; jt0 < ntile; jt0 += WT) {
+        if (jt0) load_w(jt0);
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+          const int jt = jt0 + i, c = 16 * jt + w.r;
+          if (jt < ntile) {
+            const f32x4 o = mma16(splat(0.f), ga, wv[i]);
+            const Col k = column(min(c, Din - 1));
+            if (c < Din && k.g) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int n = 16 * w.t + 4 * w.q + e;
+                if (n < N) k.g[(size_t)n * k.wd] = o[e];
+              }
+            }
+          }
+        }
       }
     }
     first = false;
-    if (NT > 1) __syncthreads();   // the arena turns back into tiles
+  STW_T();
+    if (NT > 1) __syncthreads();   // GT / GR / the hand-over area are reused
   }
 }
 
@@ -628,15 +811,15 @@ __device__ __forceinline__ void stw_fwd_body(const StArgs &a, float *smem, int b
   float *X = smem, *W1s = X + 16 * NT * XS, *sm = W1s + 16 * XS;
   const Tiles<NT> tiles{sm, sm + S_FWD_SMALL * Geo<NT>::SMALL, nullptr};
   // zero padding of X / W1s (rows >= N, columns >= Din), then W1, once per workgroup
-  for (int i = threadIdx.x; i < (16 * NT + 16) * XS; i += 64 * NT) X[i] = 0.f;
+  lds_zero(X, (16 * NT + 16) * XS, threadIdx.x, 64 * NT);
   lds_fence();
   if (NT > 1) __syncthreads();
+  NarrowRows nr;
+  if (blk_id < a.B) stage_input_issue(a, blk_id, w, X, XS, nr);   // (in flight with W1)
   dma_rows(a.params, a.Din, w.t, D, a.Din, W1s, XS, w.lane, NT);
-  dma_wait();
-  if (NT > 1) __syncthreads();
   int blk = 0;   // running SAB counter: parity picks the K / V buffers
   for (int b = blk_id; b < a.B; b += nblk) {
-    stage_input(a, b, w, X, XS);
+    if (b != blk_id) stage_input_issue(a, b, w, X, XS, nr);
     f32x4 pres;
     float kmask[NT];
 #pragma unroll
@@ -650,7 +833,10 @@ __device__ __forceinline__ void stw_fwd_body(const StArgs &a, float *smem, int b
       kmask[u] = a.presence && m < N ? (1.f - a.presence[(size_t)b * N + m]) * 1e32f : 0.f;
     }
     const float bias1 = a.params[lay.b1() + w.r];
+    stage_input_commit(X, nr);
     dma_wait();
+    lds_fence();
+    if (NT > 1 && b == blk_id) __syncthreads();   // W1s: rows of every wave
     f32x4 h = fc1_forward(w, X, W1s, XS, bias1);
     float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
     const bool quad_ok = 16 * w.t + 4 * w.q + 3 < N;   // the lane's four rows all valid
@@ -683,7 +869,21 @@ __global__ __launch_bounds__(64 * NT) void stw_fwd_kernel(StArgs a) {
 }
 }  // namespace
 
+#pragma clang fp contract(fast)   // (the toolchain's default, for what an includer adds)
+
 #ifndef SCAE_DEVICE_ONLY   // (trunk_logprob.hip includes this file for its device code)
+#ifdef SCAE_STW_PROF
+}  // namespace scae_st
+extern "C" int scae_debug_stw_prof(unsigned long long *out, int n) {
+  int cnt = 0;
+  (void)hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(scae_st::g_stw_n), sizeof(int)) != hipSuccess) return -1;
+  if (cnt > n) cnt = n;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scae_st::g_stw_prof), cnt * 8) != hipSuccess) return -1;
+  return cnt;
+}
+namespace scae_st {
+#endif
 static int tiles_of(int N) { return (N + 15) / 16; }
 static size_t lds_need(int N, int Din, bool bwd) {
   switch (tiles_of(N)) {

@@ -18,6 +18,9 @@
 
 namespace {
 template <int NT, int C>
+#ifdef SCAE_TL_WAVES
+__attribute__((amdgpu_waves_per_eu(SCAE_TL_WAVES, SCAE_TL_WAVES)))
+#endif
 __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
     scae_st::StArgs a, int n_trunk, scae_decoder_desc d, const float *__restrict__ x,
     float *__restrict__ lse_post, float *__restrict__ lse_prior, int ppb, int tiles,
@@ -25,6 +28,11 @@ __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < n_trunk) {   // (workgroup-uniform)
     if (threadIdx.x >= 64 * NT) return;   // whole waves
+#ifndef SCAE_TL_NOPRIO
+    // a chain of dependent latencies sharing its SIMD with the likelihood's VALU waves: it
+    // goes first whenever it can issue
+    __builtin_amdgcn_s_setprio(3);
+#endif
     scae_st::stw_fwd_body<NT, false>(a, smem, blockIdx.x, n_trunk);
     return;
   }
