@@ -189,9 +189,16 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
             scale = float(ref.abs().max())
             got = grads[k].detach().cpu()
             if scale < (1e-10 if fp64_judge else 1e-30):
-                # exactly zero, or dust (the HIP side flushes denormals)
-                assert float(got.abs().max()) <= max(1e-6, entry_bar * entry_abs), \
-                    (what, it, k)
+                # exactly zero, or dust (the HIP side flushes denormals).  In the
+                # trained state (fp64_judge) the background's mixing-logit gradient is
+                # sum_pixels g (w_post - w_prior) with both responsibilities exactly 1
+                # in torch's log_softmax; K1's backward recomputes w_post from the
+                # forward's saved log-sum-exp, one rounding (6e-8 of ~5) away from it:
+                # 2e5 terms of g = 1 / B with a 5e-7 relative wobble sum to ~1e-5
+                # where the alive state has O(1) -- 1e-9 of the terms' magnitudes.
+                assert float(got.abs().max()) <= \
+                    max(2e-5 if fp64_judge else 1e-6, entry_bar * entry_abs), \
+                    (what, it, k, float(got.abs().max()))
                 continue
             err = max(0.0, float((got - ref).abs().max()) - slack.get(k, 0.0))
             off.append((err / (scale + entry_abs), k, scale))

@@ -40,7 +40,7 @@ for l in (2, 1, 0):
     names += [f"L{l} fwd: " + x for x in ("weights+h->LDS", "qkv+barrier", "S", "softmax", "PV", "oproj+LN0", "ff+LN1")]
     names += [f"L{l} bwd: " + x for x in ("LN1+ff", "LN0+oproj", "dP+softmax", "dS writes+barrier", "dq dk dv", "projections")]
     names += [f"L{l} flush"]
-names += ["fc1: operand loads issued, G -> LDS, barrier", "fc1: dW1", "fc1: input grads"]
+names += ["fc1: operand loads issued, G -> LDS, barrier", "fc1: products", "fc1: stores"]
 print(n, "stamps; total ticks", t[-1] - t[0])
 for i in range(1, n):
     print("%6d  %s" % (t[i] - t[i - 1], names[i] if i < len(names) else "?"))

@@ -701,28 +701,40 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
       }
       return k;
     };
+    // column tiles that hold a column of a segment that wants its gradient (uniform; tiles
+    // from 64 on count as wanted)
+    unsigned long long want = 0;
+    {
+      int c0 = 0;
+#pragma unroll
+      for (int sgi = 0; sgi < MAXSEG; ++sgi) {
+        if (sgi < a.nseg) {
+          const int lo = c0 >> 4, hi = (c0 + a.seg[sgi].width - 1) >> 4;
+          if (a.seg[sgi].grad && a.seg[sgi].width > 0 && lo < 64)
+            want |= (hi >= 63 ? ~0ull : (2ull << hi) - 1) & ~((1ull << lo) - 1);
+          c0 += a.seg[sgi].width;
+        }
+      }
+    }
     float xv[XT][4 * NT];
+    // (no branches around the loads -- tiles past the end re-read the last one -- or the
+    // compiler moves each load down to the branch that uses it)
     auto load_x = [&](int jt0) {   // tiles jt0 + NT i of this wave
 #pragma unroll
       for (int i = 0; i < XT; ++i) {
-        const int jt = jt0 + NT * i;
-        if (jt < ntile) {
-          const Col k = column(min(16 * jt + w.r, Din - 1));
+        const Col k = column(min(16 * min(jt0 + NT * i, ntile - 1) + w.r, Din - 1));
 #pragma unroll
-          for (int j = 0; j < 4 * NT; ++j)   // (rows >= N meet zero rows of G: any finite value)
-            xv[i][j] = k.x[(size_t)min(4 * NT * w.q + j, N - 1) * k.rs];
-        }
+        for (int j = 0; j < 4 * NT; ++j)   // (rows >= N meet zero rows of G: any finite value)
+          xv[i][j] = k.x[(size_t)min(4 * NT * w.q + j, N - 1) * k.rs];
       }
     };
     float4 wv[WT];
     auto load_w = [&](int jt0) {
 #pragma unroll
       for (int i = 0; i < WT; ++i) {
-        const int jt = jt0 + i;
-        if (jt < ntile) {
-          const float *wp = a.params + (size_t)(4 * w.q) * Din + min(16 * jt + w.r, Din - 1);
-          wv[i] = make_float4(wp[0], wp[Din], wp[2 * Din], wp[3 * Din]);
-        }
+        const float *wp = a.params + (size_t)(4 * w.q) * Din +
+                          min(16 * min(jt0 + i, ntile - 1) + w.r, Din - 1);
+        wv[i] = make_float4(wp[0], wp[Din], wp[2 * Din], wp[3 * Din]);
       }
     };
     load_x(w.t);
@@ -741,54 +753,60 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
       for (int t = 1; t < NT; ++t) v += scr[(t - 1) * PW + 5 * 256 + 9 * D + w.r];
       part[lay.b1() + w.r] = first ? v : part[lay.b1() + w.r] + v;
     }
+    // Every product of a chunk first, unconditionally (tiles past the end repeat the last
+    // one), then the stores: a load whose only use sits in a guarded block is moved down
+    // into that block by the compiler, and each tile then waits for its own latency.
     {
       const FK<NT> ga = w.template rdk<NT>(GT, 0);   // A[row i][k = n]: row i of G^T
+      const float4 gr = w.rd16(GR, w.t);
+      int jx = w.t, jw = 0;
 #pragma unroll 1
-      for (int jt0 = w.t; jt0 < ntile; jt0 += NT * XT) {
-        if (jt0 != w.t) load_x(jt0);
+      do {
+        f32x4 gx[WT], dw[XT];
+#pragma unroll
+        for (int i = 0; i < WT; ++i) gx[i] = mma16(splat(0.f), gr, wv[i]);
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
-          const int jt = jt0 + NT * i;
-          if (jt < ntile) {
-            FK<NT> xb;   // B[k = n][col]: column 16 jt + r of the input
+          FK<NT> xb;   // B[k = n][col]: column 16 jt + r of the input
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-              xb.v[j] = make_float4(xv[i][4 * j], xv[i][4 * j + 1], xv[i][4 * j + 2],
-                                    xv[i][4 * j + 3]);
-            const f32x4 acc = mmak<NT>(splat(0.f), ga, xb);
-            if (16 * jt + w.r < Din) {
+          for (int j = 0; j < NT; ++j)
+            xb.v[j] = make_float4(xv[i][4 * j], xv[i][4 * j + 1], xv[i][4 * j + 2],
+                                  xv[i][4 * j + 3]);
+          dw[i] = mmak<NT>(splat(0.f), ga, xb);
+        }
+  STW_T();
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int idx = (4 * w.q + e) * Din + 16 * jt + w.r;
-                part[idx] = first ? acc[e] : part[idx] + acc[e];
-              }
+        for (int i = 0; i < XT; ++i) {
+          const int jt = jx + NT * i;
+          if (jt < ntile && 16 * jt + w.r < Din) {
+            float *dst = part + (4 * w.q) * Din + 16 * jt + w.r;
+            if (!first) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dw[i][e] += dst[e * Din];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e * Din] = dw[i][e];
           }
         }
-      }
-    }
-  STW_T();
-    {
-      const float4 ga = w.rd16(GR, w.t);
-#pragma unroll 1
-      for (int jt0 = 0; jt0 < ntile; jt0 += WT) {
-        if (jt0) load_w(jt0);
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-          const int jt = jt0 + i, c = 16 * jt + w.r;
-          if (jt < ntile) {
-            const f32x4 o = mma16(splat(0.f), ga, wv[i]);
+          const int jt = jw + i, c = 16 * jt + w.r;
+          if (jt < ntile && (jt >= 64 || (want >> jt & 1))) {
             const Col k = column(min(c, Din - 1));
             if (c < Din && k.g) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const int n = 16 * w.t + 4 * w.q + e;
-                if (n < N) k.g[(size_t)n * k.wd] = o[e];
+                if (n < N) k.g[(size_t)n * k.wd] = gx[i][e];
               }
             }
           }
         }
-      }
+        // (more than one chunk: wide inputs only)
+        jx += NT * XT, jw += WT;
+        if (jx < ntile) load_x(jx);
+        if (jw < ntile) load_w(jw);
+      } while (jx < ntile || jw < ntile);
     }
     first = false;
   STW_T();
