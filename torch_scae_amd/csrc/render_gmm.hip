@@ -1170,6 +1170,14 @@ LpTiling lp_tiling(const scae_decoder_desc *d) {
     const int want = (512 + d->B - 1) / d->B;
     if (tiles < want) tiles = want;
     if (tiles > waves) tiles = waves;
+    // A CU deals a workgroup's waves to its four SIMDs starting at the first one, so it holds
+    // floor(waves per SIMD / ceil(workgroup waves / 4)) workgroups (tools/probes/
+    // lds_residency.cpp, tools/tl_prof.py): at the 4 waves per SIMD of the launch shared with
+    // the object encoder's trunk, 7-wave workgroups are 2 per CU -- 512 places for 128 + 512
+    // workgroups, a quarter of the likelihood ran in a second round -- and 4-wave workgroups
+    // are 4 per CU.  Small batches take 4-wave workgroups.
+    const int tiles4 = (waves + 3) / 4;
+    if ((long)d->B * tiles4 <= 1024 && tiles4 > tiles) tiles = tiles4;
     const int wpt = (waves + tiles - 1) / tiles;
     t.wave = true;
     t.ksplit = 1;

@@ -37,7 +37,11 @@ __global__ __launch_bounds__(1024) void logprob_wave_kernel(
 template <int C>
 int launch_c(const scae_decoder_desc *d, const LpTiling &t, const float *x, float *log_prob,
              float *lse_post, float *lse_prior, float *block_sums, hipStream_t st) {
+#ifdef SCAE_LP_LDS_PAD   // (occupancy experiments)
+  const size_t lds = logprob_wave_lds(d) + SCAE_LP_LDS_PAD;
+#else
   const size_t lds = logprob_wave_lds(d);
+#endif
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(logprob_wave_kernel<C>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -207,7 +211,7 @@ int launch_bwd_c(const scae_decoder_desc *d, const CellGeom &g, const float *x,
 size_t logprob_wave_lds(const scae_decoder_desc *d) {
   if (!d->templates_alpha || d->C < 1 || d->C > 4) return 0;   // alpha-channel mode only
   const int TX = d->C == 1 ? 2 : (d->C <= 3 ? 4 : 8);
-  const size_t bytes = sizeof(float) * ((size_t)d->M * pad_elems(d->th, d->tw) * TX +
+  const size_t bytes = sizeof(float) * ((size_t)d->M * plane_elems(d->th, d->tw, kLogprobPadLow) * TX +
                                         (size_t)(d->M + KC) * 8 + 16);
   return bytes <= 160 * 1024 ? bytes : 0;
 }

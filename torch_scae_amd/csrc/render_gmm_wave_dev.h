@@ -11,6 +11,7 @@ constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f
 constexpr int KC = 8;          // components per register chunk
 constexpr float kMasked = -3.0e38f;
 
+constexpr int kLogprobPadLow = 1;   // the likelihood forward's planes (stage_planes)
 template <int C> struct TexelOf { static constexpr int TX = C == 1 ? 2 : (C <= 3 ? 4 : 8); };
 
 __device__ __forceinline__ float ex2(float v) { return __builtin_amdgcn_exp2f(v); }
@@ -19,22 +20,31 @@ __device__ __forceinline__ float lg2(float v) { return __builtin_amdgcn_logf(v);
 // Components [k0, k0 + nk) of image b as padded planes of interleaved TX-float texels
 // {channel 0 .. C - 1, alpha * alpha_scale, 0 ..}: one padded texel ROW per thread (one
 // division per row); the caller synchronises.
-template <int C>
+// PL: zero texels to the left of / above the template (2 to the right / below).  2 lets a
+// coordinate be clamped at -2, where the bilinear value AND its derivative are zero (the
+// kernels that differentiate); 1 is enough for the value alone (clamp at -1: both taps of
+// anything further out are the zero column) and takes the 24 planes of cfg-2 from 43 to
+// 37.6 KB -- under the 40 KB that let four workgroups share a CU's LDS.
+__host__ __device__ inline int plane_w(int tw, int PL) { return tw + PL + 2; }
+__host__ __device__ inline int plane_elems(int th, int tw, int PL) {
+  return (th + PL + 2) * (tw + PL + 2);
+}
+template <int C, int PL = 2>
 __device__ __forceinline__ void stage_planes(float *s_pl, const scae_decoder_desc &d, int b, int k0,
                                              int nk, float alpha_scale, int tid, int nthr) {
   constexpr int TX = TexelOf<C>::TX;
   const int M = d.M, th = d.th, tw = d.tw, tsz = th * tw;
-  const int psz = pad_elems(th, tw), pw = pad_w(tw), prow = th + 4;
+  const int psz = plane_elems(th, tw, PL), pw = plane_w(tw, PL), prow = th + PL + 2;
   const float *g_tmpl = d.templates + (size_t)tb(d, b) * M * C * tsz;
   const float inv_prow = 1.f / (float)prow;
   for (int r = tid; r < nk * prow; r += nthr) {
-    const int kl = (int)(((float)r + 0.5f) * inv_prow), yp = r - kl * prow, y = yp - 2, k = k0 + kl;
+    const int kl = (int)(((float)r + 0.5f) * inv_prow), yp = r - kl * prow, y = yp - PL, k = k0 + kl;
     float *dst = s_pl + ((size_t)kl * psz + yp * pw) * TX;
     const bool in = y >= 0 && y < th;
     const float *ts = g_tmpl + (size_t)k * C * tsz + y * tw;
     const float *as = d.templates_alpha + (size_t)k * tsz + y * tw;
     for (int xp = 0; xp < pw; ++xp) {
-      const int xx = xp - 2;
+      const int xx = xp - PL;
       float v[TX];
 #pragma unroll
       for (int c = 0; c < TX; ++c) v[c] = 0.f;
@@ -65,7 +75,8 @@ __device__ __forceinline__ void logprob_wave_body(
   constexpr int TX = TexelOf<C>::TX;
   const int tid = threadIdx.x;
   const int M = d.M, W = d.W, HW = d.H * d.W, th = d.th, tw = d.tw;
-  const int psz = pad_elems(th, tw), pw = pad_w(tw);
+  constexpr int PL = kLogprobPadLow;
+  const int psz = plane_elems(th, tw, PL), pw = plane_w(tw, PL);
   const Scalars sc = load_scalars(d);
   float *s_pl = smem;                              // M padded planes of TX-float texels
   float *s_coef = s_pl + (size_t)M * psz * TX;     // (M + KC) x 8: texel-space map, presence
@@ -73,7 +84,7 @@ __device__ __forceinline__ void logprob_wave_body(
 
   // ---- stage: one padded texel row per thread ---------------------------------------
   {
-    stage_planes<C>(s_pl, d, b, 0, M, kLog2e, tid, nthr);
+    stage_planes<C, PL>(s_pl, d, b, 0, M, kLog2e, tid, nthr);
     // texel position of normalised (xn, yn):  ix = ((a0 xn + a1 yn + a2 + 1) tw - 1) / 2
     for (int k = tid; k < M + KC; k += nthr) {
       float co[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, kMasked, 0.f};   // k >= M: masked out
@@ -113,7 +124,7 @@ __device__ __forceinline__ void logprob_wave_body(
     spost[c] = 1.f;
   }
 
-  const float *s_tap = s_pl + (size_t)(2 * pw + 2) * TX;   // tap (0, 0) of plane 0
+  const float *s_tap = s_pl + (size_t)(PL * pw + PL) * TX;   // tap (0, 0) of plane 0
   for (int k0 = 0; k0 < M; k0 += KC) {
     float uv[KC], pv[KC][C];
 #pragma unroll
@@ -123,8 +134,8 @@ __device__ __forceinline__ void logprob_wave_body(
       const float4 cb = *reinterpret_cast<const float4 *>(s_coef + k * 8 + 4);
       float ix = fmaf(ca.x, xn, fmaf(ca.y, yn, ca.z));
       float iy = fmaf(ca.w, xn, fmaf(cb.x, yn, cb.y));
-      ix = fminf(fmaxf(ix, -2.f), txf);   // fmaxf(NaN, -2) = -2: everything outside
-      iy = fminf(fmaxf(iy, -2.f), tyf);
+      ix = fminf(fmaxf(ix, -(float)PL), txf);   // fmaxf(NaN, -PL) = -PL: everything outside
+      iy = fminf(fmaxf(iy, -(float)PL), tyf);
       const float x0f = floorf(ix), y0f = floorf(iy);
       const float fx = ix - x0f, fy = iy - y0f;
       const int idx = (int)fmaf(y0f, pwf, x0f);

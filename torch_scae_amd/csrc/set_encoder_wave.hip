@@ -310,6 +310,12 @@ __device__ __forceinline__ void sab_forward(const Wave &w, const Lay &lay, const
 // memory).
 __host__ __device__ inline int xs_of(int Din) { return (Din + 15) / 16 * 16 + 4; }
 template <int NT>
+__host__ __device__ inline size_t lds_floats_fwd_aliased(int Din) {
+  const size_t xw = (size_t)(16 * NT + 16) * xs_of(Din),
+               tl = (size_t)S_FWD_SMALL * Geo<NT>::SMALL + (size_t)L_FWD_LARGE * Geo<NT>::LARGE;
+  return xw > tl ? xw : tl;
+}
+template <int NT>
 __host__ __device__ inline size_t lds_floats(int Din, bool bwd) {
   const size_t xs = xs_of(Din);
   if (!bwd)
@@ -817,7 +823,11 @@ __global__ __launch_bounds__(64 * NT) void stw_bwd_kernel(StArgs a) {
 // The forward pass as a device function of workgroup `blk` of `nblk` (threads 0 .. 64 NT - 1 of
 // the workgroup; `smem`: its dynamic LDS) -- so that it can also run as a block range of a
 // launch it shares with an independent kernel (trunk_logprob.hip).
-template <int NT, bool BF>
+// ALIAS: the tiles of the blocks lie over X | W1s (dead after fc1) -- (16 NT + 16) XS floats
+// instead of that plus the tiles, 28 KB instead of 51 at cfg-2 -- for the launch this body
+// shares with the likelihood, where every workgroup is given the larger body's LDS; costs a
+// re-staging of W1 and three more barriers per set.
+template <int NT, bool BF, bool ALIAS = false>
 __device__ __forceinline__ void stw_fwd_body(const StArgs &a, float *smem, int blk_id, int nblk) {
   const Lay lay{a.Din, a.L, a.layer_norm};
   const int N = a.N, XS = xs_of(a.Din);
@@ -825,10 +835,11 @@ __device__ __forceinline__ void stw_fwd_body(const StArgs &a, float *smem, int b
   w.lane = threadIdx.x & 63, w.r = w.lane & 15, w.q = w.lane >> 4;
   w.t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   w.ts = Geo<NT>::TSN;
-  // X | W1s | small slots | large slots
-  float *X = smem, *W1s = X + 16 * NT * XS, *sm = W1s + 16 * XS;
+  // X | W1s | small slots | large slots  (ALIAS: the slots start at X)
+  float *X = smem, *W1s = X + 16 * NT * XS, *sm = ALIAS ? smem : W1s + 16 * XS;
   const Tiles<NT> tiles{sm, sm + S_FWD_SMALL * Geo<NT>::SMALL, nullptr};
-  // zero padding of X / W1s (rows >= N, columns >= Din), then W1, once per workgroup
+  // zero padding of X / W1s (rows >= N, columns >= Din), then W1: once per workgroup, or
+  // (ALIAS) per set, after the previous set's tiles
   lds_zero(X, (16 * NT + 16) * XS, threadIdx.x, 64 * NT);
   lds_fence();
   if (NT > 1) __syncthreads();
@@ -837,7 +848,16 @@ __device__ __forceinline__ void stw_fwd_body(const StArgs &a, float *smem, int b
   dma_rows(a.params, a.Din, w.t, D, a.Din, W1s, XS, w.lane, NT);
   int blk = 0;   // running SAB counter: parity picks the K / V buffers
   for (int b = blk_id; b < a.B; b += nblk) {
-    if (b != blk_id) stage_input_issue(a, b, w, X, XS, nr);
+    if (b != blk_id) {
+      if (ALIAS) {
+        if (NT > 1) __syncthreads();   // every wave is past its last tile read
+        lds_zero(X, (16 * NT + 16) * XS, threadIdx.x, 64 * NT);
+        lds_fence();
+        if (NT > 1) __syncthreads();
+        dma_rows(a.params, a.Din, w.t, D, a.Din, W1s, XS, w.lane, NT);
+      }
+      stage_input_issue(a, b, w, X, XS, nr);
+    }
     f32x4 pres;
     float kmask[NT];
 #pragma unroll
@@ -854,8 +874,12 @@ __device__ __forceinline__ void stw_fwd_body(const StArgs &a, float *smem, int b
     stage_input_commit(X, nr);
     dma_wait();
     lds_fence();
-    if (NT > 1 && b == blk_id) __syncthreads();   // W1s: rows of every wave
+    if (NT > 1 && (ALIAS || b == blk_id)) __syncthreads();   // W1s: rows of every wave
     f32x4 h = fc1_forward(w, X, W1s, XS, bias1);
+    if (ALIAS) {   // the tiles take over: every wave has read W1s
+      lds_fence();
+      if (NT > 1) __syncthreads();
+    }
     float *hs = a.hsave + (size_t)b * (a.L + 1) * N * D;
     const bool quad_ok = 16 * w.t + 4 * w.q + 3 < N;   // the lane's four rows all valid
     auto save = [&](float *dst) {
@@ -949,6 +973,6 @@ int wave_launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
 #else
 // the LDS floats a forward workgroup needs (for the shared launch)
 template <int NT>
-static size_t stw_fwd_lds_floats(int Din) { return lds_floats<NT>(Din, false); }
+static size_t stw_fwd_lds_floats(int Din) { return lds_floats_fwd_aliased<NT>(Din); }
 #endif
 }  // namespace scae_st

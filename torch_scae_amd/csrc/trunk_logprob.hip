@@ -16,6 +16,21 @@
 #undef SCAE_DEVICE_ONLY
 #include "render_gmm_wave_dev.h"
 
+#ifdef SCAE_TL_PROF   // start / end stamp (s_memrealtime, 100 MHz) of every workgroup
+__device__ unsigned long long g_tl_prof[2048][2];
+extern "C" int scae_debug_tl_prof(unsigned long long *out, int n) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_prof), (size_t)n * 16);
+}
+#define TL_STAMP(i)                                                                       \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < 2048)                                            \
+      g_tl_prof[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();                        \
+  } while (0)
+#else
+#define TL_STAMP(i)
+#endif
+
 namespace {
 template <int NT, int C>
 #ifdef SCAE_TL_WAVES
@@ -26,6 +41,7 @@ __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
     float *__restrict__ lse_post, float *__restrict__ lse_prior, int ppb, int tiles,
     float *__restrict__ tile_sums) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  TL_STAMP(0);
   if ((int)blockIdx.x < n_trunk) {   // (workgroup-uniform)
     if (threadIdx.x >= 64 * NT) return;   // whole waves
 #ifndef SCAE_TL_NOPRIO
@@ -33,12 +49,14 @@ __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
     // goes first whenever it can issue
     __builtin_amdgcn_s_setprio(3);
 #endif
-    scae_st::stw_fwd_body<NT, false>(a, smem, blockIdx.x, n_trunk);
+    scae_st::stw_fwd_body<NT, false, true>(a, smem, blockIdx.x, n_trunk);
+    TL_STAMP(1);
     return;
   }
   const int id = (int)blockIdx.x - n_trunk, b = id / tiles, tile = id - b * tiles;
   scae_k1::logprob_wave_body<C>(d, x, nullptr, lse_post, lse_prior, ppb, tile_sums, smem, tile, b,
                                 tiles, blockDim.x);
+  TL_STAMP(1);
 }
 
 template <int NT, int C>
