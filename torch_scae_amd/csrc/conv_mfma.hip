@@ -692,6 +692,18 @@ __global__ __launch_bounds__(pipe::NT) void conv_bwd_pair_pipe_kernel(
   }
 }
 
+#ifdef SCAE_CONV_PROF   // start / end stamp (s_memrealtime, 100 MHz) of every workgroup of the
+// mixed backward pairs, a slot per DMODE (tools/conv_prof.py)
+__device__ unsigned long long g_conv_prof[3][4096][2];
+#define CV_STAMP(mode, i)                                                       \
+  do {                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < 4096)                                  \
+      g_conv_prof[mode][blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();      \
+  } while (0)
+#else
+#define CV_STAMP(mode, i)
+#endif
+
 // first-generation data-gradient tiles (many small workgroups per CU suit the short K
 // loops of the tap classes) beside second-generation weight-gradient tiles
 template <int DMODE, class TW>
@@ -702,12 +714,14 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_kernel(
   constexpr int SM = Tile<DMODE>::SMEM > TW::SMEM ? Tile<DMODE>::SMEM : TW::SMEM;
   __shared__ __attribute__((aligned(1024))) float smem[SM];
   const int bid = blockIdx.x;
+  CV_STAMP(DMODE, 0);
   if (bid < pg.nd) {   // workgroup-uniform
     dgrad_tile<DMODE>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
   } else {
     const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
     wgrad_pipe_tile<TW>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
   }
+  CV_STAMP(DMODE, 1);
 }
 
 // The same launch with a rider as the HEAD of its grid: a kernel of the object encoder's
@@ -736,11 +750,13 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_rider_kernel(
   constexpr int SM = Tile<DMODE>::SMEM > TW::SMEM ? Tile<DMODE>::SMEM : TW::SMEM;
   static_assert(SM * sizeof(float) >= 24 * 1024, "the riders' LDS");
   __shared__ __attribute__((aligned(1024))) float smem[SM];
+  CV_STAMP(DMODE, 0);
   if ((int)blockIdx.x < r.n) {   // workgroup-uniform
     if (r.kind == 1)
       scae_saw::saw_reduce_body<NT>(r.red, smem, blockIdx.x);
     else   // C = 256 threads, one part
       scae_sf::fold_bwd_body<4, 4>(r.a, r.g, r.pl, smem, blockIdx.x, threadIdx.x, 0, 1);
+    CV_STAMP(DMODE, 1);
     return;
   }
   const int bid = (int)blockIdx.x - r.n;
@@ -750,7 +766,22 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_rider_kernel(
     const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
     wgrad_pipe_tile<TW>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
   }
+  CV_STAMP(DMODE, 1);
+#ifdef SCAE_CONV_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 1) {   // (grid layout for the reader)
+    g_conv_prof[DMODE][4095][0] = ((unsigned long long)r.n << 32) | (unsigned)pg.nd;
+    g_conv_prof[DMODE][4095][1] = gridDim.x;
+  }
+#endif
 }
+#ifdef SCAE_CONV_PROF
+}  // namespace
+extern "C" int scae_debug_conv_prof(unsigned long long *out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_prof), sizeof(g_conv_prof));
+}
+namespace {
+#endif
 
 // ---- small helpers ---------------------------------------------------------------
 // W[co][ci][3][3] -> Wf[co][tap][ci], Wd[ci][tap][co]

@@ -194,7 +194,7 @@ __device__ __forceinline__ void probabilities(const SwArgs &a, const Lane &l, co
     mx = rmax(mx);
 #pragma unroll
     for (int u = 0; u < NT; ++u) v[u] = __expf(v[u] - mx), sum += v[u];
-    const float inv = 1.f / rsum(sum);
+    const float inv = __builtin_amdgcn_rcpf(rsum(sum));   // (sum >= 1: the row maximum's term)
 #pragma unroll
     for (int u = 0; u < NT; ++u) p[u][e] = v[u] * inv;
   }
@@ -206,7 +206,9 @@ __global__ __launch_bounds__(NTH) void saw_fwd_kernel(SwArgs a) {
   const Tl<NT> tl{smem};
   const Lane l = make_lane();
   const int C = a.C, O = a.O;
-  for (int i = threadIdx.x; i < Geo<NT>::LDS_FLOATS; i += NTH) smem[i] = 0.f;
+  static_assert(Geo<NT>::LDS_FLOATS % 4 == 0, "16-byte zero fill");
+  for (int i = 4 * threadIdx.x; i < Geo<NT>::LDS_FLOATS; i += 4 * NTH)
+    *reinterpret_cast<float4 *>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   fold_qk<NT>(a, l, tl, false);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -252,7 +254,9 @@ __device__ __forceinline__ void saw_bwd_body(const SwArgs &a, float *smem, int b
   const int npar = O * D + C * D + C;
   float *part = a.partial + (size_t)blk * npar;
   float *scr = tl.scr();
-  for (int i = threadIdx.x; i < Geo<NT>::LDS_FLOATS; i += NTH) smem[i] = 0.f;
+  static_assert(Geo<NT>::LDS_FLOATS % 4 == 0, "16-byte zero fill");
+  for (int i = 4 * threadIdx.x; i < Geo<NT>::LDS_FLOATS; i += 4 * NTH)
+    *reinterpret_cast<float4 *>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   fold_qk<NT>(a, l, tl, true);
   bool first = true;
