@@ -1175,9 +1175,11 @@ LpTiling lp_tiling(const scae_decoder_desc *d) {
     // lds_residency.cpp, tools/tl_prof.py): at the 4 waves per SIMD of the launch shared with
     // the object encoder's trunk, 7-wave workgroups are 2 per CU -- 512 places for 128 + 512
     // workgroups, a quarter of the likelihood ran in a second round -- and 4-wave workgroups
-    // are 4 per CU.  Small batches take 4-wave workgroups.
+    // are 4 per CU.  Small batches take 4-wave workgroups ...
+    // ... when four of them also fit the CU's LDS (the planes of all M components per workgroup)
     const int tiles4 = (waves + 3) / 4;
-    if ((long)d->B * tiles4 <= 1024 && tiles4 > tiles) tiles = tiles4;
+    if ((long)d->B * tiles4 <= 1024 && tiles4 > tiles && logprob_wave_lds(d) <= 40 * 1024)
+      tiles = tiles4;
     const int wpt = (waves + tiles - 1) / tiles;
     t.wave = true;
     t.ksplit = 1;
