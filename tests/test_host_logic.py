@@ -309,3 +309,28 @@ def test_grad_slot_has_one_taker_per_step():
     assert not ops._in_slot(w) and w.data_ptr() != v.data_ptr()
     flat.clear_grads()
     assert not slot.taken and ops._in_slot(ops._grad_out(slot, lin.weight))
+
+
+def test_likelihood_tiling_follows_the_workgroups_a_cu_holds():
+    """scae_render_gmm_logprob_tiles (host logic, no launch): the wave form's
+    tile count.  cfg-2 takes 4-wave workgroups (7 tiles of 256 pixels: four
+    of them fit a CU's wave slots AND its LDS, so the launch shared with the
+    object encoder's trunk runs in one round -- DESIGN.md section 5, round 4);
+    shapes whose template planes do not fit four times (hydra 40 capsules,
+    CIFAR's three channels) and large batches keep the >= 512-workgroup rule."""
+    import ctypes
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(16)      # (never dereferenced by the host logic)
+
+    def tiles(B, M, C, t, H):
+        d = _lib.DecoderDesc(templates=dummy, templates_alpha=dummy, pose=dummy,
+                             presence=dummy, bg_image=None, bg_value=dummy,
+                             bg_mixing_logit=dummy, temperature_logit=None,
+                             out_scale=None, B=B, M=M, C=C, th=t, tw=t, H=H, W=H,
+                             template_repeat=1)
+        return lib.scae_render_gmm_logprob_tiles(ctypes.byref(d))
+    assert tiles(128, 24, 1, 11, 40) == 7       # cfg-2: 25 waves in 4-wave tiles
+    assert tiles(128, 40, 1, 11, 40) == 4       # hydra: 62 KB of planes per workgroup
+    assert tiles(256, 32, 3, 14, 32) == 2       # cfg-5
+    assert tiles(1024, 48, 1, 11, 40) == 2      # cfg-3: the batch fills the device
