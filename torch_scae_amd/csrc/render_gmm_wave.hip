@@ -37,11 +37,7 @@ __global__ __launch_bounds__(1024) void logprob_wave_kernel(
 template <int C>
 int launch_c(const scae_decoder_desc *d, const LpTiling &t, const float *x, float *log_prob,
              float *lse_post, float *lse_prior, float *block_sums, hipStream_t st) {
-#ifdef SCAE_LP_LDS_PAD   // (occupancy experiments)
-  const size_t lds = logprob_wave_lds(d) + SCAE_LP_LDS_PAD;
-#else
   const size_t lds = logprob_wave_lds(d);
-#endif
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(logprob_wave_kernel<C>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

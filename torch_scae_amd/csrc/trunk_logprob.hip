@@ -4,12 +4,18 @@
 // render_gmm_wave_dev.h: VALU work that fills the chip).  Both only need the part
 // encoder's outputs, kernels do not overlap on this stack (forked graphs serialise,
 // DESIGN.md section 5), so the likelihood's workgroups ride in the trunk's launch as a
-// second block range: 15.8 + 15.3 us become ~17.
+// second block range: 14.3 + 13.2 us alone, 19.5 together.
 //   blocks [0, n_trunk)            : trunk workgroup (threads 0 .. 64 NT - 1; the other waves
 //                                    of the workgroup exit at once)
 //   blocks [n_trunk, + tiles * B)  : likelihood workgroup (tile, image)
-// Register allocation is the maximum of the two bodies (the trunk's, 82-104 VGPRs: the
-// likelihood keeps 5 waves per SIMD); dynamic LDS the maximum of the two.
+// Register allocation is the maximum of the two bodies (the trunk's 128 VGPRs: 4 waves per
+// SIMD), dynamic LDS the maximum of the two (the trunk's tiles lie over its dead input rows
+// here, stw_fwd_body<.., ALIAS>: 28 KB; the likelihood's planes 38 KB at cfg-2).  What
+// decides the launch's time is whether ALL its workgroups are resident at once: a CU deals a
+// workgroup's waves to its SIMDs from the first one on, so at 4 waves per SIMD it holds two
+// 5- or 7-wave workgroups but four 4-wave ones (tools/probes/lds_residency.cpp); the
+// likelihood's tiling (render_gmm.hip, lp_tiling) takes 4-wave workgroups where four also
+// fit the LDS -- with 7-wave ones a quarter of them ran in a second round (tools/tl_prof.py).
 #include "common.h"
 #define SCAE_DEVICE_ONLY
 #include "set_encoder_wave.hip"
@@ -33,9 +39,6 @@ extern "C" int scae_debug_tl_prof(unsigned long long *out, int n) {
 
 namespace {
 template <int NT, int C>
-#ifdef SCAE_TL_WAVES
-__attribute__((amdgpu_waves_per_eu(SCAE_TL_WAVES, SCAE_TL_WAVES)))
-#endif
 __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
     scae_st::StArgs a, int n_trunk, scae_decoder_desc d, const float *__restrict__ x,
     float *__restrict__ lse_post, float *__restrict__ lse_prior, int ppb, int tiles,
@@ -44,11 +47,6 @@ __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
   TL_STAMP(0);
   if ((int)blockIdx.x < n_trunk) {   // (workgroup-uniform)
     if (threadIdx.x >= 64 * NT) return;   // whole waves
-#ifndef SCAE_TL_NOPRIO
-    // a chain of dependent latencies sharing its SIMD with the likelihood's VALU waves: it
-    // goes first whenever it can issue
-    __builtin_amdgcn_s_setprio(3);
-#endif
     scae_st::stw_fwd_body<NT, false, true>(a, smem, blockIdx.x, n_trunk);
     TL_STAMP(1);
     return;
