@@ -1,5 +1,5 @@
 // How many workgroups of a kernel with L bytes of dynamic LDS does an MI355X CU hold at once?
-//   hipcc --offload-arch=gfx950 -O2 tools/probes/lds_residency.cpp -o /tmp/lds_residency && /tmp/lds_residency
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/lds_residency.cpp -o tools/probes/lds_residency   (git-ignored; travels with gpurun)
 // 2048 workgroups (8 per CU) of `waves` waves spin for ~20 us and stamp their start; those that
 // start within the first 5 us are the first round: residency = that count / 256 CUs.
 #include <hip/hip_runtime.h>
