@@ -195,9 +195,11 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
                 # in torch's log_softmax; K1's backward recomputes w_post from the
                 # forward's saved log-sum-exp, one rounding (6e-8 of ~5) away from it:
                 # 2e5 terms of g = 1 / B with a 5e-7 relative wobble sum to ~1e-5
-                # where the alive state has O(1) -- 1e-9 of the terms' magnitudes.
+                # (9e-6 measured; 2e-6 if the wobbles were independent, 8e-4 if they
+                # all had one sign) where the alive state has O(1) -- 1e-9 of the
+                # terms' magnitudes.  The bar leaves the trajectory room to move.
                 assert float(got.abs().max()) <= \
-                    max(2e-5 if fp64_judge else 1e-6, entry_bar * entry_abs), \
+                    max(5e-5 if fp64_judge else 1e-6, entry_bar * entry_abs), \
                     (what, it, k, float(got.abs().max()))
                 continue
             err = max(0.0, float((got - ref).abs().max()) - slack.get(k, 0.0))
