@@ -77,7 +77,7 @@ def parse():
                          "not the headline fp32 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--force-spawn", action="store_true",
                     help="take the rank-launcher + RCCL process-group path even "
                          "for --gpus 1 (a 1-rank nccl group; proves the N>1 "
@@ -469,6 +469,21 @@ def cpu_baseline(cfg, steps):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     cores = torch.get_num_threads()
+    # the same step followed by the reference's optimiser (stock
+    # torch.optim.RMSprop with the reference's hyper-parameters,
+    # base_experiment.py:44-77): what the GPU headline's "+ RMSprop step" is
+    # like-for-like with
+    opt = torch.optim.RMSprop(list(P.values()), lr=3e-5, momentum=0.9,
+                              eps=1e-2 / float(B) ** 2)
+    step()
+    opt.step()
+    with_opt = []
+    for _ in range(max(3, steps // 3)):
+        t0 = time.perf_counter()
+        step()
+        opt.step()
+        with_opt.append(time.perf_counter() - t0)
+    med_opt = float(np.median(with_opt))
     # the same step on ONE thread (SURVEY.md 8d asks for both), 3 steps
     torch.set_num_threads(1)
     step()
@@ -482,8 +497,16 @@ def cpu_baseline(cfg, steps):
     return {"value": round(B / med, 1), "unit": "images/sec",
             "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{steps} steps of the same workload (B={B}) after 3 "
-                      f"warm-up, median; fwd+loss+bwd, no optimiser",
+                      f"warm-up, median; forward + loss + backward WITHOUT the "
+                      f"optimiser (compare with step_without_optimizer; the "
+                      f"GPU headline includes its RMSprop launch)",
             "ms_per_step": round(med * 1e3, 2),
+            "spread_ms": [round(min(times) * 1e3, 2), round(max(times) * 1e3, 2)],
+            "with_optimizer": {
+                "value": round(B / med_opt, 1), "unit": "images/sec",
+                "ms_per_step": round(med_opt * 1e3, 2),
+                "sample": f"{len(with_opt)} steps + torch.optim.RMSprop.step, "
+                          f"median (like-for-like with the GPU headline)"},
             "one_thread": {"value": round(B / med1, 1), "unit": "images/sec",
                            "ms_per_step": round(med1 * 1e3, 2),
                            "sample": "3 steps after 1 warm-up, median"}}
@@ -509,22 +532,31 @@ def synthetic_batches(cfg, device, seed, n_batches=8):
 
 
 def timed_blocks(step, images, labels, steps, warmup, blocks, barrier,
-                 reduce_max=None):
-    """`warmup` untimed steps, then `blocks` back-to-back timed regions of
-    EXACTLY `steps` steps each, every one bracketed by barrier() (a
-    dist.barrier when there are ranks + torch.cuda.synchronize) on both sides;
-    per block the MAX over ranks.  -> list of block seconds."""
+                 reduce_max=None, before_block=None, after_block=None):
+    """`blocks` back-to-back timed regions of EXACTLY `steps` steps each,
+    every one bracketed by barrier() (a dist.barrier when there are ranks +
+    torch.cuda.synchronize) on both sides; per block the MAX over ranks.
+    `warmup` untimed steps run once in front -- or, with ``before_block``
+    (which puts the training state back where the measurement wants it, outside
+    the timed region), in front of EVERY block, so that a timed step is never
+    more than warmup + steps optimiser steps away from that state.
+    -> list of block seconds."""
     n = images.shape[0]
-    for i in range(warmup):
-        step(images[i % n], labels[i % n])
     out = []
-    for _ in range(blocks):
+    for b in range(blocks):
+        if before_block is not None:
+            before_block(b)
+        if before_block is not None or b == 0:
+            for i in range(warmup):
+                step(images[i % n], labels[i % n])
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
             step(images[i % n], labels[i % n])
         barrier()
         out.append(time.perf_counter() - t0)
+        if after_block is not None:
+            after_block(b)
     if reduce_max is not None:
         out = reduce_max(out)
     return out
@@ -558,6 +590,12 @@ def capsule_state(model, image):
             "presence_below_1e-16": round(float((pres < 1e-16).float().mean()), 4),
             "pose_scale_median": round(float(lin.median()), 4),
             "pose_scale_min": round(float(lin.min()), 4)}
+
+
+def brief_state(st):
+    return {"presence_median": float("%.3g" % st["presence_median"]),
+            "presence_below_1e-16": st["presence_below_1e-16"],
+            "pose_scale_median": st["pose_scale_median"]}
 
 
 def structured_leg(device, n_steps=600):
@@ -653,26 +691,53 @@ def extra_workloads(device, budget_s=25.0):
 
 
 def probe_modes(make, which, images, labels, barrier, reduce_max, steps=40,
-                warmup=10, blocks=3):
+                warmup=10, blocks=3, agree=None):
     """ms per step of the collective modes `which` of TrainStep on the ranks at
     hand, each on a FRESH model (the step time depends on how far training has
     got, see capsule_state): the contract's timing procedure (barrier +
     synchronize around exactly `steps` steps, MAX over ranks), median of
     `blocks`.  Every rank gets the same numbers, hence the same choice.
     "off": the collective-free build of the same step (its ranks drift apart,
-    so it runs last)."""
-    out = {}
+    so it runs last).
+
+    A mode may fail on ONE rank only (memory, a graph capture with the
+    collective inside): ``agree(ok) -> bool`` (an all-reduce over a gloo group,
+    which does not depend on the state of the RCCL communicator) makes every
+    rank see the failure BEFORE the mode's first collective-bearing timed
+    region, so nobody is left waiting in a barrier; a mode whose build failed
+    anywhere is recorded with its error and skipped everywhere.  A failure
+    inside the timed region itself cannot be agreed on (the other ranks are
+    already inside RCCL); it is recorded, and the remaining probes are skipped
+    -- the communicator may be unusable after a half-captured collective."""
+    out, broken = {}, False
     for mode in which:
-        step = None
+        if broken:
+            out[mode] = {"ms_per_step": None,
+                         "error": "skipped: an earlier mode failed inside its "
+                                  "timed region"}
+            continue
+        step, err = None, None
         try:
             step = make(mode)
+            step.prepare(images[0], labels[0])     # build + capture, no step
+            torch.cuda.synchronize()
+        except Exception as e:      # a mode this stack cannot build
+            err = repr(e)[:200]
+        ok = agree(err is None) if agree is not None else err is None
+        if not ok:
+            out[mode] = {"ms_per_step": None,
+                         "error": err or "failed to build on another rank"}
+            del step
+            torch.cuda.empty_cache()
+            continue
+        try:
             t = timed_blocks(step, images, labels, steps, warmup, blocks,
                              barrier, reduce_max)
             out[mode] = {"ms_per_step": round(float(np.median(t)) / steps * 1e3, 4),
                          "runs_as": step.collective_mode}
-        except Exception as e:      # a mode this stack cannot run is not chosen
+        except Exception as e:
             out[mode] = {"ms_per_step": None, "error": repr(e)[:200]}
-            torch.cuda.synchronize()
+            broken = True
         del step
         torch.cuda.empty_cache()
     return out
@@ -793,22 +858,87 @@ def main():
     mode, modes = None, None
     if collective:
         from torch_scae_amd.train_step import TrainStep
+        # host-side agreement between the ranks goes over gloo: it must work
+        # whatever state a failed probe has left the RCCL communicator in
+        ctl = dist.new_group(backend="gloo")
+
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+            return bool(flag.item())
+
         mode = "1 bucket" if args.no_overlap else args.comm_mode
         which = TrainStep.MODES if mode == "auto" else (mode,)
         modes = probe_modes(make, which + ("off",), images, labels, barrier,
-                            reduce_max)
-        if mode == "auto":
-            mode = min(which, key=lambda m: modes[m]["ms_per_step"] or 1e9)
+                            reduce_max, agree=agree)
+        # per-rank diagnostics on stderr (rank 0's stdout carries the one JSON
+        # line): what every rank measured, also when a mode raised
+        print(f"[bench rank {rank}/{world}] rccl_ranks={rccl_ranks} "
+              f"comm.modes={json.dumps(modes)}", file=sys.stderr, flush=True)
+        usable = [m for m in which if modes[m]["ms_per_step"]]
+        if not usable:
+            raise SystemExit(f"rank {rank}: no collective mode ran: {modes}")
+        if mode == "auto" or mode not in usable:
+            mode = min(usable, key=lambda m: modes[m]["ms_per_step"])
     step = make(mode)
+
+    # The state the headline is quoted on (parameters at the
+    # build's init, noise on): the step is captured first (the capture's
+    # warm-ups touch neither parameters nor optimiser state), its training
+    # state snapshotted, and put back -- outside the timed region -- before
+    # every timed block.  U[0,1) images carry nothing to model and the part
+    # capsules switch off within a few hundred RMSprop steps; a block that
+    # started wherever the previous one ended would time the data-dependent K1
+    # backward at its zero-gradient exit (round 4's headline did).
+    step.prepare(images[0], labels[0])
+    snap = step.snapshot()
+    state0 = capsule_state(step.model, images[0])
+    per_block = []
+
+    def before_block(b):
+        step.restore(snap)
+
+    def after_block(b):
+        per_block.append(brief_state(capsule_state(step.model, images[0])))
 
     # the timed region of the contract -- W warm-ups, then EXACTLY K steps
     # between barrier + synchronize, MAX over ranks -- repeated `blocks` times
-    # back to back; the reported step time is the MEDIAN block
+    # back to back, each from the restored state; the reported step time is
+    # the MEDIAN block
     blocks = timed_blocks(step, images, labels, args.steps, args.warmup,
-                          max(1, args.blocks), barrier, reduce_max)
+                          max(1, args.blocks), barrier, reduce_max,
+                          before_block=before_block, after_block=after_block)
     timing = timing_summary(blocks, args.steps)
+    timing["state"] = (
+        f"parameters + optimiser state restored to the build's init before "
+        f"every block: every timed step is within {args.warmup} + "
+        f"{args.steps} RMSprop steps of init")
+    timing["per_block"] = [
+        dict(ms=round(1e3 * t / args.steps, 4), capsules_after=st)
+        for t, st in zip(blocks, per_block)]
     final_loss = float(step.loss)
     final_state = capsule_state(step.model, images[0])
+    # "optimizer step reported separately" (the reference's step
+    # is base_experiment.py:109-126 + its optimiser): the same step captured
+    # without the RMSprop launch, same procedure (its state never moves)
+    no_opt = None
+    if not args.no_optimizer:
+        st2 = make_step(cfg, device, alternatives=args.alternatives,
+                        use_graph=not args.no_graph, optimizer=False,
+                        autocast_dtype=torch.bfloat16 if args.bf16 else None,
+                        force_collective=args.force_spawn, lazy_render=lazy,
+                        collective_mode=mode)
+        t2 = timing_summary(timed_blocks(
+            st2, images, labels, args.steps, args.warmup,
+            max(1, min(7, args.blocks)), barrier, reduce_max), args.steps)
+        no_opt = {"ms_per_step": t2["median_ms"],
+                  "images_per_sec": round(B * world / t2["median_ms"] * 1e3, 1),
+                  "timing": t2,
+                  "step": "forward + SCAE.loss + backward"
+                          + (" + RCCL all-reduce" if collective else "")
+                          + ", no optimiser launch (parameters stay at init)"}
+        del st2
+        torch.cuda.empty_cache()
     comm = None
     if collective:
         comm = comm_diagnostics(step, images, labels, max(10, args.steps),
@@ -820,6 +950,11 @@ def main():
         if modes[mode]["ms_per_step"] and modes["off"]["ms_per_step"]:
             comm["exposed_us"] = round((modes[mode]["ms_per_step"]
                                         - modes["off"]["ms_per_step"]) * 1e3, 1)
+        print(f"[bench rank {rank}/{world}] chosen={mode!r} "
+              f"allreduce_us={comm['allreduce_us']} "
+              f"exposed_us={comm.get('exposed_us')} "
+              f"step_ms={comm['step_ms']} per_rank_ms={comm['per_rank_ms']}",
+              file=sys.stderr, flush=True)
 
     result = None
     if rank == 0:
@@ -852,16 +987,24 @@ def main():
                 "reconstruct_alternatives": bool(args.alternatives),
                 "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                 "final_loss": round(final_loss, 3),
-                # (the timed steps also train: what the data-dependent kernels
-                # ran on by the end -- see extra_workloads' structured leg)
+                # the state of the part capsules the data-dependent kernels
+                # (K1's backward) ran on: at the restored init / after the
+                # last timed block
+                "capsules_before": state0,
                 "capsules_after": final_state,
-                "data_note": "U[0,1) noise images carry nothing to model: the "
-                             "part capsules switch off within ~600 steps "
-                             "(capsules_after) and K1's backward then skips "
-                             "them (exact zeros); extra_workloads' structured "
-                             "leg times the same step with live capsules",
+                "data_note": "U[0,1) noise images, parameters put back to the "
+                             "build's init before every timed block "
+                             "(timing.state): every part capsule is live in "
+                             "every timed step.  Left to train on noise the "
+                             "capsules switch off within a few hundred steps "
+                             "and K1's backward skips them (exact zeros): "
+                             "extra_workloads' last leg times that collapsed "
+                             "state (same_steps_on_uniform_noise) next to the "
+                             "step on structured images",
             },
         }
+        if no_opt is not None:
+            result["step_without_optimizer"] = no_opt
         if comm is not None:
             result["comm"] = comm
         if not args.no_roofline:

@@ -380,6 +380,8 @@ typedef struct scae_mlp_chain_desc {
   const float *in;
   int64_t in_gs, in_bs;
   int in_dim, B, G;
+  int row_tile; /* batch rows per workgroup: 0 = chosen by the launcher from the shape
+                   (the production setting); 16 | 32 force one (tests, measurements) */
 } scae_mlp_chain_desc;
 int scae_mlp_chain_max_width(void);
 int scae_mlp_chain_fwd_f32(const scae_mlp_chain_desc *desc, void *stream);

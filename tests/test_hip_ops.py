@@ -2236,7 +2236,7 @@ def test_mlp_chain_vs_fp64(B, G, Kin, dims, ones_at, row_tile, monkeypatch):
     batch rows per workgroup -- 32 is what large batches take (the activation
     buffers then are as wide as what each holds), forced here at every size."""
     from torch_scae_amd import ops
-    monkeypatch.setenv("SCAE_CHAIN_RB", str(row_tile))
+    monkeypatch.setattr(ops, "_CHAIN_ROW_TILE", row_tile)
     g = torch.Generator().manual_seed(B + G + Kin)
     layers, K = [], Kin
     for l, N in enumerate(dims):
@@ -2318,7 +2318,7 @@ def test_chain_votes_matches_chain_then_votes(B, O, V, noise, sim, row_tile,
     test_mlp_chain_vs_fp64: with 32 rows the vote blocks run twice per
     workgroup, their scratch in the weight tiles."""
     from torch_scae_amd import ops
-    monkeypatch.setenv("SCAE_CHAIN_RB", str(row_tile))
+    monkeypatch.setattr(ops, "_CHAIN_ROW_TILE", row_tile)
     g = torch.Generator().manual_seed(B * O + V)
     Kin, H, Dc, A = 64, 48, 12, 8 * V + 7
     dims = [(H, Kin, True, False), (Dc, H, True, False), (H, Dc + 1, False, True),
@@ -2709,3 +2709,24 @@ def test_deferred_sums_with_a_parameter_used_twice():
         names = {id(p): n for n, p in tg.named_parameters()}
         for p, v in zip(flat.params, flat.grad_views()):
             assert torch.equal(v, ref[names[id(p)]].grad), (twice, names[id(p)])
+
+
+def test_grouped_mlp_equals_per_capsule_loop():
+    """Stacked-weight batched evaluation on K7 == the reference's loop of
+    per-capsule MLPs (object_decoder.py:137-158; the loop evaluated with stock
+    torch modules on the CPU from the same state_dict), with bias and with the
+    ``caps_exist`` ones column."""
+    from torch_scae_amd.nn_ext import MLP, GroupedMLP
+    torch.manual_seed(0)
+    G, B = 5, 7
+    for bias, ones in ((True, False), (False, True)):
+        d_in = 6 + (1 if ones else 0)
+        gm = GroupedMLP(G, [d_in, 9, 4], bias=bias, ones_input=ones)
+        loop = torch.nn.ModuleList([MLP([d_in, 9, 4], bias=bias)
+                                    for _ in range(G)])
+        loop.load_state_dict(gm.state_dict())
+        x = torch.randn(B, G, 6)
+        xin = torch.cat([x, torch.ones(B, G, 1)], -1) if ones else x
+        want = torch.stack([loop[g](xin[:, g]) for g in range(G)], 1)
+        got = gm.cuda()(x.cuda()).cpu()
+        assert torch.allclose(got, want, atol=1e-6), (bias, ones)

@@ -167,21 +167,15 @@ def test_attr_dict_behaviour():
     assert d.get("c") == 3 and d.get("zz") is None
 
 
-def test_grouped_mlp_equals_per_capsule_loop():
-    """Stacked-weight batched evaluation == the reference's loop of MLPs."""
-    from torch_scae_amd.nn_ext import MLP, GroupedMLP
-    torch.manual_seed(0)
-    G, B = 5, 7
-    for bias, ones in ((True, False), (False, True)):
-        d_in = 6 + (1 if ones else 0)
-        gm = GroupedMLP(G, [d_in, 9, 4], bias=bias, ones_input=ones)
-        loop = torch.nn.ModuleList([MLP([d_in, 9, 4], bias=bias)
-                                    for _ in range(G)])
-        loop.load_state_dict(gm.state_dict())
-        x = torch.randn(B, G, 6)
-        xin = torch.cat([x, torch.ones(B, G, 1)], -1) if ones else x
-        want = torch.stack([loop[g](xin[:, g]) for g in range(G)], 1)
-        assert torch.allclose(gm(x), want, atol=1e-6)
+def test_grouped_mlp_has_no_eager_form():
+    """No CPU fallback anywhere on the hot path: the stacked per-capsule MLPs
+    raise on a CPU tensor like every other op (their parity with the
+    reference's loop of MLPs is a GPU test, test_hip_ops.py)."""
+    from torch_scae_amd.nn_ext import GroupedMLP
+    from torch_scae_amd.ops import ScaeHipError
+    gm = GroupedMLP(3, [6, 9, 4])
+    with pytest.raises(ScaeHipError):
+        gm(torch.randn(2, 3, 6))
 
 
 def test_fixed_noise_replay_and_shape_check():

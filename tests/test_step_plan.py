@@ -394,3 +394,60 @@ def test_two_steps_interleaved_in_one_process_equal_the_steps_run_apart():
         assert float(loss) == l0
         assert torch.equal(step.flat.flat_grad, g0), \
             ("plain", differing(step, step.flat.flat_grad, g0)[:8])
+
+
+@pytest.mark.gpu
+def test_fusing_and_deferring_on_a_model_without_gradient_slots_vs_oracle():
+    """``ops.step_fusion`` + ``ops.deferred_param_sums``
+    on a PLAIN model (no ``FlatParameters``: no gradient slots).  The K1
+    backward used to be parked there although the column sums over its
+    partial matrices (``templates_alpha``, the background scalars) are not
+    deferrable without slots and launched at once -- on partials the parked
+    launch had not written.  Now K1 launches directly unless every one of
+    those sums waits too; every gradient against the oracle."""
+    from oracle import scae_oracle as O
+    from tests.gate_screen import screened_scae_batch
+    from torch_scae_amd import factory, nn_ext, nn_utils, ops
+    cfg = _medium_cfg(vote_type="enc", presence_type="enc")
+    sd, g = _filled_state(cfg)
+    B = 32
+    image, label, noise = screened_scae_batch(O, cfg, sd, B, g)
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = O.prepare_model_params(**cfg)
+    ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label, noise)
+
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    assert not any(hasattr(p, "_scae_grad_slot") for p in model.parameters())
+    x, y = image.cuda(), label.cuda()
+    calls, real = [], ops._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    ops._lib.call = spy
+    try:
+        with nn_utils.fixed_noise([n.clone() for n in noise]), \
+                ops.step_fusion(x):
+            res = model(x)
+            loss, _ = model.loss(res, x, y)
+            with ops.deferred_param_sums():
+                loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops._lib.call = real
+    # without slots nothing of K1's sums can wait, so K1 is not parked
+    assert "scae_render_gmm_sums_bwd_likelihood_f32" not in calls, calls
+    k1 = calls.index("scae_render_gmm_sums_bwd_f32")
+    sums = [i for i, c in enumerate(calls) if c == "scae_sum_rows_multi_f32"]
+    assert sums and min(sums) > k1, calls
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
+    got = nn_ext.named_reference_grads(model)
+    for k in ("part_decoder.templates_alpha", "part_decoder.bg_value",
+              "part_decoder.bg_mixing_logit"):
+        assert ref_grads[k] is not None and float(ref_grads[k].abs().max()) > 0
+    worst = _assert_grads(got, ref_grads, 1e-4, "no slots")
+    print("no slots: worst gradient entry", worst)

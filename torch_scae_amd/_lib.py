@@ -64,7 +64,7 @@ class MlpChainDesc(Structure):
     """struct scae_mlp_chain_desc"""
     _fields_ = [("layer", MlpChainLayer * 4), ("n_layers", c_int), ("in_", P),
                 ("in_gs", c_int64), ("in_bs", c_int64), ("in_dim", c_int),
-                ("B", c_int), ("G", c_int)]
+                ("B", c_int), ("G", c_int), ("row_tile", c_int)]
 
 
 class VotesDesc(Structure):

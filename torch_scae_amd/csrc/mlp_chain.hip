@@ -399,8 +399,8 @@ int launch(const scae_mlp_chain_desc *d, const scae_votes_desc *v, void *stream)
   // of the odd layers (the last layer's only when the vote kernel reads it from LDS),
   // buffer 1 the even layers' -- each as wide as what it holds; the vote blocks take their
   // scratch in the weight tiles.
-  const char *env = getenv("SCAE_CHAIN_RB");   // (16 | 32: force a row tile -- tests, measurements)
-  const int want = env ? atoi(env) : 0;
+  const int want = d->row_tile;   // (16 | 32: a forced row tile -- tests, measurements; 0: by shape)
+  if (want != 0 && want != 16 && want != 32) return SCAE_ERR_BAD_ARG;
   Chain c2 = c;
   int dim[2] = {c.in_dim, 16};
   for (int i = 0; i < c.n; ++i)

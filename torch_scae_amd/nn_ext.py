@@ -87,29 +87,13 @@ class GroupedMLP(nn.Module):
     def forward(self, x, grad_pregated=False, x_is_relu=False, pad_out=False):
         """``grad_pregated`` / ``x_is_relu``: private backward contracts of
         a fused chain (ops._GroupedMLP); HIP path only."""
-        if x.is_cuda:      # batched fp32-MFMA GEMMs with fused bias / ReLU (K7)
-            from . import ops
-            return ops.grouped_mlp(x, self.weights, self.biases,
-                                   ones_input=self.ones_input,
-                                   grad_pregated=grad_pregated,
-                                   x_is_relu=x_is_relu, pad_out=pad_out)
-        if grad_pregated or x_is_relu or pad_out:
-            raise ValueError("fused-chain gradient contracts need the HIP path")
-        h = x.transpose(0, 1)                                  # (G, B, in)
-        for j, w in enumerate(self.weights):
-            wt = w.transpose(1, 2)                             # (G, in, out)
-            if j == 0 and self.ones_input:
-                add = wt[:, -1:, :]                            # the 1.0 column
-                wt = wt[:, :-1, :]
-                if self.biases is not None:
-                    add = add + self.biases[j].unsqueeze(1)
-                h = torch.baddbmm(add, h, wt)
-            elif self.biases is not None:
-                h = torch.baddbmm(self.biases[j].unsqueeze(1), h, wt)
-            else:
-                h = torch.bmm(h, wt)
-            h = F.relu(h)
-        return h.transpose(0, 1)
+        # batched fp32-MFMA GEMMs with fused bias / ReLU (K7); like every hot
+        # op there is no eager form: a CPU tensor raises ops.ScaeHipError
+        from . import ops
+        return ops.grouped_mlp(x, self.weights, self.biases,
+                               ones_input=self.ones_input,
+                               grad_pregated=grad_pregated,
+                               x_is_relu=x_is_relu, pad_out=pad_out)
 
     # -- reference-compatible (per-capsule) checkpoint keys ------------------
     def _save_to_state_dict(self, destination, prefix, keep_vars):

@@ -158,10 +158,18 @@ class CapsuleLayer(nn.Module):
                                           nonlinear=True, as_matrix=True)
         else:
             cvr = parent_transform
-        if cvr.is_cuda and cvr.dtype == torch.float32 and cvr.shape[2] == 1:
-            vote = ops.mat3_mul(cvr, cpr)       # one launch, no repeat
+        # the 3 x 3 object -> part pose products (object_decoder.py:189-191) on
+        # the HIP kernel, no ``repeat``: one parent matrix per capsule, or --
+        # a parent_transform given per vote -- one per (capsule, vote)
+        if cvr.shape[2] == 1:
+            vote = ops.mat3_mul(cvr, cpr)
+        elif cvr.shape[2] == self.n_votes:
+            vote = ops.mat3_mul(cvr.reshape(-1, 1, 3, 3),
+                                cpr.reshape(-1, 1, 3, 3)).view(cpr.shape)
         else:
-            vote = torch.matmul(cvr.repeat(1, 1, self.n_votes, 1, 1), cpr)
+            raise ValueError(
+                f"parent transform has {cvr.shape[2]} matrices per capsule, "
+                f"expected 1 or n_votes = {self.n_votes}")
         if self.noise_type == 'uniform':
             logit_caps = logit_caps + (rand_like(logit_caps) - 0.5) \
                 * self.noise_scale

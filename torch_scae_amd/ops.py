@@ -2112,6 +2112,7 @@ def _chain_forward_desc(x, ones_flags, weights, biases):
     d = _lib.MlpChainDesc()
     d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
         L, x.data_ptr(), x.stride(1), x.stride(0), Kin, B, G
+    d.row_tile = _CHAIN_ROW_TILE
     acts, K = [], Kin
     for l, (w, b) in enumerate(zip(weights, biases)):
         N, ldw = w.shape[1], w.shape[2]
@@ -2136,6 +2137,11 @@ def _chain_forward_desc(x, ones_flags, weights, biases):
     return d, acts
 
 
+# batch rows per K7b workgroup handed to the launcher (scae_mlp_chain_desc.row_tile):
+# 0 = by shape; the chain tests set 16 / 32 to run both forms at every size
+_CHAIN_ROW_TILE = 0
+
+
 def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
                     need_gx, gpre=None, votes=None, park=False):
     """The backward of the chain: the data-gradient chain (one launch; with
@@ -2149,6 +2155,7 @@ def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
     d = _lib.MlpChainDesc()
     d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
         L, gpre.data_ptr(), gpre.stride(1), gpre.stride(0), gpre.shape[2], B, G
+    d.row_tile = _CHAIN_ROW_TILE
     gx = torch.empty(B, G, Kin, device=dev, dtype=dt) if need_gx else None
     gs = [None] * L          # gradient w.r.t. every pre-activation
     gs[L - 1] = gpre
@@ -2833,29 +2840,6 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
     g_presence = torch.empty_like(presence) if presence is not None else None
     g_bg_image = torch.empty_like(bg_image) if bg_image is not None else None
     g_scal = torch.empty(B, M + 1, 4, device=dev, dtype=dt)
-    if g_tile is not None and park:
-        # inside a training step: parked for the capsule likelihood's backward
-        # to carry (both only wait for the loss tail); the gradient buffers are
-        # handed to autograd now and filled by that launch -- their consumers
-        # (template generator, part encoder, the deferred column sums) all run
-        # after it
-        plan = _plan()
-        plan.flush_scope("deferring")
-        addr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
-        plan.park("k1_bwd", _PendingK1Backward(
-            d, ctx_tensors, (x, lse_post, lse_prior, g_tile),
-            (addr(g_templates), g_alpha_p, addr(g_pose), addr(g_presence),
-             addr(g_bg_image), g_scal), templates))
-    elif g_tile is not None:
-        _lib.call("scae_render_gmm_sums_bwd_f32", ctypes.byref(d), _p(x),
-                  _p(lse_post), _p(lse_prior), _p(g_tile), _p(g_templates),
-                  _p(g_alpha_p), _p(g_pose), _p(g_presence), _p(g_bg_image),
-                  _p(g_scal), _stream(templates))
-    else:
-        _lib.call("scae_render_gmm_bwd_f32", ctypes.byref(d), _p(x),
-                  _p(lse_post), _p(lse_prior), _p(g_lp), _p(g_tt), _p(g_ml),
-                  _p(g_templates), _p(g_alpha_p), _p(g_pose), _p(g_presence),
-                  _p(g_bg_image), _p(g_scal), _stream(templates))
     slots = slots or [None] * 9
     # batch sums of the alpha partials and of the four scalar parameters'
     # (B*(M+1), 4) partials: one launch
@@ -2874,6 +2858,37 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
                          outs=[_grad_out(slots[5 + i], t) for i, t in scal],
                          defer=all(slots[5 + i] is not None
                                    for i, _ in scal)))
+    # a parked launch fills the partial matrices LATER: only when every column
+    # sum over them waits too (deferred, i.e. all of its outputs are slot views
+    # this backward took itself -- _sum_rows_multi's own rule); a sum that
+    # would launch now would read partials nobody has written yet
+    if park:
+        plan = _plan()
+        park = plan.deferred is not None and all(
+            job["defer"] and all(_in_slot(o) for o in job["outs"])
+            for job in jobs)
+    if g_tile is not None and park:
+        # inside a training step: parked for the capsule likelihood's backward
+        # to carry (both only wait for the loss tail); the gradient buffers are
+        # handed to autograd now and filled by that launch -- their consumers
+        # (template generator, part encoder, the deferred column sums) all run
+        # after it
+        plan.flush_scope("deferring")
+        addr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        plan.park("k1_bwd", _PendingK1Backward(
+            d, ctx_tensors, (x, lse_post, lse_prior, g_tile),
+            (addr(g_templates), g_alpha_p, addr(g_pose), addr(g_presence),
+             addr(g_bg_image), g_scal), templates))
+    elif g_tile is not None:
+        _lib.call("scae_render_gmm_sums_bwd_f32", ctypes.byref(d), _p(x),
+                  _p(lse_post), _p(lse_prior), _p(g_tile), _p(g_templates),
+                  _p(g_alpha_p), _p(g_pose), _p(g_presence), _p(g_bg_image),
+                  _p(g_scal), _stream(templates))
+    else:
+        _lib.call("scae_render_gmm_bwd_f32", ctypes.byref(d), _p(x),
+                  _p(lse_post), _p(lse_prior), _p(g_lp), _p(g_tt), _p(g_ml),
+                  _p(g_templates), _p(g_alpha_p), _p(g_pose), _p(g_presence),
+                  _p(g_bg_image), _p(g_scal), _stream(templates))
     res = _sum_rows_multi(jobs) if jobs else []
     if alpha is not None:
         g_alpha = res[0][0]

@@ -279,6 +279,35 @@ class TrainStep:
             self._capture()
             self._refresh_prologue()   # the capture consumed the last one
 
+    def prepare(self, image, label):
+        """Stage a batch and build the step's graph(s) WITHOUT stepping: what
+        a measurement does before it snapshots the state it wants to time."""
+        self._stage(image, label)
+        self.capture()
+
+    def snapshot(self):
+        """The training state this step advances -- parameters, the
+        optimiser's two moment buffers and its learning rate -- as clones (a
+        few device copies; not for use inside a timed region).  ``restore``
+        puts it back, under an already captured graph too: the graph reads
+        and writes the same flat buffers, and everything derived from the
+        parameters (folding products, filter re-layouts) is recomputed by
+        every step's own prologue / graph."""
+        snap = {"param": self.flat.flat_param.clone()}
+        if self.opt is not None:
+            snap.update(square_avg=self.opt.square_avg.clone(),
+                        buf=self.opt.buf.clone(), lr=self.opt.lr)
+        return snap
+
+    @torch.no_grad()
+    def restore(self, snap):
+        self.flat.flat_param.copy_(snap["param"])
+        if self.opt is not None:
+            self.opt.square_avg.copy_(snap["square_avg"])
+            self.opt.buf.copy_(snap["buf"])
+            if self.opt.lr != snap["lr"]:
+                self.opt.set_lr(snap["lr"])
+
     def _refresh_prologue(self):
         """Noise + folding products for the next forward (no batch)."""
         if self._pro is not None:
