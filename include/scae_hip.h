@@ -441,6 +441,17 @@ int scae_conv3x3_fwd_fold_f32(const float *in, const float *wf, const float *bia
                               const float *post_bias, float *out_post, int B, int IH, int IW,
                               int Cin, int Cout, int stride, const scae_seed_fold_desc *fold,
                               void *stream);
+/* K8r: the forward with the input images resident in LDS (csrc/conv_resident.hip), for the
+ * small layers of the encoder: a workgroup owns `group` images x 32 output channels, stages
+ * their input pixels once, reads the filter from its fragment-major copy `wp` (see relayout)
+ * straight into MFMA fragments.  Same contract as scae_conv3x3_fwd_f32 otherwise (results agree
+ * to fp32 round-off: the K sum is split by input-channel block).  Cin % 128 == 0,
+ * Cout % 32 == 0, the group's pixels <= 64 KiB of LDS: scae_conv3x3_fwd_res_supported, else
+ * SCAE_ERR_UNSUPPORTED.  group: 0 = by shape; > 0 forces a group size (tests). */
+int scae_conv3x3_fwd_res_supported(int B, int IH, int IW, int Cin, int Cout, int stride);
+int scae_conv3x3_fwd_res_f32(const float *in, const float *wp, const float *bias, float *out,
+                             const float *post_bias, float *out_post, int B, int IH, int IW,
+                             int Cin, int Cout, int stride, int group, void *stream);
 int scae_conv3x3_fwd_bf16(const float *in, const float *wf, const float *bias, float *out,
                           const float *post_bias, float *out_post, int B, int IH, int IW, int Cin,
                           int Cout, int stride, void *stream);
@@ -453,7 +464,10 @@ int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *
  *     fp32 matrix cores      replaces part_encoder.py:26-44 / nn_ext.py:34-59
  *     (Conv2d(k=3, stride, padding=0) + ReLU) and their autograd backward.
  *   Activations NHWC: in (B,IH,IW,Cin) -> out (B,OH,OW,Cout), OH=(IH-3)/s+1.
- *   relayout: w (Cout,Cin,3,3) -> wf (Cout,9,Cin), wd (Cin,9,Cout).
+ *   relayout: w (Cout,Cin,3,3) -> wf, wd (Cin,9,Cout).  `wf` holds 2*Cout*9*Cin floats:
+ *     the (Cout,9,Cin) layout the tile kernels read (`wf` of fwd / fwd_fold / fwd_bf16: a
+ *     caller may fill that block by hand), followed -- when Cin, Cout % 32 == 0 -- by the
+ *     fragment-major copy `wp` = wf + Cout*9*Cin of the image-resident forward (fwd_res).
  *   first_*: direct kernels for the image layer (NCHW image, small Cin; w in
  *     the reference layout, Cout % 64 == 0); first_wgrad writes
  *     scae_conv3x3_first_wgrad_rows(B,Cout) partial rows, each

@@ -45,3 +45,31 @@ def nccl_group():
     yield dist
     if created:
         dist.destroy_process_group()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """What the gate screen kept / drew and where imposed convolution gates differed from the
+    oracle's own, for the record (profiles/rNN/gate_screen.txt): a screen that
+    quietly rejects more and more would be choosing the batches."""
+    try:
+        from tests import gate_screen as gs
+    except Exception:
+        return
+    if not (gs.ALL_STATS or gs.LAST_DISAGREEMENTS):
+        return
+    out = os.environ.get("SCAE_GATE_SCREEN_LOG",
+                         os.path.join(ROOT, "gpurun_out", "gate_screen.txt"))
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        with open(out, "w") as f:
+            f.write(f"SAFETY {gs.SAFETY}  FLOOR {gs.FLOOR}  MIN_KEPT_RATIO {gs.MIN_KEPT_RATIO}  "
+                    f"DISAGREE_BAR {gs.DISAGREE_BAR}\n")
+            f.write("# gate screen: what, kept, drawn, ratio, skipped leading ReLU calls\n")
+            for what, kept, drawn, skip in gs.ALL_STATS:
+                f.write(f"screen  {what!r}  {kept}  {drawn}  {kept / max(1, drawn):.3f}  skip={skip}\n")
+            f.write("# imposed convolution gates: what, layer, units decided differently, units, "
+                    "worst |pre| / layer max\n")
+            for what, k, n_diff, n, worst in gs.LAST_DISAGREEMENTS:
+                f.write(f"impose  {what!r}  layer {k}  {n_diff}  {n}  {worst:.2e}\n")
+    except OSError:
+        pass

@@ -2730,3 +2730,61 @@ def test_grouped_mlp_equals_per_capsule_loop():
         want = torch.stack([loop[g](xin[:, g]) for g in range(G)], 1)
         got = gm.cuda()(x.cuda()).cpu()
         assert torch.allclose(got, want, atol=1e-6), (bias, ones)
+
+
+@pytest.mark.parametrize("B,IH,Ci,Co,s,group,post", [
+    (128, 9, 128, 128, 1, 0, False),    # the encoder's third layer at cfg-2
+    (128, 7, 128, 128, 1, 0, True),     # its fourth, with the embedding bias output
+    (5, 7, 128, 128, 1, 2, True),       # a last group with one image of two
+    (7, 7, 128, 64, 1, 3, False),       # three images per workgroup, 3 row tiles
+    (3, 9, 256, 96, 2, 1, False),       # stride 2, two channel blocks per wave and tap
+    (6, 5, 128, 32, 1, 4, True),        # 3 x 3 outputs, four images per workgroup
+])
+def test_conv_resident_forward_vs_conv2d(B, IH, Ci, Co, s, group, post):
+    """K8r (csrc/conv_resident.hip): the forward of a small layer with the input
+    images resident in LDS and the filter read from its fragment-major copy,
+    against fp64 conv2d + ReLU (part_encoder.py:26-44) at 1e-5 of the output's
+    largest entry, and against the tile kernel of the same layer."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(B * IH + Ci + Co)
+    x = torch.randn(B, Ci, IH, IH, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** .5
+    bias = torch.randn(Co, generator=g) * .1
+    OH = (IH - 3) // s + 1
+    pbias = torch.randn(Co, OH, OH, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), bias.double(),
+                                                stride=s))
+    lib = _lib.load()
+    if group == 0:      # (a forced group may exceed what the launcher picks by itself)
+        assert lib.scae_conv3x3_fwd_res_supported(B, IH, IH, Ci, Co, s) == 1
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd_, wf = torch.empty(Ci, 9, Co, device="cuda"), torch.empty(2, Co, 9, Ci, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    P = ops._p
+    _lib.call("scae_conv3x3_relayout_f32", P(w.cuda()), P(wf), P(wd_), Co, Ci, st)
+    out = torch.full((B, OH, OH, Co), float("nan"), device="cuda")
+    outp = torch.full((B, OH, OH, Co), float("nan"), device="cuda") if post else None
+    pb = pbias.cuda() if post else None
+    _lib.call("scae_conv3x3_fwd_res_f32", P(xn), P(wf[1]), P(bias.cuda()), P(out), P(pb),
+              P(outp), B, IH, IH, Ci, Co, s, group, st)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu().double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 1e-5 * scale
+    if post:
+        gotp = outp.permute(0, 3, 1, 2).cpu().double()
+        assert float((gotp - (ref + pbias.double())).abs().max()) <= 1e-5 * scale
+    if Co % 64 == 0:        # the ring-pipelined tiles of the same layer
+        out2 = torch.empty_like(out)
+        _lib.call("scae_conv3x3_fwd_f32", P(xn), P(wf[0]), P(bias.cuda()), P(out2), None,
+                  None, B, IH, IH, Ci, Co, s, st)
+        assert float((out2 - out).abs().max()) <= 2e-6 * scale
+
+
+def test_conv_resident_forward_rejects_what_it_cannot_hold():
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    assert lib.scae_conv3x3_fwd_res_supported(128, 19, 19, 128, 128, 2) == 0   # 185 KB of pixels
+    assert lib.scae_conv3x3_fwd_res_supported(128, 7, 7, 64, 128, 1) == 0      # Cin % 128
+    assert lib.scae_conv3x3_fwd_res_supported(128, 7, 7, 128, 48, 1) == 0      # Cout % 32

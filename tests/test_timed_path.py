@@ -85,7 +85,7 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
                          loss_rtol=1e-4, entry_bar=1e-4, l2_bar=None,
                          update_l2=5e-2, what="", min_tensors=200, screen=True,
                          entry_abs=0.0, fp64_judge=False, make_batch=None,
-                         shared=None):
+                         shared=None, impose=True):
     """``iters`` replays of ``step`` against the oracle + torch.optim.RMSprop
     started from the model's CURRENT state (``P``: leaf copies of it).
     ``entry_bar``: every entry of every parameter gradient within that fraction
@@ -98,13 +98,24 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
     far from the fp64 oracle as 1e-4 of its tensor's largest + 4 x the fp32
     oracle's own worst error on that tensor, and tensors whose gradient is
     below 1e-10 everywhere (dust next to RMSprop's eps) only have to be dust;
+    ``impose`` (fp32 steps on the implicit-GEMM encoder): the gates of the
+    convolution layers and of the per-capsule MLPs are not screened -- the HIP
+    side's own pattern is imposed on the oracle (tests/gate_screen.py, round
+    5), so the images are arbitrary as far as 97 % of the units go; only the
+    units inside fused kernels that keep no activations (colour MLP,
+    set-transformer feed-forward, relu1) are still screened;
     ``shared``: a dict through which two runs from the same state and noise
     (fp32 and bf16 operands) share the screened batch and the oracle's result; ``l2_bar``: additionally a relative-L2 bound
     per tensor (bf16 operands); ``update_l2`` None: no per-step update check."""
     ocfg = O.prepare_model_params(**cfg)
     ropt = torch.optim.RMSprop(list(P.values()), lr=lr, alpha=0.99,
                                momentum=0.9, eps=1e-2 / B ** 2)
-    from tests.gate_screen import screened_batch_for_noise
+    from tests.gate_screen import (hip_gates, imposed_gates,
+                                   screened_batch_for_noise)
+    enc = model.part_encoder.encoder
+    impose = bool(impose and getattr(enc, "_hip_stack", False)
+                  and step.autocast_dtype is None)
+    n_conv = len(enc.strides) if impose else 0
     for it in range(iters):
         # the SAME state-before on both sides, every step: RMSprop's update is
         # ~10 lr sign(g) wherever |g| >> eps, so an entry whose gradient is at
@@ -126,7 +137,7 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
         elif screen:
             image, label = screened_batch_for_noise(
                 O, cfg, {k: p.detach() for k, p in P.items()}, noise, g,
-                n_classes=cfg["n_classes"])
+                n_classes=cfg["n_classes"], skip=n_conv, skip_caps=impose)
         elif make_batch is not None:
             image, label = make_batch(it)
         else:
@@ -136,8 +147,16 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
             ref_loss, ref_grads = reuse["loss"], reuse["grads"]
             for k, p in P.items():
                 p.grad = ref_grads[k]
+        elif impose:
+            # the branch of every convolution unit as the HIP kernels decide it
+            # (same parameters, same image: the step has not run yet)
+            conv, caps = hip_gates(model, image.cuda(), noise)
+            with imposed_gates(O, conv, caps, f"{what} step {it}"):
+                ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label,
+                                                      noise)
         else:
             ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label, noise)
+        if reuse is None:
             if shared is not None:
                 shared[it] = dict(noise=flat_noise.cpu(), image=image, label=label,
                                   loss=ref_loss.detach(),
@@ -226,8 +245,9 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
             if nr == 0.0:
                 assert float(d_hip.abs().max()) == 0.0, (what, it, k)
                 continue
-            if nr < 1e-3 * lr:   # dust (a step moves an entry by ~10 lr): both sides negligible
-                assert float(d_hip.norm()) < 1e-2 * lr, (what, it, k)
+            if nr < 1e-2 * lr:   # dust: the WHOLE tensor moved by less than 1e-3 of what
+                # one entry with |g| >> eps moves (~10 lr) -- both sides negligible
+                assert float(d_hip.norm()) < 1e-1 * lr, (what, it, k)
                 continue
             assert float((d_hip - d_ref).norm()) <= update_l2 * nr, \
                 (what, it, k, float((d_hip - d_ref).norm()), nr)

@@ -208,6 +208,8 @@ SIGNATURES = {
     "scae_conv3x3_first_wgrad_f32": [P] * 3 + [c_int] * 6 + [P],
     "scae_conv3x3_fwd_f32": [P] * 6 + [c_int] * 6 + [P],
     "scae_conv3x3_fwd_fold_f32": [P] * 6 + [c_int] * 6 + [POINTER(SeedFoldDesc), P],
+    "scae_conv3x3_fwd_res_supported": [c_int] * 6,
+    "scae_conv3x3_fwd_res_f32": [P] * 6 + [c_int] * 7 + [P],
     "scae_conv3x3_fwd_bf16": [P] * 6 + [c_int] * 6 + [P],
     "scae_conv3x3_dgrad_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_bwd_pair_f32": [P] * 5 + [c_int] * 6 + [P],

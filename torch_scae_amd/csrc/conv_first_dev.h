@@ -10,19 +10,34 @@ struct ConvGeom {
   int B, IH, IW, OH, OW, Cin, Cout, stride;
 };
 
-// W[co][ci][3][3] -> Wf[co][tap][ci], Wd[ci][tap][co] for up to 8 layers
+// W[co][ci][3][3] -> Wf[co][tap][ci] (+ its fragment-major copy behind it), Wd[ci][tap][co] for up
+// to 8 layers
 struct RelayoutBatch {
   const float *w[8];
   float *wf[8], *wd[8];
   int Cout[8], Cin[8];
 };
-__device__ __forceinline__ void relayout_batch(const RelayoutBatch &r, int l, int e) {
-  const int Cout = r.Cout[l], Cin = r.Cin[l];
+// Where element (co, tap, ci) of a filter lies in the FRAGMENT-MAJOR copy the image-resident
+// forward (conv_resident.hip) reads -- the second Cout*9*Cin floats of a `wf` buffer:
+// [co / 32][chunk = tap * Cin/32 + ci/32][quad = ci%16 / 4][lane = (ci%32 / 16) * 32 + co%32][ci%4],
+// i.e. the 64 lanes x 16 bytes of one MFMA fragment quad (v_mfma_f32_32x32x2_f32: lane =
+// (column, k half)) are 1 KiB contiguous.  Needs Cin % 32 == 0 and Cout % 32 == 0.
+__host__ __device__ inline size_t packed_index(int Cin, int co, int tap, int ci) {
+  const size_t chunk = (size_t)(co >> 5) * (9 * (Cin >> 5)) + tap * (Cin >> 5) + (ci >> 5);
+  return ((chunk * 4 + ((ci & 15) >> 2)) * 64 + ((ci & 31) >> 4) * 32 + (co & 31)) * 4 + (ci & 3);
+}
+__device__ __forceinline__ void relayout_one(const float *w, float *wf, float *wd, int Cout,
+                                             int Cin, int e) {
   if (e >= Cout * Cin * 9) return;
   const int co = e / (Cin * 9), rem = e - co * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
-  const float v = r.w[l][e];
-  r.wf[l][((size_t)co * 9 + tap) * Cin + ci] = v;
-  r.wd[l][((size_t)ci * 9 + tap) * Cout + co] = v;
+  const float v = w[e];
+  wf[((size_t)co * 9 + tap) * Cin + ci] = v;
+  wd[((size_t)ci * 9 + tap) * Cout + co] = v;
+  if (Cin % 32 == 0 && Cout % 32 == 0)
+    wf[(size_t)Cout * 9 * Cin + packed_index(Cin, co, tap, ci)] = v;
+}
+__device__ __forceinline__ void relayout_batch(const RelayoutBatch &r, int l, int e) {
+  relayout_one(r.w[l], r.wf[l], r.wd[l], r.Cout[l], r.Cin[l], e);
 }
 // fills a RelayoutBatch; returns the workgroups (of 256 elements) per layer or < 0
 inline int fill_relayout(RelayoutBatch &r, int n_layers, const float *const *w, float *const *wf,

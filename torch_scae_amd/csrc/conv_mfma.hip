@@ -384,6 +384,18 @@ namespace pipe = scae_pipe;
             lane = tid & 63, li = lane & 31, lk = lane >> 5;                           \
   const int wn = wid % T::WN, ks = wid / T::WN;
 
+#ifdef SCAE_FWD_PROF   // phase stamps (s_memrealtime, 100 MHz) of every forward workgroup, a slot
+// per layer (by input height): entry, set-up done, main loop done, end (tools/fwd_prof.py)
+__device__ unsigned long long g_fwd_prof[3][2048][4];
+#define FW_STAMP(g, blk, i)                                                               \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && (blk) < 2048)                                                 \
+      g_fwd_prof[(g).IH >= 15 ? 0 : ((g).IH >= 9 ? 1 : 2)][blk][i] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define FW_STAMP(g, blk, i)
+#endif
+
 // ---- forward ------------------------------------------------------------------------
 template <class T>
 __device__ __forceinline__ void fwd_pipe_tile(float *smem, int bx, int by,
@@ -394,6 +406,7 @@ __device__ __forceinline__ void fwd_pipe_tile(float *smem, int bx, int by,
                                               const float *__restrict__ post_bias,
                                               float *__restrict__ out_post, const ConvGeom &g) {
   SCAE_PIPE_IDS
+  FW_STAMP(g, by * (g.Cout / T::TB) + bx, 0);
   const int M = g.B * g.OH * g.OW, K = 9 * g.Cin;
   const int m0 = by * T::TA, n0 = bx * T::TB;
   const pipe::DmaLane da = pipe::dma_lane<T::TA>(wid, lane), db = pipe::dma_lane<T::TB>(wid, lane);
@@ -433,16 +446,41 @@ __device__ __forceinline__ void fwd_pipe_tile(float *smem, int bx, int by,
   };
   pipe::f32x16 acc[T::MI][T::NI];
   pipe::kk_zero<T>(acc);
+  FW_STAMP(g, by * (g.Cout / T::TB) + bx, 1);
   pipe::kk_mainloop<T>(K / pipe::BK, smem, acc, wn, ks, li, lk, chunk, issue);
+  FW_STAMP(g, by * (g.Cout / T::TB) + bx, 2);
   const int hw = g.OH * g.OW;
-  pipe::kk_epilogue<T>(smem, acc, wid, wn, ks, li, lk, [&](int row, int col, float v) {
-    const int m = m0 + row, n = n0 + col;
-    if (m >= M) return;
-    const float o = fmaxf(v + bias[n], 0.f);
-    out[(size_t)m * g.Cout + n] = o;
-    if (out_post)   // + the per-(channel, pixel) embedding bias, (Cout, OH, OW)
-      out_post[(size_t)m * g.Cout + n] = o + post_bias[(size_t)n * hw + m % hw];
+  // every load of the epilogue is in flight before the first store (a load behind the row
+  // guard costs its own L2 round trip per element: 16 x 2 of them were 2.4 us per tile)
+  float bn[T::NI];
+#pragma unroll
+  for (int ni = 0; ni < T::NI; ++ni) bn[ni] = bias[n0 + (wn * T::NI + ni) * 32 + li];
+  float pb[T::MI][T::NI][16];
+  if (out_post) {   // the per-(channel, pixel) embedding bias, (Cout, OH, OW)
+#pragma unroll
+    for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = min(m0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk, M - 1);
+          pb[mi][ni][e] = post_bias[(size_t)(n0 + (wn * T::NI + ni) * 32 + li) * hw + m % hw];
+        }
+  }
+  // Stores through range-checked descriptors: a row past M is dropped by the hardware, so the
+  // epilogue has no divergent branch -- behind one the compiler cannot count the outstanding
+  // stores and waits for each of them (vmcnt(0)) before the next one's operands.
+  const pipe::rsrc_t ro = pipe::make_rsrc(out, (unsigned)((size_t)M * g.Cout * 4));
+  const pipe::rsrc_t rp = pipe::make_rsrc(out_post ? out_post : out, (unsigned)((size_t)M * g.Cout * 4));
+  pipe::kk_epilogue_idx<T>(smem, acc, wid, wn, ks, li, lk,
+                           [&](int mi, int ni, int e, int row, int col, float v) {
+    const int off = ((m0 + row) * g.Cout + n0 + col) * 4;
+    const float o = fmaxf(v + bn[ni], 0.f);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o), ro, off, 0, 0);
+    if (out_post)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o + pb[mi][ni][e]), rp, off, 0, 0);
   });
+  FW_STAMP(g, by * (g.Cout / T::TB) + bx, 3);
 }
 
 template <class T>
@@ -544,14 +582,28 @@ __device__ __forceinline__ void dgrad_pipe_tile(float *smem, int bx, int by,
   pipe::f32x16 acc[T::MI][T::NI];
   pipe::kk_zero<T>(acc);
   pipe::kk_mainloop<T>(nchunk, smem, acc, wn, ks, li, lk, chunk, issue);
-  pipe::kk_epilogue<T>(smem, acc, wid, wn, ks, li, lk, [&](int row, int col, float v) {
-    const int m = m0 + row;
-    if (m >= M) return;
-    const int nb = m / (AH * AW), rem = m - nb * AH * AW, a = rem / AW, b = rem - a * AW;
-    const int ih = pl.rlist[pl.rstart[rc] + a], iw = pl.clist[pl.cstart[cc] + b];
-    const size_t o = (((size_t)nb * g.IH + ih) * g.IW + iw) * g.Cin + n0 + col;
-    if (gate) v = gate[o] > 0.f ? v : 0.f;
-    din[o] = v;
+  // the rows this lane finishes (16 per 32-row block), their pixels and gates: every load in
+  // flight before the first store, stores through a range-checked descriptor (no branches)
+  int ooff[T::MI][16];
+  float gt[T::MI][T::NI][16];
+#pragma unroll
+  for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk, mc = min(m, M - 1);
+      const int nb = mc / (AH * AW), rem = mc - nb * AH * AW, a = rem / AW, b = rem - a * AW;
+      const int ih = pl.rlist[pl.rstart[rc] + a], iw = pl.clist[pl.cstart[cc] + b];
+      const int o = (((nb * g.IH + ih) * g.IW + iw) * g.Cin + n0) * 4;
+      ooff[mi][e] = m < M ? o : pipe::DMA_ZERO;
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni)
+        gt[mi][ni][e] = gate ? gate[o / 4 + (wn * T::NI + ni) * 32 + li] : 1.f;
+    }
+  const pipe::rsrc_t rdin = pipe::make_rsrc(din, (unsigned)((size_t)g.B * g.IH * g.IW * g.Cin * 4));
+  pipe::kk_epilogue_idx<T>(smem, acc, wid, wn, ks, li, lk,
+                           [&](int mi, int ni, int e, int, int col, float v) {
+    v = gt[mi][ni][e] > 0.f ? v : 0.f;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rdin, ooff[mi][e] + col * 4, 0, 0);
   });
 }
 
@@ -623,29 +675,12 @@ __device__ __forceinline__ void wgrad_pipe_tile(float *smem, int bx, int by, int
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
   float bsum = 0.f;   // column sum of dpre over this split (thread = channel, tid < TA)
-  {
-    constexpr int LA = T::NS - 1;
-#pragma unroll
-    for (int c = 0; c < LA; ++c)
-      if (c < nchunk) {
-#pragma unroll
-        for (int j = 0; j < T::PPW; ++j) issue(c, smem + c * T::STAGE, j);
-      }
-    int s = 0;
-    for (int c = 0; c < nchunk; ++c) {
-      pipe::wait_chunk<T::PPW, LA>(min(LA - 1, nchunk - 1 - c));
-      pipe::wg_barrier();
-      float *s2 = smem + (s >= 1 ? s - 1 : T::NS - 1) * T::STAGE;
-      const float *st = smem + s * T::STAGE;
-      if (want_bias && tid < T::TA) {
+  pipe::ss_mainloop<T>(nchunk, smem, acc, wm, wn, li, lk, issue, [&](const float *st) {
+    if (want_bias && tid < T::TA) {
 #pragma unroll 16
-        for (int k = 0; k < T::BKW; ++k) bsum += st[k * T::TA + tid];
-      }
-      pipe::ss_compute<T>(st, acc, wm, wn, li, lk, c + LA < nchunk,
-                          [&](int j) { issue(c + LA, s2, j); });
-      s = s + 1 == T::NS ? 0 : s + 1;
+      for (int k = 0; k < T::BKW; ++k) bsum += st[k * T::TA + tid];
     }
-  }
+  });
   float *dst = partial + (size_t)(split * 9 + tap) * g.Cout * g.Cin;
 #pragma unroll
   for (int a = 0; a < T::MI; ++a)
@@ -784,15 +819,10 @@ namespace {
 #endif
 
 // ---- small helpers ---------------------------------------------------------------
-// W[co][ci][3][3] -> Wf[co][tap][ci], Wd[ci][tap][co]
+// W[co][ci][3][3] -> Wf[co][tap][ci] (+ its fragment-major copy), Wd[ci][tap][co]
 __global__ void relayout_weights_kernel(const float *__restrict__ w, float *__restrict__ wf,
                                         float *__restrict__ wd, int Cout, int Cin) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= Cout * Cin * 9) return;
-  const int co = e / (Cin * 9), rem = e - co * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
-  const float v = w[e];
-  wf[((size_t)co * 9 + tap) * Cin + ci] = v;
-  wd[((size_t)ci * 9 + tap) * Cout + co] = v;
+  scae_first::relayout_one(w, wf, wd, Cout, Cin, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // (RelayoutBatch / relayout_batch: conv_first_dev.h)
@@ -1471,6 +1501,118 @@ extern "C" int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, co
   return conv_bwd_pair_impl(dpre, wd, in, din, partial, B, IH, IW, Cin, Cout, stride, true,
                             stream);
 }
+
+#ifdef SCAE_FWD_PROF
+extern "C" int scae_debug_fwd_prof(unsigned long long *out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_prof), sizeof(g_fwd_prof));
+}
+#endif
+#ifdef SCAE_CONV_MULTI_PROBE
+// Upper-bound probe (tools/conv_multi_probe.py): the tiles of up to 3 layers in ONE launch
+// WITHOUT dependencies between them (every layer reads buffers that already exist) -- what a
+// dependency-tracking multi-layer launch could gain at most over one launch per layer.
+namespace {
+struct MultiFwd {
+  const float *in[3], *wf[3], *bias[3];
+  float *out[3];
+  ConvGeom g[3];
+  int start[4], gx[3];
+};
+template <class T>
+__global__ __launch_bounds__(pipe::NT) void conv_fwd_multi_probe_kernel(MultiFwd a) {
+  __shared__ __attribute__((aligned(1024))) float smem[T::SMEM];
+  const int b = blockIdx.x;
+  const int l = b >= a.start[2] ? 2 : (b >= a.start[1] ? 1 : 0);
+  const int t = b - a.start[l];
+  fwd_pipe_tile<T>(smem, t % a.gx[l], t / a.gx[l], a.in[l], a.wf[l], a.bias[l], a.out[l], nullptr,
+                   nullptr, a.g[l]);
+}
+struct MultiBwd {
+  const float *dpre[3], *wd[3], *gate[3], *in[3];
+  float *din[3], *partial[3];
+  ConvGeom g[3];
+  DgradPlan pl[3];
+  int splits[3], mode[3];
+  PairGrid pg[3];
+  int start[4];
+};
+__global__ __launch_bounds__(NT) void conv_bwd_multi_probe_kernel(const MultiBwd *ap) {
+  constexpr int SM = Tile<0>::SMEM > PipeW::SMEM ? Tile<0>::SMEM : PipeW::SMEM;
+  __shared__ __attribute__((aligned(1024))) float smem[SM];
+  const MultiBwd &a = *ap;
+  const int b = blockIdx.x;
+  const int l = b >= a.start[2] ? 2 : (b >= a.start[1] ? 1 : 0);
+  const int bid = b - a.start[l];
+  const PairGrid pg = a.pg[l];
+  if (bid < pg.nd) {
+    if (a.mode[l] == 0)
+      dgrad_tile<0>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
+    else if (a.mode[l] == 2)
+      dgrad_tile<2>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
+    else
+      dgrad_tile<1>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
+  } else {
+    const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
+    wgrad_pipe_tile<PipeW>(smem, bx, t % pg.wy, t / pg.wy, a.dpre[l], a.in[l], a.partial[l], a.g[l],
+                           a.splits[l]);
+  }
+}
+}  // namespace
+extern "C" int scae_debug_conv_fwd_multi(int n, const float *const *in, const float *const *wf,
+                                         const float *const *bias, float *const *out, const int *B,
+                                         const int *IH, const int *Cin, const int *Cout,
+                                         const int *stride, void *stream) {
+  MultiFwd a{};
+  int tot = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int k = l < n ? l : n - 1;
+    a.in[l] = in[k], a.wf[l] = wf[k], a.bias[l] = bias[k], a.out[l] = out[k];
+    a.g[l] = ConvGeom{B[k], IH[k], IH[k], (IH[k] - 3) / stride[k] + 1, (IH[k] - 3) / stride[k] + 1,
+                      Cin[k], Cout[k], stride[k]};
+    a.gx[l] = Cout[k] / PipeC2::TB;
+    a.start[l] = tot;
+    if (l < n) tot += a.gx[l] * ((B[k] * a.g[l].OH * a.g[l].OW + PipeC2::TA - 1) / PipeC2::TA);
+  }
+  a.start[3] = tot;
+  for (int l = n; l < 3; ++l) a.start[l] = tot;
+  hipLaunchKernelGGL(conv_fwd_multi_probe_kernel<PipeC2>, dim3(tot), dim3(pipe::NT), 0,
+                     (hipStream_t)stream, a);
+  return scae_launch_status();
+}
+// `scratch`: device memory for the argument block (sizeof(MultiBwd) bytes, >= 8 KiB given)
+extern "C" int scae_debug_conv_bwd_multi(int n, const float *const *dpre, const float *const *wd,
+                                         const float *const *in, float *const *din,
+                                         float *const *partial, const int *B, const int *IH,
+                                         const int *Cin, const int *Cout, const int *stride,
+                                         void *scratch, void *stream) {
+  static MultiBwd a;
+  a = MultiBwd{};
+  int tot = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int k = l < n ? l : n - 1;
+    a.dpre[l] = dpre[k], a.wd[l] = wd[k], a.gate[l] = in[k], a.in[l] = in[k], a.din[l] = din[k],
+    a.partial[l] = partial[k];
+    ConvGeom g{B[k], IH[k], IH[k], (IH[k] - 3) / stride[k] + 1, (IH[k] - 3) / stride[k] + 1,
+               Cin[k], Cout[k], stride[k]};
+    a.g[l] = g;
+    const DgradLaunch d = plan_dgrad(g, true, false);
+    const WgradPlan p = wgrad_plan(B[k] * g.OH * g.OW, Cin[k], Cout[k]);
+    a.pl[l] = d.pl, a.mode[l] = d.mode, a.splits[l] = p.splits;
+    a.pg[l] = PairGrid{d.gx * d.ny, d.gx, Cin[k] / 64, Cout[k] / 64};
+    a.start[l] = tot;
+    if (l < n) tot += a.pg[l].nd + a.pg[l].wx * a.pg[l].wy * 9 * p.splits;
+  }
+  a.start[3] = tot;
+  for (int l = n; l < 3; ++l) a.start[l] = tot;
+  hipError_t e = hipMemcpyAsync(scratch, &a, sizeof(a), hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(conv_bwd_multi_probe_kernel, dim3(tot), dim3(NT), 0, (hipStream_t)stream,
+                     (const MultiBwd *)scratch);
+  return scae_launch_status();
+}
+extern "C" int scae_debug_conv_bwd_multi_bytes(void) { return (int)sizeof(MultiBwd); }
+#endif
 
 extern "C" int scae_conv3x3_wgrad_splits(int B, int OH, int OW, int Cin, int Cout) {
   if (B <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0) return 0;

@@ -18,6 +18,8 @@
 //     fragment reads are 32 consecutive floats per k (conflict free as they are).
 // Workgroup = 256 threads = 4 waves.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace scae_pipe {
@@ -118,89 +120,111 @@ __device__ __forceinline__ void kk_zero(f32x16 (&acc)[T::MI][T::NI]) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 }
 
-// The MFMAs of one chunk from ring stage `st`.  The fragments of 4-k group g + 1 are
-// read while the MFMAs of group g run (one wave cannot hide a ds_read behind anything
-// else), and `dma(j)` -- the DMA pieces of a later chunk, with their address
-// arithmetic -- is spread between the groups instead of idling the matrix pipe at
-// the head of the chunk.
-template <class T, class Dma>
-__device__ __forceinline__ void kk_compute(const float *st, f32x16 (&acc)[T::MI][T::NI], int wn,
-                                           int ks, int i, int kk, bool more, Dma dma) {
-  const float *As = st + kk * T::TA * BKH + i * BKH;
-  const float *Bs = st + T::TA * BK + (kk * T::TB + wn * 32 * T::NI + i) * BKH;
-  const int sw = (i >> 2) & 3;
-  constexpr int G = 4 / T::KS;
-  float4 a[2][T::MI], b[2][T::NI];
-  auto load = [&](int gg, int buf) {
-    const int qo = ((ks * G + gg) ^ sw) << 2;
-#pragma unroll
-    for (int mi = 0; mi < T::MI; ++mi) a[buf][mi] = lds4(As + mi * 32 * BKH + qo);
-#pragma unroll
-    for (int ni = 0; ni < T::NI; ++ni) b[buf][ni] = lds4(Bs + ni * 32 * BKH + qo);
-  };
-  load(0, 0);
-#pragma unroll
-  for (int gg = 0; gg < G; ++gg) {
-    const int cur = gg & 1;
-    if (gg + 1 < G) load(gg + 1, cur ^ 1);
-#pragma unroll
-    for (int mi = 0; mi < T::MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < T::NI; ++ni) {
-#if SCAE_PIPE_ABL == 2
-        acc[mi][ni][0] += a[cur][mi].x * b[cur][ni].x + a[cur][mi].y * b[cur][ni].y +
-                          a[cur][mi].z * b[cur][ni].z + a[cur][mi].w * b[cur][ni].w;
-#else
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].x, b[cur][ni].x, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].y, b[cur][ni].y, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].z, b[cur][ni].z, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].w, b[cur][ni].w, acc[mi][ni], 0, 0, 0);
-#endif
-      }
-    if (more) {   // workgroup-uniform
-#pragma unroll
-      for (int j = gg * T::PPW / G; j < (gg + 1) * T::PPW / G; ++j) dma(j);
-    }
-  }
-}
-
-// The K loop.  chunk(c) -- called once per chunk, c = 0, 1, 2, ... in order -- returns
-// the wave-uniform context of chunk c (its offsets); issue(ctx, stage, j) starts DMA
-// piece j (of this wave's T::PPW) of that chunk.
+// The K loop (third form, round 5).  Measured with phase stamps (tools/fwd_prof.py): a 32 x 64
+// tile alone on its CU (layer 4 at B = 128: 200 workgroups on 256 CUs) spent ~1100 cycles per
+// 32-wide chunk on 512 cycles of MFMAs -- after the chunk's barrier the wave waited for its
+// first fragment reads, and the three DMA instructions of the chunk (60-180 cycles of issue
+// each) sat behind the last MFMA where nothing covers them.  Now
+//   * the wait + barrier for chunk c + 1 and the read of its first fragments happen in the
+//     MIDDLE of chunk c, ahead of chunk c's last MFMA group: the barrier's skew and the LDS
+//     latency run under MFMAs already in the pipe;
+//   * every fragment of chunk c is in registers by then, so the barrier also frees chunk c's
+//     OWN stage: the DMA pieces issued behind it are those of chunk c + NS (a ring of NS stages
+//     keeps NS chunks in flight, not NS - 1);
+//   * those pieces go BETWEEN the MFMAs of the last group, one behind an MFMA each (a dependent
+//     MFMA cannot issue for 64 cycles anyway).
+// The order of the products within an accumulator is unchanged (bit-identical results).
+// chunk(c) -- called once per chunk, c = 0, 1, 2, ... in order -- returns the wave-uniform context
+// of chunk c (its offsets); issue(ctx, stage, j) starts DMA piece j (of this wave's T::PPW).
 template <class T, class Chunk, class Issue>
 __device__ __forceinline__ void kk_mainloop(int nchunk, float *smem, f32x16 (&acc)[T::MI][T::NI],
                                             int wn, int ks, int i, int kk, Chunk chunk,
                                             Issue issue) {
-  constexpr int LA = T::NS - 1;   // chunks in flight beyond the one being multiplied
+#ifndef SCAE_PIPE_ABL
+#define SCAE_PIPE_ABL 0
+#endif
+  constexpr int NS = T::NS, G = 4 / T::KS, NM = 4 * T::MI * T::NI;
+  const int sw = (i >> 2) & 3;
+  const int aoff = kk * T::TA * BKH + i * BKH;
+  const int boff = T::TA * BK + (kk * T::TB + wn * 32 * T::NI + i) * BKH;
+  float4 a[2][T::MI], b[2][T::NI];
+  auto load = [&](const float *st, int gg, int buf) {
+    const int qo = ((ks * G + gg) ^ sw) << 2;
 #pragma unroll
-  for (int c = 0; c < LA; ++c)
+    for (int mi = 0; mi < T::MI; ++mi) a[buf][mi] = lds4(st + aoff + mi * 32 * BKH + qo);
+#pragma unroll
+    for (int ni = 0; ni < T::NI; ++ni) b[buf][ni] = lds4(st + boff + ni * 32 * BKH + qo);
+  };
+#pragma unroll
+  for (int c = 0; c < NS; ++c)
     if (c < nchunk) {
       const auto ctx = chunk(c);
 #pragma unroll
       for (int j = 0; j < T::PPW; ++j) issue(ctx, smem + c * T::STAGE, j);
     }
+  if (nchunk <= 0) return;
+  wait_chunk<T::PPW, NS>(min(NS - 1, nchunk - 1));   // chunk 0 has landed
+  wg_barrier();
+  load(smem, 0, 0);
   int s = 0;   // stage of chunk c
-  for (int c = 0; c < nchunk; ++c) {
-#ifndef SCAE_PIPE_ABL
-#define SCAE_PIPE_ABL 0
+  // (`last` is a compile-time constant: a run-time test around the barrier + reads makes the
+  // compiler wait for ALL outstanding LDS reads -- the next chunk's too -- before the last group)
+  auto body = [&](int c, auto last_t) {
+    constexpr bool last = decltype(last_t)::value;
+    const bool more = SCAE_PIPE_ABL != 1 && !last && c + NS < nchunk;
+    const auto ctx = chunk(c + NS);   // (a few scalar instructions; unused past the end)
+    float *st = smem + s * T::STAGE;
+    const int sn = s + 1 == NS ? 0 : s + 1;
+    const float *stn = smem + sn * T::STAGE;
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+      const int cur = gg & 1;
+      if (gg + 1 < G) {
+        load(st, gg + 1, cur ^ 1);
+      } else if (!last) {
+        // chunk c + 1 has landed (chunks c + 2 .. may still be in flight); everyone's pieces
+        // of it, and everyone done reading chunk c
+        wait_chunk<T::PPW, NS>(min(NS - 2, nchunk - 2 - c));
+        wg_barrier();
+        load(stn, 0, cur ^ 1);
+      }
+      const bool dma_here = gg + 1 == G && more;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int mi = (m >> 2) / T::NI, ni = (m >> 2) % T::NI, e = m & 3;
+#if SCAE_PIPE_ABL == 2
+        acc[mi][ni][0] += a[cur][mi][e] * b[cur][ni][e];
+#else
+        const float av = e == 0 ? a[cur][mi].x : e == 1 ? a[cur][mi].y : e == 2 ? a[cur][mi].z : a[cur][mi].w;
+        const float bv = e == 0 ? b[cur][ni].x : e == 1 ? b[cur][ni].y : e == 2 ? b[cur][ni].z : b[cur][ni].w;
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
 #endif
-    const bool more = SCAE_PIPE_ABL != 1 && c + LA < nchunk;
-    const auto ctx = chunk(c + LA);   // (a few scalar instructions; unused past the end)
-    // chunk c has landed; younger chunks may still be in flight
-    wait_chunk<T::PPW, LA>(min(LA - 1, nchunk - 1 - c));
-    wg_barrier();   // everyone's pieces of chunk c; everyone done with chunk c - 1
-    float *s2 = smem + (s >= 1 ? s - 1 : T::NS - 1) * T::STAGE;   // stage of chunk c - 1
-    kk_compute<T>(smem + s * T::STAGE, acc, wn, ks, i, kk, more,
-                  [&](int j) { issue(ctx, s2, j); });
-    s = s + 1 == T::NS ? 0 : s + 1;
-  }
+        if (dma_here && m + 1 < NM) {   // pieces spread over the NM - 1 gaps between the MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = m * T::PPW / (NM - 1); j < (m + 1) * T::PPW / (NM - 1); ++j) issue(ctx, st, j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (G & 1) {   // the next chunk's first fragments were read into the other buffer
+#pragma unroll
+      for (int mi = 0; mi < T::MI; ++mi) a[0][mi] = a[1][mi];
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni) b[0][ni] = b[1][ni];
+    }
+    s = sn;
+  };
+  for (int c = 0; c + 1 < nchunk; ++c) body(c, std::false_type{});
+  body(nchunk - 1, std::true_type{});
 }
 
 // Accumulators out: epi(row, col, value) per element (row-major C, 32 consecutive
 // columns per store instruction).  With KS > 1 the wave groups meet in LDS first.
+// epi(mi, ni, e, row, col, value): the accumulator's indices as compile-time constants too
 template <class T, class Epi>
-__device__ __forceinline__ void kk_epilogue(float *smem, f32x16 (&acc)[T::MI][T::NI], int wid,
-                                            int wn, int ks, int i, int kk, Epi epi) {
+__device__ __forceinline__ void kk_epilogue_idx(float *smem, f32x16 (&acc)[T::MI][T::NI], int wid,
+                                                int wn, int ks, int i, int kk, Epi epi) {
   if (T::KS > 1) {
     // [ks - 1][wn][mi][ni][reg][lane]: conflict-free, 64 consecutive floats per store
     wg_barrier();   // the ring is dead
@@ -234,7 +258,14 @@ __device__ __forceinline__ void kk_epilogue(float *smem, f32x16 (&acc)[T::MI][T:
     for (int ni = 0; ni < T::NI; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        epi(mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk, (wn * T::NI + ni) * 32 + i, acc[mi][ni][e]);
+        epi(mi, ni, e, mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk, (wn * T::NI + ni) * 32 + i,
+            acc[mi][ni][e]);
+}
+template <class T, class Epi>
+__device__ __forceinline__ void kk_epilogue(float *smem, f32x16 (&acc)[T::MI][T::NI], int wid,
+                                            int wn, int ks, int i, int kk, Epi epi) {
+  kk_epilogue_idx<T>(smem, acc, wid, wn, ks, i, kk,
+                     [&](int, int, int, int row, int col, float v) { epi(row, col, v); });
 }
 
 // ---------------------------------------------------------------------------------
@@ -252,41 +283,78 @@ struct SS {
   static_assert(MI >= 1 && NI >= 1 && (PA + PB) % 4 == 0 && (NS >= 2 && NS <= 7), "tile shape");
 };
 
-template <class T, class Dma>
-__device__ __forceinline__ void ss_compute(const float *st, f32x16 (&acc)[T::MI][T::NI], int wm,
-                                           int wn, int i, int kk, bool more, Dma dma) {
-  const float *As = st + kk * T::TA + wm * 32 * T::MI + i;
-  const float *Bs = st + T::TA * T::BKW + kk * T::TB + wn * 32 * T::NI + i;
-  constexpr int S = T::BKW / 2, U = 4;   // MFMA steps per chunk, per fragment batch
+// The K loop of an SS tile (same structure as kk_mainloop: the wait + barrier for chunk c + 1
+// and the read of its first fragments sit in front of chunk c's LAST fragment batch, under
+// MFMAs already in the pipe).  issue(c, stage, j): DMA piece j of chunk c; each(st): called once
+// per chunk with its landed stage (the weight gradient's bias column sums).
+template <class T, class Issue, class Each>
+__device__ __forceinline__ void ss_mainloop(int nchunk, float *smem, f32x16 (&acc)[T::MI][T::NI],
+                                            int wm, int wn, int i, int kk, Issue issue, Each each) {
+  constexpr int LA = T::NS - 1, S = T::BKW / 2, U = 4, NB = S / U;
+  static_assert(NB >= 2 && NB % 2 == 0 && T::PPW % NB == 0, "fragment batches per chunk");
+  const int aoff = kk * T::TA + wm * 32 * T::MI + i;
+  const int boff = T::TA * T::BKW + kk * T::TB + wn * 32 * T::NI + i;
   float a[2][U][T::MI], b[2][U][T::NI];
-  auto load = [&](int blk, int buf) {
+  auto load = [&](const float *st, int blk, int buf) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int s = blk * U + u;
 #pragma unroll
-      for (int mi = 0; mi < T::MI; ++mi) a[buf][u][mi] = As[2 * s * T::TA + mi * 32];
+      for (int mi = 0; mi < T::MI; ++mi) a[buf][u][mi] = st[aoff + 2 * s * T::TA + mi * 32];
 #pragma unroll
-      for (int ni = 0; ni < T::NI; ++ni) b[buf][u][ni] = Bs[2 * s * T::TB + ni * 32];
+      for (int ni = 0; ni < T::NI; ++ni) b[buf][u][ni] = st[boff + 2 * s * T::TB + ni * 32];
     }
   };
-  load(0, 0);
 #pragma unroll
-  for (int blk = 0; blk < S / U; ++blk) {
-    const int cur = blk & 1;
-    if (blk + 1 < S / U) load(blk + 1, cur ^ 1);
+  for (int c = 0; c < LA; ++c)
+    if (c < nchunk) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int mi = 0; mi < T::MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < T::NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][u][mi], b[cur][u][ni],
-                                                            acc[mi][ni], 0, 0, 0);
-    if (more) {
-#pragma unroll
-      for (int j = blk * T::PPW / (S / U); j < (blk + 1) * T::PPW / (S / U); ++j) dma(j);
+      for (int j = 0; j < T::PPW; ++j) issue(c, smem + c * T::STAGE, j);
     }
-  }
+  if (nchunk <= 0) return;
+  wait_chunk<T::PPW, LA>(min(LA - 1, nchunk - 1));
+  wg_barrier();
+  load(smem, 0, 0);
+  int s = 0;
+  auto body = [&](int c, auto last_t) {
+    constexpr bool last = decltype(last_t)::value;
+    const bool more = !last && c + LA < nchunk;
+    const float *st = smem + s * T::STAGE;
+    float *s2 = smem + (s >= 1 ? s - 1 : T::NS - 1) * T::STAGE;   // stage of chunk c - 1: free
+    const int sn = s + 1 == T::NS ? 0 : s + 1;
+    each(st);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const int cur = blk & 1;
+      if (blk + 1 < NB) {
+        load(st, blk + 1, cur ^ 1);
+      } else if (!last) {
+        // chunk c + 1 has landed: what is younger are the pieces of chunk c + LA issued so far
+        // in this iteration (and, with a deeper ring, the chunks between)
+        if (more)
+          wait_vm<(LA - 2) * T::PPW + (NB - 1) * (T::PPW / NB)>();
+        else
+          wait_chunk<T::PPW, LA>(min(LA - 2, nchunk - 2 - c));
+        wg_barrier();
+        load(smem + sn * T::STAGE, 0, cur ^ 1);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < T::NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][u][mi], b[cur][u][ni],
+                                                              acc[mi][ni], 0, 0, 0);
+      if (more) {
+#pragma unroll
+        for (int j = blk * (T::PPW / NB); j < (blk + 1) * (T::PPW / NB); ++j) issue(c + LA, s2, j);
+      }
+    }
+    s = sn;
+  };
+  for (int c = 0; c + 1 < nchunk; ++c) body(c, std::false_type{});
+  body(nchunk - 1, std::true_type{});
 }
 
 }  // namespace scae_pipe

@@ -1046,6 +1046,18 @@ def conv_stack_supported(in_channels, out_channels, kernel_sizes, strides):
             and all(c <= 1024 for c in chans))
 
 
+# K8r takes a layer when the ring-pipelined tiles would leave the chip short of work:
+# fewer than ~3 of their 32 x 64 tiles per CU (measured at B = 128 / 1024)
+_CONV_RESIDENT_MAX_TILES = 768
+
+
+def _conv_resident(B, ih, iw, ci, co, s):
+    oh, ow = (ih - 3) // s + 1, (iw - 3) // s + 1
+    tiles = -(-B * oh * ow // 32) * (co // 64)
+    return tiles < _CONV_RESIDENT_MAX_TILES and bool(
+        _lib.load().scae_conv3x3_fwd_res_supported(B, ih, iw, ci, co, s))
+
+
 def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
     """-> (acts, wds, x_post): the NHWC ReLU outputs of every layer, the
     re-laid-out filters the data-gradient kernels read, and (with
@@ -1072,7 +1084,8 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
         wds, wfs = [], []
         for l in range(1, L):
             co, ci = weights[l].shape[0], weights[l].shape[1]
-            wfs.append(new(co, 9, ci))
+            # (Cout,9,Cin) + its fragment-major copy (include/scae_hip.h, K8)
+            wfs.append(new(2, co, 9, ci))
             wds.append(new(ci, 9, co))
         if pro is not None:
             pro.first_inputs = (image, list(weights), list(biases),
@@ -1122,7 +1135,12 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
                     _lib.check(rc, "scae_conv3x3_fwd_fold_f32")
                     carried = pro.fold_fresh = pro.fold_rides_conv = True
         if not carried:
-            _lib.call(_prec("scae_conv3x3_fwd_f32"), *conv, st)
+            # small layers: the input images resident in LDS (K8r)
+            if not _bf16() and _conv_resident(B, ih, iw, ci, co, s):
+                _lib.call("scae_conv3x3_fwd_res_f32", _p(act),
+                          _p(wfs[l - 1][1]), *conv[2:], 0, st)
+            else:
+                _lib.call(_prec("scae_conv3x3_fwd_f32"), *conv, st)
         acts.append(out)
         act = out
     return acts, wds, x_post
