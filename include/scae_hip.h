@@ -1042,6 +1042,16 @@ int scae_set_encoder_fwd_logprob_f32(int nseg, const float *const *seg_ptr,
                                      float *tile_sums, float *lse_post, float *lse_prior,
                                      void *stream);
 
+/* ... with the bf16 attention products of scae_set_encoder_fwd_bf16 in the trunk */
+int scae_set_encoder_fwd_logprob_bf16(int nseg, const float *const *seg_ptr,
+                                      const int *seg_width, const int *seg_row_stride,
+                                      const int64_t *seg_batch_stride, const float *presence,
+                                      const float *params, float *z, float *hsave, int B, int N,
+                                      int D, int Din, int Dout, int L, int layer_norm,
+                                      const scae_decoder_desc *d, const float *x,
+                                      float *tile_sums, float *lse_post, float *lse_prior,
+                                      void *stream);
+
 /* scae_render_gmm_sums_bwd_f32 and scae_capsule_likelihood_bwd_f32 as ONE launch: both
  * backward kernels only wait for the loss tail's (stacked_capsule_auto_encoder.py:217-287)
  * and are independent of each other; the capsule likelihood's one-workgroup-per-image kernel

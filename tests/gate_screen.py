@@ -48,7 +48,8 @@ import torch.nn.functional as F
 # 1e-4 .. 2e-4 for one in eight -- single gate flips the screen had let through.
 SAFETY = 8.0
 FLOOR = 2e-7          # ... but at least this (relative to the layer's max)
-MIN_KEPT_RATIO = 0.45
+MIN_KEPT_RATIO = 0.45      # full screens (the medium configurations of test_step_plan.py)
+MIN_KEPT_IMPOSED = 0.9     # screens beside imposed gates: what is observed is >= 0.97
 LAST_STATS = []       # [(what, kept, drawn)] of the most recent calls
 ALL_STATS = []        # [(what, kept, drawn, skip)] of the whole session (conftest writes them out)
 # a unit whose gate the HIP side and the oracle decide differently has a pre-activation
@@ -162,8 +163,11 @@ def _note(what, kept, drawn, margins, skip=0):
     ratio = kept / max(1, drawn)
     print(f"[gate screen] {what}: kept {kept} of {drawn} drawn ({ratio:.3f}); "
           f"layer margins {min(margins):.1e} .. {max(margins):.1e}")
-    assert ratio >= MIN_KEPT_RATIO, \
-        f"gate screen {what}: kept only {kept} of {drawn} candidates"
+    # (with the convolution and capsule-MLP gates imposed the screen covers 0.25 M short-sum
+    # units and keeps 0.97 - 1.0 of what it draws, profiles/r05/gate_screen.txt)
+    floor = MIN_KEPT_IMPOSED if str(skip).endswith("+caps") else MIN_KEPT_RATIO
+    assert ratio >= floor, \
+        f"gate screen {what}: kept only {kept} of {drawn} candidates (floor {floor})"
     return ratio
 
 

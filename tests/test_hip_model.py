@@ -65,11 +65,18 @@ def test_scae_vs_golden(name):
     assert n >= 27
     grads = nn_ext.named_reference_grads(model)
     m = 0
+    worst = (0.0, None)
     for k, g in sub(blob, "grad/").items():
         assert grads[k] is not None, k
-        assert_close(grads[k], g, 1e-4, 5e-4, "grad " + k)
+        # the north-star bar on gradients: every entry within 1e-4 of its
+        # tensor's largest entry (tensors that are zero throughout: 1e-7)
+        scale = float(g.abs().max())
+        err = float((grads[k].detach().cpu() - g).abs().max())
+        assert err <= 1e-4 * scale + 1e-7, ("grad " + k, err, scale)
+        worst = max(worst, (err / max(scale, 1e-30), k))
         m += 1
     assert m > 20
+    print(f"{name}: worst gradient entry {worst[0]:.1e} of its tensor's largest ({worst[1]})")
     for k in meta["no_grad_params"]:
         assert grads[k] is None or float(grads[k].abs().sum()) == 0.0, k
 

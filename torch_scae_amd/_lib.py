@@ -157,6 +157,8 @@ SIGNATURES = {
     "scae_render_gmm_sums_bwd_likelihood_f32": [P] * 13,
     "scae_set_encoder_fwd_logprob_f32": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7
                                         + [P] * 6,
+    "scae_set_encoder_fwd_logprob_bf16": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7
+                                         + [P] * 6,
     "scae_set_encoder_bf16_supported": [c_int] * 6,
     "scae_set_encoder_fwd_bf16": [c_int, P, P, P, P, P, P, P, P] + [c_int] * 7 + [P],
     "scae_set_encoder_bwd_bf16": [c_int, P, P, P, P, P, P, P, P, P, P]

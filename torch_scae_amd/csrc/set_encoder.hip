@@ -798,12 +798,13 @@ int trunk_logprob_launch(const scae_st::StArgs &a, int n_trunk, const scae_decod
 
 // The trunk forward with the part decoder's likelihood (tile sums) riding in the same launch
 // where the shapes allow; two launches otherwise.  Same results either way.
-extern "C" int scae_set_encoder_fwd_logprob_f32(
-    int nseg, const float *const *seg_ptr, const int *seg_width, const int *seg_row_stride,
-    const int64_t *seg_batch_stride, const float *presence, const float *params, float *z,
-    float *hsave, int B, int N, int D, int Din, int Dout, int L, int layer_norm,
-    const scae_decoder_desc *d, const float *x, float *tile_sums, float *lse_post,
-    float *lse_prior, void *stream) {
+static int encoder_fwd_logprob(bool bf16, int nseg, const float *const *seg_ptr,
+                               const int *seg_width, const int *seg_row_stride,
+                               const int64_t *seg_batch_stride, const float *presence,
+                               const float *params, float *z, float *hsave, int B, int N, int D,
+                               int Din, int Dout, int L, int layer_norm,
+                               const scae_decoder_desc *d, const float *x, float *tile_sums,
+                               float *lse_post, float *lse_prior, void *stream) {
   SCAE_REQUIRE(d && x && tile_sums && lse_post && lse_prior && z && hsave);
   StArgs a{};
   int rc = fill_args(a, nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride, nullptr,
@@ -811,16 +812,38 @@ extern "C" int scae_set_encoder_fwd_logprob_f32(
   if (rc) return rc;
   a.z = z;
   a.hsave = hsave;
+  a.bf16_attention = bf16;
   const char *e = getenv("SCAE_FUSE_TRUNK_LOGPROB");
   if (!(e && *e == '0') && use_wave(a, D) && scae_fused::trunk_logprob_supported(a, D, d) &&
       scae_render_gmm_logprob_tiles(d) > 0)
     return scae_fused::trunk_logprob_launch(a, scae_set_encoder_grid(B), d, x, tile_sums,
                                             lse_post, lse_prior, (hipStream_t)stream);
-  rc = scae_set_encoder_fwd_f32(nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride,
-                                presence, params, z, hsave, B, N, D, Din, Dout, L, layer_norm,
-                                stream);
+  rc = (bf16 ? scae_set_encoder_fwd_bf16 : scae_set_encoder_fwd_f32)(
+      nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride, presence, params, z, hsave, B,
+      N, D, Din, Dout, L, layer_norm, stream);
   if (rc) return rc;
   return scae_render_gmm_logprob_sums_fwd_f32(d, x, tile_sums, lse_post, lse_prior, stream);
+}
+extern "C" int scae_set_encoder_fwd_logprob_f32(
+    int nseg, const float *const *seg_ptr, const int *seg_width, const int *seg_row_stride,
+    const int64_t *seg_batch_stride, const float *presence, const float *params, float *z,
+    float *hsave, int B, int N, int D, int Din, int Dout, int L, int layer_norm,
+    const scae_decoder_desc *d, const float *x, float *tile_sums, float *lse_post,
+    float *lse_prior, void *stream) {
+  return encoder_fwd_logprob(false, nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride,
+                             presence, params, z, hsave, B, N, D, Din, Dout, L, layer_norm, d, x,
+                             tile_sums, lse_post, lse_prior, stream);
+}
+// ... with the bf16 attention products of scae_set_encoder_fwd_bf16 (BASELINE configs[2])
+extern "C" int scae_set_encoder_fwd_logprob_bf16(
+    int nseg, const float *const *seg_ptr, const int *seg_width, const int *seg_row_stride,
+    const int64_t *seg_batch_stride, const float *presence, const float *params, float *z,
+    float *hsave, int B, int N, int D, int Din, int Dout, int L, int layer_norm,
+    const scae_decoder_desc *d, const float *x, float *tile_sums, float *lse_post,
+    float *lse_prior, void *stream) {
+  return encoder_fwd_logprob(true, nseg, seg_ptr, seg_width, seg_row_stride, seg_batch_stride,
+                             presence, params, z, hsave, B, N, D, Din, Dout, L, layer_norm, d, x,
+                             tile_sums, lse_post, lse_prior, stream);
 }
 
 namespace {

@@ -38,7 +38,7 @@ extern "C" int scae_debug_tl_prof(unsigned long long *out, int n) {
 #endif
 
 namespace {
-template <int NT, int C>
+template <int NT, int C, bool BF>
 __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
     scae_st::StArgs a, int n_trunk, scae_decoder_desc d, const float *__restrict__ x,
     float *__restrict__ lse_post, float *__restrict__ lse_prior, int ppb, int tiles,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
   TL_STAMP(0);
   if ((int)blockIdx.x < n_trunk) {   // (workgroup-uniform)
     if (threadIdx.x >= 64 * NT) return;   // whole waves
-    scae_st::stw_fwd_body<NT, false, true>(a, smem, blockIdx.x, n_trunk);
+    scae_st::stw_fwd_body<NT, BF, true>(a, smem, blockIdx.x, n_trunk);
     TL_STAMP(1);
     return;
   }
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(1024) void trunk_logprob_kernel(
   TL_STAMP(1);
 }
 
-template <int NT, int C>
+template <int NT, int C, bool BF>
 int launch(const scae_st::StArgs &a, int n_trunk, const scae_decoder_desc *d,
            const scae_k1::LpTiling &t, const float *x, float *tile_sums, float *lse_post,
            float *lse_prior, hipStream_t st) {
@@ -66,23 +66,27 @@ int launch(const scae_st::StArgs &a, int n_trunk, const scae_decoder_desc *d,
   const size_t lds = lds_t > lds_l ? lds_t : lds_l;
   if (lds > 160 * 1024) return SCAE_ERR_UNSUPPORTED;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trunk_logprob_kernel<NT, C>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trunk_logprob_kernel<NT, C, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const int threads = t.ppb > 64 * NT ? t.ppb : 64 * NT;
-  hipLaunchKernelGGL((trunk_logprob_kernel<NT, C>), dim3(n_trunk + t.tiles * d->B), dim3(threads),
+  hipLaunchKernelGGL((trunk_logprob_kernel<NT, C, BF>), dim3(n_trunk + t.tiles * d->B), dim3(threads),
                      lds, st, a, n_trunk, *d, x, lse_post, lse_prior, t.ppb, t.tiles, tile_sums);
   return scae_launch_status();
 }
 }  // namespace
 
 namespace scae_fused {
-// true when the shared launch covers this pair of problems (fp32 trunk on the matrix-core
-// kernels, wave-form likelihood with 1 or 3 channels, the likelihood's workgroup at least as
+// true when the shared launch covers this pair of problems (the trunk on the matrix-core
+// kernels -- fp32 or bf16 attention products --, wave-form likelihood with 1 or 3 channels, the likelihood's workgroup at least as
 // wide as the trunk's)
 bool trunk_logprob_supported(const scae_st::StArgs &a, int Dh, const scae_decoder_desc *d) {
-  if (!scae_st::wave_supported(a, Dh) || a.bf16_attention) return false;
+  if (!scae_st::wave_supported(a, Dh)) return false;   // (fp32 and bf16 attention products alike)
+  // Sharing pays while the whole grid is resident at once: at B = 1024 (cfg-3) the shared
+  // launch took 226 us against 36 + 145 apart (profiles/r04, the likelihood's 7000 workgroups
+  // at the trunk's register / LDS allocation)
+  if (d->B > 512) return false;
   if (d->C != 1 && d->C != 3) return false;
   const scae_k1::LpTiling t = scae_k1::lp_tiling(d);
   const int nt = (a.N + 15) / 16;
@@ -94,9 +98,15 @@ int trunk_logprob_launch(const scae_st::StArgs &a, int n_trunk, const scae_decod
                          hipStream_t st) {
   const scae_k1::LpTiling t = scae_k1::lp_tiling(d);
   const int nt = (a.N + 15) / 16;
-#define SCAE_TL(NTV)                                                                        \
-  return d->C == 1 ? launch<NTV, 1>(a, n_trunk, d, t, x, tile_sums, lse_post, lse_prior, st) \
-                   : launch<NTV, 3>(a, n_trunk, d, t, x, tile_sums, lse_post, lse_prior, st)
+#define SCAE_TL2(NTV, BFV)                                                                        \
+  return d->C == 1 ? launch<NTV, 1, BFV>(a, n_trunk, d, t, x, tile_sums, lse_post, lse_prior, st) \
+                   : launch<NTV, 3, BFV>(a, n_trunk, d, t, x, tile_sums, lse_post, lse_prior, st)
+#define SCAE_TL(NTV)                 \
+  if (a.bf16_attention) {            \
+    SCAE_TL2(NTV, true);             \
+  } else {                           \
+    SCAE_TL2(NTV, false);            \
+  }
   switch (nt) {
     case 1: SCAE_TL(1);
     case 2: SCAE_TL(2);
@@ -104,5 +114,6 @@ int trunk_logprob_launch(const scae_st::StArgs &a, int n_trunk, const scae_decod
     default: SCAE_TL(4);
   }
 #undef SCAE_TL
+#undef SCAE_TL2
 }
 }  // namespace scae_fused

@@ -701,10 +701,12 @@ class _SetEncoder(torch.autograd.Function):
         ctx.bf16 = bool(_bf16() and lib.scae_set_encoder_bf16_supported(
             N, D, Din, Dout, L, int(layer_norm)))
         rider = ctx.plan.rider
-        if rider is not None and not rider.launched and not ctx.bf16 \
+        if rider is not None and not rider.launched \
                 and rider.x.device == packed.device:
-            # the part decoder's likelihood rides in this launch
-            _lib.call("scae_set_encoder_fwd_logprob_f32", len(segs), ptrs,
+            # the part decoder's likelihood rides in this launch (where the
+            # launcher finds that it pays; two launches otherwise)
+            _lib.call("scae_set_encoder_fwd_logprob_bf16" if ctx.bf16 else
+                      "scae_set_encoder_fwd_logprob_f32", len(segs), ptrs,
                       widths, rs, bs, _p(presence), _p(packed), _p(z),
                       _p(hsave), B, N, D, Din, Dout, L, int(layer_norm),
                       ctypes.byref(rider.desc), _p(rider.x), _p(rider.sums),
