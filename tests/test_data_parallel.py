@@ -243,3 +243,94 @@ def test_two_rank_bucketed_all_reduce_on_scae_layout():
             expect[off:off + v.numel()] = v.reshape(-1)
     assert torch.allclose(g0, expect, atol=1e-6)
     assert 0 < n_front < g0.numel()
+
+
+CFG2 = dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24, n_obj_caps=24,
+            scae_params=dict(reconstruct_alternatives=False))
+
+
+def _cfg2_step_worker(rank, world, port, out):
+    """TrainStep's OWN two-bucket schedule (``TrainStep._run``: part A, bucket
+    0 in flight while part B runs, bucket 1, both waited for, fused RMSprop)
+    on the real flat layout of BASELINE.json configs[1] -- 2.4 M parameters,
+    228 tensors, the decoders' block in front -- with stand-ins for the two
+    halves of the backward (no GPU here)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from torch_scae_amd import factory
+    from torch_scae_amd.train_step import EARLY_PREFIXES, TrainStep
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = factory.make_scae(CFG2)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.125 * rank)          # broadcast_parameters has to undo this
+    step = TrainStep(model, 128, CFG2["image_shape"], use_graph=False,
+                     lr=1e-3, collective_mode="2 buckets")
+    assert step.collective and step.split and step.world == world
+    flat = step.flat
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    names = [by_id[id(p)] for p in flat.params]
+    lo0, hi0 = flat.block(0)
+    lo1, hi1 = flat.block(1)
+    assert (lo0, hi0, hi1) == (0, flat.front_count, len(flat.params)) and lo1 == hi0
+    assert all(n.startswith(EARLY_PREFIXES) for n in names[:hi0])
+    assert not any(n.startswith(EARLY_PREFIXES) for n in names[hi0:])
+    order, wants = [], {}
+
+    def half(which):
+        lo, hi = flat.block(which)
+        g = torch.Generator().manual_seed(100 * rank + which)
+
+        def run():
+            if which == 0:
+                flat.clear_grads()
+            for n, p in zip(names[lo:hi], flat.params[lo:hi]):
+                if n.endswith("dummy_vote") or n.startswith("posterior_classifier"):
+                    continue                       # no gradient in this configuration
+                v = p._scae_grad_slot.take()
+                v.copy_(torch.randn(p.shape, generator=g))
+                p.grad = v
+                wants[n] = v.clone()
+            flat.gather_grads(which)
+            order.append(("part", which))
+        return run
+
+    reduce_real = step._reduce
+
+    def reduce_spy(which=None, async_op=False):
+        order.append(("reduce", which))
+        return reduce_real(which, async_op=async_op)
+    step._reduce = reduce_spy
+    before = flat.flat_param.clone()
+    step._run(half(0), half(1))
+    step.opt.step(grad_scale=1.0 / world)
+    assert order == [("part", 0), ("reduce", 0), ("part", 1), ("reduce", 1)], order
+    out[rank] = dict(names=names, offsets=list(flat.offsets), n_front=flat.n_front,
+                     numel=flat.numel, wants=wants, grads=flat.flat_grad.clone(),
+                     before=before, after=flat.flat_param.clone())
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_step_bucket_schedule_on_cfg2_layout():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cfg2_step_worker, args=(world, _free_port(), out), nprocs=world,
+             join=True)
+    a, b = out[0], out[1]
+    # BASELINE.json configs[1]: 2 414 879 parameters (SURVEY.md Appendix A); the first
+    # bucket -- the two decoders and the classifier heads -- is two thirds of the bytes
+    assert 2414879 <= a["numel"] <= 2414879 + 4 * len(a["names"])
+    assert 0.6 < a["n_front"] / a["numel"] < 0.72
+    assert torch.equal(a["before"], b["before"])          # rank 0's weights everywhere
+    assert torch.equal(a["grads"], b["grads"]) and torch.equal(a["after"], b["after"])
+    expect = torch.zeros_like(a["grads"])
+    for n, off in zip(a["names"], a["offsets"]):
+        if n in a["wants"]:
+            v = a["wants"][n] + b["wants"][n]
+            expect[off:off + v.numel()] = v.reshape(-1)
+    assert torch.allclose(a["grads"], expect, atol=1e-6)
+    assert float((a["after"] - a["before"]).abs().max()) > 0
