@@ -561,3 +561,27 @@ def test_likelihood_riding_in_the_trunk_launch_changes_nothing():
     assert l0 == l1, (l0, l1)
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_recorded_launch_list_equals_graph_replay_bitwise():
+    """``TrainStep(replay="launches")``: the captured step re-issued launch by launch from
+    the recorded C-ABI calls (torch_scae_amd/_lib.py recorder) instead of as a HIP-graph
+    replay -- the same launches, so loss, parameters and optimiser state after three steps
+    must agree bit for bit with the graph's (cfg-2, B = 128, noise on)."""
+    cfg, B, sd, g = full_size_params("cfg2")
+    images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
+    labels = torch.randint(0, cfg["n_classes"], (3, B), generator=g).cuda()
+    out = []
+    for mode in ("graph", "launches"):
+        model, step = build_step(cfg, B, sd, replay=mode)
+        losses = []
+        for i in range(3):
+            losses.append(float(step(images[i], labels[i])))
+        torch.cuda.synchronize()
+        assert step.graph is not None and len(step._launches) >= 15
+        out.append((losses, step.flat.flat_param.clone(), step.opt.square_avg.clone(),
+                    step.opt.buf.clone(), step.flat.flat_grad.clone()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for a, b, what in zip(out[0][1:], out[1][1:], ("param", "square_avg", "buf", "grad")):
+        assert torch.equal(a, b), what
+    assert float(out[0][4].abs().max()) > 0

@@ -306,8 +306,60 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_char_p if name == "scae_error_string" else (
             c_int64 if name == "scae_loss_tail_workspace_floats" else c_int)
+        if argtypes and argtypes[-1] is P:      # a launcher: (..., void *stream)
+            setattr(lib, name, _recording(fn))
     _lib = lib
     return lib
+
+
+# Launch recording (train_step.TrainStep(replay="launches")): while a recorder is installed
+# every successful launcher call is kept as (function, arguments); the list IS the step -- the
+# same launches a captured HIP graph holds -- and can be re-issued on any stream without the
+# Python above the C ABI.  The arguments keep what they point to alive (device buffers of the
+# capture's private pool are owned by the graph object).
+_RECORDER = None
+
+
+def _recording(fn):
+    def launcher(*args):
+        rc = fn(*args)
+        if _RECORDER is not None and rc == 0:
+            # arguments converted ONCE to the C types of the prototype (a replay then only
+            # passes ready ctypes objects: the per-call conversion of ~20 Python ints / floats
+            # per launcher was most of a replay's host time)
+            conv = []
+            for t, a in zip(fn.argtypes, args):
+                if a is None or isinstance(a, (int, float)):
+                    a = t(a) if a is not None else t()
+                conv.append(a)
+            _RECORDER.append((fn, tuple(conv[:-1]), args))
+        return rc
+    launcher.__name__ = getattr(fn, "__name__", "launcher")
+    return launcher
+
+
+class recorder:
+    """``with _lib.recorder() as launches:`` -- collects the launcher calls made inside."""
+
+    def __enter__(self):
+        global _RECORDER
+        self.prev, self.launches = _RECORDER, []
+        _RECORDER = self.launches
+        return self.launches
+
+    def __exit__(self, *exc):
+        global _RECORDER
+        _RECORDER = self.prev
+        return False
+
+
+def replay(launches, stream):
+    """Re-issue recorded launches on ``stream`` (a ``c_void_p`` handle): every launcher's
+    last argument is its stream."""
+    for fn, cargs, _keep in launches:
+        rc = fn(*cargs, stream)
+        if rc != 0:
+            check(rc, getattr(fn, "__name__", "launch"))
 
 
 ERR_UNSUPPORTED = -2     # SCAE_ERR_UNSUPPORTED

@@ -1041,6 +1041,14 @@ using PipeC2 = pipe::KK<32, 64, 2, SCAE_PIPE_NS>;    // 2 x 2 (columns x k halve
 using PipeC3 = pipe::KK<64, 64, 2, SCAE_PIPE_NS>;    // 2 x 2, 64 rows; 16 KiB
 // weight gradient: 2 x 2 waves x (32 x 32)
 using PipeW = pipe::SS<64, 64, SCAE_PIPE_WBK, SCAE_PIPE_NS>;
+// ... with 16-pixel chunks: a 24 KiB ring instead of 48, so that the pair launches of the small
+// layers hold more than three workgroups per CU (their data-gradient tiles need 18 KiB and
+// 60-114 registers).  B = 128: layer 4 31.7 -> 28.9 us, layer 3 47.4 -> 46.1, layer 2 +0.4;
+// at B = 1024 the 32-pixel chunks win by 7 % (tools/conv_multi_probe.py, round 5).
+using PipeW16 = pipe::SS<64, 64, 16, SCAE_PIPE_NS>;
+#ifndef SCAE_WGRAD_SHORT_CHUNK_PIXELS
+#define SCAE_WGRAD_SHORT_CHUNK_PIXELS 8192   // layers with fewer output pixels take PipeW16
+#endif
 
 // shape for an (M rows) x (N columns) k-contiguous problem; an environment variable
 // (read per call; tuning aid) overrides: -1 = first-generation kernels
@@ -1415,23 +1423,27 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
   if (!(pe && atoi(pe) < 0)) {   // second-generation weight-gradient tiles (64 x 64)
     const PairGrid mg{d.gx * d.ny, d.gx, Cin / 64, Cout / 64};
     const dim3 mgrid(mg.nd + mg.wx * mg.wy * 9 * p.splits);
-#define SCAE_PAIR_MIXED(DM)                                                                  \
-  hipLaunchKernelGGL((conv_bwd_pair_mixed_kernel<DM, PipeW>), mgrid, dim3(NT), 0, st, dpre, wd, \
-                     in, din, in, partial, g, d.pl, p.splits, mg)
+    const bool w16 = (long)B * g.OH * g.OW < SCAE_WGRAD_SHORT_CHUNK_PIXELS;
+#define SCAE_PAIR_MIXED(DM, TW)                                                              \
+  hipLaunchKernelGGL((conv_bwd_pair_mixed_kernel<DM, TW>), mgrid, dim3(NT), 0, st, dpre, wd, in, \
+                     din, in, partial, g, d.pl, p.splits, mg)
+#define SCAE_PAIR_MIXED_FOLD(DM, TW)                                                          \
+  hipLaunchKernelGGL((conv_bwd_pair_mixed_rider_kernel<DM, TW>), rgrid, dim3(NT), 0, st, dpre, wd, \
+                     in, din, in, partial, g, d.pl, p.splits, mg, *rider)
+#define SCAE_PAIR_BY_MODE(LAUNCH, TW) \
+  if (d.mode == 0) LAUNCH(0, TW);     \
+  else if (d.mode == 2) LAUNCH(2, TW); \
+  else LAUNCH(1, TW)
     if (rider) {
       const dim3 rgrid(mgrid.x + rider->n);
-#define SCAE_PAIR_MIXED_FOLD(DM)                                                              \
-  hipLaunchKernelGGL((conv_bwd_pair_mixed_rider_kernel<DM, PipeW>), rgrid, dim3(NT), 0, st, dpre, \
-                     wd, in, din, in, partial, g, d.pl, p.splits, mg, *rider)
-      if (d.mode == 0) SCAE_PAIR_MIXED_FOLD(0);
-      else if (d.mode == 2) SCAE_PAIR_MIXED_FOLD(2);
-      else SCAE_PAIR_MIXED_FOLD(1);
-#undef SCAE_PAIR_MIXED_FOLD
+      if (w16) { SCAE_PAIR_BY_MODE(SCAE_PAIR_MIXED_FOLD, PipeW16); }
+      else { SCAE_PAIR_BY_MODE(SCAE_PAIR_MIXED_FOLD, PipeW); }
       return scae_launch_status();
     }
-    if (d.mode == 0) SCAE_PAIR_MIXED(0);
-    else if (d.mode == 2) SCAE_PAIR_MIXED(2);
-    else SCAE_PAIR_MIXED(1);
+    if (w16) { SCAE_PAIR_BY_MODE(SCAE_PAIR_MIXED, PipeW16); }
+    else { SCAE_PAIR_BY_MODE(SCAE_PAIR_MIXED, PipeW); }
+#undef SCAE_PAIR_BY_MODE
+#undef SCAE_PAIR_MIXED_FOLD
 #undef SCAE_PAIR_MIXED
     return scae_launch_status();
   }

@@ -39,15 +39,15 @@ __global__ __launch_bounds__(NT) void sum_rows_kernel(Jobs jobs) {
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (j < cols) {  // eight loads in flight per thread: the kernel is latency bound
     const long per = (rows + PY - 1) / PY, r0 = py * per, r1 = min(rows, r0 + per);
-    long r = r0;
-    for (; r + 8 <= r1; r += 8) {
+    // (the tail batch too: a row part of 5 or 6 rows -- the 22 split partials of a convolution
+    // weight gradient over 4 parts -- used to be a chain of dependent round trips)
+    for (long r = r0; r < r1; r += 8) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(r + u) * cols + j];
+      for (int u = 0; u < 8; ++u) v[u] = r + u < r1 ? src[(r + u) * cols + j] : 0.f;
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] += v[u];
     }
-    for (; r < r1; ++r) acc[0] += src[r * cols + j];
   }
   red[py * CX + cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();

@@ -306,6 +306,9 @@ def _launch_sum_units(units):
         for a, (partial, rows, cols, segp, n, _keep) in zip(arr, chunk):
             a.src, a.rows, a.cols, a.segments, a.n_segments = \
                 partial.data_ptr(), rows, cols, segp, n
+        # (the job array points into the segment arrays: whoever keeps it -- a recorded
+        # launch list, _lib.recorder -- keeps them and the partial matrices too)
+        arr._keep = [(unit[0], unit[-1]) for unit in chunk]
         _lib.call("scae_sum_rows_multi_f32", arr, len(chunk),
                   _stream(chunk[0][0]))
 

@@ -53,7 +53,8 @@ class TrainStep:
                  optimizer=True, momentum=0.9, weight_decay=0.0,
                  lr_decay_rate=0.997, autocast_dtype=None,
                  force_collective=False, overlap=True, lazy_render=True,
-                 prologue=True, fuse_kernels=True, collective_mode=None):
+                 prologue=True, fuse_kernels=True, collective_mode=None,
+                 replay="graph"):
         self.model = model
         self.device = next(model.parameters()).device
         self.world = world()[1]
@@ -125,6 +126,15 @@ class TrainStep:
         self.loss = torch.zeros((), device=self.device)
         self._one = torch.ones((), device=self.device)   # d loss / d loss
         self.use_graph = use_graph
+        # how a captured step is re-issued: "graph" (hipGraphLaunch: ~10 us of host time and
+        # ~8.6 us of device time between two replays, tools/graph_gap_probe.py) or "launches"
+        # (the recorded C-ABI launches, one by one on the current stream: no per-replay
+        # device cost -- 4-5 us per step at cfg-2 -- for ~350 us of host time per step,
+        # tools/launch_list_probe.py; single-rank steps only)
+        if replay not in ("graph", "launches"):
+            raise ValueError("replay must be 'graph' or 'launches'")
+        self.replay = replay
+        self._launches = None
         # independent kernels of the step sharing launches (ops.step_fusion:
         # the reconstruction likelihood rides with the object encoder's trunk)
         self.fuse_kernels = fuse_kernels
@@ -253,12 +263,17 @@ class TrainStep:
         # then) the check is narrowed to the capturing thread.
         mode = "thread_local" if dist.is_available() and dist.is_initialized() \
             else "global"
-        with torch.cuda.graph(self.graph, stream=s, capture_error_mode=mode):
+        from . import _lib
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode=mode), \
+                _lib.recorder() as launches:
             self._part_a()
             if not self.split:
                 self._part_b()
                 if not self.collective or self.in_graph_collective:
                     self._finish()
+        # the step as a plain list of C-ABI launches (the graph holds exactly these when no
+        # collective is captured with them): replay_launches()
+        self._launches = launches if not self.collective else None
         if self.split:
             # part B allocates from part A's pool: the tensors A left for it
             # (saved activations, the cut gradients) are alive across the two
@@ -269,6 +284,14 @@ class TrainStep:
                                   capture_error_mode=mode):
                 self._part_b()
         self._capturing = False
+
+    def replay_launches(self):
+        """The captured step re-issued launch by launch on the current stream instead of as a
+        graph replay (single-rank steps): no per-replay graph cost on the device."""
+        import ctypes
+        from . import _lib
+        _lib.replay(self._launches, ctypes.c_void_p(
+            torch.cuda.current_stream(self.device).cuda_stream))
 
     def capture(self):
         """Build the step's HIP graph(s) now instead of at the first call
@@ -360,7 +383,10 @@ class TrainStep:
                 if self.opt is not None:
                     self.opt.step(grad_scale=1.0 / self.world)
             else:
-                self.graph.replay()
+                if self.replay == "launches" and self._launches is not None:
+                    self.replay_launches()
+                else:
+                    self.graph.replay()
                 if self.collective and not self.in_graph_collective:
                     self._finish()
         elif self.split:
