@@ -916,6 +916,15 @@ def main():
     timing["per_block"] = [
         dict(ms=round(1e3 * t / args.steps, 4), capsules_after=st)
         for t, st in zip(blocks, per_block)]
+    # the same captured step re-issued launch by launch (TrainStep(replay="launches"): no
+    # per-replay graph cost on the device, ~350 us of host time per step instead of ~10)
+    if not collective and step.use_graph and getattr(step, "_launches", None):
+        step.replay = "launches"
+        t3 = timing_summary(timed_blocks(
+            step, images, labels, args.steps, args.warmup, max(1, min(7, args.blocks)),
+            barrier, reduce_max, before_block=before_block), args.steps)
+        step.replay = "graph"
+        timing["replay_as_launch_list_ms"] = t3["median_ms"]
     final_loss = float(step.loss)
     final_state = capsule_state(step.model, images[0])
     # "optimizer step reported separately" (the reference's step

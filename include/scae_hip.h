@@ -643,6 +643,16 @@ int scae_rmsprop_step_f32(float *param, const float *grad, float *square_avg, fl
                           int64_t n, float lr, const float *lr_dev, float alpha, float eps,
                           float momentum, float weight_decay, float grad_scale, void *stream);
 
+/* A training step's last column sums (scae_sum_rows_multi_f32 over `jobs`, whose destinations
+ * are parameter-gradient slots of `grad`) and the RMSprop pass above as ONE launch: the sum
+ * workgroups apply the update of the elements they produce, the streaming workgroups skip
+ * them; bit for bit the two launches' results.  No weight decay in this form. */
+struct scae_sum_job;
+int scae_rmsprop_sums_step_f32(float *param, float *grad, float *square_avg, float *buf,
+                               int64_t n, float lr, const float *lr_dev, float alpha, float eps,
+                               float momentum, float grad_scale, const struct scae_sum_job *jobs,
+                               int n_jobs, void *stream);
+
 /* The batch hand-over of a training step (base_experiment.py:109-112): n_image
  * floats and n_label int64 labels (device memory) into the step's resident
  * input buffers, in one launch. */

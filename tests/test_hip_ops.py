@@ -2788,3 +2788,56 @@ def test_conv_resident_forward_rejects_what_it_cannot_hold():
     assert lib.scae_conv3x3_fwd_res_supported(128, 19, 19, 128, 128, 2) == 0   # 185 KB of pixels
     assert lib.scae_conv3x3_fwd_res_supported(128, 7, 7, 64, 128, 1) == 0      # Cin % 128
     assert lib.scae_conv3x3_fwd_res_supported(128, 7, 7, 128, 48, 1) == 0      # Cout % 32
+
+
+def test_sums_riding_in_the_optimizer_launch_equal_two_launches_bitwise():
+    """scae_rmsprop_sums_step_f32: a step's last column sums (plain, periodic and
+    transposed windows into slots of the flat gradient buffer) as the head of the
+    RMSprop launch -- bit for bit scae_sum_rows_multi_f32 + scae_rmsprop_step_f32, on
+    every one of the four flat buffers, with slots that start off 16-byte boundaries."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    n = 20011
+    P = ctypes.c_void_p
+    st = P(torch.cuda.current_stream().cuda_stream)
+
+    def fresh():
+        gg = torch.Generator().manual_seed(5)
+        return [torch.randn(n, generator=gg).cuda() for _ in range(2)] + \
+            [torch.rand(n, generator=gg).cuda(), torch.randn(n, generator=gg).cuda() * .1]
+    partials = [torch.randn(22, 9 * 40, generator=g).cuda(),     # transposed (n x W)
+                torch.randn(128, 5 * 12, generator=g).cuda(),    # periodic windows
+                torch.randn(7, 333, generator=g).cuda(),         # plain, two outputs
+                torch.randn(300, 6, generator=g).cuda()]         # tall and skinny
+    # (offset into the flat gradient, segments) per job
+    layout = [(1, [(0, 360, -40, 360)]),
+              (3001, [(0, 5, 12, 50), (5, 12, 12, 70)]),
+              (7002, [(0, 100, 0, 100), (120, 333, 0, 213)]),
+              (19990, [(0, 6, 0, 6)])]
+    results = []
+    for fused in (False, True):
+        param, grad, sq, buf = fresh()
+        keep, jobs = [], (_lib.SumJob * len(partials))()
+        for job, part, (off, segs) in zip(jobs, partials, layout):
+            arr = (_lib.SumSegment * len(segs))()
+            pos = off
+            for a, (b, e, per, length) in zip(arr, segs):
+                a.dst, a.begin, a.end, a.period = grad.data_ptr() + 4 * pos, b, e, per
+                pos += length
+            keep.append(arr)
+            job.src, job.rows, job.cols = part.data_ptr(), part.shape[0], part.shape[1]
+            job.segments, job.n_segments = arr, len(segs)
+        args = (P(param.data_ptr()), P(grad.data_ptr()), P(sq.data_ptr()), P(buf.data_ptr()),
+                n, 1e-3, None, 0.99, 1e-4, 0.9)
+        if fused:
+            _lib.call("scae_rmsprop_sums_step_f32", *args, 1.0, jobs, len(partials), st)
+        else:
+            _lib.call("scae_sum_rows_multi_f32", jobs, len(partials), st)
+            _lib.call("scae_rmsprop_step_f32", *args, 0.0, 1.0, st)
+        torch.cuda.synchronize()
+        results.append([t.clone() for t in (param, grad, sq, buf)])
+    for a, b, what in zip(results[0], results[1], ("param", "grad", "square_avg", "buf")):
+        bad = (a != b).nonzero().flatten()
+        assert bad.numel() == 0, (what, bad[:8].tolist(), bad.numel())
+    assert float((results[0][0] - fresh()[0]).abs().max()) > 0

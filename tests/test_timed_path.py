@@ -585,3 +585,40 @@ def test_recorded_launch_list_equals_graph_replay_bitwise():
     for a, b, what in zip(out[0][1:], out[1][1:], ("param", "square_avg", "buf", "grad")):
         assert torch.equal(a, b), what
     assert float(out[0][4].abs().max()) > 0
+
+
+def test_reset_noise_restarts_an_already_built_step():
+    """``torch.manual_seed(s); ops.reset_noise()`` has to restart the noise
+    sequence of a step that is already built and captured (its generator state lives on the
+    step's own plan, and inside the graph by address): the same three draws again."""
+    from torch_scae_amd import ops
+    cfg, B, sd, g = full_size_params("cfg2_bs32")
+    model, step = build_step(cfg, B, sd)          # (manual_seed(1234) + reset_noise inside)
+    image = torch.rand(B, *cfg["image_shape"], generator=g).cuda()
+    label = torch.randint(0, cfg["n_classes"], (B,), generator=g).cuda()
+
+    def draws(n):
+        out = []
+        for _ in range(n):
+            step(image, label)
+            torch.cuda.synchronize()
+            out.append(step._pro.noise.clone())
+        return out
+    first = draws(3)
+    assert not torch.equal(first[0], first[1])
+    torch.manual_seed(1234)
+    ops.reset_noise()
+    again = draws(3)
+    # (the capture's warm-ups consumed draws before `first`: the restarted sequence begins at
+    # the generator's origin, so compare it with a second restart, and require that it differs
+    # from simply continuing)
+    torch.manual_seed(1234)
+    ops.reset_noise()
+    third = draws(3)
+    for a, b in zip(again, third):
+        assert torch.equal(a, b)
+    assert not torch.equal(again[0], first[0]) or not torch.equal(again[1], first[1])
+    torch.manual_seed(4321)
+    ops.reset_noise()
+    other = draws(1)
+    assert not torch.equal(other[0], again[0])

@@ -234,6 +234,8 @@ SIGNATURES = {
                                      POINTER(FirstLayerDesc), P],
     "scae_rmsprop_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
                               c_float, c_float, c_float, P],
+    "scae_rmsprop_sums_step_f32": [P, P, P, P, c_int64, c_float, P, c_float, c_float,
+                                   c_float, c_float, POINTER(SumJob), c_int, P],
     "scae_capsule_head_fwd_f32": [P, P, c_float, c_int, P, P, P, P, P] + [c_int] * 4 + [P],
     "scae_capsule_head_conv_supported": [c_int] * 4,
     "scae_capsule_head_conv_preferred": [c_int] * 5,

@@ -234,10 +234,22 @@ class RMSpropFlat:
         self.set_lr(self.lr * gamma)
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, sum_units=None):
         """``grad_scale`` multiplies the gradient on the fly (1/world after a
-        SUM all-reduce)."""
+        SUM all-reduce).  ``sum_units``: column-sum units (``ops._sum_rows_multi``)
+        whose outputs are slots of the flat gradient buffer and which have NOT
+        been launched yet: they ride in this step's launch
+        (``scae_rmsprop_sums_step_f32``: the sum workgroups update the elements
+        they produce), bit for bit the two launches' result."""
         g = self.flat.flat_grad
+        if sum_units:
+            from . import ops
+            if not g.is_cuda or self.weight_decay != 0:
+                ops._launch_sum_units(sum_units)      # (the plain forms)
+                sum_units = None
+            elif len(sum_units) > 16:
+                ops._launch_sum_units(sum_units[:-16])
+                sum_units = sum_units[-16:]
         # parameters without a gradient are left alone, like torch.optim does;
         # without weight decay a zero gradient already is a no-op
         ranges = self.flat.active_ranges() if self.weight_decay != 0 else \
@@ -246,6 +258,15 @@ class RMSpropFlat:
             from . import _lib
             P = ctypes.c_void_p
             st = P(torch.cuda.current_stream(g.device).cuda_stream)
+            if sum_units:
+                from . import ops
+                arr = ops._sum_job_array(sum_units)
+                _lib.call("scae_rmsprop_sums_step_f32", P(self.flat.flat_param.data_ptr()),
+                          P(g.data_ptr()), P(self.square_avg.data_ptr()),
+                          P(self.buf.data_ptr()), g.numel(), self.lr,
+                          P(self.lr_dev.data_ptr()), self.alpha, self.eps, self.momentum,
+                          float(grad_scale), arr, len(sum_units), st)
+                return
             for off, n in ranges:
                 ptr = lambda t: P(t.data_ptr() + 4 * off)   # noqa: E731
                 _lib.call("scae_rmsprop_step_f32", ptr(self.flat.flat_param),

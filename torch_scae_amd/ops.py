@@ -232,10 +232,17 @@ def step_prologue(pro):
 def reset_noise():
     """Restart the device noise generators from ``torch.initial_seed()`` (call
     after ``torch.manual_seed`` to replay a noise sequence; not inside a graph
-    capture).  Every step plan has its own generators: the current one's and
-    the process-wide ones restart."""
-    _plan().noise.clear()
-    step_plan.ambient.noise.clear()
+    capture).  Every step plan has its own generators -- a ``TrainStep`` owns
+    one -- and ALL live plans restart, so ``torch.manual_seed(s);
+    ops.reset_noise()`` replays the sequence of an already built step too.
+    (A step whose graph is captured keeps drawing from its device-resident
+    generator state: that state is re-seeded in place, see ``uniform``.)"""
+    for plan in step_plan.live_plans():
+        for key, (seed, state) in list(plan.noise.items()):
+            # in place: captured graphs and prologues hold this tensor's address
+            fresh = int(torch.initial_seed()) & ((1 << 63) - 1)
+            state.copy_(torch.tensor([fresh, 0, 0], dtype=torch.int64))
+            plan.noise[key] = (fresh, state)
 
 
 def uniform(n, ref):
@@ -299,17 +306,22 @@ def flush_param_sums():
     _plan().flush_sums()
 
 
+def _sum_job_array(chunk):
+    """struct scae_sum_job[len(chunk)] of column-sum units (<= 16)."""
+    arr = (_lib.SumJob * len(chunk))()
+    for a, (partial, rows, cols, segp, n, _keep) in zip(arr, chunk):
+        a.src, a.rows, a.cols, a.segments, a.n_segments = \
+            partial.data_ptr(), rows, cols, segp, n
+    # (the job array points into the segment arrays: whoever keeps it -- a recorded
+    # launch list, _lib.recorder -- keeps them and the partial matrices too)
+    arr._keep = [(unit[0], unit[-1]) for unit in chunk]
+    return arr
+
+
 def _launch_sum_units(units):
     for k in range(0, len(units), _SUMS_PER_LAUNCH):
         chunk = units[k:k + _SUMS_PER_LAUNCH]
-        arr = (_lib.SumJob * len(chunk))()
-        for a, (partial, rows, cols, segp, n, _keep) in zip(arr, chunk):
-            a.src, a.rows, a.cols, a.segments, a.n_segments = \
-                partial.data_ptr(), rows, cols, segp, n
-        # (the job array points into the segment arrays: whoever keeps it -- a recorded
-        # launch list, _lib.recorder -- keeps them and the partial matrices too)
-        arr._keep = [(unit[0], unit[-1]) for unit in chunk]
-        _lib.call("scae_sum_rows_multi_f32", arr, len(chunk),
+        _lib.call("scae_sum_rows_multi_f32", _sum_job_array(chunk), len(chunk),
                   _stream(chunk[0][0]))
 
 

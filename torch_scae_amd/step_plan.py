@@ -24,8 +24,10 @@ node's launch.  This module is the only holder of such parked work.
 import collections
 import contextlib
 import contextvars
+import weakref
 
 ANY = "*"
+_LIVE = weakref.WeakSet()     # every live StepPlan
 
 
 class Ride:
@@ -96,12 +98,18 @@ RIDES = collections.OrderedDict([
 
 class StepPlan:
     def __init__(self, name="step", prologue=None):
+        _LIVE.add(self)
         self.name = name
         self.target = None        # the loss's reconstruction target while fusing
         self.rider = None         # ops.LogProbRider offered to the trunk launch
         self.offers = {}          # kind -> launch offered to an earlier node's launch
         self.parked = {}          # kind -> parked launch (has .launch_alone())
         self.deferred = None      # queued column-sum units while deferring
+        # the step's last column sums ride in the optimiser's launch (train_step.TrainStep
+        # sets this; data_parallel.RMSpropFlat.step(sum_units=...) takes them): the outermost
+        # ``deferring`` exit then HOLDS what is queued instead of launching it
+        self.sums_to_optimizer = False
+        self.held_sums = []
         self.prologue = prologue  # ops.StepPrologue or None
         self.bf16 = False         # configs[2]'s operand precision
         self.noise = {}           # (device, stream) -> (seed, generator state)
@@ -180,6 +188,10 @@ class StepPlan:
             from . import ops
             ops._launch_sum_units(units)
 
+    def take_held_sums(self):
+        units, self.held_sums = self.held_sums, []
+        return units
+
     # -- scopes -------------------------------------------------------------
     @contextlib.contextmanager
     def fusing(self, target):
@@ -215,7 +227,11 @@ class StepPlan:
                 try:
                     if ok:
                         self.flush_scope("deferring")
-                        self.flush_sums()
+                        if self.sums_to_optimizer:
+                            self.held_sums.extend(self.deferred)
+                            del self.deferred[:]
+                        else:
+                            self.flush_sums()
                 finally:
                     self.deferred = None
 
@@ -234,6 +250,12 @@ class StepPlan:
             yield self
         finally:
             self.bf16 = prev
+
+
+def live_plans():
+    """Every StepPlan that is still alive (``ops.reset_noise`` restarts the noise
+    generators of all of them)."""
+    return list(_LIVE)
 
 
 _CURRENT = contextvars.ContextVar("scae_step_plan", default=None)

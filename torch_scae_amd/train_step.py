@@ -111,6 +111,12 @@ class TrainStep:
                                weight_decay=weight_decay) \
             if optimizer else None
         self.lr_decay_rate = lr_decay_rate
+        # the backward's last column sums (parameter gradients only) ride in the optimiser's
+        # launch: one launch less on the step's dependent chain.  Not with a collective (the
+        # all-reduce reads the finished gradient buffer first) nor with weight decay.
+        self.plan.sums_to_optimizer = bool(
+            self.opt is not None and fuse_kernels and not self.collective
+            and weight_decay == 0 and self.device.type == "cuda")
         # torch.bfloat16 (BASELINE.json configs[2]): the GEMM-shaped kernels --
         # K8 convolutions, K7 capsule-MLP / 1x1-conv GEMMs, forward and backward
         # -- take bf16 operands with fp32 accumulation (ops.mfma_bf16); the
@@ -161,8 +167,11 @@ class TrainStep:
     # -- the step in two parts ------------------------------------------------
     def _part_a(self):
         """forward + loss + backward (split: down to the decoders' inputs)."""
-        self.flat.clear_grads()
         plan = self.plan
+        stale = plan.take_held_sums()
+        if stale:     # (a backward nobody followed by the optimiser: a capture's warm-ups)
+            ops._launch_sum_units(stale)
+        self.flat.clear_grads()
         with plan.active(), plan.precision(self.autocast_dtype is not None), \
                 self._lazy(), \
                 plan.fusing(self.image if self.fuse_kernels else None):
@@ -224,7 +233,8 @@ class TrainStep:
         if self.collective:
             self._reduce()
         if self.opt is not None:
-            self.opt.step(grad_scale=1.0 / self.world)
+            self.opt.step(grad_scale=1.0 / self.world,
+                          sum_units=self.plan.take_held_sums())
 
     def _run(self, part_a, part_b):
         """One step from its two parts (graph replays or eager calls)."""
