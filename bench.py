@@ -82,6 +82,9 @@ def parse():
                     help="take the rank-launcher + RCCL process-group path even "
                          "for --gpus 1 (a 1-rank nccl group; proves the N>1 "
                          "plumbing on a 1-GPU box)")
+    ap.add_argument("--watchdog-s", type=float, default=1500.0,
+                    help="a rank process ends itself (exit code 3) when the run takes longer "
+                         "than this; 0: no watchdog")
     ap.add_argument("--blocks", type=int, default=21,
                     help="the K-step timed region is repeated this many times "
                          "back to back (each bracketed by barrier + "
@@ -811,6 +814,23 @@ def main():
         return launch_ranks(args)       # nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ONE JSON line on stdout: libraries that print banners there (RCCL's version block) go to
+    # stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if args.watchdog_s > 0:
+        # a rank that waits for a collective its peers never enter would wait forever: give up
+        # loudly instead (the launcher then ends the other ranks)
+        import threading
+
+        def _give_up():
+            print(f"[bench rank {rank}] watchdog: no result after {args.watchdog_s} s",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        t = threading.Timer(args.watchdog_s, _give_up)
+        t.daemon = True
+        t.start()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -868,7 +888,13 @@ def main():
             return bool(flag.item())
 
         mode = "1 bucket" if args.no_overlap else args.comm_mode
-        which = TrainStep.MODES if mode == "auto" else (mode,)
+        # auto: with real ranks the two schedules that keep RCCL outside the HIP graph -- the
+        # all-reduce captured INSIDE the graph has only ever run on a 1-rank group here, and a
+        # capture that stalls on 8 ranks would cost the whole measurement; --comm-mode
+        # "in graph" (or a 1-rank group) still measures it
+        auto = TrainStep.MODES if world == 1 else tuple(
+            m for m in TrainStep.MODES if m != "in graph")
+        which = auto if mode == "auto" else (mode,)
         modes = probe_modes(make, which + ("off",), images, labels, barrier,
                             reduce_max, agree=agree)
         # per-rank diagnostics on stderr (rank 0's stdout carries the one JSON
@@ -1038,7 +1064,8 @@ def main():
             result["extra_workloads"].append(structured_leg(device))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if collective:
         dist.barrier()
         dist.destroy_process_group()
