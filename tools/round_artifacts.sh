@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/round_artifacts.sh r02 [notests] -- refresh the round's measurement artifacts into
 # gpurun_out/<round>/ (run on the GPU box from the repo root; copy what is to be judged into profiles/<round>/)
-RN=${1:-r04}; R=$PWD; O=$R/gpurun_out/$RN; mkdir -p $O; export TMPDIR=/tmp
+RN=${1:-r05}; R=$PWD; O=$R/gpurun_out/$RN; mkdir -p $O; export TMPDIR=/tmp
 if [ "$2" != "notests" ]; then
   timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "^FAILED|^E  |passed|failed" | tail -12 > $O/pytest_gpu.txt
 fi
@@ -33,4 +33,10 @@ done
 # the rank-launcher + RCCL path on one GPU (1-rank nccl group)
 timeout 600 python bench.py --gpus 1 --force-spawn --steps 100 --no-cpu-baseline --no-roofline 2> /dev/null | grep '^{' > $O/bench_force_spawn.json
 rm -f $O/*_domain_stats.csv
+# upper bound of a multi-layer K8 launch and the image-resident forward (variant library built here)
+[ -f tools/ablibs/libscae_multi.so ] && timeout 300 python tools/conv_multi_probe.py tools/ablibs/libscae_multi.so > $O/conv_multi_probe.txt 2>&1
+[ -f tools/ablibs/libfwd_prof.so ] && timeout 300 python tools/fwd_prof.py tools/ablibs/libfwd_prof.so > $O/fwd_tile_timeline.txt 2>&1
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o gap -- python3 $R/tools/graph_gap_probe.py > /dev/null 2>&1)
+python3 tools/graph_gap_report.py $O/gap_kernel_trace.csv > $O/graph_gap.txt 2>&1; rm -f $O/gap_*.csv
+timeout 300 python tools/launch_list_probe.py > $O/launch_list.txt 2>&1
 ls $O
