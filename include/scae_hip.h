@@ -382,6 +382,9 @@ typedef struct scae_mlp_chain_desc {
   int in_dim, B, G;
   int row_tile; /* batch rows per workgroup: 0 = chosen by the launcher from the shape
                    (the production setting); 16 | 32 force one (tests, measurements) */
+  int bf16;     /* != 0: the layer products on v_mfma_f32_16x16x16_bf16 -- both operands rounded
+                   to bf16 (nearest even) on their way into the matrix core, fp32 accumulate,
+                   fp32 tensors in memory, epilogues unchanged (BASELINE.json configs[2]) */
 } scae_mlp_chain_desc;
 int scae_mlp_chain_max_width(void);
 int scae_mlp_chain_fwd_f32(const scae_mlp_chain_desc *desc, void *stream);
@@ -433,6 +436,9 @@ int scae_gemm_bf16(const float *A, const float *B, float *C, const float *bias,
                    int ldmask, int64_t mask_batch, int64_t asum_batch, int asum_ld, int relu,
                    void *stream);
 int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_desc *second, void *stream);
+/* scae_gemm_multi_f32 on the bf16 tiles when every problem has both sides >= 32 (else the
+ * fp32 tiles, unchanged) */
+int scae_gemm_multi_bf16(const scae_gemm_desc *descs, int n, void *stream);
 /* scae_conv3x3_fwd_f32 (the 32 x 64 second-generation tiles: Cin % 32 == 0, Cout % 64 == 0)
  * with the workgroups of scae_seed_fold_fwd_f32(fold) as the tail of its grid: in a training
  * step the parameter-only folding products hide behind an early, large launch instead of

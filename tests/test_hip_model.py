@@ -771,8 +771,14 @@ def test_cfg3_bf16_operands_vs_fp32_oracle_with_gradients():
     finally:
         ops._lib.call = real
     used = {n for n in calls if n.endswith("_bf16")}
+    # the fusions of the fp32 step stay: the capsule MLPs + votes are the chain launches
+    assert "scae_mlp_chain_votes_fwd_f32" in calls and "scae_mlp_chain_votes_bwd_f32" in calls
+    assert "scae_capsule_votes_bwd_f32" not in calls
     assert used == {"scae_conv3x3_fwd_bf16", "scae_conv3x3_bwd_pair_bf16",
                     "scae_gemm_bf16", "scae_gemm_pair_bf16",
+                    # the capsule MLPs' weight gradients (their forward and data
+                    # gradient: the one-launch chain with its bf16 flag set)
+                    "scae_gemm_multi_bf16",
                     # the attention products of the fused object-encoder trunk
                     "scae_set_encoder_fwd_bf16", "scae_set_encoder_bwd_bf16",
                     # ... and of its output attention

@@ -2658,6 +2658,62 @@ def test_grouped_mlp_bf16_operands_vs_fp64():
         assert _rel_l2(a, b) <= 8e-2, _rel_l2(a, b)
 
 
+@pytest.mark.parametrize("row_tile", [16, 32])
+def test_mlp_chain_bf16_operands_vs_fp32(row_tile, monkeypatch):
+    """K7b inside ``ops.mfma_bf16()`` (BASELINE.json configs[2]): the one-launch
+    chain stays the path -- its layer products take bf16 operands
+    (v_mfma_f32_16x16x16_bf16, rounded at the matrix core, fp32 accumulate,
+    fp32 tensors in memory), the weight-gradient launch runs the bf16 tiles.
+    Same bars as the batched-GEMM form: outputs 1e-2 in relative L2 against
+    the fp32 chain (held to fp64 above), gradients 8e-2 (two ReLU gates whose
+    borderline units bf16's rounding flips)."""
+    from torch_scae_amd import ops
+    monkeypatch.setattr(ops, "_CHAIN_ROW_TILE", row_tile)
+    G, B, Kin, dims = 6, 256, 256, [128, 32, 128, 391]
+    g = torch.Generator().manual_seed(11)
+    layers, K = [], Kin
+    for l, N in enumerate(dims):
+        ones = l == 2
+        w = torch.randn(G, N, K + (1 if ones else 0), generator=g) / K ** 0.5
+        b = None if l >= 2 else torch.randn(G, N, generator=g) * 0.1
+        layers.append((w, b, ones))
+        K = N
+    x = torch.randn(B, G, Kin, generator=g)
+    R = torch.randn(B, G, dims[-1], generator=g)
+
+    def run(bf16):
+        xh = x.cuda().requires_grad_()
+        lh = [(w.cuda().requires_grad_(),
+               None if b is None else b.cuda().requires_grad_(), o)
+              for w, b, o in layers]
+        calls = []
+        real = ops._lib.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        ops._lib.call = spy
+        try:
+            with ops.mfma_bf16(bf16):
+                assert ops.mlp_chain_supported(xh, lh)
+                y = ops.mlp_chain(xh, lh)
+                y.backward(R.cuda() * (y.detach() > 0))
+        finally:
+            ops._lib.call = real
+        grads = [xh.grad] + [w.grad for w, _, _ in lh] + \
+            [b.grad for _, b, _ in lh if b is not None]
+        return y.detach(), grads, calls
+
+    y32, g32, _ = run(False)
+    y16, g16, calls = run(True)
+    assert "scae_mlp_chain_fwd_f32" in calls and "scae_mlp_chain_bwd_f32" in calls
+    assert "scae_gemm_multi_bf16" in calls
+    assert not torch.equal(y16, y32)            # (the flag reaches the kernel)
+    assert _rel_l2(y16, y32) <= 1e-2, _rel_l2(y16, y32)
+    for a, b in zip(g16, g32):
+        assert _rel_l2(a, b) <= 8e-2, _rel_l2(a, b)
+
+
 def test_deferred_sums_with_a_parameter_used_twice():
     """under ``deferred_param_sums`` a column sum may only wait when
     its output is the parameter's own slot AND nobody else contributes to that

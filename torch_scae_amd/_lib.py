@@ -64,7 +64,8 @@ class MlpChainDesc(Structure):
     """struct scae_mlp_chain_desc"""
     _fields_ = [("layer", MlpChainLayer * 4), ("n_layers", c_int), ("in_", P),
                 ("in_gs", c_int64), ("in_bs", c_int64), ("in_dim", c_int),
-                ("B", c_int), ("G", c_int), ("row_tile", c_int)]
+                ("B", c_int), ("G", c_int), ("row_tile", c_int),
+                ("bf16", c_int)]
 
 
 class VotesDesc(Structure):
@@ -195,6 +196,7 @@ SIGNATURES = {
                                               P],
     "scae_gemm_pair_f32": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     "scae_gemm_multi_f32": [POINTER(GemmDesc), c_int, P],
+    "scae_gemm_multi_bf16": [POINTER(GemmDesc), c_int, P],
     "scae_mlp_chain_max_width": [],
     "scae_mlp_chain_fwd_f32": [POINTER(MlpChainDesc), P],
     "scae_mlp_chain_bwd_f32": [POINTER(MlpChainDesc), P],

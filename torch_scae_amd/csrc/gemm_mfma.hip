@@ -258,8 +258,15 @@ int fill_args(GemmArgs &g, const scae_gemm_desc *d) {
   return SCAE_OK;
 }
 
-// the 1-D tile grid of up to four problems; T: 32 (split-K tiles) or 64
-int plan_multi(GemmMulti &p, int &T, const scae_gemm_desc *descs, int n) {
+// the 1-D tile grid of up to four problems; T: 32 (split-K tiles) or 64 -- or, asked for
+// bf16 operands, 128 when every problem is large enough for those tiles (bf16_shape)
+#ifndef SCAE_BF16_MIN_SIDE
+#define SCAE_BF16_MIN_SIDE 32
+#endif
+static bool bf16_shape(int M, int N) {
+  return M >= SCAE_BF16_MIN_SIDE && N >= SCAE_BF16_MIN_SIDE;
+}
+int plan_multi(GemmMulti &p, int &T, const scae_gemm_desc *descs, int n, bool bf16 = false) {
   if (!descs || n < 1 || n > 4) return SCAE_ERR_BAD_ARG;
   p = GemmMulti{};
   p.n = n;
@@ -271,6 +278,11 @@ int plan_multi(GemmMulti &p, int &T, const scae_gemm_desc *descs, int n) {
     tiles64 += (long)((descs[i].N + 63) / 64) * ((descs[i].M + 63) / 64) * descs[i].batch;
   }
   T = tiles64 < kSplitKBelow ? 32 : 64;
+  if (bf16) {
+    bool all = true;
+    for (int i = 0; i < n; ++i) all = all && bf16_shape(descs[i].M, descs[i].N);
+    if (all) T = 128;
+  }
   for (int i = 0; i < n; ++i) {
     p.tx[i] = (descs[i].N + T - 1) / T, p.ty[i] = (descs[i].M + T - 1) / T;
     p.first[i + 1] = p.first[i] + p.tx[i] * p.ty[i] * descs[i].batch;
@@ -298,13 +310,8 @@ void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
 #ifndef SCAE_DEVICE_ONLY
 
 // bf16 operands (MODE 3, 128 x 128 tiles) unless a side is so short that most of a tile
-// would be padding (rows / columns past the problem are not loaded, only multiplied)
-#ifndef SCAE_BF16_MIN_SIDE
-#define SCAE_BF16_MIN_SIDE 32
-#endif
-static bool bf16_shape(int M, int N) {
-  return M >= SCAE_BF16_MIN_SIDE && N >= SCAE_BF16_MIN_SIDE;
-}
+// would be padding (rows / columns past the problem are not loaded, only multiplied):
+// bf16_shape above
 
 static int gemm_impl(const float *A, const float *B, float *C, const float *bias,
                      const float *mask, float *asum, int batch, int M, int N, int K,
@@ -348,13 +355,15 @@ extern "C" int scae_gemm_bf16(const float *A, const float *B, float *C, const fl
                    asum_batch, asum_ld, relu, true, stream);
 }
 
-static int gemm_multi_impl(const scae_gemm_desc *descs, int n, void *stream) {
+static int gemm_multi_impl(const scae_gemm_desc *descs, int n, void *stream, bool bf16 = false) {
   SCAE_REQUIRE(descs && n >= 1 && n <= 4);
   GemmMulti p;
   int T;
-  int rc = plan_multi(p, T, descs, n);
+  int rc = plan_multi(p, T, descs, n, bf16);
   if (rc) return rc;
-  if (T == 32)
+  if (T == 128)
+    hipLaunchKernelGGL(gemm_multi_kernel<3>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
+  else if (T == 32)
     hipLaunchKernelGGL(gemm_multi_kernel<1>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(gemm_multi_kernel<0>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
@@ -395,5 +404,8 @@ extern "C" int scae_gemm_pair_bf16(const scae_gemm_desc *first, const scae_gemm_
 
 extern "C" int scae_gemm_multi_f32(const scae_gemm_desc *descs, int n, void *stream) {
   return gemm_multi_impl(descs, n, stream);
+}
+extern "C" int scae_gemm_multi_bf16(const scae_gemm_desc *descs, int n, void *stream) {
+  return gemm_multi_impl(descs, n, stream, true);
 }
 #endif  // SCAE_DEVICE_ONLY

@@ -65,6 +65,7 @@ struct Chain {
   // the capsule votes (K3) at the end of the forward chain / at the head of the
   // data-gradient chain
   int votes;
+  int bf16;        // the layer products on v_mfma_f32_16x16x16_bf16 (operands rounded at the MFMA)
   scae_votes::VoteArgs va;
   scae_votes::VoteOut vo;
   scae_votes::VoteGrads vg;
@@ -72,6 +73,24 @@ struct Chain {
 
 __device__ __forceinline__ float4 ld4(const float *p) {
   return *reinterpret_cast<const float4 *>(p);
+}
+// bf16 form (BASELINE.json configs[2]): the same four k per lane, rounded to bf16 (nearest
+// even) on their way from LDS, as ONE v_mfma_f32_16x16x16_bf16 (fp32 accumulate)
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+// (the conversion is left to the compiler -- two v_cvt_pk_bf16_f32 -- and not written as
+// inline asm: the hazard recogniser does not see into an asm body, and a VALU result consumed
+// by the very next MFMA needs wait states it then does not insert: stale operands)
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x4 to_bf16(float4 v) {
+  const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const u32x2 u = {__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16v2)),
+                   __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16v2))};
+  return __builtin_bit_cast(bf16x4, u);
+}
+__device__ __forceinline__ f32x4 mma16_bf16(f32x4 acc, bf16x4 a, bf16x4 b) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mma16(f32x4 acc, float4 a, float4 b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
@@ -158,7 +177,7 @@ __device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g
 // One workgroup barrier per layer boundary separates the writes of a layer's output from
 // its reads.
 // (16-row workgroups: four waves per SIMD, so that two of them share a CU)
-template <bool BWD, int RBT>
+template <bool BWD, int RBT, bool BF>
 __global__ __launch_bounds__(NT, (RBT == 1 && SCAE_CHAIN_LB4) ? 4 : 2) void chain_kernel(Chain c) {
   constexpr int RB = 16 * RBT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -266,9 +285,16 @@ __global__ __launch_bounds__(NT, (RBT == 1 && SCAE_CHAIN_LB4) ? 4 : 2) void chai
           for (int s = 0; s < CH; ++s)
             if (ch * CH + s < nsteps) {   // (uniform)
               const float4 bw = ld4(brow + 16 * s);
+              if (BF) {
+                const bf16x4 bh = to_bf16(bw);
 #pragma unroll
-              for (int rb = 0; rb < RBT; ++rb)
-                acc[rb] = mma16(acc[rb], ld4(arow + 16 * rb * cs + 16 * s), bw);
+                for (int rb = 0; rb < RBT; ++rb)
+                  acc[rb] = mma16_bf16(acc[rb], to_bf16(ld4(arow + 16 * rb * cs + 16 * s)), bh);
+              } else {
+#pragma unroll
+                for (int rb = 0; rb < RBT; ++rb)
+                  acc[rb] = mma16(acc[rb], ld4(arow + 16 * rb * cs + 16 * s), bw);
+              }
             }
           if (ch != nch - 1) continue;
           const int col = 16 * tile + r;
@@ -340,6 +366,7 @@ int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd, const scae_votes_desc
   // launch() narrows each buffer to what it holds when it takes 32 rows per workgroup
   c.stride[0] = c.stride[1] = ((maxdim + 15) & ~15) + 4;
   c.votes = 0;
+  c.bf16 = d->bf16 != 0;
   if (v) {
     const int V = v->V, A = 8 * V + 7;
     if (V <= 0 || !v->cpr_static || !v->bias_cvr || !v->bias_caps || !v->bias_vote ||
@@ -376,18 +403,22 @@ int fill(Chain &c, const scae_mlp_chain_desc *d, bool bwd, const scae_votes_desc
 #ifndef SCAE_CHAIN_RB32_MIN_WGS
 #define SCAE_CHAIN_RB32_MIN_WGS 512   // 32-row workgroups only while >= 2 of them per CU remain
 #endif
-template <bool BWD, int RBT>
-int launch_rb(const Chain &c, void *stream) {
+template <bool BWD, int RBT, bool BF>
+int launch_rb_bf(const Chain &c, void *stream) {
   constexpr int RB = 16 * RBT;
   const size_t lds = ((size_t)RB * (c.stride[0] + c.stride[1]) + (size_t)NW * 16 * WLD) * sizeof(float);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<BWD, RBT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<BWD, RBT, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const int blocks = c.G * ((c.B + RB - 1) / RB);
-  hipLaunchKernelGGL((chain_kernel<BWD, RBT>), dim3(blocks), dim3(NT), lds, (hipStream_t)stream, c);
+  hipLaunchKernelGGL((chain_kernel<BWD, RBT, BF>), dim3(blocks), dim3(NT), lds, (hipStream_t)stream, c);
   return scae_launch_status();
+}
+template <bool BWD, int RBT>
+int launch_rb(const Chain &c, void *stream) {
+  return c.bf16 ? launch_rb_bf<BWD, RBT, true>(c, stream) : launch_rb_bf<BWD, RBT, false>(c, stream);
 }
 
 template <bool BWD>

@@ -34,13 +34,18 @@ __device__ __forceinline__ f32x4 mma16(f32x4 acc, float4 a, float4 b) {
 // attention path"): the lane's four consecutive k are rounded to bf16 (nearest even) and
 // contracted by ONE v_mfma_f32_16x16x16_bf16, fp32 accumulate.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
   // (a compiler-visible conversion, not inline asm: the result feeds an MFMA directly and
-  // the hazard recogniser must see the VALU write to place the wait states)
-  const f32x4 f = {v.x, v.y, v.z, v.w};
-  const bf16x4v h = __builtin_convertvector(f, bf16x4v);
-  return __builtin_bit_cast(bf16x4, h);
+  // the hazard recogniser must see the VALU write to place the wait states; two 2-vectors:
+  // a 4-vector conversion is scalarised into four v_cvt + two v_perm, these are two
+  // v_cvt_pk_bf16_f32)
+  const f32x2v a = {v.x, v.y}, b = {v.z, v.w};
+  const u32x2v u = {__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2v)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2v))};
+  return __builtin_bit_cast(bf16x4, u);
 }
 template <bool BF>
 __device__ __forceinline__ f32x4 mma16p(f32x4 acc, float4 a, float4 b) {

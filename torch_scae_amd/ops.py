@@ -2127,9 +2127,10 @@ class HipLayerNorm(torch.nn.LayerNorm):
 
 
 def mlp_chain_supported(x, layers):
-    """The one-launch chain (csrc/mlp_chain.hip) covers fp32, <= 4 layers,
-    widths <= scae_mlp_chain_max_width()."""
-    if _bf16() or not x.is_cuda or x.dtype != torch.float32 or \
+    """The one-launch chain (csrc/mlp_chain.hip) covers fp32 tensors (inside
+    ``mfma_bf16()`` its products take bf16 operands), <= 4 layers, widths <=
+    scae_mlp_chain_max_width()."""
+    if not x.is_cuda or x.dtype != torch.float32 or \
             not 1 <= len(layers) <= 4:
         return False
     wmax = _lib.load().scae_mlp_chain_max_width()
@@ -2148,6 +2149,7 @@ def _chain_forward_desc(x, ones_flags, weights, biases):
     d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
         L, x.data_ptr(), x.stride(1), x.stride(0), Kin, B, G
     d.row_tile = _CHAIN_ROW_TILE
+    d.bf16 = int(_bf16())
     acts, K = [], Kin
     for l, (w, b) in enumerate(zip(weights, biases)):
         N, ldw = w.shape[1], w.shape[2]
@@ -2191,6 +2193,7 @@ def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
     d.n_layers, d.in_, d.in_gs, d.in_bs, d.in_dim, d.B, d.G = \
         L, gpre.data_ptr(), gpre.stride(1), gpre.stride(0), gpre.shape[2], B, G
     d.row_tile = _CHAIN_ROW_TILE
+    d.bf16 = int(_bf16())
     gx = torch.empty(B, G, Kin, device=dev, dtype=dt) if need_gx else None
     gs = [None] * L          # gradient w.r.t. every pre-activation
     gs[L - 1] = gpre
@@ -2252,12 +2255,12 @@ def _chain_backward(x, weights, acts, ones_flags, has_bias, x_is_relu, slots,
         gws[l] = gw
     # (parked only when every output is a slot view taken here: a fresh buffer
     # is accumulated by autograd as soon as this node returns)
-    if park and L <= 4 and all(_in_slot(t) for t in gws) and \
+    if park and not _bf16() and L <= 4 and all(_in_slot(t) for t in gws) and \
             all(_in_slot(t) for t in gbs if t is not None):
         _plan().park("wgrads", _PendingWeightGemms(
             descs, L, (x, gs, acts, [w for w in weights]), x))
     else:
-        _lib.call("scae_gemm_multi_f32", descs, L, _stream(x))
+        _lib.call(_prec("scae_gemm_multi_f32"), descs, L, _stream(x))
     return gx, gws, gbs
 
 
