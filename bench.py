@@ -957,9 +957,10 @@ def main():
     timing["per_block"] = [
         dict(ms=round(1e3 * t / args.steps, 4), capsules_after=st)
         for t, st in zip(blocks, per_block)]
-    # the same captured step re-issued launch by launch (TrainStep(replay="launches"): no
-    # per-replay graph cost on the device, ~350 us of host time per step instead of ~10)
-    if not collective and step.use_graph and getattr(step, "_launches", None):
+    # the same captured step re-issued from the library's record of its kernel launches
+    # (TrainStep(replay="launches"), scae_launch_list_run: a hipLaunchKernel per launch, no
+    # per-replay graph cost on the device)
+    if not collective and step.use_graph and getattr(step, "_klist", None):
         step.replay = "launches"
         t3 = timing_summary(timed_blocks(
             step, images, labels, args.steps, args.warmup, max(1, min(7, args.blocks)),

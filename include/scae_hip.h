@@ -47,6 +47,21 @@ extern "C" {
 int scae_abi_version(void);
 const char *scae_error_string(int code);
 
+/* Launch lists: a training step as the library's own record of its kernel launches.
+ * Between scae_launch_list_begin() and scae_launch_list_end() every kernel launch any
+ * entry point of this library issues (from any host thread; also into a capturing stream)
+ * is appended to the list -- kernel, grid, block, LDS bytes, a copy of the argument bytes.
+ * scae_launch_list_run re-issues them, in order, on `stream`: what replaying a captured
+ * HIP graph of the same launches does, with a hipLaunchKernel per launch on the host and
+ * without the graph's end-of-launch cost on the device.  The list holds pointers, not
+ * buffers: the caller keeps every buffer the recorded launches use alive and unmoved.
+ * One recording at a time per process (begin returns SCAE_ERR_BAD_ARG while one is open). */
+int scae_launch_list_begin(void);
+void *scae_launch_list_end(void); /* the list (NULL when none was open); free it with _free */
+int scae_launch_list_size(const void *list);
+int scae_launch_list_run(const void *list, void *stream);
+void scae_launch_list_free(void *list);
+
 /* ------------------------------------------------------------------------
  * Presence-logit noise     replaces torch.rand_like (part_encoder.py:106,
  *     object_decoder.py:201): out[0..n) ~ U[0,1), Philox4x32-10 keyed by

@@ -564,10 +564,11 @@ def test_likelihood_riding_in_the_trunk_launch_changes_nothing():
 
 
 def test_recorded_launch_list_equals_graph_replay_bitwise():
-    """``TrainStep(replay="launches")``: the captured step re-issued launch by launch from
-    the recorded C-ABI calls (torch_scae_amd/_lib.py recorder) instead of as a HIP-graph
-    replay -- the same launches, so loss, parameters and optimiser state after three steps
-    must agree bit for bit with the graph's (cfg-2, B = 128, noise on)."""
+    """``TrainStep(replay="launches")``: the captured step re-issued from the library's own record of the kernel launches
+    the capture made (``scae_launch_list_*``: kernel, grid, block, LDS, argument bytes; one
+    hipLaunchKernel each) instead of as a HIP-graph replay -- the same launches, so loss,
+    parameters and optimiser state after three steps must agree bit for bit with the
+    graph's (cfg-2, B = 128, noise on)."""
     cfg, B, sd, g = full_size_params("cfg2")
     images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
     labels = torch.randint(0, cfg["n_classes"], (3, B), generator=g).cuda()
@@ -579,6 +580,9 @@ def test_recorded_launch_list_equals_graph_replay_bitwise():
             losses.append(float(step(images[i], labels[i])))
         torch.cuda.synchronize()
         assert step.graph is not None and len(step._launches) >= 15
+        from torch_scae_amd import _lib
+        # (a C-ABI call is at least one kernel launch)
+        assert _lib.load().scae_launch_list_size(step._klist) >= len(step._launches)
         out.append((losses, step.flat.flat_param.clone(), step.opt.square_avg.clone(),
                     step.opt.buf.clone(), step.flat.flat_grad.clone()))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])

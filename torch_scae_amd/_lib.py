@@ -195,6 +195,12 @@ SIGNATURES = {
                                               c_int, c_int64, c_int64, c_int, c_int,
                                               P],
     "scae_gemm_pair_f32": [POINTER(GemmDesc), POINTER(GemmDesc), P],
+    # the library's own record of a step's kernel launches (train_step.TrainStep)
+    "scae_launch_list_begin": [],
+    "scae_launch_list_end": [],
+    "scae_launch_list_size": [P],
+    "scae_launch_list_run": [P, P],
+    "scae_launch_list_free": [P],
     "scae_gemm_multi_f32": [POINTER(GemmDesc), c_int, P],
     "scae_gemm_multi_bf16": [POINTER(GemmDesc), c_int, P],
     "scae_mlp_chain_max_width": [],
@@ -309,9 +315,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_char_p if name == "scae_error_string" else (
-            c_int64 if name == "scae_loss_tail_workspace_floats" else c_int)
-        if argtypes and argtypes[-1] is P:      # a launcher: (..., void *stream)
-            setattr(lib, name, _recording(fn))
+            c_int64 if name == "scae_loss_tail_workspace_floats" else (
+                P if name == "scae_launch_list_end" else (
+                    None if name == "scae_launch_list_free" else c_int)))
+        if argtypes and argtypes[-1] is P and not name.startswith("scae_launch_list"):
+            setattr(lib, name, _recording(fn))     # a launcher: (..., void *stream)
     _lib = lib
     return lib
 

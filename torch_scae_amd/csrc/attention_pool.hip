@@ -373,7 +373,7 @@ extern "C" int scae_capsule_head_bwd_tc_f32(
   const size_t lp = lds_floats(HW, A / k.splits, P, true),
                lt = scae_tc::lds_floats(A / k.splits, C, F, H1, true);
   const int nA = B * k.splits;
-  hipLaunchKernelGGL(pool_tc_bwd_kernel, dim3(nA + scae_tc::bwd_elementwise_blocks(tk)), dim3(NT),
+  scae::launch(pool_tc_bwd_kernel, dim3(nA + scae_tc::bwd_elementwise_blocks(tk)), dim3(NT),
                      (lp > lt ? lp : lt) * sizeof(float), (hipStream_t)stream, k, tk, nA);
   return scae_launch_status();
 }
@@ -391,7 +391,7 @@ extern "C" int scae_attention_pool_fwd_f32(const float *y, float *out, int B, in
   int rc = check(k);
   if (rc) return rc;
   SCAE_REQUIRE(y && out);
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
+  scae::launch(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
                      lds_floats(HW, A / k.splits, P, false) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();
@@ -405,7 +405,7 @@ extern "C" int scae_attention_pool_bwd_f32(const float *y, const float *g, float
   int rc = check(k);
   if (rc) return rc;
   SCAE_REQUIRE(y && g && dy);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B * k.splits), dim3(NT),
+  scae::launch(pool_bwd_kernel, dim3(B * k.splits), dim3(NT),
                      lds_floats(HW, A / k.splits, P, true) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();
@@ -424,7 +424,7 @@ extern "C" int scae_capsule_head_fwd_f32(const float *y, const float *noise_u, f
   if (rc) return rc;
   if (P < 8) return SCAE_ERR_UNSUPPORTED;  // 6 pose + presence + attention logit
   SCAE_REQUIRE(y && pooled && pose && presence && (feature || P == 8));
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
+  scae::launch(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
                      lds_floats(HW, A / k.splits, P, false) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();
@@ -466,7 +466,7 @@ extern "C" int scae_capsule_head_conv_fwd_f32(const float *x, const float *w, co
   SCAE_REQUIRE(x && w && y && pooled && pose && presence && (feature || P == 8));
   SCAE_REQUIRE((((size_t)x | (size_t)w) & 15) == 0);
   const int Ag = A / k.splits;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
+  scae::launch(pool_fwd_kernel, dim3(B * k.splits), dim3(NT),
                      (conv_x_offset(HW, Ag, P) + (size_t)HW * (C + 4)) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();
@@ -507,7 +507,7 @@ extern "C" int scae_capsule_head_conv_fwd_tc_f32(
   const int Ag = A / k.splits;
   const size_t lp = conv_x_offset(HW, Ag, P) + (size_t)HW * (C + 4),
                lt = scae_tc::lds_floats(Ag, Ct, F, H1, false);
-  hipLaunchKernelGGL(pool_tc_fwd_kernel, dim3(B * k.splits), dim3(NT),
+  scae::launch(pool_tc_fwd_kernel, dim3(B * k.splits), dim3(NT),
                      (lp > lt ? lp : lt) * sizeof(float), (hipStream_t)stream, k, tk);
   return scae_launch_status();
 }
@@ -527,7 +527,7 @@ extern "C" int scae_capsule_head_bwd_f32(const float *y, const float *pooled,
   if (rc) return rc;
   if (P < 8) return SCAE_ERR_UNSUPPORTED;
   SCAE_REQUIRE(y && pooled && dy);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B * k.splits), dim3(NT),
+  scae::launch(pool_bwd_kernel, dim3(B * k.splits), dim3(NT),
                      lds_floats(HW, A / k.splits, P, true) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();

@@ -45,7 +45,7 @@ extern "C" int scae_capsule_likelihood_fwd_f32(
     if (e != hipSuccess) return (int)e;
   }
 #define SCAE_LK_FWD(BG)                                                                        \
-  hipLaunchKernelGGL(likelihood_fwd_kernel<BG>, dim3(B < 1024 ? B : 1024), dim3(NT), lds,      \
+  scae::launch(likelihood_fwd_kernel<BG>, dim3(B < 1024 ? B : 1024), dim3(NT), lds,      \
                      (hipStream_t)stream, a, log_prob_per_point, vote_presence_binary, winner, \
                      winner_presence, winner_idx, is_from_capsule, soft_winner,                \
                      soft_winner_presence, posterior, mixing_log_prob, mixing_logit)
@@ -81,7 +81,7 @@ extern "C" int scae_capsule_likelihood_bwd_f32(
     if (e != hipSuccess) return (int)e;
   }
 #define SCAE_LK_BWD(BG)                                                                         \
-  hipLaunchKernelGGL(likelihood_bwd_kernel<BG>, dim3(B < 1024 ? B : 1024), dim3(NT), lds,       \
+  scae::launch(likelihood_bwd_kernel<BG>, dim3(B < 1024 ? B : 1024), dim3(NT), lds,       \
                      (hipStream_t)stream, a, winner_idx, g_lpp, g_winner, g_winner_presence,    \
                      g_soft_winner, g_soft_winner_presence, g_posterior, g_mixing_log_prob,     \
                      g_mixing_logit, gvote, gscale, gvote_presence, gx, gpresence,              \

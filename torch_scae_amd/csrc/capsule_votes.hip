@@ -202,7 +202,7 @@ extern "C" int scae_capsule_votes_fwd_f32(
   if (rc) return rc;
   SCAE_REQUIRE(vote && scale && vote_presence && logit_caps && logit_vote && reg_partial);
   SCAE_REQUIRE(!caps_presence == !caps_arg);
-  hipLaunchKernelGGL(votes_fwd_kernel, dim3(B * O), dim3(NT), 0, (hipStream_t)stream, a,
+  scae::launch(votes_fwd_kernel, dim3(B * O), dim3(NT), 0, (hipStream_t)stream, a,
                      vote, scale, vote_presence, logit_caps, logit_vote, reg_partial,
                      caps_presence, caps_arg);
   return scae_launch_status();
@@ -223,7 +223,7 @@ extern "C" int scae_capsule_votes_bwd_f32(
   int rc = check_votes(a);
   if (rc) return rc;
   SCAE_REQUIRE(gall_param && gcpr_in && (!gcaps_presence || caps_arg));
-  hipLaunchKernelGGL(votes_bwd_kernel, dim3(B * O), dim3(NT), 0, (hipStream_t)stream, a,
+  scae::launch(votes_bwd_kernel, dim3(B * O), dim3(NT), 0, (hipStream_t)stream, a,
                      gvote, gscale, gvote_presence, glogit_caps, glogit_vote, greg,
                      gall_param, gcpr_in, gcaps_presence, caps_arg, gall_param_gated);
   return scae_launch_status();

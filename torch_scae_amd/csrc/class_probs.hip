@@ -27,6 +27,6 @@ extern "C" int scae_class_probs_f32(const float *caps_presence, const float *pos
   int rc = scae_cp::fill(a, caps_presence, posterior, w, bias, prior_prob, post_prob, B, O, M,
                          ncls, extra_sums, n_extra);
   if (rc) return rc;
-  hipLaunchKernelGGL(class_probs_kernel, dim3(B + n_extra), dim3(64), 0, (hipStream_t)stream, a);
+  scae::launch(class_probs_kernel, dim3(B + n_extra), dim3(64), 0, (hipStream_t)stream, a);
   return scae_launch_status();
 }

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
 #include "scae_hip.h"
 
 #define SCAE_WAVE 64
@@ -18,7 +22,40 @@ static inline int scae_launch_status() {
   return e == hipSuccess ? SCAE_OK : (int)e;
 }
 
+// ---- launches, and the list a training step replays --------------------------------------
+// Every kernel of this library is launched through scae::launch (the arguments of
+// hipLaunchKernelGGL).  While a launch list is being recorded (scae_launch_list_begin /
+// _end, abi.hip) each launch is also appended to it -- kernel, grid, block, LDS bytes and a
+// copy of its arguments -- and scae_launch_list_run re-issues the list on a stream: what a
+// captured HIP graph of the same launches does, without the ~8.6 us the end of a graph launch
+// costs on the device and without the launchers' host-side
+// planning.  The list holds pointers, not buffers: whoever replays it keeps them alive.
+namespace scae_rec {
+bool recording();   // (a relaxed flag: no cost when nothing records)
+void append(const void *fn, dim3 grid, dim3 block, size_t lds, void *const *args,
+            const size_t *sizes, int n);
+}  // namespace scae_rec
+
 namespace scae {
+template <class... KA, size_t... I, class... A>
+inline void launch_impl(void (*kernel)(KA...), std::index_sequence<I...>, dim3 grid, dim3 block,
+                        size_t lds, hipStream_t st, A &&...args) {
+  static_assert(sizeof...(KA) == sizeof...(A), "one argument per kernel parameter");
+  std::tuple<std::remove_cv_t<KA>...> held{static_cast<std::remove_cv_t<KA>>(args)...};
+  void *ptrs[sizeof...(KA) + 1] = {const_cast<void *>(static_cast<const void *>(&std::get<I>(held)))...};
+  (void)hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, lds, st);
+  if (scae_rec::recording()) {
+    const size_t sizes[sizeof...(KA) + 1] = {sizeof(std::remove_cv_t<KA>)...};
+    scae_rec::append(reinterpret_cast<const void *>(kernel), grid, block, lds, ptrs, sizes,
+                     (int)sizeof...(KA));
+  }
+}
+template <class... KA, class... A>
+inline void launch(void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                   A &&...args) {
+  launch_impl(kernel, std::index_sequence_for<KA...>{}, grid, block, lds, st,
+              std::forward<A>(args)...);
+}
 
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kLogSafeEps = 1e-16f;   // math_ops.py:18

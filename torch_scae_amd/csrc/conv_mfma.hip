@@ -1072,7 +1072,7 @@ extern "C" int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, i
                                          int Cin, void *stream) {
   SCAE_REQUIRE(w && wf && wd && Cout > 0 && Cin > 0);
   const int n = Cout * Cin * 9;
-  hipLaunchKernelGGL(relayout_weights_kernel, dim3((n + 255) / 256), dim3(256), 0,
+  scae::launch(relayout_weights_kernel, dim3((n + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, w, wf, wd, Cout, Cin);
   return scae_launch_status();
 }
@@ -1085,7 +1085,7 @@ extern "C" int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const 
   RelayoutBatch r{};
   const int rb = fill_relayout(r, n_layers, w, wf, wd, Cout, Cin);
   SCAE_REQUIRE(rb > 0);
-  hipLaunchKernelGGL(relayout_batch_kernel, dim3(rb, n_layers), dim3(256), 0,
+  scae::launch(relayout_batch_kernel, dim3(rb, n_layers), dim3(256), 0,
                      (hipStream_t)stream, r);
   return scae_launch_status();
 }
@@ -1111,7 +1111,7 @@ extern "C" int scae_conv3x3_first_fwd_relayout_f32(
   const int n_first = B * f.slices;
 #define SCAE_FIRST_FWD(CI)                                                                    \
   case CI:                                                                                    \
-    hipLaunchKernelGGL(conv_first_fwd_kernel<CI>, dim3(n_first + n_layers * rb), dim3(256),   \
+    scae::launch(conv_first_fwd_kernel<CI>, dim3(n_first + n_layers * rb), dim3(256),   \
                        lds, (hipStream_t)stream, img, w, bias, out, g, r, n_first, rb);       \
     break;
   switch (Cin) {
@@ -1175,7 +1175,7 @@ extern "C" int scae_conv3x3_first_wgrad_reduce_f32(
   const int n_first = B * f.slices;
 #define SCAE_FIRST_WGRAD(CI)                                                                  \
   case CI:                                                                                    \
-    hipLaunchKernelGGL(conv_first_wgrad_kernel<CI>, dim3(n_first + n_layers * rb), dim3(256), \
+    scae::launch(conv_first_wgrad_kernel<CI>, dim3(n_first + n_layers * rb), dim3(256), \
                        lds, (hipStream_t)stream, dpre, img, partial, g, r, n_first, rb);      \
     break;
   switch (Cin) {
@@ -1210,14 +1210,14 @@ static int conv_fwd_impl(const float *in, const float *wf, const float *bias, fl
   const int M = B * g.OH * g.OW;
   hipStream_t st = (hipStream_t)stream;
   if (bf16 && conv_bf16_shape(M, Cin, Cout)) {
-    hipLaunchKernelGGL(conv_fwd_kernel<3>, dim3(Cout / 128, (M + 127) / 128), dim3(NT), 0, st, in,
+    scae::launch(conv_fwd_kernel<3>, dim3(Cout / 128, (M + 127) / 128), dim3(NT), 0, st, in,
                        wf, bias, out, post_bias, out_post, g);
     return scae_launch_status();
   }
   const int cfg = pipe_cfg("SCAE_K8_FWD", M, Cout);
   if (cfg >= 0) {
 #define SCAE_FWD_PIPE(TT)                                                                    \
-  hipLaunchKernelGGL(conv_fwd_pipe_kernel<TT>, dim3(Cout / TT::TB, (M + TT::TA - 1) / TT::TA), \
+  scae::launch(conv_fwd_pipe_kernel<TT>, dim3(Cout / TT::TB, (M + TT::TA - 1) / TT::TA), \
                      dim3(pipe::NT), 0, st, in, wf, bias, out, post_bias, out_post, g)
     switch (cfg) {
       case 0: SCAE_FWD_PIPE(PipeC0); break;
@@ -1237,15 +1237,15 @@ static int conv_fwd_impl(const float *in, const float *wf, const float *bias, fl
   const long f64 = (long)(Cout / 64) * ((M + 63) / 64), f32 = (long)(Cout / 64) * ((M + 31) / 32);
   switch (f64 >= SCAE_FWD_SMALL_TILES ? 0 : (f32 >= SCAE_FWD_WIDE_MIN ? 2 : 1)) {
     case 0:
-      hipLaunchKernelGGL(conv_fwd_kernel<0>, dim3(Cout / 64, (M + 63) / 64), dim3(NT), 0, st, in,
+      scae::launch(conv_fwd_kernel<0>, dim3(Cout / 64, (M + 63) / 64), dim3(NT), 0, st, in,
                          wf, bias, out, post_bias, out_post, g);
       break;
     case 2:
-      hipLaunchKernelGGL(conv_fwd_kernel<2>, dim3(Cout / 64, (M + 31) / 32), dim3(NT), 0, st, in,
+      scae::launch(conv_fwd_kernel<2>, dim3(Cout / 64, (M + 31) / 32), dim3(NT), 0, st, in,
                          wf, bias, out, post_bias, out_post, g);
       break;
     default:
-      hipLaunchKernelGGL(conv_fwd_kernel<1>, dim3(Cout / 32, (M + 31) / 32), dim3(NT), 0, st, in,
+      scae::launch(conv_fwd_kernel<1>, dim3(Cout / 32, (M + 31) / 32), dim3(NT), 0, st, in,
                          wf, bias, out, post_bias, out_post, g);
   }
   return scae_launch_status();
@@ -1276,7 +1276,7 @@ extern "C" int scae_conv3x3_fwd_fold_f32(const float *in, const float *wf, const
   const int M = B * g.OH * g.OW, gx = Cout / PipeC2::TB,
             n_conv = gx * ((M + PipeC2::TA - 1) / PipeC2::TA);
   const scae_fold::Plan plan = scae_fold::plan(a.C, a.D);
-  hipLaunchKernelGGL(conv_fwd_pipe_fold_kernel<PipeC2>, dim3(n_conv + plan.blocks()),
+  scae::launch(conv_fwd_pipe_fold_kernel<PipeC2>, dim3(n_conv + plan.blocks()),
                      dim3(pipe::NT), 0, (hipStream_t)stream, in, wf, bias, out, post_bias, out_post,
                      g, gx, n_conv, a, plan);
   return scae_launch_status();
@@ -1359,7 +1359,7 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
   const dim3 grid(d.gx, d.ny);
   if (d.cfg >= 0) {
 #define SCAE_DG_PIPE(TT)                                                                   \
-  hipLaunchKernelGGL(conv_dgrad_pipe_kernel<TT>, grid, dim3(pipe::NT), 0, st, dpre, wd, gate, \
+  scae::launch(conv_dgrad_pipe_kernel<TT>, grid, dim3(pipe::NT), 0, st, dpre, wd, gate, \
                      din, g, d.pl)
     switch (d.cfg) {
       case 0: SCAE_DG_PIPE(PipeC0); break;
@@ -1371,11 +1371,11 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
     return scae_launch_status();
   }
   if (d.mode == 0)
-    hipLaunchKernelGGL(conv_dgrad_kernel<0>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+    scae::launch(conv_dgrad_kernel<0>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
   else if (d.mode == 2)
-    hipLaunchKernelGGL(conv_dgrad_kernel<2>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+    scae::launch(conv_dgrad_kernel<2>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
   else
-    hipLaunchKernelGGL(conv_dgrad_kernel<1>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+    scae::launch(conv_dgrad_kernel<1>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
   return scae_launch_status();
 }
 
@@ -1397,7 +1397,7 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
   }
   if (bf16) {   // both gradients on bf16 operands, 128 x 128 tiles
     const PairGrid bg{d.gx * d.ny, d.gx, Cin / 128, Cout / 128};
-    hipLaunchKernelGGL((conv_bwd_pair_kernel<3, 3>), dim3(bg.nd + bg.wx * bg.wy * 9 * p.splits),
+    scae::launch((conv_bwd_pair_kernel<3, 3>), dim3(bg.nd + bg.wx * bg.wy * 9 * p.splits),
                        dim3(NT), 0, (hipStream_t)stream, dpre, wd, in, din, in, partial, g, d.pl,
                        p.splits, bg);
     return scae_launch_status();
@@ -1408,7 +1408,7 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
   hipStream_t st = (hipStream_t)stream;
   if (d.cfg >= 0) {
 #define SCAE_PAIR_PIPE(TT)                                                                  \
-  hipLaunchKernelGGL((conv_bwd_pair_pipe_kernel<TT, PipeW>), grid, dim3(pipe::NT), 0, st,   \
+  scae::launch((conv_bwd_pair_pipe_kernel<TT, PipeW>), grid, dim3(pipe::NT), 0, st,   \
                      dpre, wd, in, din, in, partial, g, d.pl, p.splits, pg)
     switch (d.cfg) {
       case 0: SCAE_PAIR_PIPE(PipeC0); break;
@@ -1425,10 +1425,10 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
     const dim3 mgrid(mg.nd + mg.wx * mg.wy * 9 * p.splits);
     const bool w16 = (long)B * g.OH * g.OW < SCAE_WGRAD_SHORT_CHUNK_PIXELS;
 #define SCAE_PAIR_MIXED(DM, TW)                                                              \
-  hipLaunchKernelGGL((conv_bwd_pair_mixed_kernel<DM, TW>), mgrid, dim3(NT), 0, st, dpre, wd, in, \
+  scae::launch((conv_bwd_pair_mixed_kernel<DM, TW>), mgrid, dim3(NT), 0, st, dpre, wd, in, \
                      din, in, partial, g, d.pl, p.splits, mg)
 #define SCAE_PAIR_MIXED_FOLD(DM, TW)                                                          \
-  hipLaunchKernelGGL((conv_bwd_pair_mixed_rider_kernel<DM, TW>), rgrid, dim3(NT), 0, st, dpre, wd, \
+  scae::launch((conv_bwd_pair_mixed_rider_kernel<DM, TW>), rgrid, dim3(NT), 0, st, dpre, wd, \
                      in, din, in, partial, g, d.pl, p.splits, mg, *rider)
 #define SCAE_PAIR_BY_MODE(LAUNCH, TW) \
   if (d.mode == 0) LAUNCH(0, TW);     \
@@ -1448,7 +1448,7 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
     return scae_launch_status();
   }
 #define SCAE_PAIR(DM, WS)                                                                     \
-  hipLaunchKernelGGL((conv_bwd_pair_kernel<DM, WS>), grid, dim3(NT), 0, st, dpre, wd, in, din, \
+  scae::launch((conv_bwd_pair_kernel<DM, WS>), grid, dim3(NT), 0, st, dpre, wd, in, din, \
                      in, partial, g, d.pl, p.splits, pg)
   if (d.mode == 0) {
     if (p.small) SCAE_PAIR(0, true); else SCAE_PAIR(0, false);
@@ -1588,7 +1588,7 @@ extern "C" int scae_debug_conv_fwd_multi(int n, const float *const *in, const fl
   }
   a.start[3] = tot;
   for (int l = n; l < 3; ++l) a.start[l] = tot;
-  hipLaunchKernelGGL(conv_fwd_multi_probe_kernel<PipeC2>, dim3(tot), dim3(pipe::NT), 0,
+  scae::launch(conv_fwd_multi_probe_kernel<PipeC2>, dim3(tot), dim3(pipe::NT), 0,
                      (hipStream_t)stream, a);
   return scae_launch_status();
 }
@@ -1619,7 +1619,7 @@ extern "C" int scae_debug_conv_bwd_multi(int n, const float *const *dpre, const 
   for (int l = n; l < 3; ++l) a.start[l] = tot;
   hipError_t e = hipMemcpyAsync(scratch, &a, sizeof(a), hipMemcpyHostToDevice, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(conv_bwd_multi_probe_kernel, dim3(tot), dim3(NT), 0, (hipStream_t)stream,
+  scae::launch(conv_bwd_multi_probe_kernel, dim3(tot), dim3(NT), 0, (hipStream_t)stream,
                      (const MultiBwd *)scratch);
   return scae_launch_status();
 }
@@ -1641,17 +1641,17 @@ extern "C" int scae_conv3x3_wgrad_f32(const float *dpre, const float *in, float 
   const WgradPlan p = wgrad_plan(B * g.OH * g.OW, Cin, Cout);
   const char *e = getenv("SCAE_K8_WG");
   if (!(e && atoi(e) < 0))
-    hipLaunchKernelGGL(conv_wgrad_pipe_kernel<PipeW>, dim3(Cin / 64, Cout / 64, 9 * p.splits),
+    scae::launch(conv_wgrad_pipe_kernel<PipeW>, dim3(Cin / 64, Cout / 64, 9 * p.splits),
                        dim3(pipe::NT), 0, (hipStream_t)stream, dpre, in, partial, g, p.splits);
   else if (p.small)
-    hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(Cin / 32, Cout / 32, 9 * p.splits), dim3(NT),
+    scae::launch(conv_wgrad_kernel<true>, dim3(Cin / 32, Cout / 32, 9 * p.splits), dim3(NT),
                        0, (hipStream_t)stream, dpre, in, partial, g, p.splits);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(Cin / 64, Cout / 64, 9 * p.splits),
+    scae::launch(conv_wgrad_kernel<false>, dim3(Cin / 64, Cout / 64, 9 * p.splits),
                        dim3(NT), 0, (hipStream_t)stream, dpre, in, partial, g, p.splits);
   if (dw) {  // else: the caller reduces later (scae_conv3x3_wgrad_reduce_batch_f32)
     const int n = 9 * Cout * Cin + Cout;
-    hipLaunchKernelGGL(reduce_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0,
+    scae::launch(reduce_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, partial, dw, db, Cout, Cin, p.splits);
   }
   return scae_launch_status();
@@ -1664,7 +1664,7 @@ extern "C" int scae_conv3x3_wgrad_reduce_batch_f32(int n_layers, const float *co
   ReduceBatch r{};
   const int rb = fill_reduce(r, n_layers, partial, dw, db, Cout, Cin, splits);
   SCAE_REQUIRE(rb > 0);
-  hipLaunchKernelGGL(reduce_wgrad_batch_kernel, dim3(rb, n_layers), dim3(256), 0,
+  scae::launch(reduce_wgrad_batch_kernel, dim3(rb, n_layers), dim3(256), 0,
                      (hipStream_t)stream, r);
   return scae_launch_status();
 }

@@ -213,7 +213,7 @@ extern "C" int scae_conv3x3_fwd_res_f32(const float *in, const float *wp, const 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
       if (e != hipSuccess) return (int)e;                                                        \
     }                                                                                            \
-    hipLaunchKernelGGL(conv_res_fwd_kernel<M>, grid, dim3(NT), p.lds, st, a);                    \
+    scae::launch(conv_res_fwd_kernel<M>, grid, dim3(NT), p.lds, st, a);                    \
     break;                                                                                       \
   }
   switch (p.MI) {

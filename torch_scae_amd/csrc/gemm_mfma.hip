@@ -296,13 +296,13 @@ void launch(const GemmArgs &g, int batch, bool ak, bool bk, hipStream_t st) {
   constexpr int T = Tile<SK>::T;
   const dim3 grid((g.N + T - 1) / T, (g.M + T - 1) / T, batch);
   if (ak && bk)
-    hipLaunchKernelGGL((gemm_kernel<SK, true, true>), grid, dim3(NT), 0, st, g);
+    scae::launch((gemm_kernel<SK, true, true>), grid, dim3(NT), 0, st, g);
   else if (ak)
-    hipLaunchKernelGGL((gemm_kernel<SK, true, false>), grid, dim3(NT), 0, st, g);
+    scae::launch((gemm_kernel<SK, true, false>), grid, dim3(NT), 0, st, g);
   else if (bk)
-    hipLaunchKernelGGL((gemm_kernel<SK, false, true>), grid, dim3(NT), 0, st, g);
+    scae::launch((gemm_kernel<SK, false, true>), grid, dim3(NT), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<SK, false, false>), grid, dim3(NT), 0, st, g);
+    scae::launch((gemm_kernel<SK, false, false>), grid, dim3(NT), 0, st, g);
 }
 #endif
 }  // namespace
@@ -362,11 +362,11 @@ static int gemm_multi_impl(const scae_gemm_desc *descs, int n, void *stream, boo
   int rc = plan_multi(p, T, descs, n, bf16);
   if (rc) return rc;
   if (T == 128)
-    hipLaunchKernelGGL(gemm_multi_kernel<3>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
+    scae::launch(gemm_multi_kernel<3>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
   else if (T == 32)
-    hipLaunchKernelGGL(gemm_multi_kernel<1>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
+    scae::launch(gemm_multi_kernel<1>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL(gemm_multi_kernel<0>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
+    scae::launch(gemm_multi_kernel<0>, dim3(p.first[n]), dim3(NT), 0, (hipStream_t)stream, p);
   return scae_launch_status();
 }
 
@@ -387,7 +387,7 @@ static int gemm_pair_impl(const scae_gemm_desc *first, const scae_gemm_desc *sec
   p.layout[1] = 2 * (second->a_kcontig != 0) + (second->b_kcontig != 0);
   const int M = first->M > second->M ? first->M : second->M;
   const int N = first->N > second->N ? first->N : second->N;
-  hipLaunchKernelGGL(gemm_pair_kernel<3>, dim3((N + 127) / 128, (M + 127) / 128,
+  scae::launch(gemm_pair_kernel<3>, dim3((N + 127) / 128, (M + 127) / 128,
                                                first->batch + second->batch),
                      dim3(NT), 0, (hipStream_t)stream, p);
   return scae_launch_status();

@@ -60,7 +60,7 @@ extern "C" int scae_geometric_transform_fwd_f32(const float *pose, float *out, i
                                                 int similarity, int nonlinear,
                                                 int as_matrix, void *stream) {
   SCAE_REQUIRE(pose && out && n > 0);
-  hipLaunchKernelGGL(gt_fwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
+  scae::launch(gt_fwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
                      (hipStream_t)stream, pose, out, n, similarity, nonlinear, as_matrix);
   return scae_launch_status();
 }
@@ -70,7 +70,7 @@ extern "C" int scae_geometric_transform_bwd_f32(const float *pose, const float *
                                                 int nonlinear, int as_matrix,
                                                 void *stream) {
   SCAE_REQUIRE(pose && gout && gpose && n > 0);
-  hipLaunchKernelGGL(gt_bwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
+  scae::launch(gt_bwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
                      (hipStream_t)stream, pose, gout, gpose, n, similarity, nonlinear,
                      as_matrix);
   return scae_launch_status();
@@ -134,7 +134,7 @@ extern "C" int scae_mat3_mul_fwd_f32(const float *left, const float *right, floa
                                      int64_t n_caps, int V, void *stream) {
   SCAE_REQUIRE(left && right && out && n_caps > 0 && V > 0);
   const int64_t n = n_caps * V;
-  hipLaunchKernelGGL(mat3_fwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
+  scae::launch(mat3_fwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
                      (hipStream_t)stream, left, right, out, n, V);
   return scae_launch_status();
 }
@@ -144,7 +144,7 @@ extern "C" int scae_mat3_mul_bwd_f32(const float *left, const float *right, cons
                                      void *stream) {
   SCAE_REQUIRE(left && right && gout && gright && n_caps > 0 && V > 0);
   const int per = NT / 64;
-  hipLaunchKernelGGL(mat3_bwd_kernel, dim3((unsigned)((n_caps + per - 1) / per)), dim3(NT), 0,
+  scae::launch(mat3_bwd_kernel, dim3((unsigned)((n_caps + per - 1) / per)), dim3(NT), 0,
                      (hipStream_t)stream, left, right, gout, gleft, gright, n_caps, V);
   return scae_launch_status();
 }

@@ -111,7 +111,7 @@ extern "C" int scae_layer_norm_fwd_f32(const float *x, const float *weight, cons
                                        float eps, void *stream) {
   SCAE_REQUIRE(x && y && mean && rstd && rows > 0 && d > 0);
   if (d > 64 * CPL) return SCAE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(scae_layer_norm_rows(rows)), dim3(NT), 0,
+  scae::launch(ln_fwd_kernel, dim3(scae_layer_norm_rows(rows)), dim3(NT), 0,
                      (hipStream_t)stream, x, weight, bias, y, mean, rstd, (long)rows, d, eps);
   return scae_launch_status();
 }
@@ -121,7 +121,7 @@ extern "C" int scae_layer_norm_bwd_f32(const float *x, const float *weight, cons
                                        float *partial, int64_t rows, int d, void *stream) {
   SCAE_REQUIRE(x && mean && rstd && gy && (gx || partial) && rows > 0 && d > 0);
   if (d > 64 * CPL) return SCAE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(scae_layer_norm_rows(rows)), dim3(NT), 0,
+  scae::launch(ln_bwd_kernel, dim3(scae_layer_norm_rows(rows)), dim3(NT), 0,
                      (hipStream_t)stream, x, weight, mean, rstd, gy, gx, partial, (long)rows, d);
   return scae_launch_status();
 }

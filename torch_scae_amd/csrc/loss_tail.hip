@@ -419,10 +419,10 @@ static size_t combine_lds(int O) { return (2 * O + 6 * (NTC_LARGE / 64)) * sizeo
 static void launch_combine(const TailArgs &a, const scae_loss_extras &x, const Ws &ws, float *out12,
                            hipStream_t st) {
   if (scae_loss_tail_defer_preferred(a.B, a.O))
-    hipLaunchKernelGGL(tail_combine_kernel<NT_SMALL>, dim3(1), dim3(NT_SMALL), combine_lds(a.O), st,
+    scae::launch(tail_combine_kernel<NT_SMALL>, dim3(1), dim3(NT_SMALL), combine_lds(a.O), st,
                        a, x, ws, out12);
   else
-    hipLaunchKernelGGL(tail_combine_kernel<NTC_LARGE>, dim3(1), dim3(NTC_LARGE), combine_lds(a.O),
+    scae::launch(tail_combine_kernel<NTC_LARGE>, dim3(1), dim3(NTC_LARGE), combine_lds(a.O),
                        st, a, x, ws, out12);
 }
 
@@ -465,7 +465,7 @@ static int tail_fwd(const float *lpp, const float *posterior, const float *caps_
   const Ws ws = carve_ws(workspace, B, O, ncls);
   hipStream_t st = (hipStream_t)stream;
   const int n_cp = cpa ? cpa->B + cpa->extra.n : 0;
-  hipLaunchKernelGGL(tail_image_kernel, dim3(B + n_cp), dim3(NTI), 3 * O * sizeof(float), st, a,
+  scae::launch(tail_image_kernel, dim3(B + n_cp), dim3(NTI), 3 * O * sizeof(float), st, a,
                      ws, cpa ? *cpa : scae_cp::Args{}, n_cp);
   if (!x.defer_combine)   // (else: the backward launch -- or scae_loss_tail_combine_f32)
     launch_combine(a, x, ws, out12, st);
@@ -555,7 +555,7 @@ extern "C" int scae_loss_tail_bwd_f32(const float *lpp, const float *posterior,
 #define SCAE_TAIL_BWD(NTH)                                                                       \
   do {                                                                                           \
     const int cls_blocks = label ? (ncls * O + ncls + NTH / 4 - 1) / (NTH / 4) : 0;              \
-    hipLaunchKernelGGL(tail_bwd_kernel<NTH>, dim3(B + cls_blocks + (x.defer_combine ? 1 : 0)),   \
+    scae::launch(tail_bwd_kernel<NTH>, dim3(B + cls_blocks + (x.defer_combine ? 1 : 0)),   \
                        dim3(NTH), lds, (hipStream_t)stream, a, x, ws, gout12, g_lpp, g_posterior, \
                        g_caps_presence, g_cls_w, g_cls_b);                                       \
   } while (0)

@@ -413,7 +413,7 @@ int launch_rb_bf(const Chain &c, void *stream) {
     if (e != hipSuccess) return (int)e;
   }
   const int blocks = c.G * ((c.B + RB - 1) / RB);
-  hipLaunchKernelGGL((chain_kernel<BWD, RBT, BF>), dim3(blocks), dim3(NT), lds, (hipStream_t)stream, c);
+  scae::launch((chain_kernel<BWD, RBT, BF>), dim3(blocks), dim3(NT), lds, (hipStream_t)stream, c);
   return scae_launch_status();
 }
 template <bool BWD, int RBT>

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(scae_noise::NT) void uniform_kernel(float *__restri
 
 extern "C" int scae_uniform_f32(float *out, int64_t n, uint64_t *state, void *stream) {
   SCAE_REQUIRE(out && state && n > 0);
-  hipLaunchKernelGGL(uniform_kernel, dim3(scae_noise::blocks_for(n)), dim3(scae_noise::NT), 0,
+  scae::launch(uniform_kernel, dim3(scae_noise::blocks_for(n)), dim3(scae_noise::NT), 0,
                      (hipStream_t)stream, out, n, state);
   return scae_launch_status();
 }

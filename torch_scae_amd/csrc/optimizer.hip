@@ -186,7 +186,7 @@ extern "C" int scae_stage_batch(float *dst_image, const float *src_image, int64_
                (n_label == 0 || (dst_label && src_label)));
   long blocks = (n_image / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-  hipLaunchKernelGGL(stage_batch_kernel, dim3((unsigned)blocks), dim3(256), 0,
+  scae::launch(stage_batch_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, dst_image, src_image, (long)n_image, dst_label,
                      src_label, (long)n_label);
   return scae_launch_status();
@@ -210,7 +210,7 @@ extern "C" int scae_rmsprop_step_f32(float *param, const float *grad, float *squ
             eps, momentum, weight_decay, grad_scale};
   long blocks = (n / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-  hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a,
+  scae::launch(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a,
                      head);
   return scae_launch_status();
 }
@@ -243,7 +243,7 @@ extern "C" int scae_rmsprop_sums_step_f32(float *param, float *grad, float *squa
   const long room = 2048 - sum_blocks;
   const long cap = room > 512 ? room : 512;
   blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
-  hipLaunchKernelGGL(rmsprop_sums_kernel, dim3((unsigned)(sum_blocks + blocks)), dim3(256), 0,
+  scae::launch(rmsprop_sums_kernel, dim3((unsigned)(sum_blocks + blocks)), dim3(256), 0,
                      (hipStream_t)stream, a, head, js, sum_blocks);
   return scae_launch_status();
 }

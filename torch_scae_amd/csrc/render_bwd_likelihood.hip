@@ -54,7 +54,7 @@ int launch(const scae_decoder_desc *d, const scae_k1::CellGeom &g, const scae_k1
     if (e != hipSuccess) return (int)e;
   }
   const int n_lk = lk.a.B < 1024 ? lk.a.B : 1024;
-  hipLaunchKernelGGL((bwd_cell_likelihood_kernel<C>), dim3(n_lk + (d->M + 1) * d->B), dim3(256),
+  scae::launch((bwd_cell_likelihood_kernel<C>), dim3(n_lk + (d->M + 1) * d->B), dim3(256),
                      lds, st, *d, x, lse_post, lse_prior, g_tile, lt.tiles, lt.ppb, g_templates,
                      g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,
                      g.chunk_rows, g.max_items, g.item_budget, lk, n_lk);

@@ -1150,7 +1150,7 @@ extern "C" int scae_template_render_fwd_f32(const scae_decoder_desc *d,
   const size_t lds = sizeof(float) * (size_t)(d->C + 1) * pad_elems(d->th, d->tw);
   int rc2 = set_lds(render_fwd_kernel, lds);
   if (rc2) return rc2;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(d->M + 1, d->B), dim3(NT), lds,
+  scae::launch(render_fwd_kernel, dim3(d->M + 1, d->B), dim3(NT), lds,
                      (hipStream_t)stream, *d, transformed_templates, mixing_logits);
   return scae_launch_status();
 }
@@ -1223,7 +1223,7 @@ int launch_logprob_fwd(const scae_decoder_desc *d, const float *x, float *log_pr
 #define SCAE_LAUNCH_LP2(KS, PD)                                                           \
   rc = set_lds(logprob_fwd_kernel<C, KS, PD>, lds);                                       \
   if (rc) return rc;                                                                      \
-  hipLaunchKernelGGL((logprob_fwd_kernel<C, KS, PD>), grid, dim3(NT), lds, st, *d, x,     \
+  scae::launch((logprob_fwd_kernel<C, KS, PD>), grid, dim3(NT), lds, st, *d, x,     \
                      log_prob, lse_post, lse_prior, ppb, block_sums)
 #define SCAE_LAUNCH_LP(KS)  \
   if (pad) {                \
@@ -1275,7 +1275,7 @@ int launch_bwd(const scae_decoder_desc *d, const float *x, const float *lse_post
 #define SCAE_LAUNCH_BWD(KERNEL, FU)                                                          \
   rc = set_lds(KERNEL<C, FU>, lds);                                                          \
   if (rc) return rc;                                                                         \
-  hipLaunchKernelGGL((KERNEL<C, FU>), grid, dim3(NT), lds, st, *d, x, lse_post, lse_prior,  \
+  scae::launch((KERNEL<C, FU>), grid, dim3(NT), lds, st, *d, x, lse_post, lse_prior,  \
                      g_logprob, g_tt, g_ml, g_templates, g_alpha_partial, g_pose, g_presence, \
                      g_bg_image, g_scalar_partial, rows, g_tile, lt.tiles, lt.ppb)
   if (scatter) {
@@ -1380,7 +1380,7 @@ template <int C>
 int launch_gmm_fwd(const float *loc, const float *ml, const float *sigma, const float *x,
                    float *out, int B, int K, int Cm, int64_t P, hipStream_t st) {
   const dim3 grid((unsigned)((P + NT - 1) / NT), B);
-  hipLaunchKernelGGL((gmm_logprob_fwd_kernel<C>), grid, dim3(NT), 0, st, loc, ml, sigma, x,
+  scae::launch((gmm_logprob_fwd_kernel<C>), grid, dim3(NT), 0, st, loc, ml, sigma, x,
                      out, K, Cm, P);
   return scae_launch_status();
 }
@@ -1391,7 +1391,7 @@ int launch_gmm_bwd(const float *loc, const float *ml, const float *sigma, const 
   hipError_t e = hipMemsetAsync(g_sigma_partial, 0, sizeof(float) * B, st);
   if (e != hipSuccess) return (int)e;
   const dim3 grid((unsigned)((P + NT - 1) / NT), B);
-  hipLaunchKernelGGL((gmm_logprob_bwd_kernel<C>), grid, dim3(NT), 0, st, loc, ml, sigma, x,
+  scae::launch((gmm_logprob_bwd_kernel<C>), grid, dim3(NT), 0, st, loc, ml, sigma, x,
                      g, g_loc, g_ml, g_sigma_partial, g_x, K, Cm, P);
   return scae_launch_status();
 }
@@ -1401,10 +1401,10 @@ int launch_gmm_mm(bool mode, const float *loc, const float *ml, const float *sig
                   hipStream_t st) {
   const dim3 grid((unsigned)((P + NT - 1) / NT), B);
   if (mode)
-    hipLaunchKernelGGL((gmm_mean_mode_kernel<C, true>), grid, dim3(NT), 0, st, loc, ml,
+    scae::launch((gmm_mean_mode_kernel<C, true>), grid, dim3(NT), 0, st, loc, ml,
                        sigma, out, maximum, K, Cm, P);
   else
-    hipLaunchKernelGGL((gmm_mean_mode_kernel<C, false>), grid, dim3(NT), 0, st, loc, ml,
+    scae::launch((gmm_mean_mode_kernel<C, false>), grid, dim3(NT), 0, st, loc, ml,
                        sigma, out, maximum, K, Cm, P);
   return scae_launch_status();
 }

@@ -43,7 +43,7 @@ int launch_c(const scae_decoder_desc *d, const LpTiling &t, const float *x, floa
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((logprob_wave_kernel<C>), dim3(t.tiles, d->B), dim3(t.ppb), lds, st, *d, x,
+  scae::launch((logprob_wave_kernel<C>), dim3(t.tiles, d->B), dim3(t.ppb), lds, st, *d, x,
                      log_prob, lse_post, lse_prior, t.ppb, block_sums);
   return scae_launch_status();
 }
@@ -167,7 +167,7 @@ int launch_render_c(const scae_decoder_desc *d, const RenderGeom &g, float *tt, 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((render_wave_kernel<C>), dim3(g.groups, d->B), dim3(g.threads), g.lds, st, *d,
+  scae::launch((render_wave_kernel<C>), dim3(g.groups, d->B), dim3(g.threads), g.lds, st, *d,
                      tt, ml, g.KG);
   return scae_launch_status();
 }
@@ -196,7 +196,7 @@ int launch_bwd_c(const scae_decoder_desc *d, const CellGeom &g, const float *x,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((bwd_cell_kernel<C, NTB>), dim3(d->M + 1, d->B), dim3(NTB), g.lds, st, *d, x,
+  scae::launch((bwd_cell_kernel<C, NTB>), dim3(d->M + 1, d->B), dim3(NTB), g.lds, st, *d, x,
                      lse_post, lse_prior, g_logprob, g_tile, lp_tiles, lp_ppb, g_templates,
                      g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,
                      g.chunk_rows, g.max_items, g.item_budget);

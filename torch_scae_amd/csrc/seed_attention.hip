@@ -465,9 +465,9 @@ int launch(SaArgs a, bool bwd, hipStream_t st) {
   }
   const int grid = scae_seed_attention_grid(a.B, a.O);
   if (bwd)
-    hipLaunchKernelGGL(sa_bwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
+    scae::launch(sa_bwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
   else
-    hipLaunchKernelGGL(sa_fwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
+    scae::launch(sa_fwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
   return scae_launch_status();
 }
 }  // namespace

@@ -503,9 +503,9 @@ int launch_nt(const SwArgs &a, bool bwd, hipStream_t st) {
   }
   const dim3 grid(a.B < 512 ? a.B : 512);
   if (bwd)
-    hipLaunchKernelGGL((saw_bwd_kernel<NT, BF>), grid, dim3(NTH), lds, st, a);
+    scae::launch((saw_bwd_kernel<NT, BF>), grid, dim3(NTH), lds, st, a);
   else
-    hipLaunchKernelGGL((saw_fwd_kernel<NT, BF>), grid, dim3(NTH), lds, st, a);
+    scae::launch((saw_fwd_kernel<NT, BF>), grid, dim3(NTH), lds, st, a);
   return scae_launch_status();
 }
 int launch(const SwArgs &a, bool bwd, hipStream_t st) {
@@ -557,7 +557,7 @@ extern "C" int scae_seed_attention_mfma_reduce_f32(const float *partial, int row
   ReduceArgs r;
   int rc = reduce_args(r, partial, rows, q, wk, gq, gwk, gbk, gwv, gbv, O, C);
   if (rc) return rc;
-  hipLaunchKernelGGL(saw_reduce_kernel, dim3(reduce_blocks(r, RTH)), dim3(RTH), 0,
+  scae::launch(saw_reduce_kernel, dim3(reduce_blocks(r, RTH)), dim3(RTH), 0,
                      (hipStream_t)stream, r);
   return scae_launch_status();
 }

@@ -54,7 +54,7 @@ int launch(const scae_saw::SwArgs &a, const scae_gemm::GemmMulti &p, hipStream_t
     if (e != hipSuccess) return (int)e;
   }
   const int n_saw = a.B < 512 ? a.B : 512;   // = scae_seed_attention_mfma_rows(B)
-  hipLaunchKernelGGL((saw_bwd_gemm_kernel<NT, BF>), dim3(n_saw + p.first[p.n]), dim3(NTH), lds,
+  scae::launch((saw_bwd_gemm_kernel<NT, BF>), dim3(n_saw + p.first[p.n]), dim3(NTH), lds,
                      st, a, n_saw, p);
   return scae_launch_status();
 }

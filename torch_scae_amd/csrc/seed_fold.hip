@@ -232,7 +232,7 @@ extern "C" int scae_seed_fold_fwd_f32(const scae_seed_fold_desc *desc, void *str
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                  \
     }                                                                                      \
-    hipLaunchKernelGGL(fold_fwd_kernel<DD>, dim3(pl.blocks()), dim3(NT), lds, st, *desc, pl); \
+    scae::launch(fold_fwd_kernel<DD>, dim3(pl.blocks()), dim3(NT), lds, st, *desc, pl); \
   } break;
   switch (desc->D) {
     SCAE_FOLD_FWD(8) SCAE_FOLD_FWD(16) SCAE_FOLD_FWD(32)
@@ -257,11 +257,11 @@ extern "C" int scae_seed_fold_bwd_f32(const scae_seed_fold_desc *desc,
   const dim3 grid(pl.ncol + desc->C), block(desc->C, parts);
   hipStream_t st = (hipStream_t)stream;
   if (parts == 4)
-    hipLaunchKernelGGL(fold_bwd_kernel<4>, grid, block, lds, st, *desc, *g, pl);
+    scae::launch(fold_bwd_kernel<4>, grid, block, lds, st, *desc, *g, pl);
   else if (parts == 2)
-    hipLaunchKernelGGL(fold_bwd_kernel<8>, grid, block, lds, st, *desc, *g, pl);
+    scae::launch(fold_bwd_kernel<8>, grid, block, lds, st, *desc, *g, pl);
   else
-    hipLaunchKernelGGL(fold_bwd_kernel<16>, grid, block, lds, st, *desc, *g, pl);
+    scae::launch(fold_bwd_kernel<16>, grid, block, lds, st, *desc, *g, pl);
   return scae_launch_status();
 }
 #endif  // SCAE_DEVICE_ONLY

@@ -481,7 +481,7 @@ extern "C" int scae_qkv_attention_fwd_f32(const float *q, const float *k, const 
   const size_t lds = sizeof(float) * (size_t)(2 * Npad + Mpad) * LD;
   rc = raise_lds(reinterpret_cast<const void *>(attn_fwd_kernel), lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k, v,
+  scae::launch(attn_fwd_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k, v,
                      presence, out, probs, N, M, dk, dv, sqrt_dk);
   return scae_launch_status();
 }
@@ -495,7 +495,7 @@ extern "C" int scae_qkv_attention_fwd_bf16(const uint16_t *q, const uint16_t *k,
   if (big_set(N, M)) return SCAE_ERR_UNSUPPORTED;   // (the bf16 form has the tile limits)
   SCAE_REQUIRE(q && k && v && out && probs && sqrt_dk > 0.f);
   const size_t lds = sizeof(unsigned short) * 3 * (size_t)SCAE_ATTN_MAX_SET * LDH;
-  hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k,
+  scae::launch(attn_fwd_bf16_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k,
                      v, presence, out, probs, N, M, dk, dv, sqrt_dk);
   return scae_launch_status();
 }
@@ -515,7 +515,7 @@ extern "C" int scae_qkv_attention_bwd_f32(const float *q, const float *k, const 
   const size_t lds = sizeof(float) * (size_t)(3 * Npad + Mpad) * LD;
   rc = raise_lds(reinterpret_cast<const void *>(attn_bwd_kernel), lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k, v,
+  scae::launch(attn_bwd_kernel, dim3(HB), dim3(NT), lds, (hipStream_t)stream, q, k, v,
                      probs, gout, gq, gk, gv, gpresence, N, M, dk, dv, sqrt_dk);
   return scae_launch_status();
 }

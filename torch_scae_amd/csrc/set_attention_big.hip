@@ -120,7 +120,7 @@ int fwd(const float *q, const float *k, const float *v, const float *presence, f
   const size_t lds = sizeof(float) * (size_t)NW * M;
   int rc = raise(reinterpret_cast<const void *>(fwd_kernel), lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(fwd_kernel, dim3(HB), dim3(NT), lds, st, q, k, v, presence, out, probs, N, M,
+  scae::launch(fwd_kernel, dim3(HB), dim3(NT), lds, st, q, k, v, presence, out, probs, N, M,
                      dk, dv, sqrt_dk);
   return scae_launch_status();
 }
@@ -131,7 +131,7 @@ int bwd(const float *q, const float *k, const float *v, const float *probs, cons
   const size_t lds = sizeof(float) * (size_t)N * M;   // dS of one problem
   int rc = raise(reinterpret_cast<const void *>(bwd_kernel), lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(bwd_kernel, dim3(HB), dim3(NT), lds, st, q, k, v, probs, gout, gq, gk, gv,
+  scae::launch(bwd_kernel, dim3(HB), dim3(NT), lds, st, q, k, v, probs, gout, gq, gk, gv,
                      gpresence, N, M, dk, dv, sqrt_dk);
   return scae_launch_status();
 }

@@ -711,9 +711,9 @@ int launch(const StArgs &a, bool bwd, int grid, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
   }
   if (bwd)
-    hipLaunchKernelGGL(st_bwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
+    scae::launch(st_bwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
   else
-    hipLaunchKernelGGL(st_fwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
+    scae::launch(st_fwd_kernel<D>, dim3(grid), dim3(NT), lds, st, a);
   return scae_launch_status();
 }
 

@@ -951,9 +951,9 @@ static int launch_nt(const StArgs &a, bool bwd, int grid, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
   }
   if (bwd)
-    hipLaunchKernelGGL((stw_bwd_kernel<NT, BF>), dim3(grid), dim3(64 * NT), lds, st, a);
+    scae::launch((stw_bwd_kernel<NT, BF>), dim3(grid), dim3(64 * NT), lds, st, a);
   else
-    hipLaunchKernelGGL((stw_fwd_kernel<NT, BF>), dim3(grid), dim3(64 * NT), lds, st, a);
+    scae::launch((stw_fwd_kernel<NT, BF>), dim3(grid), dim3(64 * NT), lds, st, a);
   return scae_launch_status();
 }
 

@@ -144,7 +144,7 @@ extern "C" int scae_step_prologue_first_f32(float *dst_image, const float *src_i
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                     \
     }                                                                                         \
-    hipLaunchKernelGGL(step_prologue_kernel<CI>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p); \
+    scae::launch(step_prologue_kernel<CI>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p); \
   } break;
   switch (cin) {
     SCAE_PROLOGUE(0) SCAE_PROLOGUE(1) SCAE_PROLOGUE(2) SCAE_PROLOGUE(3) SCAE_PROLOGUE(4)

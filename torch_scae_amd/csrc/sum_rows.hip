@@ -31,7 +31,7 @@ extern "C" int scae_scaled_sums_f32(const scae_scaled_sum *jobs, int n_jobs, voi
     sj.j[i] = jobs[i];
     SCAE_REQUIRE(sj.j[i].src && sj.j[i].dst && sj.j[i].n > 0);
   }
-  hipLaunchKernelGGL(scaled_sums_kernel, dim3(n_jobs), dim3(1024), 0, (hipStream_t)stream, sj);
+  scae::launch(scaled_sums_kernel, dim3(n_jobs), dim3(1024), 0, (hipStream_t)stream, sj);
   return scae_launch_status();
 }
 
@@ -39,7 +39,7 @@ extern "C" int scae_sum_rows_multi_f32(const scae_sum_job *jobs, int n_jobs, voi
   Jobs js;
   const int blocks = fill_jobs(js, jobs, n_jobs);
   SCAE_REQUIRE(blocks > 0);
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, js);
+  scae::launch(sum_rows_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, js);
   return scae_launch_status();
 }
 

@@ -300,7 +300,7 @@ extern "C" int scae_template_color_fwd_f32(const float *logits, const float *fea
   int rc = check(k);
   if (rc) return rc;
   SCAE_REQUIRE(logits && feature && w1 && b1 && w2 && b2 && raw && templates && color);
-  hipLaunchKernelGGL(tc_fwd_kernel, dim3(B * k.splits), dim3(NT),
+  scae::launch(tc_fwd_kernel, dim3(B * k.splits), dim3(NT),
                      lds_floats(M / k.splits, C, F, H1, false) * sizeof(float),
                      (hipStream_t)stream, k);
   return scae_launch_status();
@@ -318,7 +318,7 @@ extern "C" int scae_template_color_bwd_f32(const float *logits, const float *fea
                     g_feature, partial, B, M, C, hw, F, H1, template_nonlin, color_nonlin);
   if (rc) return rc;
   const int nA = B * k.splits;
-  hipLaunchKernelGGL(tc_bwd_kernel, dim3(nA + bwd_elementwise_blocks(k)), dim3(NT),
+  scae::launch(tc_bwd_kernel, dim3(nA + bwd_elementwise_blocks(k)), dim3(NT),
                      lds_floats(M / k.splits, C, F, H1, true) * sizeof(float),
                      (hipStream_t)stream, k, nA);
   return scae_launch_status();

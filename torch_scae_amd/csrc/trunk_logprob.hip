@@ -71,7 +71,7 @@ int launch(const scae_st::StArgs &a, int n_trunk, const scae_decoder_desc *d,
     if (e != hipSuccess) return (int)e;
   }
   const int threads = t.ppb > 64 * NT ? t.ppb : 64 * NT;
-  hipLaunchKernelGGL((trunk_logprob_kernel<NT, C, BF>), dim3(n_trunk + t.tiles * d->B), dim3(threads),
+  scae::launch((trunk_logprob_kernel<NT, C, BF>), dim3(n_trunk + t.tiles * d->B), dim3(threads),
                      lds, st, a, n_trunk, *d, x, lse_post, lse_prior, t.ppb, t.tiles, tile_sums);
   return scae_launch_status();
 }

@@ -134,13 +134,15 @@ class TrainStep:
         self.use_graph = use_graph
         # how a captured step is re-issued: "graph" (hipGraphLaunch: ~10 us of host time and
         # ~8.6 us of device time between two replays, tools/graph_gap_probe.py) or "launches"
-        # (the recorded C-ABI launches, one by one on the current stream: no per-replay
-        # device cost -- 4-5 us per step at cfg-2 -- for ~350 us of host time per step,
-        # tools/launch_list_probe.py; single-rank steps only)
+        # (the library's record of the captured launches -- scae_launch_list_run: a
+        # hipLaunchKernel each on the current stream, no per-replay device cost: 0-5 us per
+        # step at cfg-2 depending on the host -- ~18 us of host time per launch leave little
+        # room beside a 550 us step --, tools/launch_list_probe.py; single-rank steps only)
         if replay not in ("graph", "launches"):
             raise ValueError("replay must be 'graph' or 'launches'")
         self.replay = replay
         self._launches = None
+        self._klist = None
         # independent kernels of the step sharing launches (ops.step_fusion:
         # the reconstruction likelihood rides with the object encoder's trunk)
         self.fuse_kernels = fuse_kernels
@@ -274,16 +276,29 @@ class TrainStep:
         mode = "thread_local" if dist.is_available() and dist.is_initialized() \
             else "global"
         from . import _lib
-        with torch.cuda.graph(self.graph, stream=s, capture_error_mode=mode), \
-                _lib.recorder() as launches:
-            self._part_a()
-            if not self.split:
-                self._part_b()
-                if not self.collective or self.in_graph_collective:
-                    self._finish()
-        # the step as a plain list of C-ABI launches (the graph holds exactly these when no
-        # collective is captured with them): replay_launches()
+        lib = _lib.load()
+        self._free_list()
+        recording = lib.scae_launch_list_begin() == 0   # (one recording per process at a time)
+        try:
+            with torch.cuda.graph(self.graph, stream=s, capture_error_mode=mode), \
+                    _lib.recorder() as launches:
+                self._part_a()
+                if not self.split:
+                    self._part_b()
+                    if not self.collective or self.in_graph_collective:
+                        self._finish()
+        finally:
+            klist = lib.scae_launch_list_end() if recording else None
+        # The step as a plain list of kernel launches (the graph holds exactly these when no
+        # collective is captured with them): the library's own record of every
+        # hipLaunchKernel the capture issued (kernel, grid, block, LDS, argument bytes --
+        # scae_launch_list_*), re-issued by replay_launches().  `launches` (the C-ABI calls
+        # with their ctypes arguments) keeps the buffers the list points into alive.
         self._launches = launches if not self.collective else None
+        if klist and not self.collective and not self.split:
+            self._klist = klist
+        elif klist:
+            lib.scae_launch_list_free(klist)
         if self.split:
             # part B allocates from part A's pool: the tensors A left for it
             # (saved activations, the cut gradients) are alive across the two
@@ -297,11 +312,24 @@ class TrainStep:
 
     def replay_launches(self):
         """The captured step re-issued launch by launch on the current stream instead of as a
-        graph replay (single-rank steps): no per-replay graph cost on the device."""
+        graph replay (single-rank steps): no per-replay graph cost on the device, one C call
+        (a hipLaunchKernel per recorded launch) on the host."""
         import ctypes
         from . import _lib
-        _lib.replay(self._launches, ctypes.c_void_p(
+        _lib.call("scae_launch_list_run", self._klist, ctypes.c_void_p(
             torch.cuda.current_stream(self.device).cuda_stream))
+
+    def _free_list(self):
+        if getattr(self, "_klist", None):
+            from . import _lib
+            _lib.load().scae_launch_list_free(self._klist)
+        self._klist = None
+
+    def __del__(self):
+        try:
+            self._free_list()
+        except Exception:      # (interpreter shutdown)
+            pass
 
     def capture(self):
         """Build the step's HIP graph(s) now instead of at the first call
@@ -393,7 +421,7 @@ class TrainStep:
                 if self.opt is not None:
                     self.opt.step(grad_scale=1.0 / self.world)
             else:
-                if self.replay == "launches" and self._launches is not None:
+                if self.replay == "launches" and self._klist:
                     self.replay_launches()
                 else:
                     self.graph.replay()
