@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from torch_scae_amd import ops
 B, G, Kin, dims = 128, 24, 256, [128, 32, 128, 199]
+if len(sys.argv) > 2 and sys.argv[2] == "cfg3":
+    B, G, Kin, dims = 1024, 64, 256, [128, 32, 128, 391]
 g = torch.Generator().manual_seed(0)
 layers, K = [], Kin
 for l, N in enumerate(dims):

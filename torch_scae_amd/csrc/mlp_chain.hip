@@ -32,6 +32,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SCAE_CHAIN_CH
 #define SCAE_CHAIN_CH 4   // 16-wide k steps per item: 64-wide chunks, 35 KB of weight tiles (8: 128-wide, 68 KB)
 #endif
+#ifndef SCAE_CHAIN_ABL
+// timing ablations (tools/chain_time.py, profiles/r05/chain_ablations.txt; results are garbage):
+// 1: no weight loads, 2: no MFMAs, 3: no MFMAs and no output stores
+#define SCAE_CHAIN_ABL 0
+#endif
 #ifndef SCAE_CHAIN_LB4
 #define SCAE_CHAIN_LB4 1
 #endif
@@ -133,6 +138,9 @@ __device__ __forceinline__ void fetch_item(const Layer &L, const float *W, int g
   // rows of the matrix: N (forward) / K (data gradient)
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(W), 0, (BWD ? L.K : L.N) * ldw * 4, 0x00020000);
+#if SCAE_CHAIN_ABL == 1   // (no weight loads)
+  if (ldw >= 0) return;
+#endif
   if (!BWD) {
     const int o = ((n0 + lane / QPR) * ldw + k0 + 4 * (lane % QPR)) * 4;
 #pragma unroll
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(NT, (RBT == 1 && SCAE_CHAIN_LB4) ? 4 : 2) void chai
           for (int s = 0; s < CH; ++s)
             if (ch * CH + s < nsteps) {   // (uniform)
               const float4 bw = ld4(brow + 16 * s);
+              if (SCAE_CHAIN_ABL >= 2 && cs >= 0) continue;
               if (BF) {
                 const bf16x4 bh = to_bf16(bw);
 #pragma unroll
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(NT, (RBT == 1 && SCAE_CHAIN_LB4) ? 4 : 2) void chai
               if (L.relu) v = fmaxf(v, 0.f);
               v = cok && gt[e] > 0.f ? v : 0.f;   // (also the zero padding of the next contraction)
               if (!last || (!BWD && c.votes)) nxt[row * ns + col] = v;
+              if (SCAE_CHAIN_ABL == 3 && cs >= 0) continue;
               if (out && cok && b < c.B) out[(size_t)b * L.out_bs + col] = v;
             }
           }
