@@ -171,7 +171,10 @@ class TrainStep:
         """forward + loss + backward (split: down to the decoders' inputs)."""
         plan = self.plan
         stale = plan.take_held_sums()
-        if stale:     # (a backward nobody followed by the optimiser: a capture's warm-ups)
+        if stale and not self._capturing:
+            # (a backward nobody followed by the optimiser; inside a capture they are the
+            # warm-ups' -- whose gradients nobody reads -- and are dropped: launched here they
+            # would become a launch of every replay)
             ops._launch_sum_units(stale)
         self.flat.clear_grads()
         with plan.active(), plan.precision(self.autocast_dtype is not None), \
