@@ -580,6 +580,11 @@ def test_recorded_launch_list_equals_graph_replay_bitwise():
             losses.append(float(step(images[i], labels[i])))
         torch.cuda.synchronize()
         assert step.graph is not None and len(step._launches) >= 15
+        # every column sum of the step rides in the optimiser's launch: none on its own
+        # (the warm-ups' held sums must not be flushed INTO the capture)
+        names = [getattr(fn, "__name__", "?") for fn, _, _ in step._launches]
+        assert "scae_rmsprop_sums_step_f32" in names, names
+        assert "scae_sum_rows_multi_f32" not in names, names
         from torch_scae_amd import _lib
         # (a C-ABI call is at least one kernel launch)
         assert _lib.load().scae_launch_list_size(step._klist) >= len(step._launches)
