@@ -2203,6 +2203,47 @@ def test_scaled_sums_alone_and_riding_in_class_probs():
                  1e-5, 1e-4, "posterior")
 
 
+def test_launch_list_replays_recorded_launches():
+    """scae_launch_list_*: the launches two entry points make while a list is recording are
+    re-issued by scae_launch_list_run on another stream with the recorded arguments -- the
+    outputs reappear after being wiped -- and nothing is recorded outside begin / end."""
+    import ctypes
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    g = torch.Generator().manual_seed(7)
+    pose = torch.randn(300, 6, generator=g).cuda()
+    out = torch.empty(300, 6, device="cuda")
+    src = torch.rand(1000, generator=g).cuda()
+    lab = torch.randint(0, 10, (16,), generator=g).cuda()
+    u = torch.empty(1000, device="cuda")
+    lab2 = torch.empty(16, dtype=torch.long, device="cuda")
+    st = P(torch.cuda.current_stream().cuda_stream)
+    assert lib.scae_launch_list_begin() == 0
+    _lib.call("scae_geometric_transform_fwd_f32", P(pose.data_ptr()), P(out.data_ptr()), 300,
+              0, 1, 0, st)
+    _lib.call("scae_stage_batch", P(u.data_ptr()), P(src.data_ptr()), 1000,
+              P(lab2.data_ptr()), P(lab.data_ptr()), 16, st)
+    lst = lib.scae_launch_list_end()
+    assert lib.scae_launch_list_size(lst) == 2
+    _lib.call("scae_geometric_transform_fwd_f32", P(pose.data_ptr()), P(out.data_ptr()), 300,
+              0, 1, 0, st)                       # (not recorded)
+    assert lib.scae_launch_list_size(lst) == 2
+    torch.cuda.synchronize()
+    ref_out = out.clone()
+    assert torch.equal(u, src) and torch.equal(lab2, lab)
+    out.zero_()
+    u.zero_()
+    lab2.zero_()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert lib.scae_launch_list_run(lst, P(side.cuda_stream)) == 0
+    side.synchronize()
+    lib.scae_launch_list_free(lst)
+    assert torch.equal(out, ref_out) and torch.equal(u, src) and torch.equal(lab2, lab)
+    assert float(ref_out.abs().max()) > 0
+
+
 def test_stage_batch_one_launch():
     import ctypes
     from torch_scae_amd import _lib

@@ -28,6 +28,21 @@ def test_library_exports_every_declared_symbol():
     assert b"limits" in lib.scae_error_string(-2)
 
 
+def test_launch_list_bookkeeping_without_a_gpu():
+    """scae_launch_list_*: one recording at a time, an empty recording is a list of size 0,
+    running nothing is a no-op (no HIP call is made for an empty list)."""
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    assert lib.scae_launch_list_begin() == 0
+    assert lib.scae_launch_list_begin() == -1          # already recording
+    lst = lib.scae_launch_list_end()
+    assert lst and lib.scae_launch_list_size(lst) == 0
+    assert lib.scae_launch_list_run(lst, None) == 0
+    lib.scae_launch_list_free(lst)
+    assert not lib.scae_launch_list_end()              # none open
+    assert lib.scae_launch_list_run(None, None) == -1
+
+
 def test_launchers_reject_bad_arguments_without_a_gpu():
     """Argument validation happens before any HIP call."""
     from torch_scae_amd import _lib
