@@ -82,6 +82,9 @@ def parse():
                     help="take the rank-launcher + RCCL process-group path even "
                          "for --gpus 1 (a 1-rank nccl group; proves the N>1 "
                          "plumbing on a 1-GPU box)")
+    ap.add_argument("--in-graph-probe-s", type=float, default=30.0,
+                    help="N > 1, --comm-mode auto: time limit of the guarded probe (build, "
+                         "capture, two replays) of the all-reduce captured inside the graph")
     ap.add_argument("--watchdog-s", type=float, default=1500.0,
                     help="a rank process ends itself (exit code 3) when the run takes longer "
                          "than this; 0: no watchdog")
@@ -703,8 +706,29 @@ def extra_workloads(device, budget_s=25.0):
     return out
 
 
+def guarded(fn, seconds):
+    """fn() on a worker thread, given up after `seconds`: (result, error).  A call that
+    does not return (a collective captured into a HIP graph that stalls on real ranks) leaves
+    its thread behind -- a daemon, abandoned at exit -- and an error here, instead of a rank
+    that waits until the watchdog ends it."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn()
+        except Exception as e:      # noqa: BLE001 (recorded, not raised)
+            box["err"] = repr(e)[:200]
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, f"no result after {seconds:g} s (guarded probe given up)"
+    return box.get("out"), box.get("err")
+
+
 def probe_modes(make, which, images, labels, barrier, reduce_max, steps=40,
-                warmup=10, blocks=3, agree=None):
+                warmup=10, blocks=3, agree=None, guard=(), guard_s=30.0):
     """ms per step of the collective modes `which` of TrainStep on the ranks at
     hand, each on a FRESH model (the step time depends on how far training has
     got, see capsule_state): the contract's timing procedure (barrier +
@@ -730,12 +754,26 @@ def probe_modes(make, which, images, labels, barrier, reduce_max, steps=40,
                                   "timed region"}
             continue
         step, err = None, None
-        try:
-            step = make(mode)
-            step.prepare(images[0], labels[0])     # build + capture, no step
+
+        def build(mode=mode, probe=mode in guard):
+            torch.cuda.set_device(images.device)   # (the current device is per host thread)
+            st = make(mode)
+            st.prepare(images[0], labels[0])       # build + capture, no step
             torch.cuda.synchronize()
-        except Exception as e:      # a mode this stack cannot build
-            err = repr(e)[:200]
+            if probe:                              # ... and two replays with the collective
+                for i in range(2):
+                    st(images[i % len(images)], labels[i % len(labels)])
+                torch.cuda.synchronize()
+            return st
+        if mode in guard:
+            # a mode that has never run on real ranks (the all-reduce captured INSIDE the
+            # graph): built and stepped twice under a time limit, every rank at once
+            step, err = guarded(build, guard_s)
+        else:
+            try:
+                step = build()
+            except Exception as e:      # a mode this stack cannot build
+                err = repr(e)[:200]
         ok = agree(err is None) if agree is not None else err is None
         if not ok:
             out[mode] = {"ms_per_step": None,
@@ -902,11 +940,20 @@ def main():
         # all-reduce captured INSIDE the graph has only ever run on a 1-rank group here, and a
         # capture that stalls on 8 ranks would cost the whole measurement; --comm-mode
         # "in graph" (or a 1-rank group) still measures it
+        # (round 6) ... so with real ranks it is tried LAST, behind a guard: build + capture +
+        # two replays on a worker thread with a time limit, and only if EVERY rank came
+        # through (the gloo agreement) is it timed and allowed into the automatic choice.
+        # A probe that stalls leaves the two measured schedules to choose from.
         auto = TrainStep.MODES if world == 1 else tuple(
-            m for m in TrainStep.MODES if m != "in graph")
+            m for m in TrainStep.MODES if m != "in graph") + ("in graph",)
         which = auto if mode == "auto" else (mode,)
-        modes = probe_modes(make, which + ("off",), images, labels, barrier,
-                            reduce_max, agree=agree)
+        guard = ("in graph",) if world > 1 and mode == "auto" else ()
+        # ("off" -- the collective-free build, whose ranks drift apart -- before the guarded
+        # probe: nothing is measured after a mode that may leave the communicator wedged)
+        order = tuple(m for m in which if m not in guard) + ("off",) + guard
+        modes = probe_modes(make, order, images, labels, barrier,
+                            reduce_max, agree=agree, guard=guard,
+                            guard_s=args.in_graph_probe_s)
         # per-rank diagnostics on stderr (rank 0's stdout carries the one JSON
         # line): what every rank measured, also when a mode raised
         print(f"[bench rank {rank}/{world}] rccl_ranks={rccl_ranks} "

@@ -12,7 +12,8 @@
  *
  * Conventions
  *   - plain pointers + sizes only; no torch types, no exceptions, no
- *     allocation, no global state, no implicit synchronisation;
+ *     allocation, no global state (the one stateful object, a launch list,
+ *     is a handle the caller holds), no implicit synchronisation;
  *   - every pointer is a DEVICE pointer to densely packed (contiguous,
  *     row-major, last index fastest) float32 unless stated otherwise; the
  *     caller owns every buffer, including the "saved"/"partial" workspaces;
@@ -33,7 +34,10 @@
 extern "C" {
 #endif
 
-#define SCAE_ABI_VERSION 1
+/* 2: scae_launch_list_begin(stream) -> handle; scae_conv3x3_relayout* write the packed
+ * fragment-major filter copy behind wf (scae_conv3x3_wf_floats); scae_mlp_chain_desc has
+ * row_tile / bf16 */
+#define SCAE_ABI_VERSION 2
 
 #define SCAE_OK 0
 #define SCAE_ERR_BAD_ARG (-1)      /* null pointer / non-positive size     */
@@ -48,19 +52,25 @@ int scae_abi_version(void);
 const char *scae_error_string(int code);
 
 /* Launch lists: a training step as the library's own record of its kernel launches.
- * Between scae_launch_list_begin() and scae_launch_list_end() every kernel launch any
- * entry point of this library issues (from any host thread; also into a capturing stream)
- * is appended to the list -- kernel, grid, block, LDS bytes, a copy of the argument bytes.
- * scae_launch_list_run re-issues them, in order, on `stream`: what replaying a captured
- * HIP graph of the same launches does, with a hipLaunchKernel per launch on the host and
- * without the graph's end-of-launch cost on the device.  The list holds pointers, not
- * buffers: the caller keeps every buffer the recorded launches use alive and unmoved.
- * One recording at a time per process (begin returns SCAE_ERR_BAD_ARG while one is open). */
-int scae_launch_list_begin(void);
-void *scae_launch_list_end(void); /* the list (NULL when none was open); free it with _free */
+ * scae_launch_list_begin(stream) opens a recording and returns its handle (NULL: out of
+ * memory).  Until scae_launch_list_end(list) every kernel launch that an entry point of
+ * this library SUCCESSFULLY issues on exactly that `stream` (from any host thread --
+ * autograd's backward worker launches there too; also into the stream while it is being
+ * captured) is appended to the list: kernel, grid, block, LDS bytes, a copy of the argument
+ * bytes.  Launches on other streams are not seen, and any number of recordings -- one per
+ * stream -- may be open at once: the recording is the only state, and the caller holds it.
+ * scae_launch_list_run re-issues the launches, in order, on `stream`: what replaying a
+ * captured HIP graph of the same launches does, with a hipLaunchKernel per launch on the
+ * host and without the graph's end-of-launch cost on the device.  The list holds pointers,
+ * not buffers: the caller keeps every buffer the recorded launches use alive and unmoved.
+ * Only this library's kernels are recorded -- a graph captured over the same region may
+ * hold other nodes (memsets, another library's kernels); whoever replays a list in place
+ * of a graph checks scae_launch_list_size against the graph's node count. */
+void *scae_launch_list_begin(void *stream);
+int scae_launch_list_end(void *list); /* stops recording; SCAE_ERR_BAD_ARG if not open */
 int scae_launch_list_size(const void *list);
 int scae_launch_list_run(const void *list, void *stream);
-void scae_launch_list_free(void *list);
+void scae_launch_list_free(void *list); /* (also ends a recording that is still open) */
 
 /* ------------------------------------------------------------------------
  * Presence-logit noise     replaces torch.rand_like (part_encoder.py:106,
@@ -505,6 +515,9 @@ int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *
  *          dw == NULL leaves the partials unreduced; wgrad_reduce_batch then
  *          reduces the partials of up to 8 layers in one launch (HOST arrays).
  * ---------------------------------------------------------------------- */
+/* floats a `wf` buffer of relayout / relayout_batch / first_fwd_relayout / the step prologue
+ * must hold for a (Cout, Cin) layer: Cout*9*Cin, doubled when the packed copy is written */
+int64_t scae_conv3x3_wf_floats(int Cout, int Cin);
 int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout, int Cin,
                               void *stream);
 /* the same for n_layers <= 8 layers in one launch; the five arrays are HOST arrays */
@@ -751,7 +764,8 @@ int scae_template_color_bwd_f32(const float *logits, const float *feature, const
  * 8 contiguous destinations: column j in [begin, end) of segment i goes to
  * segments[i].dst[j - begin]; with period > 0 the window [begin, end) of
  * every period-wide block of columns is gathered instead:
- * dst[(j / period) * (end - begin) + j % period - begin].  period = -W < 0:
+ * dst[(j / period) * (end - begin) + j % period - begin] (cols must be a
+ * multiple of period: SCAE_ERR_BAD_ARG otherwise).  period = -W < 0:
  * the window is an (n x W) matrix whose TRANSPOSE is written,
  * dst[((j - begin) % W) * n + (j - begin) / W] (an NHWC batch sum landing in
  * a (C,H,W) parameter).  Columns in no

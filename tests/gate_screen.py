@@ -48,13 +48,14 @@ import torch.nn.functional as F
 # 1e-4 .. 2e-4 for one in eight -- single gate flips the screen had let through.
 SAFETY = 8.0
 FLOOR = 2e-7          # ... but at least this (relative to the layer's max)
-MIN_KEPT_RATIO = 0.45      # full screens (the medium configurations of test_step_plan.py)
+MIN_KEPT_RATIO = 0.6       # full screens (the medium configurations of test_step_plan.py:
+                           # 0.645 and 0.844 observed, profiles/r05/gate_screen.txt)
 MIN_KEPT_IMPOSED = 0.9     # screens beside imposed gates: what is observed is >= 0.97
 LAST_STATS = []       # [(what, kept, drawn)] of the most recent calls
 ALL_STATS = []        # [(what, kept, drawn, skip)] of the whole session (conftest writes them out)
 # a unit whose gate the HIP side and the oracle decide differently has a pre-activation
 # this close to zero (relative to its layer's largest): fp32 round-off of a <= 1152-term sum
-DISAGREE_BAR = 2e-5
+DISAGREE_BAR = 2e-6       # (worst ever recorded: 2.1e-7, profiles/r05/gate_screen.txt)
 LAST_DISAGREEMENTS = []   # [(what, layer, units that differ, all units, worst |pre| / max)]
 
 

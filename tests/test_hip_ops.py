@@ -2204,9 +2204,11 @@ def test_scaled_sums_alone_and_riding_in_class_probs():
 
 
 def test_launch_list_replays_recorded_launches():
-    """scae_launch_list_*: the launches two entry points make while a list is recording are
+    """scae_launch_list_*: the launches two entry points make on the recording's stream are
     re-issued by scae_launch_list_run on another stream with the recorded arguments -- the
-    outputs reappear after being wiped -- and nothing is recorded outside begin / end."""
+    outputs reappear after being wiped -- and nothing is recorded after end.  A second
+    recording open at the same time on ANOTHER stream sees only that stream's launches (two
+    steps capturing in one process do not pollute each other's list)."""
     import ctypes
     from torch_scae_amd import _lib
     lib = _lib.load()
@@ -2214,33 +2216,49 @@ def test_launch_list_replays_recorded_launches():
     g = torch.Generator().manual_seed(7)
     pose = torch.randn(300, 6, generator=g).cuda()
     out = torch.empty(300, 6, device="cuda")
+    out_b = torch.empty(300, 6, device="cuda")
     src = torch.rand(1000, generator=g).cuda()
     lab = torch.randint(0, 10, (16,), generator=g).cuda()
     u = torch.empty(1000, device="cuda")
     lab2 = torch.empty(16, dtype=torch.long, device="cuda")
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
     st = P(torch.cuda.current_stream().cuda_stream)
-    assert lib.scae_launch_list_begin() == 0
+    st_b = P(other.cuda_stream)
+    lst = lib.scae_launch_list_begin(st)
+    lst_b = lib.scae_launch_list_begin(st_b)
+    assert lst and lst_b
     _lib.call("scae_geometric_transform_fwd_f32", P(pose.data_ptr()), P(out.data_ptr()), 300,
               0, 1, 0, st)
+    _lib.call("scae_geometric_transform_fwd_f32", P(pose.data_ptr()), P(out_b.data_ptr()),
+              300, 0, 1, 0, st_b)                # (the other recording's stream)
     _lib.call("scae_stage_batch", P(u.data_ptr()), P(src.data_ptr()), 1000,
               P(lab2.data_ptr()), P(lab.data_ptr()), 16, st)
-    lst = lib.scae_launch_list_end()
-    assert lib.scae_launch_list_size(lst) == 2
+    assert lib.scae_launch_list_end(P(lst)) == 0
+    assert lib.scae_launch_list_size(P(lst)) == 2
+    assert lib.scae_launch_list_size(P(lst_b)) == 1
     _lib.call("scae_geometric_transform_fwd_f32", P(pose.data_ptr()), P(out.data_ptr()), 300,
               0, 1, 0, st)                       # (not recorded)
-    assert lib.scae_launch_list_size(lst) == 2
+    assert lib.scae_launch_list_size(P(lst)) == 2
+    assert lib.scae_launch_list_end(P(lst_b)) == 0
     torch.cuda.synchronize()
     ref_out = out.clone()
-    assert torch.equal(u, src) and torch.equal(lab2, lab)
+    assert torch.equal(u, src) and torch.equal(lab2, lab) and torch.equal(out_b, ref_out)
     out.zero_()
+    out_b.zero_()
     u.zero_()
     lab2.zero_()
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
-        assert lib.scae_launch_list_run(lst, P(side.cuda_stream)) == 0
+        assert lib.scae_launch_list_run(P(lst), P(side.cuda_stream)) == 0
     side.synchronize()
-    lib.scae_launch_list_free(lst)
+    lib.scae_launch_list_free(P(lst))
     assert torch.equal(out, ref_out) and torch.equal(u, src) and torch.equal(lab2, lab)
+    assert float(out_b.abs().max()) == 0         # (list A holds nothing of stream B)
+    assert lib.scae_launch_list_run(P(lst_b), st) == 0
+    torch.cuda.synchronize()
+    lib.scae_launch_list_free(P(lst_b))
+    assert torch.equal(out_b, ref_out)
     assert float(ref_out.abs().max()) > 0
 
 

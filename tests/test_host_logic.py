@@ -24,23 +24,50 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.scae_abi_version() == 1
+    assert lib.scae_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.scae_conv3x3_wf_floats(128, 128) == 2 * 128 * 9 * 128   # (+ the packed copy)
+    assert lib.scae_conv3x3_wf_floats(8, 8) == 8 * 9 * 8
+    assert lib.scae_conv3x3_wf_floats(0, 8) == 0
     assert b"limits" in lib.scae_error_string(-2)
 
 
 def test_launch_list_bookkeeping_without_a_gpu():
-    """scae_launch_list_*: one recording at a time, an empty recording is a list of size 0,
-    running nothing is a no-op (no HIP call is made for an empty list)."""
+    """scae_launch_list_*: a recording is a handle bound to a stream -- several may be open at
+    once (two steps capturing in one process), each is ended and freed on its own; an empty
+    recording is a list of size 0, running it is a no-op (no HIP call is made), an open one
+    refuses to run."""
+    import ctypes
     from torch_scae_amd import _lib
     lib = _lib.load()
-    assert lib.scae_launch_list_begin() == 0
-    assert lib.scae_launch_list_begin() == -1          # already recording
-    lst = lib.scae_launch_list_end()
-    assert lst and lib.scae_launch_list_size(lst) == 0
-    assert lib.scae_launch_list_run(lst, None) == 0
-    lib.scae_launch_list_free(lst)
-    assert not lib.scae_launch_list_end()              # none open
+    P = ctypes.c_void_p
+    a = lib.scae_launch_list_begin(P(0x1000))           # (stream handles are only compared)
+    b = lib.scae_launch_list_begin(P(0x2000))
+    assert a and b and a != b
+    assert lib.scae_launch_list_run(P(a), None) == -1   # still recording
+    assert lib.scae_launch_list_end(P(a)) == 0
+    assert lib.scae_launch_list_end(P(a)) == -1         # not open any more
+    assert lib.scae_launch_list_size(P(a)) == 0
+    assert lib.scae_launch_list_run(P(a), None) == 0
+    lib.scae_launch_list_free(P(a))
+    lib.scae_launch_list_free(P(b))                     # (free also ends an open recording)
+    c = lib.scae_launch_list_begin(None)                # the null stream is a stream too
+    assert c and lib.scae_launch_list_end(P(c)) == 0
+    lib.scae_launch_list_free(P(c))
+    assert lib.scae_launch_list_end(None) == -1
     assert lib.scae_launch_list_run(None, None) == -1
+    assert lib.scae_launch_list_size(None) == 0
+
+
+def test_sum_jobs_reject_a_ragged_periodic_window():
+    """a periodic segment over a column count that is not a multiple of its period
+    has no well-defined destination range (the optimiser launch derives the elements a sum
+    workgroup owns from cols / period): rejected before any HIP call."""
+    import ctypes
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    seg = (_lib.SumSegment * 1)(_lib.SumSegment(ctypes.c_void_p(0x1000), 0, 4, 8))
+    assert lib.scae_sum_rows_f32(ctypes.c_void_p(0x2000), 4, 20, seg, 1, None) == -1
+    assert lib.scae_sum_rows_f32(None, 4, 24, seg, 1, None) == -1      # (null source)
 
 
 def test_launchers_reject_bad_arguments_without_a_gpu():

@@ -131,13 +131,22 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
         flat_noise = predict_noise(step)
         noise = split_noise(flat_noise, cfg, B)
         reuse = shared.get(it) if shared is not None else None
+        # the capsule MLPs' gates leave the screen only if they WILL be imposed: whether the
+        # model takes the kernel that keeps them (K7b) is asked of the model itself, on a
+        # probe image, before the batch is drawn (a model on the GEMM-by-GEMM
+        # form has its capsule gates screened like every other unit)
+        caps_imposed = False
+        if impose and reuse is None:
+            probe = torch.rand(B, *cfg["image_shape"],
+                               generator=torch.Generator().manual_seed(it))
+            caps_imposed = hip_gates(model, probe.cuda(), noise)[1] is not None
         if reuse is not None:
             assert torch.equal(reuse["noise"], flat_noise.cpu())
             image, label = reuse["image"], reuse["label"]
         elif screen:
             image, label = screened_batch_for_noise(
                 O, cfg, {k: p.detach() for k, p in P.items()}, noise, g,
-                n_classes=cfg["n_classes"], skip=n_conv, skip_caps=impose)
+                n_classes=cfg["n_classes"], skip=n_conv, skip_caps=caps_imposed)
         elif make_batch is not None:
             image, label = make_batch(it)
         else:
@@ -151,6 +160,7 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
             # the branch of every convolution unit as the HIP kernels decide it
             # (same parameters, same image: the step has not run yet)
             conv, caps = hip_gates(model, image.cuda(), noise)
+            assert (caps is not None) == caps_imposed
             with imposed_gates(O, conv, caps, f"{what} step {it}"):
                 ref_loss, _, ref_grads = O.train_step(P, ocfg, image, label,
                                                       noise)
@@ -585,15 +595,55 @@ def test_recorded_launch_list_equals_graph_replay_bitwise():
         names = [getattr(fn, "__name__", "?") for fn, _, _ in step._launches]
         assert "scae_rmsprop_sums_step_f32" in names, names
         assert "scae_sum_rows_multi_f32" not in names, names
-        from torch_scae_amd import _lib
-        # (a C-ABI call is at least one kernel launch)
-        assert _lib.load().scae_launch_list_size(step._klist) >= len(step._launches)
+        if mode == "launches":
+            from torch_scae_amd import _lib
+            # the list is taken because the graph holds exactly its launches, nothing else;
+            # (a C-ABI call is at least one kernel launch)
+            assert step._klist, step.graph_nodes
+            nodes, kernels, recorded = step.graph_nodes
+            assert nodes == kernels == recorded >= len(step._launches), step.graph_nodes
+            assert _lib.load().scae_launch_list_size(step._klist) == recorded
+        else:
+            assert step._klist is None
         out.append((losses, step.flat.flat_param.clone(), step.opt.square_avg.clone(),
                     step.opt.buf.clone(), step.flat.flat_grad.clone()))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     for a, b, what in zip(out[0][1:], out[1][1:], ("param", "square_avg", "buf", "grad")):
         assert torch.equal(a, b), what
     assert float(out[0][4].abs().max()) > 0
+
+
+def test_launch_replay_steps_aside_for_a_graph_with_other_nodes():
+    """``training_step()`` computes the accuracy and copies the log values with
+    torch kernels -- nodes of the captured graph that the library's launch list does not
+    hold.  ``replay="launches"`` must then replay the GRAPH (the list would freeze the log at
+    its capture-time values): the log of three steps on three batches equals the graph
+    mode's, entry for entry, and changes from step to step.  Two steps built in one process,
+    each with its own recording."""
+    cfg, B, sd, g = full_size_params("cfg2_bs32")
+    images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
+    labels = torch.randint(0, cfg["n_classes"], (3, B), generator=g).cuda()
+    logs = {}
+    steps = []
+    for mode in ("graph", "launches"):
+        model, step = build_step(cfg, B, sd, replay=mode)
+        steps.append(step)             # (both stay alive: two captured steps in one process)
+        rows = []
+        for i in range(3):
+            out = step.training_step(images[i], labels[i])
+            torch.cuda.synchronize()
+            rows.append({k: float(v) for k, v in out["log"].items()})
+        logs[mode] = rows
+        if mode == "launches":
+            assert step._klist is None, "a graph with torch nodes must not be replayed as a list"
+            assert step.graph_nodes is None or step.graph_nodes[0] > step.graph_nodes[2]
+    assert logs["graph"] == logs["launches"], (logs["graph"], logs["launches"])
+    assert logs["graph"][0]["loss"] != logs["graph"][1]["loss"]
+    # the plain step of the same process still takes its list
+    model, step = build_step(cfg, B, sd, replay="launches")
+    step(images[0], labels[0])
+    torch.cuda.synchronize()
+    assert step._klist, step.graph_nodes
 
 
 def test_reset_noise_restarts_an_already_built_step():

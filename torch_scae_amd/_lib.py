@@ -196,8 +196,8 @@ SIGNATURES = {
                                               P],
     "scae_gemm_pair_f32": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     # the library's own record of a step's kernel launches (train_step.TrainStep)
-    "scae_launch_list_begin": [],
-    "scae_launch_list_end": [],
+    "scae_launch_list_begin": [P],
+    "scae_launch_list_end": [P],
     "scae_launch_list_size": [P],
     "scae_launch_list_run": [P, P],
     "scae_launch_list_free": [P],
@@ -209,6 +209,7 @@ SIGNATURES = {
     "scae_mlp_chain_votes_fwd_f32": [POINTER(MlpChainDesc), POINTER(VotesDesc), P],
     "scae_mlp_chain_votes_bwd_f32": [POINTER(MlpChainDesc), POINTER(VotesDesc), P],
     "scae_gemm_pair_bf16": [POINTER(GemmDesc), POINTER(GemmDesc), P],
+    "scae_conv3x3_wf_floats": [c_int, c_int],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_relayout_batch_f32": [c_int, P, P, P, P, P, P],
     "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
@@ -293,6 +294,14 @@ SIGNATURES = {
     "scae_gmm_mode_f32": [P] * 4 + [c_int] * 5 + [c_int64, P],
 }
 
+# (everything else returns int)
+_RESTYPES = {"scae_error_string": c_char_p,
+             "scae_loss_tail_workspace_floats": c_int64,
+             "scae_conv3x3_wf_floats": c_int64,
+             "scae_launch_list_begin": P,
+             "scae_launch_list_free": None}
+ABI_VERSION = 2     # SCAE_ABI_VERSION of the include/scae_hip.h this binding mirrors
+
 _lib = None
 
 
@@ -314,12 +323,13 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = c_char_p if name == "scae_error_string" else (
-            c_int64 if name == "scae_loss_tail_workspace_floats" else (
-                P if name == "scae_launch_list_end" else (
-                    None if name == "scae_launch_list_free" else c_int)))
+        fn.restype = _RESTYPES.get(name, c_int)
         if argtypes and argtypes[-1] is P and not name.startswith("scae_launch_list"):
             setattr(lib, name, _recording(fn))     # a launcher: (..., void *stream)
+    if lib.scae_abi_version() != ABI_VERSION:
+        raise ScaeHipError(
+            f"{LIB_PATH} has ABI version {lib.scae_abi_version()}, this package "
+            f"binds version {ABI_VERSION}: rebuild it (make -C torch_scae_amd/csrc)")
     _lib = lib
     return lib
 

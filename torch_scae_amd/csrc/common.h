@@ -16,25 +16,31 @@
     if (!(cond)) return SCAE_ERR_BAD_ARG; \
   } while (0)
 
-// Returns the hipError_t of the launch that was just enqueued (0 = success).
-static inline int scae_launch_status() {
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SCAE_OK : (int)e;
-}
-
 // ---- launches, and the list a training step replays --------------------------------------
 // Every kernel of this library is launched through scae::launch (the arguments of
-// hipLaunchKernelGGL).  While a launch list is being recorded (scae_launch_list_begin /
-// _end, abi.hip) each launch is also appended to it -- kernel, grid, block, LDS bytes and a
-// copy of its arguments -- and scae_launch_list_run re-issues the list on a stream: what a
-// captured HIP graph of the same launches does, without the ~8.6 us the end of a graph launch
-// costs on the device and without the launchers' host-side
-// planning.  The list holds pointers, not buffers: whoever replays it keeps them alive.
+// hipLaunchKernelGGL).  While a launch list is recording on the launch's stream
+// (scae_launch_list_begin(stream) / _end, abi.hip) each SUCCESSFUL launch is also appended to
+// it -- kernel, grid, block, LDS bytes and a copy of its arguments -- and
+// scae_launch_list_run re-issues the list on a stream: what a captured HIP graph of the same
+// launches does, without the ~8.6 us the end of a graph launch costs on the device
+//  and without the launchers' host-side planning.  The list
+// holds pointers, not buffers: whoever replays it keeps them alive.
 namespace scae_rec {
-bool recording();   // (a relaxed flag: no cost when nothing records)
-void append(const void *fn, dim3 grid, dim3 block, size_t lds, void *const *args,
-            const size_t *sizes, int n);
+bool recording();   // (a relaxed counter: no cost when nothing records)
+void append(const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t st,
+            void *const *args, const size_t *sizes, int n);
+void note_launch_error(int e);   // per host thread
+int take_launch_error();
 }  // namespace scae_rec
+
+// Returns the hipError_t of the launch(es) this thread has just enqueued (0 = success): what
+// hipLaunchKernel itself returned to scae::launch, else the runtime's sticky last error.
+static inline int scae_launch_status() {
+  const int own = scae_rec::take_launch_error();
+  hipError_t e = hipGetLastError();
+  if (own) return own;
+  return e == hipSuccess ? SCAE_OK : (int)e;
+}
 
 namespace scae {
 template <class... KA, size_t... I, class... A>
@@ -43,10 +49,15 @@ inline void launch_impl(void (*kernel)(KA...), std::index_sequence<I...>, dim3 g
   static_assert(sizeof...(KA) == sizeof...(A), "one argument per kernel parameter");
   std::tuple<std::remove_cv_t<KA>...> held{static_cast<std::remove_cv_t<KA>>(args)...};
   void *ptrs[sizeof...(KA) + 1] = {const_cast<void *>(static_cast<const void *>(&std::get<I>(held)))...};
-  (void)hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, lds, st);
+  const hipError_t e =
+      hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, lds, st);
+  if (e != hipSuccess) {   // (a launcher that issues several kernels reports the first failure)
+    scae_rec::note_launch_error((int)e);
+    return;                // never recorded: a replay must not re-issue a launch that failed
+  }
   if (scae_rec::recording()) {
     const size_t sizes[sizeof...(KA) + 1] = {sizeof(std::remove_cv_t<KA>)...};
-    scae_rec::append(reinterpret_cast<const void *>(kernel), grid, block, lds, ptrs, sizes,
+    scae_rec::append(reinterpret_cast<const void *>(kernel), grid, block, lds, st, ptrs, sizes,
                      (int)sizeof...(KA));
   }
 }

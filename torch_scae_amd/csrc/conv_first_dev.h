@@ -26,6 +26,7 @@ __host__ __device__ inline size_t packed_index(int Cin, int co, int tap, int ci)
   const size_t chunk = (size_t)(co >> 5) * (9 * (Cin >> 5)) + tap * (Cin >> 5) + (ci >> 5);
   return ((chunk * 4 + ((ci & 15) >> 2)) * 64 + ((ci & 31) >> 4) * 32 + (co & 31)) * 4 + (ci & 3);
 }
+__host__ __device__ inline bool packed_copy(int Cout, int Cin) { return Cin % 32 == 0 && Cout % 32 == 0; }
 __device__ __forceinline__ void relayout_one(const float *w, float *wf, float *wd, int Cout,
                                              int Cin, int e) {
   if (e >= Cout * Cin * 9) return;
@@ -33,7 +34,7 @@ __device__ __forceinline__ void relayout_one(const float *w, float *wf, float *w
   const float v = w[e];
   wf[((size_t)co * 9 + tap) * Cin + ci] = v;
   wd[((size_t)ci * 9 + tap) * Cout + co] = v;
-  if (Cin % 32 == 0 && Cout % 32 == 0)
+  if (packed_copy(Cout, Cin))
     wf[(size_t)Cout * 9 * Cin + packed_index(Cin, co, tap, ci)] = v;
 }
 __device__ __forceinline__ void relayout_batch(const RelayoutBatch &r, int l, int e) {

@@ -1068,6 +1068,12 @@ inline int pipe_cfg(const char *env, long M, int N) {
 }
 }  // namespace
 
+extern "C" int64_t scae_conv3x3_wf_floats(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  const int64_t n = (int64_t)Cout * 9 * Cin;
+  return scae_first::packed_copy(Cout, Cin) ? 2 * n : n;
+}
+
 extern "C" int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout,
                                          int Cin, void *stream) {
   SCAE_REQUIRE(w && wf && wd && Cout > 0 && Cin > 0);

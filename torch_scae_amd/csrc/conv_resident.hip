@@ -176,7 +176,10 @@ bool res_plan(const ConvGeom &g, ResPlan &p, int force_g) {
   for (int G = 1; G <= 8 && G <= g.B; ++G) {
     if (force_g > 0 && G != force_g) continue;
     const int MI = (G * opix + 31) / 32;
-    const size_t lds = std::max((size_t)G * ipix * g.Cin * 4, (size_t)4 * MI * 16 * 64 * 4);
+    // (the staging DMA writes whole pieces of 64 lanes x 16 B: the image block is rounded up to
+    // a piece, or an odd G * ipix would put the last piece's zero half past the allocation)
+    const size_t stage = ((size_t)G * ipix * g.Cin * 4 + 1023) & ~(size_t)1023;
+    const size_t lds = std::max(stage, (size_t)4 * MI * 16 * 64 * 4);
     if (MI > 4 || lds > (force_g > 0 ? 150 : 64) * 1024) break;
     const double use = (double)G * opix / (32. * MI);
     if (use > best + 1e-9) best = use, p.G = G, p.MI = MI, p.lds = lds;

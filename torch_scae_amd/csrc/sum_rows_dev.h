@@ -88,6 +88,9 @@ inline int fill_jobs(Jobs &js, const scae_sum_job *jobs, int n_jobs) {
             g.end <= (g.period > 0 ? g.period : in.cols)))
         return -1;
       if (!(g.period >= 0 || (g.end - g.begin) % -g.period == 0)) return -1;
+      // a periodic window over a ragged last period has no well-defined destination range
+      // (rmsprop_sums_kernel derives the elements a sum workgroup owns from cols / period)
+      if (g.period > 0 && in.cols % g.period != 0) return -1;
     }
     // few rows: a thread per column; tall and skinny: many row parts per column
 #ifndef SCAE_SUMROWS_MID

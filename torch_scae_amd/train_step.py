@@ -137,12 +137,15 @@ class TrainStep:
         # (the library's record of the captured launches -- scae_launch_list_run: a
         # hipLaunchKernel each on the current stream, no per-replay device cost: 0-5 us per
         # step at cfg-2 depending on the host -- ~18 us of host time per launch leave little
-        # room beside a 550 us step --, tools/launch_list_probe.py; single-rank steps only)
+        # room beside a 550 us step --, tools/launch_list_probe.py; single-rank steps only,
+        # and only when the captured graph holds nothing but those launches: otherwise --
+        # e.g. training_step()'s log outputs, computed by torch kernels -- the graph replays)
         if replay not in ("graph", "launches"):
             raise ValueError("replay must be 'graph' or 'launches'")
         self.replay = replay
         self._launches = None
         self._klist = None
+        self.graph_nodes = None  # (graph nodes, kernel nodes, recorded launches) of a capture
         # independent kernels of the step sharing launches (ops.step_fusion:
         # the reconstruction likelihood rides with the object encoder's trunk)
         self.fuse_kernels = fuse_kernels
@@ -270,18 +273,27 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(s)
         # capture on the SAME stream the warm-up ran on: autograd caches each
         # parameter's AccumulateGrad node together with its stream
-        self.graph = torch.cuda.CUDAGraph()
-        self._capturing = True
+        # (keep_graph: the captured hipGraph_t stays readable -- _graph_is_only_launches)
+        try:
+            self.graph = torch.cuda.CUDAGraph(keep_graph=self.replay == "launches")
+        except TypeError:            # (a torch without keep_graph: graph replay only)
+            self.graph = torch.cuda.CUDAGraph()
         # With a process group alive its watchdog thread polls HIP events at
         # any time; under the default "global" capture mode such a poll during
         # the capture is an error that aborts the process.  Then (and only
         # then) the check is narrowed to the capturing thread.
         mode = "thread_local" if dist.is_available() and dist.is_initialized() \
             else "global"
+        import ctypes
         from . import _lib
         lib = _lib.load()
         self._free_list()
-        recording = lib.scae_launch_list_begin() == 0   # (one recording per process at a time)
+        # the library's record of the launches this capture issues: bound to the capturing
+        # stream, so another step's (or an eager forward's) launches on other streams are
+        # not in it (include/scae_hip.h, launch lists)
+        klist = lib.scae_launch_list_begin(ctypes.c_void_p(s.cuda_stream))
+        self._capturing = True
+        ok = False
         try:
             with torch.cuda.graph(self.graph, stream=s, capture_error_mode=mode), \
                     _lib.recorder() as launches:
@@ -290,28 +302,66 @@ class TrainStep:
                     self._part_b()
                     if not self.collective or self.in_graph_collective:
                         self._finish()
+            if klist:
+                lib.scae_launch_list_end(klist)
+            # The step as a plain list of kernel launches (scae_launch_list_*: kernel, grid,
+            # block, LDS, argument bytes), re-issued by replay_launches() -- but only when the
+            # graph holds exactly these: a captured torch kernel (training_step's accuracy
+            # and log copies), a memset inside a launcher or a collective is a node of the
+            # graph that the list does not have, and replaying the list would silently drop
+            # it.  `launches` (the C-ABI calls with their ctypes arguments) keeps the
+            # buffers the list points into alive.
+            self._launches = launches if not self.collective else None
+            if klist and not self.collective and not self.split \
+                    and self.replay == "launches" \
+                    and self._graph_is_only_launches(lib.scae_launch_list_size(klist)):
+                self._klist, klist = klist, None
+            if self.split:
+                # part B allocates from part A's pool: the tensors A left for it
+                # (saved activations, the cut gradients) are alive across the two
+                # captures, and the graphs are always replayed A, B, A, B, ...
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, stream=s,
+                                      pool=self.graph.pool(),
+                                      capture_error_mode=mode):
+                    self._part_b()
+            ok = True
         finally:
-            klist = lib.scae_launch_list_end() if recording else None
-        # The step as a plain list of kernel launches (the graph holds exactly these when no
-        # collective is captured with them): the library's own record of every
-        # hipLaunchKernel the capture issued (kernel, grid, block, LDS, argument bytes --
-        # scae_launch_list_*), re-issued by replay_launches().  `launches` (the C-ABI calls
-        # with their ctypes arguments) keeps the buffers the list points into alive.
-        self._launches = launches if not self.collective else None
-        if klist and not self.collective and not self.split:
-            self._klist = klist
-        elif klist:
-            lib.scae_launch_list_free(klist)
-        if self.split:
-            # part B allocates from part A's pool: the tensors A left for it
-            # (saved activations, the cut gradients) are alive across the two
-            # captures, and the graphs are always replayed A, B, A, B, ...
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, stream=s,
-                                  pool=self.graph.pool(),
-                                  capture_error_mode=mode):
-                self._part_b()
-        self._capturing = False
+            # (a capture that raised -- out of memory, an op that cannot be captured -- must
+            # not leave the step in capture mode: eager calls would drop held column sums
+            # and alias self.loss to a pool tensor)
+            self._capturing = False
+            if klist:
+                lib.scae_launch_list_free(klist)
+            if not ok:
+                self.graph = self.graph_b = None
+                self._launches = None
+                self._free_list()
+
+    def _graph_is_only_launches(self, n_launches):
+        """True when the captured graph's nodes are exactly ``n_launches`` kernel nodes (what
+        the library recorded): only then is the launch list the whole step.  Anything that
+        cannot be verified counts as a mismatch (the step then replays its graph)."""
+        import ctypes
+        try:
+            raw = self.graph.raw_cuda_graph()
+            hip = ctypes.CDLL("libamdhip64.so")
+            n = ctypes.c_size_t(0)
+            if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+                return False
+            nodes = (ctypes.c_void_p * max(1, n.value))()
+            if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+                return False
+            kernels = 0
+            for i in range(n.value):
+                t = ctypes.c_int(-1)
+                if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+                    return False
+                kernels += t.value == 0          # hipGraphNodeTypeKernel
+            self.graph_nodes = (n.value, kernels, n_launches)
+            return n.value == kernels == n_launches
+        except Exception:       # (no raw graph in this torch build, no HIP runtime handle)
+            return False
 
     def replay_launches(self):
         """The captured step re-issued launch by launch on the current stream instead of as a
