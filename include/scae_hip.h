@@ -36,7 +36,7 @@ extern "C" {
 
 /* 2: scae_launch_list_begin(stream) -> handle; scae_conv3x3_relayout* write the packed
  * fragment-major filter copy behind wf (scae_conv3x3_wf_floats); scae_mlp_chain_desc has
- * row_tile / bf16 */
+ * row_tile / bf16; scae_decoder_desc has bwd_resident */
 #define SCAE_ABI_VERSION 2
 
 #define SCAE_OK 0
@@ -68,9 +68,35 @@ const char *scae_error_string(int code);
  * of a graph checks scae_launch_list_size against the graph's node count. */
 void *scae_launch_list_begin(void *stream);
 int scae_launch_list_end(void *list); /* stops recording; SCAE_ERR_BAD_ARG if not open */
-int scae_launch_list_size(const void *list);
+int scae_launch_list_size(const void *list); /* kernel launches recorded (both lanes) */
 int scae_launch_list_run(const void *list, void *stream);
 void scae_launch_list_free(void *list); /* (also ends a recording that is still open) */
+/* Two lanes.  A HIP graph with a forked branch replays its branches one after the other on
+ * this stack, while kernels of two plain streams do run side by side
+ * (tools/probes/stream_overlap.cpp): a step whose backward has two independent chains is
+ * therefore recorded on TWO streams and re-issued on two.
+ *   _side_stream: launches on `side_stream` are recorded too, as lane 1 (once per list,
+ *     while it is open).
+ *   _order(later, earlier): the caller has just made `later_stream` wait for the work given
+ *     to `earlier_stream` so far (an event of its own: the library issues nothing here);
+ *     every open recording that holds both streams notes the edge at this position.  Returns
+ *     the number of recordings that did.
+ *   _run2: lane 0 on `stream`, lane 1 on `side_stream`, each noted edge re-issued as an
+ *     event record + stream wait (events owned by the list; one run of a list at a time).
+ *     side_stream NULL or equal to stream: everything in recorded order on `stream`
+ *     (= scae_launch_list_run).
+ *   _side_size: the launches of lane 1. */
+int scae_launch_list_side_stream(void *list, void *side_stream);
+int scae_launch_list_order(void *later_stream, void *earlier_stream);
+int scae_launch_list_run2(const void *list, void *stream, void *side_stream);
+int scae_launch_list_side_size(const void *list);
+int scae_launch_list_lane(const void *list, int i); /* lane of launch i (0 / 1), -1 past the end */
+/* Diagnostic: one run with a timing event in front of and behind every launch, on the
+ * launch's own stream; out_us[2 i], out_us[2 i + 1] = start / end of launch i in microseconds
+ * after the first (n_out >= 2 * size).  Synchronises both streams.  A kernel trace serialises
+ * the dispatches of a process; this shows the two lanes as they run. */
+int scae_launch_list_timeline(const void *list, void *stream, void *side_stream, float *out_us,
+                              int n_out);
 
 /* ------------------------------------------------------------------------
  * Presence-logit noise     replaces torch.rand_like (part_encoder.py:106,
@@ -1023,6 +1049,11 @@ typedef struct scae_decoder_desc {
   int B, M, C, th, tw, H, W;
   int template_repeat; /* > 1: templates is (B / template_repeat, M, C, th, tw) and images
                           r*k .. r*k + r-1 share template set k (forward only) */
+  int bwd_resident;    /* > 0 (scae_render_gmm_sums_bwd_f32 / _bwd_f32, alpha mode): the
+                          likelihood backward runs from this many resident workgroups, each
+                          walking (component, image) pairs, instead of one workgroup per
+                          pair -- same results; a launch that shares the chip with another
+                          stream's kernels.  0: one workgroup per pair */
 } scae_decoder_desc;
 
 /* materialise transformed_templates (B,K,C,H,W) and mixing_logits

@@ -178,6 +178,19 @@ MODEL_CASES = {
         TINY_BASE, n_part_caps=70, n_obj_caps=66,
         ocae_decoder_capsule_params=dict(dim_caps=4, hidden_sizes=(4,))),
         2, True),
+    # round 6: a reference-captured model on the TIMED path's kernel instantiations --
+    # 64-channel 3x3 layers (the implicit-GEMM encoder K8 / K8r instead of the vendor
+    # convolution the 8-channel fixtures fall back to), the defaults everywhere else:
+    # dim_hidden = 16 (the one-wave-per-tile trunk), 11 x 11 templates, capsule MLPs of
+    # hidden size 128 / 32 capsule parameters (the one-launch chain), a 64-wide object
+    # encoding (the folded output attention on the matrix cores; 256 would put the
+    # fixture past 3 MB)
+    "scae_kernels": (dict(
+        image_shape=(1, 24, 24), n_classes=4, n_part_caps=8, n_obj_caps=6,
+        pcae_cnn_encoder_params=dict(out_channels=[64, 64, 64],
+                                     kernel_sizes=[3, 3, 3], strides=[2, 1, 1]),
+        ocae_encoder_set_transformer_params=dict(dim_out=64),
+        scae_params=dict(reconstruct_alternatives=False)), 4, True),
 }
 
 

@@ -81,6 +81,48 @@ def test_scae_vs_golden(name):
         assert grads[k] is None or float(grads[k].abs().sum()) == 0.0, k
 
 
+def test_kernels_fixture_runs_on_the_timed_paths_entry_points():
+    """``scae_kernels`` (captured from the reference like the other model fixtures) is the
+    one whose shapes take the kernels the bench times: the implicit-GEMM encoder (64-channel
+    3x3 layers: K8 / K8r forward, the paired data + weight gradient launches) instead of the
+    vendor convolution, the one-wave-per-tile trunk (dim_hidden = 16), the folded output
+    attention on the matrix cores, the one-launch capsule-MLP chain with the votes riding,
+    the wave-form mixture likelihood and its cell-gather backward, the fused loss tail.
+    Asserted through the C-ABI calls the forward + backward make."""
+    from torch_scae_amd import _lib, nn_ext
+    blob, meta = load("scae_kernels")
+    noise = sub(blob, "noise/")
+    noise = [noise[k] for k in sorted(noise)]
+    with _lib.recorder() as launches:
+        model, res, loss, log = run_model(meta["config"], sub(blob, "param/"),
+                                          blob["in/image"], blob["in/label"], noise,
+                                          meta["train"])
+        loss.backward()
+    torch.cuda.synchronize()
+    names = {getattr(fn, "__name__", "?") for fn, _, _ in launches}
+    expected = {
+        "scae_conv3x3_first_fwd_relayout_f32", "scae_conv3x3_fwd_f32",
+        "scae_conv3x3_bwd_pair_f32", "scae_conv3x3_first_wgrad_reduce_f32",
+        "scae_capsule_head_fwd_f32", "scae_capsule_head_bwd_f32",
+        "scae_set_encoder_fwd_f32", "scae_set_encoder_bwd_f32",
+        "scae_seed_fold_fwd_f32", "scae_seed_fold_bwd_f32",
+        "scae_seed_attention_mfma_fwd_f32", "scae_seed_attention_mfma_bwd_f32",
+        "scae_mlp_chain_votes_fwd_f32", "scae_mlp_chain_votes_bwd_f32",
+        "scae_capsule_likelihood_fwd_f32", "scae_capsule_likelihood_bwd_f32",
+        "scae_render_gmm_logprob_sums_fwd_f32", "scae_render_gmm_sums_bwd_f32",
+        "scae_template_color_fwd_f32", "scae_template_color_bwd_f32",
+        "scae_loss_tail_fwd_f32", "scae_loss_tail_bwd_f32", "scae_class_probs_f32"}
+    assert expected <= names, sorted(expected - names)
+    enc = model.part_encoder.encoder
+    assert getattr(enc, "_hip_stack", False), "the encoder fell back to the vendor convolution"
+    lib = _lib.load()
+    st = meta["config"]["ocae_encoder_set_transformer_params"]
+    M, O = meta["config"]["n_part_caps"], meta["config"]["n_obj_caps"]
+    assert lib.scae_seed_attention_mfma_supported(M, O, 16, st["dim_out"]) == 1
+    assert lib.scae_seed_fold_supported(O, st["dim_out"], 16) == 1
+    assert abs(float(loss) - float(blob["out/loss"])) <= 1e-4 * abs(float(blob["out/loss"]))
+
+
 FULL = {
     # BASELINE.json configs[1]: MNIST 40x40, 24/24, bs=128, fp32
     "cfg2": (dict(image_shape=(1, 40, 40), n_classes=10, n_part_caps=24,

@@ -58,6 +58,34 @@ def test_launch_list_bookkeeping_without_a_gpu():
     assert lib.scae_launch_list_size(None) == 0
 
 
+def test_launch_list_lanes_and_order_edges_without_a_gpu():
+    """A recording with a side stream: stream-order edges the caller reports
+    (scae_launch_list_order) are noted by the recordings that hold BOTH streams, an edge
+    that is already implied (same edge, nothing given to the earlier lane since) is not
+    noted twice, and a list without launches runs as a no-op on one stream or two."""
+    import ctypes
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    a = lib.scae_launch_list_begin(P(0x10))
+    b = lib.scae_launch_list_begin(P(0x30))             # knows nothing of 0x20
+    assert lib.scae_launch_list_side_stream(P(a), P(0x20)) == 0
+    assert lib.scae_launch_list_side_stream(P(a), P(0x40)) == -1   # one side lane per list
+    assert lib.scae_launch_list_side_stream(P(b), P(0x30)) == -1   # not its own stream
+    assert lib.scae_launch_list_order(P(0x20), P(0x10)) == 1       # side waits for main: a
+    assert lib.scae_launch_list_order(P(0x20), P(0x10)) == 1       # (implied: not noted again)
+    assert lib.scae_launch_list_order(P(0x10), P(0x20)) == 1       # main waits for side
+    assert lib.scae_launch_list_order(P(0x20), P(0x30)) == 0       # no list holds both
+    assert lib.scae_launch_list_end(P(a)) == 0 and lib.scae_launch_list_end(P(b)) == 0
+    assert lib.scae_launch_list_order(P(0x20), P(0x10)) == 0       # nothing open
+    assert lib.scae_launch_list_size(P(a)) == 0 and lib.scae_launch_list_side_size(P(a)) == 0
+    assert lib.scae_launch_list_lane(P(a), 0) == -1
+    assert lib.scae_launch_list_run2(P(a), None, None) == 0        # (one stream: edges skipped)
+    assert lib.scae_launch_list_side_stream(P(a), P(0x50)) == -1   # closed
+    lib.scae_launch_list_free(P(a))
+    lib.scae_launch_list_free(P(b))
+
+
 def test_sum_jobs_reject_a_ragged_periodic_window():
     """a periodic segment over a column count that is not a multiple of its period
     has no well-defined destination range (the optimiser launch derives the elements a sum

@@ -613,6 +613,39 @@ def test_recorded_launch_list_equals_graph_replay_bitwise():
     assert float(out[0][4].abs().max()) > 0
 
 
+def test_two_lane_launch_replay_equals_graph_replay_bitwise():
+    """``TrainStep(replay="launches", two_lanes=True)``: K1's backward on a second stream,
+    as whole grid and from a fixed number of resident workgroups
+    (``scae_decoder_desc.bwd_resident``), the fork / join edges re-issued from the list's own
+    record.  Whatever the lanes' relative timing, loss, parameters, gradients and optimiser
+    state after three steps equal the graph replay's bit for bit (cfg-2, B = 128, noise on)."""
+    from torch_scae_amd import _lib
+    cfg, B, sd, g = full_size_params("cfg2")
+    images = torch.rand(3, B, *cfg["image_shape"], generator=g).cuda()
+    labels = torch.randint(0, cfg["n_classes"], (3, B), generator=g).cuda()
+    out = []
+    for mode, resident in (("graph", None), ("launches", 0), ("launches", 384)):
+        model, step = build_step(cfg, B, sd, replay=mode, two_lanes=mode == "launches")
+        if resident is not None:
+            step.plan.side_resident = resident
+        losses = [float(step(images[i], labels[i])) for i in range(3)]
+        torch.cuda.synchronize()
+        if mode == "launches":
+            lib = _lib.load()
+            assert step._klist, step.graph_nodes
+            # K1's backward alone on the side lane, the capsule likelihood's on its own
+            assert lib.scae_launch_list_side_size(step._klist) == 1
+            names = [getattr(fn, "__name__", "?") for fn, _, _ in step._launches]
+            assert "scae_render_gmm_sums_bwd_f32" in names, names
+            assert "scae_capsule_likelihood_bwd_f32" in names, names
+        out.append((losses, step.flat.flat_param.clone(), step.opt.square_avg.clone(),
+                    step.opt.buf.clone(), step.flat.flat_grad.clone()))
+    for other in out[1:]:
+        assert out[0][0] == other[0], (out[0][0], other[0])
+        for a, b, what in zip(out[0][1:], other[1:], ("param", "square_avg", "buf", "grad")):
+            assert torch.equal(a, b), what
+
+
 def test_launch_replay_steps_aside_for_a_graph_with_other_nodes():
     """``training_step()`` computes the accuracy and copies the log values with
     torch kernels -- nodes of the captured graph that the library's launch list does not

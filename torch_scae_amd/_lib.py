@@ -25,7 +25,7 @@ class DecoderDesc(Structure):
                 ("out_scale", P),
                 ("B", c_int), ("M", c_int), ("C", c_int), ("th", c_int),
                 ("tw", c_int), ("H", c_int), ("W", c_int),
-                ("template_repeat", c_int)]
+                ("template_repeat", c_int), ("bwd_resident", c_int)]
 
 
 class LikelihoodBwdDesc(Structure):
@@ -200,6 +200,12 @@ SIGNATURES = {
     "scae_launch_list_end": [P],
     "scae_launch_list_size": [P],
     "scae_launch_list_run": [P, P],
+    "scae_launch_list_side_stream": [P, P],
+    "scae_launch_list_order": [P, P],
+    "scae_launch_list_run2": [P, P, P],
+    "scae_launch_list_side_size": [P],
+    "scae_launch_list_lane": [P, c_int],
+    "scae_launch_list_timeline": [P, P, P, POINTER(c_float), c_int],
     "scae_launch_list_free": [P],
     "scae_gemm_multi_f32": [POINTER(GemmDesc), c_int, P],
     "scae_gemm_multi_bf16": [POINTER(GemmDesc), c_int, P],

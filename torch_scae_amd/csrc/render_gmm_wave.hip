@@ -185,6 +185,31 @@ __global__ __launch_bounds__(NTB) void bwd_cell_kernel(
   bwd_cell_body<C, NTB>(d, x, lse_post, lse_prior, g_logprob, g_tile, lp_tiles, lp_ppb, g_templates, g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial, chunk_rows, max_items, item_budget, smem, blockIdx.x, blockIdx.y);
 }
 
+// The same work from a FIXED number of resident workgroups, each walking (component, image)
+// pairs: a launch that leaves most of every CU's wave slots, registers and LDS to the
+// kernels of another stream (train_step's second lane: the whole-grid form floods the chip
+// with 3 200 workgroups of 27 KB, and the capsule-MLP chain's 85 KB workgroups on the main
+// lane then wait until it has drained).
+template <int C, int NTB>
+__global__ __launch_bounds__(NTB) void bwd_cell_walk_kernel(
+    scae_decoder_desc d, const float *__restrict__ x, const float *__restrict__ lse_post,
+    const float *__restrict__ lse_prior, const float *__restrict__ g_logprob,
+    const float *__restrict__ g_tile, int lp_tiles, int lp_ppb,
+    float *__restrict__ g_templates, float *__restrict__ g_alpha_partial,
+    float *__restrict__ g_pose, float *__restrict__ g_presence,
+    float *__restrict__ g_bg_image, float *__restrict__ g_scalar_partial, int chunk_rows,
+    int max_items, int item_budget) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = d.M + 1, total = K * d.B;
+  for (int id = blockIdx.x; id < total; id += gridDim.x) {   // (workgroup-uniform)
+    const int b = id / K, k = id - b * K;
+    bwd_cell_body<C, NTB>(d, x, lse_post, lse_prior, g_logprob, g_tile, lp_tiles, lp_ppb,
+                          g_templates, g_alpha_partial, g_pose, g_presence, g_bg_image,
+                          g_scalar_partial, chunk_rows, max_items, item_budget, smem, k, b);
+    __syncthreads();   // the next pair re-stages the planes
+  }
+}
+
 template <int C, int NTB>
 int launch_bwd_c(const scae_decoder_desc *d, const CellGeom &g, const float *x,
                  const float *lse_post, const float *lse_prior, const float *g_logprob,
@@ -195,6 +220,19 @@ int launch_bwd_c(const scae_decoder_desc *d, const CellGeom &g, const float *x,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_cell_kernel<C, NTB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
     if (e != hipSuccess) return (int)e;
+  }
+  const int resident = d->bwd_resident;
+  if (resident > 0 && resident < (d->M + 1) * d->B) {
+    if (g.lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_cell_walk_kernel<C, NTB>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    scae::launch((bwd_cell_walk_kernel<C, NTB>), dim3(resident), dim3(NTB), g.lds, st, *d, x,
+                 lse_post, lse_prior, g_logprob, g_tile, lp_tiles, lp_ppb, g_templates,
+                 g_alpha_partial, g_pose, g_presence, g_bg_image, g_scalar_partial,
+                 g.chunk_rows, g.max_items, g.item_budget);
+    return scae_launch_status();
   }
   scae::launch((bwd_cell_kernel<C, NTB>), dim3(d->M + 1, d->B), dim3(NTB), g.lds, st, *d, x,
                      lse_post, lse_prior, g_logprob, g_tile, lp_tiles, lp_ppb, g_templates,

@@ -70,9 +70,16 @@ def _bwd(f):
     (step_plan.RIDES) is launched first."""
     node = f.__qualname__
 
+    side = node in step_plan.SIDE_NODES
+
     @functools.wraps(f)
     def backward(ctx, *grads):
-        with step_plan.running(ctx.plan, node):
+        reads = ()
+        if side and ctx.plan.side_stream is not None:
+            # (everything the node reads that autograd hands it: incoming
+            # gradients and saved tensors)
+            reads = tuple(grads) + tuple(ctx.saved_tensors)
+        with step_plan.running(ctx.plan, node, reads):
             return f(ctx, *grads)
     return staticmethod(backward)
 
@@ -2870,6 +2877,11 @@ def _decoder_backward(ctx_tensors, output_size, needs, x, lse_post, lse_prior,
     (templates, alpha, pose, presence, bg_image, bg_value, bg_ml, temp,
      out_scale) = ctx_tensors
     d, (B, M, C, th, tw, H, W) = _make_desc(ctx_tensors, output_size)
+    # on a step's second lane the backward shares the chip with the main
+    # lane's launches: a fixed number of resident workgroups (step_plan)
+    lane_plan = _plan()
+    if lane_plan.side_stream is not None and lane_plan.side_open:
+        d.bwd_resident = int(lane_plan.side_resident)
     dev, dt = templates.device, templates.dtype
     g_templates = torch.empty_like(templates)
     g_alpha_p = torch.empty(B, M, th, tw, device=dev, dtype=dt) \
@@ -3067,8 +3079,11 @@ class _RenderGmmLogProbSums(torch.autograd.Function):
                                        # inside a fused training step, pose
                                        # and presence not the capsule
                                        # likelihood's own outputs)
+                                       # (with a second lane the launch goes
+                                       # there at once: step_plan.SIDE_NODES)
                                        park=ctx.plan.parking
-                                       and ctx.parkable))
+                                       and ctx.parkable
+                                       and ctx.plan.side_stream is None))
         if grads[1] is not None:
             grads[1] = grads[1].view(ctx.alpha_shape)
         return (None, None, None, None, *grads)

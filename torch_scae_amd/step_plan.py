@@ -96,6 +96,42 @@ RIDES = collections.OrderedDict([
 ])
 
 
+# The second lane (round 6).  Below the loss tail a step's backward has two chains that meet
+# again at the part-capsule head: the part decoder's likelihood backward (K1: 3 200
+# workgroups of VALU work, ~50 us at cfg-2, needs nothing but the loss tail's seed) and the
+# object path (capsule likelihood -> capsule-MLP chain -> output attention -> trunk: ~90 us
+# of latency-bound launches of one workgroup per image / set / capsule block, whose input
+# gradient for the special features the head's backward adds to K1's).  A forked HIP graph
+# replays its branches one after the other on this stack, but kernels of two plain streams
+# do overlap (tools/probes/stream_overlap.cpp), so a step that is re-issued launch by launch
+# (train_step.TrainStep(replay="launches")) gives K1's backward a stream of its own: the
+# launches and allocations of the nodes below happen on ``StepPlan.side_stream``.
+SIDE_NODES = frozenset(("_RenderGmmLogProbSums.backward",))
+# Plan-aware nodes of the main lane that do not read what a side node returned (the object
+# path).  Any OTHER node that starts while the side lane is open -- the readers of K1's
+# gradients: the template generator, the part-capsule head, the part encoder -- makes the
+# main lane wait for the side lane first.
+MAIN_NODES = frozenset((
+    "_LossTail.backward", "_ClassProbs.backward", "_CapsuleLikelihood.backward",
+    "_ChainVotes.backward", "_MLPChain.backward", "_GroupedMLP.backward",
+    "_CapsuleVotes.backward", "_SeedAttention.backward", "_SetEncoder.backward",
+    "_SeedFold.backward", "_PackParams.backward", "_Linear.backward",
+    "_LayerNorm.backward", "_QKVAttention.backward"))
+
+
+import os as _os
+_DEBUG = bool(_os.environ.get("SCAE_LANES_DEBUG"))
+
+
+def _note_order(later, earlier):
+    """Tell the library's open launch recordings about a stream dependency the caller has
+    just created (include/scae_hip.h, scae_launch_list_order)."""
+    import ctypes
+    from . import _lib
+    _lib.load().scae_launch_list_order(ctypes.c_void_p(later.cuda_stream),
+                                       ctypes.c_void_p(earlier.cuda_stream))
+
+
 class StepPlan:
     def __init__(self, name="step", prologue=None):
         _LIVE.add(self)
@@ -113,6 +149,59 @@ class StepPlan:
         self.prologue = prologue  # ops.StepPrologue or None
         self.bf16 = False         # configs[2]'s operand precision
         self.noise = {}           # (device, stream) -> (seed, generator state)
+        self.side_stream = None   # torch.cuda.Stream of the second lane (None: one lane)
+        # resident workgroups of the side lane's K1 backward (scae_decoder_desc.bwd_resident;
+        # 0: one workgroup per (component, image) pair, which floods the chip)
+        self.side_resident = int(_os.environ.get("SCAE_SIDE_RESIDENT", "512"))
+        self._main = None         # the stream the side lane forked from, while it is open
+
+    # -- the second lane ----------------------------------------------------
+    @contextlib.contextmanager
+    def side_lane(self, reads=()):
+        """The calling node's launches and allocations go to the side stream, which first
+        waits for everything the main stream has been given so far.  ``reads``: the
+        tensors the node reads -- those allocated on the main stream are marked as in use
+        by the side stream (inside a graph capture their memory is then not handed out
+        again before the capture ends)."""
+        import torch
+        side = self.side_stream
+        if side is None:
+            yield
+            return
+        main = torch.cuda.current_stream(side.device)
+        if main == side:          # (already there: a nested node)
+            yield
+            return
+        if _DEBUG:
+            print("[lanes] fork", flush=True)
+        side.wait_stream(main)
+        _note_order(side, main)
+        self._main = main
+        for t in reads:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            yield
+
+    def join_side(self):
+        """The main stream waits for the side lane (before its first launch that reads what
+        the side lane wrote; before the optimiser)."""
+        import torch
+        if self.side_stream is None or self._main is None:
+            return
+        if _DEBUG:
+            import traceback
+            print("[lanes] join from", traceback.extract_stack(limit=3)[0][2:4], flush=True)
+        main, self._main = self._main, None
+        cur = torch.cuda.current_stream(self.side_stream.device)
+        if cur != self.side_stream:     # (called from the main lane: the usual case)
+            main = cur
+        main.wait_stream(self.side_stream)
+        _note_order(main, self.side_stream)
+
+    @property
+    def side_open(self):
+        return self._main is not None
 
     # -- who is current ---------------------------------------------------
     @contextlib.contextmanager
@@ -183,6 +272,7 @@ class StepPlan:
     # -- deferred column sums ----------------------------------------------
     def flush_sums(self):
         if self.deferred:
+            self.join_side()     # (the units' partial matrices may be the side lane's)
             units = list(self.deferred)
             del self.deferred[:]
             from . import ops
@@ -226,6 +316,7 @@ class StepPlan:
             if outer is None:
                 try:
                     if ok:
+                        self.join_side()
                         self.flush_scope("deferring")
                         if self.sums_to_optimizer:
                             self.held_sums.extend(self.deferred)
@@ -268,12 +359,22 @@ def current():
 
 
 @contextlib.contextmanager
-def running(plan, node):
+def running(plan, node, reads=()):
     """For autograd's backward thread: ``plan`` is current while ``node`` (a
-    qualified method name) runs, and what ``node`` reads is launched first."""
+    qualified method name) runs, and what ``node`` reads is launched first.  A
+    node of the object path's backward (``SIDE_NODES``) runs on the plan's side
+    stream when it has one; ``reads``: the tensors it reads."""
     token = _CURRENT.set(plan)
     try:
         plan.enter(node)
-        yield plan
+        if plan.side_stream is not None and node in SIDE_NODES:
+            with plan.side_lane(reads):
+                yield plan
+        else:
+            if plan.side_open and node not in MAIN_NODES:
+                if _DEBUG:
+                    print(f"[lanes] join before {node}", flush=True)
+                plan.join_side()
+            yield plan
     finally:
         _CURRENT.reset(token)

@@ -23,6 +23,36 @@ EARLY_PREFIXES = ("obj_decoder.", "part_decoder.", "prior_classifier.",
                   "posterior_classifier.")
 
 
+def _side_stream(device, spec):
+    """The second lane's stream.  ``spec`` True: a stream of torch's pool; an int n (or the
+    string "n" / "n:stride"): a stream restricted to n compute units
+    (hipExtStreamCreateWithCUMask; every stride-th CU of the mask's numbering) -- the side
+    lane's kernel then leaves the other CUs to the main lane's launches."""
+    if spec is True:
+        return torch.cuda.Stream(device)
+    import ctypes
+    n, _, stride = str(spec).partition(":")
+    n, stride = int(n), int(stride or 1)
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    cu, taken = 0, 0
+    while taken < min(n, total):
+        if not mask[cu // 32] >> (cu % 32) & 1:
+            mask[cu // 32] |= 1 << (cu % 32)
+            taken += 1
+        cu = (cu + stride) % total
+        if stride > 1 and cu < stride and mask[cu // 32] >> (cu % 32) & 1:
+            cu += 1        # (wrapped onto a taken CU: shift the comb)
+    hip = ctypes.CDLL("libamdhip64.so")
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class TrainStep:
     """collective modes (world > 1, or ``force_collective`` in a 1-rank group):
 
@@ -54,7 +84,7 @@ class TrainStep:
                  lr_decay_rate=0.997, autocast_dtype=None,
                  force_collective=False, overlap=True, lazy_render=True,
                  prologue=True, fuse_kernels=True, collective_mode=None,
-                 replay="graph"):
+                 replay="graph", two_lanes=False):
         self.model = model
         self.device = next(model.parameters()).device
         self.world = world()[1]
@@ -143,6 +173,17 @@ class TrainStep:
         if replay not in ("graph", "launches"):
             raise ValueError("replay must be 'graph' or 'launches'")
         self.replay = replay
+        # replay="launches", two_lanes: the part decoder's likelihood backward (K1) on a
+        # second stream beside the object path's backward (step_plan.SIDE_NODES): kernels of
+        # two plain streams do overlap on this stack (branches of a replayed graph do not),
+        # and the recorded list re-issues the two lanes with their fork / join edges.
+        # Measured at cfg-2 (profiles/r06/lanes.txt): the lanes overlap and the step gets
+        # SLOWER -- 0.540 - 0.558 against 0.5205 ms: beside K1's workgroups the capsule-MLP
+        # chain runs 57 - 68 us instead of 31, the attention's backward 32 instead of 22;
+        # what the object path's launches leave idle is not what K1 needs.  Not the default.
+        self.plan.side_stream = _side_stream(self.device, two_lanes) if (
+            two_lanes and replay == "launches" and not self.collective
+            and self.device.type == "cuda") else None
         self._launches = None
         self._klist = None
         self.graph_nodes = None  # (graph nodes, kernel nodes, recorded launches) of a capture
@@ -292,6 +333,9 @@ class TrainStep:
         # stream, so another step's (or an eager forward's) launches on other streams are
         # not in it (include/scae_hip.h, launch lists)
         klist = lib.scae_launch_list_begin(ctypes.c_void_p(s.cuda_stream))
+        if klist and self.plan.side_stream is not None:
+            lib.scae_launch_list_side_stream(
+                klist, ctypes.c_void_p(self.plan.side_stream.cuda_stream))
         self._capturing = True
         ok = False
         try:
@@ -352,14 +396,17 @@ class TrainStep:
             nodes = (ctypes.c_void_p * max(1, n.value))()
             if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
                 return False
-            kernels = 0
+            kernels = other = 0
             for i in range(n.value):
                 t = ctypes.c_int(-1)
                 if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
                     return False
                 kernels += t.value == 0          # hipGraphNodeTypeKernel
-            self.graph_nodes = (n.value, kernels, n_launches)
-            return n.value == kernels == n_launches
+                # (what a forked capture adds carries no work: empty / event nodes -- the
+                # list re-issues the stream edges from its own record of them)
+                other += t.value not in (0, 5, 6, 7)   # ... Empty, WaitEvent, EventRecord
+            self.graph_nodes = (n.value - (n.value - kernels - other), kernels, n_launches)
+            return other == 0 and kernels == n_launches
         except Exception:       # (no raw graph in this torch build, no HIP runtime handle)
             return False
 
@@ -369,8 +416,10 @@ class TrainStep:
         (a hipLaunchKernel per recorded launch) on the host."""
         import ctypes
         from . import _lib
-        _lib.call("scae_launch_list_run", self._klist, ctypes.c_void_p(
-            torch.cuda.current_stream(self.device).cuda_stream))
+        side = self.plan.side_stream
+        _lib.call("scae_launch_list_run2", self._klist, ctypes.c_void_p(
+            torch.cuda.current_stream(self.device).cuda_stream),
+            None if side is None else ctypes.c_void_p(side.cuda_stream))
 
     def _free_list(self):
         if getattr(self, "_klist", None):
