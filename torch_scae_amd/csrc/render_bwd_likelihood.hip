@@ -70,9 +70,12 @@ extern "C" int scae_render_gmm_sums_bwd_likelihood_f32(
   SCAE_REQUIRE(d && k);
   const char *e = getenv("SCAE_FUSE_K1_K4_BWD");
   const scae_k1::CellGeom g = scae_k1::cell_geom(d);
+  // (the rider must not raise the launch's LDS above what K1's own workgroups need: at 48 / 64
+  // capsules its 39.5 KB against K1's 27 took a workgroup per CU from K1 -- B = 1024: 3.81 ms
+  // per step merged, 3.78 apart, profiles/r06/cfg3_fuse.txt)
   const bool fits = !(e && *e == '0') && g.lds && (d->C == 1 || d->C == 3) && k->O <= 64 &&
-                    scae_lk::lk_lds(k->O, k->M, true) <= 64 * 1024 && k->B > 0 && k->O > 0 &&
-                    k->M > 0 && d->template_repeat <= 1;
+                    scae_lk::lk_lds(k->O, k->M, true) <= g.lds && k->B > 0 && k->O > 0 &&
+                    k->M > 0 && d->template_repeat <= 1 && d->bwd_resident <= 0;
   if (!fits) {   // two launches, same results
     int rc = scae_render_gmm_sums_bwd_f32(d, x, lse_post, lse_prior, g_tile_sums, g_templates,
                                           g_alpha_partial, g_pose, g_presence, g_bg_image,
