@@ -67,6 +67,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="mnist_24_24_bs128",
                     choices=sorted(CONFIGS))
+    ap.add_argument("--replay", default="auto", choices=["auto", "graph", "launches"],
+                    help="how the captured step is re-issued: a HIP-graph replay, or the "
+                         "library's record of the captured kernel launches, one "
+                         "hipLaunchKernel each (TrainStep(replay=...): the same launches, "
+                         "bit-identical state).  auto (single rank): both are timed over 3 "
+                         "blocks and the faster runs the timed region")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-optimizer", action="store_true")
@@ -905,6 +911,10 @@ def main():
     def make(mode):
         return make_step(cfg, device, alternatives=args.alternatives,
                          use_graph=not args.no_graph,
+                         # (the capture keeps the library's launch list beside the graph;
+                         # which of the two re-issues the step is chosen below)
+                         replay="launches" if not collective and not args.no_graph
+                         and args.replay != "graph" else "graph",
                          optimizer=not args.no_optimizer,
                          autocast_dtype=torch.bfloat16 if args.bf16 else None,
                          force_collective=args.force_spawn,
@@ -984,6 +994,25 @@ def main():
     def after_block(b):
         per_block.append(brief_state(capsule_state(step.model, images[0])))
 
+    # graph replay or the launch list: the same launches either way; which is faster
+    # depends on the box (the graph costs ~9 us on the device per replay, the list ~220 -
+    # 360 us of host time per step beside a ~550 us step), so it is measured
+    replay_probe = None
+    has_list = bool(getattr(step, "_klist", None))
+    if not has_list:
+        step.replay = "graph"
+    elif args.replay == "auto":
+        replay_probe = {}
+        for how in ("graph", "launches"):
+            step.replay = how
+            t = timed_blocks(step, images, labels, args.steps, args.warmup, 3, barrier,
+                             reduce_max, before_block=before_block,
+                             refresh=(lambda: step.restore(snap))
+                             if args.steps > LIVE_SPAN else None)
+            replay_probe[how] = round(float(np.median(t)) / args.steps * 1e3, 4)
+        step.replay = min(replay_probe, key=replay_probe.get)
+    else:
+        step.replay = args.replay
     # the timed region of the contract -- W warm-ups, then EXACTLY K steps
     # between barrier + synchronize, MAX over ranks -- repeated `blocks` times
     # back to back, each from the restored state; the reported step time is
@@ -1007,15 +1036,21 @@ def main():
     # the same captured step re-issued from the library's record of its kernel launches
     # (TrainStep(replay="launches"), scae_launch_list_run: a hipLaunchKernel per launch, no
     # per-replay graph cost on the device)
-    if not collective and step.use_graph and getattr(step, "_klist", None):
-        step.replay = "launches"
+    timing["replay"] = step.replay if step.use_graph else "eager"
+    if replay_probe is not None:
+        timing["replay_probe_ms"] = replay_probe
+    if not collective and step.use_graph and has_list:
+        chosen = step.replay
+        other = "graph" if chosen == "launches" else "launches"
+        step.replay = other
         t3 = timing_summary(timed_blocks(
             step, images, labels, args.steps, args.warmup, max(1, min(7, args.blocks)),
             barrier, reduce_max, before_block=before_block,
             refresh=(lambda: step.restore(snap))
             if args.steps > LIVE_SPAN else None), args.steps)
-        step.replay = "graph"
-        timing["replay_as_launch_list_ms"] = t3["median_ms"]
+        step.replay = chosen
+        timing["replay_as_launch_list_ms" if other == "launches"
+               else "replay_as_graph_ms"] = t3["median_ms"]
     final_loss = float(step.loss)
     final_state = capsule_state(step.model, images[0])
     # "optimizer step reported separately" (the reference's step
