@@ -546,6 +546,35 @@ int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *
 int64_t scae_conv3x3_wf_floats(int Cout, int Cin);
 int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout, int Cin,
                               void *stream);
+
+/* K8 with bf16-RESIDENT operands (BASELINE configs[2]; csrc/conv_bf16.hip): the same three
+ * passes of part_encoder.py:26-44 / nn_ext.py:34-59 with every GEMM operand stored as bf16
+ * (uint16_t bit patterns, round-to-nearest-even of the fp32 values) -- NHWC activations,
+ * pre-activation gradients, the re-laid-out filters wf (Cout,9,Cin) / wd (Cin,9,Cout) --
+ * multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Cin, Cout % 128 == 0,
+ * stride 1 or 2, tensors below 2 GiB (scae_conv3x3_bf16r_supported).
+ *   cvt_bf16_batch: dst[a][0..n[a]) = bf16(src[a]) for up to 8 arrays (n[a] % 8 == 0) in one
+ *     launch; the three arrays are HOST arrays.
+ *   fwd:   out_h (bf16) = relu(conv(in, wf) + bias); out_f (nullable, fp32): the same values
+ *          unrounded; out_post (nullable, fp32) = relu(.) + post_bias (Cout,OH,OW).
+ *   dgrad: din = conv^T(dpre, wd), zeroed where gate <= 0 (gate: bf16 (B,IH,IW,Cin),
+ *          nullable), written as bf16 (din_h) and / or fp32 (din_f).
+ *   wgrad: partial = scae_conv3x3_wgrad_bf16r_splits(..) x (9*Cout*Cin + Cout) fp32 partials
+ *          in the layout of scae_conv3x3_wgrad_f32's (dw == NULL): the fp32 reduction
+ *          launches (wgrad_reduce_batch, first_wgrad_reduce) sum them. */
+int scae_conv3x3_bf16r_supported(int B, int IH, int IW, int Cin, int Cout, int stride);
+int scae_cvt_bf16_batch(int n_arrays, const float *const *src, uint16_t *const *dst,
+                        const int64_t *n, void *stream);
+int scae_conv3x3_fwd_bf16r(const uint16_t *in, const uint16_t *wf, const float *bias,
+                           uint16_t *out_h, float *out_f, const float *post_bias,
+                           float *out_post, int B, int IH, int IW, int Cin, int Cout, int stride,
+                           void *stream);
+int scae_conv3x3_dgrad_bf16r(const uint16_t *dpre, const uint16_t *wd, const uint16_t *gate,
+                             uint16_t *din_h, float *din_f, int B, int IH, int IW, int Cin,
+                             int Cout, int stride, void *stream);
+int scae_conv3x3_wgrad_bf16r_splits(int B, int OH, int OW, int Cin, int Cout);
+int scae_conv3x3_wgrad_bf16r(const uint16_t *dpre, const uint16_t *x, float *partial, int B,
+                             int IH, int IW, int Cin, int Cout, int stride, void *stream);
 /* the same for n_layers <= 8 layers in one launch; the five arrays are HOST arrays */
 int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const *w, float *const *wf,
                                     float *const *wd, const int *Cout, const int *Cin,

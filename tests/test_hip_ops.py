@@ -2624,11 +2624,13 @@ def _rel_l2(got, ref):
     return float((got - ref).norm() / (ref.norm() + 1e-30))
 
 
+@pytest.mark.parametrize("resident", [True, False])
 @pytest.mark.parametrize("B,HW,chans,strides", [
     (256, 40, [128, 128, 128], [2, 2, 1]),     # 128-channel layers: bf16 tiles
     (64, 24, [128, 128], [1, 1]),
+    (3, 29, [128, 128, 128, 128], [2, 2, 1, 1]),   # ragged tiles, every class of the stride-2 gradient
 ])
-def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides):
+def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides, resident, monkeypatch):
     """K8 with bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): outputs
     and weight / bias gradients against conv2d in fp64.  Bar: every operand is
     rounded to 8 significant bits (relative 2^-9), a K-long dot product of
@@ -2639,6 +2641,9 @@ def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides):
     <= 8e-2 relative L2 per tensor, the lower layers' being the worst."""
     import torch.nn.functional as F
     from torch_scae_amd import ops
+    # resident: the operands of layers 1.. kept as bf16 in HBM (csrc/conv_bf16.hip); else the
+    # first form, fp32 tensors rounded on their way into LDS -- the same rounded operands
+    monkeypatch.setattr(ops, "_CONV_BF16R", resident)
     g = torch.Generator().manual_seed(B + HW)
     image = torch.rand(B, 1, HW, HW, generator=g)
     ws, bs, cin = [], [], 1
@@ -2667,7 +2672,12 @@ def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides):
             y.backward(gy.cuda())
     finally:
         ops._lib.call = real
-    assert "scae_conv3x3_fwd_bf16" in calls and "scae_conv3x3_bwd_pair_bf16" in calls
+    if resident:
+        assert {"scae_conv3x3_fwd_bf16r", "scae_conv3x3_dgrad_bf16r",
+                "scae_conv3x3_wgrad_bf16r"} <= set(calls), calls
+        assert "scae_conv3x3_fwd_bf16" not in calls
+    elif B >= 64:    # (the first form needs a few 128 x 128 tiles per CU)
+        assert "scae_conv3x3_fwd_bf16" in calls and "scae_conv3x3_bwd_pair_bf16" in calls
     y_ref.backward(gy.double())
     assert _rel_l2(y, y_ref) <= 1e-2
     assert float((y.cpu().double() - y_ref).abs().max()) <= 2 ** -6 * float(y_ref.abs().max())

@@ -217,6 +217,12 @@ SIGNATURES = {
     "scae_gemm_pair_bf16": [POINTER(GemmDesc), POINTER(GemmDesc), P],
     "scae_conv3x3_wf_floats": [c_int, c_int],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
+    "scae_conv3x3_bf16r_supported": [c_int] * 6,
+    "scae_cvt_bf16_batch": [c_int, P, P, P, P],
+    "scae_conv3x3_fwd_bf16r": [P] * 7 + [c_int] * 6 + [P],
+    "scae_conv3x3_dgrad_bf16r": [P] * 5 + [c_int] * 6 + [P],
+    "scae_conv3x3_wgrad_bf16r_splits": [c_int] * 5,
+    "scae_conv3x3_wgrad_bf16r": [P] * 3 + [c_int] * 6 + [P],
     "scae_conv3x3_relayout_batch_f32": [c_int, P, P, P, P, P, P],
     "scae_conv3x3_first_fwd_f32": [P] * 4 + [c_int] * 6 + [P],
     "scae_conv3x3_first_fwd_relayout_f32": [P] * 4 + [c_int] * 7 + [P] * 6,

@@ -1,0 +1,546 @@
+// K8 with bf16-RESIDENT operands (BASELINE.json configs[2]: "bs=1024 bf16"): the 3x3 "valid"
+// convolutions of the part-capsule CNN encoder (part_encoder.py:26-44, nn_ext.py:34-59) and
+// their backward as implicit GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), with the
+// activations, the pre-activation gradients and the re-laid-out filters kept as bf16 in HBM.
+//
+// The first bf16 form (mfma_tile.h MODE 3) reads fp32 tensors and rounds them on their way
+// into LDS: twice the bytes per operand, a v_cvt per pair in the tile loop, 32-deep K chunks
+// staged through registers with a barrier every 8 MFMAs -- 0.07 of the bf16 matrix peak on the
+// backward pair.  Here every GEMM operand already IS bf16:
+//   * NHWC activations (B, H, W, C) as bf16: one (pixel, tap) row of the implicit A matrix is
+//     C contiguous bf16 -- 256 bytes at C = 128;
+//   * 128 x 128 output tiles, 2 x 2 waves of 64 x 64 (2 x 2 MFMA tiles: four 32x32x16 products
+//     per pair of 16-byte fragment reads), K walked in chunks of 64 (= one tap x 64 channels:
+//     128-byte LDS rows, 16 MFMAs per wave between barriers);
+//   * k-contiguous operands (forward, data gradient) go global -> LDS by DMA
+//     (buffer_load ... lds, 16 bytes per lane, 1 KiB per wave instruction) into two stages; the
+//     eight 16-byte quads of a 128-byte row are XOR-swizzled with (row >> 1) & 7 on the SOURCE
+//     address (the LDS image of a DMA piece is lane-linear), which makes the row-per-lane
+//     ds_read_b128 fragment reads conflict free; ONE barrier per chunk, the DMA of chunk c + 1
+//     runs under the MFMAs of chunk c;
+//   * k-strided operands (weight gradient: K = pixels) are loaded as (4 pixels) x (4 channels)
+//     blocks -- 8-byte loads, 256 bytes of a pixel per 32 lanes --, transposed in registers
+//     (v_perm_b32) and written into the same k-contiguous LDS image, so the three passes
+//     share one fragment-read / MFMA core;
+//   * the data gradient walks input pixels grouped by stride parity, each class only over the
+//     taps that reach it (no MFMA multiplies a structural zero of the stride-2 layer); rows whose
+//     tap falls outside the output read zeros through the buffer descriptor's range check.
+// Accumulation order over K is (tap, channel) ascending in 16-wide MFMA steps -- the order of
+// the first form, whose results these kernels reproduce to round-off of the fp32 accumulators.
+#include "mfma_pipe.h"
+#include "conv_first_dev.h"
+
+namespace {
+namespace pipe = scae_pipe;
+using scae_first::ConvGeom;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;   // storage type
+
+constexpr int NT = 256, TM = 128, TN = 128, BKE = 64;   // BKE: K chunk in elements
+constexpr int ROWB = 2 * BKE;                            // bytes per LDS row (128)
+constexpr int TILE_B = TM * ROWB;                        // 16 KiB per operand tile
+constexpr int STAGE_B = 2 * TILE_B;                      // A + B
+constexpr int LDS_B = 2 * STAGE_B;                       // two stages: 64 KiB
+constexpr int SLAB = 32 * 36;                            // epilogue: floats per wave
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 r = __builtin_convertvector((f2){lo, hi}, b2);   // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// slot of 16-byte quad g of LDS row `row`
+__device__ __forceinline__ int swz(int row, int g) { return g ^ ((row >> 1) & 7); }
+
+// ---- the MFMAs of one 64-deep chunk: stage = [A tile | B tile], rows of 128 bytes --------
+__device__ __forceinline__ void mma_chunk(const unsigned char *stage, f32x16 (&acc)[2][2], int wm,
+                                          int wn, int i, int kk) {
+  const unsigned char *As = stage, *Bs = stage + TILE_B;
+#pragma unroll
+  for (int s = 0; s < BKE / 16; ++s) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ra = wm * 64 + t * 32 + i, rb = wn * 64 + t * 32 + i;
+      a[t] = *reinterpret_cast<const bf16x8 *>(As + ra * ROWB + swz(ra, 2 * s + kk) * 16);
+      b[t] = *reinterpret_cast<const bf16x8 *>(Bs + rb * ROWB + swz(rb, 2 * s + kk) * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
+  }
+}
+
+// ---- accumulators out: epi(tile row, tile col (multiple of 8), 8 floats) ------------------
+// each wave's four 32 x 32 accumulator tiles pass one at a time through its private
+// [32][36] LDS slab and leave as rows of 8 consecutive columns per lane
+template <class Epi>
+__device__ __forceinline__ void tile_epilogue(float *smem, const f32x16 (&acc)[2][2], int wid,
+                                              int lane, Epi epi) {
+  const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  pipe::wg_barrier();   // the operand stages are dead: the slabs alias them
+  float *slab = smem + wid * SLAB;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * kk) * 36 + i] = acc[t][u][e];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own slab)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = (lane >> 2) + 16 * pass, c8 = 8 * (lane & 3);
+        const float4 v0 = pipe::lds4(slab + row * 36 + c8), v1 = pipe::lds4(slab + row * 36 + c8 + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        epi(wm * 64 + t * 32 + row, wn * 64 + u * 32 + c8, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// ---- the K loop of the DMA-staged passes --------------------------------------------------
+// issue(c, stage): this wave's 8 DMA pieces of chunk c (4 of the A tile, 4 of the B tile)
+template <class Issue>
+__device__ __forceinline__ void dma_mainloop(int nchunk, unsigned char *smem, f32x16 (&acc)[2][2],
+                                             int wid, int lane, Issue issue) {
+  const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  if (nchunk <= 0) return;
+  issue(0, smem);
+  for (int c = 0; c < nchunk; ++c) {
+    pipe::wait_vm<0>();   // this wave's pieces of chunk c have landed
+    pipe::wg_barrier();   // ... everyone's; and everyone is done reading the other stage
+    if (c + 1 < nchunk) issue(c + 1, smem + ((c + 1) & 1) * STAGE_B);
+    mma_chunk(smem + (c & 1) * STAGE_B, acc, wm, wn, i, kk);
+  }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+}
+
+// the rows a lane moves by DMA: piece j of wave w covers tile rows 32 w + 8 j .. + 7, lane l
+// the row 32 w + 8 j + (l >> 3) and the LDS slot l & 7 of it
+struct DmaRows {
+  int row[4];    // tile row of piece j
+  int lds[4];    // byte offset of the piece in an operand tile (wave-uniform)
+};
+__device__ __forceinline__ DmaRows dma_rows(int wid, int lane) {
+  DmaRows d;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    d.row[j] = 32 * wid + 8 * j + (lane >> 3);
+    d.lds[j] = (32 * wid + 8 * j) * ROWB;
+  }
+  return d;
+}
+// byte offset within a 128-byte source row of the quad that lands in this lane's LDS slot
+__device__ __forceinline__ int src_quad(int row, int lane) { return swz(row, lane & 7) * 16; }
+
+// ---- forward -------------------------------------------------------------------------------
+// out[m][co] = relu(sum_{tap, ci} in[pix(m, tap)][ci] wf[co][tap][ci] + bias[co])
+//   grid (Cout / 128, ceil(M / 128)); out_h bf16 NHWC; out_f / out_post (nullable) fp32
+__global__ __launch_bounds__(NT, 2) void conv_fwd_bf16r_kernel(
+    const bf16_t *__restrict__ in, const bf16_t *__restrict__ wf, const float *__restrict__ bias,
+    bf16_t *__restrict__ out_h, float *__restrict__ out_f, const float *__restrict__ post_bias,
+    float *__restrict__ out_post, ConvGeom g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int M = g.B * g.OH * g.OW;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const pipe::rsrc_t ra = pipe::make_rsrc(in, (unsigned)((size_t)g.B * g.IH * g.IW * g.Cin * 2));
+  const pipe::rsrc_t rb = pipe::make_rsrc(wf, (unsigned)((size_t)g.Cout * 9 * g.Cin * 2));
+  const DmaRows dr = dma_rows(wid, lane);
+  int va[4], vb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + dr.row[j];
+    va[j] = pipe::DMA_ZERO;
+    if (m < M) {
+      const int n = m / (g.OH * g.OW), rem = m - n * g.OH * g.OW, oh = rem / g.OW,
+                ow = rem - oh * g.OW;
+      va[j] = (((n * g.IH + oh * g.stride) * g.IW + ow * g.stride) * g.Cin) * 2 +
+              src_quad(dr.row[j], lane);
+    }
+    vb[j] = ((n0 + dr.row[j]) * 9 * g.Cin) * 2 + src_quad(dr.row[j], lane);
+  }
+  const int cpt = g.Cin / BKE;   // chunks per tap
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  dma_mainloop(9 * cpt, smem, acc, wid, lane, [&](int c, unsigned char *stage) {
+    const int tap = c / cpt, h = c - tap * cpt, kh = tap / 3, kw = tap - kh * 3;
+    const int sa = ((kh * g.IW + kw) * g.Cin + h * BKE) * 2, sb = (tap * g.Cin + h * BKE) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pipe::dma16(ra, reinterpret_cast<float *>(stage + dr.lds[j]), va[j], sa);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pipe::dma16(rb, reinterpret_cast<float *>(stage + TILE_B + dr.lds[j]), vb[j], sb);
+  });
+  const int hw = g.OH * g.OW;
+  tile_epilogue(reinterpret_cast<float *>(smem), acc, wid, lane,
+                [&](int row, int col, const float (&v)[8]) {
+    const int m = m0 + row, n = n0 + col;
+    if (m >= M) return;
+    const float4 b0 = pipe::lds4(bias + n), b1 = pipe::lds4(bias + n + 4);
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaxf(v[e] + bb[e], 0.f);
+    const size_t at = (size_t)m * g.Cout + n;
+    *reinterpret_cast<uint4 *>(out_h + at) =
+        make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+    if (out_f) {
+      *reinterpret_cast<float4 *>(out_f + at) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4 *>(out_f + at + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (out_post) {   // + the per-(channel, pixel) embedding bias, (Cout, OH, OW)
+      const float *pb = post_bias + (size_t)n * hw + m % hw;
+      float p[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p[e] = o[e] + pb[(size_t)e * hw];
+      *reinterpret_cast<float4 *>(out_post + at) = make_float4(p[0], p[1], p[2], p[3]);
+      *reinterpret_cast<float4 *>(out_post + at + 4) = make_float4(p[4], p[5], p[6], p[7]);
+    }
+  });
+}
+
+// ---- data gradient -------------------------------------------------------------------------
+// din[pixel][ci] = gate(sum over the taps that reach the pixel of dpre[.][co] wd[ci][tap][co]).
+// Input pixels are grouped by stride parity (one class at stride 1): class (ph, pw) holds
+// ih = s a + ph, iw = s b + pw and is reached by the taps kh = ph + s ti <= 2, kw = pw + s tj
+// <= 2 at the output pixel (a - ti, b - tj); a tap that falls outside the output reads zeros.
+struct DgradClasses {
+  int n;              // classes (1 or 4)
+  int tile_start[5];  // first tile (grid.y) of each class
+};
+// gate: the producing layer's ReLU output (bf16, nullable); din_h (bf16) or din_f (fp32)
+__global__ __launch_bounds__(NT, 2) void conv_dgrad_bf16r_kernel(
+    const bf16_t *__restrict__ dpre, const bf16_t *__restrict__ wd, const bf16_t *__restrict__ gate,
+    bf16_t *__restrict__ din_h, float *__restrict__ din_f, ConvGeom g, DgradClasses cl) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int s = g.stride;
+  int z = 0;
+#pragma unroll
+  for (int c = 1; c < 4; ++c)
+    if (c < cl.n && (int)blockIdx.y >= cl.tile_start[c]) z = c;
+  const int ph = s == 1 ? 0 : z >> 1, pw = s == 1 ? 0 : z & 1;
+  const int na = (g.IH - ph + s - 1) / s, nb = (g.IW - pw + s - 1) / s, M = g.B * na * nb;
+  const int nkh = (2 - ph) / s + 1, nkw = (2 - pw) / s + 1;
+  const int m0 = ((int)blockIdx.y - cl.tile_start[z]) * TM, n0 = blockIdx.x * TN;
+  const pipe::rsrc_t ra = pipe::make_rsrc(dpre, (unsigned)((size_t)g.B * g.OH * g.OW * g.Cout * 2));
+  const pipe::rsrc_t rb = pipe::make_rsrc(wd, (unsigned)((size_t)g.Cin * 9 * g.Cout * 2));
+  const DmaRows dr = dma_rows(wid, lane);
+  int pn[4], pa[4], pb[4], vb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + dr.row[j];
+    pn[j] = -1, pa[j] = 0, pb[j] = 0;
+    if (m < M) {
+      const int n = m / (na * nb), rem = m - n * na * nb;
+      pa[j] = rem / nb, pb[j] = rem - pa[j] * nb, pn[j] = n * g.OH * g.OW;
+    }
+    vb[j] = ((n0 + dr.row[j]) * 9 * g.Cout) * 2 + src_quad(dr.row[j], lane);
+  }
+  const int cpt = g.Cout / BKE;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  dma_mainloop(nkh * nkw * cpt, smem, acc, wid, lane, [&](int c, unsigned char *stage) {
+    const int t = c / cpt, h = c - t * cpt, ti = t / nkw, tj = t - ti * nkw;
+    const int kh = ph + s * ti, kw = pw + s * tj;
+    const int sb = ((kh * 3 + kw) * g.Cout + h * BKE) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int oh = pa[j] - ti, ow = pb[j] - tj;
+      const bool ok = pn[j] >= 0 && oh >= 0 && ow >= 0 && oh < g.OH && ow < g.OW;
+      const int v = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout) * 2 + src_quad(dr.row[j], lane)
+                       : pipe::DMA_ZERO;
+      pipe::dma16(ra, reinterpret_cast<float *>(stage + dr.lds[j]), v, h * BKE * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pipe::dma16(rb, reinterpret_cast<float *>(stage + TILE_B + dr.lds[j]), vb[j], sb);
+  });
+  tile_epilogue(reinterpret_cast<float *>(smem), acc, wid, lane,
+                [&](int row, int col, const float (&v)[8]) {
+    const int m = m0 + row;
+    if (m >= M) return;
+    const int n = m / (na * nb), rem = m - n * na * nb, a = rem / nb, b = rem - a * nb;
+    const size_t o = (((size_t)n * g.IH + a * s + ph) * g.IW + b * s + pw) * g.Cin + n0 + col;
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = v[e];
+    if (gate) {
+      const uint4 gt = *reinterpret_cast<const uint4 *>(gate + o);
+      const unsigned gw[4] = {gt.x, gt.y, gt.z, gt.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r[2 * e] = bf_lo(gw[e]) > 0.f ? r[2 * e] : 0.f;
+        r[2 * e + 1] = bf_hi(gw[e]) > 0.f ? r[2 * e + 1] : 0.f;
+      }
+    }
+    if (din_h)
+      *reinterpret_cast<uint4 *>(din_h + o) =
+          make_uint4(pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7]));
+    if (din_f) {
+      *reinterpret_cast<float4 *>(din_f + o) = make_float4(r[0], r[1], r[2], r[3]);
+      *reinterpret_cast<float4 *>(din_f + o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+    }
+  });
+}
+
+// ---- weight gradient -----------------------------------------------------------------------
+// partial[(split * 9 + tap)][co][ci] = sum over the split's pixels m of dpre[m][co] x[pix(m, tap)][ci];
+// bias partials [split][co] behind the 9 * splits slabs (the layout of the fp32 kernels: the
+// same reduction launch sums them).  grid (Cin / 128, Cout / 128, 9 * splits).
+// Both operands are k-strided in memory ([pixel][channel]): a thread loads (4 pixels) x (4
+// channels) blocks -- 8 bytes per pixel --, transposes them in registers and writes 8-byte
+// runs of 4 consecutive k into the k-contiguous LDS image the MFMA core reads.
+struct PixelWalk {   // (n, oh, ow) of a pixel index, advanced without divisions
+  int n, oh, ow;
+};
+__device__ __forceinline__ void walk(PixelWalk &p, int dq, int drm, const ConvGeom &g) {
+  p.ow += drm;
+  const int carry = p.ow >= g.OW;
+  p.ow -= carry ? g.OW : 0;
+  p.oh += dq + carry;
+  while (p.oh >= g.OH) p.oh -= g.OH, ++p.n;
+}
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16r_kernel(
+    const bf16_t *__restrict__ dpre, const bf16_t *__restrict__ x, float *__restrict__ partial,
+    ConvGeom g, int splits) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  const int M = g.B * g.OH * g.OW;
+  const int tap = blockIdx.z % 9, split = blockIdx.z / 9, kh = tap / 3, kw = tap - kh * 3;
+  const int per = ((M + splits - 1) / splits + BKE - 1) / BKE * BKE;
+  const int kbeg = split * per, kend = min(M, kbeg + per);
+  const int co0 = blockIdx.y * TM, ci0 = blockIdx.x * TN;
+  const bool want_bias = tap == 0 && blockIdx.x == 0;   // (workgroup-uniform)
+  // this thread's blocks: channel group chg (4 channels), pixel groups pxg + 8 j (4 pixels)
+  const int chg = tid & 31, pxg = tid >> 5;
+  PixelWalk pw_[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = kbeg + 4 * (pxg + 8 * j);
+    pw_[j].n = m / (g.OH * g.OW);
+    const int rem = m - pw_[j].n * g.OH * g.OW;
+    pw_[j].oh = rem / g.OW, pw_[j].ow = rem - pw_[j].oh * g.OW;
+  }
+  const int dq = BKE / g.OW, drm = BKE - dq * g.OW;
+  uint2 qa[2][4], qb[2][4];   // [block j][pixel i]: 4 channels of dpre / x
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int c) {
+    const int k0 = kbeg + c * BKE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      PixelWalk p = pw_[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = k0 + 4 * (pxg + 8 * j) + e;
+        qa[j][e] = qb[j][e] = make_uint2(0u, 0u);
+        if (m < kend) {
+          const size_t pix = ((size_t)p.n * g.IH + p.oh * g.stride + kh) * g.IW + p.ow * g.stride + kw;
+          qa[j][e] = *reinterpret_cast<const uint2 *>(dpre + (size_t)m * g.Cout + co0 + 4 * chg);
+          qb[j][e] = *reinterpret_cast<const uint2 *>(x + pix * g.Cin + ci0 + 4 * chg);
+        }
+        walk(p, 0, 1, g);   // the next pixel
+      }
+      walk(pw_[j], dq, drm, g);   // this block's first pixel of the next chunk
+    }
+  };
+  // (4 pixels) x (4 channels) -> 4 channel rows of 4 consecutive k, 8 bytes each
+  auto deposit = [&](unsigned char *tile, const uint2 (&q)[4], int pg) {
+    const unsigned lo01 = __builtin_amdgcn_perm(q[1].x, q[0].x, 0x05040100u);   // ch 0: k0 k1
+    const unsigned lo23 = __builtin_amdgcn_perm(q[3].x, q[2].x, 0x05040100u);   //       k2 k3
+    const unsigned hi01 = __builtin_amdgcn_perm(q[1].x, q[0].x, 0x07060302u);   // ch 1
+    const unsigned hi23 = __builtin_amdgcn_perm(q[3].x, q[2].x, 0x07060302u);
+    const unsigned lo01b = __builtin_amdgcn_perm(q[1].y, q[0].y, 0x05040100u);  // ch 2
+    const unsigned lo23b = __builtin_amdgcn_perm(q[3].y, q[2].y, 0x05040100u);
+    const unsigned hi01b = __builtin_amdgcn_perm(q[1].y, q[0].y, 0x07060302u);  // ch 3
+    const unsigned hi23b = __builtin_amdgcn_perm(q[3].y, q[2].y, 0x07060302u);
+    const uint2 rows[4] = {make_uint2(lo01, lo23), make_uint2(hi01, hi23), make_uint2(lo01b, lo23b),
+                           make_uint2(hi01b, hi23b)};
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int row = 4 * chg + cc;
+      *reinterpret_cast<uint2 *>(tile + row * ROWB + swz(row, pg >> 1) * 16 + (pg & 1) * 8) = rows[cc];
+    }
+  };
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  const int nchunk = kbeg < kend ? (kend - kbeg + BKE - 1) / BKE : 0;
+  if (nchunk > 0) fetch(0);
+  for (int c = 0; c < nchunk; ++c) {
+    unsigned char *stage = smem + (c & 1) * STAGE_B;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      deposit(stage, qa[j], pxg + 8 * j);
+      deposit(stage + TILE_B, qb[j], pxg + 8 * j);
+    }
+    if (want_bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bsum[0] += bf_lo(qa[j][e].x), bsum[1] += bf_hi(qa[j][e].x);
+          bsum[2] += bf_lo(qa[j][e].y), bsum[3] += bf_hi(qa[j][e].y);
+        }
+    }
+    __syncthreads();   // the stage is complete; everyone is done with the other stage
+    if (c + 1 < nchunk) fetch(c + 1);
+    mma_chunk(stage, acc, wm, wn, i, kk);
+  }
+  float *dst = partial + (size_t)(split * 9 + tap) * g.Cout * g.Cin;
+  tile_epilogue(reinterpret_cast<float *>(smem), acc, wid, lane,
+                [&](int row, int col, const float (&v)[8]) {
+    float *o = dst + (size_t)(co0 + row) * g.Cin + ci0 + col;
+    *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  });
+  if (want_bias) {   // the eight pixel groups of a channel group meet in LDS (fixed order)
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(pxg * 32 + chg) * 4 + e] = bsum[e];
+    __syncthreads();
+    if (tid < TM) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) t += red[(p * 32 + (tid >> 2)) * 4 + (tid & 3)];
+      partial[(size_t)splits * 9 * g.Cout * g.Cin + (size_t)split * g.Cout + co0 + tid] = t;
+    }
+  }
+}
+
+// ---- helpers: fp32 -> bf16 copies -----------------------------------------------------------
+// up to 8 arrays in one launch (grid.y = array): activations of the image layer, the top
+// pre-activation gradient, the re-laid-out filters
+struct CvtBatch {
+  const float *src[8];
+  bf16_t *dst[8];
+  long n[8];   // multiples of 8
+};
+__global__ __launch_bounds__(NT) void cvt_bf16_kernel(CvtBatch c) {
+  const int a = blockIdx.y;
+  const long n8 = c.n[a] >> 3;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n8; e += (long)gridDim.x * NT) {
+    const float4 v0 = pipe::lds4(c.src[a] + 8 * e), v1 = pipe::lds4(c.src[a] + 8 * e + 4);
+    *reinterpret_cast<uint4 *>(c.dst[a] + 8 * e) =
+        make_uint4(pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w));
+  }
+}
+
+int check(const ConvGeom &g) {
+  if (g.B <= 0 || g.IH < 3 || g.IW < 3 || g.Cin <= 0 || g.Cout <= 0 || g.stride < 1 || g.stride > 2)
+    return SCAE_ERR_BAD_ARG;
+  if (g.Cin % 128 || g.Cout % 128) return SCAE_ERR_UNSUPPORTED;
+  // (the DMA offsets are 32-bit byte offsets)
+  const size_t big = (size_t)g.B * g.IH * g.IW * (g.Cin > g.Cout ? g.Cin : g.Cout) * 2;
+  if (big >= (1ull << 31) - 4096) return SCAE_ERR_UNSUPPORTED;
+  return SCAE_OK;
+}
+template <class K>
+int raise_lds(K kernel) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  return e == hipSuccess ? SCAE_OK : (int)e;
+}
+}  // namespace
+
+extern "C" int scae_conv3x3_bf16r_supported(int B, int IH, int IW, int Cin, int Cout, int stride) {
+  if (IH < 3 || IW < 3 || stride < 1) return 0;
+  ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
+  return check(g) == SCAE_OK ? 1 : 0;
+}
+
+extern "C" int scae_cvt_bf16_batch(int n_arrays, const float *const *src, uint16_t *const *dst,
+                                   const int64_t *n, void *stream) {
+  SCAE_REQUIRE(n_arrays > 0 && n_arrays <= 8 && src && dst && n);
+  CvtBatch c{};
+  long nmax = 0;
+  for (int a = 0; a < n_arrays; ++a) {
+    SCAE_REQUIRE(src[a] && dst[a] && n[a] > 0 && n[a] % 8 == 0);
+    c.src[a] = src[a], c.dst[a] = dst[a], c.n[a] = n[a];
+    nmax = nmax > n[a] ? nmax : n[a];
+  }
+  long blocks = (nmax / 8 + NT - 1) / NT;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  scae::launch(cvt_bf16_kernel, dim3((unsigned)blocks, n_arrays), dim3(NT), 0, (hipStream_t)stream, c);
+  return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_fwd_bf16r(const uint16_t *in, const uint16_t *wf, const float *bias,
+                                      uint16_t *out_h, float *out_f, const float *post_bias,
+                                      float *out_post, int B, int IH, int IW, int Cin, int Cout,
+                                      int stride, void *stream) {
+  SCAE_REQUIRE(in && wf && bias && out_h && (!out_post || post_bias) && IH >= 3 && IW >= 3 && stride >= 1);
+  ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
+  int rc = check(g);
+  if (rc) return rc;
+  if ((rc = raise_lds(conv_fwd_bf16r_kernel))) return rc;
+  const int M = B * g.OH * g.OW;
+  scae::launch(conv_fwd_bf16r_kernel, dim3(Cout / TN, (M + TM - 1) / TM), dim3(NT), LDS_B,
+               (hipStream_t)stream, in, wf, bias, out_h, out_f, post_bias, out_post, g);
+  return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_dgrad_bf16r(const uint16_t *dpre, const uint16_t *wd,
+                                        const uint16_t *gate, uint16_t *din_h, float *din_f, int B,
+                                        int IH, int IW, int Cin, int Cout, int stride,
+                                        void *stream) {
+  SCAE_REQUIRE(dpre && wd && (din_h || din_f) && IH >= 3 && IW >= 3 && stride >= 1);
+  ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
+  int rc = check(g);
+  if (rc) return rc;
+  if ((rc = raise_lds(conv_dgrad_bf16r_kernel))) return rc;
+  DgradClasses cl{};
+  cl.n = stride == 1 ? 1 : 4;
+  int tiles = 0;
+  for (int z = 0; z < cl.n; ++z) {
+    const int ph = stride == 1 ? 0 : z >> 1, pw = stride == 1 ? 0 : z & 1;
+    const int na = (IH - ph + stride - 1) / stride, nb = (IW - pw + stride - 1) / stride;
+    cl.tile_start[z] = tiles;
+    tiles += (B * na * nb + TM - 1) / TM;
+  }
+  cl.tile_start[cl.n] = tiles;
+  scae::launch(conv_dgrad_bf16r_kernel, dim3(Cin / TN, tiles), dim3(NT), LDS_B,
+               (hipStream_t)stream, dpre, wd, gate, din_h, din_f, g, cl);
+  return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_wgrad_bf16r_splits(int B, int OH, int OW, int Cin, int Cout) {
+  if (B <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || Cin % 128 || Cout % 128) return 0;
+  // ~3 workgroups per CU over the 9 taps x channel tiles; at least 4 chunks of K each
+  const long tiles = 9L * (Cin / 128) * (Cout / 128), M = (long)B * OH * OW;
+  long s = (768 + tiles - 1) / tiles;
+  const long cap = M / (4 * BKE);
+  s = s > cap ? cap : s;
+  return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
+}
+
+extern "C" int scae_conv3x3_wgrad_bf16r(const uint16_t *dpre, const uint16_t *x, float *partial,
+                                        int B, int IH, int IW, int Cin, int Cout, int stride,
+                                        void *stream) {
+  SCAE_REQUIRE(dpre && x && partial && IH >= 3 && IW >= 3 && stride >= 1);
+  ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
+  int rc = check(g);
+  if (rc) return rc;
+  if ((rc = raise_lds(conv_wgrad_bf16r_kernel))) return rc;
+  const int splits = scae_conv3x3_wgrad_bf16r_splits(B, g.OH, g.OW, Cin, Cout);
+  scae::launch(conv_wgrad_bf16r_kernel, dim3(Cin / TN, Cout / TM, 9 * splits), dim3(NT), LDS_B,
+               (hipStream_t)stream, dpre, x, partial, g, splits);
+  return scae_launch_status();
+}

@@ -1131,6 +1131,9 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
                   ints([w.shape[0] for w in weights[1:]]),
                   ints([w.shape[1] for w in weights[1:]]), st)
     x_post = None
+    if _conv_bf16_resident(B, act.shape[1], act.shape[2], weights, strides):
+        return _conv_stack_fwd_bf16r(act, wfs, wds, weights, biases, strides,
+                                     post_bias)
     for l in range(1, L):
         w, s = weights[l], strides[l]
         co, ci = w.shape[0], w.shape[1]
@@ -1170,6 +1173,73 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
     return acts, wds, x_post
 
 
+_CONV_BF16R = __import__("os").environ.get("SCAE_CONV_BF16R", "1") != "0"
+
+
+def _conv_bf16_resident(B, ih, iw, weights, strides):
+    """configs[2]'s precision with every GEMM operand of layers 1.. kept as
+    bf16 in HBM (csrc/conv_bf16.hip): inside ``mfma_bf16()`` when every such
+    layer has the kernels' shapes."""
+    if not (_bf16() and _CONV_BF16R and len(strides) >= 2):
+        return False
+    lib = _lib.load()
+    for l in range(1, len(strides)):
+        co, ci, s = weights[l].shape[0], weights[l].shape[1], strides[l]
+        if not lib.scae_conv3x3_bf16r_supported(B, ih, iw, ci, co, s):
+            return False
+        ih, iw = (ih - 3) // s + 1, (iw - 3) // s + 1
+    return True
+
+
+def _cvt_bf16(pairs, ref):
+    """bf16 copies of fp32 tensors, up to 8 per launch: [(src, dst)]."""
+    for k in range(0, len(pairs), 8):
+        chunk = pairs[k:k + 8]
+        n = len(chunk)
+        _lib.call("scae_cvt_bf16_batch", n,
+                  (ctypes.c_void_p * n)(*[a.data_ptr() for a, _ in chunk]),
+                  (ctypes.c_void_p * n)(*[b.data_ptr() for _, b in chunk]),
+                  (ctypes.c_int64 * n)(*[a.numel() for a, _ in chunk]),
+                  _stream(ref))
+
+
+def _conv_stack_fwd_bf16r(act, wfs, wds, weights, biases, strides, post_bias):
+    """Layers 1.. of the stack on the bf16-resident kernels.  -> (acts, wds,
+    x_post) like ``_conv_stack_fwd``, with the activations of layers 0 .. L-2
+    and the data-gradient filters as bf16 tensors (what ``_conv_stack_bwd``
+    then reads); the last layer's output stays fp32 (the attention conv and
+    its ReLU gate read it)."""
+    L = len(strides)
+    B, dev, st = act.shape[0], act.device, _stream(act)
+    half = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.bfloat16)
+    act_h = half(*act.shape)
+    pairs, wfh, wdh = [(act, act_h)], [], []
+    for l in range(1, L):
+        co, ci = weights[l].shape[0], weights[l].shape[1]
+        wfh.append(half(co, 9, ci))
+        wdh.append(half(ci, 9, co))
+        pairs += [(wfs[l - 1][0], wfh[-1]), (wds[l - 1], wdh[-1])]
+    _cvt_bf16(pairs, act)
+    acts, x_post = [act_h], None
+    for l in range(1, L):
+        co, ci, s = weights[l].shape[0], weights[l].shape[1], strides[l]
+        ih, iw = act_h.shape[1], act_h.shape[2]
+        oh, ow = (ih - 3) // s + 1, (iw - 3) // s + 1
+        out_h = half(B, oh, ow, co)
+        last = l == L - 1
+        out_f = torch.empty(B, oh, ow, co, device=dev, dtype=act.dtype) \
+            if last else None
+        if last and post_bias is not None:
+            x_post = torch.empty_like(out_f)
+        _lib.call("scae_conv3x3_fwd_bf16r", _p(act_h), _p(wfh[l - 1]),
+                  _p(biases[l]), _p(out_h), _p(out_f),
+                  _p(post_bias if x_post is not None else None), _p(x_post),
+                  B, ih, iw, ci, co, s, st)
+        acts.append(out_f if last else out_h)
+        act_h = out_h
+    return acts, wdh, x_post
+
+
 def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
                     defer=False):
     """Weight / bias gradients of the stack from ``dpre``, the (B,OH,OW,C)
@@ -1182,7 +1252,32 @@ def _conv_stack_bwd(image, acts, wds, strides, wshapes, dpre, gout,
     gws, gbs = [None] * L, [None] * L
     pending = []       # (partial, gw, gb, co, ci, splits): reduced in one launch
     lib, plan = _lib.load(), _plan()
-    for l in range(L - 1, 0, -1):
+    resident = L >= 2 and acts[0].dtype == torch.bfloat16
+    if resident:
+        # bf16-resident operands (``_conv_stack_fwd_bf16r``): the incoming
+        # gradient once to bf16, then per layer the weight-gradient partials
+        # and the gated data gradient (bf16; fp32 for the image layer's kernel)
+        dpre_h = torch.empty(dpre.shape, device=dev, dtype=torch.bfloat16)
+        _cvt_bf16([(dpre.contiguous(), dpre_h)], image)
+    for l in (range(L - 1, 0, -1) if resident else ()):
+        co, ci = wshapes[l][0], wshapes[l][1]
+        xin, s = acts[l - 1], strides[l]
+        ih, iw, oh, ow = xin.shape[1], xin.shape[2], dpre_h.shape[1], dpre_h.shape[2]
+        splits = lib.scae_conv3x3_wgrad_bf16r_splits(B, oh, ow, ci, co)
+        partial = new(splits * (9 * co * ci + co))
+        gw, gb = gout(l), gout(L + l)
+        _lib.call("scae_conv3x3_wgrad_bf16r", _p(dpre_h), _p(xin), _p(partial),
+                  B, ih, iw, ci, co, s, st)
+        din_h = torch.empty(B, ih, iw, ci, device=dev, dtype=torch.bfloat16) \
+            if l > 1 else None
+        din_f = new(B, ih, iw, ci) if l == 1 else None
+        _lib.call("scae_conv3x3_dgrad_bf16r", _p(dpre_h), _p(wds[l - 1]),
+                  _p(xin), _p(din_h), _p(din_f), B, ih, iw, ci, co, s, st)
+        pending.append((partial, gw, gb, co, ci, splits))
+        gws[l], gbs[l] = gw, gb
+        dpre_h = din_h
+        dpre = din_f
+    for l in (range(L - 1, 0, -1) if not resident else ()):
         co, ci = wshapes[l][0], wshapes[l][1]
         xin, s = acts[l - 1], strides[l]
         ih, iw, oh, ow = xin.shape[1], xin.shape[2], dpre.shape[1], dpre.shape[2]
