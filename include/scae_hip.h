@@ -36,7 +36,8 @@ extern "C" {
 
 /* 2: scae_launch_list_begin(stream) -> handle; scae_conv3x3_relayout* write the packed
  * fragment-major filter copy behind wf (scae_conv3x3_wf_floats); scae_mlp_chain_desc has
- * row_tile / bf16; scae_decoder_desc has bwd_resident */
+ * row_tile / bf16; scae_decoder_desc has bwd_resident; scae_first_layer_desc has out_h /
+ * rwfh / rwdh */
 #define SCAE_ABI_VERSION 2
 
 #define SCAE_OK 0
@@ -563,6 +564,15 @@ int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout, in
  *          in the layout of scae_conv3x3_wgrad_f32's (dw == NULL): the fp32 reduction
  *          launches (wgrad_reduce_batch, first_wgrad_reduce) sum them. */
 int scae_conv3x3_bf16r_supported(int B, int IH, int IW, int Cin, int Cout, int stride);
+/* scae_conv3x3_first_fwd_relayout_f32 for the bf16-resident encoder: the image layer's output
+ * as bf16 (out_h), the re-laid-out filters as fp32 (rwf / rwd, as there) AND as bf16 (rwfh / rwdh) */
+int scae_conv3x3_first_fwd_relayout_bf16(const float *img, const float *w, const float *bias,
+                                         uint16_t *out_h, int B, int Cin, int IH, int IW,
+                                         int Cout, int stride, int n_layers,
+                                         const float *const *rw, float *const *rwf,
+                                         float *const *rwd, uint16_t *const *rwfh,
+                                         uint16_t *const *rwdh, const int *rCout,
+                                         const int *rCin, void *stream);
 int scae_cvt_bf16_batch(int n_arrays, const float *const *src, uint16_t *const *dst,
                         const int64_t *n, void *stream);
 int scae_conv3x3_fwd_bf16r(const uint16_t *in, const uint16_t *wf, const float *bias,
@@ -779,6 +789,12 @@ typedef struct scae_first_layer_desc {
   float *rwf[8];      /* (rCout, 9, rCin) */
   float *rwd[8];      /* (rCin, 9, rCout) */
   int rCout[8], rCin[8];
+  /* bf16-resident encoder (scae_conv3x3_*_bf16r): out_h non-NULL -> the layer's output is
+   * written as bf16 to out_h INSTEAD of `out` (which must still be a valid pointer), and bf16
+   * copies of the re-laid-out filters go to rwfh / rwdh */
+  uint16_t *out_h;    /* (B, OH, OW, Cout) bf16, nullable */
+  uint16_t *rwfh[8];  /* (rCout, 9, rCin) bf16 */
+  uint16_t *rwdh[8];  /* (rCin, 9, rCout) bf16 */
 } scae_first_layer_desc;
 int scae_step_prologue_first_f32(float *dst_image, const float *src_image, int64_t n_image,
                                  int64_t *dst_label, const int64_t *src_label,

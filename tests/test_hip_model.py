@@ -820,7 +820,8 @@ def test_cfg3_bf16_operands_vs_fp32_oracle_with_gradients():
     # tensors on their way into LDS
     assert {"scae_conv3x3_fwd_bf16r", "scae_conv3x3_dgrad_bf16r", "scae_conv3x3_wgrad_bf16r",
             "scae_cvt_bf16_batch"} <= set(calls)
-    assert used == {"scae_gemm_bf16", "scae_gemm_pair_bf16",
+    assert used == {"scae_conv3x3_first_fwd_relayout_bf16",   # (the image layer writes bf16)
+                    "scae_gemm_bf16", "scae_gemm_pair_bf16",
                     # the capsule MLPs' weight gradients (their forward and data
                     # gradient: the one-launch chain with its bf16 flag set)
                     "scae_gemm_multi_bf16",

@@ -2628,7 +2628,7 @@ def _rel_l2(got, ref):
 @pytest.mark.parametrize("B,HW,chans,strides", [
     (256, 40, [128, 128, 128], [2, 2, 1]),     # 128-channel layers: bf16 tiles
     (64, 24, [128, 128], [1, 1]),
-    (3, 29, [128, 128, 128, 128], [2, 2, 1, 1]),   # ragged tiles, every class of the stride-2 gradient
+    (24, 29, [128, 128, 128, 128], [2, 2, 1, 1]),   # ragged tiles, every class of the stride-2 gradient
 ])
 def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides, resident, monkeypatch):
     """K8 with bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): outputs

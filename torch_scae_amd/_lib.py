@@ -122,7 +122,8 @@ class FirstLayerDesc(Structure):
         [(n, c_int) for n in ("B", "Cin", "IH", "IW", "Cout", "stride",
                               "n_layers")] + \
         [("rw", P * 8), ("rwf", P * 8), ("rwd", P * 8),
-         ("rCout", c_int * 8), ("rCin", c_int * 8)]
+         ("rCout", c_int * 8), ("rCin", c_int * 8),
+         ("out_h", P), ("rwfh", P * 8), ("rwdh", P * 8)]
 
 
 class SeedFoldGrads(Structure):
@@ -218,6 +219,7 @@ SIGNATURES = {
     "scae_conv3x3_wf_floats": [c_int, c_int],
     "scae_conv3x3_relayout_f32": [P, P, P, c_int, c_int, P],
     "scae_conv3x3_bf16r_supported": [c_int] * 6,
+    "scae_conv3x3_first_fwd_relayout_bf16": [P] * 4 + [c_int] * 7 + [P] * 8,
     "scae_cvt_bf16_batch": [c_int, P, P, P, P],
     "scae_conv3x3_fwd_bf16r": [P] * 7 + [c_int] * 6 + [P],
     "scae_conv3x3_dgrad_bf16r": [P] * 5 + [c_int] * 6 + [P],

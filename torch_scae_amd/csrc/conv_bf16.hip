@@ -27,6 +27,8 @@
 //     tap falls outside the output read zeros through the buffer descriptor's range check.
 // Accumulation order over K is (tap, channel) ascending in 16-wide MFMA steps -- the order of
 // the first form, whose results these kernels reproduce to round-off of the fp32 accumulators.
+#include <cstdlib>
+
 #include "mfma_pipe.h"
 #include "conv_first_dev.h"
 
@@ -41,7 +43,6 @@ constexpr int NT = 256, TM = 128, TN = 128, BKE = 64;   // BKE: K chunk in eleme
 constexpr int ROWB = 2 * BKE;                            // bytes per LDS row (128)
 constexpr int TILE_B = TM * ROWB;                        // 16 KiB per operand tile
 constexpr int STAGE_B = 2 * TILE_B;                      // A + B
-constexpr int LDS_B = 2 * STAGE_B;                       // two stages: 64 KiB
 constexpr int SLAB = 32 * 36;                            // epilogue: floats per wave
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
@@ -105,18 +106,38 @@ __device__ __forceinline__ void tile_epilogue(float *smem, const f32x16 (&acc)[2
 }
 
 // ---- the K loop of the DMA-staged passes --------------------------------------------------
-// issue(c, stage): this wave's 8 DMA pieces of chunk c (4 of the A tile, 4 of the B tile)
-template <class Issue>
+// issue(c, stage): this wave's 8 DMA pieces of chunk c (4 of the A tile, 4 of the B tile).
+// NS stages of 32 KiB: NS - 1 chunks in flight under the MFMAs of the current one, ONE barrier
+// per chunk (NS = 1: no overlap inside the workgroup, two barriers per chunk, but five
+// workgroups share a CU's LDS and cover each other).
+template <int NS, class Issue>
 __device__ __forceinline__ void dma_mainloop(int nchunk, unsigned char *smem, f32x16 (&acc)[2][2],
                                              int wid, int lane, Issue issue) {
   const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
   if (nchunk <= 0) return;
-  issue(0, smem);
+  if (NS == 1) {
+    for (int c = 0; c < nchunk; ++c) {
+      issue(c, smem);
+      pipe::wait_vm<0>();
+      pipe::wg_barrier();
+      mma_chunk(smem, acc, wm, wn, i, kk);
+      pipe::wg_barrier();   // everyone has read the stage: the next chunk may land
+    }
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < NS - 1; ++c)
+    if (c < nchunk) issue(c, smem + c * STAGE_B);
+  int s = 0;   // stage of chunk c
   for (int c = 0; c < nchunk; ++c) {
-    pipe::wait_vm<0>();   // this wave's pieces of chunk c have landed
-    pipe::wg_barrier();   // ... everyone's; and everyone is done reading the other stage
-    if (c + 1 < nchunk) issue(c + 1, smem + ((c + 1) & 1) * STAGE_B);
-    mma_chunk(smem + (c & 1) * STAGE_B, acc, wm, wn, i, kk);
+    // this wave's pieces of chunk c have landed: what may still be in flight are the (up to
+    // NS - 2) chunks issued after it
+    pipe::wait_chunk<8, NS>(min(NS - 2, nchunk - 1 - c));
+    pipe::wg_barrier();   // ... everyone's; and everyone is done reading chunk c - 1's stage
+    const int sp = s == 0 ? NS - 1 : s - 1;   // = stage of chunk c - 1 = of chunk c + NS - 1
+    if (c + NS - 1 < nchunk) issue(c + NS - 1, smem + sp * STAGE_B);
+    mma_chunk(smem + s * STAGE_B, acc, wm, wn, i, kk);
+    s = s + 1 == NS ? 0 : s + 1;
   }
 }
 
@@ -150,6 +171,7 @@ __device__ __forceinline__ int src_quad(int row, int lane) { return swz(row, lan
 // ---- forward -------------------------------------------------------------------------------
 // out[m][co] = relu(sum_{tap, ci} in[pix(m, tap)][ci] wf[co][tap][ci] + bias[co])
 //   grid (Cout / 128, ceil(M / 128)); out_h bf16 NHWC; out_f / out_post (nullable) fp32
+template <int NS>
 __global__ __launch_bounds__(NT, 2) void conv_fwd_bf16r_kernel(
     const bf16_t *__restrict__ in, const bf16_t *__restrict__ wf, const float *__restrict__ bias,
     bf16_t *__restrict__ out_h, float *__restrict__ out_f, const float *__restrict__ post_bias,
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_bf16r_kernel(
   const int cpt = g.Cin / BKE;   // chunks per tap
   f32x16 acc[2][2];
   zero_acc(acc);
-  dma_mainloop(9 * cpt, smem, acc, wid, lane, [&](int c, unsigned char *stage) {
+  dma_mainloop<NS>(9 * cpt, smem, acc, wid, lane, [&](int c, unsigned char *stage) {
     const int tap = c / cpt, h = c - tap * cpt, kh = tap / 3, kw = tap - kh * 3;
     const int sa = ((kh * g.IW + kw) * g.Cin + h * BKE) * 2, sb = (tap * g.Cin + h * BKE) * 2;
 #pragma unroll
@@ -225,6 +247,7 @@ struct DgradClasses {
   int tile_start[5];  // first tile (grid.y) of each class
 };
 // gate: the producing layer's ReLU output (bf16, nullable); din_h (bf16) or din_f (fp32)
+template <int NS>
 __global__ __launch_bounds__(NT, 2) void conv_dgrad_bf16r_kernel(
     const bf16_t *__restrict__ dpre, const bf16_t *__restrict__ wd, const bf16_t *__restrict__ gate,
     bf16_t *__restrict__ din_h, float *__restrict__ din_f, ConvGeom g, DgradClasses cl) {
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_bf16r_kernel(
   const int cpt = g.Cout / BKE;
   f32x16 acc[2][2];
   zero_acc(acc);
-  dma_mainloop(nkh * nkw * cpt, smem, acc, wid, lane, [&](int c, unsigned char *stage) {
+  dma_mainloop<NS>(nkh * nkw * cpt, smem, acc, wid, lane, [&](int c, unsigned char *stage) {
     const int t = c / cpt, h = c - t * cpt, ti = t / nkw, tj = t - ti * nkw;
     const int kh = ph + s * ti, kw = pw + s * tj;
     const int sb = ((kh * 3 + kw) * g.Cout + h * BKE) * 2;
@@ -317,7 +340,7 @@ __device__ __forceinline__ void walk(PixelWalk &p, int dq, int drm, const ConvGe
   p.oh += dq + carry;
   while (p.oh >= g.OH) p.oh -= g.OH, ++p.n;
 }
-__global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16r_kernel(
+__global__ __launch_bounds__(NT, 3) void conv_wgrad_bf16r_kernel(
     const bf16_t *__restrict__ dpre, const bf16_t *__restrict__ x, float *__restrict__ partial,
     ConvGeom g, int splits) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -384,7 +407,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16r_kernel(
   const int nchunk = kbeg < kend ? (kend - kbeg + BKE - 1) / BKE : 0;
   if (nchunk > 0) fetch(0);
   for (int c = 0; c < nchunk; ++c) {
-    unsigned char *stage = smem + (c & 1) * STAGE_B;
+    // ONE stage: 32 KiB per workgroup -- three workgroups per CU at this kernel's 160 VGPRs;
+    // the next chunk waits in registers while this one is multiplied
+    unsigned char *stage = smem;
+    if (c) __syncthreads();   // everyone has read the previous chunk
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       deposit(stage, qa[j], pxg + 8 * j);
@@ -399,7 +425,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16r_kernel(
           bsum[2] += bf_lo(qa[j][e].y), bsum[3] += bf_hi(qa[j][e].y);
         }
     }
-    __syncthreads();   // the stage is complete; everyone is done with the other stage
+    __syncthreads();   // the stage is complete
     if (c + 1 < nchunk) fetch(c + 1);
     mma_chunk(stage, acc, wm, wn, i, kk);
   }
@@ -453,10 +479,17 @@ int check(const ConvGeom &g) {
   return SCAE_OK;
 }
 template <class K>
-int raise_lds(K kernel) {
+int raise_lds(K kernel, int bytes) {
+  if (bytes <= 48 * 1024) return SCAE_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e == hipSuccess ? SCAE_OK : (int)e;
+}
+// ring depth of the DMA-staged passes (tuning aid: SCAE_BF16R_NS=1..4)
+int ring_depth(const char *env, int dflt) {
+  const char *e = getenv(env);
+  const int v = e && *e ? atoi(e) : dflt;
+  return v < 1 ? 1 : (v > 4 ? 4 : v);
 }
 }  // namespace
 
@@ -490,10 +523,20 @@ extern "C" int scae_conv3x3_fwd_bf16r(const uint16_t *in, const uint16_t *wf, co
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check(g);
   if (rc) return rc;
-  if ((rc = raise_lds(conv_fwd_bf16r_kernel))) return rc;
   const int M = B * g.OH * g.OW;
-  scae::launch(conv_fwd_bf16r_kernel, dim3(Cout / TN, (M + TM - 1) / TM), dim3(NT), LDS_B,
-               (hipStream_t)stream, in, wf, bias, out_h, out_f, post_bias, out_post, g);
+  const dim3 grid(Cout / TN, (M + TM - 1) / TM);
+#define SCAE_FWD_NS(N)                                                                          \
+  case N:                                                                                       \
+    if ((rc = raise_lds(conv_fwd_bf16r_kernel<N>, N * STAGE_B))) return rc;                     \
+    scae::launch(conv_fwd_bf16r_kernel<N>, grid, dim3(NT), N * STAGE_B, (hipStream_t)stream, in, \
+                 wf, bias, out_h, out_f, post_bias, out_post, g);                                \
+    break;
+  // many tiles: one stage, five workgroups per CU covering each other; few: two stages
+  // (measured at B = 1024: 648 tiles 37.5 us against 41.6, 392 tiles 27.1 against 23.3)
+  switch (ring_depth("SCAE_BF16R_FWD_NS", (long)grid.x * grid.y > 512 ? 1 : 2)) {
+    SCAE_FWD_NS(1) SCAE_FWD_NS(2) SCAE_FWD_NS(3) SCAE_FWD_NS(4)
+  }
+#undef SCAE_FWD_NS
   return scae_launch_status();
 }
 
@@ -505,7 +548,6 @@ extern "C" int scae_conv3x3_dgrad_bf16r(const uint16_t *dpre, const uint16_t *wd
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check(g);
   if (rc) return rc;
-  if ((rc = raise_lds(conv_dgrad_bf16r_kernel))) return rc;
   DgradClasses cl{};
   cl.n = stride == 1 ? 1 : 4;
   int tiles = 0;
@@ -516,16 +558,26 @@ extern "C" int scae_conv3x3_dgrad_bf16r(const uint16_t *dpre, const uint16_t *wd
     tiles += (B * na * nb + TM - 1) / TM;
   }
   cl.tile_start[cl.n] = tiles;
-  scae::launch(conv_dgrad_bf16r_kernel, dim3(Cin / TN, tiles), dim3(NT), LDS_B,
-               (hipStream_t)stream, dpre, wd, gate, din_h, din_f, g, cl);
+  const dim3 grid(Cin / TN, tiles);
+#define SCAE_DG_NS(N)                                                                           \
+  case N:                                                                                       \
+    if ((rc = raise_lds(conv_dgrad_bf16r_kernel<N>, N * STAGE_B))) return rc;                   \
+    scae::launch(conv_dgrad_bf16r_kernel<N>, grid, dim3(NT), N * STAGE_B, (hipStream_t)stream,  \
+                 dpre, wd, gate, din_h, din_f, g, cl);                                           \
+    break;
+  switch (ring_depth("SCAE_BF16R_DGRAD_NS", (long)grid.x * grid.y > 512 ? 1 : 2)) {
+    SCAE_DG_NS(1) SCAE_DG_NS(2) SCAE_DG_NS(3) SCAE_DG_NS(4)
+  }
+#undef SCAE_DG_NS
   return scae_launch_status();
 }
 
 extern "C" int scae_conv3x3_wgrad_bf16r_splits(int B, int OH, int OW, int Cin, int Cout) {
   if (B <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || Cin % 128 || Cout % 128) return 0;
-  // ~3 workgroups per CU over the 9 taps x channel tiles; at least 4 chunks of K each
+  // 3 workgroups per CU (the kernel's registers) over the 9 taps x channel tiles, all
+  // resident at once: <= 768; at least 4 chunks of K each
   const long tiles = 9L * (Cin / 128) * (Cout / 128), M = (long)B * OH * OW;
-  long s = (768 + tiles - 1) / tiles;
+  long s = 768 / tiles;
   const long cap = M / (4 * BKE);
   s = s > cap ? cap : s;
   return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
@@ -538,9 +590,8 @@ extern "C" int scae_conv3x3_wgrad_bf16r(const uint16_t *dpre, const uint16_t *x,
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check(g);
   if (rc) return rc;
-  if ((rc = raise_lds(conv_wgrad_bf16r_kernel))) return rc;
   const int splits = scae_conv3x3_wgrad_bf16r_splits(B, g.OH, g.OW, Cin, Cout);
-  scae::launch(conv_wgrad_bf16r_kernel, dim3(Cin / TN, Cout / TM, 9 * splits), dim3(NT), LDS_B,
+  scae::launch(conv_wgrad_bf16r_kernel, dim3(Cin / TN, Cout / TM, 9 * splits), dim3(NT), STAGE_B,
                (hipStream_t)stream, dpre, x, partial, g, splits);
   return scae_launch_status();
 }

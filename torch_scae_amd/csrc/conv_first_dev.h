@@ -16,7 +16,17 @@ struct RelayoutBatch {
   const float *w[8];
   float *wf[8], *wd[8];
   int Cout[8], Cin[8];
+  // bf16 copies of wf (Cout,9,Cin) / wd (Cin,9,Cout) for the bf16-resident kernels
+  // (conv_bf16.hip), nullable
+  unsigned short *wfh[8], *wdh[8];
 };
+// fp32 -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does; finite values)
+__host__ __device__ inline unsigned short bf16_bits(float v) {
+  union { float f; unsigned u; } c;
+  c.f = v;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((c.u >> 16) | 0x40);   // NaN
+  return (unsigned short)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
 // Where element (co, tap, ci) of a filter lies in the FRAGMENT-MAJOR copy the image-resident
 // forward (conv_resident.hip) reads -- the second Cout*9*Cin floats of a `wf` buffer:
 // [co / 32][chunk = tap * Cin/32 + ci/32][quad = ci%16 / 4][lane = (ci%32 / 16) * 32 + co%32][ci%4],
@@ -28,7 +38,8 @@ __host__ __device__ inline size_t packed_index(int Cin, int co, int tap, int ci)
 }
 __host__ __device__ inline bool packed_copy(int Cout, int Cin) { return Cin % 32 == 0 && Cout % 32 == 0; }
 __device__ __forceinline__ void relayout_one(const float *w, float *wf, float *wd, int Cout,
-                                             int Cin, int e) {
+                                             int Cin, int e, unsigned short *wfh = nullptr,
+                                             unsigned short *wdh = nullptr) {
   if (e >= Cout * Cin * 9) return;
   const int co = e / (Cin * 9), rem = e - co * Cin * 9, ci = rem / 9, tap = rem - ci * 9;
   const float v = w[e];
@@ -36,18 +47,23 @@ __device__ __forceinline__ void relayout_one(const float *w, float *wf, float *w
   wd[((size_t)ci * 9 + tap) * Cout + co] = v;
   if (packed_copy(Cout, Cin))
     wf[(size_t)Cout * 9 * Cin + packed_index(Cin, co, tap, ci)] = v;
+  if (wfh) wfh[((size_t)co * 9 + tap) * Cin + ci] = bf16_bits(v);
+  if (wdh) wdh[((size_t)ci * 9 + tap) * Cout + co] = bf16_bits(v);
 }
 __device__ __forceinline__ void relayout_batch(const RelayoutBatch &r, int l, int e) {
-  relayout_one(r.w[l], r.wf[l], r.wd[l], r.Cout[l], r.Cin[l], e);
+  relayout_one(r.w[l], r.wf[l], r.wd[l], r.Cout[l], r.Cin[l], e, r.wfh[l], r.wdh[l]);
 }
 // fills a RelayoutBatch; returns the workgroups (of 256 elements) per layer or < 0
 inline int fill_relayout(RelayoutBatch &r, int n_layers, const float *const *w, float *const *wf,
-                         float *const *wd, const int *Cout, const int *Cin) {
+                         float *const *wd, const int *Cout, const int *Cin,
+                         unsigned short *const *wfh = nullptr,
+                         unsigned short *const *wdh = nullptr) {
   if (!(n_layers > 0 && n_layers <= 8 && w && wf && wd && Cout && Cin)) return -1;
   int nmax = 0;
   for (int l = 0; l < n_layers; ++l) {
     if (!(w[l] && wf[l] && wd[l] && Cout[l] > 0 && Cin[l] > 0)) return -1;
     r.w[l] = w[l], r.wf[l] = wf[l], r.wd[l] = wd[l], r.Cout[l] = Cout[l], r.Cin[l] = Cin[l];
+    r.wfh[l] = wfh ? wfh[l] : nullptr, r.wdh[l] = wdh ? wdh[l] : nullptr;
     nmax = nmax > Cout[l] * Cin[l] * 9 ? nmax : Cout[l] * Cin[l] * 9;
   }
   return (nmax + 255) / 256;
@@ -86,7 +102,10 @@ __device__ __forceinline__ void fwd_block(const float *__restrict__ img,
                                           const float *__restrict__ w,
                                           const float *__restrict__ bias,
                                           float *__restrict__ out, const ConvGeom &g, int blk,
-                                          float *s_img) {
+                                          float *s_img,
+                                          unsigned short *__restrict__ out_h = nullptr) {
+  // out_h (nullable): the same values as bf16 INSTEAD of the fp32 tensor (the bf16-resident
+  // layers behind it read nothing else)
   const FirstSplit f = first_split(g.B, g.Cout);
   const int n = blk / f.slices, slice = blk % f.slices;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -109,6 +128,7 @@ __device__ __forceinline__ void fwd_block(const float *__restrict__ img,
     int p = pbeg + wave * PPW + ps;
     int oh = p / g.OW, ow = p - oh * g.OW;
     float *dst = out + ((size_t)n * P + p) * g.Cout + 4 * cq;
+    unsigned short *dst_h = out_h ? out_h + ((size_t)n * P + p) * g.Cout + 4 * cq : nullptr;
     for (; p < pend; p += step) {
       const float *src = s_img + oh * g.stride * g.IW + ow * g.stride;
       float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
@@ -120,8 +140,15 @@ __device__ __forceinline__ void fwd_block(const float *__restrict__ img,
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[c] = fmaf(x, wr[c][ci * 9 + t], acc[c]);
         }
-      *reinterpret_cast<float4 *>(dst) = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f),
-                                                     fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+      if (dst_h) {
+        const unsigned lo = bf16_bits(fmaxf(acc[0], 0.f)) | ((unsigned)bf16_bits(fmaxf(acc[1], 0.f)) << 16);
+        const unsigned hi = bf16_bits(fmaxf(acc[2], 0.f)) | ((unsigned)bf16_bits(fmaxf(acc[3], 0.f)) << 16);
+        *reinterpret_cast<uint2 *>(dst_h) = make_uint2(lo, hi);
+        dst_h += (size_t)step * g.Cout;
+      } else {
+        *reinterpret_cast<float4 *>(dst) = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f),
+                                                       fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+      }
       dst += (size_t)step * g.Cout;
       ow += step;
       while (ow >= g.OW) ow -= g.OW, ++oh;
@@ -145,7 +172,10 @@ __device__ __forceinline__ void fwd_block(const float *__restrict__ img,
 #pragma unroll
         for (int t = 0; t < 9; ++t)
           acc = fmaf(src[(ci * g.IH + t / 3) * g.IW + t % 3], wr[ci * 9 + t], acc);
-      *dst = fmaxf(acc, 0.f);
+      if (out_h)
+        out_h[dst - out] = bf16_bits(fmaxf(acc, 0.f));
+      else
+        *dst = fmaxf(acc, 0.f);
       dst += (size_t)f.parts * g.Cout;
       ow += f.parts;
       while (ow >= g.OW) ow -= g.OW, ++oh;

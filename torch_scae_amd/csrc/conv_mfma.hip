@@ -896,14 +896,15 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float *__rest
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out,
                                                              ConvGeom g, RelayoutBatch rl,
-                                                             int n_first, int rb) {
+                                                             int n_first, int rb,
+                                                             unsigned short *__restrict__ out_h) {
   extern __shared__ float s_img[];
   if ((int)blockIdx.x >= n_first) {  // workgroup-uniform
     const int w_ = (int)blockIdx.x - n_first;
     relayout_batch(rl, w_ / rb, (w_ % rb) * 256 + threadIdx.x);
     return;
   }
-  scae_first::fwd_block<CIN>(img, w, bias, out, g, blockIdx.x, s_img);
+  scae_first::fwd_block<CIN>(img, w, bias, out, g, blockIdx.x, s_img, out_h);
 }
 
 // weight/bias gradient partials: partial[(n*slices + slice)*parts + part] = one row
@@ -1096,14 +1097,16 @@ extern "C" int scae_conv3x3_relayout_batch_f32(int n_layers, const float *const 
   return scae_launch_status();
 }
 
-extern "C" int scae_conv3x3_first_fwd_relayout_f32(
-    const float *img, const float *w, const float *bias, float *out, int B, int Cin, int IH,
-    int IW, int Cout, int stride, int n_layers, const float *const *rw, float *const *rwf,
-    float *const *rwd, const int *rCout, const int *rCin, void *stream) {
+static int first_fwd_relayout(
+    const float *img, const float *w, const float *bias, float *out, unsigned short *out_h, int B,
+    int Cin, int IH, int IW, int Cout, int stride, int n_layers, const float *const *rw,
+    float *const *rwf, float *const *rwd, unsigned short *const *rwfh,
+    unsigned short *const *rwdh, const int *rCout, const int *rCin, void *stream) {
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check_geom(g, false);
   if (rc) return rc;
-  SCAE_REQUIRE(img && w && bias && out && n_layers >= 0);
+  SCAE_REQUIRE(img && w && bias && (out || out_h) && n_layers >= 0);
+  if (!out) out = reinterpret_cast<float *>(out_h);   // (only its address arithmetic is used)
   if (Cout % 64) return SCAE_ERR_UNSUPPORTED;
   const FirstSplit f = first_split(B, Cout);
   const size_t lds = (size_t)Cin * IH * IW * sizeof(float);
@@ -1111,14 +1114,14 @@ extern "C" int scae_conv3x3_first_fwd_relayout_f32(
   RelayoutBatch r{};
   int rb = 0;
   if (n_layers > 0) {
-    rb = fill_relayout(r, n_layers, rw, rwf, rwd, rCout, rCin);
+    rb = fill_relayout(r, n_layers, rw, rwf, rwd, rCout, rCin, rwfh, rwdh);
     SCAE_REQUIRE(rb > 0);
   }
   const int n_first = B * f.slices;
 #define SCAE_FIRST_FWD(CI)                                                                    \
   case CI:                                                                                    \
     scae::launch(conv_first_fwd_kernel<CI>, dim3(n_first + n_layers * rb), dim3(256),   \
-                       lds, (hipStream_t)stream, img, w, bias, out, g, r, n_first, rb);       \
+                       lds, (hipStream_t)stream, img, w, bias, out, g, r, n_first, rb, out_h); \
     break;
   switch (Cin) {
     SCAE_FIRST_FWD(1) SCAE_FIRST_FWD(2) SCAE_FIRST_FWD(3) SCAE_FIRST_FWD(4)
@@ -1126,6 +1129,24 @@ extern "C" int scae_conv3x3_first_fwd_relayout_f32(
   }
 #undef SCAE_FIRST_FWD
   return scae_launch_status();
+}
+
+extern "C" int scae_conv3x3_first_fwd_relayout_f32(
+    const float *img, const float *w, const float *bias, float *out, int B, int Cin, int IH,
+    int IW, int Cout, int stride, int n_layers, const float *const *rw, float *const *rwf,
+    float *const *rwd, const int *rCout, const int *rCin, void *stream) {
+  SCAE_REQUIRE(out);
+  return first_fwd_relayout(img, w, bias, out, nullptr, B, Cin, IH, IW, Cout, stride, n_layers, rw,
+                            rwf, rwd, nullptr, nullptr, rCout, rCin, stream);
+}
+extern "C" int scae_conv3x3_first_fwd_relayout_bf16(
+    const float *img, const float *w, const float *bias, uint16_t *out_h, int B, int Cin, int IH,
+    int IW, int Cout, int stride, int n_layers, const float *const *rw, float *const *rwf,
+    float *const *rwd, uint16_t *const *rwfh, uint16_t *const *rwdh, const int *rCout,
+    const int *rCin, void *stream) {
+  SCAE_REQUIRE(out_h && (n_layers == 0 || (rwfh && rwdh)));
+  return first_fwd_relayout(img, w, bias, nullptr, out_h, B, Cin, IH, IW, Cout, stride, n_layers,
+                            rw, rwf, rwd, rwfh, rwdh, rCout, rCin, stream);
 }
 
 extern "C" int scae_conv3x3_first_fwd_f32(const float *img, const float *w, const float *bias,

@@ -36,6 +36,7 @@ struct Prologue {
   // the image layer: first_img / first_w / first_bias -> first_out; re-layouts rl
   const float *first_img, *first_w, *first_bias;
   float *first_out;
+  unsigned short *first_out_h;   // (nullable: bf16 instead of fp32)
   scae_first::ConvGeom first_g;
   scae_first::RelayoutBatch rl;
   int n_first, rb;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(NT) void step_prologue_kernel(Prologue p) {
   if (CIN > 0) {
     if (blk < p.n_first) {
       scae_first::fwd_block<(CIN > 0 ? CIN : 1)>(p.first_img, p.first_w, p.first_bias, p.first_out,
-                                               p.first_g, blk, lds);
+                                               p.first_g, blk, lds, p.first_out_h);
       return;
     }
     if (blk < p.nb_first) {
@@ -125,11 +126,13 @@ extern "C" int scae_step_prologue_first_f32(float *dst_image, const float *src_i
     if (img_lds > 64 * 1024) return SCAE_ERR_UNSUPPORTED;
     lds = lds > img_lds ? lds : img_lds;
     p.first_img = f.img, p.first_w = f.w, p.first_bias = f.bias, p.first_out = f.out;
+    p.first_out_h = f.out_h;
     p.first_g = scae_first::ConvGeom{f.B, f.IH, f.IW, (f.IH - 3) / f.stride + 1,
                                      (f.IW - 3) / f.stride + 1, f.Cin, f.Cout, f.stride};
     p.n_first = f.B * scae_first::first_split(f.B, f.Cout).slices;
     if (f.n_layers > 0) {
-      p.rb = scae_first::fill_relayout(p.rl, f.n_layers, f.rw, f.rwf, f.rwd, f.rCout, f.rCin);
+      p.rb = scae_first::fill_relayout(p.rl, f.n_layers, f.rw, f.rwf, f.rwd, f.rCout, f.rCin,
+                                       f.out_h ? f.rwfh : nullptr, f.out_h ? f.rwdh : nullptr);
       SCAE_REQUIRE(p.rb > 0);
     }
     p.nb_first = p.n_first + f.n_layers * p.rb;

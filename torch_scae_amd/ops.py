@@ -169,6 +169,9 @@ class StepPrologue:
         # the encoder's image layer: (image, weights, biases, strides) it was
         # last computed from, its persistent outputs (act, wfs, wds)
         self.first_inputs = self.first_outs = None
+        # ... and, for the bf16-resident encoder (csrc/conv_bf16.hip), the bf16
+        # tensors the launch writes instead / as well: (act_h, wfh, wdh)
+        self.first_half = None
         self.noise_fresh = self.fold_fresh = self.first_fresh = False
         # the folding products ride in the encoder's second conv launch once
         # that launch has shown it can carry them (``_conv_stack_fwd``): the
@@ -189,6 +192,11 @@ class StepPrologue:
             d.rw[i], d.rwf[i], d.rwd[i] = w.data_ptr(), wf.data_ptr(), \
                 wd.data_ptr()
             d.rCout[i], d.rCin[i] = w.shape[0], w.shape[1]
+        if self.first_half is not None:
+            act_h, wfh, wdh = self.first_half
+            d.out_h = act_h.data_ptr()
+            for i, (a, b) in enumerate(zip(wfh, wdh)):
+                d.rwfh[i], d.rwdh[i] = a.data_ptr(), b.data_ptr()
         return d
 
     def launch(self, dst_image=None, src_image=None, dst_label=None,
@@ -1094,27 +1102,40 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
     oh, ow = (H - 3) // s + 1, (W - 3) // s + 1
     pro, launch = _plan().prologue, True
     key = lambda ts: [(t.data_ptr(), tuple(t.shape)) for t in ts]
+    # configs[2]'s precision with bf16-resident operands: the image layer then
+    # writes bf16 (and bf16 copies of the re-laid-out filters)
+    resident = _conv_bf16_resident(B, oh, ow, weights, strides)
+    halves = None
     if pro is not None and pro.first_outs is not None and \
             key([image, *weights, *biases]) == key(
                 [pro.first_inputs[0], *pro.first_inputs[1],
                  *pro.first_inputs[2]]) and \
-            tuple(strides) == pro.first_inputs[3]:
+            tuple(strides) == pro.first_inputs[3] and \
+            (pro.first_half is not None) == resident:
         # persistent outputs: filled by the step's prologue launch (fresh),
         # else by the launch below
         act, wfs, wds = pro.first_outs
+        halves = pro.first_half
         launch = not pro.first_fresh
     else:
-        act = new(B, oh, ow, c1)
+        act = new(B, oh, ow, c1) if not resident else new(1)
         wds, wfs = [], []
         for l in range(1, L):
             co, ci = weights[l].shape[0], weights[l].shape[1]
             # (Cout,9,Cin) + its fragment-major copy (include/scae_hip.h, K8)
             wfs.append(new(2, co, 9, ci))
             wds.append(new(ci, 9, co))
+        if resident:
+            half = lambda *shape: torch.empty(*shape, device=dev,
+                                              dtype=torch.bfloat16)
+            halves = (half(B, oh, ow, c1),
+                      [half(w.shape[0], 9, w.shape[1]) for w in weights[1:]],
+                      [half(w.shape[1], 9, w.shape[0]) for w in weights[1:]])
         if pro is not None:
             pro.first_inputs = (image, list(weights), list(biases),
                                 tuple(strides))
             pro.first_outs = (act, wfs, wds)
+            pro.first_half = halves
     if pro is not None:
         pro.first_fresh = False
     acts = [act]
@@ -1125,15 +1146,23 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
         arr = lambda ts: (ctypes.c_void_p * max(n, 1))(
             *[t.data_ptr() for t in ts])
         ints = lambda v: (ctypes.c_int * max(n, 1))(*v)
-        _lib.call("scae_conv3x3_first_fwd_relayout_f32", _p(image),
-                  _p(weights[0]), _p(biases[0]), _p(act), B, C0, H, W, c1, s, n,
-                  arr(weights[1:]), arr(wfs), arr(wds),
-                  ints([w.shape[0] for w in weights[1:]]),
-                  ints([w.shape[1] for w in weights[1:]]), st)
+        if resident:
+            _lib.call("scae_conv3x3_first_fwd_relayout_bf16", _p(image),
+                      _p(weights[0]), _p(biases[0]), _p(halves[0]), B, C0, H, W,
+                      c1, s, n, arr(weights[1:]), arr(wfs), arr(wds),
+                      arr(halves[1]), arr(halves[2]),
+                      ints([w.shape[0] for w in weights[1:]]),
+                      ints([w.shape[1] for w in weights[1:]]), st)
+        else:
+            _lib.call("scae_conv3x3_first_fwd_relayout_f32", _p(image),
+                      _p(weights[0]), _p(biases[0]), _p(act), B, C0, H, W, c1, s,
+                      n, arr(weights[1:]), arr(wfs), arr(wds),
+                      ints([w.shape[0] for w in weights[1:]]),
+                      ints([w.shape[1] for w in weights[1:]]), st)
     x_post = None
-    if _conv_bf16_resident(B, act.shape[1], act.shape[2], weights, strides):
-        return _conv_stack_fwd_bf16r(act, wfs, wds, weights, biases, strides,
-                                     post_bias)
+    if resident:
+        return _conv_stack_fwd_bf16r(halves, weights, biases, strides,
+                                     post_bias, image.dtype)
     for l in range(1, L):
         w, s = weights[l], strides[l]
         co, ci = w.shape[0], w.shape[1]
@@ -1203,23 +1232,17 @@ def _cvt_bf16(pairs, ref):
                   _stream(ref))
 
 
-def _conv_stack_fwd_bf16r(act, wfs, wds, weights, biases, strides, post_bias):
-    """Layers 1.. of the stack on the bf16-resident kernels.  -> (acts, wds,
-    x_post) like ``_conv_stack_fwd``, with the activations of layers 0 .. L-2
-    and the data-gradient filters as bf16 tensors (what ``_conv_stack_bwd``
-    then reads); the last layer's output stays fp32 (the attention conv and
-    its ReLU gate read it)."""
+def _conv_stack_fwd_bf16r(halves, weights, biases, strides, post_bias, dt):
+    """Layers 1.. of the stack on the bf16-resident kernels.  ``halves``: the
+    image layer's output and the re-laid-out filters as bf16 (act_h, wfh,
+    wdh).  -> (acts, wds, x_post) like ``_conv_stack_fwd``, with the
+    activations of layers 0 .. L-2 and the data-gradient filters as bf16
+    tensors (what ``_conv_stack_bwd`` then reads); the last layer's output
+    stays fp32 (the attention conv and its ReLU gate read it)."""
+    act_h, wfh, wdh = halves
     L = len(strides)
-    B, dev, st = act.shape[0], act.device, _stream(act)
+    B, dev, st = act_h.shape[0], act_h.device, _stream(act_h)
     half = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.bfloat16)
-    act_h = half(*act.shape)
-    pairs, wfh, wdh = [(act, act_h)], [], []
-    for l in range(1, L):
-        co, ci = weights[l].shape[0], weights[l].shape[1]
-        wfh.append(half(co, 9, ci))
-        wdh.append(half(ci, 9, co))
-        pairs += [(wfs[l - 1][0], wfh[-1]), (wds[l - 1], wdh[-1])]
-    _cvt_bf16(pairs, act)
     acts, x_post = [act_h], None
     for l in range(1, L):
         co, ci, s = weights[l].shape[0], weights[l].shape[1], strides[l]
@@ -1227,7 +1250,7 @@ def _conv_stack_fwd_bf16r(act, wfs, wds, weights, biases, strides, post_bias):
         oh, ow = (ih - 3) // s + 1, (iw - 3) // s + 1
         out_h = half(B, oh, ow, co)
         last = l == L - 1
-        out_f = torch.empty(B, oh, ow, co, device=dev, dtype=act.dtype) \
+        out_f = torch.empty(B, oh, ow, co, device=dev, dtype=dt) \
             if last else None
         if last and post_bias is not None:
             x_post = torch.empty_like(out_f)
