@@ -13,15 +13,15 @@
 //     per pair of 16-byte fragment reads), K walked in chunks of 64 (= one tap x 64 channels:
 //     128-byte LDS rows, 16 MFMAs per wave between barriers);
 //   * k-contiguous operands (forward, data gradient) go global -> LDS by DMA
-//     (buffer_load ... lds, 16 bytes per lane, 1 KiB per wave instruction) into two stages; the
+//     (buffer_load ... lds, 16 bytes per lane, 1 KiB per wave instruction) into one or two stages
+//     of 32 KiB (one: five workgroups per CU cover each other -- the faster form once a layer
+//     has more than ~500 tiles; two: the DMA of chunk c + 1 under the MFMAs of chunk c); the
 //     eight 16-byte quads of a 128-byte row are XOR-swizzled with (row >> 1) & 7 on the SOURCE
 //     address (the LDS image of a DMA piece is lane-linear), which makes the row-per-lane
-//     ds_read_b128 fragment reads conflict free; ONE barrier per chunk, the DMA of chunk c + 1
-//     runs under the MFMAs of chunk c;
-//   * k-strided operands (weight gradient: K = pixels) are loaded as (4 pixels) x (4 channels)
-//     blocks -- 8-byte loads, 256 bytes of a pixel per 32 lanes --, transposed in registers
-//     (v_perm_b32) and written into the same k-contiguous LDS image, so the three passes
-//     share one fragment-read / MFMA core;
+//     ds_read_b128 fragment reads conflict free;
+//   * k-strided operands (weight gradient: K = pixels) go global -> LDS by DMA as they lie in
+//     memory ([pixel][channel] rows of 256 bytes) and the MFMA fragments come out of that image
+//     through gfx950's transposing read ds_read_b64_tr_b16;
 //   * the data gradient walks input pixels grouped by stride parity, each class only over the
 //     taps that reach it (no MFMA multiplies a structural zero of the stride-2 layer); rows whose
 //     tap falls outside the output read zeros through the buffer descriptor's range check.
@@ -110,17 +110,15 @@ __device__ __forceinline__ void tile_epilogue(float *smem, const f32x16 (&acc)[2
 // NS stages of 32 KiB: NS - 1 chunks in flight under the MFMAs of the current one, ONE barrier
 // per chunk (NS = 1: no overlap inside the workgroup, two barriers per chunk, but five
 // workgroups share a CU's LDS and cover each other).
-template <int NS, class Issue>
-__device__ __forceinline__ void dma_mainloop(int nchunk, unsigned char *smem, f32x16 (&acc)[2][2],
-                                             int wid, int lane, Issue issue) {
-  const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+template <int NS, class Issue, class Mma>
+__device__ __forceinline__ void dma_loop(int nchunk, unsigned char *smem, Issue issue, Mma mma) {
   if (nchunk <= 0) return;
   if (NS == 1) {
     for (int c = 0; c < nchunk; ++c) {
       issue(c, smem);
       pipe::wait_vm<0>();
       pipe::wg_barrier();
-      mma_chunk(smem, acc, wm, wn, i, kk);
+      mma(smem);
       pipe::wg_barrier();   // everyone has read the stage: the next chunk may land
     }
     return;
@@ -136,9 +134,16 @@ __device__ __forceinline__ void dma_mainloop(int nchunk, unsigned char *smem, f3
     pipe::wg_barrier();   // ... everyone's; and everyone is done reading chunk c - 1's stage
     const int sp = s == 0 ? NS - 1 : s - 1;   // = stage of chunk c - 1 = of chunk c + NS - 1
     if (c + NS - 1 < nchunk) issue(c + NS - 1, smem + sp * STAGE_B);
-    mma_chunk(smem + s * STAGE_B, acc, wm, wn, i, kk);
+    mma(smem + s * STAGE_B);
     s = s + 1 == NS ? 0 : s + 1;
   }
+}
+template <int NS, class Issue>
+__device__ __forceinline__ void dma_mainloop(int nchunk, unsigned char *smem, f32x16 (&acc)[2][2],
+                                             int wid, int lane, Issue issue) {
+  const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  dma_loop<NS>(nchunk, smem, issue,
+               [&](const unsigned char *stage) { mma_chunk(stage, acc, wm, wn, i, kk); });
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
@@ -327,9 +332,7 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_bf16r_kernel(
 // partial[(split * 9 + tap)][co][ci] = sum over the split's pixels m of dpre[m][co] x[pix(m, tap)][ci];
 // bias partials [split][co] behind the 9 * splits slabs (the layout of the fp32 kernels: the
 // same reduction launch sums them).  grid (Cin / 128, Cout / 128, 9 * splits).
-// Both operands are k-strided in memory ([pixel][channel]): a thread loads (4 pixels) x (4
-// channels) blocks -- 8 bytes per pixel --, transposes them in registers and writes 8-byte
-// runs of 4 consecutive k into the k-contiguous LDS image the MFMA core reads.
+// Both operands are k-strided in memory ([pixel][channel]).
 struct PixelWalk {   // (n, oh, ow) of a pixel index, advanced without divisions
   int n, oh, ow;
 };
@@ -340,95 +343,114 @@ __device__ __forceinline__ void walk(PixelWalk &p, int dq, int drm, const ConvGe
   p.oh += dq + carry;
   while (p.oh >= g.OH) p.oh -= g.OH, ++p.n;
 }
-__global__ __launch_bounds__(NT, 3) void conv_wgrad_bf16r_kernel(
+// A first form loaded (4 pixels) x (4 channels) blocks, transposed them in registers (v_perm_b32)
+// and wrote 8-byte runs into a k-contiguous image: 16 8-byte loads, 32 v_perm and 16
+// ds_write_b64 per thread and chunk -- 150 us for the three layers at B = 1024 against 121 for
+// what follows.  gfx950's ds_read_b64_tr_b16 hands a lane
+// COLUMN t of a 4 x 16 block of 16-bit elements whose rows the 16 lanes of its group address
+// (tools/probes/tr_read.cpp: any row stride) -- the MFMA fragment of a k-strided operand
+// straight from a [pixel][channel] image.  So both operands go global -> LDS by DMA exactly as
+// they lie in memory (a pixel's 128 channels = 256 bytes = 16 lanes x 16 bytes; a 1 KiB piece
+// = 4 pixels), and the fragments are two transposing reads each:
+//   lane l = 16 g + t of a wave: channel 16 (g & 1) + t of the 32-row block, k half g >> 1;
+//   it supplies the address of pixel k0 + (t >> 2), channels 16 (g & 1) + 4 (t & 3) .. + 3 and
+//   receives its channel at pixels k0 .. k0 + 3 (k0 = 8 (g >> 1), then + 4).
+// The sixteen 16-byte units of a pixel row are XOR-swizzled with a bit permutation of the row
+// index (on the DMA's source address), so that the four rows a lane group reads -- and the rows
+// of the other groups -- lie in different banks.  The bias gradient (column sums of dpre) is
+// one more MFMA per fragment against a tile of ones in the tap-0 workgroups.
+__device__ __forceinline__ int swz_px(int row) {   // 4-bit XOR mask of pixel row `row`
+  return ((row & 3) << 1) | ((row >> 2) & 1) | (row & 8);
+}
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *tile, int c0, int k0, int t) {
+  // channels c0 + 4 (t & 3) .. + 3 of pixel rows k0 + (t >> 2) and k0 + 4 + (t >> 2)
+  const int ch = c0 + 4 * (t & 3), u = ch >> 3, half = (ch >> 2) & 1;
+  const int r0 = k0 + (t >> 2), r1 = r0 + 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(tile + r0 * 256 + ((u ^ swz_px(r0)) << 4) + half * 8));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(tile + r1 * 256 + ((u ^ swz_px(r1)) << 4) + half * 8));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int NS>
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16r_tr_kernel(
     const bf16_t *__restrict__ dpre, const bf16_t *__restrict__ x, float *__restrict__ partial,
     ConvGeom g, int splits) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  const int wm = wid >> 1, wn = wid & 1, t = lane & 15, grp = lane >> 4;
   const int M = g.B * g.OH * g.OW;
   const int tap = blockIdx.z % 9, split = blockIdx.z / 9, kh = tap / 3, kw = tap - kh * 3;
   const int per = ((M + splits - 1) / splits + BKE - 1) / BKE * BKE;
   const int kbeg = split * per, kend = min(M, kbeg + per);
   const int co0 = blockIdx.y * TM, ci0 = blockIdx.x * TN;
   const bool want_bias = tap == 0 && blockIdx.x == 0;   // (workgroup-uniform)
-  // this thread's blocks: channel group chg (4 channels), pixel groups pxg + 8 j (4 pixels)
-  const int chg = tid & 31, pxg = tid >> 5;
-  PixelWalk pw_[2];
+  const pipe::rsrc_t ra = pipe::make_rsrc(dpre, (unsigned)((size_t)M * g.Cout * 2));
+  const pipe::rsrc_t rb = pipe::make_rsrc(x, (unsigned)((size_t)g.B * g.IH * g.IW * g.Cin * 2));
+  // DMA: piece j of wave w = pixel rows 4 (4 w + j) .. + 3 of the chunk; lane l the row
+  // 4 (4 w + j) + (l >> 4) and the LDS unit l & 15 of it
+  int prow[4], usrc[4];
+  PixelWalk pwk[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = kbeg + 4 * (pxg + 8 * j);
-    pw_[j].n = m / (g.OH * g.OW);
-    const int rem = m - pw_[j].n * g.OH * g.OW;
-    pw_[j].oh = rem / g.OW, pw_[j].ow = rem - pw_[j].oh * g.OW;
+  for (int j = 0; j < 4; ++j) {
+    prow[j] = 4 * (4 * wid + j) + (lane >> 4);
+    usrc[j] = ((lane & 15) ^ swz_px(prow[j])) << 4;   // byte offset of the source unit
+    const int m = kbeg + prow[j];
+    pwk[j].n = m / (g.OH * g.OW);
+    const int rem = m - pwk[j].n * g.OH * g.OW;
+    pwk[j].oh = rem / g.OW, pwk[j].ow = rem - pwk[j].oh * g.OW;
   }
   const int dq = BKE / g.OW, drm = BKE - dq * g.OW;
-  uint2 qa[2][4], qb[2][4];   // [block j][pixel i]: 4 channels of dpre / x
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](int c) {
+  f32x16 acc[2][2], accb[2];
+  zero_acc(acc);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[tt][e] = 0.f;
+  const int nchunk = kbeg < kend ? (kend - kbeg + BKE - 1) / BKE : 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  dma_loop<NS>(nchunk, smem,
+               [&](int c, unsigned char *stage) {   // (called once per chunk, c ascending)
     const int k0 = kbeg + c * BKE;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      PixelWalk p = pw_[j];
+    for (int j = 0; j < 4; ++j) {
+      const int m = k0 + prow[j];
+      const bool ok = m < kend;
+      const int va = ok ? (m * g.Cout + co0) * 2 + usrc[j] : pipe::DMA_ZERO;
+      const int pix = (pwk[j].n * g.IH + pwk[j].oh * g.stride + kh) * g.IW + pwk[j].ow * g.stride + kw;
+      const int vb = ok ? (pix * g.Cin + ci0) * 2 + usrc[j] : pipe::DMA_ZERO;
+      pipe::dma16(ra, reinterpret_cast<float *>(stage + (4 * wid + j) * 1024), va, 0);
+      pipe::dma16(rb, reinterpret_cast<float *>(stage + TILE_B + (4 * wid + j) * 1024), vb, 0);
+      walk(pwk[j], dq, drm, g);
+    }
+  },
+               [&](const unsigned char *stage) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = k0 + 4 * (pxg + 8 * j) + e;
-        qa[j][e] = qb[j][e] = make_uint2(0u, 0u);
-        if (m < kend) {
-          const size_t pix = ((size_t)p.n * g.IH + p.oh * g.stride + kh) * g.IW + p.ow * g.stride + kw;
-          qa[j][e] = *reinterpret_cast<const uint2 *>(dpre + (size_t)m * g.Cout + co0 + 4 * chg);
-          qb[j][e] = *reinterpret_cast<const uint2 *>(x + pix * g.Cin + ci0 + 4 * chg);
-        }
-        walk(p, 0, 1, g);   // the next pixel
+    for (int s16 = 0; s16 < BKE / 16; ++s16) {
+      const int k0 = 16 * s16 + 8 * (grp >> 1);
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        a[tt] = tr_frag(stage, wm * 64 + tt * 32 + 16 * (grp & 1), k0, t);
+        b[tt] = tr_frag(stage + TILE_B, wn * 64 + tt * 32 + 16 * (grp & 1), k0, t);
       }
-      walk(pw_[j], dq, drm, g);   // this block's first pixel of the next chunk
-    }
-  };
-  // (4 pixels) x (4 channels) -> 4 channel rows of 4 consecutive k, 8 bytes each
-  auto deposit = [&](unsigned char *tile, const uint2 (&q)[4], int pg) {
-    const unsigned lo01 = __builtin_amdgcn_perm(q[1].x, q[0].x, 0x05040100u);   // ch 0: k0 k1
-    const unsigned lo23 = __builtin_amdgcn_perm(q[3].x, q[2].x, 0x05040100u);   //       k2 k3
-    const unsigned hi01 = __builtin_amdgcn_perm(q[1].x, q[0].x, 0x07060302u);   // ch 1
-    const unsigned hi23 = __builtin_amdgcn_perm(q[3].x, q[2].x, 0x07060302u);
-    const unsigned lo01b = __builtin_amdgcn_perm(q[1].y, q[0].y, 0x05040100u);  // ch 2
-    const unsigned lo23b = __builtin_amdgcn_perm(q[3].y, q[2].y, 0x05040100u);
-    const unsigned hi01b = __builtin_amdgcn_perm(q[1].y, q[0].y, 0x07060302u);  // ch 3
-    const unsigned hi23b = __builtin_amdgcn_perm(q[3].y, q[2].y, 0x07060302u);
-    const uint2 rows[4] = {make_uint2(lo01, lo23), make_uint2(hi01, hi23), make_uint2(lo01b, lo23b),
-                           make_uint2(hi01b, hi23b)};
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int row = 4 * chg + cc;
-      *reinterpret_cast<uint2 *>(tile + row * ROWB + swz(row, pg >> 1) * 16 + (pg & 1) * 8) = rows[cc];
-    }
-  };
-  f32x16 acc[2][2];
-  zero_acc(acc);
-  const int nchunk = kbeg < kend ? (kend - kbeg + BKE - 1) / BKE : 0;
-  if (nchunk > 0) fetch(0);
-  for (int c = 0; c < nchunk; ++c) {
-    // ONE stage: 32 KiB per workgroup -- three workgroups per CU at this kernel's 160 VGPRs;
-    // the next chunk waits in registers while this one is multiplied
-    unsigned char *stage = smem;
-    if (c) __syncthreads();   // everyone has read the previous chunk
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      deposit(stage, qa[j], pxg + 8 * j);
-      deposit(stage + TILE_B, qb[j], pxg + 8 * j);
-    }
-    if (want_bias) {
+        for (int u = 0; u < 2; ++u)
+          acc[tt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt], b[u], acc[tt][u], 0, 0, 0);
+      if (want_bias && wn == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bsum[0] += bf_lo(qa[j][e].x), bsum[1] += bf_hi(qa[j][e].x);
-          bsum[2] += bf_lo(qa[j][e].y), bsum[3] += bf_hi(qa[j][e].y);
-        }
+        for (int tt = 0; tt < 2; ++tt)
+          accb[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt], ones, accb[tt], 0, 0, 0);
+      }
     }
-    __syncthreads();   // the stage is complete
-    if (c + 1 < nchunk) fetch(c + 1);
-    mma_chunk(stage, acc, wm, wn, i, kk);
-  }
+  });
   float *dst = partial + (size_t)(split * 9 + tap) * g.Cout * g.Cin;
   tile_epilogue(reinterpret_cast<float *>(smem), acc, wid, lane,
                 [&](int row, int col, const float (&v)[8]) {
@@ -436,18 +458,14 @@ __global__ __launch_bounds__(NT, 3) void conv_wgrad_bf16r_kernel(
     *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
   });
-  if (want_bias) {   // the eight pixel groups of a channel group meet in LDS (fixed order)
-    __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);
+  if (want_bias && wn == 0 && (lane & 31) == 0) {   // column 0 of the ones product
+    const int kk = lane >> 5;
+    float *db = partial + (size_t)splits * 9 * g.Cout * g.Cin + (size_t)split * g.Cout + co0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[(pxg * 32 + chg) * 4 + e] = bsum[e];
-    __syncthreads();
-    if (tid < TM) {
-      float t = 0.f;
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int p = 0; p < 8; ++p) t += red[(p * 32 + (tid >> 2)) * 4 + (tid & 3)];
-      partial[(size_t)splits * 9 * g.Cout * g.Cin + (size_t)split * g.Cout + co0 + tid] = t;
-    }
+      for (int e = 0; e < 16; ++e)
+        db[wm * 64 + tt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk] = accb[tt][e];
   }
 }
 
@@ -574,10 +592,11 @@ extern "C" int scae_conv3x3_dgrad_bf16r(const uint16_t *dpre, const uint16_t *wd
 
 extern "C" int scae_conv3x3_wgrad_bf16r_splits(int B, int OH, int OW, int Cin, int Cout) {
   if (B <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || Cin % 128 || Cout % 128) return 0;
-  // 3 workgroups per CU (the kernel's registers) over the 9 taps x channel tiles, all
-  // resident at once: <= 768; at least 4 chunks of K each
+  // two workgroups per CU over the 9 taps x channel tiles (measured at B = 1024, the three
+  // layers: 256 workgroups 166 us, 384 132, 512 121, 768 126, 1024 145; fewer splits also
+  // mean fewer partial slabs to write and reduce); at least 4 chunks of K each
   const long tiles = 9L * (Cin / 128) * (Cout / 128), M = (long)B * OH * OW;
-  long s = 768 / tiles;
+  long s = 512 / tiles;
   const long cap = M / (4 * BKE);
   s = s > cap ? cap : s;
   return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
@@ -591,7 +610,16 @@ extern "C" int scae_conv3x3_wgrad_bf16r(const uint16_t *dpre, const uint16_t *x,
   int rc = check(g);
   if (rc) return rc;
   const int splits = scae_conv3x3_wgrad_bf16r_splits(B, g.OH, g.OW, Cin, Cout);
-  scae::launch(conv_wgrad_bf16r_kernel, dim3(Cin / TN, Cout / TM, 9 * splits), dim3(NT), STAGE_B,
-               (hipStream_t)stream, dpre, x, partial, g, splits);
+  const dim3 grid(Cin / TN, Cout / TM, 9 * splits);
+#define SCAE_WG_NS(N)                                                                           \
+  case N:                                                                                       \
+    if ((rc = raise_lds(conv_wgrad_bf16r_tr_kernel<N>, N * STAGE_B))) return rc;                \
+    scae::launch(conv_wgrad_bf16r_tr_kernel<N>, grid, dim3(NT), N * STAGE_B,                    \
+                 (hipStream_t)stream, dpre, x, partial, g, splits);                             \
+    break;
+  switch (ring_depth("SCAE_BF16R_WGRAD_NS", 1)) {
+    SCAE_WG_NS(1) SCAE_WG_NS(2) SCAE_WG_NS(3) SCAE_WG_NS(4)
+  }
+#undef SCAE_WG_NS
   return scae_launch_status();
 }
