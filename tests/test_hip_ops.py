@@ -2687,6 +2687,82 @@ def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides, resident, monke
             assert _rel_l2(got, ref) <= 8e-2, (name, l, _rel_l2(got, ref))
 
 
+@pytest.mark.parametrize("B,IH,IW,stride", [
+    (2, 9, 9, 1),        # one partial tile
+    (3, 9, 11, 2),       # every parity class of the stride-2 data gradient, ragged
+    (5, 19, 19, 2),      # cfg-3's second layer
+    (130, 5, 5, 1),      # several tiles, the last one ragged; 2 weight-gradient splits
+])
+def test_conv_bf16_resident_kernels_vs_fp64(B, IH, IW, stride):
+    """csrc/conv_bf16.hip, each pass on its own through the C ABI: operands that ARE bf16
+    (so nothing is rounded on the way in), products on v_mfma_f32_32x32x16_bf16 with fp32
+    accumulation -- the fp32 outputs (forward: out_f / out_post; data gradient: din_f; weight
+    gradient: the summed partial slabs and the bias partials) against conv2d in fp64 at fp32
+    round-off (1e-5 of the tensor's largest entry), the bf16 outputs at bf16's (2^-8)."""
+    import ctypes
+    import torch.nn.functional as F
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    C, s = 128, stride
+    g = torch.Generator().manual_seed(B * 100 + IH)
+    OH, OW = (IH - 3) // s + 1, (IW - 3) // s + 1
+    st = P(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else P(t.data_ptr())
+    x = torch.relu(torch.randn(B, IH, IW, C, generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(torch.bfloat16).cuda()   # (co,ci,3,3)
+    bias, post = torch.randn(C, generator=g).cuda(), torch.randn(C, OH, OW, generator=g).cuda()
+    wf = w.permute(0, 2, 3, 1).contiguous()       # (co, 9, ci)
+    wd = w.permute(1, 2, 3, 0).contiguous()       # (ci, 9, co)
+    assert lib.scae_conv3x3_bf16r_supported(B, IH, IW, C, C, s) == 1
+    assert lib.scae_conv3x3_bf16r_supported(B, IH, IW, 64, C, s) == 0
+    out_h = torch.empty(B, OH, OW, C, device="cuda", dtype=torch.bfloat16)
+    out_f, out_p = torch.empty(B, OH, OW, C, device="cuda"), torch.empty(B, OH, OW, C, device="cuda")
+    _lib.call("scae_conv3x3_fwd_bf16r", p(x), p(wf), p(bias), p(out_h), p(out_f), p(post), p(out_p),
+              B, IH, IW, C, C, s, st)
+    x64 = x.double().permute(0, 3, 1, 2).cpu()
+    ref = torch.relu(F.conv2d(x64, w.double().cpu(), bias.double().cpu(), stride=s)).permute(0, 2, 3, 1)
+    top = float(ref.abs().max())
+    assert float((out_f.double().cpu() - ref).abs().max()) <= 1e-5 * top
+    assert float((out_h.double().cpu() - ref).abs().max()) <= 2 ** -8 * top
+    assert float((out_p.double().cpu() - ref - post.double().cpu().permute(1, 2, 0)).abs().max()) \
+        <= 1e-5 * (top + float(post.abs().max()))
+    # data gradient, gated by x > 0
+    dpre = torch.randn(B, OH, OW, C, generator=g).to(torch.bfloat16).cuda()
+    din_h = torch.empty(B, IH, IW, C, device="cuda", dtype=torch.bfloat16)
+    din_f = torch.full((B, IH, IW, C), 7.0, device="cuda")
+    _lib.call("scae_conv3x3_dgrad_bf16r", p(dpre), p(wd), p(x), p(din_h), p(din_f), B, IH, IW, C, C,
+              s, st)
+    xr = x64.clone().requires_grad_(True)
+    F.conv2d(xr, w.double().cpu(), None, stride=s).backward(dpre.double().permute(0, 3, 1, 2).cpu())
+    dref = (xr.grad * (xr.detach() > 0)).permute(0, 2, 3, 1)
+    top = float(dref.abs().max())
+    assert float((din_f.double().cpu() - dref).abs().max()) <= 1e-5 * top
+    assert float((din_h.double().cpu() - dref).abs().max()) <= 2 ** -8 * top
+    # weight gradient: split partials in the fp32 kernels' layout
+    splits = lib.scae_conv3x3_wgrad_bf16r_splits(B, OH, OW, C, C)
+    assert splits >= 1
+    part = torch.full((splits * (9 * C * C + C),), 3.0, device="cuda")
+    _lib.call("scae_conv3x3_wgrad_bf16r", p(dpre), p(x), p(part), B, IH, IW, C, C, s, st)
+    torch.cuda.synchronize()
+    dw = part[:splits * 9 * C * C].view(splits, 9, C, C).sum(0).double().cpu()     # (tap, co, ci)
+    db = part[splits * 9 * C * C:].view(splits, C).sum(0).double().cpu()
+    wr = w.double().cpu().requires_grad_(True)
+    F.conv2d(x64, wr, None, stride=s).backward(dpre.double().permute(0, 3, 1, 2).cpu())
+    wref = wr.grad.permute(2, 3, 0, 1).reshape(9, C, C)
+    assert float((dw - wref).abs().max()) <= 1e-5 * float(wref.abs().max())
+    bref = dpre.double().cpu().sum((0, 1, 2))
+    assert float((db - bref).abs().max()) <= 1e-5 * float(dpre.double().abs().sum((0, 1, 2)).max())
+    # the batched fp32 -> bf16 copy: round to nearest even, like torch's
+    a, b = torch.randn(1000 * 8, generator=g).cuda(), torch.randn(24, generator=g).cuda()
+    ah = torch.empty(a.shape, device="cuda", dtype=torch.bfloat16)
+    bh = torch.empty(b.shape, device="cuda", dtype=torch.bfloat16)
+    _lib.call("scae_cvt_bf16_batch", 2, (P * 2)(a.data_ptr(), b.data_ptr()),
+              (P * 2)(ah.data_ptr(), bh.data_ptr()), (ctypes.c_int64 * 2)(a.numel(), b.numel()), st)
+    torch.cuda.synchronize()
+    assert torch.equal(ah, a.to(torch.bfloat16)) and torch.equal(bh, b.to(torch.bfloat16))
+
+
 def test_grouped_mlp_bf16_operands_vs_fp64():
     """K7 (the per-capsule MLPs as batched GEMMs) with bf16 operands: forward,
     input gradient and weight / bias gradients at configs[2]'s layer sizes."""

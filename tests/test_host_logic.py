@@ -86,6 +86,37 @@ def test_launch_list_lanes_and_order_edges_without_a_gpu():
     lib.scae_launch_list_free(P(b))
 
 
+def test_bf16_resident_conv_entry_points_reject_bad_arguments_without_a_gpu():
+    """csrc/conv_bf16.hip: shape predicate, split rule and argument checks happen before any
+    HIP call."""
+    import ctypes
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    d = P(0x1000)
+    assert lib.scae_conv3x3_bf16r_supported(1024, 19, 19, 128, 128, 2) == 1
+    assert lib.scae_conv3x3_bf16r_supported(128, 9, 9, 256, 128, 1) == 1
+    assert lib.scae_conv3x3_bf16r_supported(128, 9, 9, 64, 128, 1) == 0      # channels % 128
+    assert lib.scae_conv3x3_bf16r_supported(128, 9, 9, 128, 128, 3) == 0     # stride
+    assert lib.scae_conv3x3_bf16r_supported(128, 2, 9, 128, 128, 1) == 0     # no output row
+    assert lib.scae_conv3x3_bf16r_supported(1 << 16, 40, 40, 128, 128, 1) == 0   # >= 2 GiB
+    assert lib.scae_conv3x3_fwd_bf16r(None, d, d, d, None, None, None, 4, 9, 9, 128, 128, 1,
+                                      None) == -1
+    assert lib.scae_conv3x3_fwd_bf16r(d, d, d, d, None, None, d, 4, 9, 9, 128, 128, 1,
+                                      None) == -1      # out_post without its bias
+    assert lib.scae_conv3x3_fwd_bf16r(d, d, d, d, None, None, None, 4, 9, 9, 64, 128, 1,
+                                      None) == -2
+    assert lib.scae_conv3x3_dgrad_bf16r(d, d, None, None, None, 4, 9, 9, 128, 128, 1, None) == -1
+    assert lib.scae_conv3x3_wgrad_bf16r(d, None, d, 4, 9, 9, 128, 128, 1, None) == -1
+    # two workgroups per CU over the 9 taps, at least four 64-pixel chunks each
+    assert lib.scae_conv3x3_wgrad_bf16r_splits(1024, 9, 9, 128, 128) == 56
+    assert lib.scae_conv3x3_wgrad_bf16r_splits(2, 7, 7, 128, 128) == 1
+    assert lib.scae_conv3x3_wgrad_bf16r_splits(2, 7, 7, 64, 128) == 0
+    assert lib.scae_cvt_bf16_batch(0, None, None, None, None) == -1
+    assert lib.scae_cvt_bf16_batch(1, (P * 1)(0x1000), (P * 1)(0x2000),
+                                   (ctypes.c_int64 * 1)(12), None) == -1     # n % 8
+
+
 def test_sum_jobs_reject_a_ragged_periodic_window():
     """a periodic segment over a column count that is not a multiple of its period
     has no well-defined destination range (the optimiser launch derives the elements a sum
