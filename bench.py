@@ -314,18 +314,37 @@ def time_k8_kernels(cfg, device, reps=50, bf16=False):
         part = f(splits * (9 * Co * Ci + Co))
         geo = (I(B), I(IH), I(IH), I(Ci), I(Co), I(s))
         calls = {
-            "conv_fwd_kernel": lambda: (lib.scae_conv3x3_fwd_bf16 if bf16
-                                        else lib.scae_conv3x3_fwd_f32)(
+            "conv_fwd_kernel": lambda: lib.scae_conv3x3_fwd_f32(
                 p(x), p(wf), p(bias), p(y), None, None, *geo, st),
             "conv_dgrad_kernel": lambda: lib.scae_conv3x3_dgrad_f32(
                 p(dy), p(wd), p(x), p(dx), *geo, st),
             "conv_wgrad_kernel": lambda: lib.scae_conv3x3_wgrad_f32(
                 p(dy), p(x), p(part), p(dw), p(db), *geo, st),
             # what the step launches: both gradients of a layer together
-            "conv_bwd_pair_kernel": lambda: (lib.scae_conv3x3_bwd_pair_bf16 if bf16
-                                             else lib.scae_conv3x3_bwd_pair_f32)(
+            "conv_bwd_pair_kernel": lambda: lib.scae_conv3x3_bwd_pair_f32(
                 p(dy), p(wd), p(x), p(dx), p(part), *geo, st),
         }
+        if bf16 and lib.scae_conv3x3_bf16r_supported(B, IH, IH, Ci, Co, s):
+            # configs[2]'s precision: the bf16-RESIDENT kernels (csrc/conv_bf16.hip) on bf16
+            # tensors -- what the step launches; its "pair" is two launches
+            h = lambda t: t.to(torch.bfloat16)     # noqa: E731
+            xh, yh, dyh, dxh = h(x), h(y), h(dy), h(dx)
+            wfh, wdh = h(wf[0]), h(wd)
+            hs = lib.scae_conv3x3_wgrad_bf16r_splits(B, OH, OH, Ci, Co)
+            parth = f(hs * (9 * Co * Ci + Co))
+
+            def fwd_h():
+                return lib.scae_conv3x3_fwd_bf16r(p(xh), p(wfh), p(bias), p(yh), None, None,
+                                                  None, *geo, st)
+
+            def dgrad_h():
+                return lib.scae_conv3x3_dgrad_bf16r(p(dyh), p(wdh), p(xh), p(dxh), None, *geo, st)
+
+            def wgrad_h():
+                return lib.scae_conv3x3_wgrad_bf16r(p(dyh), p(xh), p(parth), *geo, st)
+            calls = {"conv_fwd_kernel": fwd_h, "conv_dgrad_kernel": dgrad_h,
+                     "conv_wgrad_kernel": wgrad_h,
+                     "conv_bwd_pair_kernel": lambda: dgrad_h() or wgrad_h()}
         flops1 = 2.0 * B * OH * OH * Co * 9 * Ci       # MACs x 2 of one pass
         for name, fn in calls.items():
             flops = flops1 * (2 if name == "conv_bwd_pair_kernel" else 1)
@@ -359,9 +378,8 @@ def roofline(cfg, device, bf16=False, light=False):
     alg = k1_algorithmic_bytes(cfg)
     B = cfg["batch"]
     k8 = time_k8_kernels(cfg, device, reps=15 if light else 50, bf16=bf16)
-    # --bf16: the forward / pair launchers round their operands to bf16 and run on
-    # v_mfma_f32_32x32x16_bf16 -- priced against the dense bf16 peak; the separate dgrad /
-    # wgrad launchers have no bf16 form and stay fp32
+    # --bf16: the bf16-resident kernels on v_mfma_f32_32x32x16_bf16, priced against the dense
+    # bf16 peak (shapes they do not cover stay on the fp32 kernels)
     peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_FP32_PEAK_TFLOPS
     name = "conv_bwd_pair_kernel"
     launches = k8[name]
@@ -385,8 +403,7 @@ def roofline(cfg, device, bf16=False, light=False):
             "bytes_per_image": alg[k]} for k, v in k1.items()}
     for k, ls in k8.items():
         t, fl = sum(l["seconds"] for l in ls), sum(l["flops"] for l in ls)
-        pk = peak if k in ("conv_fwd_kernel", "conv_bwd_pair_kernel") \
-            else MFMA_FP32_PEAK_TFLOPS
+        pk = peak
         others[k] = {"us_per_step": round(t * 1e6, 2), "launches": len(ls),
                      "bound": "mfma", "TFLOPs": round(fl / t / 1e12, 1),
                      "peak": pk, "frac": round(fl / t / 1e12 / pk, 4)}
@@ -405,6 +422,40 @@ def roofline(cfg, device, bf16=False, light=False):
                 "from profiles/r0x/k8_pmc.json (separate rocprofv3 --pmc "
                 "passes); K1 byte figures: DESIGN.md section 4",
     }
+
+
+def step_timeline(step):
+    """Per-launch (name, lane, start us, duration us) of ONE real step, from a timing event
+    in front of and behind every launch of the step's recorded launch list, on the launch's
+    own stream (scae_launch_list_timeline): the kernels in their places in the step, caches
+    and clocks as the step leaves them -- not a stand-alone loop of one kernel.  None when
+    the step has no launch list or its C-ABI calls and kernel launches are not one to one."""
+    import ctypes
+    from torch_scae_amd import _lib
+    kl = getattr(step, "_klist", None)
+    if not kl or not step._launches:
+        return None
+    lib = _lib.load()
+    n = lib.scae_launch_list_size(kl)
+    names = [getattr(fn, "__name__", "?") for fn, _, _ in step._launches]
+    if n != len(names):
+        return None
+    out = (ctypes.c_float * (2 * n))()
+    P = ctypes.c_void_p
+    side = step.plan.side_stream
+    best = None
+    for _ in range(7):
+        rc = lib.scae_launch_list_timeline(
+            kl, P(torch.cuda.current_stream().cuda_stream),
+            None if side is None else P(side.cuda_stream), out, 2 * n)
+        if rc != 0:
+            return None
+        t = list(out)
+        if best is None or max(t[1::2]) < max(best[1::2]):
+            best = t
+    return [dict(name=names[i], lane=lib.scae_launch_list_lane(kl, i),
+                 start_us=round(best[2 * i], 2),
+                 us=round(best[2 * i + 1] - best[2 * i], 2)) for i in range(n)]
 
 
 def host_cores():
@@ -1051,6 +1102,13 @@ def main():
         step.replay = chosen
         timing["replay_as_launch_list_ms" if other == "launches"
                else "replay_as_graph_ms"] = t3["median_ms"]
+    in_step = None
+    if not collective and has_list and not args.no_roofline:
+        step.restore(snap)
+        for i in range(args.warmup):
+            step(images[i % len(images)], labels[i % len(labels)])
+        torch.cuda.synchronize()
+        in_step = step_timeline(step)
     final_loss = float(step.loss)
     final_state = capsule_state(step.model, images[0])
     # "optimizer step reported separately" (the reference's step
@@ -1144,6 +1202,28 @@ def main():
             result["comm"] = comm
         if not args.no_roofline:
             result["roofline"] = roofline(cfg, device, bf16=args.bf16)
+            if in_step is not None:
+                # the dominant kernel IN the step: its launches' durations between HIP events
+                # on the step's own stream (round 5's review: the stand-alone loop flatters it)
+                r = result["roofline"]
+                pair = [l["us"] for l in in_step if "conv3x3_bwd_pair" in l["name"]
+                        or "conv3x3_dgrad_bf16r" in l["name"]
+                        or "conv3x3_wgrad_bf16r" in l["name"]]
+                # (bf16-resident: a layer's data and weight gradient are two launches)
+                if len(pair) in (r["launches_per_step"], 2 * r["launches_per_step"]):
+                    fl_all = r["algorithmic_flops_per_launch"] * len(pair)
+                    r["standalone"] = dict(achieved=r["achieved"], frac=r["frac"],
+                                           us_per_launch=r["us_per_launch"],
+                                           per_layer_us=r["per_layer_us"])
+                    r["achieved"] = round(fl_all / (sum(pair) * 1e-6) / 1e12, 1)
+                    r["frac"] = round(r["achieved"] / r["peak"], 4)
+                    r["us_per_launch"] = round(sum(pair) / r["launches_per_step"], 2)
+                    r["per_layer_us"] = pair
+                    r["measured"] = ("in the step: a HIP event in front of and behind every "
+                                     "launch of one real step on the step's stream "
+                                     "(scae_launch_list_timeline; `standalone`: back-to-back "
+                                     "launches of the kernel alone)")
+                r["step_launches"] = in_step
             fl, by = step_algorithmic(cfg)
             ips = result["value"] / world        # per GPU
             result["roofline"]["step"] = {
