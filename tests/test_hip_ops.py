@@ -2689,7 +2689,8 @@ def test_conv_stack_bf16_operands_vs_fp64(B, HW, chans, strides, resident, monke
 
 @pytest.mark.parametrize("B,IH,IW,stride", [
     (2, 9, 9, 1),        # one partial tile
-    (3, 9, 11, 2),       # every parity class of the stride-2 data gradient, ragged
+    (3, 9, 11, 2),       # every tap-set class of the stride-2 data gradient, ragged
+    (2, 10, 12, 2),      # ... with a last row / column that no tap reaches (zero gradient)
     (5, 19, 19, 2),      # cfg-3's second layer
     (130, 5, 5, 1),      # several tiles, the last one ragged; 2 weight-gradient splits
 ])

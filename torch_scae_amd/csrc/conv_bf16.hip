@@ -244,40 +244,95 @@ __global__ __launch_bounds__(NT, 2) void conv_fwd_bf16r_kernel(
 
 // ---- data gradient -------------------------------------------------------------------------
 // din[pixel][ci] = gate(sum over the taps that reach the pixel of dpre[.][co] wd[ci][tap][co]).
-// Input pixels are grouped by stride parity (one class at stride 1): class (ph, pw) holds
-// ih = s a + ph, iw = s b + pw and is reached by the taps kh = ph + s ti <= 2, kw = pw + s tj
-// <= 2 at the output pixel (a - ti, b - tj); a tap that falls outside the output reads zeros.
-struct DgradClasses {
-  int n;              // classes (1 or 4)
-  int tile_start[5];  // first tile (grid.y) of each class
+// An input row ih receives tap kh iff (ih - kh) is a multiple of the stride with (ih - kh) / s
+// < OH: near the border -- and for one stride parity -- most of the nine taps miss (on a 7 x 7
+// input of a stride-1 layer 49 % of the (pixel, tap) pairs of the gather form are structural
+// zeros).  Rows are grouped into classes of equal valid-kh set, columns likewise; a tile holds
+// pixels of ONE (row class, column class) pair and walks exactly that pair's taps: no MFMA
+// multiplies a structural zero and the operand addresses need no per-tap range checks.
+constexpr int DG_MAXCLS = 6;     // classes per axis (5 at stride 1, 2 at stride 2)
+// every class is an arithmetic progression: i = first + step a, a < count (stride 1: the runs
+// {0}, {1}, {2 .. O - 1}, {O}, {O + 1}, step 1; stride 2: the two parities, step 2)
+struct DgradPlan {
+  int nrc, ncc, step;
+  unsigned char rmask[DG_MAXCLS], cmask[DG_MAXCLS];   // bit kh (kw): the tap reaches the class
+  short rcount[DG_MAXCLS], ccount[DG_MAXCLS], rfirst[DG_MAXCLS], cfirst[DG_MAXCLS];
+  int tile_start[DG_MAXCLS * DG_MAXCLS + 1];          // first tile (grid.y) of class pair z
 };
-// gate: the producing layer's ReLU output (bf16, nullable); din_h (bf16) or din_f (fp32)
-template <int NS>
+// classes of one axis, largest tap sets first (the tiles with the longest K loops are
+// dispatched first); returns their number or -1
+inline int dgrad_axis(int I, int O, int stride, unsigned char *mask, short *count, short *first) {
+  auto taps = [&](int i) {
+    int m = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int d = i - k;
+      if (d >= 0 && d % stride == 0 && d / stride < O) m |= 1 << k;
+    }
+    return m;
+  };
+  static const int order[8] = {7, 3, 5, 6, 1, 2, 4, 0};
+  int n = 0;
+  // stride 1: one class per distinct tap set (interior + the border rows).  Stride 2: one
+  // class per parity -- the tap sets differ mainly by parity there, and splitting the single
+  // border row off each parity only fragments the tiles (measured at B = 1024, 19 x 19: 73.7 us
+  // against 69) --, the class mask is the union and the operand fetch range-checks
+  for (int wi = 0; wi < (stride == 1 ? 8 : stride); ++wi) {
+    int cnt = 0, m = 0, f = -1, last = -1;
+    for (int i = 0; i < I; ++i)
+      if ((stride == 1 ? taps(i) == order[wi] : i % stride == wi)) {
+        if (f < 0) f = i;
+        if (last >= 0 && i != last + stride) return -1;   // (not a progression: never)
+        last = i, ++cnt, m |= taps(i);
+      }
+    if (!cnt) continue;
+    if (!m) return -1;   // a row no tap reaches (stride 1: impossible)
+    if (n == DG_MAXCLS) return -1;
+    mask[n] = (unsigned char)m, count[n] = (short)cnt, first[n] = (short)f;
+    ++n;
+  }
+  return n;
+}
+__device__ __forceinline__ int nth_bit(int mask, int n) {   // n-th set bit of a 3-bit mask
+  const int k0 = (mask & 1) ? 0 : ((mask & 2) ? 1 : 2);
+  if (n == 0) return k0;
+  const int rest = mask & ~(1 << k0);
+  return (n == 1 && (rest & 2)) ? 1 : 2;
+}
+// gate: the producing layer's ReLU output (bf16, nullable); din_h (bf16) and / or din_f (fp32)
+// S2: stride 2 (merged parity classes: per-lane range checks); stride 1: every tap of a class
+// reaches every pixel of it, so a lane's source offset is fixed and the tap moves the
+// wave-uniform offset only
+template <int NS, bool S2>
 __global__ __launch_bounds__(NT, 2) void conv_dgrad_bf16r_kernel(
     const bf16_t *__restrict__ dpre, const bf16_t *__restrict__ wd, const bf16_t *__restrict__ gate,
-    bf16_t *__restrict__ din_h, float *__restrict__ din_f, ConvGeom g, DgradClasses cl) {
+    bf16_t *__restrict__ din_h, float *__restrict__ din_f, ConvGeom g, DgradPlan pl) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int s = g.stride;
+  const int nz = pl.nrc * pl.ncc;
   int z = 0;
-#pragma unroll
-  for (int c = 1; c < 4; ++c)
-    if (c < cl.n && (int)blockIdx.y >= cl.tile_start[c]) z = c;
-  const int ph = s == 1 ? 0 : z >> 1, pw = s == 1 ? 0 : z & 1;
-  const int na = (g.IH - ph + s - 1) / s, nb = (g.IW - pw + s - 1) / s, M = g.B * na * nb;
-  const int nkh = (2 - ph) / s + 1, nkw = (2 - pw) / s + 1;
-  const int m0 = ((int)blockIdx.y - cl.tile_start[z]) * TM, n0 = blockIdx.x * TN;
+  for (int c = 1; c < nz; ++c)   // (workgroup-uniform)
+    if ((int)blockIdx.y >= pl.tile_start[c]) z = c;
+  const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
+  const int AH = pl.rcount[rc], AW = pl.ccount[cc], M = g.B * AH * AW;
+  const int rm = pl.rmask[rc], cm = pl.cmask[cc], nkh = __popc(rm), nkw = __popc(cm);
+  const int m0 = ((int)blockIdx.y - pl.tile_start[z]) * TM, n0 = blockIdx.x * TN;
   const pipe::rsrc_t ra = pipe::make_rsrc(dpre, (unsigned)((size_t)g.B * g.OH * g.OW * g.Cout * 2));
   const pipe::rsrc_t rb = pipe::make_rsrc(wd, (unsigned)((size_t)g.Cin * 9 * g.Cout * 2));
   const DmaRows dr = dma_rows(wid, lane);
-  int pn[4], pa[4], pb[4], vb[4];
+  // the class pair's taps; the LAST one (largest kh, kw) is the lanes' reference position
+  const int khl = nth_bit(rm, nkh - 1), kwl = nth_bit(cm, nkw - 1);
+  int pn[4], pih[4], piw[4], va[4], vb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + dr.row[j];
-    pn[j] = -1, pa[j] = 0, pb[j] = 0;
+    pn[j] = -1, pih[j] = 0, piw[j] = 0, va[j] = pipe::DMA_ZERO;
     if (m < M) {
-      const int n = m / (na * nb), rem = m - n * na * nb;
-      pa[j] = rem / nb, pb[j] = rem - pa[j] * nb, pn[j] = n * g.OH * g.OW;
+      const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
+      pn[j] = n * g.OH * g.OW;
+      pih[j] = pl.rfirst[rc] + pl.step * a, piw[j] = pl.cfirst[cc] + pl.step * b;
+      if (!S2)   // output pixel of the reference tap: inside for every pixel of the class
+        va[j] = ((pn[j] + (pih[j] - khl) * g.OW + piw[j] - kwl) * g.Cout) * 2 +
+                src_quad(dr.row[j], lane);
     }
     vb[j] = ((n0 + dr.row[j]) * 9 * g.Cout) * 2 + src_quad(dr.row[j], lane);
   }
@@ -286,15 +341,25 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_bf16r_kernel(
   zero_acc(acc);
   dma_mainloop<NS>(nkh * nkw * cpt, smem, acc, wid, lane, [&](int c, unsigned char *stage) {
     const int t = c / cpt, h = c - t * cpt, ti = t / nkw, tj = t - ti * nkw;
-    const int kh = ph + s * ti, kw = pw + s * tj;
+    const int kh = nth_bit(rm, ti), kw = nth_bit(cm, tj);
     const int sb = ((kh * 3 + kw) * g.Cout + h * BKE) * 2;
+    if (!S2) {
+      // tap (kh, kw) reads (khl - kh) rows and (kwl - kw) columns behind the reference
+      const int sa = (((khl - kh) * g.OW + kwl - kw) * g.Cout + h * BKE) * 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int oh = pa[j] - ti, ow = pb[j] - tj;
-      const bool ok = pn[j] >= 0 && oh >= 0 && ow >= 0 && oh < g.OH && ow < g.OW;
-      const int v = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout) * 2 + src_quad(dr.row[j], lane)
-                       : pipe::DMA_ZERO;
-      pipe::dma16(ra, reinterpret_cast<float *>(stage + dr.lds[j]), v, h * BKE * 2);
+      for (int j = 0; j < 4; ++j)
+        pipe::dma16(ra, reinterpret_cast<float *>(stage + dr.lds[j]), va[j], sa);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // (ih - kh) is even for every tap of the parity class; the range check fails on the
+        // class's border row / column only
+        const int dh = pih[j] - kh, dw = piw[j] - kw, oh = dh >> 1, ow = dw >> 1;
+        const bool ok = pn[j] >= 0 && dh >= 0 && dw >= 0 && oh < g.OH && ow < g.OW;
+        const int v = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout) * 2 + src_quad(dr.row[j], lane)
+                         : pipe::DMA_ZERO;
+        pipe::dma16(ra, reinterpret_cast<float *>(stage + dr.lds[j]), v, h * BKE * 2);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -304,8 +369,9 @@ __global__ __launch_bounds__(NT, 2) void conv_dgrad_bf16r_kernel(
                 [&](int row, int col, const float (&v)[8]) {
     const int m = m0 + row;
     if (m >= M) return;
-    const int n = m / (na * nb), rem = m - n * na * nb, a = rem / nb, b = rem - a * nb;
-    const size_t o = (((size_t)n * g.IH + a * s + ph) * g.IW + b * s + pw) * g.Cin + n0 + col;
+    const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
+    const int ih = pl.rfirst[rc] + pl.step * a, iw = pl.cfirst[cc] + pl.step * b;
+    const size_t o = (((size_t)n * g.IH + ih) * g.IW + iw) * g.Cin + n0 + col;
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = v[e];
@@ -566,22 +632,32 @@ extern "C" int scae_conv3x3_dgrad_bf16r(const uint16_t *dpre, const uint16_t *wd
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
   int rc = check(g);
   if (rc) return rc;
-  DgradClasses cl{};
-  cl.n = stride == 1 ? 1 : 4;
-  int tiles = 0;
-  for (int z = 0; z < cl.n; ++z) {
-    const int ph = stride == 1 ? 0 : z >> 1, pw = stride == 1 ? 0 : z & 1;
-    const int na = (IH - ph + stride - 1) / stride, nb = (IW - pw + stride - 1) / stride;
-    cl.tile_start[z] = tiles;
-    tiles += (B * na * nb + TM - 1) / TM;
-  }
-  cl.tile_start[cl.n] = tiles;
+  DgradPlan pl{};
+  pl.step = stride;
+  pl.nrc = dgrad_axis(IH, g.OH, stride, pl.rmask, pl.rcount, pl.rfirst);
+  pl.ncc = dgrad_axis(IW, g.OW, stride, pl.cmask, pl.ccount, pl.cfirst);
+  if (pl.nrc <= 0 || pl.ncc <= 0) return SCAE_ERR_UNSUPPORTED;
+  int tiles = 0, covered = 0;
+  for (int rc_ = 0; rc_ < pl.nrc; ++rc_)
+    for (int cc_ = 0; cc_ < pl.ncc; ++cc_) {
+      pl.tile_start[rc_ * pl.ncc + cc_] = tiles;
+      tiles += (B * pl.rcount[rc_] * pl.ccount[cc_] + TM - 1) / TM;
+      covered += pl.rcount[rc_] * pl.ccount[cc_];
+    }
+  pl.tile_start[pl.nrc * pl.ncc] = tiles;
+  if (covered != IH * IW) return SCAE_ERR_UNSUPPORTED;   // (every pixel is in one class pair)
   const dim3 grid(Cin / TN, tiles);
 #define SCAE_DG_NS(N)                                                                           \
   case N:                                                                                       \
-    if ((rc = raise_lds(conv_dgrad_bf16r_kernel<N>, N * STAGE_B))) return rc;                   \
-    scae::launch(conv_dgrad_bf16r_kernel<N>, grid, dim3(NT), N * STAGE_B, (hipStream_t)stream,  \
-                 dpre, wd, gate, din_h, din_f, g, cl);                                           \
+    if (stride == 2) {                                                                          \
+      if ((rc = raise_lds(conv_dgrad_bf16r_kernel<N, true>, N * STAGE_B))) return rc;           \
+      scae::launch((conv_dgrad_bf16r_kernel<N, true>), grid, dim3(NT), N * STAGE_B,             \
+                   (hipStream_t)stream, dpre, wd, gate, din_h, din_f, g, pl);                    \
+    } else {                                                                                    \
+      if ((rc = raise_lds(conv_dgrad_bf16r_kernel<N, false>, N * STAGE_B))) return rc;          \
+      scae::launch((conv_dgrad_bf16r_kernel<N, false>), grid, dim3(NT), N * STAGE_B,            \
+                   (hipStream_t)stream, dpre, wd, gate, din_h, din_f, g, pl);                    \
+    }                                                                                           \
     break;
   switch (ring_depth("SCAE_BF16R_DGRAD_NS", (long)grid.x * grid.y > 512 ? 1 : 2)) {
     SCAE_DG_NS(1) SCAE_DG_NS(2) SCAE_DG_NS(3) SCAE_DG_NS(4)
