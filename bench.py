@@ -390,7 +390,7 @@ def roofline(cfg, device, bf16=False, light=False):
     # (counters cannot be read from inside this run)
     traffic = None
     pmc = next((q for q in (os.path.join(ROOT, "profiles", r, "k8_pmc.json")
-                            for r in ("r05", "r04", "r03", "r02", "r01"))
+                            for r in ("r06", "r05", "r04", "r03", "r02", "r01"))
                 if os.path.exists(q)), "")
     if os.path.exists(pmc) and cfg is CONFIGS["mnist_24_24_bs128"] and not bf16:
         k = json.load(open(pmc))["kernels"].get(name)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/round_artifacts.sh r02 [notests] -- refresh the round's measurement artifacts into
 # gpurun_out/<round>/ (run on the GPU box from the repo root; copy what is to be judged into profiles/<round>/)
-RN=${1:-r05}; R=$PWD; O=$R/gpurun_out/$RN; mkdir -p $O; export TMPDIR=/tmp
+RN=${1:-r06}; R=$PWD; O=$R/gpurun_out/$RN; mkdir -p $O; export TMPDIR=/tmp
 if [ "$2" != "notests" ]; then
   timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "^FAILED|^E  |passed|failed" | tail -12 > $O/pytest_gpu.txt
 fi
@@ -38,5 +38,9 @@ rm -f $O/*_domain_stats.csv
 [ -f tools/ablibs/libfwd_prof.so ] && timeout 300 python tools/fwd_prof.py tools/ablibs/libfwd_prof.so > $O/fwd_tile_timeline.txt 2>&1
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o gap -- python3 $R/tools/graph_gap_probe.py > /dev/null 2>&1)
 python3 tools/graph_gap_report.py $O/gap_kernel_trace.csv > $O/graph_gap.txt 2>&1; rm -f $O/gap_*.csv
-timeout 300 python tools/launch_list_probe.py > $O/launch_list.txt 2>&1
+# round 6: do two plain streams overlap (yes); graph replay / launch list on one lane / on two lanes
+[ -x tools/probes/stream_overlap ] && ./tools/probes/stream_overlap > $O/stream_overlap.txt 2>&1
+RESIDENT=0,384,512,768 timeout 400 python tools/lanes_probe.py 2>&1 | grep -v amdgpu.ids > $O/lanes.txt
+# the bf16-resident K8 kernels alone at cfg-3's layer shapes
+timeout 200 python tools/conv_bf16_time.py 2>&1 | grep "B=1024" > $O/conv_bf16_time.txt
 ls $O
