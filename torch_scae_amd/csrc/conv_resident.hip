@@ -21,6 +21,9 @@
 // Pixels are stored with the 16-byte slots of a pixel XOR-swizzled by (pixel & 15), applied on
 // the source side of the staging DMA, so the row-per-lane fragment reads (32 pixels x 16 B, a
 // pixel = Cin x 4 B apart) are bank-conflict free.
+#include <cstdlib>
+
+#include "bf16x6.h"
 #include "mfma_pipe.h"
 #include "conv_first_dev.h"
 
@@ -36,7 +39,9 @@ struct ResArgs {
   int G;   // images per workgroup
 };
 
-template <int MI>
+// X6: the products on the bf16 matrix cores as six exact partial products of a three-way split
+// of the fp32 operands (bf16x6.h): fp32 results at 6 / 16 of the fp32 MFMA time
+template <int MI, bool X6>
 __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
   extern __shared__ __attribute__((aligned(1024))) float smem[];
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63,
@@ -74,11 +79,21 @@ __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
   const int CPT = CB / 4;            // ... per wave
   const int NCW = 9 * CPT;           // this wave's chunks
   const float4 *wq = reinterpret_cast<const float4 *>(a.wp) + (size_t)nt * (9 * CB) * 256 + lane;
-  pipe::f32x16 acc[MI];
+  // X6: NS small-product accumulators per tile -- with one tile per wave three, so that two
+  // MFMAs on the same accumulator are three instructions apart (a dependent MFMA waits ~64
+  // cycles); with more tiles the tiles themselves interleave
+  constexpr int NS = !X6 ? 1 : (MI == 1 ? 3 : 1);
+  pipe::f32x16 acc[MI], accl[X6 ? MI : 1][NS];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
+    for (int e = 0; e < 16; ++e) {
+      acc[mi][e] = 0.f;
+      if (X6) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n) accl[mi][n][e] = 0.f;
+      }
+    }
   float4 bq[2][4];
   auto load_b = [&](int c, int buf) {
     const int tap = c / CPT, cb = wid + 4 * (c - tap * CPT);
@@ -102,6 +117,35 @@ __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
       ap[mi] = smem + p * g.Cin;
       sw[mi] = p & 15;
     }
+    if (X6) {
+      // two quads = the lane's eight k of one bf16 MFMA (the same eight for A and B)
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const scae_x6::Split3 bs = scae_x6::split3(bq[buf][2 * qp], bq[buf][2 * qp + 1]);
+        scae_x6::Split3 as[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const float4 a0 = pipe::lds4(ap[mi] + (((slot0 + 2 * qp) ^ sw[mi]) << 2));
+          const float4 a1 = pipe::lds4(ap[mi] + (((slot0 + 2 * qp + 1) ^ sw[mi]) << 2));
+          as[mi] = scae_x6::split3(a0, a1);
+        }
+        // the six products, product by product over the tiles: consecutive MFMAs write
+        // different accumulators (smallest products first within an accumulator)
+#define SCAE_X6_STEP(AP, BP, N)                                                                   \
+  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) accl[mi][(N) % NS] =                          \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[mi].AP, bs.BP, accl[mi][(N) % NS], 0, 0, 0);
+        SCAE_X6_STEP(hi, lo, 0)
+        SCAE_X6_STEP(lo, hi, 1)
+        SCAE_X6_STEP(mid, mid, 2)
+        SCAE_X6_STEP(hi, mid, 0)
+        SCAE_X6_STEP(mid, hi, 1)
+#undef SCAE_X6_STEP
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[mi].hi, bs.hi, acc[mi], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 af[MI];
@@ -120,6 +164,15 @@ __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
   for (int c = 0; c < NCW; c += 2) {
     chunk(c, 0);
     if (c + 1 < NCW) chunk(c + 1, 1);
+  }
+  if (X6) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      pipe::f32x16 small = accl[mi][0];
+#pragma unroll
+      for (int n = 1; n < NS; ++n) small += accl[mi][n];
+      acc[mi] += small;
+    }
   }
   // ---- 3. the four K parts meet in LDS (the staged pixels are dead), fixed order ------------
   __syncthreads();
@@ -209,20 +262,27 @@ extern "C" int scae_conv3x3_fwd_res_f32(const float *in, const float *wp, const 
   ResArgs a{in, wp, bias, post_bias, out, out_post, g, p.G};
   const dim3 grid((Cout / 32) * ((B + p.G - 1) / p.G));
   hipStream_t st = (hipStream_t)stream;
-#define SCAE_RES(M)                                                                              \
-  case M: {                                                                                      \
+  // (SCAE_X6=0: the fp32 MFMA form, for A/B measurements)
+  const char *xe = getenv("SCAE_X6");
+  const bool x6 = !(xe && *xe == '0');
+#define SCAE_RES_K(M, X)                                                                         \
+  {                                                                                              \
     if (p.lds > 48 * 1024) {                                                                     \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_res_fwd_kernel<M>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_res_fwd_kernel<M, X>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
       if (e != hipSuccess) return (int)e;                                                        \
     }                                                                                            \
-    scae::launch(conv_res_fwd_kernel<M>, grid, dim3(NT), p.lds, st, a);                    \
-    break;                                                                                       \
+    scae::launch((conv_res_fwd_kernel<M, X>), grid, dim3(NT), p.lds, st, a);                     \
   }
+#define SCAE_RES(M)                                                                              \
+  case M:                                                                                        \
+    if (x6) SCAE_RES_K(M, true) else SCAE_RES_K(M, false)                                        \
+    break;
   switch (p.MI) {
     SCAE_RES(1) SCAE_RES(2) SCAE_RES(3) SCAE_RES(4)
     default: return SCAE_ERR_UNSUPPORTED;
   }
+#undef SCAE_RES_K
 #undef SCAE_RES
   return scae_launch_status();
 }

@@ -20,10 +20,19 @@
 #pragma once
 #include <type_traits>
 
+#include "bf16x6.h"
 #include "common.h"
+
+// The products of the second-generation loops: exact three-way bf16 split, six bf16 MFMAs per
+// 16 k (bf16x6.h) -- fp32 results at 6 / 16 of the fp32 MFMA time; -DSCAE_PIPE_X6=0: the
+// fp32 MFMA chain (v_mfma_f32_32x32x2_f32), for A/B builds.
+#ifndef SCAE_PIPE_X6
+#define SCAE_PIPE_X6 1
+#endif
 
 namespace scae_pipe {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef scae_x6::bf16x8 bf16x8;
 constexpr int NT = 256;
 constexpr int BK = 32;   // K chunk per ring stage
 constexpr int BKH = 16;  // per k plane
@@ -143,18 +152,35 @@ __device__ __forceinline__ void kk_mainloop(int nchunk, float *smem, f32x16 (&ac
 #ifndef SCAE_PIPE_ABL
 #define SCAE_PIPE_ABL 0
 #endif
-  constexpr int NS = T::NS, G = 4 / T::KS, NM = 4 * T::MI * T::NI;
+  // X6 (where a wave has an even number of 4-k groups per chunk): a group is a PAIR of quads --
+  // the lane's eight k of one bf16 MFMA -- and its products the six exact partial products of
+  // bf16x6.h, the five small ones into an accumulator of their own
+  constexpr bool X6 = SCAE_PIPE_X6 != 0 && (4 / T::KS) % 2 == 0;
+  constexpr int NS = T::NS, QG = X6 ? 2 : 1, G = 4 / T::KS / QG;
+  constexpr int NM = (X6 ? 6 : 4) * T::MI * T::NI;
   const int sw = (i >> 2) & 3;
   const int aoff = kk * T::TA * BKH + i * BKH;
   const int boff = T::TA * BK + (kk * T::TB + wn * 32 * T::NI + i) * BKH;
-  float4 a[2][T::MI], b[2][T::NI];
+  float4 a[2][QG][T::MI], b[2][QG][T::NI];
   auto load = [&](const float *st, int gg, int buf) {
-    const int qo = ((ks * G + gg) ^ sw) << 2;
 #pragma unroll
-    for (int mi = 0; mi < T::MI; ++mi) a[buf][mi] = lds4(st + aoff + mi * 32 * BKH + qo);
+    for (int h = 0; h < QG; ++h) {
+      const int qo = ((ks * G * QG + gg * QG + h) ^ sw) << 2;
 #pragma unroll
-    for (int ni = 0; ni < T::NI; ++ni) b[buf][ni] = lds4(st + boff + ni * 32 * BKH + qo);
+      for (int mi = 0; mi < T::MI; ++mi) a[buf][h][mi] = lds4(st + aoff + mi * 32 * BKH + qo);
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni) b[buf][h][ni] = lds4(st + boff + ni * 32 * BKH + qo);
+    }
   };
+  f32x16 accl[X6 ? T::MI : 1][X6 ? T::NI : 1];
+  if (X6) {
+#pragma unroll
+    for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accl[mi][ni][e] = 0.f;
+  }
 #pragma unroll
   for (int c = 0; c < NS; ++c)
     if (c < nchunk) {
@@ -189,16 +215,37 @@ __device__ __forceinline__ void kk_mainloop(int nchunk, float *smem, f32x16 (&ac
         load(stn, 0, cur ^ 1);
       }
       const bool dma_here = gg + 1 == G && more;
+      scae_x6::Split3 as[X6 ? T::MI : 1], bs[X6 ? T::NI : 1];
+      if (X6) {
+#pragma unroll
+        for (int mi = 0; mi < T::MI; ++mi) as[mi] = scae_x6::split3(a[cur][0][mi], a[cur][QG - 1][mi]);
+#pragma unroll
+        for (int ni = 0; ni < T::NI; ++ni) bs[ni] = scae_x6::split3(b[cur][0][ni], b[cur][QG - 1][ni]);
+      }
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        const int mi = (m >> 2) / T::NI, ni = (m >> 2) % T::NI, e = m & 3;
+        if (X6) {
+          // product by product over the wave's tiles (m / tiles: hi lo, lo hi, mid mid, hi mid,
+          // mid hi -> the small accumulator; hi hi -> the tile's)
+          constexpr int NTL = T::MI * T::NI;
+          const int pr = m / NTL, mi = (m % NTL) / T::NI, ni = (m % NTL) % T::NI;
+          const bf16x8 av = pr == 1 ? as[mi].lo : (pr == 2 || pr == 4) ? as[mi].mid : as[mi].hi;
+          const bf16x8 bv = pr == 0 ? bs[ni].lo : (pr == 2 || pr == 3) ? bs[ni].mid : bs[ni].hi;
+          if (pr < 5)
+            accl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accl[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
+        } else {
+          const int mi = (m >> 2) / T::NI, ni = (m >> 2) % T::NI, e = m & 3;
 #if SCAE_PIPE_ABL == 2
-        acc[mi][ni][0] += a[cur][mi][e] * b[cur][ni][e];
+          acc[mi][ni][0] += a[cur][0][mi][e] * b[cur][0][ni][e];
 #else
-        const float av = e == 0 ? a[cur][mi].x : e == 1 ? a[cur][mi].y : e == 2 ? a[cur][mi].z : a[cur][mi].w;
-        const float bv = e == 0 ? b[cur][ni].x : e == 1 ? b[cur][ni].y : e == 2 ? b[cur][ni].z : b[cur][ni].w;
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+          const float4 &aq = a[cur][0][mi], &bq = b[cur][0][ni];
+          const float av = e == 0 ? aq.x : e == 1 ? aq.y : e == 2 ? aq.z : aq.w;
+          const float bv = e == 0 ? bq.x : e == 1 ? bq.y : e == 2 ? bq.z : bq.w;
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
 #endif
+        }
         if (dma_here && m + 1 < NM) {   // pieces spread over the NM - 1 gaps between the MFMAs
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -209,14 +256,23 @@ __device__ __forceinline__ void kk_mainloop(int nchunk, float *smem, f32x16 (&ac
     }
     if (G & 1) {   // the next chunk's first fragments were read into the other buffer
 #pragma unroll
-      for (int mi = 0; mi < T::MI; ++mi) a[0][mi] = a[1][mi];
+      for (int h = 0; h < QG; ++h) {
 #pragma unroll
-      for (int ni = 0; ni < T::NI; ++ni) b[0][ni] = b[1][ni];
+        for (int mi = 0; mi < T::MI; ++mi) a[0][h][mi] = a[1][h][mi];
+#pragma unroll
+        for (int ni = 0; ni < T::NI; ++ni) b[0][h][ni] = b[1][h][ni];
+      }
     }
     s = sn;
   };
   for (int c = 0; c + 1 < nchunk; ++c) body(c, std::false_type{});
   body(nchunk - 1, std::true_type{});
+  if (X6) {
+#pragma unroll
+    for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni) acc[mi][ni] += accl[mi][ni];
+  }
 }
 
 // Accumulators out: epi(row, col, value) per element (row-major C, 32 consecutive
@@ -290,8 +346,10 @@ struct SS {
 template <class T, class Issue, class Each>
 __device__ __forceinline__ void ss_mainloop(int nchunk, float *smem, f32x16 (&acc)[T::MI][T::NI],
                                             int wm, int wn, int i, int kk, Issue issue, Each each) {
-  constexpr int LA = T::NS - 1, S = T::BKW / 2, U = 4, NB = S / U;
-  static_assert(NB >= 2 && NB % 2 == 0 && T::PPW % NB == 0, "fragment batches per chunk");
+  constexpr bool X6 = SCAE_PIPE_X6 != 0;
+  // a batch = the lane's U k of each fragment: 4 fp32 MFMA steps, or (X6) the 8 k of one bf16 MFMA
+  constexpr int LA = T::NS - 1, S = T::BKW / 2, U = X6 ? 8 : 4, NB = S / U;
+  static_assert(NB >= 1 && S % U == 0 && T::PPW % NB == 0, "fragment batches per chunk");
   const int aoff = kk * T::TA + wm * 32 * T::MI + i;
   const int boff = T::TA * T::BKW + kk * T::TB + wn * 32 * T::NI + i;
   float a[2][U][T::MI], b[2][U][T::NI];
@@ -305,6 +363,22 @@ __device__ __forceinline__ void ss_mainloop(int nchunk, float *smem, f32x16 (&ac
       for (int ni = 0; ni < T::NI; ++ni) b[buf][u][ni] = st[boff + 2 * s * T::TB + ni * 32];
     }
   };
+  // X6: the small products' accumulator
+  // (one: in the launch these tiles share with the data gradient's, the registers of two more
+  // accumulators cost a workgroup per CU -- B = 128, the three pair launches: 145 us with one,
+  // 159 with two or three, 152 on the fp32 MFMA chain)
+  constexpr int NSM = 1;
+  f32x16 accl[X6 ? T::MI : 1][X6 ? T::NI : 1][NSM];
+  if (X6) {
+#pragma unroll
+    for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni)
+#pragma unroll
+        for (int n = 0; n < NSM; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) accl[mi][ni][n][e] = 0.f;
+  }
 #pragma unroll
   for (int c = 0; c < LA; ++c)
     if (c < nchunk) {
@@ -338,23 +412,75 @@ __device__ __forceinline__ void ss_mainloop(int nchunk, float *smem, f32x16 (&ac
         wg_barrier();
         load(smem + sn * T::STAGE, 0, cur ^ 1);
       }
+      if (X6) {
+        scae_x6::Split3 as[T::MI], bs[T::NI];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+        for (int mi = 0; mi < T::MI; ++mi) {
+          const float x[8] = {a[cur][0][mi], a[cur][1][mi], a[cur][2][mi], a[cur][3][mi],
+                              a[cur][4 % U][mi], a[cur][5 % U][mi], a[cur][6 % U][mi], a[cur][7 % U][mi]};
+          as[mi] = scae_x6::split3(x);
+        }
+#pragma unroll
+        for (int ni = 0; ni < T::NI; ++ni) {
+          const float x[8] = {b[cur][0][ni], b[cur][1][ni], b[cur][2][ni], b[cur][3][ni],
+                              b[cur][4 % U][ni], b[cur][5 % U][ni], b[cur][6 % U][ni], b[cur][7 % U][ni]};
+          bs[ni] = scae_x6::split3(x);
+        }
+#define SCAE_SS_STEP(AP, BP, N)                                                                   \
+  _Pragma("unroll") for (int mi = 0; mi < T::MI; ++mi)                                            \
+  _Pragma("unroll") for (int ni = 0; ni < T::NI; ++ni) accl[mi][ni][(N) % NSM] =                  \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[mi].AP, bs[ni].BP, accl[mi][ni][(N) % NSM], 0, 0, 0);
+        SCAE_SS_STEP(hi, lo, 0)
+        SCAE_SS_STEP(lo, hi, 1)
+        SCAE_SS_STEP(mid, mid, 2)
+        SCAE_SS_STEP(hi, mid, 0)
+        SCAE_SS_STEP(mid, hi, 1)
+#undef SCAE_SS_STEP
 #pragma unroll
         for (int mi = 0; mi < T::MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < T::NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][u][mi], b[cur][u][ni],
-                                                              acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[mi].hi, bs[ni].hi, acc[mi][ni],
+                                                                  0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < T::NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][u][mi], b[cur][u][ni],
+                                                                acc[mi][ni], 0, 0, 0);
+      }
       if (more) {
 #pragma unroll
         for (int j = blk * (T::PPW / NB); j < (blk + 1) * (T::PPW / NB); ++j) issue(c + LA, s2, j);
+      }
+    }
+    if (NB & 1) {   // the next chunk's first batch was read into the other buffer
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int mi = 0; mi < T::MI; ++mi) a[0][u][mi] = a[1][u][mi];
+#pragma unroll
+        for (int ni = 0; ni < T::NI; ++ni) b[0][u][ni] = b[1][u][ni];
       }
     }
     s = sn;
   };
   for (int c = 0; c + 1 < nchunk; ++c) body(c, std::false_type{});
   body(nchunk - 1, std::true_type{});
+  if (X6) {
+#pragma unroll
+    for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < T::NI; ++ni) {
+        f32x16 small = accl[mi][ni][0];
+#pragma unroll
+        for (int n = 1; n < NSM; ++n) small += accl[mi][ni][n];
+        acc[mi][ni] += small;
+      }
+  }
 }
 
 }  // namespace scae_pipe
