@@ -416,6 +416,11 @@ def roofline(cfg, device, bf16=False, light=False):
         "algorithmic_flops_per_launch": flops / len(launches),
         "per_layer_us": [round(l["seconds"] * 1e6, 2) for l in launches],
         "other_kernels": others,
+        "arithmetic": "fp32 operands and results; the weight-gradient tiles (and the forward "
+                      "loops) multiply them as six exact bf16 partial products on the bf16 "
+                      "matrix cores (csrc/bf16x6.h), the data-gradient tiles on the fp32 MFMA; "
+                      "achieved / peak: algorithmic fp32 FLOP/s against the fp32 MFMA peak"
+        if not bf16 else "bf16 operands, fp32 accumulation",
         "note": "achieved/us_per_launch/algorithmic_flops_per_launch are "
                 "averages over the kernel's launches of one step (one per "
                 "encoder layer); traffic = FETCH_SIZE+WRITE_SIZE per launch "

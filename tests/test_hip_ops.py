@@ -2986,6 +2986,69 @@ def test_conv_resident_forward_vs_conv2d(B, IH, Ci, Co, s, group, post):
         assert float((out2 - out).abs().max()) <= 2e-6 * scale
 
 
+def test_exact_split_products_reproduce_fp32_values_bitwise():
+    """csrc/bf16x6.h: the K8 loops multiply fp32 operands as six exact partial products of a
+    three-way bf16 split (8 + 8 + 8 significant bits) on the bf16 matrix cores.  What "exact"
+    means is checked bit for bit where the result must be an input value itself:
+      * forward with a one-hot filter (centre tap, co == ci, weight 1): out = x at the window
+        centre -- x's full 24-bit values must come back from hi + mid + lo -- through the
+        image-resident kernel (K8r) and the ring-pipelined tiles;
+      * weight gradient with a one-hot pre-activation gradient (one pixel, one channel, 1.0):
+        dW[co, :, tap] = x at that tap's input pixel, and the products with the other channels
+        and pixels are exact zeros.
+    And the accuracy claim: on random data the K8r forward is within 1e-6 of the output's
+    largest entry of fp64 (the fp32 MFMA chain measures 1.2e-6 max / 1.2e-7 rms there, the split
+    form 7.4e-7 / 5.9e-8: tools/x6_probe.py)."""
+    import ctypes
+    import torch.nn.functional as F
+    from torch_scae_amd import _lib, ops
+    lib, P = _lib.load(), ops._p
+    st = torch.cuda.current_stream().cuda_stream
+    B, IH, C = 6, 9, 128
+    OH = IH - 2
+    g = torch.Generator().manual_seed(5)
+    # full-mantissa values of mixed magnitude (and exact zeros, as ReLU outputs have)
+    x = torch.relu(torch.randn(B, IH, IH, C, generator=g) * torch.exp(torch.randn(B, IH, IH, C, generator=g) * 3)).cuda()
+    w = torch.zeros(C, C, 3, 3)
+    w[torch.arange(C), torch.arange(C), 1, 1] = 1.0
+    wf, wd = torch.empty(2, C, 9, C, device="cuda"), torch.empty(C, 9, C, device="cuda")
+    _lib.call("scae_conv3x3_relayout_f32", P(w.cuda()), P(wf), P(wd), C, C, st)
+    zero = torch.zeros(C, device="cuda")
+    want = x[:, 1:-1, 1:-1, :].contiguous()
+    out = torch.full((B, OH, OH, C), float("nan"), device="cuda")
+    _lib.call("scae_conv3x3_fwd_res_f32", P(x), P(wf[1]), P(zero), P(out), None, None, B, IH, IH,
+              C, C, 1, 0, st)
+    assert torch.equal(out, want)
+    out.fill_(float("nan"))
+    _lib.call("scae_conv3x3_fwd_f32", P(x), P(wf[0]), P(zero), P(out), None, None, B, IH, IH, C, C,
+              1, st)
+    assert torch.equal(out, want)
+    # weight gradient: dpre = 1 at (image 2, output pixel (3, 4), channel 17), 0 elsewhere
+    dpre = torch.zeros(B, OH, OH, C, device="cuda")
+    dpre[2, 3, 4, 17] = 1.0
+    splits = lib.scae_conv3x3_wgrad_splits(B, OH, OH, C, C)
+    part = torch.empty(splits * (9 * C * C + C), device="cuda")
+    dw, db = torch.empty(C, C, 3, 3, device="cuda"), torch.empty(C, device="cuda")
+    _lib.call("scae_conv3x3_wgrad_f32", P(dpre), P(x), P(part), P(dw), P(db), B, IH, IH, C, C, 1, st)
+    torch.cuda.synchronize()
+    expect = torch.zeros(C, C, 3, 3, device="cuda")
+    for kh in range(3):
+        for kw in range(3):
+            expect[17, :, kh, kw] = x[2, 3 + kh, 4 + kw, :]
+    assert torch.equal(dw, expect)
+    assert torch.equal(db, F.one_hot(torch.tensor(17), C).float().cuda())
+    # accuracy on random data, against fp64
+    xr = torch.relu(torch.randn(B, IH, IH, C, generator=g)).cuda()
+    wr = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
+    br = torch.randn(C, generator=g).cuda()
+    _lib.call("scae_conv3x3_relayout_f32", P(wr), P(wf), P(wd), C, C, st)
+    _lib.call("scae_conv3x3_fwd_res_f32", P(xr), P(wf[1]), P(br), P(out), None, None, B, IH, IH, C,
+              C, 1, 0, st)
+    ref = torch.relu(F.conv2d(xr.double().permute(0, 3, 1, 2).cpu(), wr.double().cpu(),
+                              br.double().cpu())).permute(0, 2, 3, 1)
+    assert float((out.double().cpu() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
 def test_conv_resident_forward_rejects_what_it_cannot_hold():
     from torch_scae_amd import _lib
     lib = _lib.load()
