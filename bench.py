@@ -305,7 +305,7 @@ def time_k8_kernels(cfg, device, reps=50, bf16=False):
         OH = (IH - 3) // s + 1
         f = lambda *sh: torch.randn(*sh, device=device)   # noqa: E731
         x, w, bias = f(B, IH, IH, Ci), f(Co, Ci, 3, 3), f(Co)
-        wf, wd = f(2, Co, 9, Ci), f(Ci, 9, Co)   # (wf: + its fragment-major copy)
+        wf, wd = f(3, Co, 9, Ci), f(Ci, 9, Co)   # (wf: + its fragment-major copy, 2.5 x)
         y, dy, dx, dw, db = f(B, OH, OH, Co), f(B, OH, OH, Co), f(B, IH, IH, Ci), \
             f(Co, Ci, 3, 3), f(Co)
         st = ops._stream(x)

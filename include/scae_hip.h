@@ -522,10 +522,11 @@ int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *
  *     fp32 matrix cores      replaces part_encoder.py:26-44 / nn_ext.py:34-59
  *     (Conv2d(k=3, stride, padding=0) + ReLU) and their autograd backward.
  *   Activations NHWC: in (B,IH,IW,Cin) -> out (B,OH,OW,Cout), OH=(IH-3)/s+1.
- *   relayout: w (Cout,Cin,3,3) -> wf, wd (Cin,9,Cout).  `wf` holds 2*Cout*9*Cin floats:
- *     the (Cout,9,Cin) layout the tile kernels read (`wf` of fwd / fwd_fold / fwd_bf16: a
- *     caller may fill that block by hand), followed -- when Cin, Cout % 32 == 0 -- by the
- *     fragment-major copy `wp` = wf + Cout*9*Cin of the image-resident forward (fwd_res).
+ *   relayout: w (Cout,Cin,3,3) -> wf, wd (Cin,9,Cout).  `wf` holds scae_conv3x3_wf_floats(Cout,Cin)
+ *     floats: the (Cout,9,Cin) layout the tile kernels read (`wf` of fwd / fwd_fold: a caller may
+ *     fill that block by hand), followed -- when Cin, Cout % 32 == 0 -- by the fragment-major copy
+ *     `wp` = wf + Cout*9*Cin of the image-resident forward (fwd_res): the filter split into the
+ *     three bf16 planes of its exact fp32 products (csrc/bf16x6.h), 1.5 * Cout*9*Cin floats.
  *   first_*: direct kernels for the image layer (NCHW image, small Cin; w in
  *     the reference layout, Cout % 64 == 0); first_wgrad writes
  *     scae_conv3x3_first_wgrad_rows(B,Cout) partial rows, each
@@ -543,7 +544,7 @@ int scae_conv3x3_bwd_pair_bf16(const float *dpre, const float *wd, const float *
  *          reduces the partials of up to 8 layers in one launch (HOST arrays).
  * ---------------------------------------------------------------------- */
 /* floats a `wf` buffer of relayout / relayout_batch / first_fwd_relayout / the step prologue
- * must hold for a (Cout, Cin) layer: Cout*9*Cin, doubled when the packed copy is written */
+ * must hold for a (Cout, Cin) layer: Cout*9*Cin, x 2.5 when the packed copy is written */
 int64_t scae_conv3x3_wf_floats(int Cout, int Cin);
 int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout, int Cin,
                               void *stream);

@@ -2963,7 +2963,8 @@ def test_conv_resident_forward_vs_conv2d(B, IH, Ci, Co, s, group, post):
     if group == 0:      # (a forced group may exceed what the launcher picks by itself)
         assert lib.scae_conv3x3_fwd_res_supported(B, IH, IH, Ci, Co, s) == 1
     xn = x.permute(0, 2, 3, 1).contiguous().cuda()
-    wd_, wf = torch.empty(Ci, 9, Co, device="cuda"), torch.empty(2, Co, 9, Ci, device="cuda")
+    wd_, wf = torch.empty(Ci, 9, Co, device="cuda"), torch.empty(3, Co, 9, Ci, device="cuda")
+    assert wf.numel() >= lib.scae_conv3x3_wf_floats(Co, Ci)
     st = torch.cuda.current_stream().cuda_stream
     P = ops._p
     _lib.call("scae_conv3x3_relayout_f32", P(w.cuda()), P(wf), P(wd_), Co, Ci, st)
@@ -3011,7 +3012,7 @@ def test_exact_split_products_reproduce_fp32_values_bitwise():
     x = torch.relu(torch.randn(B, IH, IH, C, generator=g) * torch.exp(torch.randn(B, IH, IH, C, generator=g) * 3)).cuda()
     w = torch.zeros(C, C, 3, 3)
     w[torch.arange(C), torch.arange(C), 1, 1] = 1.0
-    wf, wd = torch.empty(2, C, 9, C, device="cuda"), torch.empty(C, 9, C, device="cuda")
+    wf, wd = torch.empty(3, C, 9, C, device="cuda"), torch.empty(C, 9, C, device="cuda")
     _lib.call("scae_conv3x3_relayout_f32", P(w.cuda()), P(wf), P(wd), C, C, st)
     zero = torch.zeros(C, device="cuda")
     want = x[:, 1:-1, 1:-1, :].contiguous()

@@ -22,7 +22,7 @@ T = []
 for IH, Ci, Co, s in layers:
     OH = (IH - 3) // s + 1
     t = dict(x=f(B, IH, IH, Ci), wf=f(Co, 9, Ci), wd=f(Ci, 9, Co), bias=f(Co),
-             wf2=f(2, Co, 9, Ci), w=f(Co, Ci, 3, 3), y=f(B, OH, OH, Co), dy=f(B, OH, OH, Co), dx=f(B, IH, IH, Ci),
+             wf2=f(3, Co, 9, Ci), w=f(Co, Ci, 3, 3), y=f(B, OH, OH, Co), dy=f(B, OH, OH, Co), dx=f(B, IH, IH, Ci),
              IH=IH, Ci=Ci, Co=Co, s=s, OH=OH)
     lib.scae_conv3x3_wgrad_splits.restype = I
     sp = lib.scae_conv3x3_wgrad_splits(B, OH, OH, Ci, Co)

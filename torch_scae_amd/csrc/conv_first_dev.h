@@ -27,14 +27,31 @@ __host__ __device__ inline unsigned short bf16_bits(float v) {
   if ((c.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((c.u >> 16) | 0x40);   // NaN
   return (unsigned short)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
 }
-// Where element (co, tap, ci) of a filter lies in the FRAGMENT-MAJOR copy the image-resident
-// forward (conv_resident.hip) reads -- the second Cout*9*Cin floats of a `wf` buffer:
-// [co / 32][chunk = tap * Cin/32 + ci/32][quad = ci%16 / 4][lane = (ci%32 / 16) * 32 + co%32][ci%4],
-// i.e. the 64 lanes x 16 bytes of one MFMA fragment quad (v_mfma_f32_32x32x2_f32: lane =
-// (column, k half)) are 1 KiB contiguous.  Needs Cin % 32 == 0 and Cout % 32 == 0.
-__host__ __device__ inline size_t packed_index(int Cin, int co, int tap, int ci) {
+// The FRAGMENT-MAJOR copy the image-resident forward (conv_resident.hip) reads -- behind the first
+// Cout*9*Cin floats of a `wf` buffer -- holds the filter ALREADY SPLIT into the three bf16 planes
+// of bf16x6.h (hi / mid / lo: the exact 8 + 8 + 8 cut of each fp32 value), so that kernel splits
+// no B operand.  Unit = bf16; element (co, tap, ci), plane p at
+//   [co / 32][chunk = tap * Cin/32 + ci/32][pair = ci%16 / 8][p][lane = (ci%32 / 16) * 32 + co%32][ci%8]:
+// the 64 lanes x 16 bytes of one MFMA operand (v_mfma_f32_32x32x16_bf16: lane = (column, k half),
+// eight k each) are 1 KiB contiguous -- one coalesced global_load_dwordx4.  1.5 * Cout*9*Cin floats.
+// Needs Cin % 32 == 0 and Cout % 32 == 0.
+__host__ __device__ inline size_t packed_index(int Cin, int co, int tap, int ci, int plane) {
   const size_t chunk = (size_t)(co >> 5) * (9 * (Cin >> 5)) + tap * (Cin >> 5) + (ci >> 5);
-  return ((chunk * 4 + ((ci & 15) >> 2)) * 64 + ((ci & 31) >> 4) * 32 + (co & 31)) * 4 + (ci & 3);
+  return ((((chunk * 2 + ((ci & 15) >> 3)) * 3 + plane) * 64 + ((ci & 31) >> 4) * 32 + (co & 31)) << 3) +
+         (ci & 7);
+}
+// the three bf16 planes of an fp32 value (bf16x6.h's split: masks and exact differences)
+__host__ __device__ inline void split3_bits(float v, unsigned short (&out)[3]) {
+  union { float f; unsigned u; } a, b, c;
+  a.f = v;
+  const unsigned h = a.u & 0xffff0000u;
+  a.u = h;
+  b.f = v - a.f;
+  const unsigned m = b.u & 0xffff0000u;
+  b.u = m;
+  c.f = (v - a.f) - b.f;
+  out[0] = (unsigned short)(h >> 16), out[1] = (unsigned short)(m >> 16),
+  out[2] = (unsigned short)(c.u >> 16);
 }
 __host__ __device__ inline bool packed_copy(int Cout, int Cin) { return Cin % 32 == 0 && Cout % 32 == 0; }
 __device__ __forceinline__ void relayout_one(const float *w, float *wf, float *wd, int Cout,
@@ -45,8 +62,12 @@ __device__ __forceinline__ void relayout_one(const float *w, float *wf, float *w
   const float v = w[e];
   wf[((size_t)co * 9 + tap) * Cin + ci] = v;
   wd[((size_t)ci * 9 + tap) * Cout + co] = v;
-  if (packed_copy(Cout, Cin))
-    wf[(size_t)Cout * 9 * Cin + packed_index(Cin, co, tap, ci)] = v;
+  if (packed_copy(Cout, Cin)) {
+    unsigned short pl[3], *dst = reinterpret_cast<unsigned short *>(wf + (size_t)Cout * 9 * Cin);
+    split3_bits(v, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[packed_index(Cin, co, tap, ci, p)] = pl[p];
+  }
   if (wfh) wfh[((size_t)co * 9 + tap) * Cin + ci] = bf16_bits(v);
   if (wdh) wdh[((size_t)ci * 9 + tap) * Cout + co] = bf16_bits(v);
 }

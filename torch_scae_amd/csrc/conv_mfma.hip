@@ -1072,7 +1072,7 @@ inline int pipe_cfg(const char *env, long M, int N) {
 extern "C" int64_t scae_conv3x3_wf_floats(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0) return 0;
   const int64_t n = (int64_t)Cout * 9 * Cin;
-  return scae_first::packed_copy(Cout, Cin) ? 2 * n : n;
+  return scae_first::packed_copy(Cout, Cin) ? n + (3 * n + 1) / 2 : n;   // + three bf16 planes
 }
 
 extern "C" int scae_conv3x3_relayout_f32(const float *w, float *wf, float *wd, int Cout,

@@ -39,10 +39,13 @@ struct ResArgs {
   int G;   // images per workgroup
 };
 
-// X6: the products on the bf16 matrix cores as six exact partial products of a three-way split
-// of the fp32 operands (bf16x6.h): fp32 results at 6 / 16 of the fp32 MFMA time
-template <int MI, bool X6>
+// The products run on the bf16 matrix cores as six exact partial products of a three-way split
+// of the fp32 operands (bf16x6.h): fp32 results at 6 / 16 of the fp32 MFMA time.  The filter
+// arrives already split (the fragment-major copy holds its three bf16 planes), the pixels are
+// split on the fragments in registers.
+template <int MI>
 __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
+  constexpr bool X6 = true;
   extern __shared__ __attribute__((aligned(1024))) float smem[];
   const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63,
             li = lane & 31, lk = lane >> 5;
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
   const int CB = g.Cin / 32;         // 32-channel blocks per tap
   const int CPT = CB / 4;            // ... per wave
   const int NCW = 9 * CPT;           // this wave's chunks
-  const float4 *wq = reinterpret_cast<const float4 *>(a.wp) + (size_t)nt * (9 * CB) * 256 + lane;
+  // (per 32-channel chunk: 2 pairs of quads x 3 planes x 64 lanes x 16 bytes)
+  const uint4 *wq = reinterpret_cast<const uint4 *>(a.wp) + (size_t)nt * (9 * CB) * 384 + lane;
   // X6: NS small-product accumulators per tile -- with one tile per wave three, so that two
   // MFMAs on the same accumulator are three instructions apart (a dependent MFMA waits ~64
   // cycles); with more tiles the tiles themselves interleave
@@ -94,12 +98,14 @@ __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
         for (int n = 0; n < NS; ++n) accl[mi][n][e] = 0.f;
       }
     }
-  float4 bq[2][4];
+  uint4 bq[2][2][3];   // [buffer][pair][plane]
   auto load_b = [&](int c, int buf) {
     const int tap = c / CPT, cb = wid + 4 * (c - tap * CPT);
-    const float4 *src = wq + (size_t)(tap * CB + cb) * 256;
+    const uint4 *src = wq + (size_t)(tap * CB + cb) * 384;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bq[buf][q] = src[q * 64];
+    for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bq[buf][qp][pl] = src[(qp * 3 + pl) * 64];
   };
   load_b(0, 0);
   pipe::wait_vm<0>();   // the staging pieces have landed (and the first B quads: one round trip, shared)
@@ -121,7 +127,10 @@ __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
       // two quads = the lane's eight k of one bf16 MFMA (the same eight for A and B)
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
-        const scae_x6::Split3 bs = scae_x6::split3(bq[buf][2 * qp], bq[buf][2 * qp + 1]);
+        scae_x6::Split3 bs;
+        bs.hi = __builtin_bit_cast(scae_x6::bf16x8, bq[buf][qp][0]);
+        bs.mid = __builtin_bit_cast(scae_x6::bf16x8, bq[buf][qp][1]);
+        bs.lo = __builtin_bit_cast(scae_x6::bf16x8, bq[buf][qp][2]);
         scae_x6::Split3 as[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -143,21 +152,6 @@ __global__ __launch_bounds__(NT, 2) void conv_res_fwd_kernel(ResArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
           acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[mi].hi, bs.hi, acc[mi], 0, 0, 0);
-      }
-      return;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 af[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = pipe::lds4(ap[mi] + (((slot0 + q) ^ sw[mi]) << 2));
-      const float4 b = bq[buf][q];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, b.x, acc[mi], 0, 0, 0);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, b.y, acc[mi], 0, 0, 0);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, b.z, acc[mi], 0, 0, 0);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, b.w, acc[mi], 0, 0, 0);
       }
     }
   };
@@ -262,27 +256,20 @@ extern "C" int scae_conv3x3_fwd_res_f32(const float *in, const float *wp, const 
   ResArgs a{in, wp, bias, post_bias, out, out_post, g, p.G};
   const dim3 grid((Cout / 32) * ((B + p.G - 1) / p.G));
   hipStream_t st = (hipStream_t)stream;
-  // (SCAE_X6=0: the fp32 MFMA form, for A/B measurements)
-  const char *xe = getenv("SCAE_X6");
-  const bool x6 = !(xe && *xe == '0');
-#define SCAE_RES_K(M, X)                                                                         \
-  {                                                                                              \
+#define SCAE_RES(M)                                                                              \
+  case M: {                                                                                      \
     if (p.lds > 48 * 1024) {                                                                     \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_res_fwd_kernel<M, X>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_res_fwd_kernel<M>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
       if (e != hipSuccess) return (int)e;                                                        \
     }                                                                                            \
-    scae::launch((conv_res_fwd_kernel<M, X>), grid, dim3(NT), p.lds, st, a);                     \
+    scae::launch(conv_res_fwd_kernel<M>, grid, dim3(NT), p.lds, st, a);                          \
+    break;                                                                                       \
   }
-#define SCAE_RES(M)                                                                              \
-  case M:                                                                                        \
-    if (x6) SCAE_RES_K(M, true) else SCAE_RES_K(M, false)                                        \
-    break;
   switch (p.MI) {
     SCAE_RES(1) SCAE_RES(2) SCAE_RES(3) SCAE_RES(4)
     default: return SCAE_ERR_UNSUPPORTED;
   }
-#undef SCAE_RES_K
 #undef SCAE_RES
   return scae_launch_status();
 }

@@ -1122,8 +1122,9 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
         wds, wfs = [], []
         for l in range(1, L):
             co, ci = weights[l].shape[0], weights[l].shape[1]
-            # (Cout,9,Cin) + its fragment-major copy (include/scae_hip.h, K8)
-            wfs.append(new(2, co, 9, ci))
+            # (Cout,9,Cin) + its fragment-major copy, three bf16 planes: 2.5 x
+            # (scae_conv3x3_wf_floats; include/scae_hip.h, K8)
+            wfs.append(new(3, co, 9, ci))
             wds.append(new(ci, 9, co))
         if resident:
             half = lambda *shape: torch.empty(*shape, device=dev,
