@@ -13,7 +13,10 @@
 // against eight fp32 MFMAs: 192 cycles of the matrix pipe instead of 512.  The five small
 // products go into an accumulator of their own (their sum is ~2^-8 of the result: its rounding
 // errors are 2^-8 of an fp32 accumulator's), so the result is, if anything, CLOSER to the
-// exact dot product than the fp32 MFMA chain's; tests hold both forms to the same bars.
+// exact dot product than the fp32 MFMA chain's (tools/x6_probe.py; profiles/r06/x6_probe.txt).
+// The loops issue the products one KIND at a time over the wave's tiles -- hi lo, lo hi, mid mid,
+// hi mid, mid hi into the small accumulator, hi hi into the tile's -- so that consecutive MFMAs
+// write different accumulators.
 // The split costs ~5.5 VALU instructions per operand element and is done on the fragments in
 // registers, so no tensor changes its layout or its type: the data in HBM and LDS stay fp32.
 #pragma once
@@ -58,14 +61,4 @@ __device__ __forceinline__ Split3 split3(float4 a, float4 b) {
   return split3(x);
 }
 
-// acc_hi += hi hi; acc_lo += the five small products (smallest first)
-__device__ __forceinline__ void mma(const Split3 &a, const Split3 &b, f32x16 &acc_hi,
-                                    f32x16 &acc_lo) {
-  acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc_lo, 0, 0, 0);
-  acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc_lo, 0, 0, 0);
-  acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc_lo, 0, 0, 0);
-  acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc_lo, 0, 0, 0);
-  acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc_lo, 0, 0, 0);
-  acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc_hi, 0, 0, 0);
-}
 }  // namespace scae_x6
