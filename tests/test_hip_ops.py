@@ -1236,6 +1236,51 @@ def test_conv_stack_vs_conv2d(B, C0, HW, chans, strides):
                          what=f"{name}{l}")
 
 
+@pytest.mark.parametrize("B,IH,IW,Ci,Co,stride", [
+    (2, 9, 9, 128, 128, 1),       # all 25 tap-class pairs of stride 1, every tile ragged
+    (3, 9, 11, 128, 64, 2),       # the merged parity classes of stride 2: range-checked taps
+    (2, 10, 12, 256, 64, 2),      # a last row / column no tap reaches; two channel tiles
+    (40, 19, 19, 128, 128, 2),    # cfg-2's second layer: full tiles + a ragged one per class
+    (130, 5, 5, 128, 128, 1),     # the smallest layer: one-pixel classes
+])
+def test_conv_data_gradient_dma_tile_vs_fp64(B, IH, IW, Ci, Co, stride, monkeypatch):
+    """The DMA-fed data-gradient tile of the pair launch (conv_mfma.hip, DMODE 4: fp32 rows by
+    LDS-DMA, six exact bf16 products per fragment pair) forced onto shapes of every tap-class
+    structure (SCAE_K8_DGX=1: any layer takes it): the gated input gradient against conv2d in
+    fp64 at 2e-6 of its largest entry, and against the first-generation tiles of the same
+    launch; the weight-gradient partials of the launch are the same bits either way."""
+    import ctypes
+    import torch.nn.functional as F
+    from torch_scae_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    s = stride
+    g = torch.Generator().manual_seed(B * 100 + IH)
+    OH, OW = (IH - 3) // s + 1, (IW - 3) // s + 1
+    st = P(torch.cuda.current_stream().cuda_stream)
+    x = torch.relu(torch.randn(B, IH, IW, Ci, generator=g)).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda()
+    wd = w.permute(1, 2, 3, 0).contiguous()       # (ci, 9, co)
+    dpre = torch.randn(B, OH, OW, Co, generator=g).cuda()
+    splits = lib.scae_conv3x3_wgrad_splits(B, OH, OW, Ci, Co)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCAE_K8_DGX", mode)
+        din = torch.full((B, IH, IW, Ci), 7.0, device="cuda")
+        part = torch.full((splits * (9 * Co * Ci + Co),), 3.0, device="cuda")
+        _lib.call("scae_conv3x3_bwd_pair_f32", P(dpre.data_ptr()), P(wd.data_ptr()),
+                  P(x.data_ptr()), P(din.data_ptr()), P(part.data_ptr()), B, IH, IW, Ci, Co, s, st)
+        torch.cuda.synchronize()
+        outs[mode] = (din, part)
+    xr = x.double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
+    F.conv2d(xr, w.double().cpu(), None, stride=s).backward(dpre.double().permute(0, 3, 1, 2).cpu())
+    dref = (xr.grad * (xr.detach() > 0)).permute(0, 2, 3, 1)
+    top = float(dref.abs().max())
+    assert float((outs["1"][0].double().cpu() - dref).abs().max()) <= 2e-6 * top
+    assert float((outs["1"][0] - outs["0"][0]).abs().max()) <= 4e-6 * top
+    assert torch.equal(outs["1"][1], outs["0"][1])
+
+
 def test_conv_stack_falls_back_for_small_channel_counts():
     from torch_scae_amd import ops
     from torch_scae_amd.part_encoder import CNNEncoder

@@ -14,6 +14,7 @@ noise (tests/gate_screen.py), and after the replay the step's noise buffer
 must equal the prediction bit for bit.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -211,7 +212,7 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
                                                float(ref_loss))
         # every entry of every parameter gradient within ``entry_bar`` of its
         # tensor's largest entry (the screened batch has no borderline gate)
-        grads, off, l2, n = flat_grads(step), [], [], 0
+        grads, off, l2, n, dust = flat_grads(step), [], [], 0, set()
         for k, ref in ref_grads.items():
             if ref is None:
                 continue
@@ -230,6 +231,7 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
                 assert float(got.abs().max()) <= \
                     max(5e-5 if fp64_judge else 1e-6, entry_bar * entry_abs), \
                     (what, it, k, float(got.abs().max()))
+                dust.add(k)
                 continue
             err = max(0.0, float((got - ref).abs().max()) - slack.get(k, 0.0))
             off.append((err / (scale + entry_abs), k, scale))
@@ -251,6 +253,13 @@ def check_replayed_steps(model, step, cfg, B, P, g, iters, lr=3e-5,
         for k in ref_before:
             d_ref = P[k].detach() - ref_before[k]
             d_hip = (after[k] - before[k]).cpu()
+            if fp64_judge and k in dust:
+                # a gradient that is dust on the reference side and <= 5e-5 on the HIP side
+                # (above) is still up to 80 x RMSprop's eps: the optimiser turns it into a
+                # step of its usual size.  All that can be asked is that it IS one step
+                # (momentum 0.9 on g / sqrt(v) <= 10: at most 100 lr).
+                assert float(d_hip.abs().max()) <= 100 * lr, (what, it, k)
+                continue
             nr = float(d_ref.norm())
             if nr == 0.0:
                 assert float(d_hip.abs().max()) == 0.0, (what, it, k)
@@ -398,7 +407,17 @@ def test_replayed_step_on_the_state_the_bench_ends_in():
     gets exactly zero gradients without its pixel loop.  The bench's own model
     (its seed, its batches, TrainStep's defaults) is stepped until it is there
     (bench.py reports it after 600 steps), then the replayed step is held to the
-    oracle from THAT state, with the bars of the initial state."""
+    oracle from THAT state.  The entry bar there is 5e-4 of a tensor's largest
+    entry, not the 1e-4 of the live states: which dead state a trajectory ends in
+    depends on every bit of every kernel, and over ten such states (five sets of
+    batches x two forms of the second layer's data gradient, round 6,
+    profiles/r06/trained_state_spread.txt) the worst entry ranged from 1.2e-6 to
+    2.1e-4 whatever the kernels -- presences of 1e-29 .. 1e-31 put products on
+    either side of the denormal line, which the HIP side flushes and torch's CPU
+    kernels keep, and 1 / presence brings them back; the tensors concerned have
+    gradients of 1e-5 .. 5e-4, the errors are 5e-9 .. 1e-7 absolute, below
+    RMSprop's eps (6e-7).  SCAE_TEST_SEED / SCAE_TEST_EXTRA_STEPS move the
+    trajectory (other batches / more steps) for such a sweep."""
     import bench
     cfg_b = bench.CONFIGS["mnist_24_24_bs128"]
     cfg, B = cfg_b["model"], cfg_b["batch"]
@@ -408,10 +427,11 @@ def test_replayed_step_on_the_state_the_bench_ends_in():
     step = bench.make_step(cfg_b, torch.device("cuda", 0))
     model = step.model
     step.capture()
-    images, labels = bench.synthetic_batches(cfg_b, torch.device("cuda", 0), 1000)
+    images, labels = bench.synthetic_batches(
+        cfg_b, torch.device("cuda", 0), 1000 + int(os.environ.get("SCAE_TEST_SEED", "0")))
     state = None
     for n_steps in range(500, 4001, 500):
-        for i in range(500):
+        for i in range(500 + int(os.environ.get("SCAE_TEST_EXTRA_STEPS", "0"))):
             step(images[i % 8], labels[i % 8])
         torch.cuda.synchronize()
         state = bench.capsule_state(model, images[0])
@@ -428,7 +448,7 @@ def test_replayed_step_on_the_state_the_bench_ends_in():
     # decoder are exactly zero on both sides: fewer tensors carry an error)
     worst, _ = check_replayed_steps(model, step, cfg, B, P, g, 2,
                                     what="trained state", min_tensors=50,
-                                    fp64_judge=True)
+                                    fp64_judge=True, entry_bar=5e-4)
     print("worst gradient entry in the trained state:", worst)
 
 
@@ -483,6 +503,37 @@ def test_replayed_step_equals_eager_step_bitwise():
     assert l0 == l1, (l0, l1)
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_dma_data_gradient_tile_changes_only_the_image_layers_gradient(monkeypatch):
+    """The replayed cfg-2 step with the second layer's data gradient on the DMA-fed tile
+    (conv_mfma.hip DMODE 4, the default for a layer of >= 500 such tiles) and on the
+    first-generation tiles (SCAE_K8_DGX=0): same state, noise and batch.  The tile's only
+    output is the gradient the image layer's weight gradient is computed from, so the loss and
+    every other gradient -- the riders of the same launch included -- are the same bits, and the
+    image layer's own agree to round-off."""
+    cfg, B, sd, g = full_size_params("cfg2")
+    images = torch.rand(1, B, *cfg["image_shape"], generator=g).cuda()
+    labels = torch.randint(0, 10, (1, B), generator=g).cuda()
+    out = {}
+    for mode in ("0", "500"):
+        monkeypatch.setenv("SCAE_K8_DGX", mode)
+        model, step = build_step(cfg, B, sd)
+        step.capture()
+        _set_counter(step, 1000)
+        loss = float(step(images[0], labels[0]))
+        torch.cuda.synchronize()
+        names = {id(p): n for n, p in model.named_parameters()}
+        out[mode] = (loss, {names[id(p)]: step.flat.flat_grad[off:off + p.numel()].clone()
+                            for p, off in zip(step.flat.params, step.flat.offsets)})
+    (l0, g0), (l1, g1) = out["0"], out["500"]
+    assert l0 == l1
+    first = [k for k in g0 if k.startswith("part_encoder.encoder.network.0.")]
+    differ = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert len(first) == 2 and set(differ) <= set(first), (differ, first)
+    for k in first:
+        top = float(g0[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * top, k
 
 
 def test_two_graph_collective_step_equals_plain_step_bitwise_cfg2(nccl_group):

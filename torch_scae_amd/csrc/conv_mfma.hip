@@ -727,9 +727,221 @@ __global__ __launch_bounds__(pipe::NT) void conv_bwd_pair_pipe_kernel(
   }
 }
 
+// ---- data-gradient tile, third form (DMODE 4) ------------------------------------------------
+// 64 input pixels of ONE tap-class pair x 128 input channels, 2 x 2 waves of 32 x 64.  Both
+// operands reach LDS by DMA as the fp32 rows they are in memory -- 32-float chunks = 128-byte
+// rows, 16-byte quads XOR-swizzled on the SOURCE side so that the 16-lane groups of a
+// ds_read_b128 cover all 64 banks --, a lane's fragment (8 consecutive k) is two quads, split in
+// registers into its three bf16 parts and multiplied as six exact products (bf16x6.h).  The
+// gradient rows of a tap that misses a pixel (stride 2: the merged parity classes) and the rows
+// past the class's end are DMA zeros.
+namespace dgx {
+constexpr int TM = 64, TN = 128, BKF = 32, ROWB = 4 * BKF;
+constexpr int A_B = TM * ROWB, B_B = TN * ROWB, STAGE_B = A_B + B_B;   // 8 + 16 KiB
+constexpr int SLAB = 32 * 36;                                          // epilogue: floats per wave
+constexpr int SMEM = STAGE_B / 4;                                      // floats of one stage
+constexpr int PPW = 6;                                                 // DMA pieces per wave, chunk
+static_assert(4 * SLAB <= SMEM, "the epilogue slabs alias a stage");
+__device__ __forceinline__ int swz(int row, int q) { return q ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int nth_bit(int mask, int n) {   // n-th set bit of a 3-bit mask
+  const int k0 = (mask & 1) ? 0 : ((mask & 2) ? 1 : 2);
+  if (n == 0) return k0;
+  const int rest = mask & ~(1 << k0);
+  return (n == 1 && (rest & 2)) ? 1 : 2;
+}
+}  // namespace dgx
+
+template <int NS>
+__device__ __forceinline__ void dgrad_x6_tile(float *smemf, int bx, int by,
+                                              const float *__restrict__ dpre,
+                                              const float *__restrict__ wd,
+                                              const float *__restrict__ gate,
+                                              float *__restrict__ din, const ConvGeom &g,
+                                              const DgradPlan &pl) {
+  using namespace dgx;
+  using scae_x6::Split3;
+  unsigned char *smem = reinterpret_cast<unsigned char *>(smemf);
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int i = lane & 31, kk = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  const int nz = pl.nrc * pl.ncc;
+  const int z = __popcll(__ballot(lane + 1 < nz && by >= pl.tile_start[min(lane + 1, 64)]));
+  const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
+  const int AH = pl.rcount[rc], AW = pl.ccount[cc], M = g.B * AH * AW;
+  const int m0 = (by - pl.tile_start[z]) * TM, n0 = bx * TN;
+  const int rm = pl.rmask[rc], cm = pl.cmask[cc], nkh = __popc(rm), nkw = __popc(cm);
+  const bool s2 = g.stride == 2;
+  const pipe::rsrc_t ra = pipe::make_rsrc(dpre, (unsigned)((size_t)g.B * g.OH * g.OW * g.Cout * 4));
+  const pipe::rsrc_t rb = pipe::make_rsrc(wd, (unsigned)((size_t)g.Cin * 9 * g.Cout * 4));
+  // the class pair's LAST tap (largest kh, kw) is the lanes' reference position at stride 1,
+  // where every tap of a class reaches every pixel of it
+  const int khl = nth_bit(rm, nkh - 1), kwl = nth_bit(cm, nkw - 1);
+  // DMA piece j of the A tile: rows 16 wid + 8 j .. + 7; of the B tile: rows 32 wid + 8 j .. + 7;
+  // lane l moves the quad that lands in slot l & 7 of row .. + (l >> 3)
+  int pn[2], pih[2], piw[2], va[2], vb[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * wid + 8 * j + (lane >> 3), m = m0 + row;
+    pn[j] = -1, pih[j] = 0, piw[j] = 0, va[j] = pipe::DMA_ZERO;
+    if (m < M) {
+      const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
+      pn[j] = n * g.OH * g.OW;
+      pih[j] = pl.rlist[pl.rstart[rc] + a], piw[j] = pl.clist[pl.cstart[cc] + b];
+      if (!s2)
+        va[j] = ((pn[j] + (pih[j] - khl) * g.OW + piw[j] - kwl) * g.Cout) * 4 +
+                swz(row, lane & 7) * 16;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * wid + 8 * j + (lane >> 3);
+    vb[j] = ((n0 + row) * 9 * g.Cout) * 4 + swz(row, lane & 7) * 16;
+  }
+  const int cpt = g.Cout / BKF, nchunk = nkh * nkw * cpt;
+  auto issue = [&](int c, unsigned char *stage) {
+    const int t = c / cpt, h = c - t * cpt, ti = t / nkw, tj = t - ti * nkw;
+    const int kh = nth_bit(rm, ti), kw = nth_bit(cm, tj);
+    const int sb = ((kh * 3 + kw) * g.Cout + h * BKF) * 4;
+    if (!s2) {
+      const int sa = (((khl - kh) * g.OW + kwl - kw) * g.Cout + h * BKF) * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        pipe::dma16(ra, reinterpret_cast<float *>(stage + (16 * wid + 8 * j) * ROWB), va[j], sa);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = 16 * wid + 8 * j + (lane >> 3);
+        const int dh = pih[j] - kh, dw = piw[j] - kw, oh = dh >> 1, ow = dw >> 1;
+        const bool ok = pn[j] >= 0 && dh >= 0 && dw >= 0 && oh < g.OH && ow < g.OW;
+        const int v = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout) * 4 + swz(row, lane & 7) * 16
+                         : pipe::DMA_ZERO;
+        pipe::dma16(ra, reinterpret_cast<float *>(stage + (16 * wid + 8 * j) * ROWB), v,
+                    h * BKF * 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pipe::dma16(rb, reinterpret_cast<float *>(stage + A_B + (32 * wid + 8 * j) * ROWB), vb[j],
+                  sb);
+  };
+  pipe::f32x16 acc[2], accl[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[u][e] = 0.f, accl[u][e] = 0.f;
+  const int rowa = wm * 32 + i, aoff = rowa * ROWB, asw = (rowa >> 1) & 7;
+  int boff[2], bsw[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rowb = wn * 64 + u * 32 + i;
+    boff[u] = A_B + rowb * ROWB, bsw[u] = (rowb >> 1) & 7;
+  }
+  auto frag = [&](const unsigned char *stage, int off, int sw, int q) {   // quads q, q + 1 of a row
+    return scae_x6::split3(
+        pipe::lds4(reinterpret_cast<const float *>(stage + off + ((q ^ sw) << 4))),
+        pipe::lds4(reinterpret_cast<const float *>(stage + off + (((q + 1) ^ sw) << 4))));
+  };
+  auto mma = [&](const unsigned char *stage) {
+#pragma unroll
+    for (int s = 0; s < BKF / 16; ++s) {
+      const int q = 4 * s + 2 * kk;
+      const Split3 a = frag(stage, aoff, asw, q);
+      Split3 b[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) b[u] = frag(stage, boff[u], bsw[u], q);
+#define SCAE_DGX_MMA(AP, BP, ACC)                                                            \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) ACC[u] =                                     \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.AP, b[u].BP, ACC[u], 0, 0, 0)
+      SCAE_DGX_MMA(hi, lo, accl);
+      SCAE_DGX_MMA(lo, hi, accl);
+      SCAE_DGX_MMA(mid, mid, accl);
+      SCAE_DGX_MMA(hi, mid, accl);
+      SCAE_DGX_MMA(mid, hi, accl);
+      SCAE_DGX_MMA(hi, hi, acc);
+#undef SCAE_DGX_MMA
+    }
+  };
+  // the K loop: NS stages, NS - 1 chunks in flight under the MFMAs of the current one
+  if (NS == 1) {
+    for (int c = 0; c < nchunk; ++c) {
+      issue(c, smem);
+      pipe::wait_vm<0>();
+      pipe::wg_barrier();
+      mma(smem);
+      pipe::wg_barrier();   // everyone has read the stage: the next chunk may land
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+      if (c < nchunk) issue(c, smem + c * STAGE_B);
+    int s = 0;   // stage of chunk c
+    for (int c = 0; c < nchunk; ++c) {
+      pipe::wait_chunk<PPW, NS>(min(NS - 2, nchunk - 1 - c));
+      pipe::wg_barrier();   // chunk c has landed; everyone is done reading chunk c - 1's stage
+      const int sp = s == 0 ? NS - 1 : s - 1;   // = the stage of chunk c + NS - 1
+      if (c + NS - 1 < nchunk) issue(c + NS - 1, smem + sp * STAGE_B);
+      mma(smem + s * STAGE_B);
+      s = s + 1 == NS ? 0 : s + 1;
+    }
+  }
+  // accumulators out: each wave's two 32 x 32 tiles pass through its [32][36] slab and leave as
+  // rows of 8 consecutive channels per lane
+  pipe::wg_barrier();   // the stages are dead: the slabs alias the first
+  float *slab = smemf + wid * SLAB;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      slab[((e & 3) + 8 * (e >> 2) + 4 * kk) * 36 + i] = acc[u][e] + accl[u][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own slab)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = (lane >> 2) + 16 * pass, c8 = 8 * (lane & 3);
+      float4 v0 = pipe::lds4(slab + row * 36 + c8), v1 = pipe::lds4(slab + row * 36 + c8 + 4);
+      const int m = m0 + wm * 32 + row;
+      if (m < M) {
+        const int nb = m / (AH * AW), rem = m - nb * AH * AW, a = rem / AW, b = rem - a * AW;
+        const int ih = pl.rlist[pl.rstart[rc] + a], iw = pl.clist[pl.cstart[cc] + b];
+        const size_t o = (((size_t)nb * g.IH + ih) * g.IW + iw) * g.Cin + n0 + wn * 64 + u * 32 + c8;
+        if (gate) {
+          const float4 g0 = ld4(gate + o), g1 = ld4(gate + o + 4);
+          v0.x = g0.x > 0.f ? v0.x : 0.f, v0.y = g0.y > 0.f ? v0.y : 0.f;
+          v0.z = g0.z > 0.f ? v0.z : 0.f, v0.w = g0.w > 0.f ? v0.w : 0.f;
+          v1.x = g1.x > 0.f ? v1.x : 0.f, v1.y = g1.y > 0.f ? v1.y : 0.f;
+          v1.z = g1.z > 0.f ? v1.z : 0.f, v1.w = g1.w > 0.f ? v1.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(din + o) = v0;
+        *reinterpret_cast<float4 *>(din + o + 4) = v1;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// data-gradient tile by DMODE: 0 - 2 the first-generation shapes of mfma_tile.h, 4 the form above
+template <int DMODE>
+struct DgradShape {
+  static constexpr int SMEM = Tile<DMODE>::SMEM;
+};
+template <>
+struct DgradShape<4> {
+  static constexpr int SMEM = dgx::SMEM;
+};
+template <int DMODE, int SM>
+__device__ __forceinline__ void dgrad_any_tile(float *smem, int bx, int by,
+                                               const float *__restrict__ dpre,
+                                               const float *__restrict__ wd,
+                                               const float *__restrict__ gate,
+                                               float *__restrict__ din, const ConvGeom &g,
+                                               const DgradPlan &pl) {
+  if constexpr (DMODE == 4)
+    dgrad_x6_tile<(SM >= 2 * dgx::SMEM ? 2 : 1)>(smem, bx, by, dpre, wd, gate, din, g, pl);
+  else
+    dgrad_tile<DMODE>(smem, bx, by, dpre, wd, gate, din, g, pl);
+}
+
 #ifdef SCAE_CONV_PROF   // start / end stamp (s_memrealtime, 100 MHz) of every workgroup of the
 // mixed backward pairs, a slot per DMODE (tools/conv_prof.py)
-__device__ unsigned long long g_conv_prof[3][4096][2];
+__device__ unsigned long long g_conv_prof[5][4096][2];
 #define CV_STAMP(mode, i)                                                       \
   do {                                                                          \
     if (threadIdx.x == 0 && blockIdx.x < 4096)                                  \
@@ -746,12 +958,12 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_kernel(
     const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
     float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
     ConvGeom g, DgradPlan pl, int splits, PairGrid pg) {
-  constexpr int SM = Tile<DMODE>::SMEM > TW::SMEM ? Tile<DMODE>::SMEM : TW::SMEM;
+  constexpr int SM = DgradShape<DMODE>::SMEM > TW::SMEM ? DgradShape<DMODE>::SMEM : TW::SMEM;
   __shared__ __attribute__((aligned(1024))) float smem[SM];
   const int bid = blockIdx.x;
   CV_STAMP(DMODE, 0);
   if (bid < pg.nd) {   // workgroup-uniform
-    dgrad_tile<DMODE>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
+    dgrad_any_tile<DMODE, SM>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
   } else {
     const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
     wgrad_pipe_tile<TW>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
@@ -782,7 +994,7 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_rider_kernel(
     const float *__restrict__ dpre, const float *__restrict__ wd, const float *__restrict__ gate,
     float *__restrict__ din, const float *__restrict__ in, float *__restrict__ partial,
     ConvGeom g, DgradPlan pl, int splits, PairGrid pg, PairRider r) {
-  constexpr int SM = Tile<DMODE>::SMEM > TW::SMEM ? Tile<DMODE>::SMEM : TW::SMEM;
+  constexpr int SM = DgradShape<DMODE>::SMEM > TW::SMEM ? DgradShape<DMODE>::SMEM : TW::SMEM;
   static_assert(SM * sizeof(float) >= 24 * 1024, "the riders' LDS");
   __shared__ __attribute__((aligned(1024))) float smem[SM];
   CV_STAMP(DMODE, 0);
@@ -796,7 +1008,7 @@ __global__ __launch_bounds__(NT) void conv_bwd_pair_mixed_rider_kernel(
   }
   const int bid = (int)blockIdx.x - r.n;
   if (bid < pg.nd) {
-    dgrad_tile<DMODE>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
+    dgrad_any_tile<DMODE, SM>(smem, bid % pg.gx, bid / pg.gx, dpre, wd, gate, din, g, pl);
   } else {
     const int w = bid - pg.nd, bx = w % pg.wx, t = w / pg.wx;
     wgrad_pipe_tile<TW>(smem, bx, t % pg.wy, t / pg.wy, dpre, in, partial, g, splits);
@@ -1325,6 +1537,9 @@ struct DgradLaunch {
 };
 // (pair = true: the launch also carries the weight-gradient tiles, so the data
 // gradient does not have to fill the chip on its own)
+#ifndef SCAE_DGX_MIN_TILES
+#define SCAE_DGX_MIN_TILES 500
+#endif
 #ifndef SCAE_PAIR_SMALL_TILES
 #define SCAE_PAIR_SMALL_TILES SCAE_SMALL_TILES
 #endif
@@ -1364,6 +1579,18 @@ static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false, bool bf16 = 
     d.ny = tiles(ta);
     d.gx = g.Cin / tb;
     return d;
+  }
+  // the DMA-fed exact-split tile (DMODE 4; the mixed pair launch only): SCAE_K8_DGX = minimal
+  // number of its 64 x 128 tiles for a layer to take it (0 = never)
+  if (pair && !(env && *env) && g.Cin % dgx::TN == 0 && g.Cout % dgx::BKF == 0 &&
+      (size_t)g.B * g.IH * g.IW * g.Cin * 4 < (1u << 31)) {
+    const char *xe = getenv("SCAE_K8_DGX");
+    const long min_tiles = xe && *xe ? atol(xe) : SCAE_DGX_MIN_TILES;
+    const long tx = (long)(g.Cin / dgx::TN) * tiles(dgx::TM);
+    if (min_tiles > 0 && tx >= min_tiles) {
+      d.mode = 4, d.ny = tiles(dgx::TM), d.gx = g.Cin / dgx::TN;
+      return d;
+    }
   }
   const long t64 = (long)(g.Cin / 64) * tiles(64), t32 = (long)(g.Cin / 64) * tiles(32);
   d.mode = pair ? (t64 >= SCAE_PAIR_SMALL_TILES ? 0 : (t32 >= SCAE_PAIR_WIDE_MIN ? 2 : 1))
@@ -1460,6 +1687,7 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
 #define SCAE_PAIR_BY_MODE(LAUNCH, TW) \
   if (d.mode == 0) LAUNCH(0, TW);     \
   else if (d.mode == 2) LAUNCH(2, TW); \
+  else if (d.mode == 4) LAUNCH(4, TW); \
   else LAUNCH(1, TW)
     if (rider) {
       const dim3 rgrid(mgrid.x + rider->n);
