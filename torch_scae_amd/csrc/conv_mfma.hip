@@ -939,6 +939,16 @@ __device__ __forceinline__ void dgrad_any_tile(float *smem, int bx, int by,
     dgrad_tile<DMODE>(smem, bx, by, dpre, wd, gate, din, g, pl);
 }
 
+template <int NS>
+__global__ __launch_bounds__(NT) void conv_dgrad_x6_kernel(const float *__restrict__ dpre,
+                                                           const float *__restrict__ wd,
+                                                           const float *__restrict__ gate,
+                                                           float *__restrict__ din, ConvGeom g,
+                                                           DgradPlan pl) {
+  __shared__ __attribute__((aligned(1024))) float smem[NS * dgx::SMEM];
+  dgrad_x6_tile<NS>(smem, blockIdx.x, blockIdx.y, dpre, wd, gate, din, g, pl);
+}
+
 #ifdef SCAE_CONV_PROF   // start / end stamp (s_memrealtime, 100 MHz) of every workgroup of the
 // mixed backward pairs, a slot per DMODE (tools/conv_prof.py)
 __device__ unsigned long long g_conv_prof[5][4096][2];
@@ -1580,9 +1590,9 @@ static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false, bool bf16 = 
     d.gx = g.Cin / tb;
     return d;
   }
-  // the DMA-fed exact-split tile (DMODE 4; the mixed pair launch only): SCAE_K8_DGX = minimal
-  // number of its 64 x 128 tiles for a layer to take it (0 = never)
-  if (pair && !(env && *env) && g.Cin % dgx::TN == 0 && g.Cout % dgx::BKF == 0 &&
+  // the DMA-fed exact-split tile (DMODE 4): SCAE_K8_DGX = minimal number of its 64 x 128 tiles
+  // for a layer to take it (0 = never)
+  if (!(env && *env) && g.Cin % dgx::TN == 0 && g.Cout % dgx::BKF == 0 &&
       (size_t)g.B * g.IH * g.IW * g.Cin * 4 < (1u << 31)) {
     const char *xe = getenv("SCAE_K8_DGX");
     const long min_tiles = xe && *xe ? atol(xe) : SCAE_DGX_MIN_TILES;
@@ -1624,7 +1634,16 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
 #undef SCAE_DG_PIPE
     return scae_launch_status();
   }
-  if (d.mode == 0)
+  if (d.mode == 4) {
+    const char *ne = getenv("SCAE_K8_DGX_NS");   // (tuning aid: ring depth)
+    const int ns = ne && *ne ? atoi(ne) : 2;
+    if (ns == 1)
+      scae::launch(conv_dgrad_x6_kernel<1>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+    else if (ns == 3)
+      scae::launch(conv_dgrad_x6_kernel<3>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+    else
+      scae::launch(conv_dgrad_x6_kernel<2>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+  } else if (d.mode == 0)
     scae::launch(conv_dgrad_kernel<0>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
   else if (d.mode == 2)
     scae::launch(conv_dgrad_kernel<2>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
@@ -1677,7 +1696,9 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
   if (!(pe && atoi(pe) < 0)) {   // second-generation weight-gradient tiles (64 x 64)
     const PairGrid mg{d.gx * d.ny, d.gx, Cin / 64, Cout / 64};
     const dim3 mgrid(mg.nd + mg.wx * mg.wy * 9 * p.splits);
-    const bool w16 = (long)B * g.OH * g.OW < SCAE_WGRAD_SHORT_CHUNK_PIXELS;
+    const char *we = getenv("SCAE_K8_W16");   // (tuning aid: 0 / 1 forces the ring)
+    const bool w16 = we && *we ? atoi(we) != 0
+                               : (long)B * g.OH * g.OW < SCAE_WGRAD_SHORT_CHUNK_PIXELS;
 #define SCAE_PAIR_MIXED(DM, TW)                                                              \
   scae::launch((conv_bwd_pair_mixed_kernel<DM, TW>), mgrid, dim3(NT), 0, st, dpre, wd, in, \
                      din, in, partial, g, d.pl, p.splits, mg)
@@ -1817,6 +1838,8 @@ __global__ __launch_bounds__(NT) void conv_bwd_multi_probe_kernel(const MultiBwd
       dgrad_tile<0>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
     else if (a.mode[l] == 2)
       dgrad_tile<2>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
+    else if (a.mode[l] == 4)
+      dgrad_any_tile<4, SM>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
     else
       dgrad_tile<1>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
   } else {
