@@ -1243,12 +1243,15 @@ def test_conv_stack_vs_conv2d(B, C0, HW, chans, strides):
     (40, 19, 19, 128, 128, 2),    # cfg-2's second layer: full tiles + a ragged one per class
     (130, 5, 5, 128, 128, 1),     # the smallest layer: one-pixel classes
 ])
-def test_conv_data_gradient_dma_tile_vs_fp64(B, IH, IW, Ci, Co, stride, monkeypatch):
-    """The DMA-fed data-gradient tile of the pair launch (conv_mfma.hip, DMODE 4: fp32 rows by
-    LDS-DMA, six exact bf16 products per fragment pair) forced onto shapes of every tap-class
-    structure (SCAE_K8_DGX=1: any layer takes it): the gated input gradient against conv2d in
-    fp64 at 2e-6 of its largest entry, and against the first-generation tiles of the same
-    launch; the weight-gradient partials of the launch are the same bits either way."""
+@pytest.mark.parametrize("form", ["tile", "ksplit"])
+def test_conv_data_gradient_dma_tile_vs_fp64(B, IH, IW, Ci, Co, stride, form, monkeypatch):
+    """The DMA-fed data-gradient tiles of the pair launch (conv_mfma.hip; fp32 rows by LDS-DMA,
+    six exact bf16 products per fragment pair) forced onto shapes of every tap-class structure
+    -- "tile": DMODE 4, 64 x 128, SCAE_K8_DGX=1 (any layer takes it); "ksplit": DMODE 5, 32 x 64
+    with the K loop split over the waves, SCAE_K8_DGK=1 --: the gated input gradient against
+    conv2d in fp64 at 2e-6 of its largest entry, and against the first-generation tiles of the
+    same launch; the weight-gradient partials of the launch are the same bits either way
+    ("ksplit": to round-off -- its launch always takes the 32-pixel ring)."""
     import ctypes
     import torch.nn.functional as F
     from torch_scae_amd import _lib
@@ -1265,7 +1268,8 @@ def test_conv_data_gradient_dma_tile_vs_fp64(B, IH, IW, Ci, Co, stride, monkeypa
     splits = lib.scae_conv3x3_wgrad_splits(B, OH, OW, Ci, Co)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SCAE_K8_DGX", mode)
+        monkeypatch.setenv("SCAE_K8_DGX", mode if form == "tile" else "0")
+        monkeypatch.setenv("SCAE_K8_DGK", mode if form == "ksplit" else "0")
         din = torch.full((B, IH, IW, Ci), 7.0, device="cuda")
         part = torch.full((splits * (9 * Co * Ci + Co),), 3.0, device="cuda")
         _lib.call("scae_conv3x3_bwd_pair_f32", P(dpre.data_ptr()), P(wd.data_ptr()),
@@ -1278,7 +1282,14 @@ def test_conv_data_gradient_dma_tile_vs_fp64(B, IH, IW, Ci, Co, stride, monkeypa
     top = float(dref.abs().max())
     assert float((outs["1"][0].double().cpu() - dref).abs().max()) <= 2e-6 * top
     assert float((outs["1"][0] - outs["0"][0]).abs().max()) <= 4e-6 * top
-    assert torch.equal(outs["1"][1], outs["0"][1])
+    if form == "tile":
+        assert torch.equal(outs["1"][1], outs["0"][1])
+    else:   # (the K-split form's launch takes the 32-pixel weight-gradient ring whatever the
+        # layer's size: the splits cut the pixels elsewhere, the sums over the splits agree)
+        n = 9 * Co * Ci
+        for lo, hi, width in ((0, splits * n, n), (splits * n, splits * (n + Co), Co)):
+            a, b = (outs[m][1][lo:hi].view(splits, width).double().sum(0) for m in ("1", "0"))
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
 
 def test_conv_stack_falls_back_for_small_channel_counts():

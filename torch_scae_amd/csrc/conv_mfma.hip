@@ -917,7 +917,184 @@ __device__ __forceinline__ void dgrad_x6_tile(float *smemf, int bx, int by,
   }
 }
 
-// data-gradient tile by DMODE: 0 - 2 the first-generation shapes of mfma_tile.h, 4 the form above
+// ---- data-gradient tile, fourth form (DMODE 5): the K loop split over the waves ---------------
+// For the layers with FEW tiles and LONG K loops (cfg-2's layers 3 / 4 at B = 128: 100 - 160 of the
+// 64 x 128 tiles above, up to 36 chunks each -- a serial chain per workgroup).  32 input pixels of one
+// tap-class pair x 64 channels per workgroup; every wave computes the WHOLE tile for a quarter of
+// the chunks (wave w: chunks w, w + 4, ..), from a stage of its own (4 + 8 KiB, DMA as above), with
+// no workgroup barrier in the loop: four independent DMA -> split -> MFMA pipelines per workgroup,
+// chains a quarter as long.  The four partial tiles meet in LDS (each wave's slab aliases its own
+// stage) and are summed in a fixed order, gated and stored by all 256 threads.
+namespace dgk {
+constexpr int TM = 32, TN = 64, BKF = 32, ROWB = 4 * BKF;
+constexpr int A_B = TM * ROWB, B_B = TN * ROWB, WAVE_B = A_B + B_B;   // 4 + 8 KiB per wave
+constexpr int LDS = 68;                                                // slab row stride (floats)
+constexpr int SMEM = 4 * WAVE_B / 4;                                   // floats per workgroup
+static_assert(TM * LDS * 4 <= WAVE_B, "a wave's slab aliases its stage");
+}  // namespace dgk
+
+__device__ __forceinline__ void dgrad_x6k_tile(float *smemf, int bx, int by,
+                                               const float *__restrict__ dpre,
+                                               const float *__restrict__ wd,
+                                               const float *__restrict__ gate,
+                                               float *__restrict__ din, const ConvGeom &g,
+                                               const DgradPlan &pl) {
+  using namespace dgk;
+  using dgx::nth_bit;
+  using dgx::swz;
+  using scae_x6::Split3;
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int i = lane & 31, kk = lane >> 5;
+  unsigned char *stage = reinterpret_cast<unsigned char *>(smemf) + wid * WAVE_B;
+  const int nz = pl.nrc * pl.ncc;
+  const int z = __popcll(__ballot(lane + 1 < nz && by >= pl.tile_start[min(lane + 1, 64)]));
+  const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
+  const int AH = pl.rcount[rc], AW = pl.ccount[cc], M = g.B * AH * AW;
+  const int m0 = (by - pl.tile_start[z]) * TM, n0 = bx * TN;
+  const int rm = pl.rmask[rc], cm = pl.cmask[cc], nkh = __popc(rm), nkw = __popc(cm);
+  const bool s2 = g.stride == 2;
+  const pipe::rsrc_t ra = pipe::make_rsrc(dpre, (unsigned)((size_t)g.B * g.OH * g.OW * g.Cout * 4));
+  const pipe::rsrc_t rb = pipe::make_rsrc(wd, (unsigned)((size_t)g.Cin * 9 * g.Cout * 4));
+  const int khl = nth_bit(rm, nkh - 1), kwl = nth_bit(cm, nkw - 1);
+  // every wave moves the whole A tile (4 pieces of 8 rows) and the whole B tile (8 pieces)
+  int pn[4], pih[4], piw[4], va[4], vb[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * j + (lane >> 3), m = m0 + row;
+    pn[j] = -1, pih[j] = 0, piw[j] = 0, va[j] = pipe::DMA_ZERO;
+    if (m < M) {
+      const int n = m / (AH * AW), rem = m - n * AH * AW, a = rem / AW, b = rem - a * AW;
+      pn[j] = n * g.OH * g.OW;
+      pih[j] = pl.rlist[pl.rstart[rc] + a], piw[j] = pl.clist[pl.cstart[cc] + b];
+      if (!s2)
+        va[j] = ((pn[j] + (pih[j] - khl) * g.OW + piw[j] - kwl) * g.Cout) * 4 +
+                swz(row, lane & 7) * 16;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = 8 * j + (lane >> 3);
+    vb[j] = ((n0 + row) * 9 * g.Cout) * 4 + swz(row, lane & 7) * 16;
+  }
+  const int cpt = g.Cout / BKF, nchunk = nkh * nkw * cpt;
+  pipe::f32x16 acc[2], accl[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[u][e] = 0.f, accl[u][e] = 0.f;
+  const int aoff = i * ROWB, asw = (i >> 1) & 7;
+  int boff[2], bsw[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rowb = u * 32 + i;
+    boff[u] = A_B + rowb * ROWB, bsw[u] = (rowb >> 1) & 7;
+  }
+  struct Raw {
+    float4 lo, hi;   // quads q, q + 1 of a row: the lane's 8 k
+  };
+  auto raw = [&](int off, int sw, int q) {
+    Raw r;
+    r.lo = pipe::lds4(reinterpret_cast<const float *>(stage + off + ((q ^ sw) << 4)));
+    r.hi = pipe::lds4(reinterpret_cast<const float *>(stage + off + (((q + 1) ^ sw) << 4)));
+    return r;
+  };
+  auto issue = [&](int c) {   // this wave's 12 pieces of chunk c
+    const int t = c / cpt, h = c - t * cpt, ti = t / nkw, tj = t - ti * nkw;
+    const int kh = nth_bit(rm, ti), kw = nth_bit(cm, tj);
+    const int sb = ((kh * 3 + kw) * g.Cout + h * BKF) * 4;
+    if (!s2) {
+      const int sa = (((khl - kh) * g.OW + kwl - kw) * g.Cout + h * BKF) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        pipe::dma16(ra, reinterpret_cast<float *>(stage + 8 * j * ROWB), va[j], sa);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        const int dh = pih[j] - kh, dw = piw[j] - kw, oh = dh >> 1, ow = dw >> 1;
+        const bool ok = pn[j] >= 0 && dh >= 0 && dw >= 0 && oh < g.OH && ow < g.OW;
+        const int v = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout) * 4 + swz(row, lane & 7) * 16
+                         : pipe::DMA_ZERO;
+        pipe::dma16(ra, reinterpret_cast<float *>(stage + 8 * j * ROWB), v, h * BKF * 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      pipe::dma16(rb, reinterpret_cast<float *>(stage + A_B + 8 * j * ROWB), vb[j], sb);
+  };
+  auto mma = [&](const Raw &ar, const Raw (&br)[2]) {   // one 16-deep step: split, six products
+    const Split3 a = scae_x6::split3(ar.lo, ar.hi);
+    Split3 b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) b[u] = scae_x6::split3(br[u].lo, br[u].hi);
+#define SCAE_DGK_MMA(AP, BP, ACC)                                                            \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) ACC[u] =                                     \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.AP, b[u].BP, ACC[u], 0, 0, 0)
+    SCAE_DGK_MMA(hi, lo, accl);
+    SCAE_DGK_MMA(lo, hi, accl);
+    SCAE_DGK_MMA(mid, mid, accl);
+    SCAE_DGK_MMA(hi, mid, accl);
+    SCAE_DGK_MMA(mid, hi, accl);
+    SCAE_DGK_MMA(hi, hi, acc);
+#undef SCAE_DGK_MMA
+  };
+  static_assert(BKF == 32, "two 16-deep steps per chunk");
+  if (wid < nchunk) issue(wid);
+  for (int c = wid; c < nchunk; c += 4) {   // (wave-uniform)
+    pipe::wait_vm<0>();   // this wave's own pieces: nobody else writes or reads its stage
+    Raw ar = raw(aoff, asw, 2 * kk), br[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) br[u] = raw(boff[u], bsw[u], 2 * kk);
+    mma(ar, br);
+    // the second step's fragments into registers: then the stage is free, and the next chunk's
+    // DMA flies under this step's splits and MFMAs
+    ar = raw(aoff, asw, 4 + 2 * kk);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) br[u] = raw(boff[u], bsw[u], 4 + 2 * kk);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c + 4 < nchunk) issue(c + 4);
+    mma(ar, br);
+  }
+  // the wave's partial tile into its slab [32][LDS] (over its own stage: its reads are done)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float *slab = reinterpret_cast<float *>(stage);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      slab[((e & 3) + 8 * (e >> 2) + 4 * kk) * LDS + u * 32 + i] = acc[u][e] + accl[u][e];
+  pipe::wg_barrier();
+  // 256 threads x 8 outputs: row tid / 8, channels 8 (tid % 8) .. + 7; the four partials in a fixed order
+  const int row = tid >> 3, c8 = 8 * (tid & 7), m = m0 + row;
+  if (m >= M) return;
+  float4 v0, v1;
+  {
+    const float *p0 = smemf + row * LDS + c8;
+    constexpr int WS = WAVE_B / 4;
+    const float4 a0 = pipe::lds4(p0), a1 = pipe::lds4(p0 + 4);
+    const float4 b0 = pipe::lds4(p0 + WS), b1 = pipe::lds4(p0 + WS + 4);
+    const float4 c0 = pipe::lds4(p0 + 2 * WS), c1 = pipe::lds4(p0 + 2 * WS + 4);
+    const float4 d0 = pipe::lds4(p0 + 3 * WS), d1 = pipe::lds4(p0 + 3 * WS + 4);
+    v0 = make_float4((a0.x + b0.x) + (c0.x + d0.x), (a0.y + b0.y) + (c0.y + d0.y),
+                     (a0.z + b0.z) + (c0.z + d0.z), (a0.w + b0.w) + (c0.w + d0.w));
+    v1 = make_float4((a1.x + b1.x) + (c1.x + d1.x), (a1.y + b1.y) + (c1.y + d1.y),
+                     (a1.z + b1.z) + (c1.z + d1.z), (a1.w + b1.w) + (c1.w + d1.w));
+  }
+  const int nb = m / (AH * AW), rem = m - nb * AH * AW, a = rem / AW, b = rem - a * AW;
+  const int ih = pl.rlist[pl.rstart[rc] + a], iw = pl.clist[pl.cstart[cc] + b];
+  const size_t o = (((size_t)nb * g.IH + ih) * g.IW + iw) * g.Cin + n0 + c8;
+  if (gate) {
+    const float4 g0 = ld4(gate + o), g1 = ld4(gate + o + 4);
+    v0.x = g0.x > 0.f ? v0.x : 0.f, v0.y = g0.y > 0.f ? v0.y : 0.f;
+    v0.z = g0.z > 0.f ? v0.z : 0.f, v0.w = g0.w > 0.f ? v0.w : 0.f;
+    v1.x = g1.x > 0.f ? v1.x : 0.f, v1.y = g1.y > 0.f ? v1.y : 0.f;
+    v1.z = g1.z > 0.f ? v1.z : 0.f, v1.w = g1.w > 0.f ? v1.w : 0.f;
+  }
+  *reinterpret_cast<float4 *>(din + o) = v0;
+  *reinterpret_cast<float4 *>(din + o + 4) = v1;
+}
+
+// data-gradient tile by DMODE: 0 - 2 the first-generation shapes of mfma_tile.h, 4 / 5 the forms above
 template <int DMODE>
 struct DgradShape {
   static constexpr int SMEM = Tile<DMODE>::SMEM;
@@ -925,6 +1102,10 @@ struct DgradShape {
 template <>
 struct DgradShape<4> {
   static constexpr int SMEM = dgx::SMEM;
+};
+template <>
+struct DgradShape<5> {
+  static constexpr int SMEM = dgk::SMEM;
 };
 template <int DMODE, int SM>
 __device__ __forceinline__ void dgrad_any_tile(float *smem, int bx, int by,
@@ -935,6 +1116,8 @@ __device__ __forceinline__ void dgrad_any_tile(float *smem, int bx, int by,
                                                const DgradPlan &pl) {
   if constexpr (DMODE == 4)
     dgrad_x6_tile<(SM >= 2 * dgx::SMEM ? 2 : 1)>(smem, bx, by, dpre, wd, gate, din, g, pl);
+  else if constexpr (DMODE == 5)
+    dgrad_x6k_tile(smem, bx, by, dpre, wd, gate, din, g, pl);
   else
     dgrad_tile<DMODE>(smem, bx, by, dpre, wd, gate, din, g, pl);
 }
@@ -949,9 +1132,18 @@ __global__ __launch_bounds__(NT) void conv_dgrad_x6_kernel(const float *__restri
   dgrad_x6_tile<NS>(smem, blockIdx.x, blockIdx.y, dpre, wd, gate, din, g, pl);
 }
 
+__global__ __launch_bounds__(NT) void conv_dgrad_x6k_kernel(const float *__restrict__ dpre,
+                                                            const float *__restrict__ wd,
+                                                            const float *__restrict__ gate,
+                                                            float *__restrict__ din, ConvGeom g,
+                                                            DgradPlan pl) {
+  __shared__ __attribute__((aligned(1024))) float smem[dgk::SMEM];
+  dgrad_x6k_tile(smem, blockIdx.x, blockIdx.y, dpre, wd, gate, din, g, pl);
+}
+
 #ifdef SCAE_CONV_PROF   // start / end stamp (s_memrealtime, 100 MHz) of every workgroup of the
 // mixed backward pairs, a slot per DMODE (tools/conv_prof.py)
-__device__ unsigned long long g_conv_prof[5][4096][2];
+__device__ unsigned long long g_conv_prof[6][4096][2];
 #define CV_STAMP(mode, i)                                                       \
   do {                                                                          \
     if (threadIdx.x == 0 && blockIdx.x < 4096)                                  \
@@ -1547,6 +1739,9 @@ struct DgradLaunch {
 };
 // (pair = true: the launch also carries the weight-gradient tiles, so the data
 // gradient does not have to fill the chip on its own)
+#ifndef SCAE_DGK_DEFAULT
+#define SCAE_DGK_DEFAULT 1
+#endif
 #ifndef SCAE_DGX_MIN_TILES
 #define SCAE_DGX_MIN_TILES 500
 #endif
@@ -1602,6 +1797,16 @@ static DgradLaunch plan_dgrad(const ConvGeom &g, bool pair = false, bool bf16 = 
       return d;
     }
   }
+  // ... and for the layers below that, the form with the K loop split over the waves (DMODE 5):
+  // SCAE_K8_DGK = 1 / 0
+  if (!(env && *env) && g.Cin % dgk::TN == 0 && g.Cout % dgk::BKF == 0 &&
+      (size_t)g.B * g.IH * g.IW * g.Cin * 4 < (1u << 31)) {
+    const char *ke = getenv("SCAE_K8_DGK");
+    if (ke && *ke ? atoi(ke) != 0 : SCAE_DGK_DEFAULT != 0) {
+      d.mode = 5, d.ny = tiles(dgk::TM), d.gx = g.Cin / dgk::TN;
+      return d;
+    }
+  }
   const long t64 = (long)(g.Cin / 64) * tiles(64), t32 = (long)(g.Cin / 64) * tiles(32);
   d.mode = pair ? (t64 >= SCAE_PAIR_SMALL_TILES ? 0 : (t32 >= SCAE_PAIR_WIDE_MIN ? 2 : 1))
                 : tile_mode(t64, t32, 600);
@@ -1643,7 +1848,9 @@ extern "C" int scae_conv3x3_dgrad_f32(const float *dpre, const float *wd, const 
       scae::launch(conv_dgrad_x6_kernel<3>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
     else
       scae::launch(conv_dgrad_x6_kernel<2>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
-  } else if (d.mode == 0)
+  } else if (d.mode == 5)
+    scae::launch(conv_dgrad_x6k_kernel, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
+  else if (d.mode == 0)
     scae::launch(conv_dgrad_kernel<0>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
   else if (d.mode == 2)
     scae::launch(conv_dgrad_kernel<2>, grid, dim3(NT), 0, st, dpre, wd, gate, din, g, d.pl);
@@ -1697,8 +1904,11 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
     const PairGrid mg{d.gx * d.ny, d.gx, Cin / 64, Cout / 64};
     const dim3 mgrid(mg.nd + mg.wx * mg.wy * 9 * p.splits);
     const char *we = getenv("SCAE_K8_W16");   // (tuning aid: 0 / 1 forces the ring)
+    // (the K-split data-gradient tile brings 48 KiB of LDS to the launch anyway: the short ring
+    // would buy no workgroup)
     const bool w16 = we && *we ? atoi(we) != 0
-                               : (long)B * g.OH * g.OW < SCAE_WGRAD_SHORT_CHUNK_PIXELS;
+                               : d.mode != 5 &&
+                                     (long)B * g.OH * g.OW < SCAE_WGRAD_SHORT_CHUNK_PIXELS;
 #define SCAE_PAIR_MIXED(DM, TW)                                                              \
   scae::launch((conv_bwd_pair_mixed_kernel<DM, TW>), mgrid, dim3(NT), 0, st, dpre, wd, in, \
                      din, in, partial, g, d.pl, p.splits, mg)
@@ -1709,6 +1919,7 @@ static int conv_bwd_pair_impl(const float *dpre, const float *wd, const float *i
   if (d.mode == 0) LAUNCH(0, TW);     \
   else if (d.mode == 2) LAUNCH(2, TW); \
   else if (d.mode == 4) LAUNCH(4, TW); \
+  else if (d.mode == 5) LAUNCH(5, TW); \
   else LAUNCH(1, TW)
     if (rider) {
       const dim3 rgrid(mgrid.x + rider->n);
@@ -1838,6 +2049,8 @@ __global__ __launch_bounds__(NT) void conv_bwd_multi_probe_kernel(const MultiBwd
       dgrad_tile<0>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
     else if (a.mode[l] == 2)
       dgrad_tile<2>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
+    else if (a.mode[l] == 5)
+      dgrad_any_tile<5, SM>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
     else if (a.mode[l] == 4)
       dgrad_any_tile<4, SM>(smem, bid % pg.gx, bid / pg.gx, a.dpre[l], a.wd[l], a.gate[l], a.din[l], a.g[l], a.pl[l]);
     else
