@@ -1292,6 +1292,49 @@ def test_conv_data_gradient_dma_tile_vs_fp64(B, IH, IW, Ci, Co, stride, form, mo
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("B,IH,IW,Ci,Co,stride,post", [
+    (3, 9, 9, 128, 64, 1, True),      # one ragged tile, the embedding bias output
+    (2, 21, 19, 64, 128, 2, False),   # two channel tiles, two chunks per tap, stride 2
+    (130, 5, 5, 128, 128, 1, True),   # several tiles, the last one ragged
+    (40, 19, 19, 128, 128, 2, False), # cfg-2's second layer
+])
+def test_conv_forward_ksplit_vs_conv2d(B, IH, IW, Ci, Co, stride, post, monkeypatch):
+    """scae_conv3x3_fwd_f32 on the tile form with the K loop dealt to the waves (conv_mfma.hip,
+    fwd_x6k_tile: an option, SCAE_K8_FWDK=1) against conv2d in fp64 at 2e-6 of the output's largest entry, and
+    against the ring-pipelined tiles (SCAE_K8_FWDK=0); rows past the last pixel are not written."""
+    import ctypes
+    import torch.nn.functional as F
+    from torch_scae_amd import _lib
+    P = ctypes.c_void_p
+    s = stride
+    g = torch.Generator().manual_seed(B * 10 + IH)
+    OH, OW = (IH - 3) // s + 1, (IW - 3) // s + 1
+    st = P(torch.cuda.current_stream().cuda_stream)
+    x = torch.relu(torch.randn(B, IH, IW, Ci, generator=g)).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5).cuda()
+    wf = w.permute(0, 2, 3, 1).contiguous()       # (co, 9, ci)
+    bias, pb = torch.randn(Co, generator=g).cuda(), torch.randn(Co, OH, OW, generator=g).cuda()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCAE_K8_FWDK", mode)
+        out = torch.full((B * OH * OW + 5, Co), 7.0, device="cuda")
+        outp = torch.full((B * OH * OW + 5, Co), 7.0, device="cuda") if post else None
+        _lib.call("scae_conv3x3_fwd_f32", P(x.data_ptr()), P(wf.data_ptr()), P(bias.data_ptr()),
+                  P(out.data_ptr()), P(pb.data_ptr()) if post else None,
+                  P(outp.data_ptr()) if post else None, B, IH, IW, Ci, Co, s, st)
+        torch.cuda.synchronize()
+        assert bool((out[-5:] == 7.0).all()) and (outp is None or bool((outp[-5:] == 7.0).all()))
+        outs[mode] = (out[:-5].view(B, OH, OW, Co), None if outp is None else outp[:-5].view(B, OH, OW, Co))
+    ref = torch.relu(F.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu(),
+                              bias.double().cpu(), stride=s)).permute(0, 2, 3, 1)
+    top = float(ref.abs().max())
+    assert float((outs["1"][0].double().cpu() - ref).abs().max()) <= 2e-6 * top
+    assert float((outs["1"][0] - outs["0"][0]).abs().max()) <= 4e-6 * top
+    if post:
+        refp = ref + pb.double().cpu().permute(1, 2, 0)
+        assert float((outs["1"][1].double().cpu() - refp).abs().max()) <= 2e-6 * float(refp.abs().max())
+
+
 def test_conv_stack_falls_back_for_small_channel_counts():
     from torch_scae_amd import ops
     from torch_scae_amd.part_encoder import CNNEncoder
@@ -1523,14 +1566,18 @@ def test_conv_backward_carrying_reduce_and_fold_backward_equals_separate_launche
         assert torch.equal(a, b), i
 
 
-def test_conv_layer_carrying_the_folding_products_equals_separate_launches():
+@pytest.mark.parametrize("ksplit", ["0", "1"])
+def test_conv_layer_carrying_the_folding_products_equals_separate_launches(ksplit, monkeypatch):
     """scae_conv3x3_fwd_fold_f32: the encoder's second conv layer with the
     output attention's folding products as the tail of its grid, against
     scae_conv3x3_fwd_f32 + scae_seed_fold_fwd_f32 (conv output bit for bit;
     the products to round-off: the carried form keeps 16 instead of 32 loads in
-    flight, same sums in the same order)."""
+    flight, same sums in the same order).  Both launches on the same tile form
+    (they choose it by the same rule): SCAE_K8_FWDK=0 the ring-pipelined tiles,
+    =1 the form with the K loop dealt to the waves."""
     import ctypes
     from torch_scae_amd import _lib, ops
+    monkeypatch.setenv("SCAE_K8_FWDK", ksplit)
     g = torch.Generator().manual_seed(21)
     B, ih, iw, ci, co, s = 16, 19, 19, 128, 128, 2
     O, C, D = 24, 256, 16

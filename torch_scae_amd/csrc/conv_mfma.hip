@@ -931,6 +931,96 @@ constexpr int A_B = TM * ROWB, B_B = TN * ROWB, WAVE_B = A_B + B_B;   // 4 + 8 K
 constexpr int LDS = 68;                                                // slab row stride (floats)
 constexpr int SMEM = 4 * WAVE_B / 4;                                   // floats per workgroup
 static_assert(TM * LDS * 4 <= WAVE_B, "a wave's slab aliases its stage");
+static_assert(BKF == 32, "two 16-deep steps per chunk");
+
+// One wave's pipeline over its chunks wid, wid + 4, ..: issue(c) = its 12 DMA pieces of chunk c
+// into ITS stage (A rows 0 .. 31 then B rows 0 .. 63, 128-byte rows, quads swizzled dgx::swz),
+// then the wave's partial 32 x 64 tile into its slab, a workgroup barrier, and the sum of the four
+// slabs in a fixed order: thread tid returns row tid / 8, columns 8 (tid % 8) .. + 7.
+struct Out8 {
+  float4 lo, hi;
+};
+template <class Issue>
+__device__ __forceinline__ Out8 pipeline(float *smemf, int nchunk, Issue issue) {
+  using scae_x6::Split3;
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int i = lane & 31, kk = lane >> 5;
+  unsigned char *stage = reinterpret_cast<unsigned char *>(smemf) + wid * WAVE_B;
+  pipe::f32x16 acc[2], accl[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[u][e] = 0.f, accl[u][e] = 0.f;
+  const int aoff = i * ROWB, asw = (i >> 1) & 7;
+  int boff[2], bsw[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rowb = u * 32 + i;
+    boff[u] = A_B + rowb * ROWB, bsw[u] = (rowb >> 1) & 7;
+  }
+  struct Raw {
+    float4 lo, hi;   // quads q, q + 1 of a row: the lane's 8 k
+  };
+  auto raw = [&](int off, int sw, int q) {
+    Raw r;
+    r.lo = pipe::lds4(reinterpret_cast<const float *>(stage + off + ((q ^ sw) << 4)));
+    r.hi = pipe::lds4(reinterpret_cast<const float *>(stage + off + (((q + 1) ^ sw) << 4)));
+    return r;
+  };
+  auto mma = [&](const Raw &ar, const Raw (&br)[2]) {   // one 16-deep step: split, six products
+    const Split3 a = scae_x6::split3(ar.lo, ar.hi);
+    Split3 b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) b[u] = scae_x6::split3(br[u].lo, br[u].hi);
+#define SCAE_DGK_MMA(AP, BP, ACC)                                                            \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) ACC[u] =                                     \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.AP, b[u].BP, ACC[u], 0, 0, 0)
+    SCAE_DGK_MMA(hi, lo, accl);
+    SCAE_DGK_MMA(lo, hi, accl);
+    SCAE_DGK_MMA(mid, mid, accl);
+    SCAE_DGK_MMA(hi, mid, accl);
+    SCAE_DGK_MMA(mid, hi, accl);
+    SCAE_DGK_MMA(hi, hi, acc);
+#undef SCAE_DGK_MMA
+  };
+  if (wid < nchunk) issue(wid, stage);
+  for (int c = wid; c < nchunk; c += 4) {   // (wave-uniform)
+    pipe::wait_vm<0>();   // this wave's own pieces: nobody else writes or reads its stage
+    Raw ar = raw(aoff, asw, 2 * kk), br[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) br[u] = raw(boff[u], bsw[u], 2 * kk);
+    mma(ar, br);
+    // the second step's fragments into registers: then the stage is free, and the next chunk's
+    // DMA flies under this step's splits and MFMAs
+    ar = raw(aoff, asw, 4 + 2 * kk);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) br[u] = raw(boff[u], bsw[u], 4 + 2 * kk);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c + 4 < nchunk) issue(c + 4, stage);
+    mma(ar, br);
+  }
+  // the wave's partial tile into its slab [32][LDS] (over its own stage: its reads are done)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float *slab = reinterpret_cast<float *>(stage);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      slab[((e & 3) + 8 * (e >> 2) + 4 * kk) * LDS + u * 32 + i] = acc[u][e] + accl[u][e];
+  pipe::wg_barrier();
+  const float *p0 = smemf + (tid >> 3) * LDS + 8 * (tid & 7);
+  constexpr int WS = WAVE_B / 4;
+  const float4 a0 = pipe::lds4(p0), a1 = pipe::lds4(p0 + 4);
+  const float4 b0 = pipe::lds4(p0 + WS), b1 = pipe::lds4(p0 + WS + 4);
+  const float4 c0 = pipe::lds4(p0 + 2 * WS), c1 = pipe::lds4(p0 + 2 * WS + 4);
+  const float4 d0 = pipe::lds4(p0 + 3 * WS), d1 = pipe::lds4(p0 + 3 * WS + 4);
+  Out8 o;
+  o.lo = make_float4((a0.x + b0.x) + (c0.x + d0.x), (a0.y + b0.y) + (c0.y + d0.y),
+                     (a0.z + b0.z) + (c0.z + d0.z), (a0.w + b0.w) + (c0.w + d0.w));
+  o.hi = make_float4((a1.x + b1.x) + (c1.x + d1.x), (a1.y + b1.y) + (c1.y + d1.y),
+                     (a1.z + b1.z) + (c1.z + d1.z), (a1.w + b1.w) + (c1.w + d1.w));
+  return o;
+}
 }  // namespace dgk
 
 __device__ __forceinline__ void dgrad_x6k_tile(float *smemf, int bx, int by,
@@ -942,10 +1032,7 @@ __device__ __forceinline__ void dgrad_x6k_tile(float *smemf, int bx, int by,
   using namespace dgk;
   using dgx::nth_bit;
   using dgx::swz;
-  using scae_x6::Split3;
-  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int i = lane & 31, kk = lane >> 5;
-  unsigned char *stage = reinterpret_cast<unsigned char *>(smemf) + wid * WAVE_B;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int nz = pl.nrc * pl.ncc;
   const int z = __popcll(__ballot(lane + 1 < nz && by >= pl.tile_start[min(lane + 1, 64)]));
   const int rc = z / pl.ncc, cc = z - rc * pl.ncc;
@@ -976,29 +1063,8 @@ __device__ __forceinline__ void dgrad_x6k_tile(float *smemf, int bx, int by,
     const int row = 8 * j + (lane >> 3);
     vb[j] = ((n0 + row) * 9 * g.Cout) * 4 + swz(row, lane & 7) * 16;
   }
-  const int cpt = g.Cout / BKF, nchunk = nkh * nkw * cpt;
-  pipe::f32x16 acc[2], accl[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[u][e] = 0.f, accl[u][e] = 0.f;
-  const int aoff = i * ROWB, asw = (i >> 1) & 7;
-  int boff[2], bsw[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int rowb = u * 32 + i;
-    boff[u] = A_B + rowb * ROWB, bsw[u] = (rowb >> 1) & 7;
-  }
-  struct Raw {
-    float4 lo, hi;   // quads q, q + 1 of a row: the lane's 8 k
-  };
-  auto raw = [&](int off, int sw, int q) {
-    Raw r;
-    r.lo = pipe::lds4(reinterpret_cast<const float *>(stage + off + ((q ^ sw) << 4)));
-    r.hi = pipe::lds4(reinterpret_cast<const float *>(stage + off + (((q + 1) ^ sw) << 4)));
-    return r;
-  };
-  auto issue = [&](int c) {   // this wave's 12 pieces of chunk c
+  const int cpt = g.Cout / BKF;
+  Out8 v = pipeline(smemf, nkh * nkw * cpt, [&](int c, unsigned char *stage) {
     const int t = c / cpt, h = c - t * cpt, ti = t / nkw, tj = t - ti * nkw;
     const int kh = nth_bit(rm, ti), kw = nth_bit(cm, tj);
     const int sb = ((kh * 3 + kw) * g.Cout + h * BKF) * 4;
@@ -1013,85 +1079,115 @@ __device__ __forceinline__ void dgrad_x6k_tile(float *smemf, int bx, int by,
         const int row = 8 * j + (lane >> 3);
         const int dh = pih[j] - kh, dw = piw[j] - kw, oh = dh >> 1, ow = dw >> 1;
         const bool ok = pn[j] >= 0 && dh >= 0 && dw >= 0 && oh < g.OH && ow < g.OW;
-        const int v = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout) * 4 + swz(row, lane & 7) * 16
-                         : pipe::DMA_ZERO;
-        pipe::dma16(ra, reinterpret_cast<float *>(stage + 8 * j * ROWB), v, h * BKF * 4);
+        const int vv = ok ? ((pn[j] + oh * g.OW + ow) * g.Cout) * 4 + swz(row, lane & 7) * 16
+                          : pipe::DMA_ZERO;
+        pipe::dma16(ra, reinterpret_cast<float *>(stage + 8 * j * ROWB), vv, h * BKF * 4);
       }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       pipe::dma16(rb, reinterpret_cast<float *>(stage + A_B + 8 * j * ROWB), vb[j], sb);
-  };
-  auto mma = [&](const Raw &ar, const Raw (&br)[2]) {   // one 16-deep step: split, six products
-    const Split3 a = scae_x6::split3(ar.lo, ar.hi);
-    Split3 b[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) b[u] = scae_x6::split3(br[u].lo, br[u].hi);
-#define SCAE_DGK_MMA(AP, BP, ACC)                                                            \
-  _Pragma("unroll") for (int u = 0; u < 2; ++u) ACC[u] =                                     \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.AP, b[u].BP, ACC[u], 0, 0, 0)
-    SCAE_DGK_MMA(hi, lo, accl);
-    SCAE_DGK_MMA(lo, hi, accl);
-    SCAE_DGK_MMA(mid, mid, accl);
-    SCAE_DGK_MMA(hi, mid, accl);
-    SCAE_DGK_MMA(mid, hi, accl);
-    SCAE_DGK_MMA(hi, hi, acc);
-#undef SCAE_DGK_MMA
-  };
-  static_assert(BKF == 32, "two 16-deep steps per chunk");
-  if (wid < nchunk) issue(wid);
-  for (int c = wid; c < nchunk; c += 4) {   // (wave-uniform)
-    pipe::wait_vm<0>();   // this wave's own pieces: nobody else writes or reads its stage
-    Raw ar = raw(aoff, asw, 2 * kk), br[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) br[u] = raw(boff[u], bsw[u], 2 * kk);
-    mma(ar, br);
-    // the second step's fragments into registers: then the stage is free, and the next chunk's
-    // DMA flies under this step's splits and MFMAs
-    ar = raw(aoff, asw, 4 + 2 * kk);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) br[u] = raw(boff[u], bsw[u], 4 + 2 * kk);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (c + 4 < nchunk) issue(c + 4);
-    mma(ar, br);
-  }
-  // the wave's partial tile into its slab [32][LDS] (over its own stage: its reads are done)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  float *slab = reinterpret_cast<float *>(stage);
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      slab[((e & 3) + 8 * (e >> 2) + 4 * kk) * LDS + u * 32 + i] = acc[u][e] + accl[u][e];
-  pipe::wg_barrier();
-  // 256 threads x 8 outputs: row tid / 8, channels 8 (tid % 8) .. + 7; the four partials in a fixed order
+  });
   const int row = tid >> 3, c8 = 8 * (tid & 7), m = m0 + row;
   if (m >= M) return;
-  float4 v0, v1;
-  {
-    const float *p0 = smemf + row * LDS + c8;
-    constexpr int WS = WAVE_B / 4;
-    const float4 a0 = pipe::lds4(p0), a1 = pipe::lds4(p0 + 4);
-    const float4 b0 = pipe::lds4(p0 + WS), b1 = pipe::lds4(p0 + WS + 4);
-    const float4 c0 = pipe::lds4(p0 + 2 * WS), c1 = pipe::lds4(p0 + 2 * WS + 4);
-    const float4 d0 = pipe::lds4(p0 + 3 * WS), d1 = pipe::lds4(p0 + 3 * WS + 4);
-    v0 = make_float4((a0.x + b0.x) + (c0.x + d0.x), (a0.y + b0.y) + (c0.y + d0.y),
-                     (a0.z + b0.z) + (c0.z + d0.z), (a0.w + b0.w) + (c0.w + d0.w));
-    v1 = make_float4((a1.x + b1.x) + (c1.x + d1.x), (a1.y + b1.y) + (c1.y + d1.y),
-                     (a1.z + b1.z) + (c1.z + d1.z), (a1.w + b1.w) + (c1.w + d1.w));
-  }
   const int nb = m / (AH * AW), rem = m - nb * AH * AW, a = rem / AW, b = rem - a * AW;
   const int ih = pl.rlist[pl.rstart[rc] + a], iw = pl.clist[pl.cstart[cc] + b];
   const size_t o = (((size_t)nb * g.IH + ih) * g.IW + iw) * g.Cin + n0 + c8;
   if (gate) {
     const float4 g0 = ld4(gate + o), g1 = ld4(gate + o + 4);
-    v0.x = g0.x > 0.f ? v0.x : 0.f, v0.y = g0.y > 0.f ? v0.y : 0.f;
-    v0.z = g0.z > 0.f ? v0.z : 0.f, v0.w = g0.w > 0.f ? v0.w : 0.f;
-    v1.x = g1.x > 0.f ? v1.x : 0.f, v1.y = g1.y > 0.f ? v1.y : 0.f;
-    v1.z = g1.z > 0.f ? v1.z : 0.f, v1.w = g1.w > 0.f ? v1.w : 0.f;
+    v.lo.x = g0.x > 0.f ? v.lo.x : 0.f, v.lo.y = g0.y > 0.f ? v.lo.y : 0.f;
+    v.lo.z = g0.z > 0.f ? v.lo.z : 0.f, v.lo.w = g0.w > 0.f ? v.lo.w : 0.f;
+    v.hi.x = g1.x > 0.f ? v.hi.x : 0.f, v.hi.y = g1.y > 0.f ? v.hi.y : 0.f;
+    v.hi.z = g1.z > 0.f ? v.hi.z : 0.f, v.hi.w = g1.w > 0.f ? v.hi.w : 0.f;
   }
-  *reinterpret_cast<float4 *>(din + o) = v0;
-  *reinterpret_cast<float4 *>(din + o + 4) = v1;
+  *reinterpret_cast<float4 *>(din + o) = v.lo;
+  *reinterpret_cast<float4 *>(din + o + 4) = v.hi;
+}
+
+// The forward of a layer in the same form: 32 output pixels x 64 output channels, the 9 x C_in / 32
+// chunks dealt to the four waves.  A = input rows (a lane's source row is fixed, the tap moves the
+// wave-uniform offset), B = wf (C_out, 9, C_in).
+__device__ __forceinline__ void fwd_x6k_tile(float *smemf, int bx, int by,
+                                             const float *__restrict__ in,
+                                             const float *__restrict__ wf,
+                                             const float *__restrict__ bias,
+                                             float *__restrict__ out,
+                                             const float *__restrict__ post_bias,
+                                             float *__restrict__ out_post, const ConvGeom &g) {
+  using namespace dgk;
+  using dgx::swz;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int M = g.B * g.OH * g.OW, hw = g.OH * g.OW;
+  const int m0 = by * TM, n0 = bx * TN;
+  const pipe::rsrc_t ra = pipe::make_rsrc(in, (unsigned)((size_t)g.B * g.IH * g.IW * g.Cin * 4));
+  const pipe::rsrc_t rb = pipe::make_rsrc(wf, (unsigned)((size_t)g.Cout * 9 * g.Cin * 4));
+  int va[4], vb[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * j + (lane >> 3), m = m0 + row;
+    va[j] = pipe::DMA_ZERO;
+    if (m < M) {
+      const int n = m / hw, rem = m - n * hw, oh = rem / g.OW, ow = rem - oh * g.OW;
+      va[j] = (((n * g.IH + oh * g.stride) * g.IW + ow * g.stride) * g.Cin) * 4 +
+              swz(row, lane & 7) * 16;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = 8 * j + (lane >> 3);
+    vb[j] = ((n0 + row) * 9 * g.Cin) * 4 + swz(row, lane & 7) * 16;
+  }
+  const int cpt = g.Cin / BKF;
+  const Out8 v = pipeline(smemf, 9 * cpt, [&](int c, unsigned char *stage) {
+    const int tap = c / cpt, h = c - tap * cpt, kh = tap / 3, kw = tap - kh * 3;
+    const int sa = ((kh * g.IW + kw) * g.Cin + h * BKF) * 4, sb = (tap * g.Cin + h * BKF) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pipe::dma16(ra, reinterpret_cast<float *>(stage + 8 * j * ROWB), va[j], sa);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      pipe::dma16(rb, reinterpret_cast<float *>(stage + A_B + 8 * j * ROWB), vb[j], sb);
+  });
+  const int row = tid >> 3, c8 = 8 * (tid & 7), m = m0 + row, n = n0 + c8;
+  if (m >= M) return;
+  const float4 b0 = ld4(bias + n), b1 = ld4(bias + n + 4);
+  const float o[8] = {fmaxf(v.lo.x + b0.x, 0.f), fmaxf(v.lo.y + b0.y, 0.f), fmaxf(v.lo.z + b0.z, 0.f),
+                      fmaxf(v.lo.w + b0.w, 0.f), fmaxf(v.hi.x + b1.x, 0.f), fmaxf(v.hi.y + b1.y, 0.f),
+                      fmaxf(v.hi.z + b1.z, 0.f), fmaxf(v.hi.w + b1.w, 0.f)};
+  const size_t at = (size_t)m * g.Cout + n;
+  *reinterpret_cast<float4 *>(out + at) = make_float4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<float4 *>(out + at + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  if (out_post) {   // + the per-(channel, pixel) embedding bias, (Cout, OH, OW)
+    const float *pb = post_bias + (size_t)n * hw + m % hw;
+    float q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = o[e] + pb[(size_t)e * hw];
+    *reinterpret_cast<float4 *>(out_post + at) = make_float4(q[0], q[1], q[2], q[3]);
+    *reinterpret_cast<float4 *>(out_post + at + 4) = make_float4(q[4], q[5], q[6], q[7]);
+  }
+}
+__global__ __launch_bounds__(NT) void conv_fwd_x6k_kernel(
+    const float *__restrict__ in, const float *__restrict__ wf, const float *__restrict__ bias,
+    float *__restrict__ out, const float *__restrict__ post_bias, float *__restrict__ out_post,
+    ConvGeom g) {
+  __shared__ __attribute__((aligned(1024))) float smem[dgk::SMEM];
+  fwd_x6k_tile(smem, blockIdx.x, blockIdx.y, in, wf, bias, out, post_bias, out_post, g);
+}
+// ... with the folding products of the output attention as the tail of its grid
+// (conv_fwd_pipe_fold_kernel's riders).  Beside the ring tiles (four workgroups per CU: tiles
+// and riders all resident at once) the riders cost 0.8 us, beside these (three per CU) 8 - 10 us:
+// worth it for the large layers only (fwd_ksplit).
+__global__ __launch_bounds__(NT) void conv_fwd_x6k_fold_kernel(
+    const float *__restrict__ in, const float *__restrict__ wf, const float *__restrict__ bias,
+    float *__restrict__ out, const float *__restrict__ post_bias, float *__restrict__ out_post,
+    ConvGeom g, int gx, int n_conv, scae_seed_fold_desc fold, scae_fold::Plan plan) {
+  static_assert(dgk::SMEM >= FOLD_SMEM, "the riders' LDS");
+  __shared__ __attribute__((aligned(1024))) float smem[dgk::SMEM];
+  const int blk = blockIdx.x;
+  if (blk < n_conv)   // workgroup-uniform
+    fwd_x6k_tile(smem, blk % gx, blk / gx, in, wf, bias, out, post_bias, out_post, g);
+  else
+    scae_fold::forward_block_any<16>(fold, plan, blk - n_conv, smem);
 }
 
 // data-gradient tile by DMODE: 0 - 2 the first-generation shapes of mfma_tile.h, 4 / 5 the forms above
@@ -1641,6 +1737,28 @@ static bool conv_bf16_shape(long rows, int Cin, int Cout) {
   return Cin % 128 == 0 && Cout % 128 == 0 && rows * (Cout / 128) >= 128 * 128;
 }
 
+// the forward form with the K loop dealt to the waves (fwd_x6k_tile) against the ring-pipelined
+// tiles, each ALONE: 34 -> 27 us at cfg-2's second layer, 42 -> 35 at CIFAR's, 210 / 121 / 68 ->
+// 184 / 102 / 57 at B = 1024.  In a training step the second layer's launch carries the folding
+// products, and beside these tiles (three workgroups per CU instead of four: tiles and riders no
+// longer fit one round) the riders cost 8 - 10 us instead of 0.8: cfg-2 35 -> 42 - 44 us, the step
+// 0.4966 -> 0.505 ms (0.498 with the riders back in the prologue); the B = 1024 step 4.61 -> 4.66
+// ms.  So it is an OPTION (SCAE_K8_FWDK = 1, or a tile-count threshold at build time), and ONE rule
+// serves the plain and the carrying launch: an eager step and a replayed one stay bit-identical.
+#ifndef SCAE_FWDK_MIN_TILES
+#define SCAE_FWDK_MIN_TILES 0   // 0: never by default
+#endif
+static bool fwd_ksplit(const ConvGeom &g) {
+  if (g.Cin % dgk::BKF || g.Cout % dgk::TN ||
+      (size_t)g.B * g.IH * g.IW * g.Cin * 4 >= (1u << 31))
+    return false;
+  const char *e = getenv("SCAE_K8_FWDK"), *f = getenv("SCAE_K8_FWD");
+  if (e && *e) return atoi(e) != 0;
+  if (f && *f) return false;
+  const long tiles = (long)(g.Cout / dgk::TN) * (((long)g.B * g.OH * g.OW + dgk::TM - 1) / dgk::TM);
+  return SCAE_FWDK_MIN_TILES > 0 && tiles >= SCAE_FWDK_MIN_TILES;
+}
+
 static int conv_fwd_impl(const float *in, const float *wf, const float *bias, float *out,
                          const float *post_bias, float *out_post, int B, int IH, int IW, int Cin,
                          int Cout, int stride, bool bf16, void *stream) {
@@ -1653,6 +1771,11 @@ static int conv_fwd_impl(const float *in, const float *wf, const float *bias, fl
   if (bf16 && conv_bf16_shape(M, Cin, Cout)) {
     scae::launch(conv_fwd_kernel<3>, dim3(Cout / 128, (M + 127) / 128), dim3(NT), 0, st, in,
                        wf, bias, out, post_bias, out_post, g);
+    return scae_launch_status();
+  }
+  if (fwd_ksplit(g)) {   // the K loop dealt to the waves (fwd_x6k_tile)
+    scae::launch(conv_fwd_x6k_kernel, dim3(Cout / dgk::TN, (M + dgk::TM - 1) / dgk::TM), dim3(NT),
+                 0, st, in, wf, bias, out, post_bias, out_post, g);
     return scae_launch_status();
   }
   const int cfg = pipe_cfg("SCAE_K8_FWD", M, Cout);
@@ -1714,9 +1837,15 @@ extern "C" int scae_conv3x3_fwd_fold_f32(const float *in, const float *wf, const
       scae_fold::lds_bytes(a.C, a.D) > FOLD_SMEM * sizeof(float))
     return SCAE_ERR_UNSUPPORTED;
   ConvGeom g{B, IH, IW, (IH - 3) / stride + 1, (IW - 3) / stride + 1, Cin, Cout, stride};
+  const scae_fold::Plan plan = scae_fold::plan(a.C, a.D);
+  if (fwd_ksplit(g)) {
+    const int M = B * g.OH * g.OW, gx = Cout / dgk::TN, n_conv = gx * ((M + dgk::TM - 1) / dgk::TM);
+    scae::launch(conv_fwd_x6k_fold_kernel, dim3(n_conv + plan.blocks()), dim3(NT), 0,
+                 (hipStream_t)stream, in, wf, bias, out, post_bias, out_post, g, gx, n_conv, a, plan);
+    return scae_launch_status();
+  }
   const int M = B * g.OH * g.OW, gx = Cout / PipeC2::TB,
             n_conv = gx * ((M + PipeC2::TA - 1) / PipeC2::TA);
-  const scae_fold::Plan plan = scae_fold::plan(a.C, a.D);
   scae::launch(conv_fwd_pipe_fold_kernel<PipeC2>, dim3(n_conv + plan.blocks()),
                      dim3(pipe::NT), 0, (hipStream_t)stream, in, wf, bias, out, post_bias, out_post,
                      g, gx, n_conv, a, plan);

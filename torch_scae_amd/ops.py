@@ -151,6 +151,12 @@ def _prec(name):
     return name.replace("_f32", "_bf16") if _plan().bf16 else name
 
 
+# where a training step's folding products of the output attention ride: "conv" = the second
+# convolution layer's forward launch, "prologue" = the step prologue's (measured per kernel
+# generation: DESIGN.md section 5)
+_FOLD_RIDES = __import__("os").environ.get("SCAE_FOLD_RIDES", "conv")
+
+
 class StepPrologue:
     """Buffers of a training step's prologue launch (csrc/step_prologue.hip):
     the step's noise draws and the folded output-attention weights live in
@@ -177,7 +183,8 @@ class StepPrologue:
         # that launch has shown it can carry them (``_conv_stack_fwd``): the
         # prologue then leaves them out (they were its longest part)
         self.fold_rides_conv = False
-        self.fold_conv_ok = None       # False: that launch cannot carry them
+        # False: that launch cannot -- or (SCAE_FOLD_RIDES=prologue) shall not -- carry them
+        self.fold_conv_ok = False if _FOLD_RIDES == "prologue" else None
 
     def _first_desc(self, image):
         """scae_first_layer_desc of the registered image layer over ``image``."""
@@ -1204,6 +1211,7 @@ def _conv_stack_fwd(image, strides, weights, biases, post_bias=None):
 
 
 _CONV_BF16R = __import__("os").environ.get("SCAE_CONV_BF16R", "1") != "0"
+
 
 
 def _conv_bf16_resident(B, ih, iw, weights, strides):
