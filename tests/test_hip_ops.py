@@ -2867,6 +2867,54 @@ def test_conv_bf16_resident_kernels_vs_fp64(B, IH, IW, stride):
     assert torch.equal(ah, a.to(torch.bfloat16)) and torch.equal(bh, b.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("B,HW,C,AP,gsz", [
+    (128, 25, 128, 576, 32),    # cfg-2's capsule head: K = 576 and 800
+    (32, 25, 64, 128, 8),       # a ragged last K chunk of the k-strided pair (K = 200)
+    (64, 9, 128, 160, 32),      # five K chunks: waves with one and with two
+])
+def test_gemm_pair_on_wave_private_pipelines_vs_fp64(B, HW, C, AP, gsz, monkeypatch):
+    """csrc/gemm_ksplit.hip through scae_gemm_pair_f32: the backward of the 1 x 1 attention
+    convolution -- dx = dy W with the ReLU gate and the ungated copy (A k-contiguous), dW per
+    group of images = dy^T x with its bias sums (both operands k-strided, batch > 1) -- against
+    fp64 at 2e-6 of each result's largest entry, and against the register-staged tiles
+    (SCAE_GEMM_KSPLIT=0).  The fast form must actually take these shapes: the two runs differ
+    somewhere in the last bits."""
+    import ctypes
+    from torch_scae_amd import _lib, ops
+    g = torch.Generator().manual_seed(B + HW)
+    S, kper, slab = B // gsz, HW * gsz, AP * C + AP
+    x = torch.randn(B, HW, C, generator=g).cuda()
+    gate = torch.relu(torch.randn(B, HW, C, generator=g)).cuda()
+    w = (torch.randn(AP, C, generator=g) / C ** 0.5).cuda()
+    dy = torch.randn(B, HW, AP, generator=g).cuda()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCAE_GEMM_KSPLIT", mode)
+        part = torch.full((S, slab), 7.0, device="cuda")
+        dx, raw = torch.full_like(x, 7.0), torch.full_like(x, 7.0)
+        dgrad = ops._gemm_desc(ops._p(dy), ops._p(w), ops._p(dx), 1, B * HW, C, AP, True, AP, 0,
+                               False, C, 0, C, 0)
+        dgrad.mask, dgrad.ldmask, dgrad.c_nomask = gate.data_ptr(), C, raw.data_ptr()
+        wgrad = ops._gemm_desc(ops._p(dy), ops._p(x), ops._p(part), S, AP, C, kper, False, AP,
+                               kper * AP, False, C, kper * C, C, slab,
+                               asum=ops._off(part, AP * C), asum_b=slab)
+        ops._gemm_pair(wgrad, dgrad, x)
+        torch.cuda.synchronize()
+        outs[mode] = (dx, raw, part)
+    dy64, x64, w64 = dy.double().cpu(), x.double().cpu(), w.double().cpu()
+    raw_ref = dy64 @ w64
+    dx_ref = raw_ref * (gate.cpu() > 0)
+    dw_ref = torch.einsum("skm,skn->smn", dy64.view(S, kper, AP), x64.view(S, kper, C))
+    db_ref = dy64.view(S, kper, AP).sum(1)
+    dx, raw, part = outs["1"]
+    for got, ref in ((dx, dx_ref), (raw, raw_ref), (part[:, :AP * C].view(S, AP, C), dw_ref),
+                     (part[:, AP * C:], db_ref)):
+        assert float((got.double().cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert not all(torch.equal(a, b) for a, b in zip(outs["1"], outs["0"]))
+    for a, b in zip(outs["1"], outs["0"]):
+        assert float((a - b).abs().max()) <= 4e-6 * float(b.abs().max())
+
+
 def test_grouped_mlp_bf16_operands_vs_fp64():
     """K7 (the per-capsule MLPs as batched GEMMs) with bf16 operands: forward,
     input gradient and weight / bias gradients at configs[2]'s layer sizes."""

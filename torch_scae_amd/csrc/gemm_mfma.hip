@@ -355,8 +355,15 @@ extern "C" int scae_gemm_bf16(const float *A, const float *B, float *C, const fl
                    asum_batch, asum_ld, relu, true, stream);
 }
 
+// gemm_ksplit.hip: small problem lists with long K on wave-private pipelines, or UNSUPPORTED
+int scae_gemm_x6k_try(const scae_gemm_desc *descs, int n, void *stream);
+
 static int gemm_multi_impl(const scae_gemm_desc *descs, int n, void *stream, bool bf16 = false) {
   SCAE_REQUIRE(descs && n >= 1 && n <= 4);
+  if (!bf16) {
+    const int rc = scae_gemm_x6k_try(descs, n, stream);
+    if (rc != SCAE_ERR_UNSUPPORTED) return rc;
+  }
   GemmMulti p;
   int T;
   int rc = plan_multi(p, T, descs, n, bf16);
